@@ -1,0 +1,330 @@
+"""Generate golden fixtures by running the UNMODIFIED reference (imported from /root/reference) on CPU.
+
+Build-container only.  Writes small .npz files to tests/golden/ and asserts, while generating, that the
+oracle restatement (oracle/dig_oracle.py) reproduces the reference to fp32 round-off.  What is stored is
+data only: seeds, scalar metrics, per-tensor gradient norms, and a few sampled elements.
+
+    python oracle/ref_harness/gen_golden.py            # all single-rank fixtures
+    python oracle/ref_harness/gen_golden.py --world 2  # SyncBN / all-gather fixtures over gloo (spawns ranks)
+"""
+import argparse
+import os
+import sys
+import types
+from functools import partial
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, HERE)
+import dig_oracle as O  # noqa: E402
+import refenv  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def sample_index(numel: int, k: int = 8):
+    """Deterministic element positions sampled from a flat tensor."""
+    if numel <= k:
+        return np.arange(numel)
+    return (np.arange(k, dtype=np.int64) * 2654435761 + 12345) % numel
+
+
+def build_ref_model(cfg: O.DiGConfig):
+    import torch.nn as nn
+    import modeling_pretrain_moco_mim_ori as M
+    return M.MoCo_ViT(img_size=(cfg.img_h, cfg.img_w), patch_size=cfg.patch, encoder_embed_dim=cfg.embed_dim,
+                      encoder_depth=cfg.depth, encoder_num_heads=cfg.heads, encoder_num_classes=0,
+                      decoder_num_classes=cfg.dec_classes, decoder_embed_dim=cfg.dec_dim, decoder_depth=4,
+                      decoder_num_heads=3, mlp_ratio=cfg.mlp_ratio, qkv_bias=True,
+                      norm_layer=partial(nn.LayerNorm, eps=1e-6), use_pixel_target=True, use_moco_target=True,
+                      mlp_dim=cfg.moco_mlp_dim, dim=cfg.moco_dim, T=cfg.T, num_windows=cfg.num_windows,
+                      patchnet_name='no_patchtrans')
+
+
+def ref_args(hp: O.StepHyper, epochs=10):
+    a = types.SimpleNamespace()
+    a.num_view = 2
+    a.moco_m = hp.moco_m
+    a.use_moco_m_cos = 1
+    a.epochs = epochs
+    a.contrast_start_epoch = 0
+    a.contrast_warmup_steps = 0
+    a.loss_weight_contrast = hp.w_contrast
+    a.loss_weight_pixel = hp.w_pixel
+    a.only_mim_on_ori_img = True
+    a.eval_freq = 500
+    a.opt = 'adamw'
+    a.lr = hp.lr
+    a.weight_decay = hp.weight_decay
+    a.opt_eps = hp.eps
+    a.opt_betas = None
+    a.momentum = 0.9
+    return a
+
+
+class ScalerCPU:
+    """NativeScalerWithGradNormCount on CPU: GradScaler is disabled without CUDA; add the `scale` key the
+    engine reads (engine_for_pretraining_moco.py:157)."""
+
+    def __init__(self, ref_utils):
+        self.inner = ref_utils.NativeScalerWithGradNormCount()
+
+    def __call__(self, *a, **k):
+        return self.inner(*a, **k)
+
+    def state_dict(self):
+        d = dict(self.inner.state_dict())
+        d.setdefault("scale", 1.0)
+        return d
+
+
+def run_reference_steps(cfg, seed, B, n_steps, hp, world=1, rank=0, sync_bn=False):
+    """Drive the unmodified engine for n_steps one-batch 'epochs-worth' loaders; capture per-step values."""
+    ref_utils = refenv.setup(rank=rank, world_size=world)
+    import engine_for_pretraining_moco as E
+    import optim_factory
+    model = build_ref_model(cfg)
+    P, S = O.det_state(cfg, seed)
+    sd = model.state_dict()
+    for k, v in P.items():
+        assert sd[k].shape == v.shape, k
+        sd[k].copy_(v)
+    assert list(P.keys()) == [n for n, _ in model.named_parameters()], "param order differs from reference"
+    args = ref_args(hp)
+    opt = optim_factory.create_optimizer(args, model)
+    scaler = ScalerCPU(ref_utils)
+    caps = {}
+    model.encoder.register_forward_hook(lambda m, i, o: caps.__setitem__("enc", o.detach().clone()))
+    model.predictor.register_forward_hook(lambda m, i, o: caps.__setitem__("qs", o.detach().clone()))
+    model.momentum_projection_layer.register_forward_hook(lambda m, i, o: caps.__setitem__("ks", o.detach().clone()))
+    fwd = model.forward
+
+    def wrapped(*a, **k):
+        out = fwd(*a, **k)
+        caps["vis_out"] = out["vis_out"][0].detach().clone()
+        return out
+    model.forward = wrapped
+    run_model = model
+    if world > 1:
+        import torch.distributed as dist
+        import torch.nn.functional as F
+        import torch.distributed.nn.functional as dnf
+        # SyncBatchNorm refuses CPU modules: keep BatchNorm1d and replace F.batch_norm by its definition over
+        # all ranks; wrap in gloo DDP for gradient averaging.
+        def synced_bn(x, rm, rv, weight=None, bias=None, training=False, momentum=0.1, eps=1e-5):
+            C = x.shape[1]
+            st = torch.cat([x.sum(0), (x * x).sum(0), x.new_tensor([float(x.shape[0])])])
+            st = dnf.all_reduce(st)
+            n = st[-1]
+            mean = st[:C] / n
+            var = st[C:2 * C] / n - mean * mean
+            with torch.no_grad():
+                rm.mul_(1 - momentum).add_(mean, alpha=momentum)
+                rv.mul_(1 - momentum).add_(var * (n / (n - 1)), alpha=momentum)
+            y = (x - mean) * torch.rsqrt(var + eps)
+            if weight is not None:
+                y = y * weight + bias
+            return y
+        F.batch_norm = synced_bn
+        run_model = torch.nn.parallel.DistributedDataParallel(model, find_unused_parameters=True)
+    steps = []
+    iters_per_epoch = 1
+    lr_sched = np.full(n_steps * 4, hp.lr)
+    wd_sched = np.full(n_steps * 4, hp.weight_decay)
+    for s in range(n_steps):
+        im, au, mk = O.synthetic_batch(B, cfg, seed * 1000 + 17 * s + rank)
+        loader = [([im, au, mk], torch.ones(1), torch.ones(1))]
+        stats = E.train_one_epoch(run_model, None, None, loader, None, opt, torch.device('cpu'), s, scaler, None,
+                                  patch_size=cfg.patch, normlize_target=False, start_steps=s,
+                                  lr_schedule_values=lr_sched, wd_schedule_values=wd_sched, args=args)
+        grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+        params = {n: p.detach().clone() for n, p in model.named_parameters()}
+        bufs = {n: b.detach().clone() for n, b in model.named_buffers()}
+        name_of = {id(p): n for n, p in model.named_parameters()}
+        moments = {name_of[id(p)]: (st["exp_avg"].clone(), st["exp_avg_sq"].clone(), int(st["step"]))
+                   for p, st in opt.state.items()}
+        steps.append(dict(stats=dict(stats), grads=grads, params=params, bufs=bufs, caps=dict(caps), moments=moments))
+    return steps
+
+
+def run_oracle_steps(cfg, seed, B, n_steps, hp, comm=None, rank=0, teacher=None):
+    """teacher: the reference's steps; when given, step s>0 starts from the reference's post-step-(s-1) state
+    (params, BN buffers, Adam moments) so each step is compared from an identical starting point -- Adam's
+    sign-like update otherwise amplifies 1e-9 gradient round-off into 1e-3 parameter differences."""
+    P, S = O.det_state(cfg, seed)
+    tr = O.OracleTrainer(cfg, P, S, comm=comm)
+    steps = []
+    for s in range(n_steps):
+        if teacher is not None and s > 0:
+            prev = teacher[s - 1]
+            for k in tr.P:
+                tr.P[k] = prev["params"][k].clone()
+            for k in tr.S:
+                tr.S[k] = prev["bufs"][k].clone()
+            for k, (m1, m2, st) in prev["moments"].items():
+                tr.exp_avg[k], tr.exp_avg_sq[k] = m1.clone(), m2.clone()
+            tr.step_count = s
+        im, au, mk = O.synthetic_batch(B, cfg, seed * 1000 + 17 * s + rank)
+        import dataclasses
+        hps = dataclasses.replace(hp, moco_m=O.adjust_moco_momentum(float(s), 10, hp.moco_m))
+        taps = {}
+        metrics, grads, out, labels = tr.step(im, au, mk, hps, taps)
+        steps.append(dict(stats=metrics, grads={k: v.clone() for k, v in grads.items()},
+                          params={k: v.detach().clone() for k, v in tr.P.items()},
+                          bufs={k: v.clone() for k, v in tr.S.items()},
+                          caps=dict(enc=taps["enc"].detach(), qs=torch.cat([taps["q1"], taps["q2"]]).detach(),
+                                    ks=torch.cat([taps["k1"], taps["k2"]]).detach(), vis_out=out["vis_out"][0].detach())))
+    return steps
+
+
+def check_adamw_formula(ref_step0, cfg, seed, hp, m0):
+    """Tight check of the optimizer restatement: feed the REFERENCE's step-0 gradients through the oracle's
+    AdamW/EMA and compare with the reference's post-step parameters (Adam's sign-like first step makes a
+    params-vs-params comparison ill-conditioned wherever |g| ~ eps, so gradients are taken as given)."""
+    P, _ = O.det_state(cfg, seed)
+    decay, no_decay = O.param_groups(P, 1.0)
+    O.ema_update(P, m0)
+    worst = 0.0
+    for names, wd in ((decay, hp.weight_decay), (no_decay, 0.0)):
+        for n in names:
+            g = ref_step0["grads"].get(n)
+            if g is None:
+                continue
+            O.adamw_update(P[n], g, torch.zeros_like(g), torch.zeros_like(g), 1, hp.lr, wd, hp.beta1, hp.beta2, hp.eps)
+    for n, p in P.items():
+        err = (p - ref_step0["params"][n]).abs().max().item()
+        worst = max(worst, err)
+        assert err <= 1e-7 + 1e-6 * p.abs().max().item(), (n, err)
+    print(f"AdamW + EMA restatement == reference given reference grads; worst abs err {worst:.2e}")
+
+
+def compare(ref_steps, ora_steps, rtol=2e-4, atol=2e-5, tag="", lr=1e-3):
+    worst = 0.0
+    for s, (r, o) in enumerate(zip(ref_steps, ora_steps)):
+        for k in ("loss", "loss_pixel", "loss_contrast", "q1_acc1", "q1_acc5", "q2_acc1", "q2_acc5", "grad_norm"):
+            a, b = float(r["stats"][k]), float(o["stats"][k])
+            assert abs(a - b) <= 1e-4 * max(1.0, abs(a)), (tag, s, k, a, b)
+        for grp in ("caps", "grads", "params", "bufs"):
+            for k, a in r[grp].items():
+                b = o[grp][k]
+                if a.dtype == torch.int64:
+                    assert int(a) == int(b), (tag, s, grp, k)
+                    continue
+                err = (a - b).abs().max().item()
+                ref = a.abs().max().item()
+                if err / (ref + 1e-12) > worst:
+                    worst, worst_at = err / (ref + 1e-12), (s, grp, k, err, ref)
+                slack = 2.5 * lr if grp == "params" else 0.0   # Adam step is sign-like where |g|~eps
+                assert err <= atol + rtol * ref + slack, (tag, s, grp, k, err, ref)
+    print(f"[{tag}] oracle == reference over {len(ref_steps)} steps; worst rel-to-max err {worst:.2e} at {worst_at}")
+
+
+def pack(ref_steps, cfg, seed, B, hp, extra=None):
+    d = {"seed": np.int64(seed), "B": np.int64(B), "n_steps": np.int64(len(ref_steps)),
+         "cfg_keys": np.array(list(vars(cfg).keys())), "cfg_vals": np.array([float(v) for v in vars(cfg).values()]),
+         "hp_keys": np.array([k for k, v in vars(hp).items() if isinstance(v, (int, float)) and v is not None]),
+         "hp_vals": np.array([float(v) for k, v in vars(hp).items() if isinstance(v, (int, float)) and v is not None])}
+    for s, r in enumerate(ref_steps):
+        for k in ("loss", "loss_pixel", "loss_contrast", "q1_acc1", "q1_acc5", "q2_acc1", "q2_acc5", "grad_norm", "moco_m"):
+            d[f"s{s}/stat/{k}"] = np.float64(r["stats"][k])
+        names = sorted(r["grads"].keys())
+        d[f"s{s}/grad_names"] = np.array(names)
+        d[f"s{s}/grad_norms"] = np.array([r["grads"][n].double().norm().item() for n in names])
+        d[f"s{s}/grad_samples"] = np.stack([np.resize(r["grads"][n].reshape(-1)[sample_index(r["grads"][n].numel())].numpy(), 8) for n in names])
+        pn = sorted(r["params"].keys())
+        d[f"s{s}/param_names"] = np.array(pn)
+        d[f"s{s}/param_norms"] = np.array([r["params"][n].double().norm().item() for n in pn])
+        d[f"s{s}/param_samples"] = np.stack([np.resize(r["params"][n].reshape(-1)[sample_index(r["params"][n].numel())].numpy(), 8) for n in pn])
+        bn = sorted(k for k in r["bufs"] if not k.endswith("num_batches_tracked"))
+        d[f"s{s}/buf_names"] = np.array(bn)
+        d[f"s{s}/buf_norms"] = np.array([r["bufs"][n].double().norm().item() for n in bn])
+        for k, v in r["caps"].items():
+            d[f"s{s}/cap/{k}/norm"] = np.float64(v.double().norm().item())
+            d[f"s{s}/cap/{k}/samples"] = v.reshape(-1)[sample_index(v.numel(), 64)].numpy()
+        d[f"s{s}/cap/vis_out/full"] = r["caps"]["vis_out"].numpy().astype(np.float32)
+    if extra:
+        d.update(extra)
+    return d
+
+
+def gen_single(tag, cfg, seed, B, n_steps, hp):
+    ref_steps = run_reference_steps(cfg, seed, B, n_steps, hp)
+    ora_steps = run_oracle_steps(cfg, seed, B, n_steps, hp, teacher=ref_steps)
+    compare(ref_steps, ora_steps, tag=tag, lr=hp.lr)
+    check_adamw_formula(ref_steps[0], cfg, seed, hp, O.adjust_moco_momentum(0.0, 10, hp.moco_m))
+    os.makedirs(GOLD, exist_ok=True)
+    np.savez_compressed(os.path.join(GOLD, f"{tag}.npz"), **pack(ref_steps, cfg, seed, B, hp))
+    print("wrote", tag)
+
+
+def gen_masks_and_schedules():
+    """Mask generator and schedule goldens straight from the reference functions."""
+    ref_utils = refenv.setup()
+    from masking_generator import RandomMaskingGenerator
+    d = {}
+    for seed in (0, 1234, 99):
+        np.random.seed(seed)
+        gen = RandomMaskingGenerator((8, 32), 0.7, num_view=2)
+        ref = np.stack([gen() for _ in range(4)])
+        mine = O.random_masks(4, O.DiGConfig(), 0.7, np.random.RandomState(seed)).numpy()
+        assert np.array_equal(ref, mine), "mask stream differs"
+        d[f"mask/{seed}"] = ref.astype(np.uint8)
+    d["sched/lr"] = ref_utils.cosine_scheduler(1.5e-4 * 4, 1e-5, 10, 50, warmup_epochs=1, warmup_steps=-1)
+    d["sched/lr_ws"] = ref_utils.cosine_scheduler(6e-4, 1e-5, 10, 50, warmup_epochs=1, warmup_steps=20)
+    d["sched/wd"] = ref_utils.cosine_scheduler(0.1, 0.1, 10, 50)
+    assert np.array_equal(d["sched/lr"], O.cosine_scheduler(1.5e-4 * 4, 1e-5, 10, 50, warmup_epochs=1))
+    assert np.array_equal(d["sched/lr_ws"], O.cosine_scheduler(6e-4, 1e-5, 10, 50, warmup_epochs=1, warmup_steps=20))
+    a = types.SimpleNamespace(epochs=10, moco_m=0.99)
+    d["sched/moco_m"] = np.array([ref_utils.adjust_moco_momentum(e / 7.0, a) for e in range(70)])
+    assert np.array_equal(d["sched/moco_m"], np.array([O.adjust_moco_momentum(e / 7.0, 10, 0.99) for e in range(70)]))
+    np.savez_compressed(os.path.join(GOLD, "masks_schedules.npz"), **d)
+    print("wrote masks_schedules")
+
+
+def worker(rank, world, cfg, seed, B, n_steps, hp, q):
+    ref_steps = run_reference_steps(cfg, seed, B, n_steps, hp, world=world, rank=rank)
+    comm = O.DistComm()
+    ora_steps = run_oracle_steps(cfg, seed, B, n_steps, hp, comm=comm, rank=rank, teacher=ref_steps)
+    compare(ref_steps, ora_steps, tag=f"w{world}r{rank}", lr=hp.lr)
+    q.put((rank, pack(ref_steps, cfg, seed, B, hp)))
+
+
+def gen_multi(world, cfg, seed, B, n_steps, hp):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=worker, args=(r, world, cfg, seed, B, n_steps, hp, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get() for _ in range(world))
+    for p in procs:
+        p.join()
+        assert p.exitcode == 0
+    for r, d in res.items():
+        np.savez_compressed(os.path.join(GOLD, f"tiny_w{world}_rank{r}.npz"), **d)
+    print("wrote multi-rank fixtures, world", world)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--world", type=int, default=1)
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    tiny = O.DiGConfig(**O.TINY)
+    hp = O.StepHyper(lr=1e-3)
+    if a.world > 1:
+        gen_multi(a.world, tiny, 3, 4, 2, hp)
+    else:
+        if a.only in ("", "masks"):
+            gen_masks_and_schedules()
+        if a.only in ("", "tiny"):
+            gen_single("tiny_w1", tiny, 3, 4, 2, hp)
+        if a.only in ("", "small"):
+            small = O.make_config("pretrain_simmim_moco_ori_vit_small_patch4_32x128")
+            gen_single("vit_small_b4_w1", small, 7, 4, 1, O.StepHyper(lr=1.5e-4 * 4 / 256))

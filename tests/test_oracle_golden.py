@@ -1,0 +1,122 @@
+"""The oracle (oracle/dig_oracle.py) replayed against fixtures produced by the unmodified reference
+(oracle/ref_harness/gen_golden.py).  CPU only; this is what pins the oracle."""
+import dataclasses
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import dig_oracle as O
+
+
+def sample_index(numel, k=8):
+    if numel <= k:
+        return np.arange(numel)
+    return (np.arange(k, dtype=np.int64) * 2654435761 + 12345) % numel
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+def cfg_from(g):
+    kw = {k: v for k, v in zip(g["cfg_keys"].tolist(), g["cfg_vals"].tolist())}
+    ints = {"img_h", "img_w", "patch", "in_chans", "embed_dim", "depth", "heads", "dec_dim", "dec_classes",
+            "moco_dim", "moco_mlp_dim", "pix_mlp_dim", "num_windows"}
+    return O.DiGConfig(**{k: (int(v) if k in ints else v) for k, v in kw.items()})
+
+
+def hp_from(g):
+    kw = {k: v for k, v in zip(g["hp_keys"].tolist(), g["hp_vals"].tolist())}
+    kw["only_mim_on_ori_img"] = bool(kw.get("only_mim_on_ori_img", 1.0))
+    return O.StepHyper(**kw)
+
+
+def check_step0(g, rtol=3e-4):
+    cfg, hp = cfg_from(g), hp_from(g)
+    seed, B = int(g["seed"]), int(g["B"])
+    P, S = O.det_state(cfg, seed)
+    tr = O.OracleTrainer(cfg, P, S)
+    im, au, mk = O.synthetic_batch(B, cfg, seed * 1000)
+    hp0 = dataclasses.replace(hp, moco_m=float(g["s0/stat/moco_m"]))
+    taps = {}
+    metrics, grads, out, labels = tr.step(im, au, mk, hp0, taps)
+    for k in ("loss", "loss_pixel", "loss_contrast", "q1_acc1", "q1_acc5", "q2_acc1", "q2_acc5", "grad_norm"):
+        assert metrics[k] == pytest.approx(float(g[f"s0/stat/{k}"]), rel=1e-4, abs=1e-5), k
+    names = g["s0/grad_names"].tolist()
+    norms = g["s0/grad_norms"]
+    samples = g["s0/grad_samples"]
+    gmax = max(norms)
+    for i, n in enumerate(names):
+        gi = grads[n]
+        assert gi.double().norm().item() == pytest.approx(norms[i], rel=rtol, abs=1e-6 * gmax), n
+        got = np.resize(gi.reshape(-1)[sample_index(gi.numel())].numpy(), 8)
+        np.testing.assert_allclose(got, samples[i], rtol=rtol, atol=1e-5 * max(1e-3, float(np.abs(samples[i]).max()) + norms[i] / np.sqrt(gi.numel())))
+    np.testing.assert_allclose(out["vis_out"][0].detach().numpy(), g["s0/cap/vis_out/full"], rtol=1e-4, atol=2e-5)
+    enc = taps["enc"].detach()
+    np.testing.assert_allclose(enc.reshape(-1)[sample_index(enc.numel(), 64)].numpy(), g["s0/cap/enc/samples"], rtol=1e-4, atol=1e-4)
+    ks = torch.cat([taps["k1"], taps["k2"]]).detach()
+    np.testing.assert_allclose(ks.reshape(-1)[sample_index(ks.numel(), 64)].numpy(), g["s0/cap/ks/samples"], rtol=1e-3, atol=1e-3)
+    # post-step state: EMA'd momentum params are well-conditioned; online params only loosely (Adam sign step)
+    pn = g["s0/param_names"].tolist()
+    pnorm = g["s0/param_norms"]
+    for i, n in enumerate(pn):
+        tol = 1e-5 if not O.is_trainable(n) else 5e-3
+        assert tr.P[n].double().norm().item() == pytest.approx(pnorm[i], rel=tol, abs=1e-6), n
+    bn = g["s0/buf_names"].tolist()
+    for i, n in enumerate(bn):
+        assert tr.S[n].double().norm().item() == pytest.approx(g["s0/buf_norms"][i], rel=1e-4, abs=1e-5), n
+
+
+def test_tiny_step_matches_reference(golden_dir):
+    check_step0(load(golden_dir, "tiny_w1"))
+
+
+def test_vit_small_b4_step_matches_reference(golden_dir):
+    """BASELINE.json configs[0]: pretrain_simmim_moco_ori_vit_small_patch4_32x128, bs=4, CPU, world 1."""
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    check_step0(load(golden_dir, "vit_small_b4_w1"))
+
+
+def test_param_inventory_matches_reference_counts():
+    cfg = O.make_config("pretrain_simmim_moco_ori_vit_small_patch4_32x128")
+    shapes = O.param_shapes(cfg)
+    numel = {k: int(np.prod(v)) for k, v in shapes.items()}
+    assert len(shapes) == 356                                            # 398 keys incl. 42 BN buffers
+    assert len(shapes) + len(O.buffer_shapes(cfg)) == 398
+    assert sum(v for k, v in numel.items() if O.is_trainable(k)) == 43606192
+    assert sum(numel.values()) == 84986800
+    assert sum(v for k, v in numel.items() if not O.is_trainable(k)) == 41380608
+
+
+def test_masks_bit_exact(golden_dir):
+    g = load(golden_dir, "masks_schedules")
+    for seed in (0, 1234, 99):
+        mine = O.random_masks(4, O.DiGConfig(), 0.7, np.random.RandomState(seed)).numpy()
+        assert np.array_equal(mine.astype(np.uint8), g[f"mask/{seed}"])
+        assert (mine.sum(-1) == 179).all()
+
+
+def test_schedules_bit_exact(golden_dir):
+    g = load(golden_dir, "masks_schedules")
+    assert np.array_equal(g["sched/lr"], O.cosine_scheduler(1.5e-4 * 4, 1e-5, 10, 50, warmup_epochs=1))
+    assert np.array_equal(g["sched/lr_ws"], O.cosine_scheduler(6e-4, 1e-5, 10, 50, warmup_epochs=1, warmup_steps=20))
+    assert np.array_equal(g["sched/wd"], O.cosine_scheduler(0.1, 0.1, 10, 50))
+    assert np.array_equal(g["sched/moco_m"], np.array([O.adjust_moco_momentum(e / 7.0, 10, 0.99) for e in range(70)]))
+
+
+def test_mim_target_gather_order():
+    """Gather indices are bit-exact: ascending token id per sample, (p1 p2 c) element order."""
+    cfg = O.DiGConfig()
+    im, au, mk = O.synthetic_batch(3, cfg, 11)
+    mask, labels = O.mim_targets(im, mk, cfg)
+    assert not mask[:, 1].any()
+    for b in range(3):
+        idx = np.nonzero(mk[b, 0].numpy())[0]
+        assert len(idx) == 179 and (np.diff(idx) > 0).all()
+        for j in (0, 57, 178):
+            t = idx[j]
+            h, w = divmod(int(t), 32)
+            patch = im[b, :, h * 4:(h + 1) * 4, w * 4:(w + 1) * 4] * 0.5 + 0.5   # [c,p1,p2]
+            assert torch.equal(labels[0][b, j], patch.permute(1, 2, 0).reshape(-1))
