@@ -1,0 +1,355 @@
+// Fused self-attention for the DiG ViT encoder on gfx950: N = 256 tokens, head_dim = 64, dense softmax.
+// Reference math: Attention.forward, modeling_finetune.py:87-120 (q is pre-scaled by head_dim^-0.5 in
+// the QKV GEMM epilogue; K has no bias); backward is the analytic softmax-attention gradient.
+//
+// One workgroup owns one (image, head): its K and V ([256,64] bf16, 32 KiB each) live in LDS for the whole
+// kernel, the 256x256 score matrix never leaves registers, nothing is written to HBM but the context
+// rows and the per-row log-sum-exp (fp32) that the backward needs.
+//
+// LDS tile layout "U" (all four operands): addr(row, col) = row*128 + ((col>>3) ^ f(row))*16 + (col&7)*2
+// with f(row) = ((row>>1)&1)<<2 | ((row>>2)&3).  The same image serves
+//   * ds_read_b128 fragments along the contiguous (col) axis  -- 16 distinct rows hit 16 distinct 16-B slots;
+//   * ds_read_b64_tr_b16 fragments along the row axis (4 consecutive rows x 16 cols per 16-lane group),
+// both bank-conflict free, so Q/K/V/dO are staged once (buffer_load ... lds, swizzle on the source side).
+//
+// MFMAs are issued "swapped" (D' = X^T-side operand first) so that the lane that owns a query (forward,
+// dQ phase) or a key (dK/dV phase) holds that row's scores in its own registers: the softmax row
+// reductions are 127 in-lane ops + one cross-half exchange, and P / dS feed the next MFMA as the B operand
+// without any data movement (the V / K / Q / dO operand is fetched with the matching row permutation by
+// the transpose read).
+#include "common.h"
+
+namespace {
+
+constexpr int N_TOK = 256;
+constexpr int DH = 64;
+constexpr int TILE = N_TOK * DH * 2;  // 32 KiB
+
+__device__ __forceinline__ int swz(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
+__device__ __forceinline__ int u_addr(int row, int col) { return row * 128 + ((((col >> 3) ^ swz(row))) << 4) + (col & 7) * 2; }
+
+// Stage a [256 x 64] bf16 tile (row stride ld elements, starting at element offset base) into LDS layout U.
+// 2048 16-B pieces; NT threads.
+template <int NT>
+__device__ __forceinline__ void stage_tile(unsigned char* lds, __amdgpu_buffer_rsrc_t rs, unsigned base_bytes, int ld,
+                                           int tid, int wave) {
+#pragma unroll
+  for (int it = 0; it < 2048 / NT; ++it) {
+    const int piece = it * NT + tid;
+    const int row = piece >> 3, pc = piece & 7;
+    const int c = pc ^ swz(row);
+    const unsigned off = base_bytes + (unsigned)((row * ld + c * 8) * 2);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(lds + (it * NT + wave * 64) * 16), 16, off, 0, 0, 0);
+  }
+}
+
+// 8 contiguous bf16 (cols 16*s + 8*hi ..) of row (rowoff + lane&31)
+__device__ __forceinline__ bf16x8 frag_direct(const unsigned char* tile, int rowoff, int s, int lane) {
+  const int row = rowoff + (lane & 31);
+  const int chunk = 2 * s + (lane >> 5);
+  return *reinterpret_cast<const bf16x8*>(tile + row * 128 + ((chunk ^ swz(row)) << 4));
+}
+
+// Transposed fragment: for column (coloff + lane&31) return rows {r0 + 4*hi + 0..3, r0 + 8 + 4*hi + 0..3}
+// (the row permutation of a 32x32 MFMA accumulator quad pair).
+__device__ __forceinline__ bf16x8 frag_tr(const unsigned char* tile, int r0, int coloff, int lane) {
+  const int hi = lane >> 5;
+  const int i = lane & 15;
+  const int col = coloff + ((lane >> 4) & 1) * 16 + (i & 3) * 4;
+  const int ra = r0 + 4 * hi + (i >> 2);
+  const int rb = ra + 8;
+  bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(tile + u_addr(ra, col)));
+  bf16x4 h4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(tile + u_addr(rb, col)));
+  bf16x8 r;
+  r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+  r[4] = h4[0]; r[5] = h4[1]; r[6] = h4[2]; r[7] = h4[3];
+  return r;
+}
+
+__device__ __forceinline__ bf16x8 pack8(const f32x16& a, int u) {
+  bf16x8 r;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) r[e] = (short)f2bf(a[u * 8 + e]);
+  return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
+                                                          float* __restrict__ lse, int D, int H, unsigned qkv_bytes) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* Kt = smem;
+  unsigned char* Vt = smem + TILE;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int img = blockIdx.x / H, h = blockIdx.x - img * H;
+  const int ld = 3 * D;
+  const size_t tok0 = (size_t)img * N_TOK;
+  const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)qkv, 0, qkv_bytes, 0x00020000);
+  const unsigned base = (unsigned)((tok0 * ld + h * DH) * 2);
+  stage_tile<256>(Kt, rs, base + (unsigned)(D * 2), ld, tid, wave);
+  stage_tile<256>(Vt, rs, base + (unsigned)(2 * D * 2), ld, tid, wave);
+
+  const int hi = lane >> 5;
+  // Q fragments for both passes straight from global (each wave reads only its own 64 rows)
+  bf16x8 qf[2][4];
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps) {
+    const int q = (wave * 2 + ps) * 32 + (lane & 31);
+    const bf16_t* qp = qkv + (tok0 + q) * ld + h * DH + hi * 8;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[ps][s] = *reinterpret_cast<const bf16x8*>(qp + s * 16);
+  }
+  __syncthreads();
+
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps) {
+    const int qb = wave * 2 + ps;
+    f32x16 sc[8];
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) sc[kt][e] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_direct(Kt, kt * 32, s, lane), qf[ps][s], sc[kt], 0, 0, 0);
+    }
+    float m = -3.0e38f;
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) m = fmaxf(m, sc[kt][e]);
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float l = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float p = __expf(sc[kt][e] - m);
+        sc[kt][e] = p;
+        l += p;
+      }
+    l += __shfl_xor(l, 32, 64);
+    f32x16 oa[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) oa[dt][e] = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const bf16x8 pf = pack8(sc[kt], u);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+          oa[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Vt, kt * 32 + u * 16, dt * 32, lane), pf, oa[dt], 0, 0, 0);
+      }
+    }
+    const float inv = 1.0f / l;
+    const int q = qb * 32 + (lane & 31);
+    bf16_t* op = ctx + (tok0 + q) * D + h * DH;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = dt * 32 + 8 * g + 4 * hi;
+        *reinterpret_cast<uint2*>(op + d) = make_uint2(pack_bf2(oa[dt][g * 4] * inv, oa[dt][g * 4 + 1] * inv),
+                                                       pack_bf2(oa[dt][g * 4 + 2] * inv, oa[dt][g * 4 + 3] * inv));
+      }
+    if (hi == 0) lse[(size_t)blockIdx.x * N_TOK + q] = m + __logf(l);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward: dqkv = d/d(qkv) given d(ctx); 8 waves, phase A (dQ, wave = query block), phase B (dK,dV, wave = key block)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 2) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ ctx,
+                                                          const bf16_t* __restrict__ dctx, const float* __restrict__ lse,
+                                                          bf16_t* __restrict__ dqkv, int D, int H, float scale,
+                                                          unsigned qkv_bytes, unsigned ctx_bytes) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* Qt = smem;
+  unsigned char* Kt = smem + TILE;
+  unsigned char* Vt = smem + 2 * TILE;
+  unsigned char* Gt = smem + 3 * TILE;                                   // dO
+  float* lse_s = reinterpret_cast<float*>(smem + 4 * TILE);              // [256]
+  float* del_s = lse_s + N_TOK;                                          // [256]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int img = blockIdx.x / H, h = blockIdx.x - img * H;
+  const int ld = 3 * D;
+  const size_t tok0 = (size_t)img * N_TOK;
+  const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)qkv, 0, qkv_bytes, 0x00020000);
+  const auto rg = __builtin_amdgcn_make_buffer_rsrc((void*)dctx, 0, ctx_bytes, 0x00020000);
+  const unsigned base = (unsigned)((tok0 * ld + h * DH) * 2);
+  stage_tile<512>(Qt, rs, base, ld, tid, wave);
+  stage_tile<512>(Kt, rs, base + (unsigned)(D * 2), ld, tid, wave);
+  stage_tile<512>(Vt, rs, base + (unsigned)(2 * D * 2), ld, tid, wave);
+  stage_tile<512>(Gt, rg, (unsigned)((tok0 * D + h * DH) * 2), D, tid, wave);
+  // delta[q] = sum_d dO[q,d] * O[q,d]; two threads per query (32 d each)
+  {
+    const int q = tid >> 1, half = tid & 1;
+    const bf16_t* o = ctx + (tok0 + q) * D + h * DH + half * 32;
+    const bf16_t* g = dctx + (tok0 + q) * D + h * DH + half * 32;
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const bf16x8 ov = *reinterpret_cast<const bf16x8*>(o + c * 8);
+      const bf16x8 gv = *reinterpret_cast<const bf16x8*>(g + c * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc += bf2f((bf16_t)ov[e]) * bf2f((bf16_t)gv[e]);
+    }
+    acc += __shfl_xor(acc, 1, 64);
+    if (half == 0) {
+      del_s[q] = acc;
+      lse_s[q] = lse[(size_t)blockIdx.x * N_TOK + q];
+    }
+  }
+  __syncthreads();
+  const int hi = lane >> 5;
+
+  // ---------------- phase A: dQ for query block `wave` ----------------
+  {
+    const int q0 = wave * 32;
+    const int q = q0 + (lane & 31);
+    const float my_lse = lse_s[q], my_del = del_s[q];
+    bf16x8 qf[4], gf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      qf[s] = frag_direct(Qt, q0, s, lane);
+      gf[s] = frag_direct(Gt, q0, s, lane);
+    }
+    f32x16 dq[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) dq[dt][e] = 0.f;
+#pragma unroll 2
+    for (int kt = 0; kt < 8; ++kt) {
+      f32x16 st, dp;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { st[e] = 0.f; dp[e] = 0.f; }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_direct(Kt, kt * 32, s, lane), qf[s], st, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_direct(Vt, kt * 32, s, lane), gf[s], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) st[e] = __expf(st[e] - my_lse) * (dp[e] - my_del);   // dS^T
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const bf16x8 ds = pack8(st, u);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+          dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Kt, kt * 32 + u * 16, dt * 32, lane), ds, dq[dt], 0, 0, 0);
+      }
+    }
+    bf16_t* op = dqkv + (tok0 + q) * ld + h * DH;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = dt * 32 + 8 * g + 4 * hi;
+        *reinterpret_cast<uint2*>(op + d) = make_uint2(pack_bf2(dq[dt][g * 4] * scale, dq[dt][g * 4 + 1] * scale),
+                                                       pack_bf2(dq[dt][g * 4 + 2] * scale, dq[dt][g * 4 + 3] * scale));
+      }
+  }
+
+  // ---------------- phase B: dK, dV for key block `wave` ----------------
+  {
+    const int k0 = wave * 32;
+    const int key = k0 + (lane & 31);
+    bf16x8 kf[4], vf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      kf[s] = frag_direct(Kt, k0, s, lane);
+      vf[s] = frag_direct(Vt, k0, s, lane);
+    }
+    f32x16 dk[2], dv[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { dk[dt][e] = 0.f; dv[dt][e] = 0.f; }
+#pragma unroll 2
+    for (int qt = 0; qt < 8; ++qt) {
+      f32x16 st, dp;   // rows = queries qt*32 + (e&3) + 8*(e>>2) + 4*hi, col = key
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { st[e] = 0.f; dp[e] = 0.f; }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_direct(Qt, qt * 32, s, lane), kf[s], st, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_direct(Gt, qt * 32, s, lane), vf[s], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int qr = qt * 32 + 8 * g + 4 * hi;
+        const float4 l4 = *reinterpret_cast<const float4*>(lse_s + qr);
+        const float4 d4 = *reinterpret_cast<const float4*>(del_s + qr);
+        const float ls[4] = {l4.x, l4.y, l4.z, l4.w};
+        const float dl[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float p = __expf(st[g * 4 + e] - ls[e]);
+          st[g * 4 + e] = p;
+          dp[g * 4 + e] = p * (dp[g * 4 + e] - dl[e]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const bf16x8 pf = pack8(st, u);
+        const bf16x8 ds = pack8(dp, u);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Gt, qt * 32 + u * 16, dt * 32, lane), pf, dv[dt], 0, 0, 0);
+          dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Qt, qt * 32 + u * 16, dt * 32, lane), ds, dk[dt], 0, 0, 0);
+        }
+      }
+    }
+    bf16_t* okp = dqkv + (tok0 + key) * ld + D + h * DH;
+    bf16_t* ovp = okp + D;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = dt * 32 + 8 * g + 4 * hi;
+        *reinterpret_cast<uint2*>(okp + d) = make_uint2(pack_bf2(dk[dt][g * 4], dk[dt][g * 4 + 1]), pack_bf2(dk[dt][g * 4 + 2], dk[dt][g * 4 + 3]));
+        *reinterpret_cast<uint2*>(ovp + d) = make_uint2(pack_bf2(dv[dt][g * 4], dv[dt][g * 4 + 1]), pack_bf2(dv[dt][g * 4 + 2], dv[dt][g * 4 + 3]));
+      }
+  }
+}
+
+}  // namespace
+
+extern "C" int dig_attn_fwd(const void* qkv, void* ctx, float* lse, int n_img, int heads, int embed_dim,
+                            hipStream_t stream) {
+  if (!qkv || !ctx || !lse || n_img <= 0 || heads <= 0 || embed_dim != heads * DH) return DIG_ERR_ARG;
+  if (!aligned16(qkv) || !aligned16(ctx)) return DIG_ERR_ALIGN;
+  const size_t qb = (size_t)n_img * N_TOK * 3 * embed_dim * 2;
+  if (qb >= (1ull << 32)) return DIG_ERR_ARG;
+  static bool attr = false;
+  if (!attr) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TILE);
+    attr = true;
+  }
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3(n_img * heads), dim3(256), 2 * TILE, stream, (const bf16_t*)qkv, (bf16_t*)ctx,
+                     lse, embed_dim, heads, (unsigned)qb);
+  return dig_check_launch();
+}
+
+extern "C" int dig_attn_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse, void* dqkv, int n_img,
+                            int heads, int embed_dim, float scale, hipStream_t stream) {
+  if (!qkv || !ctx || !dctx || !lse || !dqkv || n_img <= 0 || heads <= 0 || embed_dim != heads * DH) return DIG_ERR_ARG;
+  if (!aligned16(qkv) || !aligned16(ctx) || !aligned16(dctx) || !aligned16(dqkv)) return DIG_ERR_ALIGN;
+  const size_t qb = (size_t)n_img * N_TOK * 3 * embed_dim * 2;
+  if (qb >= (1ull << 32)) return DIG_ERR_ARG;
+  const int lds = 4 * TILE + 2 * N_TOK * 4;
+  static bool attr = false;
+  if (!attr) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr = true;
+  }
+  hipLaunchKernelGGL(attn_bwd_kernel, dim3(n_img * heads), dim3(512), lds, stream, (const bf16_t*)qkv, (const bf16_t*)ctx,
+                     (const bf16_t*)dctx, lse, (bf16_t*)dqkv, embed_dim, heads, scale, (unsigned)qb, (unsigned)(qb / 3));
+  return dig_check_launch();
+}
