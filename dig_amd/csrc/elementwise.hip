@@ -1,0 +1,383 @@
+// Token-level data movement kernels of the DiG step (all HBM-bound, coalesced on the channel axis).
+//   patch_embed_{fwd,bwd}: PatchEmbed conv k4 s4 as a 48-wide dot per token, fused with the mask-token mix and the
+//       sinusoid position add (modeling_finetune.py:173-196, modeling_pretrain_vit.py:89-99).
+//   window_pool_{fwd,bwd}: PatchNet 'no_patchtrans' = adaptive_avg_pool2d of the 8x32 token grid to (1, 4)
+//       (modeling_pretrain_moco_mim_ori.py:189-193).
+//   mask_to_index: boolean mask -> ascending token indices per sample (the order boolean indexing yields,
+//       engine_for_pretraining_moco.py:107, modeling_pretrain_moco_mim_ori.py:567) -- bit-exact integer work.
+//   gather_rows / scatter_rows_add: masked-token row gather for the SimMIM decoder and its backward.
+//   mim_target: un-normalise + 'b c (h p1) (w p2) -> b (h w) (p1 p2 c)' patchify + masked gather
+//       (engine_for_pretraining_moco.py:85-111), one pass.
+//   mse_fwd_bwd: F.mse_loss(reduction='mean') and its gradient (engine_for_pretraining_moco.py:141).
+#include "common.h"
+
+namespace {
+
+constexpr int PE_TOK = 64;   // tokens per workgroup (forward)
+
+// grid: ceil(n_tok / PE_TOK); block: D threads (one output channel each)
+__global__ void patch_embed_fwd_kernel(const float* __restrict__ img, const float* __restrict__ W, const float* __restrict__ bias,
+                                       const unsigned char* __restrict__ mask, const float* __restrict__ mask_token,
+                                       const float* __restrict__ pos, bf16_t* __restrict__ out, int n_tok, int D, int gh, int gw,
+                                       int Himg, int Wimg) {
+  __shared__ float patch[PE_TOK][48];
+  __shared__ unsigned char mk[PE_TOK];
+  const int t0 = blockIdx.x * PE_TOK;
+  const int ntok_img = gh * gw;
+  for (int e = threadIdx.x; e < PE_TOK * 48; e += blockDim.x) {
+    const int tl = e / 48, k = e - tl * 48;
+    const int t = t0 + tl;
+    float v = 0.f;
+    if (t < n_tok) {
+      const int b = t / ntok_img, n = t - b * ntok_img;
+      const int ph = n / gw, pw = n - ph * gw;
+      const int c = k >> 4, p1 = (k >> 2) & 3, p2 = k & 3;       // conv weight order (c, p1, p2)
+      v = img[(((size_t)b * 3 + c) * Himg + ph * 4 + p1) * Wimg + pw * 4 + p2];
+    }
+    patch[tl][k] = v;
+  }
+  for (int e = threadIdx.x; e < PE_TOK; e += blockDim.x) mk[e] = (t0 + e < n_tok && mask) ? mask[t0 + e] : 0;
+  const int d = threadIdx.x;
+  float w[48];
+#pragma unroll
+  for (int k = 0; k < 48; ++k) w[k] = W[d * 48 + k];
+  const float bd = bias[d], mt = mask_token[d];
+  __syncthreads();
+  for (int tl = 0; tl < PE_TOK; ++tl) {
+    const int t = t0 + tl;
+    if (t >= n_tok) break;
+    float acc = bd;
+#pragma unroll
+    for (int k = 0; k < 48; ++k) acc += patch[tl][k] * w[k];
+    const int n = t % ntok_img;
+    const float v = (mk[tl] ? mt : acc) + pos[(size_t)n * D + d];
+    out[(size_t)t * D + d] = f2bf(v);
+  }
+}
+
+// grid: chunks of tokens; block: D threads.  dW[d][k] += sum_t (1-m_t) dy[t,d] patch[t,k]; dbias[d]; dmask_token[d]
+__global__ void patch_embed_bwd_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ img,
+                                       const unsigned char* __restrict__ mask, float* __restrict__ dW, float* __restrict__ dbias,
+                                       float* __restrict__ dmask_token, int n_tok, int D, int gh, int gw, int Himg, int Wimg,
+                                       int tok_per_block) {
+  __shared__ float patch[PE_TOK][48];
+  __shared__ unsigned char mk[PE_TOK];
+  const int d = threadIdx.x;
+  const int ntok_img = gh * gw;
+  float acc[48];
+#pragma unroll
+  for (int k = 0; k < 48; ++k) acc[k] = 0.f;
+  float ab = 0.f, am = 0.f;
+  const int tb = blockIdx.x * tok_per_block;
+  const int te = min(n_tok, tb + tok_per_block);
+  for (int t0 = tb; t0 < te; t0 += PE_TOK) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < PE_TOK * 48; e += blockDim.x) {
+      const int tl = e / 48, k = e - tl * 48;
+      const int t = t0 + tl;
+      float v = 0.f;
+      if (t < te) {
+        const int b = t / ntok_img, n = t - b * ntok_img;
+        const int ph = n / gw, pw = n - ph * gw;
+        const int c = k >> 4, p1 = (k >> 2) & 3, p2 = k & 3;
+        v = img[(((size_t)b * 3 + c) * Himg + ph * 4 + p1) * Wimg + pw * 4 + p2];
+      }
+      patch[tl][k] = v;
+    }
+    for (int e = threadIdx.x; e < PE_TOK; e += blockDim.x) mk[e] = (t0 + e < te && mask) ? mask[t0 + e] : 0;
+    __syncthreads();
+    for (int tl = 0; tl < PE_TOK && t0 + tl < te; ++tl) {
+      const float g = bf2f(dy[(size_t)(t0 + tl) * D + d]);
+      if (mk[tl]) {
+        am += g;
+      } else {
+        ab += g;
+#pragma unroll
+        for (int k = 0; k < 48; ++k) acc[k] += g * patch[tl][k];
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 48; ++k) atomicAdd(dW + d * 48 + k, acc[k]);
+  atomicAdd(dbias + d, ab);
+  atomicAdd(dmask_token + d, am);
+}
+
+// x [n_img, gh*gw, D] bf16 -> out [n_img*nwin, D] (fp32 or bf16): mean over all gh rows and gw/nwin columns
+template <typename OutT>
+__global__ void window_pool_fwd_kernel(const bf16_t* __restrict__ x, OutT* __restrict__ out, int n_img, int gh, int gw,
+                                       int nwin, int D) {
+  const int idx = blockIdx.x;                 // img * nwin + win
+  const int img = idx / nwin, win = idx - img * nwin;
+  const int wlen = gw / nwin;
+  const float inv = 1.0f / (gh * wlen);
+  for (int d2 = threadIdx.x; d2 < D / 2; d2 += blockDim.x) {
+    float a0 = 0.f, a1 = 0.f;
+    for (int r = 0; r < gh; ++r)
+      for (int c = 0; c < wlen; ++c) {
+        const int n = r * gw + win * wlen + c;
+        const unsigned u = *reinterpret_cast<const unsigned*>(x + ((size_t)img * gh * gw + n) * D + d2 * 2);
+        a0 += bf2f((bf16_t)(u & 0xffff));
+        a1 += bf2f((bf16_t)(u >> 16));
+      }
+    if constexpr (sizeof(OutT) == 4) {
+      out[(size_t)idx * D + d2 * 2] = a0 * inv;
+      out[(size_t)idx * D + d2 * 2 + 1] = a1 * inv;
+    } else {
+      *reinterpret_cast<unsigned*>(out + (size_t)idx * D + d2 * 2) = pack_bf2(a0 * inv, a1 * inv);
+    }
+  }
+}
+
+// dx[img, n, :] (+)= dpool[img*nwin + win(n), :] / (gh*wlen)
+__global__ void window_pool_bwd_kernel(const bf16_t* __restrict__ dpool, bf16_t* __restrict__ dx, int n_img, int gh, int gw,
+                                       int nwin, int D, int accumulate) {
+  const int t = blockIdx.x;                    // token index over n_img*gh*gw
+  const int ntok = gh * gw;
+  const int img = t / ntok, n = t - img * ntok;
+  const int win = (n % gw) / (gw / nwin);
+  const float inv = 1.0f / (gh * (gw / nwin));
+  for (int d2 = threadIdx.x; d2 < D / 2; d2 += blockDim.x) {
+    const unsigned u = *reinterpret_cast<const unsigned*>(dpool + ((size_t)img * nwin + win) * D + d2 * 2);
+    float a0 = bf2f((bf16_t)(u & 0xffff)) * inv, a1 = bf2f((bf16_t)(u >> 16)) * inv;
+    unsigned* o = reinterpret_cast<unsigned*>(dx + (size_t)t * D + d2 * 2);
+    if (accumulate) {
+      const unsigned v = *o;
+      a0 += bf2f((bf16_t)(v & 0xffff));
+      a1 += bf2f((bf16_t)(v >> 16));
+    }
+    *o = pack_bf2(a0, a1);
+  }
+}
+
+// one wave per sample: idx[b, j] = b*N + (j-th set position of mask[b, :]) ; count[b] = popcount
+__global__ void mask_to_index_kernel(const unsigned char* __restrict__ mask, int* __restrict__ idx, int* __restrict__ count,
+                                     int B, int N, int max_per_sample) {
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x;
+  int base = 0;
+  for (int n0 = 0; n0 < N; n0 += 64) {
+    const int n = n0 + lane;
+    const bool set = n < N && mask[(size_t)b * N + n] != 0;
+    const unsigned long long bal = __ballot(set);
+    const int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (set && base + before < max_per_sample) idx[(size_t)b * max_per_sample + base + before] = b * N + n;
+    base += __popcll(bal);
+  }
+  if (lane == 0) count[b] = base;
+}
+
+// dst[m, :] = src[idx[m], :]  (rows m >= M are zero-filled up to M_pad)
+__global__ void gather_rows_kernel(const bf16_t* __restrict__ src, const int* __restrict__ idx, bf16_t* __restrict__ dst, int M,
+                                   int D8) {
+  const int m = blockIdx.x;
+  const uint4* s = m < M ? reinterpret_cast<const uint4*>(src) + (size_t)idx[m] * D8 : nullptr;
+  uint4* d = reinterpret_cast<uint4*>(dst) + (size_t)m * D8;
+  for (int c = threadIdx.x; c < D8; c += blockDim.x) d[c] = s ? s[c] : make_uint4(0, 0, 0, 0);
+}
+
+// dst[idx[m], :] += src[m, :]   (idx unique)
+__global__ void scatter_rows_add_kernel(const bf16_t* __restrict__ src, const int* __restrict__ idx, bf16_t* __restrict__ dst,
+                                        int M, int D8) {
+  const int m = blockIdx.x;
+  const uint4* s = reinterpret_cast<const uint4*>(src) + (size_t)m * D8;
+  uint4* d = reinterpret_cast<uint4*>(dst) + (size_t)idx[m] * D8;
+  for (int c = threadIdx.x; c < D8; c += blockDim.x) {
+    const uint4 a = s[c], b = d[c];
+    const unsigned aa[4] = {a.x, a.y, a.z, a.w}, bb[4] = {b.x, b.y, b.z, b.w};
+    unsigned r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      r[k] = pack_bf2(bf2f((bf16_t)(aa[k] & 0xffff)) + bf2f((bf16_t)(bb[k] & 0xffff)), bf2f((bf16_t)(aa[k] >> 16)) + bf2f((bf16_t)(bb[k] >> 16)));
+    d[c] = make_uint4(r[0], r[1], r[2], r[3]);
+  }
+}
+
+// target[m, (p1*4+p2)*3 + c] = img[b, c, ph*4+p1, pw*4+p2] * 0.5 + 0.5  for token idx[m] = b*N + n
+__global__ void mim_target_kernel(const float* __restrict__ img, const int* __restrict__ idx, float* __restrict__ target, int M,
+                                  int gh, int gw, int Himg, int Wimg) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= M * 48) return;
+  const int m = e / 48, k = e - m * 48;
+  const int t = idx[m];
+  const int ntok = gh * gw;
+  const int b = t / ntok, n = t - b * ntok;
+  const int ph = n / gw, pw = n - ph * gw;
+  const int c = k % 3, p = k / 3, p1 = p >> 2, p2 = p & 3;
+  target[e] = img[(((size_t)b * 3 + c) * Himg + ph * 4 + p1) * Wimg + pw * 4 + p2] * 0.5f + 0.5f;
+}
+
+// loss += sum (pred - target)^2 * inv_count ;  dpred = gscale * 2 * (pred - target) * inv_count (bf16, ld_d, pad cols zeroed)
+__global__ void mse_fwd_bwd_kernel(const float* __restrict__ pred, int ld_p, const float* __restrict__ target, int M, int C,
+                                   float inv_count, float gscale, float* __restrict__ loss, bf16_t* __restrict__ dpred, int ld_d) {
+  float acc = 0.f;
+  const int total = M * ld_d;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const int m = e / ld_d, c = e - m * ld_d;
+    float g = 0.f;
+    if (c < C) {
+      const float df = pred[(size_t)m * ld_p + c] - target[(size_t)m * C + c];
+      acc += df * df;
+      g = 2.f * df * inv_count * gscale;
+    }
+    if (dpred) dpred[e] = f2bf(g);
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0 && loss) atomicAdd(loss, acc * inv_count);
+}
+
+__global__ void add_bf16_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, bf16_t* __restrict__ o, size_t n8) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+    const uint4 x = reinterpret_cast<const uint4*>(a)[i], y = reinterpret_cast<const uint4*>(b)[i];
+    const unsigned xx[4] = {x.x, x.y, x.z, x.w}, yy[4] = {y.x, y.y, y.z, y.w};
+    unsigned r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      r[k] = pack_bf2(bf2f((bf16_t)(xx[k] & 0xffff)) + bf2f((bf16_t)(yy[k] & 0xffff)), bf2f((bf16_t)(xx[k] >> 16)) + bf2f((bf16_t)(yy[k] >> 16)));
+    reinterpret_cast<uint4*>(o)[i] = make_uint4(r[0], r[1], r[2], r[3]);
+  }
+}
+
+// d(pre-activation) = d(act) * gelu'(pre)   (FFN backward between the fc2 dgrad and the fc1 dgrad/wgrad)
+__global__ void gelu_bwd_kernel(const bf16_t* __restrict__ dact, const bf16_t* __restrict__ pre, bf16_t* __restrict__ dpre, size_t n8) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+    const uint4 x = reinterpret_cast<const uint4*>(dact)[i], y = reinterpret_cast<const uint4*>(pre)[i];
+    const unsigned xx[4] = {x.x, x.y, x.z, x.w}, yy[4] = {y.x, y.y, y.z, y.w};
+    unsigned r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      r[k] = pack_bf2(bf2f((bf16_t)(xx[k] & 0xffff)) * dgelu_f(bf2f((bf16_t)(yy[k] & 0xffff))),
+                      bf2f((bf16_t)(xx[k] >> 16)) * dgelu_f(bf2f((bf16_t)(yy[k] >> 16))));
+    reinterpret_cast<uint4*>(dpre)[i] = make_uint4(r[0], r[1], r[2], r[3]);
+  }
+}
+
+// out[c] += sum_r x[r, c]   (bias gradients); x bf16 [rows, C]
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ x, float* __restrict__ out, int rows, int C, int ld,
+                                                     int rows_per_block) {
+  __shared__ float red[2][4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int c = blockIdx.x * 128 + lane * 2;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  float a0 = 0.f, a1 = 0.f;
+  if (c < C)
+    for (int r = r0 + wv; r < r1; r += 4) {
+      const unsigned u = *reinterpret_cast<const unsigned*>(x + (size_t)r * ld + c);
+      a0 += bf2f((bf16_t)(u & 0xffff));
+      a1 += bf2f((bf16_t)(u >> 16));
+    }
+  red[0][wv][lane] = a0; red[1][wv][lane] = a1;
+  __syncthreads();
+  if (wv == 0 && c < C) {
+    atomicAdd(out + c, red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane]);
+    if (c + 1 < C) atomicAdd(out + c + 1, red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane]);
+  }
+}
+
+}  // namespace
+
+extern "C" int dig_patch_embed_fwd(const float* img, const float* W, const float* bias, const unsigned char* mask,
+                                   const float* mask_token, const float* pos, void* out, int n_img, int gh, int gw, int D,
+                                   hipStream_t stream) {
+  if (!img || !W || !bias || !mask_token || !pos || !out || n_img <= 0 || D <= 0 || D > 1024 || (D & 63)) return DIG_ERR_ARG;
+  const int n_tok = n_img * gh * gw;
+  hipLaunchKernelGGL(patch_embed_fwd_kernel, dim3((n_tok + PE_TOK - 1) / PE_TOK), dim3(D), 0, stream, img, W, bias, mask,
+                     mask_token, pos, (bf16_t*)out, n_tok, D, gh, gw, gh * 4, gw * 4);
+  return dig_check_launch();
+}
+
+extern "C" int dig_patch_embed_bwd(const void* dy, const float* img, const unsigned char* mask, float* dW, float* dbias,
+                                   float* dmask_token, int n_img, int gh, int gw, int D, hipStream_t stream) {
+  if (!dy || !img || !dW || !dbias || !dmask_token || n_img <= 0 || D <= 0 || D > 1024 || (D & 63)) return DIG_ERR_ARG;
+  const int n_tok = n_img * gh * gw;
+  int tpb = 512;
+  while ((n_tok + tpb - 1) / tpb > 256) tpb *= 2;
+  hipLaunchKernelGGL(patch_embed_bwd_kernel, dim3((n_tok + tpb - 1) / tpb), dim3(D), 0, stream, (const bf16_t*)dy, img, mask,
+                     dW, dbias, dmask_token, n_tok, D, gh, gw, gh * 4, gw * 4, tpb);
+  return dig_check_launch();
+}
+
+extern "C" int dig_window_pool_fwd(const void* x, void* out, int out_is_f32, int n_img, int gh, int gw, int nwin, int D,
+                                   hipStream_t stream) {
+  if (!x || !out || n_img <= 0 || nwin <= 0 || gw % nwin || (D & 1)) return DIG_ERR_ARG;
+  if (out_is_f32)
+    hipLaunchKernelGGL(window_pool_fwd_kernel<float>, dim3(n_img * nwin), dim3(std::min(256, D / 2)), 0, stream, (const bf16_t*)x,
+                       (float*)out, n_img, gh, gw, nwin, D);
+  else
+    hipLaunchKernelGGL(window_pool_fwd_kernel<bf16_t>, dim3(n_img * nwin), dim3(std::min(256, D / 2)), 0, stream, (const bf16_t*)x,
+                       (bf16_t*)out, n_img, gh, gw, nwin, D);
+  return dig_check_launch();
+}
+
+extern "C" int dig_window_pool_bwd(const void* dpool, void* dx, int n_img, int gh, int gw, int nwin, int D, int accumulate,
+                                   hipStream_t stream) {
+  if (!dpool || !dx || n_img <= 0 || nwin <= 0 || gw % nwin || (D & 1)) return DIG_ERR_ARG;
+  hipLaunchKernelGGL(window_pool_bwd_kernel, dim3(n_img * gh * gw), dim3(std::min(256, D / 2)), 0, stream, (const bf16_t*)dpool,
+                     (bf16_t*)dx, n_img, gh, gw, nwin, D, accumulate);
+  return dig_check_launch();
+}
+
+extern "C" int dig_mask_to_index(const unsigned char* mask, int* idx, int* count, int B, int N, int max_per_sample,
+                                 hipStream_t stream) {
+  if (!mask || !idx || !count || B <= 0 || N <= 0 || max_per_sample <= 0) return DIG_ERR_ARG;
+  hipLaunchKernelGGL(mask_to_index_kernel, dim3(B), dim3(64), 0, stream, mask, idx, count, B, N, max_per_sample);
+  return dig_check_launch();
+}
+
+extern "C" int dig_gather_rows(const void* src, const int* idx, void* dst, int M, int M_pad, int D, hipStream_t stream) {
+  if (!src || !idx || !dst || M <= 0 || M_pad < M || (D & 7)) return DIG_ERR_ARG;
+  if (!aligned16(src) || !aligned16(dst)) return DIG_ERR_ALIGN;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(M_pad), dim3(64), 0, stream, (const bf16_t*)src, idx, (bf16_t*)dst, M, D / 8);
+  return dig_check_launch();
+}
+
+extern "C" int dig_scatter_rows_add(const void* src, const int* idx, void* dst, int M, int D, hipStream_t stream) {
+  if (!src || !idx || !dst || M <= 0 || (D & 7)) return DIG_ERR_ARG;
+  if (!aligned16(src) || !aligned16(dst)) return DIG_ERR_ALIGN;
+  hipLaunchKernelGGL(scatter_rows_add_kernel, dim3(M), dim3(64), 0, stream, (const bf16_t*)src, idx, (bf16_t*)dst, M, D / 8);
+  return dig_check_launch();
+}
+
+extern "C" int dig_mim_target(const float* img, const int* idx, float* target, int M, int gh, int gw, hipStream_t stream) {
+  if (!img || !idx || !target || M <= 0) return DIG_ERR_ARG;
+  hipLaunchKernelGGL(mim_target_kernel, dim3((M * 48 + 255) / 256), dim3(256), 0, stream, img, idx, target, M, gh, gw, gh * 4,
+                     gw * 4);
+  return dig_check_launch();
+}
+
+extern "C" int dig_mse_fwd_bwd(const float* pred, int ld_pred, const float* target, int M, int C, float gscale, float* loss,
+                               void* dpred, int ld_dpred, hipStream_t stream) {
+  if (!pred || !target || M <= 0 || C <= 0 || ld_pred < C || (dpred && ld_dpred < C)) return DIG_ERR_ARG;
+  const int ldd = dpred ? ld_dpred : C;
+  const int total = M * ldd;
+  hipLaunchKernelGGL(mse_fwd_bwd_kernel, dim3(std::min(1024, (total + 255) / 256)), dim3(256), 0, stream, pred, ld_pred, target, M, C,
+                     1.0f / ((float)M * C), gscale, loss, (bf16_t*)dpred, ldd);
+  return dig_check_launch();
+}
+
+extern "C" int dig_add_bf16(const void* a, const void* b, void* out, long long n, hipStream_t stream) {
+  if (!a || !b || !out || n <= 0 || (n & 7)) return DIG_ERR_ARG;
+  if (!aligned16(a) || !aligned16(b) || !aligned16(out)) return DIG_ERR_ALIGN;
+  const size_t n8 = (size_t)n / 8;
+  hipLaunchKernelGGL(add_bf16_kernel, dim3((unsigned)std::min<size_t>(4096, (n8 + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)a,
+                     (const bf16_t*)b, (bf16_t*)out, n8);
+  return dig_check_launch();
+}
+
+extern "C" int dig_gelu_bwd(const void* dact, const void* pre, void* dpre, long long n, hipStream_t stream) {
+  if (!dact || !pre || !dpre || n <= 0 || (n & 7)) return DIG_ERR_ARG;
+  if (!aligned16(dact) || !aligned16(pre) || !aligned16(dpre)) return DIG_ERR_ALIGN;
+  const size_t n8 = (size_t)n / 8;
+  hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)std::min<size_t>(8192, (n8 + 255) / 256)), dim3(256), 0, stream,
+                     (const bf16_t*)dact, (const bf16_t*)pre, (bf16_t*)dpre, n8);
+  return dig_check_launch();
+}
+
+extern "C" int dig_colsum(const void* x, float* out, int rows, int C, int ld, hipStream_t stream) {
+  if (!x || !out || rows <= 0 || C <= 0 || (ld & 1)) return DIG_ERR_ARG;
+  const int cb = (C + 127) / 128;
+  int rpb = 64;
+  while ((long)cb * ((rows + rpb - 1) / rpb) > 4096) rpb *= 2;
+  hipLaunchKernelGGL(colsum_kernel, dim3(cb, (rows + rpb - 1) / rpb), dim3(256), 0, stream, (const bf16_t*)x, out, rows, C, ld, rpb);
+  return dig_check_launch();
+}

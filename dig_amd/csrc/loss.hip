@@ -1,0 +1,151 @@
+// MoCo-v3 InfoNCE head in fp32 (reference: contrastive_loss / accuracy / label_smooth_loss,
+// modeling_pretrain_moco_mim_ori.py:444-461, 593-625).  The logits are tiny ([4B, 4B*W] x 256) but feed a
+// temperature-0.2 softmax, so everything here stays fp32: L2 normalise, a plain LDS-tiled fp32 GEMM for
+// q k^T / T and for dq = dlogits k, and a fused row kernel for log-softmax / CE / top-1 / top-5 / dlogits.
+#include "common.h"
+
+namespace {
+
+// y = x / max(||x||, eps) row-wise; one wave per row
+__global__ void l2norm_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ inv_norm, int n, int C,
+                                  float eps) {
+  const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (r >= n) return;
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) { const float v = x[(size_t)r * C + c]; s += v * v; }
+  s = wave_sum(s);
+  const float inv = 1.0f / fmaxf(sqrtf(s), eps);
+  for (int c = lane; c < C; c += 64) y[(size_t)r * C + c] = x[(size_t)r * C + c] * inv;
+  if (lane == 0) inv_norm[r] = inv;
+}
+
+// dx = (dy - y * <y, dy>) * inv_norm
+__global__ void l2norm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ inv_norm,
+                                  float* __restrict__ dx, int n, int C) {
+  const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (r >= n) return;
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s += y[(size_t)r * C + c] * dy[(size_t)r * C + c];
+  s = wave_sum(s);
+  const float inv = inv_norm[r];
+  for (int c = lane; c < C; c += 64) dx[(size_t)r * C + c] = (dy[(size_t)r * C + c] - y[(size_t)r * C + c] * s) * inv;
+}
+
+// fp32 GEMM, 64x64 tile, 256 threads, 4x4 per thread.  TB=false: C = alpha * A[I,R] * B[J,R]^T ; TB=true: C = alpha * A[I,R] * B[R,J]
+template <bool TB>
+__global__ __launch_bounds__(256) void sgemm_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
+                                                    int I, int J, int R, int lda, int ldb, int ldc, float alpha) {
+  __shared__ float As[16][64 + 4];
+  __shared__ float Bs[16][64 + 4];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+  float acc[4][4] = {};
+  for (int r0 = 0; r0 < R; r0 += 16) {
+    for (int e = threadIdx.x; e < 64 * 16; e += 256) {
+      const int rr = e & 15, ii = e >> 4;
+      As[rr][ii] = (i0 + ii < I && r0 + rr < R) ? A[(size_t)(i0 + ii) * lda + r0 + rr] : 0.f;
+      if (!TB) {
+        Bs[rr][ii] = (j0 + ii < J && r0 + rr < R) ? B[(size_t)(j0 + ii) * ldb + r0 + rr] : 0.f;
+      }
+    }
+    if (TB) {
+      for (int e = threadIdx.x; e < 64 * 16; e += 256) {
+        const int jj = e & 63, rr = e >> 6;
+        Bs[rr][jj] = (j0 + jj < J && r0 + rr < R) ? B[(size_t)(r0 + rr) * ldb + j0 + jj] : 0.f;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+      float a[4], b[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { a[u] = As[rr][ty * 4 + u]; b[u] = Bs[rr][tx * 4 + u]; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[u][v] += a[u] * b[v];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int i = i0 + ty * 4 + u, j = j0 + tx * 4 + v;
+      if (i < I && j < J) C[(size_t)i * ldc + j] = acc[u][v] * alpha;
+    }
+}
+
+// Per row i of logits [n, m]: lse, loss_i = lse - logit[label], rank of the label among the row, and (in place)
+// dlogits = gscale * (softmax - onehot).  out[0] += sum_i loss_i, out[1] += #top1, out[2] += #top5.
+__global__ __launch_bounds__(256) void ce_rows_kernel(float* __restrict__ logits, int n, int m, int label_offset, float gscale,
+                                                      float* __restrict__ out) {
+  __shared__ float red[8];
+  const int i = blockIdx.x;
+  float* row = logits + (size_t)i * m;
+  const int label = i + label_offset;
+  float mx = -3.0e38f;
+  for (int j = threadIdx.x; j < m; j += 256) mx = fmaxf(mx, row[j]);
+  mx = wave_max(mx);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  const float zl = row[label];
+  float s = 0.f, gt = 0.f;
+  for (int j = threadIdx.x; j < m; j += 256) {
+    const float z = row[j];
+    s += __expf(z - mx);
+    gt += (z > zl) ? 1.f : 0.f;
+  }
+  s = wave_sum(s);
+  gt = wave_sum(gt);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = s; red[4 + (threadIdx.x >> 6)] = gt; }
+  __syncthreads();
+  s = red[0] + red[1] + red[2] + red[3];
+  gt = red[4] + red[5] + red[6] + red[7];
+  const float lse = mx + __logf(s);
+  const float inv = 1.0f / s;
+  for (int j = threadIdx.x; j < m; j += 256) {
+    const float p = __expf(row[j] - mx) * inv;
+    row[j] = gscale * (p - (j == label ? 1.f : 0.f));
+  }
+  if (threadIdx.x == 0) {
+    atomicAdd(out, lse - zl);
+    if (gt < 0.5f) atomicAdd(out + 1, 1.f);
+    if (gt < 4.5f) atomicAdd(out + 2, 1.f);
+  }
+}
+
+}  // namespace
+
+extern "C" int dig_l2norm_fwd(const float* x, float* y, float* inv_norm, int n, int C, float eps, hipStream_t stream) {
+  if (!x || !y || !inv_norm || n <= 0 || C <= 0) return DIG_ERR_ARG;
+  hipLaunchKernelGGL(l2norm_fwd_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, x, y, inv_norm, n, C, eps);
+  return dig_check_launch();
+}
+
+extern "C" int dig_l2norm_bwd(const float* dy, const float* y, const float* inv_norm, float* dx, int n, int C, hipStream_t stream) {
+  if (!dy || !y || !inv_norm || !dx || n <= 0 || C <= 0) return DIG_ERR_ARG;
+  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, dy, y, inv_norm, dx, n, C);
+  return dig_check_launch();
+}
+
+extern "C" int dig_sgemm(const float* A, const float* B, float* C, int I, int J, int R, int lda, int ldb, int ldc, int trans_b,
+                         float alpha, hipStream_t stream) {
+  if (!A || !B || !C || I <= 0 || J <= 0 || R <= 0) return DIG_ERR_ARG;
+  dim3 grid((J + 63) / 64, (I + 63) / 64);
+  if (trans_b)
+    hipLaunchKernelGGL(sgemm_kernel<true>, grid, dim3(256), 0, stream, A, B, C, I, J, R, lda, ldb, ldc, alpha);
+  else
+    hipLaunchKernelGGL(sgemm_kernel<false>, grid, dim3(256), 0, stream, A, B, C, I, J, R, lda, ldb, ldc, alpha);
+  return dig_check_launch();
+}
+
+extern "C" int dig_ce_rows(float* logits, int n, int m, int label_offset, float gscale, float* out3, hipStream_t stream) {
+  if (!logits || !out3 || n <= 0 || m <= 0 || label_offset < 0 || label_offset + n > m) return DIG_ERR_ARG;
+  hipLaunchKernelGGL(ce_rows_kernel, dim3(n), dim3(256), 0, stream, logits, n, m, label_offset, gscale, out3);
+  return dig_check_launch();
+}

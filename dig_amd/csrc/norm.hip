@@ -1,0 +1,314 @@
+// LayerNorm (row statistics) and BatchNorm1d (column statistics, cross-rank capable) for gfx950.
+// Reference: nn.LayerNorm(eps=1e-6) in Block (modeling_finetune.py:134,140) and pix_decoder
+// (modeling_pretrain_moco_mim_ori.py:424); nn.BatchNorm1d inside _build_mlp (:463-482) converted to
+// SyncBatchNorm by run_mae_pretraining_moco.py:390.
+//
+// All of these are HBM-bound: bf16 in / bf16 out, fp32 statistics, one pass over the data per kernel.
+//   LayerNorm: one 64-lane wave per row, D/64 contiguous elements per lane held in registers (row is read
+//   once), wave-shuffle reductions, grid-stride over rows; the backward also folds the skip-path gradient
+//   add and reduces dgamma/dbeta per wave -> per workgroup (LDS) -> one fp32 atomic per column per workgroup.
+//   BatchNorm: statistics are column sums over rows.  A workgroup owns 128 columns x a strip of rows (each
+//   lane two adjacent columns -> 256-B coalesced row segments), 4 waves on different rows, LDS combine,
+//   fp32 atomics into [2,C].  The [2,C] vector is what goes through RCCL all-reduce between the
+//   `stats` and `apply` kernels when world_size > 1 (SyncBN semantics: statistics over all ranks' rows).
+#include "common.h"
+
+namespace {
+
+template <int EPL>
+__device__ __forceinline__ void load_row(const bf16_t* p, float* v) {
+  if constexpr (EPL == 8) {
+    const uint4 u = *reinterpret_cast<const uint4*>(p);
+    const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { v[2 * k] = bf2f((bf16_t)(w[k] & 0xffff)); v[2 * k + 1] = bf2f((bf16_t)(w[k] >> 16)); }
+  } else if constexpr (EPL % 2 == 0) {
+    const unsigned* q = reinterpret_cast<const unsigned*>(p);
+#pragma unroll
+    for (int k = 0; k < EPL / 2; ++k) { const unsigned w = q[k]; v[2 * k] = bf2f((bf16_t)(w & 0xffff)); v[2 * k + 1] = bf2f((bf16_t)(w >> 16)); }
+  } else {
+#pragma unroll
+    for (int k = 0; k < EPL; ++k) v[k] = bf2f(p[k]);
+  }
+}
+template <int EPL>
+__device__ __forceinline__ void store_row(bf16_t* p, const float* v) {
+  if constexpr (EPL == 8) {
+    *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+  } else if constexpr (EPL % 2 == 0) {
+    unsigned* q = reinterpret_cast<unsigned*>(p);
+#pragma unroll
+    for (int k = 0; k < EPL / 2; ++k) q[k] = pack_bf2(v[2 * k], v[2 * k + 1]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < EPL; ++k) p[k] = f2bf(v[k]);
+  }
+}
+
+template <int EPL, bool GELU>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, bf16_t* __restrict__ y,
+                                                     float* __restrict__ mean, float* __restrict__ rstd, int rows, float eps) {
+  constexpr int D = EPL * 64;
+  const int lane = threadIdx.x & 63;
+  const int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nw = (gridDim.x * blockDim.x) >> 6;
+  float g[EPL], b[EPL];
+#pragma unroll
+  for (int k = 0; k < EPL; ++k) { g[k] = gamma[lane * EPL + k]; b[k] = beta[lane * EPL + k]; }
+  for (int r = w; r < rows; r += nw) {
+    float v[EPL];
+    load_row<EPL>(x + (size_t)r * D + lane * EPL, v);
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < EPL; ++k) s += v[k];
+    const float mu = wave_sum(s) * (1.0f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < EPL; ++k) { v[k] -= mu; q += v[k] * v[k]; }
+    const float rs = rsqrtf(wave_sum(q) * (1.0f / D) + eps);
+#pragma unroll
+    for (int k = 0; k < EPL; ++k) {
+      v[k] = v[k] * rs * g[k] + b[k];
+      if (GELU) v[k] = gelu_f(v[k]);
+    }
+    store_row<EPL>(y + (size_t)r * D + lane * EPL, v);
+    if (lane == 0) { mean[r] = mu; rstd[r] = rs; }
+  }
+}
+
+// dx = [dres +] rstd * (dyg - mean(dyg) - xhat * mean(dyg*xhat)),  dyg = dy' * gamma, dy' = dy (* gelu'(ln) if GELU)
+template <int EPL, bool GELU>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, int rows) {
+  constexpr int D = EPL * 64;
+  __shared__ float red[2][4][D];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nw = (gridDim.x * blockDim.x) >> 6;
+  float g[EPL], bt[EPL], dg[EPL], db[EPL];
+#pragma unroll
+  for (int k = 0; k < EPL; ++k) { g[k] = gamma[lane * EPL + k]; bt[k] = GELU ? beta[lane * EPL + k] : 0.f; dg[k] = 0.f; db[k] = 0.f; }
+  for (int r = w; r < rows; r += nw) {
+    float v[EPL], d[EPL];
+    load_row<EPL>(x + (size_t)r * D + lane * EPL, v);
+    load_row<EPL>(dy + (size_t)r * D + lane * EPL, d);
+    const float mu = mean[r], rs = rstd[r];
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < EPL; ++k) {
+      v[k] = (v[k] - mu) * rs;                     // xhat
+      if (GELU) d[k] *= dgelu_f(v[k] * g[k] + bt[k]);
+      dg[k] += d[k] * v[k];
+      db[k] += d[k];
+      d[k] *= g[k];
+      c1 += d[k];
+      c2 += d[k] * v[k];
+    }
+    c1 = wave_sum(c1) * (1.0f / D);
+    c2 = wave_sum(c2) * (1.0f / D);
+    float o[EPL];
+#pragma unroll
+    for (int k = 0; k < EPL; ++k) o[k] = rs * (d[k] - c1 - v[k] * c2);
+    if (dres) {
+      float e[EPL];
+      load_row<EPL>(dres + (size_t)r * D + lane * EPL, e);
+#pragma unroll
+      for (int k = 0; k < EPL; ++k) o[k] += e[k];
+    }
+    store_row<EPL>(dx + (size_t)r * D + lane * EPL, o);
+  }
+#pragma unroll
+  for (int k = 0; k < EPL; ++k) { red[0][wv][lane * EPL + k] = dg[k]; red[1][wv][lane * EPL + k] = db[k]; }
+  __syncthreads();
+  for (int c = threadIdx.x; c < D; c += blockDim.x) {
+    atomicAdd(dgamma + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+    atomicAdd(dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+  }
+}
+
+// ---------------- BatchNorm ----------------
+// MODE 0: out[0][c] += sum_r x, out[1][c] += sum_r x^2
+// MODE 1: g = dy * (relu ? (gamma*xhat+beta > 0) : 1); out[0][c] += sum g, out[1][c] += sum g*xhat
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_colstats_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          int relu, float* __restrict__ out, int rows, int C, int rows_per_block) {
+  __shared__ float red[4][4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int c = blockIdx.x * 128 + lane * 2;
+  const int r0 = blockIdx.y * rows_per_block;
+  const int r1 = min(rows, r0 + rows_per_block);
+  float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
+  if (c < C) {
+    float mu0 = 0, mu1 = 0, rs0 = 1, rs1 = 1, g0 = 1, g1 = 1, be0 = 0, be1 = 0;
+    if (MODE == 1) {
+      mu0 = mean[c]; mu1 = mean[c + 1]; rs0 = rstd[c]; rs1 = rstd[c + 1];
+      if (gamma) { g0 = gamma[c]; g1 = gamma[c + 1]; be0 = beta[c]; be1 = beta[c + 1]; }
+    }
+    for (int r = r0 + wv; r < r1; r += 4) {
+      const unsigned u = *reinterpret_cast<const unsigned*>(x + (size_t)r * C + c);
+      float x0 = bf2f((bf16_t)(u & 0xffff)), x1 = bf2f((bf16_t)(u >> 16));
+      if (MODE == 0) {
+        a0 += x0; a1 += x1; b0 += x0 * x0; b1 += x1 * x1;
+      } else {
+        const unsigned du = *reinterpret_cast<const unsigned*>(dy + (size_t)r * C + c);
+        float d0 = bf2f((bf16_t)(du & 0xffff)), d1 = bf2f((bf16_t)(du >> 16));
+        x0 = (x0 - mu0) * rs0; x1 = (x1 - mu1) * rs1;
+        if (relu) {
+          if (!(g0 * x0 + be0 > 0.f)) d0 = 0.f;
+          if (!(g1 * x1 + be1 > 0.f)) d1 = 0.f;
+        }
+        a0 += d0; a1 += d1; b0 += d0 * x0; b1 += d1 * x1;
+      }
+    }
+  }
+  red[0][wv][lane] = a0; red[1][wv][lane] = a1; red[2][wv][lane] = b0; red[3][wv][lane] = b1;
+  __syncthreads();
+  if (wv == 0 && c < C) {
+    atomicAdd(out + c, red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane]);
+    atomicAdd(out + c + 1, red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane]);
+    atomicAdd(out + C + c, red[2][0][lane] + red[2][1][lane] + red[2][2][lane] + red[2][3][lane]);
+    atomicAdd(out + C + c + 1, red[3][0][lane] + red[3][1][lane] + red[3][2][lane] + red[3][3][lane]);
+  }
+}
+
+// y = [relu]( gamma * (x - mean) * rstd + beta );  mean/rstd derived from global sums (sum, sumsq) and 1/n.
+__global__ __launch_bounds__(256) void bn_fwd_apply_kernel(const bf16_t* __restrict__ x, const float* __restrict__ sums,
+                                                           float inv_n, float eps, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, int relu, bf16_t* __restrict__ y,
+                                                           float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                           size_t total8, int C) {
+  const int c8 = C >> 3;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total8; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c8) * 8;
+    float v[8];
+    load_row<8>(x + i * 8, v);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float mu = sums[c + k] * inv_n;
+      const float var = fmaxf(sums[C + c + k] * inv_n - mu * mu, 0.f);
+      const float rs = rsqrtf(var + eps);
+      float o = (v[k] - mu) * rs;
+      if (gamma) o = o * gamma[c + k] + beta[c + k];
+      if (relu) o = fmaxf(o, 0.f);
+      v[k] = o;
+      if (i < (size_t)c8) { mean_out[c + k] = mu; rstd_out[c + k] = rs; }
+    }
+    store_row<8>(y + i * 8, v);
+  }
+}
+
+// dx = gamma * rstd * (g - S1/n - xhat * S2/n), S = all-rank sums of (g, g*xhat)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           int relu, const float* __restrict__ sums, float inv_n,
+                                                           bf16_t* __restrict__ dx, size_t total8, int C) {
+  const int c8 = C >> 3;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total8; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c8) * 8;
+    float v[8], d[8];
+    load_row<8>(x + i * 8, v);
+    load_row<8>(dy + i * 8, d);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float rs = rstd[c + k];
+      const float xh = (v[k] - mean[c + k]) * rs;
+      const float gm = gamma ? gamma[c + k] : 1.f;
+      float g = d[k];
+      if (relu && !(gm * xh + (gamma ? beta[c + k] : 0.f) > 0.f)) g = 0.f;
+      v[k] = gm * rs * (g - sums[c + k] * inv_n - xh * sums[C + c + k] * inv_n);
+    }
+    store_row<8>(dx + i * 8, v);
+  }
+}
+
+inline int ln_grid(int rows) { return std::max(1, std::min(2048, (rows + 3) / 4)); }
+
+}  // namespace
+
+#define LN_DISPATCH(D, GELU, KERNEL, ...)                                                          \
+  switch (D) {                                                                                     \
+    case 64: hipLaunchKernelGGL((KERNEL<1, GELU>), dim3(grid), dim3(256), 0, stream, __VA_ARGS__); break;  \
+    case 128: hipLaunchKernelGGL((KERNEL<2, GELU>), dim3(grid), dim3(256), 0, stream, __VA_ARGS__); break; \
+    case 192: hipLaunchKernelGGL((KERNEL<3, GELU>), dim3(grid), dim3(256), 0, stream, __VA_ARGS__); break; \
+    case 256: hipLaunchKernelGGL((KERNEL<4, GELU>), dim3(grid), dim3(256), 0, stream, __VA_ARGS__); break; \
+    case 384: hipLaunchKernelGGL((KERNEL<6, GELU>), dim3(grid), dim3(256), 0, stream, __VA_ARGS__); break; \
+    case 512: hipLaunchKernelGGL((KERNEL<8, GELU>), dim3(grid), dim3(256), 0, stream, __VA_ARGS__); break; \
+    default: return DIG_ERR_UNSUPPORTED;                                                           \
+  }
+
+extern "C" int dig_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                                 int rows, int D, float eps, int fuse_gelu, hipStream_t stream) {
+  if (!x || !gamma || !beta || !y || !mean || !rstd || rows <= 0) return DIG_ERR_ARG;
+  if (!aligned16(x) || !aligned16(y)) return DIG_ERR_ALIGN;
+  const int grid = ln_grid(rows);
+  if (fuse_gelu) { LN_DISPATCH(D, true, ln_fwd_kernel, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, rows, eps) }
+  else { LN_DISPATCH(D, false, ln_fwd_kernel, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, rows, eps) }
+  return dig_check_launch();
+}
+
+extern "C" int dig_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean,
+                                 const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta, int rows, int D,
+                                 int fuse_gelu, hipStream_t stream) {
+  if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || rows <= 0) return DIG_ERR_ARG;
+  if (fuse_gelu && !beta) return DIG_ERR_ARG;
+  if (!aligned16(x) || !aligned16(dy) || !aligned16(dx) || (dres && !aligned16(dres))) return DIG_ERR_ALIGN;
+  const int grid = std::max(1, std::min(512, (rows + 15) / 16));
+  if (fuse_gelu) { LN_DISPATCH(D, true, ln_bwd_kernel, (const bf16_t*)dy, (const bf16_t*)x, gamma, beta, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, dgamma, dbeta, rows) }
+  else { LN_DISPATCH(D, false, ln_bwd_kernel, (const bf16_t*)dy, (const bf16_t*)x, gamma, beta, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, dgamma, dbeta, rows) }
+  return dig_check_launch();
+}
+
+extern "C" int dig_bn_stats(const void* x, float* sums /*[2,C], accumulated into*/, int rows, int C, hipStream_t stream) {
+  if (!x || !sums || rows <= 0 || C <= 0 || (C & 7)) return DIG_ERR_ARG;
+  const int cb = (C + 127) / 128;
+  int rpb = 64;
+  while ((long)cb * ((rows + rpb - 1) / rpb) > 4096) rpb *= 2;
+  dim3 grid(cb, (rows + rpb - 1) / rpb);
+  hipLaunchKernelGGL(bn_colstats_kernel<0>, grid, dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)nullptr, nullptr,
+                     nullptr, nullptr, nullptr, 0, sums, rows, C, rpb);
+  return dig_check_launch();
+}
+
+extern "C" int dig_bn_fwd_apply(const void* x, const float* sums, float n_total, float eps, const float* gamma,
+                                const float* beta, int relu, void* y, float* mean_out, float* rstd_out, int rows, int C,
+                                hipStream_t stream) {
+  if (!x || !sums || !y || !mean_out || !rstd_out || rows <= 0 || (C & 7) || n_total <= 0.f) return DIG_ERR_ARG;
+  if ((gamma == nullptr) != (beta == nullptr)) return DIG_ERR_ARG;
+  if (!aligned16(x) || !aligned16(y)) return DIG_ERR_ALIGN;
+  const size_t total8 = (size_t)rows * C / 8;
+  const int grid = (int)std::min<size_t>(2048, (total8 + 255) / 256);
+  hipLaunchKernelGGL(bn_fwd_apply_kernel, dim3(grid), dim3(256), 0, stream, (const bf16_t*)x, sums, 1.0f / n_total, eps, gamma,
+                     beta, relu, (bf16_t*)y, mean_out, rstd_out, total8, C);
+  return dig_check_launch();
+}
+
+extern "C" int dig_bn_bwd_stats(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                                const float* beta, int relu, float* sums, int rows, int C, hipStream_t stream) {
+  if (!dy || !x || !mean || !rstd || !sums || rows <= 0 || (C & 7)) return DIG_ERR_ARG;
+  const int cb = (C + 127) / 128;
+  int rpb = 64;
+  while ((long)cb * ((rows + rpb - 1) / rpb) > 4096) rpb *= 2;
+  dim3 grid(cb, (rows + rpb - 1) / rpb);
+  hipLaunchKernelGGL(bn_colstats_kernel<1>, grid, dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)dy, mean, rstd, gamma,
+                     beta, relu, sums, rows, C, rpb);
+  return dig_check_launch();
+}
+
+extern "C" int dig_bn_bwd_apply(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                                const float* beta, int relu, const float* sums, float n_total, void* dx, int rows, int C,
+                                hipStream_t stream) {
+  if (!dy || !x || !mean || !rstd || !sums || !dx || rows <= 0 || (C & 7) || n_total <= 0.f) return DIG_ERR_ARG;
+  if (!aligned16(x) || !aligned16(dy) || !aligned16(dx)) return DIG_ERR_ALIGN;
+  const size_t total8 = (size_t)rows * C / 8;
+  const int grid = (int)std::min<size_t>(2048, (total8 + 255) / 256);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)x, mean, rstd,
+                     gamma, beta, relu, sums, 1.0f / n_total, (bf16_t*)dx, total8, C);
+  return dig_check_launch();
+}

@@ -1,0 +1,173 @@
+// Flat-arena optimizer kernels (HBM-bound, 16 B per lane per stream):
+//   adamw_step: decoupled-weight-decay Adam exactly as custom_optim/_functional.py:115-140 computes it, over a
+//       contiguous fp32 range of the parameter arena, with up to 4 (begin,end,weight_decay) segments so one launch
+//       covers the decay / no-decay groups of optim_factory.py:57-100; also refreshes the bf16 shadow the GEMMs read.
+//       Traffic: read p,g,m,v + write p,m,v (28 B/param) + 2 B/param bf16 shadow.
+//   ema_update: p_m = p_m*m + p*(1-m)  (modeling_pretrain_moco_mim_ori.py:428-442) + bf16 shadow: 12 + 2 B/param.
+//   sumsq_partial / sumsq_final: deterministic two-stage sum of squares for the global gradient norm
+//       (utils/utils.py:507-519); sqrt is taken on the host side of the ABI.
+//   cast / scale / fill helpers.
+#include "common.h"
+
+namespace {
+
+struct Segs {
+  long long begin[4];
+  long long end[4];
+  float wd[4];
+  int n;
+};
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, bf16_t* __restrict__ shadow, long long n4, Segs segs,
+                                                    float lr, float beta1, float beta2, float eps, float inv_bc1,
+                                                    float inv_sqrt_bc2, float grad_scale) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const long long e0 = i * 4;
+    float4 pp = reinterpret_cast<float4*>(p)[i];
+    float4 gg = reinterpret_cast<const float4*>(g)[i];
+    float4 mm = reinterpret_cast<float4*>(m)[i];
+    float4 vv = reinterpret_cast<float4*>(v)[i];
+    float P[4] = {pp.x, pp.y, pp.z, pp.w}, G[4] = {gg.x, gg.y, gg.z, gg.w}, M[4] = {mm.x, mm.y, mm.z, mm.w}, V[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float wd = 0.f;
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        if (s < segs.n && e0 + k >= segs.begin[s] && e0 + k < segs.end[s]) wd = segs.wd[s];
+      const float gk = G[k] * grad_scale;
+      P[k] *= (1.0f - lr * wd);
+      M[k] = M[k] * beta1 + gk * (1.0f - beta1);
+      V[k] = V[k] * beta2 + gk * gk * (1.0f - beta2);
+      const float denom = sqrtf(V[k]) * inv_sqrt_bc2 + eps;
+      P[k] -= (lr * inv_bc1) * (M[k] / denom);
+    }
+    reinterpret_cast<float4*>(p)[i] = make_float4(P[0], P[1], P[2], P[3]);
+    reinterpret_cast<float4*>(m)[i] = make_float4(M[0], M[1], M[2], M[3]);
+    reinterpret_cast<float4*>(v)[i] = make_float4(V[0], V[1], V[2], V[3]);
+    if (shadow) reinterpret_cast<uint2*>(shadow)[i] = make_uint2(pack_bf2(P[0], P[1]), pack_bf2(P[2], P[3]));
+  }
+}
+
+__global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ pm, const float* __restrict__ p, bf16_t* __restrict__ shadow,
+                                                  long long n4, float m, float one_minus_m) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    float4 a = reinterpret_cast<float4*>(pm)[i];
+    const float4 b = reinterpret_cast<const float4*>(p)[i];
+    a.x = a.x * m + b.x * one_minus_m;
+    a.y = a.y * m + b.y * one_minus_m;
+    a.z = a.z * m + b.z * one_minus_m;
+    a.w = a.w * m + b.w * one_minus_m;
+    reinterpret_cast<float4*>(pm)[i] = a;
+    if (shadow) reinterpret_cast<uint2*>(shadow)[i] = make_uint2(pack_bf2(a.x, a.y), pack_bf2(a.z, a.w));
+  }
+}
+
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ x, long long n4, float* __restrict__ partial) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const float4 a = reinterpret_cast<const float4*>(x)[i];
+    acc += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restrict__ partial, int n, float* __restrict__ out) {
+  __shared__ double red[4];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) acc += (double)partial[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = (float)(red[0] + red[1] + red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, long long n4) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const float4 a = reinterpret_cast<const float4*>(x)[i];
+    reinterpret_cast<uint2*>(y)[i] = make_uint2(pack_bf2(a.x, a.y), pack_bf2(a.z, a.w));
+  }
+}
+
+__global__ __launch_bounds__(256) void cast_back_kernel(const bf16_t* __restrict__ x, float* __restrict__ y, long long n4) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const uint2 a = reinterpret_cast<const uint2*>(x)[i];
+    reinterpret_cast<float4*>(y)[i] = make_float4(bf2f((bf16_t)(a.x & 0xffff)), bf2f((bf16_t)(a.x >> 16)), bf2f((bf16_t)(a.y & 0xffff)), bf2f((bf16_t)(a.y >> 16)));
+  }
+}
+
+__global__ __launch_bounds__(256) void scale_kernel(float* __restrict__ x, long long n4, float s) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    float4 a = reinterpret_cast<float4*>(x)[i];
+    a.x *= s; a.y *= s; a.z *= s; a.w *= s;
+    reinterpret_cast<float4*>(x)[i] = a;
+  }
+}
+
+inline int flat_grid(long long n4) { return (int)std::min<long long>(4096, (n4 + 255) / 256); }
+
+}  // namespace
+
+extern "C" int dig_adamw_step(float* p, const float* g, float* m, float* v, void* bf16_shadow, long long n, int n_seg,
+                              const long long* seg_begin, const long long* seg_end, const float* seg_wd, float lr, float beta1,
+                              float beta2, float eps, int step, float grad_scale, hipStream_t stream) {
+  if (!p || !g || !m || !v || n <= 0 || (n & 3) || n_seg < 0 || n_seg > 4 || step < 1) return DIG_ERR_ARG;
+  if (!aligned16(p) || !aligned16(g) || !aligned16(m) || !aligned16(v) || (bf16_shadow && (((uintptr_t)bf16_shadow) & 7))) return DIG_ERR_ALIGN;
+  Segs s;
+  s.n = n_seg;
+  for (int i = 0; i < 4; ++i) {
+    s.begin[i] = i < n_seg ? seg_begin[i] : 0;
+    s.end[i] = i < n_seg ? seg_end[i] : 0;
+    s.wd[i] = i < n_seg ? seg_wd[i] : 0.f;
+  }
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  hipLaunchKernelGGL(adamw_kernel, dim3(flat_grid(n / 4)), dim3(256), 0, stream, p, g, m, v, (bf16_t*)bf16_shadow, n / 4, s, lr,
+                     beta1, beta2, eps, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)), grad_scale);
+  return dig_check_launch();
+}
+
+extern "C" int dig_ema_update(float* pm, const float* p, void* bf16_shadow, long long n, float m, hipStream_t stream) {
+  if (!pm || !p || n <= 0 || (n & 3)) return DIG_ERR_ARG;
+  if (!aligned16(pm) || !aligned16(p) || (bf16_shadow && (((uintptr_t)bf16_shadow) & 7))) return DIG_ERR_ALIGN;
+  hipLaunchKernelGGL(ema_kernel, dim3(flat_grid(n / 4)), dim3(256), 0, stream, pm, p, (bf16_t*)bf16_shadow, n / 4, m,
+                     (float)(1.0 - (double)m));
+  return dig_check_launch();
+}
+
+extern "C" long long dig_sumsq_workspace_bytes(long long n) { return 1024 * sizeof(float); }
+
+extern "C" int dig_sumsq(const float* x, long long n, float* workspace, float* out, hipStream_t stream) {
+  if (!x || !workspace || !out || n <= 0 || (n & 3)) return DIG_ERR_ARG;
+  if (!aligned16(x)) return DIG_ERR_ALIGN;
+  const int grid = (int)std::min<long long>(1024, (n / 4 + 255) / 256);
+  hipLaunchKernelGGL(sumsq_partial_kernel, dim3(grid), dim3(256), 0, stream, x, n / 4, workspace);
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, stream, workspace, grid, out);
+  return dig_check_launch();
+}
+
+extern "C" int dig_cast_f32_to_bf16(const float* x, void* y, long long n, hipStream_t stream) {
+  if (!x || !y || n <= 0 || (n & 3)) return DIG_ERR_ARG;
+  if (!aligned16(x) || (((uintptr_t)y) & 7)) return DIG_ERR_ALIGN;
+  hipLaunchKernelGGL(cast_kernel, dim3(flat_grid(n / 4)), dim3(256), 0, stream, x, (bf16_t*)y, n / 4);
+  return dig_check_launch();
+}
+
+extern "C" int dig_cast_bf16_to_f32(const void* x, float* y, long long n, hipStream_t stream) {
+  if (!x || !y || n <= 0 || (n & 3)) return DIG_ERR_ARG;
+  if (!aligned16(y) || (((uintptr_t)x) & 7)) return DIG_ERR_ALIGN;
+  hipLaunchKernelGGL(cast_back_kernel, dim3(flat_grid(n / 4)), dim3(256), 0, stream, (const bf16_t*)x, y, n / 4);
+  return dig_check_launch();
+}
+
+extern "C" int dig_scale_f32(float* x, long long n, float s, hipStream_t stream) {
+  if (!x || n <= 0 || (n & 3)) return DIG_ERR_ARG;
+  if (!aligned16(x)) return DIG_ERR_ALIGN;
+  hipLaunchKernelGGL(scale_kernel, dim3(flat_grid(n / 4)), dim3(256), 0, stream, x, n / 4, s);
+  return dig_check_launch();
+}
