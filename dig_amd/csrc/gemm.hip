@@ -255,8 +255,8 @@ int launch(const GemmParams& p, int splits, hipStream_t stream) {
 // C-ABI: see include/dig_hip.h
 extern "C" int dig_gemm_bf16(const void* A, const void* B, void* C, int I, int J, int R, int lda, int ldb, int ldc,
                              int trans_a, int trans_b, int out_kind, const float* bias, const void* resid, int ldr,
-                             void* pre_act, int ldp, float alpha, int alpha_cols, int act, int splits,
-                             hipStream_t stream) {
+                             void* pre_act, int ldp, float alpha, int alpha_cols, int act, int splits, int a_rows,
+                             int b_rows, hipStream_t stream) {
   if (!A || !B || !C || I <= 0 || J <= 0 || R <= 0 || splits < 1) return DIG_ERR_ARG;
   if (out_kind < 0 || out_kind > 2 || act < 0 || act > 1) return DIG_ERR_ARG;
   if (!aligned16(A) || !aligned16(B) || !aligned16(C) || (lda & 7) || (ldb & 7)) return DIG_ERR_ALIGN;
@@ -268,7 +268,9 @@ extern "C" int dig_gemm_bf16(const void* A, const void* B, void* C, int I, int J
   GemmParams p;
   p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C;
   p.I = I; p.J = J; p.R = R; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
-  const size_t ab = (size_t)(trans_a ? R : I) * lda * 2, bb = (size_t)(trans_b ? R : J) * ldb * 2;
+  // a_rows / b_rows (0 = default) bound the rows that really exist in memory; rows past them read as zero.
+  const size_t ab = (size_t)(a_rows > 0 ? a_rows : (trans_a ? R : I)) * lda * 2;
+  const size_t bb = (size_t)(b_rows > 0 ? b_rows : (trans_b ? R : J)) * ldb * 2;
   if (ab >= (1ull << 32) || bb >= (1ull << 32)) return DIG_ERR_ARG;
   p.a_bytes = (unsigned)ab; p.b_bytes = (unsigned)bb;
   p.bias = bias; p.resid = (const bf16_t*)resid; p.ldr = ldr; p.pre = (bf16_t*)pre_act; p.ldp = ldp;

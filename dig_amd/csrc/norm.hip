@@ -228,6 +228,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t* __restr
   }
 }
 
+// running_mean/var <- (1-mom)*old + mom*(mean, unbiased var) from the (all-rank) sums
+__global__ void bn_running_kernel(const float* __restrict__ sums, float n, float momentum, float* __restrict__ rm, float* __restrict__ rv, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float mu = sums[c] / n;
+  const float var = fmaxf(sums[C + c] / n - mu * mu, 0.f);
+  rm[c] = rm[c] * (1.f - momentum) + mu * momentum;
+  rv[c] = rv[c] * (1.f - momentum) + var * (n / (n - 1.f)) * momentum;
+}
+
 inline int ln_grid(int rows) { return std::max(1, std::min(2048, (rows + 3) / 4)); }
 
 }  // namespace
@@ -310,5 +320,12 @@ extern "C" int dig_bn_bwd_apply(const void* dy, const void* x, const float* mean
   const int grid = (int)std::min<size_t>(2048, (total8 + 255) / 256);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)x, mean, rstd,
                      gamma, beta, relu, sums, 1.0f / n_total, (bf16_t*)dx, total8, C);
+  return dig_check_launch();
+}
+
+extern "C" int dig_bn_update_running(const float* sums, float n_total, float momentum, float* running_mean, float* running_var,
+                                     int C, hipStream_t stream) {
+  if (!sums || !running_mean || !running_var || C <= 0 || n_total <= 1.f) return DIG_ERR_ARG;
+  hipLaunchKernelGGL(bn_running_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, sums, n_total, momentum, running_mean, running_var, C);
   return dig_check_launch();
 }

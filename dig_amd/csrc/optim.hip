@@ -11,36 +11,29 @@
 
 namespace {
 
-struct Segs {
-  long long begin[4];
-  long long end[4];
-  float wd[4];
-  int n;
-};
-
+// group[i >> 8] selects the param group (0 = decay, 1 = no_decay) of element i; parameters are padded to 256 elements.
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                    float* __restrict__ v, bf16_t* __restrict__ shadow, long long n4, Segs segs,
-                                                    float lr, float beta1, float beta2, float eps, float inv_bc1,
+                                                    float* __restrict__ v, bf16_t* __restrict__ shadow, long long n4,
+                                                    const unsigned char* __restrict__ group, float lr0, float wd0, float lr1,
+                                                    float wd1, float beta1, float beta2, float eps, float inv_bc1,
                                                     float inv_sqrt_bc2, float grad_scale) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
-    const long long e0 = i * 4;
+    const int grp = group[i >> 6];
+    const float lr = grp ? lr1 : lr0, wd = grp ? wd1 : wd0;
     float4 pp = reinterpret_cast<float4*>(p)[i];
     float4 gg = reinterpret_cast<const float4*>(g)[i];
     float4 mm = reinterpret_cast<float4*>(m)[i];
     float4 vv = reinterpret_cast<float4*>(v)[i];
     float P[4] = {pp.x, pp.y, pp.z, pp.w}, G[4] = {gg.x, gg.y, gg.z, gg.w}, M[4] = {mm.x, mm.y, mm.z, mm.w}, V[4] = {vv.x, vv.y, vv.z, vv.w};
+    const float decay = 1.0f - lr * wd, step_size = lr * inv_bc1;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      float wd = 0.f;
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-        if (s < segs.n && e0 + k >= segs.begin[s] && e0 + k < segs.end[s]) wd = segs.wd[s];
       const float gk = G[k] * grad_scale;
-      P[k] *= (1.0f - lr * wd);
+      P[k] *= decay;
       M[k] = M[k] * beta1 + gk * (1.0f - beta1);
       V[k] = V[k] * beta2 + gk * gk * (1.0f - beta2);
       const float denom = sqrtf(V[k]) * inv_sqrt_bc2 + eps;
-      P[k] -= (lr * inv_bc1) * (M[k] / denom);
+      P[k] -= step_size * (M[k] / denom);
     }
     reinterpret_cast<float4*>(p)[i] = make_float4(P[0], P[1], P[2], P[3]);
     reinterpret_cast<float4*>(m)[i] = make_float4(M[0], M[1], M[2], M[3]);
@@ -109,26 +102,39 @@ __global__ __launch_bounds__(256) void scale_kernel(float* __restrict__ x, long 
   }
 }
 
+__global__ __launch_bounds__(256) void fill_kernel(float* __restrict__ x, long long n4, float val) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x)
+    reinterpret_cast<float4*>(x)[i] = make_float4(val, val, val, val);
+}
+
+// x *= *scalar (device scalar; keeps the upstream autograd gradient on the device)
+__global__ __launch_bounds__(256) void scale_dev_kernel(float* __restrict__ x, long long n, const float* __restrict__ scalar, float extra) {
+  const float s = scalar[0] * extra;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) x[i] *= s;
+}
+
+// dst bf16 [M_pad, ld] <- src f32 [M, C] (zero padding in rows >= M and cols >= C)
+__global__ __launch_bounds__(256) void pad_cast_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int M, int C, int M_pad, int ld) {
+  const long long total = (long long)M_pad * ld;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int r = (int)(e / ld), c = (int)(e - (long long)r * ld);
+    dst[e] = (r < M && c < C) ? f2bf(src[(size_t)r * C + c]) : (bf16_t)0;
+  }
+}
+
 inline int flat_grid(long long n4) { return (int)std::min<long long>(4096, (n4 + 255) / 256); }
 
 }  // namespace
 
-extern "C" int dig_adamw_step(float* p, const float* g, float* m, float* v, void* bf16_shadow, long long n, int n_seg,
-                              const long long* seg_begin, const long long* seg_end, const float* seg_wd, float lr, float beta1,
+extern "C" int dig_adamw_step(float* p, const float* g, float* m, float* v, void* bf16_shadow, long long n,
+                              const unsigned char* group_flags, float lr0, float wd0, float lr1, float wd1, float beta1,
                               float beta2, float eps, int step, float grad_scale, hipStream_t stream) {
-  if (!p || !g || !m || !v || n <= 0 || (n & 3) || n_seg < 0 || n_seg > 4 || step < 1) return DIG_ERR_ARG;
+  if (!p || !g || !m || !v || !group_flags || n <= 0 || (n & 255) || step < 1) return DIG_ERR_ARG;
   if (!aligned16(p) || !aligned16(g) || !aligned16(m) || !aligned16(v) || (bf16_shadow && (((uintptr_t)bf16_shadow) & 7))) return DIG_ERR_ALIGN;
-  Segs s;
-  s.n = n_seg;
-  for (int i = 0; i < 4; ++i) {
-    s.begin[i] = i < n_seg ? seg_begin[i] : 0;
-    s.end[i] = i < n_seg ? seg_end[i] : 0;
-    s.wd[i] = i < n_seg ? seg_wd[i] : 0.f;
-  }
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
-  hipLaunchKernelGGL(adamw_kernel, dim3(flat_grid(n / 4)), dim3(256), 0, stream, p, g, m, v, (bf16_t*)bf16_shadow, n / 4, s, lr,
-                     beta1, beta2, eps, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)), grad_scale);
+  hipLaunchKernelGGL(adamw_kernel, dim3(flat_grid(n / 4)), dim3(256), 0, stream, p, g, m, v, (bf16_t*)bf16_shadow, n / 4,
+                     group_flags, lr0, wd0, lr1, wd1, beta1, beta2, eps, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)), grad_scale);
   return dig_check_launch();
 }
 
@@ -169,5 +175,36 @@ extern "C" int dig_scale_f32(float* x, long long n, float s, hipStream_t stream)
   if (!x || n <= 0 || (n & 3)) return DIG_ERR_ARG;
   if (!aligned16(x)) return DIG_ERR_ALIGN;
   hipLaunchKernelGGL(scale_kernel, dim3(flat_grid(n / 4)), dim3(256), 0, stream, x, n / 4, s);
+  return dig_check_launch();
+}
+
+extern "C" int dig_fill_f32(float* x, long long n, float value, hipStream_t stream) {
+  if (!x || n <= 0 || (n & 3)) return DIG_ERR_ARG;
+  if (!aligned16(x)) return DIG_ERR_ALIGN;
+  hipLaunchKernelGGL(fill_kernel, dim3(flat_grid(n / 4)), dim3(256), 0, stream, x, n / 4, value);
+  return dig_check_launch();
+}
+
+extern "C" int dig_scale_by_device_scalar(float* x, long long n, const float* scalar, float extra, hipStream_t stream) {
+  if (!x || !scalar || n <= 0) return DIG_ERR_ARG;
+  hipLaunchKernelGGL(scale_dev_kernel, dim3(flat_grid((n + 3) / 4)), dim3(256), 0, stream, x, n, scalar, extra);
+  return dig_check_launch();
+}
+
+extern "C" int dig_pad_cast_rows(const float* src, void* dst, int M, int C, int M_pad, int ld, hipStream_t stream) {
+  if (!src || !dst || M <= 0 || C <= 0 || M_pad < M || ld < C) return DIG_ERR_ARG;
+  hipLaunchKernelGGL(pad_cast_kernel, dim3(flat_grid(((long long)M_pad * ld + 3) / 4)), dim3(256), 0, stream, src, (bf16_t*)dst, M, C, M_pad, ld);
+  return dig_check_launch();
+}
+
+namespace {
+__global__ __launch_bounds__(256) void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, long long n, float a) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) y[i] += a * x[i];
+}
+}  // namespace
+
+extern "C" int dig_axpy_f32(float* y, const float* x, long long n, float a, hipStream_t stream) {
+  if (!y || !x || n <= 0) return DIG_ERR_ARG;
+  hipLaunchKernelGGL(axpy_kernel, dim3(flat_grid((n + 3) / 4)), dim3(256), 0, stream, y, x, n, a);
   return dig_check_launch();
 }

@@ -1,0 +1,351 @@
+"""Forward and hand-written backward of MoCo_ViT as a sequence of HIP kernel launches.
+
+The math follows the reference step by step (citations: modeling_pretrain_moco_mim_ori.py:488-577 MoCo_ViT.forward,
+modeling_pretrain_vit.py:89-106 encoder, modeling_finetune.py:87-158 attention/block/MLP, :444-461 InfoNCE); what is
+new is the execution model: no autograd graph over ops, one custom autograd node for the whole model whose
+backward is the explicit reverse sequence below, activations in bf16, gradients accumulated straight into the flat
+fp32 gradient arena, per-stage callbacks so the data-parallel wrapper can start the RCCL all-reduce of a finished
+parameter range while earlier layers are still in backward.
+"""
+import torch
+
+from . import ops
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+class LocalComm:
+    world, rank = 1, 0
+
+    def all_reduce_(self, t):
+        return t
+
+    def all_gather_cat(self, t):
+        return t
+
+    def grad_ready(self, model, key):
+        pass
+
+
+LOCAL = LocalComm()
+
+
+class _EncWeights:
+    """Per-encoder (online / momentum) accessors resolved once per arena binding."""
+
+    def __init__(self, model, prefix, arena):
+        self.blocks = []
+        w16, f32 = model._w(arena), model._f32
+        g32 = model._g32 if arena == "online" else {}
+        for i in range(model.depth):
+            b = f"{prefix}blocks.{i}."
+            d = {k: f32[b + k] for k in ("norm1.weight", "norm1.bias", "attn.proj.bias", "norm2.weight", "norm2.bias",
+                                         "mlp.fc1.bias", "mlp.fc2.bias")}
+            d.update({k: w16[b + k] for k in ("attn.qkv.weight", "attn.proj.weight", "mlp.fc1.weight", "mlp.fc2.weight")})
+            d["qkv_bias"] = model._qkv_bias[b + "attn."]
+            if g32:
+                d["g"] = {k: g32[b + k] for k in ("norm1.weight", "norm1.bias", "attn.qkv.weight", "attn.proj.weight",
+                                                   "attn.proj.bias", "norm2.weight", "norm2.bias", "mlp.fc1.weight",
+                                                   "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias")}
+                d["g"]["qkv_bias"] = model._qkv_bias_grad[b + "attn."]
+            self.blocks.append(d)
+        self.pe_w = f32[prefix + "patch_embed.proj.weight"].view(model.D, 48)
+        self.pe_b = f32[prefix + "patch_embed.proj.bias"]
+        self.mask_token = f32[prefix + "mask_token"].view(model.D)
+        if g32:
+            self.g_pe_w = g32[prefix + "patch_embed.proj.weight"].view(model.D, 48)
+            self.g_pe_b = g32[prefix + "patch_embed.proj.bias"]
+            self.g_mask_token = g32[prefix + "mask_token"].view(model.D)
+
+
+def _weights(model):
+    cache = getattr(model, "_wcache", None)
+    if cache is None or cache[0] != model._views_version or model._shadow.get("online") is None or model._shadow.get("momentum") is None:
+        model.shadow("online"), model.shadow("momentum")
+        model._w16 = None
+        cache = (model._views_version, _EncWeights(model, "encoder.", "online"), _EncWeights(model, "momentum_encoder.", "momentum"))
+        model._wcache = cache
+    return cache[1], cache[2]
+
+
+class _Step:
+    def __init__(self, model):
+        self.m = model
+        self.comm = model.comm or LOCAL
+
+    # ------------------------------------------------------------------ encoder
+    def encoder_forward(self, ew, images, aug, mask_u8, save):
+        M = self.m
+        B, D, H, N = images.shape[0], M.D, M.H, M.N
+        R = 2 * B * N
+        x = torch.empty((R, D), device=images.device, dtype=BF16)
+        for half, im in enumerate((images, aug)):
+            ops.L.call("dig_patch_embed_fwd", ops.L.ptr(im), ops.L.ptr(ew.pe_w), ops.L.ptr(ew.pe_b),
+                       ops.L.ptr(mask_u8[half * B:(half + 1) * B]), ops.L.ptr(ew.mask_token), ops.L.ptr(M._pos),
+                       ops.L.ptr(x[half * B * N:(half + 1) * B * N]), B, M.gh, M.gw, D, ops.L.stream())
+        saved = []
+        scale = (D // H) ** -0.5
+        for blk in ew.blocks:
+            ln1, mu1, rs1 = ops.layernorm_fwd(x, blk["norm1.weight"], blk["norm1.bias"], M.ln_eps)
+            qkv = ops.linear_fwd(ln1, blk["attn.qkv.weight"], bias=blk["qkv_bias"], alpha=scale, alpha_cols=D)
+            ctx, lse = ops.attn_fwd(qkv, 2 * B, H, D)
+            x_mid = ops.linear_fwd(ctx, blk["attn.proj.weight"], bias=blk["attn.proj.bias"], resid=x)
+            ln2, mu2, rs2 = ops.layernorm_fwd(x_mid, blk["norm2.weight"], blk["norm2.bias"], M.ln_eps)
+            pre = torch.empty((R, M.F), device=x.device, dtype=BF16) if save else None
+            act = ops.linear_fwd(ln2, blk["mlp.fc1.weight"], bias=blk["mlp.fc1.bias"], act=1, pre=pre)
+            x_out = ops.linear_fwd(act, blk["mlp.fc2.weight"], bias=blk["mlp.fc2.bias"], resid=x_mid)
+            if save:
+                saved.append((x, ln1, mu1, rs1, qkv, ctx, lse, x_mid, ln2, mu2, rs2, pre, act))
+            x = x_out
+        return x, saved
+
+    def encoder_backward(self, ew, saved, dx, images, aug, mask_u8):
+        """dx: bf16 [R, D] gradient w.r.t. the encoder output (consumed)."""
+        M = self.m
+        B, D, H, N = images.shape[0], M.D, M.H, M.N
+        scale = (D // H) ** -0.5
+        for i in reversed(range(M.depth)):
+            blk, g = ew.blocks[i], ew.blocks[i]["g"]
+            x, ln1, mu1, rs1, qkv, ctx, lse, x_mid, ln2, mu2, rs2, pre, act = saved[i]
+            saved[i] = None
+            # x_out = x_mid + fc2(gelu(fc1(ln2)))
+            ops.linear_wgrad(dx, act, g["mlp.fc2.weight"])
+            ops.colsum(dx, g["mlp.fc2.bias"])
+            dact = ops.linear_dgrad(dx, blk["mlp.fc2.weight"])
+            ops.gelu_bwd(dact, pre, dact)
+            ops.linear_wgrad(dact, ln2, g["mlp.fc1.weight"])
+            ops.colsum(dact, g["mlp.fc1.bias"])
+            dln2 = ops.linear_dgrad(dact, blk["mlp.fc1.weight"])
+            del dact, pre, act
+            dx_mid = ops.layernorm_bwd(dln2, x_mid, blk["norm2.weight"], blk["norm2.bias"], mu2, rs2, dx, g["norm2.weight"], g["norm2.bias"], out=dln2)
+            # x_mid = x + proj(attn(ln1))
+            ops.linear_wgrad(dx_mid, ctx, g["attn.proj.weight"])
+            ops.colsum(dx_mid, g["attn.proj.bias"])
+            dctx = ops.linear_dgrad(dx_mid, blk["attn.proj.weight"])
+            dqkv = ops.attn_bwd(qkv, ctx, dctx, lse, 2 * B, H, D, scale)
+            ops.linear_wgrad(dqkv, ln1, g["attn.qkv.weight"])
+            gb = g["qkv_bias"]
+            ops.colsum(dqkv, gb[:D], cols=D)                              # q_bias (dq already carries the q scale)
+            ops.colsum(dqkv[:, 2 * D:], gb[2 * D:], cols=D)               # v_bias; K has no bias
+            dln1 = ops.linear_dgrad(dqkv, blk["attn.qkv.weight"], out=dctx)
+            dx = ops.layernorm_bwd(dln1, x, blk["norm1.weight"], blk["norm1.bias"], mu1, rs1, dx_mid, g["norm1.weight"], g["norm1.bias"], out=dln1)
+            self.comm.grad_ready(M, f"encoder.blocks.{i}")
+        for half, im in enumerate((images, aug)):
+            ops.patch_embed_bwd(dx[half * B * N:(half + 1) * B * N], im, mask_u8[half * B:(half + 1) * B], ew.g_pe_w, ew.g_pe_b,
+                                ew.g_mask_token, D, M.gh, M.gw)
+        self.comm.grad_ready(M, "encoder.embed")
+
+    # ------------------------------------------------------------------ BN-MLP heads
+    def mlp_forward(self, x, pre, arena, save):
+        """_build_mlp stack (modeling_pretrain_moco_mim_ori.py:463-482): Linear(no bias) -> BN(train, cross-rank stats)
+        -> ReLU ... ; the last BN has no affine parameters."""
+        M = self.m
+        dims = M.mlps[pre]
+        w16, f32 = M._w(arena), M._f32
+        n_local = x.shape[0]
+        n_total = float(n_local * self.comm.world)
+        saved = []
+        for l, (d1, d2) in enumerate(dims):
+            last = l == len(dims) - 1
+            h = ops.linear_fwd(x, w16[f"{pre}.{3 * l}.weight"])
+            sums = torch.zeros((2, d2), device=x.device, dtype=F32)
+            ops.bn_stats(h, sums)
+            self.comm.all_reduce_(sums)
+            gamma = None if last else f32[f"{pre}.{3 * l + 1}.weight"]
+            beta = None if last else f32[f"{pre}.{3 * l + 1}.bias"]
+            y, mean, rstd = ops.bn_fwd_apply(h, sums, n_total, M.bn_eps, gamma, beta, relu=not last)
+            rm, rv, i_bn = M._bn_views[f"{pre}.{3 * l + 1}"]
+            ops.bn_update_running(sums, n_total, M.bn_momentum, rm, rv)
+            self._bn_touched.append(i_bn)
+            if save:
+                saved.append((x, h, mean, rstd))
+            x = y
+        return x, saved
+
+    def mlp_backward(self, dy, pre, saved, need_dx=True, dx_out=None):
+        M = self.m
+        dims = M.mlps[pre]
+        w16, f32, g32 = M._w("online"), M._f32, M._g32
+        n_total = float(saved[0][0].shape[0] * self.comm.world)
+        for l in reversed(range(len(dims))):
+            d1, d2 = dims[l]
+            last = l == len(dims) - 1
+            x, h, mean, rstd = saved[l]
+            gamma = None if last else f32[f"{pre}.{3 * l + 1}.weight"]
+            beta = None if last else f32[f"{pre}.{3 * l + 1}.bias"]
+            sums = torch.zeros((2, d2), device=dy.device, dtype=F32)
+            ops.bn_bwd_stats(dy, h, mean, rstd, gamma, beta, not last, sums)
+            if not last:                                                   # local sums are the affine gradients
+                ops.axpy_f32(g32[f"{pre}.{3 * l + 1}.bias"], sums[0])
+                ops.axpy_f32(g32[f"{pre}.{3 * l + 1}.weight"], sums[1])
+            self.comm.all_reduce_(sums)
+            dh = ops.bn_bwd_apply(dy, h, mean, rstd, gamma, beta, not last, sums, n_total)
+            ops.linear_wgrad(dh, x, g32[f"{pre}.{3 * l}.weight"])
+            if l > 0 or need_dx:
+                dy = ops.linear_dgrad(dh, w16[f"{pre}.{3 * l}.weight"], out=dx_out if l == 0 else None)
+        return dy
+
+    # ------------------------------------------------------------------ full forward
+    def forward(self, images, aug, mask_b2n, m):
+        M = self.m
+        dev = images.device
+        B, D, N, nw = images.shape[0], M.D, M.N, M.num_windows
+        comm = self.comm
+        self.B = B
+        self._bn_touched = []
+        images = images.contiguous().float()
+        aug = aug.contiguous().float()
+        mask_u8 = mask_b2n.permute(1, 0, 2).reshape(2 * B, N).to(torch.uint8).contiguous()    # rows 0..B-1 = view 0 (:497)
+        self.images, self.aug, self.mask_u8 = images, aug, mask_u8
+        ew_on, ew_mo = _weights(M)
+        ops.cast_f32_to_bf16(M._flat["online"], M.shadow("online"))
+        # ---- online branch
+        enc, self.saved_enc = self.encoder_forward(ew_on, images, aug, mask_u8, True)
+        self.enc = enc
+        masked2, self.saved_pix = self.mlp_forward(enc[:B * N], "pix_projector", "online", True)
+        pooled = torch.empty((2 * B * nw, D), device=dev, dtype=BF16)
+        ops.window_pool_fwd(masked2, pooled[:B * nw], B, M.gh, M.gw, nw, D)
+        ops.window_pool_fwd(enc[B * N:], pooled[B * nw:], B, M.gh, M.gw, nw, D)
+        qs, self.saved_proj = self.mlp_forward(pooled, "encoder_projection_layer", "online", True)
+        qs, self.saved_pred = self.mlp_forward(qs, "predictor", "online", True)
+        # ---- momentum branch (no grad): EMA with the current online weights first (:526)
+        ops.ema_update(M._flat["momentum"], M._flat["online"], M.shadow("momentum"), M.n_ema, m)
+        enc_m, _ = self.encoder_forward(ew_mo, images, aug, mask_u8, False)
+        masked_m, _ = self.mlp_forward(enc_m[:B * N], "pix_projector_m", "momentum", False)
+        pooled_m = torch.empty((2 * B * nw, D), device=dev, dtype=BF16)
+        ops.window_pool_fwd(masked_m, pooled_m[:B * nw], B, M.gh, M.gw, nw, D)
+        ops.window_pool_fwd(enc_m[B * N:], pooled_m[B * nw:], B, M.gh, M.gw, nw, D)
+        ks, _ = self.mlp_forward(pooled_m, "momentum_projection_layer", "momentum", False)
+        del enc_m, masked_m, pooled_m
+        M._flat["bn_count"] += 1                                            # all 14 BatchNorm layers ran once
+        # ---- InfoNCE (:444-461): q1 vs gathered k2, q2 vs gathered k1, labels = arange + n*rank
+        n = B * nw                                                          # rows of q1 / q2
+        dim = M.moco_dim
+        qf = torch.empty((2 * n, dim), device=dev, dtype=F32)
+        kf = torch.empty((2 * n, dim), device=dev, dtype=F32)
+        ops.cast_bf16_to_f32(qs, qf)
+        ops.cast_bf16_to_f32(ks, kf)
+        qn, self.q_inv = ops.l2norm_fwd(qf)
+        kn, _ = ops.l2norm_fwd(kf)
+        self.qn = qn
+        if comm.world > 1:
+            kall = comm.all_gather_cat(kn.view(1, 2, n, dim))               # [W, 2, n, dim], rank order (:586-590)
+            k1_all = kall[:, 0].reshape(comm.world * n, dim).contiguous()
+            k2_all = kall[:, 1].reshape(comm.world * n, dim).contiguous()
+        else:
+            k1_all, k2_all = kn[:n], kn[n:]
+        mk = comm.world * n
+        stats = torch.zeros((2, 3), device=dev, dtype=F32)
+        self.dqn = torch.empty((2 * n, dim), device=dev, dtype=F32)
+        gs = 2.0 * M.T / n                                                  # d(mean CE * 2T)/dlogits scale
+        for half, kk in ((0, k2_all), (1, k1_all)):
+            logits = torch.empty((n, mk), device=dev, dtype=F32)
+            ops.sgemm(qn[half * n:(half + 1) * n], kk, logits, n, mk, dim, False, 1.0 / M.T)
+            ops.ce_rows(logits, n * comm.rank, gs, stats[half])
+            ops.sgemm(logits, kk, self.dqn[half * n:(half + 1) * n], n, dim, mk, True, 1.0 / M.T)
+        contra = (stats[0, 0] + stats[1, 0]) * (2.0 * M.T / n)
+        accs = stats[:, 1:].reshape(4) * (100.0 / n)                        # q1_acc1, q1_acc5, q2_acc1, q2_acc5
+        # ---- SimMIM decoder on the masked tokens of view 0 only (:560-570; the reference decodes all rows then selects)
+        per = M._mask_count(mask_u8, B)
+        Mrows = B * per
+        Mp = (Mrows + 63) // 64 * 64
+        idx, cnt = ops.mask_to_index(mask_u8[:B], per)
+        M._last_mask_counts, M._last_idx, M._last_images = cnt, idx, images
+        self.idx, self.Mrows, self.Mp, self.per = idx, Mrows, Mp, per
+        w16, f32 = M._w("online"), M._f32
+        gath = ops.gather_rows(enc, idx, Mrows, Mp)
+        h0 = ops.linear_fwd(gath, w16["pix_decoder.0.weight"])
+        h1 = ops.linear_fwd(h0, w16["pix_decoder.1.weight"])
+        h2, mu, rs = ops.layernorm_fwd(h1, f32["pix_decoder.2.weight"], f32["pix_decoder.2.bias"], M.ln_eps, gelu=True)
+        pred = torch.empty((Mp, 64), device=dev, dtype=F32)
+        C = M.dec_classes
+        ops.gemm(h2, w16["pix_decoder.4.weight"], Mp, C, M.dec_dim, out=pred, out_kind=ops.OUT_F32, bias=f32["pix_decoder.4.bias"], ldc=64)
+        self.saved_dec = (gath, h0, h1, h2, mu, rs)
+        vis_out = pred[:Mrows, :C].reshape(B, per, C)
+        return contra, accs, vis_out
+
+    # ------------------------------------------------------------------ full backward
+    def backward(self, g_contra, g_vis):
+        M = self.m
+        B, D, N, nw = self.B, M.D, M.N, M.num_windows
+        dev = self.enc.device
+        w16, f32, g32 = M._w("online"), M._f32, M._g32
+        d_enc = torch.empty_like(self.enc)
+        # ---- contrastive path
+        n = B * nw
+        dqn = self.dqn
+        if g_contra is not None:
+            ops.scale_by_device_scalar(dqn, g_contra.reshape(1).float())
+        else:
+            ops.fill_f32(dqn, 0.0)
+        dq = ops.l2norm_bwd(dqn, self.qn, self.q_inv)
+        dq16 = torch.empty(dq.shape, device=dev, dtype=BF16)
+        ops.cast_f32_to_bf16(dq, dq16)
+        dproj = self.mlp_backward(dq16, "predictor", self.saved_pred)
+        self.comm.grad_ready(M, "predictor")
+        dpool = self.mlp_backward(dproj, "encoder_projection_layer", self.saved_proj)
+        self.comm.grad_ready(M, "encoder_projection_layer")
+        dmasked2 = torch.empty((B * N, D), device=dev, dtype=BF16)
+        ops.window_pool_bwd(dpool[:n], dmasked2, B, M.gh, M.gw, nw, D, False)
+        ops.window_pool_bwd(dpool[n:], d_enc[B * N:], B, M.gh, M.gw, nw, D, False)
+        self.mlp_backward(dmasked2, "pix_projector", self.saved_pix, dx_out=d_enc[:B * N])
+        self.comm.grad_ready(M, "pix_projector")
+        # ---- SimMIM decoder path
+        if g_vis is not None:
+            gath, h0, h1, h2, mu, rs = self.saved_dec
+            Mrows, Mp, C, Dd = self.Mrows, self.Mp, M.dec_classes, M.dec_dim
+            dpred = torch.empty((Mp, 64), device=dev, dtype=BF16)
+            ops.pad_cast_rows(g_vis.reshape(Mrows, C).contiguous().float(), dpred, Mrows, C)
+            ops.gemm(dpred, h2, C, Dd, Mp, ta=True, tb=True, out=g32["pix_decoder.4.weight"], out_kind=ops.OUT_F32_ATOMIC,
+                     splits=ops.wgrad_splits(Mp, 2))
+            ops.colsum(dpred, g32["pix_decoder.4.bias"], cols=C)
+            dh2 = ops.gemm(dpred, w16["pix_decoder.4.weight"], Mp, Dd, 64, tb=True, b_rows=C)
+            dh1 = ops.layernorm_bwd(dh2, h1, f32["pix_decoder.2.weight"], f32["pix_decoder.2.bias"], mu, rs, None,
+                                    g32["pix_decoder.2.weight"], g32["pix_decoder.2.bias"], gelu=True)
+            ops.linear_wgrad(dh1, h0, g32["pix_decoder.1.weight"])
+            dh0 = ops.linear_dgrad(dh1, w16["pix_decoder.1.weight"])
+            ops.linear_wgrad(dh0, gath, g32["pix_decoder.0.weight"])
+            dgath = ops.linear_dgrad(dh0, w16["pix_decoder.0.weight"])
+            ops.scatter_rows_add(dgath, self.idx, d_enc, Mrows)
+        self.comm.grad_ready(M, "pix_decoder")
+        # ---- encoder
+        ew_on, _ = _weights(M)
+        self.encoder_backward(ew_on, self.saved_enc, d_enc, self.images, self.aug, self.mask_u8)
+        self.saved_enc = self.saved_pix = self.saved_proj = self.saved_pred = self.saved_dec = None
+
+
+class _DigFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, model, images, aug, mask, m):
+        step = _Step(model)
+        contra, accs, vis_out = step.forward(images, aug, mask, m)
+        ctx.step = step
+        ctx.mark_non_differentiable(accs)
+        return contra, accs, vis_out
+
+    @staticmethod
+    def backward(ctx, g_contra, g_accs, g_vis):
+        step, ctx.step = ctx.step, None
+        step.backward(g_contra, g_vis)
+        return None, None, None, None, None, None
+
+
+def dig_forward(model, image, aug_image, vis_mask_pos, m, only_mim_on_ori_img=True):
+    if not image.is_cuda:
+        raise RuntimeError("dig_amd.MoCo_ViT runs on an MI355X (cuda device) only; there is no CPU fallback")
+    if model._flat["online"].device != image.device:
+        raise RuntimeError("model and inputs are on different devices (call model.to(device))")
+    if not only_mim_on_ori_img:
+        raise NotImplementedError("only_mim_on_ori_img=False is not implemented (README configuration uses True)")
+    mask = vis_mask_pos
+    if mask.dim() == 2:
+        mask = mask.view(image.shape[0], -1, model.N)
+    anchor = getattr(model, "_anchor", None)
+    if anchor is None or anchor.device != image.device:
+        anchor = model._anchor = torch.zeros(1, device=image.device, requires_grad=True)
+    if torch.is_grad_enabled():
+        contra, accs, vis_out = _DigFn.apply(anchor, model, image, aug_image, mask, float(m))
+    else:
+        contra, accs, vis_out = _Step(model).forward(image, aug_image, mask, float(m))
+    return {"contra_loss": contra, "q1_acc1": accs[0:1], "q1_acc5": accs[1:2], "q2_acc1": accs[2:3], "q2_acc5": accs[3:4],
+            "vis_out": [vis_out]}

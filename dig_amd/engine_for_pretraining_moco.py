@@ -1,0 +1,152 @@
+"""train_one_epoch for the MI355X engine -- same signature, argument meaning, meter names and error behaviour as the
+reference step engine (engine_for_pretraining_moco.py:26-204).
+
+Per step: per-iteration lr / weight-decay (:60-66) and MoCo momentum (:69-73) from the host schedules, MIM target
+build (:83-111) as one gather kernel with bit-exact index order, model forward (one fused autograd node), loss
+combine (:119-144), backward + global grad norm + fused AdamW through the loss_scaler object (:152-157), metrics."""
+import math
+import sys
+from typing import Iterable
+
+import numpy as np
+import torch
+
+from . import ops
+from . import utils
+
+
+class _MimMSE(torch.autograd.Function):
+    """F.mse_loss(vis_out, target, 'mean') with the masked-patch target gathered on the fly
+    (un-normalise + '(p1 p2 c)' patchify + boolean select, engine_for_pretraining_moco.py:85-111,141)."""
+
+    @staticmethod
+    def forward(ctx, vis_out, images, idx):
+        B, per, C = vis_out.shape
+        M = B * per
+        target = ops.mim_target(images, idx, M, 8, 32)
+        loss = torch.zeros(1, device=vis_out.device, dtype=torch.float32)
+        dpred = torch.empty((M, C), device=vis_out.device, dtype=torch.bfloat16)
+        if vis_out.stride(2) != 1 or vis_out.stride(0) != per * vis_out.stride(1):
+            vis_out = vis_out.contiguous()
+        ops.mse_fwd_bwd(vis_out, vis_out.stride(1), target, M, C, 1.0, loss, dpred, C)
+        ctx.dpred = dpred
+        ctx.shape = (B, per, C)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        d = torch.empty(ctx.shape, device=g.device, dtype=torch.float32)
+        ops.cast_bf16_to_f32(ctx.dpred, d)
+        ops.scale_by_device_scalar(d, g.reshape(1).float())
+        return d, None, None
+
+
+def mim_mse_loss(vis_out, images, idx):
+    return _MimMSE.apply(vis_out, images, idx)
+
+
+def train_one_epoch(model: torch.nn.Module, teacher_model, teacher_model_without_ddp, data_loader: Iterable,
+                    word_data_loader: Iterable, optimizer: torch.optim.Optimizer, device: torch.device, epoch: int,
+                    loss_scaler, max_norm: float = 0, patch_size: int = 16, normlize_target: bool = True, log_writer=None,
+                    lr_scheduler=None, start_steps=None, lr_schedule_values=None, wd_schedule_values=None,
+                    momentum_schedule=None, args=None):
+    if normlize_target:
+        raise NotImplementedError("normlize_target=True is not part of the pre-training recipe (run_mae_pretraining_moco.py:90)")
+    if args.num_view != 2 or not args.only_mim_on_ori_img:
+        raise NotImplementedError("the hot path is the 2-view, only_mim_on_ori_img recipe (README.md:53-78)")
+    model.train()
+    core = model.module if hasattr(model, "module") else model
+    metric_logger = utils.MetricLogger(delimiter="  ")
+    metric_logger.add_meter('lr', utils.SmoothedValue(window_size=1, fmt='{value:.6f}'))
+    metric_logger.add_meter('min_lr', utils.SmoothedValue(window_size=1, fmt='{value:.6f}'))
+    header = 'Epoch: [{}]'.format(epoch)
+    print_freq = 100
+    iters_per_epoch = len(data_loader)
+
+    # contrast loss-weight warm-up (:48-56)
+    if epoch == args.contrast_start_epoch:
+        ws = min(args.contrast_warmup_steps, iters_per_epoch)
+        contrast_loss_weights = np.linspace(0., args.loss_weight_contrast, ws)
+        if ws < iters_per_epoch:
+            contrast_loss_weights = np.hstack([contrast_loss_weights, np.ones(iters_per_epoch - ws) * args.loss_weight_contrast])
+    elif epoch > args.contrast_start_epoch:
+        contrast_loss_weights = np.ones(iters_per_epoch) * args.loss_weight_contrast
+    else:
+        contrast_loss_weights = np.zeros(iters_per_epoch)
+
+    for step, (batch, text, text_lens) in enumerate(metric_logger.log_every(data_loader, print_freq, header)):
+        it = start_steps + step
+        if lr_schedule_values is not None or wd_schedule_values is not None:
+            for param_group in optimizer.param_groups:
+                if lr_schedule_values is not None:
+                    param_group["lr"] = lr_schedule_values[it] * param_group["lr_scale"]
+                if wd_schedule_values is not None and param_group["weight_decay"] > 0:
+                    param_group["weight_decay"] = wd_schedule_values[it]
+        moco_m = utils.adjust_moco_momentum(epoch + 1.0 * step / iters_per_epoch, args) if args.use_moco_m_cos else args.moco_m
+        metric_logger.update(moco_m=moco_m)
+
+        images, aug_images, bool_vis_masked_pos = batch
+        images = images.to(device, non_blocking=True)
+        aug_images = aug_images.to(device, non_blocking=True)
+        bool_vis_masked_pos = bool_vis_masked_pos.to(device, non_blocking=True).flatten(1).to(torch.bool)
+        B = images.shape[0]
+        bool_vis_masked_pos = bool_vis_masked_pos.view(B, args.num_view, -1)
+        bool_vis_masked_pos[:, 1, :].fill_(0)                               # only the original view is masked (:103-104)
+
+        out_dict = model(images, aug_images, bool_vis_masked_pos, moco_m, args.only_mim_on_ori_img)
+        loss = 0.
+        contra_loss = out_dict['contra_loss']
+        loss = loss + contra_loss * float(contrast_loss_weights[step])
+        vis_out = out_dict['vis_out']
+        loss_pixel = mim_mse_loss(vis_out[0], core._last_images, core._last_idx)
+        loss = loss + loss_pixel * args.loss_weight_pixel
+
+        # one device->host read for everything the reference reads with separate .item() calls
+        host = torch.stack([loss.detach().reshape(()), contra_loss.detach().reshape(()), loss_pixel.detach().reshape(()),
+                            out_dict['q1_acc1'][0], out_dict['q1_acc5'][0], out_dict['q2_acc1'][0], out_dict['q2_acc5'][0],
+                            core._last_mask_counts.min().float(), core._last_mask_counts.max().float()]).tolist()
+        loss_value = host[0]
+        metric_logger.update(loss_contrast=host[1], q1_acc1=host[3], q1_acc5=host[4], q2_acc1=host[5], q2_acc5=host[6], loss_pixel=host[2])
+        if host[7] != host[8] or int(host[7]) != core._per_sample_mask:
+            raise RuntimeError("masks must select the same number of tokens in every sample "
+                               f"(got {int(host[7])}..{int(host[8])}, expected {core._per_sample_mask})")
+        if not math.isfinite(loss_value):
+            print("Loss is {}, stopping training".format(loss_value))
+            sys.exit(1)
+
+        optimizer.zero_grad()
+        grad_norm = loss_scaler(loss, optimizer, clip_grad=max_norm, parameters=model.parameters(), create_graph=False)
+        loss_scale_value = loss_scaler.state_dict()["scale"]
+        torch.cuda.synchronize()
+
+        metric_logger.update(loss=loss_value)
+        metric_logger.update(loss_scale=loss_scale_value)
+        min_lr, max_lr = 10., 0.
+        for group in optimizer.param_groups:
+            min_lr, max_lr = min(min_lr, group["lr"]), max(max_lr, group["lr"])
+        metric_logger.update(lr=max_lr)
+        metric_logger.update(min_lr=min_lr)
+        weight_decay_value = None
+        for group in optimizer.param_groups:
+            if group["weight_decay"] > 0:
+                weight_decay_value = group["weight_decay"]
+        metric_logger.update(weight_decay=weight_decay_value)
+        metric_logger.update(grad_norm=grad_norm)
+        if log_writer is not None:
+            log_writer.update(loss=loss_value, head="loss")
+            log_writer.update(loss_scale=loss_scale_value, head="opt")
+            log_writer.update(lr=max_lr, head="opt")
+            log_writer.update(min_lr=min_lr, head="opt")
+            log_writer.update(weight_decay=weight_decay_value, head="opt")
+            log_writer.update(grad_norm=grad_norm, head="opt")
+            log_writer.set_step()
+        if lr_scheduler is not None:
+            lr_scheduler.step_update(start_steps + step)
+        if step >= 1 and step % (args.eval_freq * 10) == 0:
+            utils.save_model(args=args, model=model, model_without_ddp=core, optimizer=optimizer, loss_scaler=loss_scaler,
+                             epoch="{0}_{1}".format(epoch, step))
+        sys.stdout.flush()
+
+    metric_logger.synchronize_between_processes()
+    print("Averaged stats:", metric_logger)
+    return {k: meter.global_avg for k, meter in metric_logger.meters.items()}

@@ -1,0 +1,429 @@
+"""MoCo_ViT for MI355X: the reference's SimMIM + MoCo-v3 pre-training model
+(reference: modeling_pretrain_moco_mim_ori.py:261-577, factories :627-871; encoder modeling_pretrain_vit.py:27-111;
+blocks modeling_finetune.py:43-210) re-designed around flat HBM arenas and hand-written HIP kernels.
+
+What is kept from the reference (the drop-in surface):
+  * factory names (`pretrain_simmim_moco_ori_vit_{tiny,small,base}_patch4_32x128`) and their kwargs;
+  * `forward(image, aug_image, vis_mask_pos, m, only_mim_on_ori_img) -> dict` with keys
+    contra_loss, q1_acc1, q1_acc5, q2_acc1, q2_acc5, vis_out;
+  * `named_parameters()` / `state_dict()` key names, shapes and order (356 params + 42 BN buffers for ViT-S);
+  * `.encoder.patch_embed.patch_size`, `.no_weight_decay()`, `.train()`, `.to(device)`.
+
+What is different (MI355X-first):
+  * all trainable parameters live in ONE fp32 arena (+ one fp32 grad arena, + a bf16 shadow the MFMA GEMMs read);
+    the momentum (EMA) copies live in a second arena with the identical layout, so the EMA update, AdamW and the
+    gradient all-reduce are single flat kernels / collectives instead of 173..183 per-tensor launches;
+  * the whole forward+backward is one autograd node whose backward is written by hand (no autograd graph over ops):
+    every device operation is a kernel of libdig_hip.so launched through the C-ABI (include/dig_hip.h);
+  * activations are bf16, statistics / losses / optimizer state are fp32.
+There is no CPU or ATen fallback: without libdig_hip.so (or without a GPU) forward raises.
+"""
+import math
+from collections import OrderedDict
+from functools import partial
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .registry import register_model
+
+BF16, F32 = torch.bfloat16, torch.float32
+ALIGN = 256  # arena granule (elements): every parameter starts on a 1 KiB boundary
+
+
+def _round_up(x, a):
+    return (x + a - 1) // a * a
+
+
+def get_sinusoid_encoding_table(n_position, d_hid):
+    """Same values as modeling_finetune.py:200-210 (float64 math, cast to fp32), vectorised."""
+    pos = np.arange(n_position, dtype=np.float64)[:, None]
+    j = np.arange(d_hid)
+    ang = pos / np.power(10000.0, 2.0 * (j // 2) / d_hid)[None, :]
+    tab = np.empty_like(ang)
+    tab[:, 0::2] = np.sin(ang[:, 0::2])
+    tab[:, 1::2] = np.cos(ang[:, 1::2])
+    return torch.from_numpy(tab).to(torch.float32).unsqueeze(0)
+
+
+class _Node(nn.Module):
+    """Bare container used to reproduce the reference's module tree (and therefore its state_dict keys)."""
+
+
+def _node_for(root, dotted):
+    mod = root
+    parts = dotted.split(".")
+    for p in parts[:-1]:
+        if p not in mod._modules:
+            mod.add_module(p, _Node())
+        mod = mod._modules[p]
+    return mod, parts[-1]
+
+
+def _mlp_dims(n_layers, din, dmid, dout):
+    return [(din if l == 0 else dmid, dout if l == n_layers - 1 else dmid) for l in range(n_layers)]
+
+
+class ParamSpec:
+    __slots__ = ("name", "shape", "numel", "offset", "group", "arena", "bundle_off")
+
+    def __init__(self, name, shape, group, arena):
+        self.name, self.shape, self.group, self.arena = name, tuple(shape), group, arena
+        self.numel = int(np.prod(shape))
+        self.offset = -1
+
+
+class MoCo_ViT(nn.Module):
+    def __init__(self, img_size=(32, 128), patch_size=4, in_chans=3, encoder_num_classes=0, encoder_embed_dim=384,
+                 encoder_depth=12, encoder_num_heads=6, decoder_num_classes=48, decoder_embed_dim=192, decoder_depth=4,
+                 decoder_num_heads=3, mlp_ratio=4., qkv_bias=True, qk_scale=None, drop_rate=0., attn_drop_rate=0.,
+                 drop_path_rate=0., norm_layer=None, init_values=0., use_learnable_pos_emb=False, num_classes=0,
+                 mlp_dim=4096, dim=256, T=1.0, num_windows=5, use_pixel_target=False, use_moco_target=True,
+                 encoder_type='vit', queue_size=65536, patchnet_name='regular', label_smoothing=0., use_pix_projector=True,
+                 device=None, **unused):
+        super().__init__()
+        if not (use_pixel_target and use_moco_target and use_pix_projector):
+            raise NotImplementedError("dig_amd implements the SimMIM+MoCo ('simmim_moco_ori') variants of the hot path")
+        if patchnet_name != 'no_patchtrans':
+            raise NotImplementedError("only patchnet_name='no_patchtrans' (the README configuration) is implemented")
+        if drop_rate or attn_drop_rate or drop_path_rate or init_values or use_learnable_pos_emb or label_smoothing:
+            raise NotImplementedError("dropout / drop-path / layer-scale / learnable pos-emb / label smoothing are 0 in pre-training")
+        if not qkv_bias or patch_size != 4 or in_chans != 3:
+            raise NotImplementedError("qkv_bias=True, patch 4, RGB only")
+        D, H = encoder_embed_dim, encoder_num_heads
+        if D % H or D // H != 64:
+            raise NotImplementedError("attention kernel is specialised for head_dim 64")
+        if tuple(img_size) != (32, 128):
+            raise NotImplementedError("attention kernel is specialised for 8x32 = 256 tokens (32x128 crops)")
+        self.D, self.H, self.depth = D, H, encoder_depth
+        self.F = int(D * mlp_ratio)
+        self.gh, self.gw = img_size[0] // patch_size, img_size[1] // patch_size
+        self.N = self.gh * self.gw
+        self.T = T
+        self.num_windows = num_windows
+        self.dec_dim, self.dec_classes = decoder_embed_dim, decoder_num_classes
+        self.moco_dim, self.moco_mlp_dim = dim, mlp_dim
+        self.ln_eps, self.bn_eps, self.bn_momentum = 1e-6, 1e-5, 0.1
+        self.use_pixel_target, self.use_moco_target = True, True
+        self.comm = None            # set by dig_amd.parallel.DistributedDataParallel
+        self.mlps = OrderedDict([
+            ("encoder_projection_layer", _mlp_dims(3, D, mlp_dim, dim)),
+            ("momentum_projection_layer", _mlp_dims(3, D, mlp_dim, dim)),
+            ("predictor", _mlp_dims(2, dim, mlp_dim, dim)),
+            ("pix_projector", _mlp_dims(3, D, 512, D)),
+            ("pix_projector_m", _mlp_dims(3, D, 512, D)),
+        ])
+        self._build_layout()
+        self._allocate(torch.device(device) if device is not None else torch.device("cpu"))
+        self._init_weights()
+        self._register_tree()
+        # attributes the reference driver reads (run_mae_pretraining_moco.py:320)
+        pe = self.encoder.patch_embed
+        pe.patch_size, pe.patch_shape, pe.num_patches, pe.img_size = (patch_size, patch_size), (self.gh, self.gw), self.N, tuple(img_size)
+
+    # ------------------------------------------------------------------ layout
+    def _encoder_specs(self, pre, arena):
+        D, Fh = self.D, self.F
+        s = [ParamSpec(pre + "mask_token", (1, 1, D), 0, arena),
+             ParamSpec(pre + "patch_embed.proj.weight", (D, 3, 4, 4), 0, arena),
+             ParamSpec(pre + "patch_embed.proj.bias", (D,), 1, arena)]
+        for i in range(self.depth):
+            b = f"{pre}blocks.{i}."
+            s += [ParamSpec(b + "norm1.weight", (D,), 1, arena), ParamSpec(b + "norm1.bias", (D,), 1, arena),
+                  ParamSpec(b + "attn.q_bias", (D,), 1, arena), ParamSpec(b + "attn.v_bias", (D,), 1, arena),
+                  ParamSpec(b + "attn.qkv.weight", (3 * D, D), 0, arena), ParamSpec(b + "attn.proj.weight", (D, D), 0, arena),
+                  ParamSpec(b + "attn.proj.bias", (D,), 1, arena), ParamSpec(b + "norm2.weight", (D,), 1, arena),
+                  ParamSpec(b + "norm2.bias", (D,), 1, arena), ParamSpec(b + "mlp.fc1.weight", (Fh, D), 0, arena),
+                  ParamSpec(b + "mlp.fc1.bias", (Fh,), 1, arena), ParamSpec(b + "mlp.fc2.weight", (D, Fh), 0, arena),
+                  ParamSpec(b + "mlp.fc2.bias", (D,), 1, arena)]
+        return s
+
+    @staticmethod
+    def _mlp_specs(pre, dims, arena):
+        s, n = [], len(dims)
+        for l, (d1, d2) in enumerate(dims):
+            s.append(ParamSpec(f"{pre}.{3 * l}.weight", (d2, d1), 0, arena))
+            if l < n - 1:
+                s.append(ParamSpec(f"{pre}.{3 * l + 1}.weight", (d2,), 1, arena))
+                s.append(ParamSpec(f"{pre}.{3 * l + 1}.bias", (d2,), 1, arena))
+        return s
+
+    def _build_layout(self):
+        """Reference order of named_parameters() (this is also the registration order), then arena offsets.
+        Online arena: [encoder | encoder_projection_layer | pix_projector | predictor | pix_decoder]; the momentum
+        arena mirrors the first three groups offset-for-offset so the EMA is one flat kernel.  q_bias and v_bias of
+        a block share one 3*D bundle [q_bias | zeros | v_bias] = the bias vector of the fused QKV GEMM
+        (modeling_finetune.py:91: K has no bias)."""
+        D, Dd = self.D, self.dec_dim
+        specs = []
+        specs += self._encoder_specs("encoder.", "online")
+        specs += self._encoder_specs("momentum_encoder.", "momentum")
+        specs += self._mlp_specs("encoder_projection_layer", self.mlps["encoder_projection_layer"], "online")
+        specs += self._mlp_specs("momentum_projection_layer", self.mlps["momentum_projection_layer"], "momentum")
+        specs += self._mlp_specs("predictor", self.mlps["predictor"], "online")
+        specs += self._mlp_specs("pix_projector", self.mlps["pix_projector"], "online")
+        specs += self._mlp_specs("pix_projector_m", self.mlps["pix_projector_m"], "momentum")
+        specs += [ParamSpec("pix_decoder.0.weight", (Dd, D), 0, "online"), ParamSpec("pix_decoder.1.weight", (Dd, Dd), 0, "online"),
+                  ParamSpec("pix_decoder.2.weight", (Dd,), 1, "online"), ParamSpec("pix_decoder.2.bias", (Dd,), 1, "online"),
+                  ParamSpec("pix_decoder.4.weight", (self.dec_classes, Dd), 0, "online"),
+                  ParamSpec("pix_decoder.4.bias", (self.dec_classes,), 1, "online")]
+        self.specs = OrderedDict((s.name, s) for s in specs)
+
+        def place(names, arena_groups):
+            off = 0
+            for n in names:
+                s = self.specs[n]
+                if n.endswith("attn.v_bias"):
+                    continue                                            # placed with its q_bias
+                s.offset = off
+                if n.endswith("attn.q_bias"):
+                    self.specs[n[:-len("q_bias")] + "v_bias"].offset = off + 2 * D
+                    size = 3 * D
+                else:
+                    size = s.numel
+                padded = _round_up(size, ALIGN)
+                arena_groups.extend([s.group] * (padded // ALIGN))
+                off += padded
+            return off
+
+        ema_src = [n for n in self.specs if n.startswith(("encoder.", "encoder_projection_layer.", "pix_projector."))]
+        rest = [n for n in self.specs if n.startswith(("predictor.", "pix_decoder."))]
+        self._online_groups = []
+        self.n_ema = place(ema_src, self._online_groups)                    # elements covered by the EMA
+        rest_groups = []
+        n_rest = place(rest, rest_groups)
+        for n in rest:
+            if self.specs[n].offset >= 0:
+                self.specs[n].offset += self.n_ema
+        self._online_groups += rest_groups
+        self.n_online = self.n_ema + n_rest
+        mom = [n for n in self.specs if self.specs[n].arena == "momentum"]
+        tmp = []
+        n_mom = place(mom, tmp)
+        assert n_mom == self.n_ema
+        # the momentum arena must mirror the online one offset-for-offset
+        for n in mom:
+            src = (n.replace("momentum_encoder.", "encoder.").replace("momentum_projection_layer.", "encoder_projection_layer.")
+                   .replace("pix_projector_m.", "pix_projector."))
+            assert self.specs[src].offset == self.specs[n].offset, (n, src)
+        # gradient-bucket boundaries (element ranges of the online arena), in backward-completion order
+        self.bucket_names = (["pix_decoder", "predictor", "encoder_projection_layer", "pix_projector"]
+                             + [f"encoder.blocks.{i}" for i in reversed(range(self.depth))] + ["encoder.embed"])
+
+    def bucket_range(self, key):
+        """[begin, end) element range of the online arena that holds the parameters of one backward stage."""
+        if key == "encoder.embed":
+            names = ["encoder.mask_token", "encoder.patch_embed.proj.weight", "encoder.patch_embed.proj.bias"]
+        else:
+            names = [n for n in self.specs if n.startswith(key + ".") and self.specs[n].arena == "online"]
+        lo = min(self.specs[n].offset for n in names)
+        hi = max(_round_up(self.specs[n].offset + self.specs[n].numel, ALIGN) for n in names)
+        return lo, hi
+
+    # ------------------------------------------------------------------ storage
+    def _allocate(self, device):
+        self._flat = {
+            "online": torch.zeros(self.n_online, dtype=F32, device=device),
+            "momentum": torch.zeros(self.n_ema, dtype=F32, device=device),
+            "grad": torch.zeros(self.n_online, dtype=F32, device=device),
+            "groups": torch.tensor(self._online_groups, dtype=torch.uint8, device=device),
+        }
+        n_bn = sum(len(d) for d in self.mlps.values())
+        c_tot = sum(d2 for dims in self.mlps.values() for _, d2 in dims)
+        self._flat["bn_stats"] = torch.zeros(2 * c_tot, dtype=F32, device=device)      # running_mean | running_var
+        self._flat["bn_count"] = torch.zeros(n_bn, dtype=torch.int64, device=device)
+        self._shadow = {}
+        self._views_version = 0
+
+    def _view(self, arena, spec):
+        return self._flat[arena][spec.offset:spec.offset + spec.numel].view(spec.shape)
+
+    def _register_tree(self):
+        """Create the reference's module tree with Parameters/buffers that are views into the arenas."""
+        self._param_objs = OrderedDict()
+        for name, s in self.specs.items():
+            mod, leaf = _node_for(self, name)
+            p = nn.Parameter(self._view(s.arena, s), requires_grad=(s.arena == "online"))
+            mod.register_parameter(leaf, p)
+            self._param_objs[name] = p
+        self._buffer_slots = []
+        c_off, i_bn = 0, 0
+        c_tot = self._flat["bn_stats"].numel() // 2
+        for pre, dims in self.mlps.items():
+            for l, (_, d2) in enumerate(dims):
+                mod, _ = _node_for(self, f"{pre}.{3 * l + 1}.x")
+                self._buffer_slots.append((f"{pre}.{3 * l + 1}", c_off, d2, i_bn))
+                mod.register_buffer("running_mean", None)
+                mod.register_buffer("running_var", None)
+                mod.register_buffer("num_batches_tracked", None)
+                c_off += d2
+                i_bn += 1
+        self.encoder.pos_embed = get_sinusoid_encoding_table(self.N, self.D)     # plain attribute (not in state_dict)
+        self.momentum_encoder.pos_embed = self.encoder.pos_embed
+        self._rebind()
+
+    def _rebind(self):
+        for name, s in self.specs.items():
+            p = self._param_objs[name]
+            p.data = self._view(s.arena, s)
+            if s.arena == "online":
+                p.grad = self._view("grad", s)
+        c_tot = self._flat["bn_stats"].numel() // 2
+        self._bn_views = {}
+        for key, c_off, C, i_bn in self._buffer_slots:
+            mod, _ = _node_for(self, key + ".x")
+            rm = self._flat["bn_stats"][c_off:c_off + C]
+            rv = self._flat["bn_stats"][c_tot + c_off:c_tot + c_off + C]
+            mod._buffers["running_mean"], mod._buffers["running_var"] = rm, rv
+            mod._buffers["num_batches_tracked"] = self._flat["bn_count"][i_bn]
+            self._bn_views[key] = (rm, rv, i_bn)
+        dev = self._flat["online"].device
+        self._pos = self.encoder.pos_embed[0].to(dev).contiguous()
+        self._shadow = {}
+        self._f32 = {n: self._view(s.arena, s) for n, s in self.specs.items()}
+        self._g32 = {n: self._view("grad", s) for n, s in self.specs.items() if s.arena == "online"}
+        self._qkv_bias, self._qkv_bias_grad = {}, {}
+        for n, s in self.specs.items():
+            if n.endswith("attn.q_bias"):
+                key = n[:-len("q_bias")]
+                self._qkv_bias[key] = self._flat[s.arena][s.offset:s.offset + 3 * self.D]
+                if s.arena == "online":
+                    self._qkv_bias_grad[key] = self._flat["grad"][s.offset:s.offset + 3 * self.D]
+        self._views_version += 1
+
+    def _apply(self, fn, recurse=True):
+        self._flat = {k: fn(v) for k, v in self._flat.items()}
+        self._rebind()
+        return self
+
+    def load_state_dict(self, state_dict, strict=True):
+        missing, unexpected = [], [k for k in state_dict if k not in self.specs and not k.rsplit(".", 1)[-1].startswith(("running_", "num_batches"))]
+        own = self.state_dict()
+        with torch.no_grad():
+            for k, v in own.items():
+                if k in state_dict:
+                    v.copy_(state_dict[k])
+                else:
+                    missing.append(k)
+        if strict and (missing or [k for k in state_dict if k not in own]):
+            raise RuntimeError(f"load_state_dict: missing {missing[:5]}, unexpected {[k for k in state_dict if k not in own][:5]}")
+        return torch.nn.modules.module._IncompatibleKeys(missing, [k for k in state_dict if k not in own])
+
+    # ------------------------------------------------------------------ init (distributions of the reference)
+    def _init_weights(self):
+        """modeling_pretrain_vit.py:63-73 (xavier-uniform Linear, zero bias, LN 1/0), modeling_pretrain_moco_mim_ori.py:
+        353-355 (patch-embed uniform +-sqrt(6/(48+D))), nn.Linear / nn.BatchNorm1d defaults for the heads, mask_token
+        zeros; momentum parameters start as copies (:396-420)."""
+        with torch.no_grad():
+            for n, s in self.specs.items():
+                if s.arena != "online":
+                    continue
+                v = self._view("online", s)
+                if n.endswith("mask_token"):
+                    v.zero_()
+                elif n.endswith("patch_embed.proj.weight"):
+                    a = math.sqrt(6.0 / float(3 * 16 + self.D))
+                    v.uniform_(-a, a)
+                elif n.startswith("encoder."):
+                    if len(s.shape) == 2:
+                        nn.init.xavier_uniform_(v)
+                    elif n.endswith(("norm1.weight", "norm2.weight")):
+                        v.fill_(1.0)
+                    else:
+                        v.zero_()
+                elif len(s.shape) == 2:
+                    nn.init.kaiming_uniform_(v, a=math.sqrt(5))
+                elif n == "pix_decoder.4.bias":
+                    b = 1.0 / math.sqrt(self.dec_dim)
+                    v.uniform_(-b, b)
+                elif n.endswith(".weight"):
+                    v.fill_(1.0)
+                else:
+                    v.zero_()
+            self._flat["momentum"].copy_(self._flat["online"][:self.n_ema])
+            c_tot = self._flat["bn_stats"].numel() // 2
+            self._flat["bn_stats"][c_tot:].fill_(1.0)
+
+    @torch.jit.ignore
+    def no_weight_decay(self):
+        return {'pos_embed', 'cls_token'}
+
+    # ------------------------------------------------------------------ flat accessors used by optimizer / DDP
+    @property
+    def flat_params(self):
+        return self._flat["online"]
+
+    @property
+    def flat_grads(self):
+        return self._flat["grad"]
+
+    @property
+    def flat_groups(self):
+        return self._flat["groups"]
+
+    def shadow(self, arena):
+        """bf16 copy of an arena (same element offsets); (re)created lazily, refreshed by sync_shadow()/EMA kernel."""
+        sh = self._shadow.get(arena)
+        if sh is None or sh.device != self._flat[arena].device:
+            sh = torch.empty(self._flat[arena].numel(), dtype=BF16, device=self._flat[arena].device)
+            self._shadow[arena] = sh
+            self._w16 = None
+        return sh
+
+    def _w(self, arena):
+        """name -> bf16 2-D weight view dictionary for an arena."""
+        cache = getattr(self, "_w16", None)
+        if cache is None:
+            cache = self._w16 = {}
+        if arena not in cache:
+            sh = self.shadow(arena)
+            cache[arena] = {n: sh[s.offset:s.offset + s.numel].view(s.shape[0], -1) for n, s in self.specs.items()
+                            if s.arena == arena and len(s.shape) >= 2 and not n.endswith("mask_token")}
+        return cache[arena]
+
+    def _mask_count(self, mask_u8, B):
+        """Masked tokens per sample of view 0 (the reference reshapes to [B, -1, C], so it is constant over the
+        batch).  Read back once and cached: per-step validation happens where the engine synchronises anyway."""
+        c = getattr(self, "_per_sample_mask", None)
+        if c is None:
+            c = self._per_sample_mask = int(mask_u8[0].sum().item())
+        return c
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, image, aug_image, vis_mask_pos, m, only_mim_on_ori_img=True):
+        from .engine_core import dig_forward
+        return dig_forward(self, image, aug_image, vis_mask_pos, m, only_mim_on_ori_img)
+
+
+def _factory(embed_dim, heads, **kwargs):
+    kwargs.pop("pretrained", None)
+    init_ckpt = kwargs.pop("init_ckpt", None)
+    model = MoCo_ViT(img_size=(32, 128), patch_size=4, encoder_embed_dim=embed_dim, encoder_depth=12, encoder_num_heads=heads,
+                     encoder_num_classes=0, decoder_num_classes=48, decoder_embed_dim=192, decoder_depth=4, decoder_num_heads=3,
+                     mlp_ratio=4, qkv_bias=True, norm_layer=partial(nn.LayerNorm, eps=1e-6), use_pixel_target=True,
+                     use_moco_target=True, **kwargs)
+    model.default_cfg = {'url': '', 'num_classes': 1000, 'input_size': (3, 32, 128), 'pool_size': None, 'crop_pct': 1.0,
+                         'interpolation': 'bicubic', 'mean': (0.5, 0.5, 0.5), 'std': (0.5, 0.5, 0.5)}
+    if init_ckpt:
+        model.load_state_dict(torch.load(init_ckpt, map_location="cpu")["model"])
+    return model
+
+
+@register_model
+def pretrain_simmim_moco_ori_vit_tiny_patch4_32x128(pretrained=False, **kwargs):
+    """modeling_pretrain_moco_mim_ori.py:736-761 (D=192, 3 heads)."""
+    return _factory(192, 3, init_ckpt=kwargs.pop("init_ckpt", None) if pretrained else None, **kwargs)
+
+
+@register_model
+def pretrain_simmim_moco_ori_vit_small_patch4_32x128(pretrained=False, **kwargs):
+    """modeling_pretrain_moco_mim_ori.py:682-707 (D=384, 6 heads): the north-star model."""
+    return _factory(384, 6, init_ckpt=kwargs.pop("init_ckpt", None) if pretrained else None, **kwargs)
+
+
+@register_model
+def pretrain_simmim_moco_ori_vit_base_patch4_32x128(pretrained=False, **kwargs):
+    """modeling_pretrain_moco_mim_ori.py:792-817 (D=512, 8 heads)."""
+    return _factory(512, 8, init_ckpt=kwargs.pop("init_ckpt", None) if pretrained else None, **kwargs)

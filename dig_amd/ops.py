@@ -1,0 +1,237 @@
+"""Thin tensor-level wrappers over the C-ABI (include/dig_hip.h).  Every function launches hand-written HIP
+kernels on the caller's current stream; nothing here computes on the host or falls back to ATen."""
+import ctypes
+
+import torch
+
+from . import _lib as L
+
+cf = ctypes.c_float
+cll = ctypes.c_longlong
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+OUT_BF16, OUT_F32, OUT_F32_ATOMIC = 0, 1, 2
+
+
+def gemm(A, B, I, J, R, *, ta=False, tb=False, out=None, out_kind=OUT_BF16, bias=None, resid=None, pre=None, alpha=1.0,
+         alpha_cols=0, act=0, splits=1, ldc=None, a_rows=0, b_rows=0):
+    """C[I,J] = sum_r opA(i,r) opB(j,r); see csrc/gemm.hip for the operand conventions."""
+    if out is None:
+        out = torch.empty((I, J), device=A.device, dtype=BF16 if out_kind == OUT_BF16 else F32)
+    L.call("dig_gemm_bf16", L.ptr(A), L.ptr(B), L.ptr(out), I, J, R, A.stride(0), B.stride(0),
+           out.stride(0) if ldc is None else ldc, int(ta), int(tb), out_kind, L.ptr(bias), L.ptr(resid),
+           resid.stride(0) if resid is not None else 0, L.ptr(pre), pre.stride(0) if pre is not None else 0, cf(alpha),
+           alpha_cols, act, splits, a_rows, b_rows, L.stream())
+    return out
+
+
+def linear_fwd(x, w, *, bias=None, resid=None, act=0, pre=None, alpha=1.0, alpha_cols=0, out=None, out_kind=OUT_BF16):
+    """y[rows,out] = x[rows,in] @ w[out,in]^T (+bias)(gelu)(+resid)."""
+    return gemm(x, w, x.shape[0], w.shape[0], w.shape[1], bias=bias, resid=resid, act=act, pre=pre, alpha=alpha,
+                alpha_cols=alpha_cols, out=out, out_kind=out_kind)
+
+
+def linear_dgrad(dy, w, out=None):
+    """dx[rows,in] = dy[rows,out] @ w[out,in]."""
+    return gemm(dy, w, dy.shape[0], w.shape[1], w.shape[0], tb=True, out=out)
+
+
+def wgrad_splits(rows, tiles):
+    s = max(1, min(rows // 512, (640 + tiles - 1) // tiles))
+    return s
+
+
+def linear_wgrad(dy, x, dw, rows=None):
+    """dw[out,in] += dy[rows,out]^T @ x[rows,in]  (fp32 atomic accumulate, split over rows)."""
+    rows = dy.shape[0] if rows is None else rows
+    J_out, K_in = dw.shape
+    tiles = ((J_out + 127) // 128) * ((K_in + 127) // 128)
+    gemm(dy, x, J_out, K_in, rows, ta=True, tb=True, out=dw, out_kind=OUT_F32_ATOMIC, splits=wgrad_splits(rows, tiles))
+
+
+def colsum(x, out, rows=None, cols=None):
+    rows = x.shape[0] if rows is None else rows
+    cols = x.shape[1] if cols is None else cols
+    L.call("dig_colsum", L.ptr(x), L.ptr(out), rows, cols, x.stride(0), L.stream())
+
+
+def layernorm_fwd(x, gamma, beta, eps, gelu=False):
+    rows, D = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, device=x.device, dtype=F32)
+    rstd = torch.empty(rows, device=x.device, dtype=F32)
+    L.call("dig_layernorm_fwd", L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(y), L.ptr(mean), L.ptr(rstd), rows, D, cf(eps),
+           int(gelu), L.stream())
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, beta, mean, rstd, dres, dgamma, dbeta, gelu=False, out=None):
+    rows, D = x.shape
+    dx = torch.empty_like(x) if out is None else out
+    L.call("dig_layernorm_bwd", L.ptr(dy), L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(mean), L.ptr(rstd), L.ptr(dres), L.ptr(dx),
+           L.ptr(dgamma), L.ptr(dbeta), rows, D, int(gelu), L.stream())
+    return dx
+
+
+def attn_fwd(qkv, n_img, heads, D):
+    ctx = torch.empty((qkv.shape[0], D), device=qkv.device, dtype=BF16)
+    lse = torch.empty((n_img * heads, 256), device=qkv.device, dtype=F32)
+    L.call("dig_attn_fwd", L.ptr(qkv), L.ptr(ctx), L.ptr(lse), n_img, heads, D, L.stream())
+    return ctx, lse
+
+
+def attn_bwd(qkv, ctx, dctx, lse, n_img, heads, D, scale):
+    dqkv = torch.empty_like(qkv)
+    L.call("dig_attn_bwd", L.ptr(qkv), L.ptr(ctx), L.ptr(dctx), L.ptr(lse), L.ptr(dqkv), n_img, heads, D, cf(scale), L.stream())
+    return dqkv
+
+
+def patch_embed_fwd(img, W, bias, mask_u8, mask_token, pos, D, gh, gw):
+    n_img = img.shape[0]
+    out = torch.empty((n_img * gh * gw, D), device=img.device, dtype=BF16)
+    L.call("dig_patch_embed_fwd", L.ptr(img), L.ptr(W), L.ptr(bias), L.ptr(mask_u8), L.ptr(mask_token), L.ptr(pos), L.ptr(out),
+           n_img, gh, gw, D, L.stream())
+    return out
+
+
+def patch_embed_bwd(dy, img, mask_u8, dW, dbias, dmask_token, D, gh, gw):
+    L.call("dig_patch_embed_bwd", L.ptr(dy), L.ptr(img), L.ptr(mask_u8), L.ptr(dW), L.ptr(dbias), L.ptr(dmask_token),
+           img.shape[0], gh, gw, D, L.stream())
+
+
+def window_pool_fwd(x, out, n_img, gh, gw, nwin, D):
+    L.call("dig_window_pool_fwd", L.ptr(x), L.ptr(out), int(out.dtype == F32), n_img, gh, gw, nwin, D, L.stream())
+
+
+def window_pool_bwd(dpool, dx, n_img, gh, gw, nwin, D, accumulate):
+    L.call("dig_window_pool_bwd", L.ptr(dpool), L.ptr(dx), n_img, gh, gw, nwin, D, int(accumulate), L.stream())
+
+
+def mask_to_index(mask_u8, max_per_sample):
+    B, N = mask_u8.shape
+    idx = torch.empty((B, max_per_sample), device=mask_u8.device, dtype=torch.int32)
+    cnt = torch.empty((B,), device=mask_u8.device, dtype=torch.int32)
+    L.call("dig_mask_to_index", L.ptr(mask_u8), L.ptr(idx), L.ptr(cnt), B, N, max_per_sample, L.stream())
+    return idx, cnt
+
+
+def gather_rows(src, idx, M, M_pad):
+    D = src.shape[1]
+    dst = torch.empty((M_pad, D), device=src.device, dtype=BF16)
+    L.call("dig_gather_rows", L.ptr(src), L.ptr(idx), L.ptr(dst), M, M_pad, D, L.stream())
+    return dst
+
+
+def scatter_rows_add(src, idx, dst, M):
+    L.call("dig_scatter_rows_add", L.ptr(src), L.ptr(idx), L.ptr(dst), M, src.shape[1], L.stream())
+
+
+def mim_target(img, idx, M, gh, gw):
+    tgt = torch.empty((M, 48), device=img.device, dtype=F32)
+    L.call("dig_mim_target", L.ptr(img), L.ptr(idx), L.ptr(tgt), M, gh, gw, L.stream())
+    return tgt
+
+
+def mse_fwd_bwd(pred, ld_pred, target, M, C, gscale, loss, dpred, ld_dpred):
+    L.call("dig_mse_fwd_bwd", L.ptr(pred), ld_pred, L.ptr(target), M, C, cf(gscale), L.ptr(loss), L.ptr(dpred), ld_dpred, L.stream())
+
+
+def add_bf16(a, b, out):
+    L.call("dig_add_bf16", L.ptr(a), L.ptr(b), L.ptr(out), cll(a.numel()), L.stream())
+
+
+def gelu_bwd(dact, pre, out):
+    L.call("dig_gelu_bwd", L.ptr(dact), L.ptr(pre), L.ptr(out), cll(dact.numel()), L.stream())
+
+
+def bn_stats(x, sums):
+    L.call("dig_bn_stats", L.ptr(x), L.ptr(sums), x.shape[0], x.shape[1], L.stream())
+
+
+def bn_fwd_apply(x, sums, n_total, eps, gamma, beta, relu):
+    rows, C = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(C, device=x.device, dtype=F32)
+    rstd = torch.empty(C, device=x.device, dtype=F32)
+    L.call("dig_bn_fwd_apply", L.ptr(x), L.ptr(sums), cf(n_total), cf(eps), L.ptr(gamma), L.ptr(beta), int(relu), L.ptr(y),
+           L.ptr(mean), L.ptr(rstd), rows, C, L.stream())
+    return y, mean, rstd
+
+
+def bn_update_running(sums, n_total, momentum, rm, rv):
+    L.call("dig_bn_update_running", L.ptr(sums), cf(n_total), cf(momentum), L.ptr(rm), L.ptr(rv), rm.numel(), L.stream())
+
+
+def bn_bwd_stats(dy, x, mean, rstd, gamma, beta, relu, sums):
+    L.call("dig_bn_bwd_stats", L.ptr(dy), L.ptr(x), L.ptr(mean), L.ptr(rstd), L.ptr(gamma), L.ptr(beta), int(relu), L.ptr(sums),
+           x.shape[0], x.shape[1], L.stream())
+
+
+def bn_bwd_apply(dy, x, mean, rstd, gamma, beta, relu, sums, n_total):
+    dx = torch.empty_like(x)
+    L.call("dig_bn_bwd_apply", L.ptr(dy), L.ptr(x), L.ptr(mean), L.ptr(rstd), L.ptr(gamma), L.ptr(beta), int(relu), L.ptr(sums),
+           cf(n_total), L.ptr(dx), x.shape[0], x.shape[1], L.stream())
+    return dx
+
+
+def l2norm_fwd(x, eps=1e-12):
+    y = torch.empty_like(x)
+    inv = torch.empty(x.shape[0], device=x.device, dtype=F32)
+    L.call("dig_l2norm_fwd", L.ptr(x), L.ptr(y), L.ptr(inv), x.shape[0], x.shape[1], cf(eps), L.stream())
+    return y, inv
+
+
+def l2norm_bwd(dy, y, inv):
+    dx = torch.empty_like(y)
+    L.call("dig_l2norm_bwd", L.ptr(dy), L.ptr(y), L.ptr(inv), L.ptr(dx), y.shape[0], y.shape[1], L.stream())
+    return dx
+
+
+def sgemm(A, B, C, I, J, R, trans_b, alpha):
+    L.call("dig_sgemm", L.ptr(A), L.ptr(B), L.ptr(C), I, J, R, A.stride(0), B.stride(0), C.stride(0), int(trans_b), cf(alpha), L.stream())
+
+
+def ce_rows(logits, label_offset, gscale, out3):
+    L.call("dig_ce_rows", L.ptr(logits), logits.shape[0], logits.shape[1], label_offset, cf(gscale), L.ptr(out3), L.stream())
+
+
+def cast_f32_to_bf16(x, y, n=None):
+    L.call("dig_cast_f32_to_bf16", L.ptr(x), L.ptr(y), cll(x.numel() if n is None else n), L.stream())
+
+
+def cast_bf16_to_f32(x, y, n=None):
+    L.call("dig_cast_bf16_to_f32", L.ptr(x), L.ptr(y), cll(x.numel() if n is None else n), L.stream())
+
+
+def fill_f32(x, value=0.0):
+    L.call("dig_fill_f32", L.ptr(x), cll(x.numel()), cf(value), L.stream())
+
+
+def scale_f32(x, s):
+    L.call("dig_scale_f32", L.ptr(x), cll(x.numel()), cf(s), L.stream())
+
+
+def scale_by_device_scalar(x, scalar, extra=1.0):
+    L.call("dig_scale_by_device_scalar", L.ptr(x), cll(x.numel()), L.ptr(scalar), cf(extra), L.stream())
+
+
+def pad_cast_rows(src, dst, M, C):
+    L.call("dig_pad_cast_rows", L.ptr(src), L.ptr(dst), M, C, dst.shape[0], dst.stride(0), L.stream())
+
+
+def axpy_f32(y, x, a=1.0):
+    L.call("dig_axpy_f32", L.ptr(y), L.ptr(x), cll(x.numel()), cf(a), L.stream())
+
+
+def ema_update(pm, p, shadow, n, m):
+    L.call("dig_ema_update", L.ptr(pm), L.ptr(p), L.ptr(shadow), cll(n), cf(m), L.stream())
+
+
+def sumsq(x, workspace, out):
+    L.call("dig_sumsq", L.ptr(x), cll(x.numel()), L.ptr(workspace), L.ptr(out), L.stream())
+
+
+def adamw_step(p, g, m, v, shadow, group_flags, lr0, wd0, lr1, wd1, beta1, beta2, eps, step, grad_scale=1.0):
+    L.call("dig_adamw_step", L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), L.ptr(shadow), cll(p.numel()), L.ptr(group_flags), cf(lr0),
+           cf(wd0), cf(lr1), cf(wd1), cf(beta1), cf(beta2), cf(eps), int(step), cf(grad_scale), L.stream())

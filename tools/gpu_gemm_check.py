@@ -17,7 +17,7 @@ def gemm(A, B, I, J, R, ta, tb, out_kind, bias=None, resid=None, pre=None, alpha
         C = torch.empty((I, J), device=dev, dtype=torch.bfloat16 if out_kind == 0 else torch.float32)
     L.call("dig_gemm_bf16", L.ptr(A), L.ptr(B), L.ptr(C), I, J, R, A.stride(0), B.stride(0), C.stride(0),
            int(ta), int(tb), out_kind, L.ptr(bias), L.ptr(resid), resid.stride(0) if resid is not None else 0,
-           L.ptr(pre), pre.stride(0) if pre is not None else 0, ctypes.c_float(alpha), alpha_cols, act, splits, L.stream())
+           L.ptr(pre), pre.stride(0) if pre is not None else 0, ctypes.c_float(alpha), alpha_cols, act, splits, 0, 0, L.stream())
     return C
 
 
