@@ -1,0 +1,202 @@
+"""Benchmark of the DiG pre-training step on MI355X (the driver's contract).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one full `train_one_epoch` iteration of `pretrain_simmim_moco_ori_vit_small_patch4_32x128` on a synthetic
+batch of 128 samples per GPU (each sample = original 32x128 crop + augmented view, 179/256 patches masked), README
+loss weights (MIM 1.0 + MoCo 0.1), forward + backward + gradient all-reduce + fused AdamW, inputs resident in HBM.
+Prints ONE JSON line (rank 0).  Extra objects: `roofline` for the dominant kernel (algorithmic FLOPs / measured
+launch time from HIP events on the launch stream) and `cpu_baseline` (the fp32 CPU oracle timed on this host).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_SAMPLE = {"small": 99.6e9, "base": 171e9, "tiny": None}      # SURVEY.md §8(d), MIM+MoCo
+PEAK_BF16 = 2.5e15
+
+
+def synth_batches(n, B, device, seed):
+    """U(-1,1) crops from Generator(seed), RandomMaskingGenerator((8,32), 0.7, num_view=2) masks."""
+    g = torch.Generator().manual_seed(seed)
+    rng = np.random.RandomState(seed)
+    out = []
+    for _ in range(n):
+        im = (torch.rand((B, 3, 32, 128), generator=g) * 2 - 1).to(device)
+        au = (torch.rand((B, 3, 32, 128), generator=g) * 2 - 1).to(device)
+        mk = np.zeros((B, 2, 256), dtype=np.float64)
+        for b in range(B):
+            for v in range(2):
+                row = np.hstack([np.zeros(256 - 179), np.ones(179)])
+                rng.shuffle(row)
+                mk[b, v] = row
+        out.append(([im, au, torch.from_numpy(mk).to(device)], torch.ones(1), torch.ones(1)))
+    return out
+
+
+class GemmProbe:
+    """Times every dig_gemm_bf16 launch of one step with HIP events on the launch stream (torch's current stream)."""
+
+    def __init__(self):
+        from dig_amd import ops
+        self.ops = ops
+        self.rec = []
+        self._orig = ops.gemm
+
+    def __enter__(self):
+        ops = self.ops
+
+        def timed(A, B, I, J, R, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = self._orig(A, B, I, J, R, **kw)
+            e1.record()
+            variant = ("wgrad" if kw.get("ta") else ("dgrad" if kw.get("tb") else "fwd"))
+            self.rec.append((variant, 2.0 * I * J * R, e0, e1))
+            return out
+        ops.gemm = timed
+        return self
+
+    def __exit__(self, *a):
+        self.ops.gemm = self._orig
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for variant, fl, e0, e1 in self.rec:
+            d = agg.setdefault(variant, [0.0, 0.0, 0])
+            d[0] += fl
+            d[1] += e0.elapsed_time(e1) * 1e-3
+            d[2] += 1
+        return {k: {"flops": v[0], "seconds": v[1], "launches": v[2]} for k, v in agg.items()}
+
+
+def cpu_baseline(model_name, budget_s=20.0):
+    """The fp32 CPU oracle (oracle/dig_oracle.py, pinned to the reference by tests/golden) on this host's cores."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import dig_oracle as O
+    cfg = O.make_config(model_name)
+    Bc = 8
+    tr = O.OracleTrainer(cfg, seed=0)
+    im, au, mk = O.synthetic_batch(Bc, cfg, 1234)
+    hp = O.StepHyper(lr=1.5e-4 * Bc / 256)
+    tr.step(im, au, mk, hp)                                     # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        tr.step(im, au, mk, hp)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > budget_s or n >= 8:
+            break
+    return {"value": n * Bc / dt, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} oracle steps (fp32 torch CPU restatement of the reference step) at batch {Bc}, same model/recipe"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=128, help="samples per GPU")
+    ap.add_argument("--model", default="small", choices=["tiny", "small", "base"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    a = ap.parse_args()
+
+    import dig_amd.utils as U
+    from dig_amd.registry import create_model
+    from dig_amd.optim_factory import create_optimizer
+    from dig_amd.engine_for_pretraining_moco import train_one_epoch
+    from dig_amd.parallel import DistributedDataParallel
+
+    stdout = sys.stdout
+    sys.stdout = sys.stderr                                # logs -> stderr; stdout carries the single JSON line
+    dargs = types.SimpleNamespace()
+    U.init_distributed_mode(dargs)
+    world, rank = U.get_world_size(), U.get_rank()
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    dev = torch.device("cuda", dargs.gpu)
+    torch.cuda.set_device(dev)
+    torch.manual_seed(0 + rank)
+    model_name = f"pretrain_simmim_moco_ori_vit_{a.model}_patch4_32x128"
+    model = create_model(model_name, pretrained=False, drop_path_rate=0.0, drop_block_rate=None, mlp_dim=4096, dim=256, T=0.2,
+                         num_windows=4, encoder_type='vit', queue_size=65536, patchnet_name='no_patchtrans')
+    model.to(dev)
+    run_model = DistributedDataParallel(model) if world > 1 else model
+    B = a.batch
+    args = types.SimpleNamespace(num_view=2, moco_m=0.99, use_moco_m_cos=1, epochs=10, contrast_start_epoch=0, contrast_warmup_steps=0,
+                                 loss_weight_contrast=0.1, loss_weight_pixel=1.0, only_mim_on_ori_img=True, eval_freq=500, opt='adamw',
+                                 lr=1.5e-4 * B * world / 256, weight_decay=0.1, opt_eps=1e-8, opt_betas=[0.9, 0.999])
+    opt = create_optimizer(args, model)
+    scaler = U.NativeScalerWithGradNormCount()
+    total = a.warmup + a.steps + 4
+    lr_s, wd_s = np.full(total + 8, args.lr), np.full(total + 8, 0.1)
+    batches = synth_batches(4, B, dev, 1234 + rank)
+
+    def run(n, start):
+        loader = [batches[i % len(batches)] for i in range(n)]
+        return train_one_epoch(run_model, None, None, loader, None, opt, dev, 0, scaler, None, patch_size=4, normlize_target=False,
+                               start_steps=start, lr_schedule_values=lr_s, wd_schedule_values=wd_s, args=args)
+
+    if rank != 0:
+        sys.stdout = open(os.devnull, "w")
+    if a.warmup > 0:
+        run(a.warmup, 0)
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    stats = run(a.steps, a.warmup)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    # ---- roofline of the dominant kernel: one extra, instrumented step (outside the timed region)
+    roof = None
+    if rank == 0:
+        with GemmProbe() as probe:
+            run(2, a.warmup + a.steps)
+        summ = probe.summary()
+        dom = max(summ, key=lambda k: summ[k]["seconds"])
+        d = summ[dom]
+        ach = d["flops"] / d["seconds"] / 1e12
+        roof = {"bound": "mfma", "kernel": f"gemm_kernel[{dom}] (dig_gemm_bf16, 128x128x64 v_mfma_f32_32x32x16_bf16)",
+                "achieved": ach, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": ach / (PEAK_BF16 / 1e12), "traffic": None,
+                "avg_launch_us": d["seconds"] / d["launches"] * 1e6, "launches_per_step": d["launches"] // 2,
+                "by_variant": {k: {"TFLOP/s": v["flops"] / v["seconds"] / 1e12, "ms_per_step": v["seconds"] / 2 * 1e3,
+                                   "launches_per_step": v["launches"] // 2} for k, v in summ.items()}}
+    sys.stdout = stdout
+    if rank != 0:
+        return
+    value = a.steps * B * world / dt
+    fl = FLOP_PER_SAMPLE[a.model]
+    line = {"metric": "pretrain images/sec (32x128, 2-view, mask 0.7) ViT-S/4", "value": value, "unit": "images/sec",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{model_name}: full train_one_epoch step (SimMIM w=1.0 + MoCo-v3 w=0.1, dim 256, mlp 4096, m 0.99 cos, "
+                                   f"T 0.2, 4 windows, mask 0.7, 2 views, AdamW wd 0.1), {B} samples/GPU, random-init weights",
+                       "global_batch": B * world, "parallelism": f"dp{world}", "loss": float(stats.get("loss", float('nan')))},
+            "step_mfma_frac": (value / world * fl / PEAK_BF16) if fl else None,
+            "roofline": roof}
+    if not a.no_cpu_baseline and world == 1:
+        line["cpu_baseline"] = cpu_baseline(model_name, a.cpu_budget)
+    print(json.dumps(line), flush=True)
+
+
+if __name__ == "__main__":
+    main()
