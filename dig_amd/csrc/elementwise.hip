@@ -252,25 +252,82 @@ __global__ void gelu_bwd_kernel(const bf16_t* __restrict__ dact, const bf16_t* _
   }
 }
 
-// out[c] += sum_r x[r, c]   (bias gradients); x bf16 [rows, C]
+// out[c] += sum_r x[r, c]   (bias gradients); x bf16 [rows, C], C % 8 == 0, 16-B loads: a wave covers 512 columns
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ x, float* __restrict__ out, int rows, int C, int ld,
                                                      int rows_per_block) {
-  __shared__ float red[2][4][64];
+  __shared__ float red[4][64][8 + 1];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int c = blockIdx.x * 128 + lane * 2;
+  const int c = blockIdx.x * 512 + lane * 8;
   const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
-  float a0 = 0.f, a1 = 0.f;
-  if (c < C)
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c < C) {
     for (int r = r0 + wv; r < r1; r += 4) {
-      const unsigned u = *reinterpret_cast<const unsigned*>(x + (size_t)r * ld + c);
-      a0 += bf2f((bf16_t)(u & 0xffff));
-      a1 += bf2f((bf16_t)(u >> 16));
+      const uint4 u = *reinterpret_cast<const uint4*>(x + (size_t)r * ld + c);
+      const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { a[2 * k] += bf2f((bf16_t)(w[k] & 0xffff)); a[2 * k + 1] += bf2f((bf16_t)(w[k] >> 16)); }
     }
-  red[0][wv][lane] = a0; red[1][wv][lane] = a1;
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) red[wv][lane][k] = a[k];
   __syncthreads();
-  if (wv == 0 && c < C) {
-    atomicAdd(out + c, red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane]);
-    if (c + 1 < C) atomicAdd(out + c + 1, red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane]);
+  for (int e = threadIdx.x; e < 512; e += 256) {
+    const int l = e >> 3, k = e & 7;
+    const int cc = blockIdx.x * 512 + e;
+    if (cc < C) atomicAdd(out + cc, red[0][l][k] + red[1][l][k] + red[2][l][k] + red[3][l][k]);
+  }
+}
+
+// P[t, k] (bf16, ld 64) = masked ? 0 : img patch element k (conv order c,p1,p2), k < 48; pad columns 48..63 = 0.
+// Lets the patch-embed weight gradient run as an MFMA wgrad GEMM (dW[D,48] = dy^T P) instead of a VALU loop.
+__global__ __launch_bounds__(256) void patchify_bf16_kernel(const float* __restrict__ img, const unsigned char* __restrict__ mask,
+                                                            bf16_t* __restrict__ out, int n_tok, int gh, int gw, int Himg, int Wimg) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;     // one thread per (token, 4-element group): 16 groups per token
+  if (e >= n_tok * 16) return;
+  const int t = e >> 4, grp = e & 15;
+  const int ntok = gh * gw;
+  const int b = t / ntok, n = t - b * ntok;
+  const int ph = n / gw, pw = n - ph * gw;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  if (grp < 12 && !(mask && mask[t])) {
+    const int c = grp >> 2, p1 = grp & 3;                  // k = c*16 + p1*4 + p2
+    const float4 px = *reinterpret_cast<const float4*>(img + (((size_t)b * 3 + c) * Himg + ph * 4 + p1) * Wimg + pw * 4);
+    v[0] = px.x; v[1] = px.y; v[2] = px.z; v[3] = px.w;
+  }
+  *reinterpret_cast<uint2*>(out + (size_t)t * 64 + grp * 4) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+}
+
+// out0[c] += sum over rows with mask==0 of x[r,c]; out1[c] += sum over rows with mask!=0   (patch-embed bias / mask_token grads)
+__global__ __launch_bounds__(256) void colsum_masked_kernel(const bf16_t* __restrict__ x, const unsigned char* __restrict__ mask,
+                                                            float* __restrict__ out0, float* __restrict__ out1, int rows, int C,
+                                                            int rows_per_block) {
+  __shared__ float red[2][4][64][8 + 1];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int c = blockIdx.x * 512 + lane * 8;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  float a[2][8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { a[0][k] = 0.f; a[1][k] = 0.f; }
+  if (c < C) {
+    for (int r = r0 + wv; r < r1; r += 4) {
+      const uint4 u = *reinterpret_cast<const uint4*>(x + (size_t)r * C + c);
+      const unsigned w[4] = {u.x, u.y, u.z, u.w};
+      const bool m = mask[r] != 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float lo = bf2f((bf16_t)(w[k] & 0xffff)), hi = bf2f((bf16_t)(w[k] >> 16));
+        a[0][2 * k] += m ? 0.f : lo; a[0][2 * k + 1] += m ? 0.f : hi;
+        a[1][2 * k] += m ? lo : 0.f; a[1][2 * k + 1] += m ? hi : 0.f;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { red[0][wv][lane][k] = a[0][k]; red[1][wv][lane][k] = a[1][k]; }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 1024; e += 256) {
+    const int which = e >> 9, l = (e & 511) >> 3, k = e & 7;
+    const int cc = blockIdx.x * 512 + (e & 511);
+    if (cc < C) atomicAdd((which ? out1 : out0) + cc, red[which][0][l][k] + red[which][1][l][k] + red[which][2][l][k] + red[which][3][l][k]);
   }
 }
 
@@ -374,10 +431,32 @@ extern "C" int dig_gelu_bwd(const void* dact, const void* pre, void* dpre, long 
 }
 
 extern "C" int dig_colsum(const void* x, float* out, int rows, int C, int ld, hipStream_t stream) {
-  if (!x || !out || rows <= 0 || C <= 0 || (ld & 1)) return DIG_ERR_ARG;
-  const int cb = (C + 127) / 128;
-  int rpb = 64;
-  while ((long)cb * ((rows + rpb - 1) / rpb) > 4096) rpb *= 2;
+  if (!x || !out || rows <= 0 || C <= 0 || (C & 7) || (ld & 7)) return DIG_ERR_ARG;
+  if (!aligned16(x)) return DIG_ERR_ALIGN;
+  const int cb = (C + 511) / 512;
+  int rpb = 32;
+  while ((long)cb * ((rows + rpb - 1) / rpb) > 2048) rpb *= 2;
   hipLaunchKernelGGL(colsum_kernel, dim3(cb, (rows + rpb - 1) / rpb), dim3(256), 0, stream, (const bf16_t*)x, out, rows, C, ld, rpb);
+  return dig_check_launch();
+}
+
+extern "C" int dig_patchify_bf16(const float* img, const unsigned char* mask, void* out, int n_img, int gh, int gw, hipStream_t stream) {
+  if (!img || !out || n_img <= 0) return DIG_ERR_ARG;
+  if (!aligned16(img) || !aligned16(out)) return DIG_ERR_ALIGN;
+  const int n_tok = n_img * gh * gw;
+  hipLaunchKernelGGL(patchify_bf16_kernel, dim3((n_tok * 16 + 255) / 256), dim3(256), 0, stream, img, mask, (bf16_t*)out, n_tok, gh, gw,
+                     gh * 4, gw * 4);
+  return dig_check_launch();
+}
+
+extern "C" int dig_colsum_masked(const void* x, const unsigned char* mask, float* out_unmasked, float* out_masked, int rows, int C,
+                                 hipStream_t stream) {
+  if (!x || !mask || !out_unmasked || !out_masked || rows <= 0 || C <= 0 || (C & 7)) return DIG_ERR_ARG;
+  if (!aligned16(x)) return DIG_ERR_ALIGN;
+  const int cb = (C + 511) / 512;
+  int rpb = 32;
+  while ((long)cb * ((rows + rpb - 1) / rpb) > 2048) rpb *= 2;
+  hipLaunchKernelGGL(colsum_masked_kernel, dim3(cb, (rows + rpb - 1) / rpb), dim3(256), 0, stream, (const bf16_t*)x, mask, out_unmasked,
+                     out_masked, rows, C, rpb);
   return dig_check_launch();
 }

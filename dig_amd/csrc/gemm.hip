@@ -19,7 +19,8 @@
 // row and 4 consecutive output columns per accumulator quad: epilogue loads/stores are 8-16 B wide.
 // Epilogue (runtime flags): + bias[j], * alpha on the first alpha_cols columns (q scaling,
 // modeling_finetune.py:97), exact-erf GELU with optional pre-activation store, + residual, and either
-// bf16 / fp32 store or fp32 atomic accumulate (split-R wgrad).
+// bf16 / fp32 store, or (split-R wgrad) an fp32 partial slab per R-slice that dig_reduce_partials then sums into
+// the gradient arena -- device-scope fp32 atomics go to the memory side on a multi-XCD part and measured ~8x slower.
 // Workgroup -> tile mapping is XCD-aware (block b runs on XCD b%8): each XCD walks a contiguous range of
 // tiles with j fastest, so an A row-panel is re-read from that XCD's L2, not from HBM.
 #include "common.h"
@@ -159,81 +160,106 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
     }
   }
 
-  // ---- epilogue: lane owns output row i, columns j = jb + 8*g + 4*hi + (0..3) ----
-  const int hi = lane >> 5;
+  // ---- epilogue: C-shuffle.  Each wave parks its 64x64 fp32 tile in its own 16 KiB of the (now idle) LDS with a
+  // 16-B-chunk XOR swizzle, then re-reads it row-contiguously: 8 lanes cover one 64-column row segment, so every
+  // global access of the epilogue (bias, residual, pre-activation, output) is a 16/32-B-per-lane, 128/256-B-per-row
+  // coalesced transaction instead of 32 scattered 8-B pieces.
+  const int cg = lane & 7;
+  const int j = j0 + wj * 64 + cg * 8;
+  const bool jok = j < p.J;                                        // J % 8 == 0 (host-checked)
+  const int jc = jok ? j : 0;
+  // issue every global read of the epilogue up front (rows clamped, so the loads are unconditional and overlap)
+  uint4 rres[8];
+  if (OUT != 2 && p.resid) {
 #pragma unroll
-  for (int a = 0; a < 2; ++a) {
-    const int i = i0 + wi * 64 + a * 32 + (lane & 31);
-    if (i >= p.I) continue;
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int j = j0 + wj * 64 + b * 32 + 8 * g + 4 * hi;
-        if (j >= p.J) continue;
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[a][b][g * 4 + e];
-        if (OUT == 2) {
-          float* c = reinterpret_cast<float*>(p.C) + (size_t)i * p.ldc + j;
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (j + e < p.J) atomicAdd(c + e, v[e]);
-          continue;
-        }
-        if (p.bias) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (j + e < p.J) v[e] += p.bias[j + e];
-        }
-        if (j < p.alpha_cols) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
-        }
-        const bool full = (j + 4 <= p.J);
-        if (p.act == 1) {
-          if (p.pre) {
-            bf16_t* pp = p.pre + (size_t)i * p.ldp + j;
-            if (full) {
-              *reinterpret_cast<uint2*>(pp) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
-            } else {
-              for (int e = 0; e < 4; ++e)
-                if (j + e < p.J) pp[e] = f2bf(v[e]);
-            }
-          }
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
-        }
-        if (p.resid) {
-          const bf16_t* rp = p.resid + (size_t)i * p.ldr + j;
-          if (full) {
-            const uint2 rr = *reinterpret_cast<const uint2*>(rp);
-            v[0] += bf2f((bf16_t)(rr.x & 0xffff)); v[1] += bf2f((bf16_t)(rr.x >> 16));
-            v[2] += bf2f((bf16_t)(rr.y & 0xffff)); v[3] += bf2f((bf16_t)(rr.y >> 16));
-          } else {
-            for (int e = 0; e < 4; ++e)
-              if (j + e < p.J) v[e] += bf2f(rp[e]);
-          }
-        }
-        if (OUT == 0) {
-          bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + (size_t)i * p.ldc + j;
-          if (full) {
-            *reinterpret_cast<uint2*>(c) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
-          } else {
-            for (int e = 0; e < 4; ++e)
-              if (j + e < p.J) c[e] = f2bf(v[e]);
-          }
-        } else {
-          float* c = reinterpret_cast<float*>(p.C) + (size_t)i * p.ldc + j;
-          if (full) {
-            *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
-          } else {
-            for (int e = 0; e < 4; ++e)
-              if (j + e < p.J) c[e] = v[e];
-          }
-        }
-      }
+    for (int ps = 0; ps < 8; ++ps) {
+      const int i = min(i0 + wi * 64 + ps * 8 + (lane >> 3), p.I - 1);
+      rres[ps] = *reinterpret_cast<const uint4*>(p.resid + (size_t)i * p.ldr + jc);
     }
+  }
+  float bias8[8];
+  if (OUT != 2 && p.bias) {
+    const float4 b0 = *reinterpret_cast<const float4*>(p.bias + jc);
+    const float4 b1 = *reinterpret_cast<const float4*>(p.bias + jc + 4);
+    bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w;
+    bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
+  }
+  float* stg = reinterpret_cast<float*>(smem + wave * 16384);
+  {
+    const int hi = lane >> 5, r = lane & 31;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int row = a * 32 + r;
+          const int chunk = (b * 32 + 8 * g + 4 * hi) >> 2;          // 16-B chunk index within the 64-float row
+          *reinterpret_cast<float4*>(stg + row * 64 + ((chunk ^ (row & 15)) << 2)) =
+              make_float4(acc[a][b][g * 4], acc[a][b][g * 4 + 1], acc[a][b][g * 4 + 2], acc[a][b][g * 4 + 3]);
+        }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const float al = (j < p.alpha_cols) ? p.alpha : 1.0f;
+  float* cpart = reinterpret_cast<float*>(p.C);
+  if (OUT == 2) cpart += (size_t)blockIdx.z * p.I * p.ldc;         // split-R partial slab
+#pragma unroll
+  for (int ps = 0; ps < 8; ++ps) {
+    const int row = ps * 8 + (lane >> 3);
+    const int i = i0 + wi * 64 + row;
+    const float4 x0 = *reinterpret_cast<const float4*>(stg + row * 64 + (((2 * cg) ^ (row & 15)) << 2));
+    const float4 x1 = *reinterpret_cast<const float4*>(stg + row * 64 + (((2 * cg + 1) ^ (row & 15)) << 2));
+    const bool live = (i < p.I) && jok;
+    float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+    if (OUT == 2) {
+      if (live) {
+        float* c = cpart + (size_t)i * p.ldc + j;
+        *reinterpret_cast<float4*>(c) = x0;
+        *reinterpret_cast<float4*>(c + 4) = x1;
+      }
+      continue;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (v[e] + bias8[e]) * al;
+    if (p.act == 1) {
+      if (p.pre && live)
+        *reinterpret_cast<uint4*>(p.pre + (size_t)i * p.ldp + j) =
+            make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+    }
+    if (p.resid) {
+      const unsigned w[4] = {rres[ps].x, rres[ps].y, rres[ps].z, rres[ps].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[2 * e] += bf2f((bf16_t)(w[e] & 0xffff)); v[2 * e + 1] += bf2f((bf16_t)(w[e] >> 16)); }
+    }
+    if (!live) continue;
+    if (OUT == 0) {
+      *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)i * p.ldc + j) =
+          make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+    } else {
+      float* c = reinterpret_cast<float*>(p.C) + (size_t)i * p.ldc + j;
+      *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<float4*>(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+  }
+}
+
+// out[e] (+)= sum_s part[s][e]   (deterministic split-R combine; also the "+=" into the gradient arena)
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int splits, long long n4,
+                                                              float* __restrict__ out, int accumulate) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    float4 a = accumulate ? reinterpret_cast<const float4*>(out)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < splits; ++s) {
+      const float4 b = reinterpret_cast<const float4*>(part)[(long long)s * n4 + i];
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    reinterpret_cast<float4*>(out)[i] = a;
   }
 }
 
@@ -258,13 +284,15 @@ extern "C" int dig_gemm_bf16(const void* A, const void* B, void* C, int I, int J
                              void* pre_act, int ldp, float alpha, int alpha_cols, int act, int splits, int a_rows,
                              int b_rows, hipStream_t stream) {
   if (!A || !B || !C || I <= 0 || J <= 0 || R <= 0 || splits < 1) return DIG_ERR_ARG;
+  if (bias && !aligned16(bias)) return DIG_ERR_ALIGN;
   if (out_kind < 0 || out_kind > 2 || act < 0 || act > 1) return DIG_ERR_ARG;
   if (!aligned16(A) || !aligned16(B) || !aligned16(C) || (lda & 7) || (ldb & 7)) return DIG_ERR_ALIGN;
-  if ((ldc & 3) || (resid && ((ldr & 3) || (((uintptr_t)resid) & 7))) || (pre_act && (ldp & 3))) return DIG_ERR_ALIGN;
+  if ((J & 7) || (ldc & 7) || (resid && ((ldr & 7) || !aligned16(resid))) || (pre_act && ((ldp & 7) || !aligned16(pre_act)))) return DIG_ERR_ALIGN;
   if (!trans_a && (R % BR)) return DIG_ERR_ARG;   // direct operands need R % 64 == 0 (row-wrap would pollute)
   if (!trans_b && (R % BR)) return DIG_ERR_ARG;
   if (out_kind == 2 && (bias || resid || act)) return DIG_ERR_ARG;
   if (out_kind != 2 && splits != 1) return DIG_ERR_ARG;
+  if (out_kind == 2 && ldc != J) return DIG_ERR_ARG;            // partial slabs are dense [splits][I][J]
   GemmParams p;
   p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C;
   p.I = I; p.J = J; p.R = R; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
@@ -277,7 +305,7 @@ extern "C" int dig_gemm_bf16(const void* A, const void* B, void* C, int I, int J
   p.alpha = alpha; p.alpha_cols = alpha_cols; p.act = act;
   const int rtiles = (R + BR - 1) / BR;
   p.r_per_split = ((rtiles + splits - 1) / splits) * BR;
-  splits = (R + p.r_per_split - 1) / p.r_per_split;
+  if ((R + p.r_per_split - 1) / p.r_per_split != splits) return DIG_ERR_ARG;   // use dig_gemm_effective_splits()
   p.tiles_i = (I + BI - 1) / BI; p.tiles_j = (J + BJ - 1) / BJ;
 #define DIG_GEMM_CASE(ta, tb, o) \
   if ((trans_a != 0) == ta && (trans_b != 0) == tb && out_kind == o) return launch<ta, tb, o>(p, splits, stream);
@@ -289,4 +317,22 @@ extern "C" int dig_gemm_bf16(const void* A, const void* B, void* C, int I, int J
   DIG_GEMM_CASE(true, true, 2)
 #undef DIG_GEMM_CASE
   return DIG_ERR_UNSUPPORTED;
+}
+
+// Number of R-splits dig_gemm_bf16 will really use for a requested split count (slabs are whole 64-row K-tiles).
+extern "C" int dig_gemm_effective_splits(int R, int splits) {
+  if (R <= 0 || splits < 1) return 0;
+  const int rtiles = (R + BR - 1) / BR;
+  const int per = ((rtiles + splits - 1) / splits) * BR;
+  return (R + per - 1) / per;
+}
+
+extern "C" int dig_reduce_partials(const float* partials, int splits, long long n, float* out, int accumulate,
+                                   hipStream_t stream) {
+  if (!partials || !out || splits < 1 || n <= 0 || (n & 3)) return DIG_ERR_ARG;
+  if (!aligned16(partials) || !aligned16(out)) return DIG_ERR_ALIGN;
+  const long long n4 = n / 4;
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)std::min<long long>(2048, (n4 + 255) / 256)), dim3(256), 0, stream,
+                     partials, splits, n4, out, accumulate);
+  return dig_check_launch();
 }

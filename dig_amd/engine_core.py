@@ -131,8 +131,8 @@ class _Step:
             dx = ops.layernorm_bwd(dln1, x, blk["norm1.weight"], blk["norm1.bias"], mu1, rs1, dx_mid, g["norm1.weight"], g["norm1.bias"], out=dln1)
             self.comm.grad_ready(M, f"encoder.blocks.{i}")
         for half, im in enumerate((images, aug)):
-            ops.patch_embed_bwd(dx[half * B * N:(half + 1) * B * N], im, mask_u8[half * B:(half + 1) * B], ew.g_pe_w, ew.g_pe_b,
-                                ew.g_mask_token, D, M.gh, M.gw)
+            ops.patch_embed_bwd_mfma(dx[half * B * N:(half + 1) * B * N], im, mask_u8[half * B:(half + 1) * B], ew.g_pe_w, ew.g_pe_b,
+                                     ew.g_mask_token, D, M.gh, M.gw)
         self.comm.grad_ready(M, "encoder.embed")
 
     # ------------------------------------------------------------------ BN-MLP heads
@@ -296,8 +296,7 @@ class _Step:
             Mrows, Mp, C, Dd = self.Mrows, self.Mp, M.dec_classes, M.dec_dim
             dpred = torch.empty((Mp, 64), device=dev, dtype=BF16)
             ops.pad_cast_rows(g_vis.reshape(Mrows, C).contiguous().float(), dpred, Mrows, C)
-            ops.gemm(dpred, h2, C, Dd, Mp, ta=True, tb=True, out=g32["pix_decoder.4.weight"], out_kind=ops.OUT_F32_ATOMIC,
-                     splits=ops.wgrad_splits(Mp, 2))
+            ops.wgrad(dpred, h2, g32["pix_decoder.4.weight"], C, Dd, Mp)
             ops.colsum(dpred, g32["pix_decoder.4.bias"], cols=C)
             dh2 = ops.gemm(dpred, w16["pix_decoder.4.weight"], Mp, Dd, 64, tb=True, b_rows=C)
             dh1 = ops.layernorm_bwd(dh2, h1, f32["pix_decoder.2.weight"], f32["pix_decoder.2.bias"], mu, rs, None,

@@ -11,7 +11,16 @@ cll = ctypes.c_longlong
 BF16 = torch.bfloat16
 F32 = torch.float32
 
-OUT_BF16, OUT_F32, OUT_F32_ATOMIC = 0, 1, 2
+OUT_BF16, OUT_F32, OUT_F32_PARTIAL = 0, 1, 2
+_ws = {}
+
+
+def _workspace(dev, numel):
+    """Per-device fp32 scratch for split-R partial slabs (grown on demand, reused across launches on one stream)."""
+    w = _ws.get(dev)
+    if w is None or w.numel() < numel:
+        w = _ws[dev] = torch.empty(max(numel, 1 << 22), device=dev, dtype=F32)
+    return w
 
 
 def gemm(A, B, I, J, R, *, ta=False, tb=False, out=None, out_kind=OUT_BF16, bias=None, resid=None, pre=None, alpha=1.0,
@@ -38,16 +47,24 @@ def linear_dgrad(dy, w, out=None):
 
 
 def wgrad_splits(rows, tiles):
-    s = max(1, min(rows // 512, (640 + tiles - 1) // tiles))
-    return s
+    s = max(1, min(rows // 512, (512 + tiles - 1) // tiles))
+    return L.lib().dig_gemm_effective_splits(rows, s)
+
+
+def wgrad(dy, x, dw, I, J, rows):
+    """dw[I,J] += dy[rows, :I]^T @ x[rows, :J]: split over rows into fp32 slabs, then one deterministic reduce that
+    also performs the += into the gradient arena."""
+    tiles = ((I + 127) // 128) * ((J + 127) // 128)
+    sp = wgrad_splits(rows, tiles)
+    ws = _workspace(dy.device, sp * I * J)
+    gemm(dy, x, I, J, rows, ta=True, tb=True, out=ws, out_kind=OUT_F32_PARTIAL, splits=sp, ldc=J)
+    L.call("dig_reduce_partials", L.ptr(ws), sp, cll(I * J), L.ptr(dw), 1, L.stream())
 
 
 def linear_wgrad(dy, x, dw, rows=None):
-    """dw[out,in] += dy[rows,out]^T @ x[rows,in]  (fp32 atomic accumulate, split over rows)."""
+    """dw[out,in] += dy[rows,out]^T @ x[rows,in]."""
     rows = dy.shape[0] if rows is None else rows
-    J_out, K_in = dw.shape
-    tiles = ((J_out + 127) // 128) * ((K_in + 127) // 128)
-    gemm(dy, x, J_out, K_in, rows, ta=True, tb=True, out=dw, out_kind=OUT_F32_ATOMIC, splits=wgrad_splits(rows, tiles))
+    wgrad(dy, x, dw, dw.shape[0], dw.shape[1], rows)
 
 
 def colsum(x, out, rows=None, cols=None):
@@ -98,6 +115,16 @@ def patch_embed_fwd(img, W, bias, mask_u8, mask_token, pos, D, gh, gw):
 def patch_embed_bwd(dy, img, mask_u8, dW, dbias, dmask_token, D, gh, gw):
     L.call("dig_patch_embed_bwd", L.ptr(dy), L.ptr(img), L.ptr(mask_u8), L.ptr(dW), L.ptr(dbias), L.ptr(dmask_token),
            img.shape[0], gh, gw, D, L.stream())
+
+
+def patch_embed_bwd_mfma(dy, img, mask_u8, dW, dbias, dmask_token, D, gh, gw):
+    """Patch-embed gradients with the weight gradient on the matrix cores: P = bf16 patch matrix (masked rows zero),
+    dW[D,48] += dy^T P (wgrad GEMM), bias / mask_token gradients by one masked column-sum pass over dy."""
+    n_tok = img.shape[0] * gh * gw
+    P = torch.empty((n_tok, 64), device=img.device, dtype=BF16)
+    L.call("dig_patchify_bf16", L.ptr(img), L.ptr(mask_u8), L.ptr(P), img.shape[0], gh, gw, L.stream())
+    wgrad(dy, P, dW, D, 48, n_tok)
+    L.call("dig_colsum_masked", L.ptr(dy), L.ptr(mask_u8), L.ptr(dbias), L.ptr(dmask_token), n_tok, D, L.stream())
 
 
 def window_pool_fwd(x, out, n_img, gh, gw, nwin, D):

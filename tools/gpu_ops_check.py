@@ -92,6 +92,10 @@ for Bn, D in [(6, 384), (3, 128)]:
     dW = torch.zeros(D, 48, device=dev); dbias = torch.zeros(D, device=dev); dmt = torch.zeros(D, device=dev)
     L.call("dig_patch_embed_bwd", L.ptr(dy), L.ptr(img), L.ptr(m8), L.ptr(dW), L.ptr(dbias), L.ptr(dmt), Bn, 8, 32, D, L.stream())
     report(f"patch_embed Bn={Bn} D={D}", [rel(out, ref.reshape(-1, D)), rel(dW, Wf.grad.reshape(D, 48)), rel(dbias, bf.grad), rel(dmt, mtf.grad)], 5e-3)
+    from dig_amd import ops
+    dW2 = torch.zeros(D, 48, device=dev); db2 = torch.zeros(D, device=dev); dm2 = torch.zeros(D, device=dev)
+    ops.patch_embed_bwd_mfma(dy, img, m8, dW2, db2, dm2, D, 8, 32)
+    report(f"patch_embed_mfma Bn={Bn} D={D}", [rel(dW2, Wf.grad.reshape(D, 48)), rel(db2, bf.grad), rel(dm2, mtf.grad)], 5e-3)
 
 # ---- window pool ----
 Bn, D = 6, 384
