@@ -252,8 +252,9 @@ __global__ void gelu_bwd_kernel(const bf16_t* __restrict__ dact, const bf16_t* _
   }
 }
 
-// out[c] += sum_r x[r, c]   (bias gradients); x bf16 [rows, C], C % 8 == 0, 16-B loads: a wave covers 512 columns
-__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ x, float* __restrict__ out, int rows, int C, int ld,
+// partial[blockIdx.y][c] = sum over this block's rows of x[r, c]   (bias gradients, stage 1; no atomics: same-address
+// device-scope atomics from ~2000 workgroups serialise at the memory side).  16-B loads: a wave covers 512 columns.
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ x, float* __restrict__ partial, int rows, int C, int ld,
                                                      int rows_per_block) {
   __shared__ float red[4][64][8 + 1];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -261,7 +262,19 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
   const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
   float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (c < C) {
-    for (int r = r0 + wv; r < r1; r += 4) {
+    int r = r0 + wv;
+    for (; r + 12 < r1; r += 16) {                     // 4 independent 16-B loads in flight per lane
+      uint4 u[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) u[q] = *reinterpret_cast<const uint4*>(x + (size_t)(r + 4 * q) * ld + c);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const unsigned w[4] = {u[q].x, u[q].y, u[q].z, u[q].w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { a[2 * k] += bf2f((bf16_t)(w[k] & 0xffff)); a[2 * k + 1] += bf2f((bf16_t)(w[k] >> 16)); }
+      }
+    }
+    for (; r < r1; r += 4) {
       const uint4 u = *reinterpret_cast<const uint4*>(x + (size_t)r * ld + c);
       const unsigned w[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
@@ -274,8 +287,21 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
   for (int e = threadIdx.x; e < 512; e += 256) {
     const int l = e >> 3, k = e & 7;
     const int cc = blockIdx.x * 512 + e;
-    if (cc < C) atomicAdd(out + cc, red[0][l][k] + red[1][l][k] + red[2][l][k] + red[3][l][k]);
+    if (cc < C) partial[(size_t)blockIdx.y * C + cc] = red[0][l][k] + red[1][l][k] + red[2][l][k] + red[3][l][k];
   }
+}
+
+// out[c] += sum_b partial[b][c]; 32 columns x 8 row-groups per block
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ partial, int nb, int C, float* __restrict__ out) {
+  __shared__ float red[8][32];
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cx;
+  float a = 0.f;
+  if (c < C)
+    for (int b = ry; b < nb; b += 8) a += partial[(size_t)b * C + c];
+  red[ry][cx] = a;
+  __syncthreads();
+  if (ry == 0 && c < C) out[c] += red[0][cx] + red[1][cx] + red[2][cx] + red[3][cx] + red[4][cx] + red[5][cx] + red[6][cx] + red[7][cx];
 }
 
 // P[t, k] (bf16, ld 64) = masked ? 0 : img patch element k (conv order c,p1,p2), k < 48; pad columns 48..63 = 0.
@@ -430,13 +456,26 @@ extern "C" int dig_gelu_bwd(const void* dact, const void* pre, void* dpre, long 
   return dig_check_launch();
 }
 
-extern "C" int dig_colsum(const void* x, float* out, int rows, int C, int ld, hipStream_t stream) {
-  if (!x || !out || rows <= 0 || C <= 0 || (C & 7) || (ld & 7)) return DIG_ERR_ARG;
+static inline int colsum_rows_per_block(int rows, int C) {
+  const int cb = (C + 511) / 512;
+  int rpb = 64;
+  while ((long)cb * ((rows + rpb - 1) / rpb) > 512) rpb *= 2;
+  return rpb;
+}
+
+extern "C" long long dig_colsum_workspace_bytes(int rows, int C) {
+  const int rpb = colsum_rows_per_block(rows, C);
+  return (long long)((rows + rpb - 1) / rpb) * C * sizeof(float);
+}
+
+extern "C" int dig_colsum(const void* x, float* out, float* workspace, int rows, int C, int ld, hipStream_t stream) {
+  if (!x || !out || !workspace || rows <= 0 || C <= 0 || (C & 7) || (ld & 7)) return DIG_ERR_ARG;
   if (!aligned16(x)) return DIG_ERR_ALIGN;
   const int cb = (C + 511) / 512;
-  int rpb = 32;
-  while ((long)cb * ((rows + rpb - 1) / rpb) > 2048) rpb *= 2;
-  hipLaunchKernelGGL(colsum_kernel, dim3(cb, (rows + rpb - 1) / rpb), dim3(256), 0, stream, (const bf16_t*)x, out, rows, C, ld, rpb);
+  const int rpb = colsum_rows_per_block(rows, C);
+  const int nb = (rows + rpb - 1) / rpb;
+  hipLaunchKernelGGL(colsum_kernel, dim3(cb, nb), dim3(256), 0, stream, (const bf16_t*)x, workspace, rows, C, ld, rpb);
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, stream, workspace, nb, C, out);
   return dig_check_launch();
 }
 

@@ -46,14 +46,20 @@ struct GemmParams {
   int tiles_i, tiles_j;
 };
 
-constexpr int BI = 128, BJ = 128, BR = 64;
-constexpr int TILE_BYTES = BI * BR * 2;  // 16 KiB per operand tile (both layouts)
+constexpr int BI = 128, BJ = 128;
+constexpr int BR = 64;                   // granule of the reduction dim (R % 64 rule for direct operands, split slabs)
 
-template <bool T>
+// chunk swizzle of the direct layout: rows are BK*2 bytes; 16 consecutive rows must hit 16 distinct 16-B slots of a
+// 256-B bank row for ds_read_b128
+template <int BK>
+__device__ __forceinline__ int dswz(int row) { return BK == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3); }
+
+template <bool T, int BK>
 __device__ __forceinline__ unsigned stage_offset(int piece, int row0, int r0, int ld) {
   if (!T) {
-    const int row = piece >> 3, pc = piece & 7;
-    const int c = pc ^ ((row >> 1) & 7);
+    constexpr int CPR = BK / 8;            // 16-B chunks per row
+    const int row = piece / CPR, pc = piece % CPR;
+    const int c = pc ^ dswz<BK>(row);
     return (unsigned)(((row0 + row) * ld + r0 + c * 8) * 2);
   } else {
     const int block = piece >> 3, w = piece & 7;
@@ -64,12 +70,12 @@ __device__ __forceinline__ unsigned stage_offset(int piece, int row0, int r0, in
 }
 
 // 8 bf16 of the reduction dim (substep s, k-slot group hi = lane>>5) for tile row/col (rowoff + (lane&31)).
-template <bool T>
+template <bool T, int BK>
 __device__ __forceinline__ bf16x8 load_frag(const unsigned char* tile, int rowoff, int s, int lane) {
   if (!T) {
     const int row = rowoff + (lane & 31);
     const int chunk = 2 * s + (lane >> 5);
-    const int byte = row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+    const int byte = row * (BK * 2) + ((chunk ^ dswz<BK>(row)) << 4);
     return *reinterpret_cast<const bf16x8*>(tile + byte);
   } else {
     const int hi = lane >> 5;
@@ -85,8 +91,15 @@ __device__ __forceinline__ bf16x8 load_frag(const unsigned char* tile, int rowof
   }
 }
 
-template <bool TA, bool TB, int OUT>
+template <int BK>
+struct TileCfg {
+  static constexpr int TILE_BYTES = BI * BK * 2;        // one operand tile (either layout)
+  static constexpr int NIT = TILE_BYTES / 16 / 256;     // 16-B pieces per thread per operand tile
+};
+
+template <bool TA, bool TB, int OUT, int BK>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
+  constexpr int TILE_BYTES = TileCfg<BK>::TILE_BYTES;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -100,26 +113,26 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
   const int i0 = ti * BI, j0 = tj * BJ;
   const int rbeg = blockIdx.z * p.r_per_split;
   const int rend = min(p.R, rbeg + p.r_per_split);
-  const int nt = (rend - rbeg + BR - 1) / BR;
+  const int nt = (rend - rbeg + BK - 1) / BK;
 
   const auto ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
   const auto rb_ = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.b_bytes, 0x00020000);
 
-  unsigned offA[4], offB[4];
+  unsigned offA[4], offB[4];   // (a dependent bound here makes hipcc 7.2 drop the host-side kernel stub)
 #pragma unroll
-  for (int it = 0; it < 4; ++it) {
+  for (int it = 0; it < TileCfg<BK>::NIT; ++it) {
     const int piece = it * 256 + tid;
-    offA[it] = stage_offset<TA>(piece, i0, rbeg, p.lda);
-    offB[it] = stage_offset<TB>(piece, j0, rbeg, p.ldb);
+    offA[it] = stage_offset<TA, BK>(piece, i0, rbeg, p.lda);
+    offB[it] = stage_offset<TB, BK>(piece, j0, rbeg, p.ldb);
   }
-  const unsigned stepA = TA ? (unsigned)(BR * p.lda * 2) : (unsigned)(BR * 2);
-  const unsigned stepB = TB ? (unsigned)(BR * p.ldb * 2) : (unsigned)(BR * 2);
+  const unsigned stepA = TA ? (unsigned)(BK * p.lda * 2) : (unsigned)(BK * 2);
+  const unsigned stepB = TB ? (unsigned)(BK * p.ldb * 2) : (unsigned)(BK * 2);
 
   auto stage = [&](int buf) {
     unsigned char* a = smem + buf * 2 * TILE_BYTES + wave * 1024;
     unsigned char* b = a + TILE_BYTES;
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
+    for (int it = 0; it < TileCfg<BK>::NIT; ++it) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, LDS_PTR(a + it * 4096), 16, offA[it], 0, 0, 0);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_, LDS_PTR(b + it * 4096), 16, offB[it], 0, 0, 0);
       offA[it] += stepA;
@@ -143,12 +156,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
       const unsigned char* at = smem + (t & 1) * 2 * TILE_BYTES;
       const unsigned char* bt = at + TILE_BYTES;
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
+      for (int s = 0; s < BK / 16; ++s) {
         bf16x8 af[2], bfr[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-          af[u] = load_frag<TA>(at, wi * 64 + u * 32, s, lane);
-          bfr[u] = load_frag<TB>(bt, wj * 64 + u * 32, s, lane);
+          af[u] = load_frag<TA, BK>(at, wi * 64 + u * 32, s, lane);
+          bfr[u] = load_frag<TB, BK>(bt, wj * 64 + u * 32, s, lane);
         }
 #pragma unroll
         for (int a = 0; a < 2; ++a)
@@ -187,66 +200,74 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
   }
-  float* stg = reinterpret_cast<float*>(smem + wave * 16384);
-  {
-    const int hi = lane >> 5, r = lane & 31;
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int row = a * 32 + r;
-          const int chunk = (b * 32 + 8 * g + 4 * hi) >> 2;          // 16-B chunk index within the 64-float row
-          *reinterpret_cast<float4*>(stg + row * 64 + ((chunk ^ (row & 15)) << 2)) =
-              make_float4(acc[a][b][g * 4], acc[a][b][g * 4 + 1], acc[a][b][g * 4 + 2], acc[a][b][g * 4 + 3]);
-        }
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  float* stg = reinterpret_cast<float*>(smem + wave * 8192);      // 32 rows x 64 fp32 per wave, per half
   const float al = (j < p.alpha_cols) ? p.alpha : 1.0f;
   float* cpart = reinterpret_cast<float*>(p.C);
   if (OUT == 2) cpart += (size_t)blockIdx.z * p.I * p.ldc;         // split-R partial slab
 #pragma unroll
-  for (int ps = 0; ps < 8; ++ps) {
-    const int row = ps * 8 + (lane >> 3);
-    const int i = i0 + wi * 64 + row;
-    const float4 x0 = *reinterpret_cast<const float4*>(stg + row * 64 + (((2 * cg) ^ (row & 15)) << 2));
-    const float4 x1 = *reinterpret_cast<const float4*>(stg + row * 64 + (((2 * cg + 1) ^ (row & 15)) << 2));
-    const bool live = (i < p.I) && jok;
-    float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-    if (OUT == 2) {
-      if (live) {
-        float* c = cpart + (size_t)i * p.ldc + j;
-        *reinterpret_cast<float4*>(c) = x0;
-        *reinterpret_cast<float4*>(c + 4) = x1;
+  for (int a = 0; a < 2; ++a) {
+    {
+      const int hi = lane >> 5, row = lane & 31;
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int chunk = (b * 32 + 8 * g + 4 * hi) >> 2;          // 16-B chunk index within the 64-float row
+          *reinterpret_cast<float4*>(stg + row * 64 + ((chunk ^ (row & 15)) << 2)) =
+              make_float4(acc[a][b][g * 4], acc[a][b][g * 4 + 1], acc[a][b][g * 4 + 2], acc[a][b][g * 4 + 3]);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int ps = a * 4 + q;
+      const int row = q * 8 + (lane >> 3);
+      const int i = i0 + wi * 64 + a * 32 + row;
+      const float4 x0 = *reinterpret_cast<const float4*>(stg + row * 64 + (((2 * cg) ^ (row & 15)) << 2));
+      const float4 x1 = *reinterpret_cast<const float4*>(stg + row * 64 + (((2 * cg + 1) ^ (row & 15)) << 2));
+      const bool live = (i < p.I) && jok;
+      float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+      if (OUT == 2) {
+        if (live) {
+          float* c = cpart + (size_t)i * p.ldc + j;
+          *reinterpret_cast<float4*>(c) = x0;
+          *reinterpret_cast<float4*>(c + 4) = x1;
+        }
+        continue;
       }
-      continue;
-    }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = (v[e] + bias8[e]) * al;
-    if (p.act == 1) {
-      if (p.pre && live)
-        *reinterpret_cast<uint4*>(p.pre + (size_t)i * p.ldp + j) =
+      for (int e = 0; e < 8; ++e) v[e] = (v[e] + bias8[e]) * al;
+      if (p.act == 1) {
+        if (p.pre && live)
+          *reinterpret_cast<uint4*>(p.pre + (size_t)i * p.ldp + j) =
+              make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+      } else if (p.act == 2) {                                     // multiply by gelu'(pre): fused GELU backward (fc2 dgrad)
+        const unsigned w[4] = {rres[ps].x, rres[ps].y, rres[ps].z, rres[ps].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[2 * e] *= dgelu_f(bf2f((bf16_t)(w[e] & 0xffff))); v[2 * e + 1] *= dgelu_f(bf2f((bf16_t)(w[e] >> 16))); }
+      }
+      if (p.resid && p.act != 2) {
+        const unsigned w[4] = {rres[ps].x, rres[ps].y, rres[ps].z, rres[ps].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[2 * e] += bf2f((bf16_t)(w[e] & 0xffff)); v[2 * e + 1] += bf2f((bf16_t)(w[e] >> 16)); }
+      }
+      if (!live) continue;
+      if (OUT == 0) {
+        *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)i * p.ldc + j) =
             make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+      } else {
+        float* c = reinterpret_cast<float*>(p.C) + (size_t)i * p.ldc + j;
+        *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      }
     }
-    if (p.resid) {
-      const unsigned w[4] = {rres[ps].x, rres[ps].y, rres[ps].z, rres[ps].w};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { v[2 * e] += bf2f((bf16_t)(w[e] & 0xffff)); v[2 * e + 1] += bf2f((bf16_t)(w[e] >> 16)); }
-    }
-    if (!live) continue;
-    if (OUT == 0) {
-      *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)i * p.ldc + j) =
-          make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
-    } else {
-      float* c = reinterpret_cast<float*>(p.C) + (size_t)i * p.ldc + j;
-      *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
-      *reinterpret_cast<float4*>(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
-    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
 }
 
@@ -263,16 +284,17 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
   }
 }
 
-template <bool TA, bool TB, int OUT>
+template <bool TA, bool TB, int OUT, int BK>
 int launch(const GemmParams& p, int splits, hipStream_t stream) {
+  constexpr int LDS = (4 * BI * BK * 2) > 32768 ? (4 * BI * BK * 2) : 32768;     // 2 stages x (A,B) tiles; >= epilogue staging
   static bool attr_set = false;
-  auto k = gemm_kernel<TA, TB, OUT>;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<TA, TB, OUT, BK>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_set = true;
   }
   dim3 grid(p.tiles_i * p.tiles_j, 1, splits);
-  hipLaunchKernelGGL(k, grid, dim3(256), 4 * TILE_BYTES, stream, p);
+  hipLaunchKernelGGL((gemm_kernel<TA, TB, OUT, BK>), grid, dim3(256), LDS, stream, p);
   return dig_check_launch();
 }
 
@@ -282,10 +304,12 @@ int launch(const GemmParams& p, int splits, hipStream_t stream) {
 extern "C" int dig_gemm_bf16(const void* A, const void* B, void* C, int I, int J, int R, int lda, int ldb, int ldc,
                              int trans_a, int trans_b, int out_kind, const float* bias, const void* resid, int ldr,
                              void* pre_act, int ldp, float alpha, int alpha_cols, int act, int splits, int a_rows,
-                             int b_rows, hipStream_t stream) {
+                             int b_rows, int bk, hipStream_t stream) {
   if (!A || !B || !C || I <= 0 || J <= 0 || R <= 0 || splits < 1) return DIG_ERR_ARG;
   if (bias && !aligned16(bias)) return DIG_ERR_ALIGN;
-  if (out_kind < 0 || out_kind > 2 || act < 0 || act > 1) return DIG_ERR_ARG;
+  if (out_kind < 0 || out_kind > 2 || act < 0 || act > 2 || (bk != 0 && bk != 32 && bk != 64)) return DIG_ERR_ARG;
+  if (act == 2 && !resid) return DIG_ERR_ARG;                   // act 2: resid carries the saved pre-activation
+  if (bk == 0) bk = 64;
   if (!aligned16(A) || !aligned16(B) || !aligned16(C) || (lda & 7) || (ldb & 7)) return DIG_ERR_ALIGN;
   if ((J & 7) || (ldc & 7) || (resid && ((ldr & 7) || !aligned16(resid))) || (pre_act && ((ldp & 7) || !aligned16(pre_act)))) return DIG_ERR_ALIGN;
   if (!trans_a && (R % BR)) return DIG_ERR_ARG;   // direct operands need R % 64 == 0 (row-wrap would pollute)
@@ -307,13 +331,13 @@ extern "C" int dig_gemm_bf16(const void* A, const void* B, void* C, int I, int J
   p.r_per_split = ((rtiles + splits - 1) / splits) * BR;
   if ((R + p.r_per_split - 1) / p.r_per_split != splits) return DIG_ERR_ARG;   // use dig_gemm_effective_splits()
   p.tiles_i = (I + BI - 1) / BI; p.tiles_j = (J + BJ - 1) / BJ;
-#define DIG_GEMM_CASE(ta, tb, o) \
-  if ((trans_a != 0) == ta && (trans_b != 0) == tb && out_kind == o) return launch<ta, tb, o>(p, splits, stream);
+#define DIG_GEMM_CASE(ta, tb, o)                                                \
+  if ((trans_a != 0) == ta && (trans_b != 0) == tb && out_kind == o)           \
+    return bk == 64 ? launch<ta, tb, o, 64>(p, splits, stream) : launch<ta, tb, o, 32>(p, splits, stream);
   DIG_GEMM_CASE(false, false, 0)
   DIG_GEMM_CASE(false, false, 1)
   DIG_GEMM_CASE(false, true, 0)
   DIG_GEMM_CASE(false, true, 1)
-  DIG_GEMM_CASE(true, true, 1)
   DIG_GEMM_CASE(true, true, 2)
 #undef DIG_GEMM_CASE
   return DIG_ERR_UNSUPPORTED;

@@ -83,15 +83,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx,
-                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, int rows) {
+                                                     float* __restrict__ partial /*[grid][3][D]*/, int rows) {
   constexpr int D = EPL * 64;
-  __shared__ float red[2][4][D];
+  __shared__ float red[3][4][D];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int nw = (gridDim.x * blockDim.x) >> 6;
-  float g[EPL], bt[EPL], dg[EPL], db[EPL];
+  float g[EPL], bt[EPL], dg[EPL], db[EPL], dc[EPL];
 #pragma unroll
-  for (int k = 0; k < EPL; ++k) { g[k] = gamma[lane * EPL + k]; bt[k] = GELU ? beta[lane * EPL + k] : 0.f; dg[k] = 0.f; db[k] = 0.f; }
+  for (int k = 0; k < EPL; ++k) { g[k] = gamma[lane * EPL + k]; bt[k] = GELU ? beta[lane * EPL + k] : 0.f; dg[k] = 0.f; db[k] = 0.f; dc[k] = 0.f; }
   for (int r = w; r < rows; r += nw) {
     float v[EPL], d[EPL];
     load_row<EPL>(x + (size_t)r * D + lane * EPL, v);
@@ -117,16 +117,37 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
       float e[EPL];
       load_row<EPL>(dres + (size_t)r * D + lane * EPL, e);
 #pragma unroll
-      for (int k = 0; k < EPL; ++k) o[k] += e[k];
+      for (int k = 0; k < EPL; ++k) { o[k] += e[k]; dc[k] += e[k]; }       // dc: column sums of the skip-path gradient
     }
     store_row<EPL>(dx + (size_t)r * D + lane * EPL, o);
   }
 #pragma unroll
-  for (int k = 0; k < EPL; ++k) { red[0][wv][lane * EPL + k] = dg[k]; red[1][wv][lane * EPL + k] = db[k]; }
+  for (int k = 0; k < EPL; ++k) { red[0][wv][lane * EPL + k] = dg[k]; red[1][wv][lane * EPL + k] = db[k]; red[2][wv][lane * EPL + k] = dc[k]; }
   __syncthreads();
-  for (int c = threadIdx.x; c < D; c += blockDim.x) {
-    atomicAdd(dgamma + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
-    atomicAdd(dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+  float* out = partial + (size_t)blockIdx.x * 3 * D;
+  for (int c = threadIdx.x; c < 3 * D; c += blockDim.x) {
+    const int w = c / D, cc = c - w * D;
+    out[c] = red[w][0][cc] + red[w][1][cc] + red[w][2][cc] + red[w][3][cc];
+  }
+}
+
+// dgamma += sum_b partial[b][0], dbeta += sum_b partial[b][1], dcol (optional) += sum_b partial[b][2]   (deterministic).
+// 32 columns x 8 row-groups per block so the nb-long sum is 8-way parallel with independent loads in flight.
+__global__ __launch_bounds__(256) void ln_bwd_finalize_kernel(const float* __restrict__ partial, int nblocks, int D,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                              float* __restrict__ dcol) {
+  __shared__ float red[8][32];
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cx;
+  float a = 0.f;
+  if (c < 3 * D)
+    for (int b = ry; b < nblocks; b += 8) a += partial[(size_t)b * 3 * D + c];
+  red[ry][cx] = a;
+  __syncthreads();
+  if (ry == 0 && c < 3 * D) {
+    const int w = c / D, cc = c - w * D;
+    float* dst = w == 0 ? dgamma : (w == 1 ? dbeta : dcol);
+    if (dst) dst[cc] += red[0][cx] + red[1][cx] + red[2][cx] + red[3][cx] + red[4][cx] + red[5][cx] + red[6][cx] + red[7][cx];
   }
 }
 
@@ -263,15 +284,21 @@ extern "C" int dig_layernorm_fwd(const void* x, const float* gamma, const float*
   return dig_check_launch();
 }
 
+extern "C" long long dig_layernorm_bwd_workspace_bytes(int rows, int D) {
+  return (long long)std::max(1, std::min(1024, (rows + 15) / 16)) * 3 * D * sizeof(float);
+}
+
+// dcolsum (nullable): receives += column sums of dres (the bias gradient of the layer that produced the skip-path sum)
 extern "C" int dig_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean,
-                                 const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta, int rows, int D,
-                                 int fuse_gelu, hipStream_t stream) {
-  if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || rows <= 0) return DIG_ERR_ARG;
-  if (fuse_gelu && !beta) return DIG_ERR_ARG;
+                                 const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta, float* dcolsum,
+                                 float* workspace, int rows, int D, int fuse_gelu, hipStream_t stream) {
+  if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || !workspace || rows <= 0) return DIG_ERR_ARG;
+  if ((fuse_gelu && !beta) || (dcolsum && !dres)) return DIG_ERR_ARG;
   if (!aligned16(x) || !aligned16(dy) || !aligned16(dx) || (dres && !aligned16(dres))) return DIG_ERR_ALIGN;
-  const int grid = std::max(1, std::min(512, (rows + 15) / 16));
-  if (fuse_gelu) { LN_DISPATCH(D, true, ln_bwd_kernel, (const bf16_t*)dy, (const bf16_t*)x, gamma, beta, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, dgamma, dbeta, rows) }
-  else { LN_DISPATCH(D, false, ln_bwd_kernel, (const bf16_t*)dy, (const bf16_t*)x, gamma, beta, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, dgamma, dbeta, rows) }
+  const int grid = std::max(1, std::min(1024, (rows + 15) / 16));
+  if (fuse_gelu) { LN_DISPATCH(D, true, ln_bwd_kernel, (const bf16_t*)dy, (const bf16_t*)x, gamma, beta, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, workspace, rows) }
+  else { LN_DISPATCH(D, false, ln_bwd_kernel, (const bf16_t*)dy, (const bf16_t*)x, gamma, beta, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, workspace, rows) }
+  hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((3 * D + 31) / 32), dim3(256), 0, stream, workspace, grid, D, dgamma, dbeta, dcolsum);
   return dig_check_launch();
 }
 

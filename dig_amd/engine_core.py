@@ -110,17 +110,15 @@ class _Step:
             saved[i] = None
             # x_out = x_mid + fc2(gelu(fc1(ln2)))
             ops.linear_wgrad(dx, act, g["mlp.fc2.weight"])
-            ops.colsum(dx, g["mlp.fc2.bias"])
-            dact = ops.linear_dgrad(dx, blk["mlp.fc2.weight"])
-            ops.gelu_bwd(dact, pre, dact)
+            dact = ops.linear_dgrad(dx, blk["mlp.fc2.weight"], gelu_pre=pre)       # d(pre-activation), GELU' fused
             ops.linear_wgrad(dact, ln2, g["mlp.fc1.weight"])
             ops.colsum(dact, g["mlp.fc1.bias"])
             dln2 = ops.linear_dgrad(dact, blk["mlp.fc1.weight"])
             del dact, pre, act
-            dx_mid = ops.layernorm_bwd(dln2, x_mid, blk["norm2.weight"], blk["norm2.bias"], mu2, rs2, dx, g["norm2.weight"], g["norm2.bias"], out=dln2)
+            dx_mid = ops.layernorm_bwd(dln2, x_mid, blk["norm2.weight"], blk["norm2.bias"], mu2, rs2, dx, g["norm2.weight"], g["norm2.bias"],
+                                       out=dln2, dres_colsum=g["mlp.fc2.bias"])      # colsum(dx) = fc2 bias grad, fused
             # x_mid = x + proj(attn(ln1))
             ops.linear_wgrad(dx_mid, ctx, g["attn.proj.weight"])
-            ops.colsum(dx_mid, g["attn.proj.bias"])
             dctx = ops.linear_dgrad(dx_mid, blk["attn.proj.weight"])
             dqkv = ops.attn_bwd(qkv, ctx, dctx, lse, 2 * B, H, D, scale)
             ops.linear_wgrad(dqkv, ln1, g["attn.qkv.weight"])
@@ -128,7 +126,8 @@ class _Step:
             ops.colsum(dqkv, gb[:D], cols=D)                              # q_bias (dq already carries the q scale)
             ops.colsum(dqkv[:, 2 * D:], gb[2 * D:], cols=D)               # v_bias; K has no bias
             dln1 = ops.linear_dgrad(dqkv, blk["attn.qkv.weight"], out=dctx)
-            dx = ops.layernorm_bwd(dln1, x, blk["norm1.weight"], blk["norm1.bias"], mu1, rs1, dx_mid, g["norm1.weight"], g["norm1.bias"], out=dln1)
+            dx = ops.layernorm_bwd(dln1, x, blk["norm1.weight"], blk["norm1.bias"], mu1, rs1, dx_mid, g["norm1.weight"], g["norm1.bias"],
+                                   out=dln1, dres_colsum=g["attn.proj.bias"])            # colsum(dx_mid) = proj bias grad, fused
             self.comm.grad_ready(M, f"encoder.blocks.{i}")
         for half, im in enumerate((images, aug)):
             ops.patch_embed_bwd_mfma(dx[half * B * N:(half + 1) * B * N], im, mask_u8[half * B:(half + 1) * B], ew.g_pe_w, ew.g_pe_b,

@@ -12,6 +12,9 @@ BF16 = torch.bfloat16
 F32 = torch.float32
 
 OUT_BF16, OUT_F32, OUT_F32_PARTIAL = 0, 1, 2
+# K-tile depth of the MFMA GEMM: 64 for direct/direct (forward), 32 when a transpose-read operand is involved
+# (dgrad / wgrad): measured on MI355X, see profiles/r01_gemm_bk_sweep.txt
+GEMM_BK_FWD, GEMM_BK_BWD = 64, 32
 _ws = {}
 
 
@@ -24,14 +27,16 @@ def _workspace(dev, numel):
 
 
 def gemm(A, B, I, J, R, *, ta=False, tb=False, out=None, out_kind=OUT_BF16, bias=None, resid=None, pre=None, alpha=1.0,
-         alpha_cols=0, act=0, splits=1, ldc=None, a_rows=0, b_rows=0):
+         alpha_cols=0, act=0, splits=1, ldc=None, a_rows=0, b_rows=0, bk=0):
     """C[I,J] = sum_r opA(i,r) opB(j,r); see csrc/gemm.hip for the operand conventions."""
     if out is None:
         out = torch.empty((I, J), device=A.device, dtype=BF16 if out_kind == OUT_BF16 else F32)
+    if not bk:
+        bk = GEMM_BK_FWD if not (ta or tb) else GEMM_BK_BWD
     L.call("dig_gemm_bf16", L.ptr(A), L.ptr(B), L.ptr(out), I, J, R, A.stride(0), B.stride(0),
            out.stride(0) if ldc is None else ldc, int(ta), int(tb), out_kind, L.ptr(bias), L.ptr(resid),
            resid.stride(0) if resid is not None else 0, L.ptr(pre), pre.stride(0) if pre is not None else 0, cf(alpha),
-           alpha_cols, act, splits, a_rows, b_rows, L.stream())
+           alpha_cols, act, splits, a_rows, b_rows, bk, L.stream())
     return out
 
 
@@ -41,8 +46,10 @@ def linear_fwd(x, w, *, bias=None, resid=None, act=0, pre=None, alpha=1.0, alpha
                 alpha_cols=alpha_cols, out=out, out_kind=out_kind)
 
 
-def linear_dgrad(dy, w, out=None):
-    """dx[rows,in] = dy[rows,out] @ w[out,in]."""
+def linear_dgrad(dy, w, out=None, gelu_pre=None):
+    """dx[rows,in] = dy[rows,out] @ w[out,in]  (* gelu'(gelu_pre) when the input of this layer was a GELU output)."""
+    if gelu_pre is not None:
+        return gemm(dy, w, dy.shape[0], w.shape[1], w.shape[0], tb=True, out=out, act=2, resid=gelu_pre)
     return gemm(dy, w, dy.shape[0], w.shape[1], w.shape[0], tb=True, out=out)
 
 
@@ -67,10 +74,23 @@ def linear_wgrad(dy, x, dw, rows=None):
     wgrad(dy, x, dw, dw.shape[0], dw.shape[1], rows)
 
 
+_ws2 = {}
+
+
+def _workspace2(dev, numel):
+    """Second fp32 scratch (column-sum / LayerNorm-backward partials)."""
+    w = _ws2.get(dev)
+    if w is None or w.numel() < numel:
+        w = _ws2[dev] = torch.empty(max(numel, 1 << 20), device=dev, dtype=F32)
+    return w
+
+
 def colsum(x, out, rows=None, cols=None):
+    """out[c] += sum_r x[r, c]  (two-stage, deterministic)."""
     rows = x.shape[0] if rows is None else rows
     cols = x.shape[1] if cols is None else cols
-    L.call("dig_colsum", L.ptr(x), L.ptr(out), rows, cols, x.stride(0), L.stream())
+    ws = _workspace2(x.device, 1024 * cols)
+    L.call("dig_colsum", L.ptr(x), L.ptr(out), L.ptr(ws), rows, cols, x.stride(0), L.stream())
 
 
 def layernorm_fwd(x, gamma, beta, eps, gelu=False):
@@ -83,11 +103,14 @@ def layernorm_fwd(x, gamma, beta, eps, gelu=False):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, beta, mean, rstd, dres, dgamma, dbeta, gelu=False, out=None):
+def layernorm_bwd(dy, x, gamma, beta, mean, rstd, dres, dgamma, dbeta, gelu=False, out=None, dres_colsum=None):
+    """dx = [dres +] LN'(dy); dgamma/dbeta accumulated; dres_colsum (optional) += column sums of dres, i.e. the bias
+    gradient of the layer whose output fed the residual sum -- read for free while dres streams through."""
     rows, D = x.shape
     dx = torch.empty_like(x) if out is None else out
+    ws = _workspace2(x.device, 1024 * 3 * D)
     L.call("dig_layernorm_bwd", L.ptr(dy), L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(mean), L.ptr(rstd), L.ptr(dres), L.ptr(dx),
-           L.ptr(dgamma), L.ptr(dbeta), rows, D, int(gelu), L.stream())
+           L.ptr(dgamma), L.ptr(dbeta), L.ptr(dres_colsum), L.ptr(ws), rows, D, int(gelu), L.stream())
     return dx
 
 

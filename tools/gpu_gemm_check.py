@@ -43,6 +43,12 @@ for (I, J, R) in [(256, 256, 128), (2048, 1152, 384), (716, 48, 192), (65536, 15
     ops.linear_wgrad(dy, x, dW)
     refw = dW0 + dy.float().t() @ x.float()
     e5 = rel(dW, refw)
+    if J % 64 == 0:
+        prex = torch.randn(I, R, device=dev).bfloat16()
+        dxg = ops.linear_dgrad(dy2 := torch.randn(I, J, device=dev).bfloat16(), w, gelu_pre=prex)
+        pp = prex.float().requires_grad_(True)
+        torch.nn.functional.gelu(pp).backward(dy2.float() @ w.float())
+        e4 = max(e4, rel(dxg, pp.grad))
     good = max(e1, e2, e2b, e3, e4) < 1e-2 and e5 < 2e-3
     ok &= good
     print(f"I={I} J={J} R={R}: fwd {e1:.2e} gelu {e2:.2e} pre {e2b:.2e} alpha/f32 {e3:.2e} dgrad {e4:.2e} wgrad {e5:.2e} {'OK' if good else 'FAIL'}")
@@ -59,6 +65,10 @@ def bench(fn, n=20):
     return (time.perf_counter() - t) / n
 
 
+import os
+if os.environ.get("DIG_BK"):
+    ops.GEMM_BK_FWD = ops.GEMM_BK_BWD = int(os.environ["DIG_BK"])
+print("GEMM_BK fwd/bwd", ops.GEMM_BK_FWD, ops.GEMM_BK_BWD)
 for (I, J, R, name) in [(65536, 1152, 384, "qkv"), (65536, 384, 384, "proj"), (65536, 1536, 384, "fc1"), (65536, 384, 1536, "fc2"), (1024, 4096, 4096, "head"), (8192, 8192, 8192, "8k")]:
     x = torch.randn(I, R, device=dev).bfloat16()
     w = torch.randn(J, R, device=dev).bfloat16()

@@ -41,9 +41,10 @@ for D, gelu in [(384, 0), (512, 0), (128, 0), (192, 1), (64, 1)]:
     dy = torch.randn(rows, D, device=dev).bfloat16()
     dres = torch.randn(rows, D, device=dev).bfloat16()
     ref.backward(dy.float())
-    dx = torch.empty_like(x); dg = torch.zeros(D, device=dev); db = torch.zeros(D, device=dev)
-    L.call("dig_layernorm_bwd", L.ptr(dy), L.ptr(x), L.ptr(g), L.ptr(b), L.ptr(mean), L.ptr(rstd), L.ptr(dres), L.ptr(dx), L.ptr(dg), L.ptr(db), rows, D, gelu, L.stream())
-    report(f"layernorm D={D} gelu={gelu}", [rel(y, ref), rel(dx, xf.grad + dres.float()), rel(dg, gf.grad), rel(db, bf.grad)], 1e-2)
+    dg = torch.zeros(D, device=dev); db = torch.zeros(D, device=dev); dc = torch.zeros(D, device=dev)
+    from dig_amd import ops as _ops
+    dx = _ops.layernorm_bwd(dy, x, g, b, mean, rstd, dres, dg, db, gelu=bool(gelu), dres_colsum=dc)
+    report(f"layernorm D={D} gelu={gelu}", [rel(y, ref), rel(dx, xf.grad + dres.float()), rel(dg, gf.grad), rel(db, bf.grad), rel(dc, dres.float().sum(0))], 1e-2)
 
 # ---- BatchNorm ----
 for rows, C, affine, relu in [(1024, 4096, 1, 1), (4096, 512, 1, 1), (333, 256, 0, 0), (32, 64, 0, 0)]:
@@ -152,7 +153,8 @@ e1 = rel(o, bb.grad)
 L.call("dig_add_bf16", L.ptr(a), L.ptr(b2), L.ptr(o), ctypes.c_longlong(n), L.stream())
 e2 = rel(o, a.float() + b2.float())
 xx = torch.randn(3000, 48, device=dev).bfloat16(); cs = torch.zeros(48, device=dev)
-L.call("dig_colsum", L.ptr(xx), L.ptr(cs), 3000, 48, 48, L.stream())
+from dig_amd import ops as _ops
+_ops.colsum(xx, cs)
 report("gelu_bwd/add/colsum", [e1, e2, rel(cs, xx.float().sum(0))], 5e-3)
 
 # ---- InfoNCE pieces ----
