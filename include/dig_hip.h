@@ -1,0 +1,177 @@
+/* dig_hip.h -- C ABI of libdig_hip.so: the MI355X (gfx950) kernels behind the DiG pre-training hot path.
+ *
+ * The reference (ayumiymk/DiG) is pure PyTorch: it has no plugin / FFI boundary of its own.  The boundary this
+ * library offers sits one level below the three Python surfaces the reference exposes (model factory, step engine,
+ * optimizer -- SURVEY.md section 8b): each entry point replaces the ATen/cuDNN/cuBLAS work that ONE reference
+ * expression launches, and the comment on each declaration cites that expression (paths relative to the reference
+ * repository).  INTEGRATION.md shows the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions (all entry points):
+ *   - plain C types only; every pointer is a DEVICE pointer owned by the caller (the library never allocates, frees
+ *     or keeps a pointer); scratch is caller-allocated (see the *_workspace_bytes queries);
+ *   - `stream` is the HIP stream to launch on (pass the caller's current stream); launches are asynchronous, no
+ *     host synchronisation happens inside; callable from any host thread (forward thread or autograd worker);
+ *   - return value: 0 = launched; -1 bad argument, -2 misaligned pointer / leading dimension, -3 launch failed,
+ *     -4 unsupported configuration.  Nothing throws across the ABI;
+ *   - "bf16" buffers are raw bfloat16 bits (uint16), row-major; statistics / losses / optimizer state are fp32;
+ *   - integer work (mask -> index, gathers) is bit-exact; floating point follows the tolerances in DESIGN.md.
+ */
+#ifndef DIG_HIP_H
+#define DIG_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef __HIP_PLATFORM_AMD__
+typedef struct ihipStream_t* hipStream_t;
+#endif
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Matrix-core GEMM.  Replaces F.linear / nn.Linear and its autograd (modeling_finetune.py:53-60,91-93,119;
+ * modeling_pretrain_moco_mim_ori.py:414-426,463-482).
+ *   C[I,J] = sum_r opA(i,r) * opB(j,r)
+ *   trans_a = 0: A is [I, R] (r contiguous);  trans_a = 1: A is [R, I] (r is the row index)      (same for B / J)
+ *   forward  y = x W^T   : trans_a 0, trans_b 0;   dgrad dx = dy W : trans_a 0, trans_b 1;   wgrad dW = dy^T x : 1, 1
+ *   out_kind 0: bf16 C;  1: fp32 C;  2: fp32 partial slabs C[splits][I][J] (split over R, ldc must equal J) to be summed
+ *               by dig_reduce_partials (bias/resid/act must be unset);  `splits` must come from dig_gemm_effective_splits
+ *   epilogue (out_kind 0/1): v = (acc + bias[j]) * (j < alpha_cols ? alpha : 1);
+ *               act 1: store v to pre_act (bf16, optional) then v = gelu_erf(v);  act 2: v *= gelu'(resid[i,j]);
+ *               resid (bf16, act != 2): v += resid[i,j]
+ *   requirements: J % 8 == 0; lda, ldb, ldc, ldr, ldp % 8 == 0; 16-byte aligned pointers; R % 64 == 0 for a non-transposed
+ *   operand; a_rows / b_rows (0 = default) = rows of A / B that exist in memory (rows beyond read as zero); bk in {0,32,64}.
+ */
+int dig_gemm_bf16(const void* A, const void* B, void* C, int I, int J, int R, int lda, int ldb, int ldc, int trans_a,
+                  int trans_b, int out_kind, const float* bias, const void* resid, int ldr, void* pre_act, int ldp, float alpha,
+                  int alpha_cols, int act, int splits, int a_rows, int b_rows, int bk, hipStream_t stream);
+int dig_gemm_effective_splits(int R, int splits);
+/* out[e] (+)= sum_s partials[s][e], e < n  (deterministic split-R combine; accumulate=1 adds into the gradient arena) */
+int dig_reduce_partials(const float* partials, int splits, long long n, float* out, int accumulate, hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Fused self-attention, 256 tokens x head_dim 64 (Attention.forward, modeling_finetune.py:97-118, and its gradient).
+ * qkv: bf16 [n_img*256, 3*embed_dim] laid out (q | k | v) x (head, 64) with q already scaled by head_dim^-0.5.
+ * ctx: bf16 [n_img*256, embed_dim];  lse: fp32 [n_img*heads, 256] (log-sum-exp of every score row, saved for backward).
+ * bwd: dqkv = gradient w.r.t. qkv given dctx; the dq part is multiplied by `scale` (chain rule through the q scaling).
+ */
+int dig_attn_fwd(const void* qkv, void* ctx, float* lse, int n_img, int heads, int embed_dim, hipStream_t stream);
+int dig_attn_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse, void* dqkv, int n_img, int heads,
+                 int embed_dim, float scale, hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * LayerNorm over the last dim D in {64,128,192,256,384,512} (nn.LayerNorm(eps=1e-6): modeling_finetune.py:134,140;
+ * pix_decoder LN + GELU: modeling_pretrain_moco_mim_ori.py:424-425 when fuse_gelu=1).
+ * fwd: y = [gelu](LN(x)); mean/rstd [rows] saved.  bwd: dx = [dres +] dLN(dy); dgamma/dbeta += ; dcolsum (optional) +=
+ * column sums of dres (bias gradient of the layer feeding the residual); workspace: dig_layernorm_bwd_workspace_bytes.
+ */
+int dig_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int rows, int D,
+                      float eps, int fuse_gelu, hipStream_t stream);
+long long dig_layernorm_bwd_workspace_bytes(int rows, int D);
+int dig_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean, const float* rstd,
+                      const void* dres, void* dx, float* dgamma, float* dbeta, float* dcolsum, float* workspace, int rows, int D,
+                      int fuse_gelu, hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * BatchNorm1d in training mode, split so that the [2,C] statistics vector can be all-reduced between the halves
+ * (nn.BatchNorm1d in _build_mlp, modeling_pretrain_moco_mim_ori.py:463-482, under SyncBatchNorm,
+ * run_mae_pretraining_moco.py:390).  x, y, dy, dx: bf16 [rows, C], C % 8 == 0.
+ *   dig_bn_stats:      sums[0][c] += sum_r x, sums[1][c] += sum_r x^2          (caller zeroes sums)
+ *   dig_bn_fwd_apply:  mean/var from sums / n_total (biased var); y = [relu](gamma * xhat + beta); gamma == beta == NULL
+ *                      for the affine=False last layer; writes mean_out / rstd_out [C]
+ *   dig_bn_update_running: running_mean/var <- (1-momentum) * old + momentum * (mean, var * n/(n-1))
+ *   dig_bn_bwd_stats:  g = dy * relu_mask; sums[0][c] += sum g (= dbeta), sums[1][c] += sum g*xhat (= dgamma)
+ *   dig_bn_bwd_apply:  dx = gamma * rstd * (g - S0/n_total - xhat * S1/n_total) with S the all-rank sums
+ */
+int dig_bn_stats(const void* x, float* sums, int rows, int C, hipStream_t stream);
+int dig_bn_fwd_apply(const void* x, const float* sums, float n_total, float eps, const float* gamma, const float* beta, int relu,
+                     void* y, float* mean_out, float* rstd_out, int rows, int C, hipStream_t stream);
+int dig_bn_update_running(const float* sums, float n_total, float momentum, float* running_mean, float* running_var, int C,
+                          hipStream_t stream);
+int dig_bn_bwd_stats(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                     int relu, float* sums, int rows, int C, hipStream_t stream);
+int dig_bn_bwd_apply(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                     int relu, const float* sums, float n_total, void* dx, int rows, int C, hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Patch embedding + mask-token mix + position add (PatchEmbed conv k4 s4, modeling_finetune.py:188,195;
+ * modeling_pretrain_vit.py:95-99).  img fp32 [n_img,3,4*gh,4*gw]; W fp32 [D,48] (conv weight flattened c,p1,p2);
+ * mask uint8 [n_img, gh*gw] (1 = replaced by mask_token; may be NULL); pos fp32 [gh*gw, D]; out bf16 [n_img*gh*gw, D].
+ * Backward: dig_patchify_bf16 builds the bf16 patch matrix P [n_tok, 64] (masked rows and pad columns zero) so that
+ * dW = dy^T P runs as a wgrad dig_gemm_bf16; dig_colsum_masked gives the bias (unmasked rows) and mask_token (masked
+ * rows) gradients in one pass.  dig_patch_embed_bwd is the scalar reference form of the same three gradients.
+ */
+int dig_patch_embed_fwd(const float* img, const float* W, const float* bias, const unsigned char* mask, const float* mask_token,
+                        const float* pos, void* out, int n_img, int gh, int gw, int D, hipStream_t stream);
+int dig_patch_embed_bwd(const void* dy, const float* img, const unsigned char* mask, float* dW, float* dbias, float* dmask_token,
+                        int n_img, int gh, int gw, int D, hipStream_t stream);
+int dig_patchify_bf16(const float* img, const unsigned char* mask, void* out, int n_img, int gh, int gw, hipStream_t stream);
+int dig_colsum_masked(const void* x, const unsigned char* mask, float* out_unmasked, float* out_masked, int rows, int C,
+                      hipStream_t stream);
+
+/* PatchNet 'no_patchtrans' = adaptive_avg_pool2d of the gh x gw token grid to (1, nwin)
+ * (modeling_pretrain_moco_mim_ori.py:189-193) and its gradient (accumulate=1 adds into dx). */
+int dig_window_pool_fwd(const void* x, void* out, int out_is_f32, int n_img, int gh, int gw, int nwin, int D, hipStream_t stream);
+int dig_window_pool_bwd(const void* dpool, void* dx, int n_img, int gh, int gw, int nwin, int D, int accumulate, hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * SimMIM target / decoder plumbing (engine_for_pretraining_moco.py:85-111,141; modeling_pretrain_moco_mim_ori.py:560-570).
+ *   dig_mask_to_index: idx[b][j] = b*N + (j-th set position of mask[b,:]) in ascending order -- the order boolean
+ *                      indexing yields; count[b] = number of set positions (bit-exact)
+ *   dig_gather_rows / dig_scatter_rows_add: dst[m,:] = src[idx[m],:] (rows M..M_pad-1 zero) and its transpose
+ *   dig_mim_target:    target[m, (p1*4+p2)*3 + c] = img[b,c,ph*4+p1,pw*4+p2]*0.5+0.5 for token idx[m] ('(p1 p2 c)' order)
+ *   dig_mse_fwd_bwd:   loss += mean((pred-target)^2); dpred (bf16, optional) = gscale * 2 (pred-target) / (M*C)
+ */
+int dig_mask_to_index(const unsigned char* mask, int* idx, int* count, int B, int N, int max_per_sample, hipStream_t stream);
+int dig_gather_rows(const void* src, const int* idx, void* dst, int M, int M_pad, int D, hipStream_t stream);
+int dig_scatter_rows_add(const void* src, const int* idx, void* dst, int M, int D, hipStream_t stream);
+int dig_mim_target(const float* img, const int* idx, float* target, int M, int gh, int gw, hipStream_t stream);
+int dig_mse_fwd_bwd(const float* pred, int ld_pred, const float* target, int M, int C, float gscale, float* loss, void* dpred,
+                    int ld_dpred, hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * MoCo-v3 InfoNCE in fp32 (contrastive_loss / accuracy / label_smooth_loss, modeling_pretrain_moco_mim_ori.py:444-461,
+ * 593-625).  dig_l2norm_* = F.normalize(dim=1, eps); dig_sgemm: C = alpha * A[I,R] * (trans_b ? B[R,J] : B[J,R]^T);
+ * dig_ce_rows: per row i of logits [n,m] with label i+label_offset: out3[0] += lse - logit[label], out3[1] += top-1 hit,
+ * out3[2] += top-5 hit, and logits is overwritten by gscale * (softmax - onehot).
+ */
+int dig_l2norm_fwd(const float* x, float* y, float* inv_norm, int n, int C, float eps, hipStream_t stream);
+int dig_l2norm_bwd(const float* dy, const float* y, const float* inv_norm, float* dx, int n, int C, hipStream_t stream);
+int dig_sgemm(const float* A, const float* B, float* C, int I, int J, int R, int lda, int ldb, int ldc, int trans_b, float alpha,
+              hipStream_t stream);
+int dig_ce_rows(float* logits, int n, int m, int label_offset, float gscale, float* out3, hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Flat-arena optimizer (custom_optim/adamw.py:55-121 + _functional.py:115-140 as one kernel; EMA
+ * modeling_pretrain_moco_mim_ori.py:428-442; grad norm utils/utils.py:507-519).
+ *   dig_adamw_step: group_flags[i / 256] in {0,1} selects (lr0, wd0) or (lr1, wd1) for element i (parameters are padded
+ *                   to 256 elements); step >= 1 is the Adam step count; grad_scale multiplies g (clipping / averaging);
+ *                   bf16_shadow (optional) receives the updated parameters in bf16.
+ *   dig_ema_update: pm = pm*m + p*(1-m); bf16_shadow (optional) receives pm in bf16.
+ *   dig_sumsq:      out[0] = sum x^2 (two-stage, deterministic); workspace: dig_sumsq_workspace_bytes.
+ */
+int dig_adamw_step(float* p, const float* g, float* m, float* v, void* bf16_shadow, long long n, const unsigned char* group_flags,
+                   float lr0, float wd0, float lr1, float wd1, float beta1, float beta2, float eps, int step, float grad_scale,
+                   hipStream_t stream);
+int dig_ema_update(float* pm, const float* p, void* bf16_shadow, long long n, float m, hipStream_t stream);
+long long dig_sumsq_workspace_bytes(long long n);
+int dig_sumsq(const float* x, long long n, float* workspace, float* out, hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Small helpers: bias-gradient column sums (two-stage, deterministic), GELU backward, casts, fills, scaling.
+ */
+long long dig_colsum_workspace_bytes(int rows, int C);
+int dig_colsum(const void* x, float* out, float* workspace, int rows, int C, int ld, hipStream_t stream);
+int dig_gelu_bwd(const void* dact, const void* pre, void* dpre, long long n, hipStream_t stream);
+int dig_add_bf16(const void* a, const void* b, void* out, long long n, hipStream_t stream);
+int dig_cast_f32_to_bf16(const float* x, void* y, long long n, hipStream_t stream);
+int dig_cast_bf16_to_f32(const void* x, float* y, long long n, hipStream_t stream);
+int dig_pad_cast_rows(const float* src, void* dst, int M, int C, int M_pad, int ld, hipStream_t stream);
+int dig_fill_f32(float* x, long long n, float value, hipStream_t stream);
+int dig_scale_f32(float* x, long long n, float s, hipStream_t stream);
+int dig_scale_by_device_scalar(float* x, long long n, const float* scalar, float extra, hipStream_t stream);
+int dig_axpy_f32(float* y, const float* x, long long n, float a, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIG_HIP_H */

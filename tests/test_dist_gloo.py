@@ -1,0 +1,134 @@
+"""World-size-2 coverage on CPU (gloo): (1) the multi-rank ORACLE (SyncBN statistics over all ranks, rank-ordered key
+all-gather with label offset, DDP gradient averaging) replayed against fixtures produced by the unmodified reference
+under gloo DDP; (2) the product's communication layer (bucket all-reduce / averaging, key gather order, parameter
+broadcast) on CPU arenas.  Kernels do not run here; the RCCL path uses the same code with backend 'nccl'."""
+import dataclasses
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import dig_oracle as O
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _sample_index(numel, k=8):
+    if numel <= k:
+        return np.arange(numel)
+    return (np.arange(k, dtype=np.int64) * 2654435761 + 12345) % numel
+
+
+def _oracle_worker(rank, world, port, golden_dir, q):
+    try:
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.set_num_threads(2)
+        g = np.load(os.path.join(golden_dir, f"tiny_w{world}_rank{rank}.npz"))
+        cfg = O.DiGConfig(**O.TINY)
+        seed, B = int(g["seed"]), int(g["B"])
+        tr = O.OracleTrainer(cfg, *O.det_state(cfg, seed), comm=O.DistComm())
+        im, au, mk = O.synthetic_batch(B, cfg, seed * 1000 + rank)
+        hp = O.StepHyper(lr=1e-3, moco_m=float(g["s0/stat/moco_m"]))
+        metrics, grads, out, _ = tr.step(im, au, mk, hp)
+        for k in ("loss", "loss_pixel", "loss_contrast", "q1_acc1", "q1_acc5", "q2_acc1", "q2_acc5", "grad_norm"):
+            assert abs(metrics[k] - float(g[f"s0/stat/{k}"])) <= 1e-4 * max(1.0, abs(float(g[f"s0/stat/{k}"]))), (k, metrics[k])
+        names, norms, samples = g["s0/grad_names"].tolist(), g["s0/grad_norms"], g["s0/grad_samples"]
+        for i, n in enumerate(names):
+            gi = grads[n]
+            assert abs(gi.double().norm().item() - norms[i]) <= 3e-4 * norms[i] + 1e-6 * norms.max(), n
+            got = np.resize(gi.reshape(-1)[_sample_index(gi.numel())].numpy(), 8)
+            np.testing.assert_allclose(got, samples[i], rtol=3e-4, atol=1e-5 * (float(np.abs(samples[i]).max()) + norms[i] / np.sqrt(gi.numel()) + 1e-3))
+        np.testing.assert_allclose(out["vis_out"][0].detach().numpy(), g["s0/cap/vis_out/full"], rtol=1e-4, atol=2e-5)
+        bn = g["s0/buf_names"].tolist()
+        for i, n in enumerate(bn):
+            assert abs(tr.S[n].double().norm().item() - g["s0/buf_norms"][i]) <= 1e-4 * g["s0/buf_norms"][i] + 1e-5, n
+        q.put((rank, "ok"))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def _comm_worker(rank, world, port, q):
+    try:
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from dig_amd.modeling_pretrain_moco_mim_ori import MoCo_ViT
+        from dig_amd.parallel import DistributedDataParallel
+        cfg = O.DiGConfig(**O.TINY)
+        torch.manual_seed(100 + rank)                                         # different init per rank, as run_mae...:313
+        m = MoCo_ViT(encoder_embed_dim=cfg.embed_dim, encoder_depth=cfg.depth, encoder_num_heads=cfg.heads,
+                     decoder_embed_dim=cfg.dec_dim, mlp_dim=cfg.moco_mlp_dim, dim=cfg.moco_dim, T=cfg.T, num_windows=4,
+                     use_pixel_target=True, patchnet_name='no_patchtrans')
+        before = m.flat_params.clone()
+        ddp = DistributedDataParallel(m)
+        assert ddp.module is m and m.comm.world == world and m.comm.rank == rank
+        # broadcast from rank 0: every rank now holds rank 0's parameters
+        ref = m.flat_params.clone()
+        dist.broadcast(ref, src=0)
+        assert torch.equal(ref, m.flat_params)
+        if rank != 0:
+            assert not torch.equal(before, m.flat_params)
+        # bucketed gradient all-reduce in backward order + averaging == mean over ranks of the whole arena
+        gen = torch.Generator().manual_seed(7 + rank)
+        m.flat_grads.copy_(torch.randn(m.flat_grads.shape, generator=gen))
+        mine = m.flat_grads.clone()
+        for key in m.bucket_names:
+            m.comm.grad_ready(m, key)
+        m.comm.finish_grad_sync(m)
+        tot = mine.clone()
+        dist.all_reduce(tot)
+        torch.testing.assert_close(m.flat_grads, tot / world, rtol=1e-6, atol=1e-7)
+        # key all-gather: rank order, one message for (k1, k2)
+        k = torch.full((1, 2, 3, 4), float(rank))
+        k[0, 1] += 0.5
+        allk = m.comm.all_gather_cat(k)
+        assert allk.shape == (world, 2, 3, 4)
+        for r in range(world):
+            assert float(allk[r, 0, 0, 0]) == r and float(allk[r, 1, 0, 0]) == r + 0.5
+        # BN statistics all-reduce is a plain sum
+        s = torch.ones(2, 8) * (rank + 1)
+        m.comm.all_reduce_(s)
+        assert float(s[0, 0]) == sum(range(1, world + 1))
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def _run(target, world, *args):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, world, port) + args + (q,)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(60)
+    bad = {r: v for r, v in res.items() if v != "ok"}
+    assert not bad, "\n".join(f"rank {r}:\n{v}" for r, v in bad.items())
+
+
+def test_multirank_oracle_matches_reference_fixtures(golden_dir):
+    _run(_oracle_worker, 2, golden_dir)
+
+
+def test_comm_layer_world2():
+    _run(_comm_worker, 2)

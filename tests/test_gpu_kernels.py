@@ -1,0 +1,257 @@
+"""Kernel-level parity on the MI355X: every C-ABI op against a plain PyTorch fp32 reference of the same op
+(bf16 I/O => tolerance 1e-2 relative Frobenius; fp32 / integer paths tight or exact)."""
+import ctypes
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gpu_util import rel
+
+pytestmark = pytest.mark.gpu
+cf = ctypes.c_float
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from dig_amd import _lib
+    _lib.lib()
+    torch.manual_seed(0)
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("I,J,R", [(256, 256, 128), (2048, 1152, 384), (716, 48, 192), (8192, 1536, 384), (1024, 4096, 4096),
+                                   (300, 200, 64), (32, 64, 256), (129, 136, 192)])
+@pytest.mark.parametrize("bk", [32, 64])
+def test_gemm_fwd_dgrad_wgrad(dev, I, J, R, bk):
+    from dig_amd import ops
+    ops.GEMM_BK_FWD = ops.GEMM_BK_BWD = bk
+    try:
+        x = torch.randn(I, R, device=dev).bfloat16()
+        w = (torch.randn(J, R, device=dev) * 0.05).bfloat16()
+        bias = torch.randn(J, device=dev)
+        res = torch.randn(I, J, device=dev).bfloat16()
+        h = x.float() @ w.float().t() + bias
+        assert rel(ops.linear_fwd(x, w, bias=bias, resid=res), h + res.float()) < 1e-2
+        pre = torch.empty(I, J, device=dev, dtype=torch.bfloat16)
+        y = ops.linear_fwd(x, w, bias=bias, pre=pre, act=1)
+        assert rel(y, F.gelu(h)) < 1e-2 and rel(pre, h) < 1e-2
+        ac = (J // 16) * 8
+        ref = h.clone(); ref[:, :ac] *= 0.125
+        assert rel(ops.linear_fwd(x, w, bias=bias, alpha=0.125, alpha_cols=ac, out_kind=ops.OUT_F32), ref) < 1e-5
+        dy = torch.randn(I, J, device=dev).bfloat16()
+        if J % 64 == 0:
+            assert rel(ops.linear_dgrad(dy, w), dy.float() @ w.float()) < 1e-2
+            prex = torch.randn(I, R, device=dev).bfloat16()
+            pp = prex.float().requires_grad_(True)
+            F.gelu(pp).backward(dy.float() @ w.float())
+            assert rel(ops.linear_dgrad(dy, w, gelu_pre=prex), pp.grad) < 1e-2
+        dW = torch.randn(J, R, device=dev); dW0 = dW.clone()
+        ops.linear_wgrad(dy, x, dW)
+        assert rel(dW, dW0 + dy.float().t() @ x.float()) < 2e-5        # fp32 accumulate, deterministic
+        dW2 = dW0.clone()
+        ops.linear_wgrad(dy, x, dW2)
+        assert torch.equal(dW, dW2)                                     # bit-reproducible (no atomics)
+    finally:
+        ops.GEMM_BK_FWD, ops.GEMM_BK_BWD = 64, 32
+
+
+@pytest.mark.parametrize("Bn,H,scale,spike", [(2, 2, 1.0, False), (4, 6, 0.125, False), (3, 8, 0.125, True)])
+def test_attention_fwd_bwd(dev, Bn, H, scale, spike):
+    from dig_amd import ops
+    D = H * 64
+    qkv = torch.randn(Bn * 256, 3 * D, device=dev).bfloat16()
+    if spike:                                                           # force a peaked softmax row (dominant key)
+        qkv[5, :64] *= 6.0
+        qkv[77, D:D + 64] *= 6.0
+    ctx, lse = ops.attn_fwd(qkv, Bn, H, D)
+    x = qkv.float().requires_grad_(True)
+    t = x.reshape(Bn, 256, 3, H, 64).permute(2, 0, 3, 1, 4)
+    s = t[0] @ t[1].transpose(-2, -1)
+    o = (s.softmax(-1) @ t[2]).transpose(1, 2).reshape(Bn * 256, D)
+    assert rel(ctx, o) < 1e-2
+    assert (lse - torch.logsumexp(s, -1).reshape(Bn * H, 256)).abs().max().item() < 2e-2
+    dctx = torch.randn(Bn * 256, D, device=dev).bfloat16()
+    o.backward(dctx.float())
+    g = x.grad.clone(); g[:, :D] *= scale
+    dqkv = ops.attn_bwd(qkv, ctx, dctx, lse, Bn, H, D, scale)
+    for lo in (0, D, 2 * D):
+        assert rel(dqkv[:, lo:lo + D], g[:, lo:lo + D]) < 2e-2
+
+
+@pytest.mark.parametrize("D,gelu", [(384, 0), (512, 0), (128, 0), (192, 1), (64, 1), (256, 0)])
+def test_layernorm(dev, D, gelu):
+    from dig_amd import ops
+    rows = 1000
+    x = torch.randn(rows, D, device=dev).bfloat16()
+    g = torch.randn(D, device=dev) * 0.2 + 1
+    b = torch.randn(D, device=dev) * 0.1
+    y, mean, rstd = ops.layernorm_fwd(x, g, b, 1e-6, gelu=bool(gelu))
+    xf, gf, bf = x.float().requires_grad_(True), g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.layer_norm(xf, (D,), gf, bf, 1e-6)
+    ref = F.gelu(ref) if gelu else ref
+    dy, dres = torch.randn(rows, D, device=dev).bfloat16(), torch.randn(rows, D, device=dev).bfloat16()
+    ref.backward(dy.float())
+    dg, db, dc = torch.zeros(D, device=dev), torch.zeros(D, device=dev), torch.zeros(D, device=dev)
+    dx = ops.layernorm_bwd(dy, x, g, b, mean, rstd, dres, dg, db, gelu=bool(gelu), dres_colsum=dc)
+    assert rel(y, ref) < 1e-2 and rel(dx, xf.grad + dres.float()) < 1e-2
+    assert rel(dg, gf.grad) < 1e-4 and rel(db, bf.grad) < 1e-4 and rel(dc, dres.float().sum(0)) < 1e-4
+
+
+@pytest.mark.parametrize("rows,C,affine,relu", [(1024, 4096, 1, 1), (4096, 512, 1, 1), (333, 256, 0, 0), (32, 64, 0, 0)])
+def test_batchnorm(dev, rows, C, affine, relu):
+    from dig_amd import ops
+    x = (torch.randn(rows, C, device=dev) * 2 + 0.5).bfloat16()
+    gamma = (torch.randn(C, device=dev) * 0.2 + 1) if affine else None
+    beta = (torch.randn(C, device=dev) * 0.1) if affine else None
+    sums = torch.zeros(2, C, device=dev)
+    ops.bn_stats(x, sums)
+    y, mean, rstd = ops.bn_fwd_apply(x, sums, float(rows), 1e-5, gamma, beta, relu)
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    ops.bn_update_running(sums, float(rows), 0.1, rm, rv)
+    xf = x.float().requires_grad_(True)
+    gf = gamma.clone().requires_grad_(True) if affine else None
+    bf = beta.clone().requires_grad_(True) if affine else None
+    trm, trv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    ref = F.batch_norm(xf, trm, trv, gf, bf, True, 0.1, 1e-5)
+    ref = F.relu(ref) if relu else ref
+    dy = torch.randn(rows, C, device=dev).bfloat16()
+    ref.backward(dy.float())
+    s2 = torch.zeros(2, C, device=dev)
+    ops.bn_bwd_stats(dy, x, mean, rstd, gamma, beta, relu, s2)
+    dx = ops.bn_bwd_apply(dy, x, mean, rstd, gamma, beta, relu, s2, float(rows))
+    assert rel(y, ref) < 1e-2 and rel(dx, xf.grad) < 1.5e-2
+    assert rel(rm, trm) < 1e-4 and rel(rv, trv) < 1e-4                 # running stats incl. the n/(n-1) factor
+    if affine:
+        assert rel(s2[1], gf.grad) < 1e-4 and rel(s2[0], bf.grad) < 1e-4
+
+
+@pytest.mark.parametrize("Bn,D", [(6, 384), (3, 128)])
+def test_patch_embed(dev, Bn, D):
+    from dig_amd import ops
+    img = torch.rand(Bn, 3, 32, 128, device=dev) * 2 - 1
+    W = torch.randn(D, 3, 4, 4, device=dev) * 0.1
+    bias, mt, pos = torch.randn(D, device=dev) * 0.1, torch.randn(D, device=dev) * 0.1, torch.randn(256, D, device=dev)
+    mask = torch.rand(Bn, 256, device=dev) < 0.5
+    m8 = mask.to(torch.uint8)
+    out = ops.patch_embed_fwd(img, W.view(D, 48), bias, m8, mt, pos, D, 8, 32)
+    Wf, bf, mtf = W.clone().requires_grad_(True), bias.clone().requires_grad_(True), mt.clone().requires_grad_(True)
+    mm = mask.unsqueeze(-1).float()
+    ref = F.conv2d(img, Wf, bf, stride=4).flatten(2).transpose(1, 2) * (1 - mm) + mtf * mm + pos
+    dy = torch.randn(Bn * 256, D, device=dev).bfloat16()
+    ref.reshape(-1, D).backward(dy.float())
+    assert rel(out, ref.reshape(-1, D)) < 1e-2
+    for fn in (ops.patch_embed_bwd, ops.patch_embed_bwd_mfma):
+        dW, dbias, dmt = torch.zeros(D, 48, device=dev), torch.zeros(D, device=dev), torch.zeros(D, device=dev)
+        fn(dy, img, m8, dW, dbias, dmt, D, 8, 32)
+        assert rel(dW, Wf.grad.reshape(D, 48)) < 5e-3 and rel(dbias, bf.grad) < 1e-4 and rel(dmt, mtf.grad) < 1e-4
+
+
+def test_window_pool(dev):
+    from dig_amd import ops
+    Bn, D = 6, 384
+    x = torch.randn(Bn, 256, D, device=dev).bfloat16()
+    out = torch.empty(Bn * 4, D, device=dev, dtype=torch.bfloat16)
+    ops.window_pool_fwd(x, out, Bn, 8, 32, 4, D)
+    ref = x.float().reshape(Bn, 8, 4, 8, D).mean(dim=(1, 3)).reshape(Bn * 4, D)       # == adaptive_avg_pool2d(grid,(1,4))
+    ref2 = F.adaptive_avg_pool2d(x.float().reshape(Bn, 8, 32, D).permute(0, 3, 1, 2), (1, 4)).permute(0, 2, 3, 1).reshape(Bn * 4, D)
+    assert rel(ref, ref2) < 1e-6 and rel(out, ref) < 1e-2
+    dp = torch.randn(Bn * 4, D, device=dev).bfloat16()
+    dx = torch.randn(Bn, 256, D, device=dev).bfloat16(); dx0 = dx.clone()
+    ops.window_pool_bwd(dp, dx, Bn, 8, 32, 4, D, True)
+    refdx = dx0.float() + (dp.float().reshape(Bn, 1, 4, 1, D) / 64).expand(Bn, 8, 4, 8, D).reshape(Bn, 256, D)
+    assert rel(dx, refdx) < 1e-2
+
+
+def test_mask_index_gather_target_are_bit_exact(dev):
+    """Integer / byte work: bit-exact against the reference's boolean indexing (engine_for_pretraining_moco.py:96-107)."""
+    from dig_amd import ops
+    import dig_oracle as O
+    B = 7
+    cfg = O.DiGConfig()
+    im, _, mk = O.synthetic_batch(B, cfg, 21)
+    mask_b, labels = O.mim_targets(im, mk, cfg)
+    m8 = mask_b[:, 0].to(torch.uint8).to(dev)
+    idx, cnt = ops.mask_to_index(m8, 179)
+    ref_idx = torch.nonzero(mask_b[:, 0].reshape(-1)).squeeze(1).to(torch.int32).reshape(B, 179)
+    assert torch.equal(idx.cpu(), ref_idx) and bool((cnt.cpu() == 179).all())
+    tgt = ops.mim_target(im.to(dev), idx, B * 179, 8, 32)
+    assert torch.equal(tgt.cpu().reshape(B, 179, 48), labels[0])                          # bit-exact floats too (x*0.5+0.5)
+    src = torch.randn(B * 256, 384, device=dev).bfloat16()
+    M = B * 179
+    Mp = (M + 63) // 64 * 64
+    dst = ops.gather_rows(src, idx, M, Mp)
+    assert torch.equal(dst[:M], src[idx.reshape(-1).long()]) and bool((dst[M:] == 0).all())
+    acc = torch.randn(B * 256, 384, device=dev).bfloat16(); acc0 = acc.clone()
+    ops.scatter_rows_add(dst, idx, acc, M)
+    refacc = acc0.float(); refacc[idx.reshape(-1).long()] += dst[:M].float()
+    assert rel(acc, refacc) < 5e-3
+    # ragged / empty masks: counts are reported, nothing is written past max_per_sample
+    z = torch.zeros(2, 256, dtype=torch.uint8, device=dev); z[1, ::2] = 1
+    idx2, cnt2 = ops.mask_to_index(z, 179)
+    assert cnt2.cpu().tolist() == [0, 128] and idx2[1, :128].cpu().tolist() == list(range(256, 512, 2))
+
+
+def test_mse(dev):
+    from dig_amd import ops
+    M, Mp = 895, 896
+    pred = torch.randn(Mp, 64, device=dev); tgt = torch.rand(M, 48, device=dev)
+    loss = torch.zeros(1, device=dev); dpred = torch.empty(Mp, 64, device=dev, dtype=torch.bfloat16)
+    ops.mse_fwd_bwd(pred, 64, tgt, M, 48, 0.7, loss, dpred, 64)
+    pf = pred[:M, :48].clone().requires_grad_(True)
+    rl = F.mse_loss(pf, tgt); (rl * 0.7).backward()
+    assert abs(loss.item() - rl.item()) < 1e-5 * rl.item() and rel(dpred[:M, :48], pf.grad) < 1e-2
+    assert float(dpred[:M, 48:].abs().max()) == 0.0                     # pad columns of the written rows are zeroed
+
+
+def test_infonce(dev):
+    from dig_amd import ops
+    nq, mk, C, T, off = 512, 2048, 256, 0.2, 512
+    q, k = torch.randn(nq, C, device=dev), torch.randn(mk, C, device=dev)
+    qn, qi = ops.l2norm_fwd(q); kn, _ = ops.l2norm_fwd(k)
+    logits = torch.empty(nq, mk, device=dev)
+    ops.sgemm(qn, kn, logits, nq, mk, C, False, 1.0 / T)
+    qf = q.clone().requires_grad_(True)
+    rlog = F.normalize(qf, dim=1) @ F.normalize(k, dim=1).t() / T
+    labels = torch.arange(nq, device=dev) + off
+    rloss = F.cross_entropy(rlog, labels) * 2 * T
+    rloss.backward()
+    assert rel(logits, rlog) < 1e-5
+    out3 = torch.zeros(3, device=dev)
+    ops.ce_rows(logits, off, 2 * T / nq, out3)
+    dqn = torch.empty(nq, C, device=dev)
+    ops.sgemm(logits, kn, dqn, nq, C, mk, True, 1.0 / T)
+    dq = ops.l2norm_bwd(dqn, qn, qi)
+    hit = rlog.topk(5, 1)[1].eq(labels[:, None])
+    assert abs(out3[0].item() * 2 * T / nq - rloss.item()) < 1e-5 * rloss.item() and rel(dq, qf.grad) < 1e-4
+    assert out3[1].item() == hit[:, :1].sum().item() and out3[2].item() == hit.sum().item()
+
+
+def test_adamw_ema_sumsq_colsum(dev):
+    from dig_amd import ops
+    n = 1 << 20
+    p, g = torch.randn(n, device=dev), torch.randn(n, device=dev) * 1e-2
+    m, v = torch.randn(n, device=dev) * 1e-3, torch.rand(n, device=dev) * 1e-5
+    p0, m0, v0 = p.clone(), m.clone(), v.clone()
+    sh = torch.empty(n, device=dev, dtype=torch.bfloat16)
+    flags = torch.zeros(n // 256, dtype=torch.uint8, device=dev); flags[n // 512:] = 1
+    ops.adamw_step(p, g, m, v, sh, flags, 1e-3, 0.1, 2e-3, 0.0, 0.9, 0.999, 1e-8, 3, 0.5)
+    ge = g * 0.5
+    rp = p0.clone(); rp[: n // 2] *= (1 - 1e-3 * 0.1)
+    rm, rv = m0 * 0.9 + ge * 0.1, v0 * 0.999 + ge * ge * 0.001
+    den = rv.sqrt() / math.sqrt(1 - 0.999 ** 3) + 1e-8
+    lr = torch.full((n,), 1e-3, device=dev); lr[n // 2:] = 2e-3
+    rp -= (lr / (1 - 0.9 ** 3)) * rm / den
+    assert float((p - rp).abs().max()) < 2e-6 and rel(m, rm) < 1e-6 and rel(v, rv) < 1e-6 and rel(sh, rp) < 5e-3
+    pm = torch.randn(n, device=dev); pm0 = pm.clone()
+    ops.ema_update(pm, p, sh, n, 0.99)
+    assert float((pm - (pm0 * 0.99 + p * (1 - 0.99))).abs().max()) < 1e-6
+    ws, o1 = torch.empty(1024, device=dev), torch.empty(1, device=dev)
+    ops.sumsq(g, ws, o1)
+    assert abs(o1.item() - (g.double() ** 2).sum().item()) < 1e-5 * (g.double() ** 2).sum().item()
+    xx = torch.randn(3000, 48, device=dev).bfloat16(); cs = torch.ones(48, device=dev)
+    ops.colsum(xx, cs)
+    assert rel(cs, 1 + xx.float().sum(0)) < 1e-5

@@ -1,0 +1,176 @@
+"""Host-side logic of the product package on CPU: model surface (state_dict layout), flat-arena invariants, param
+groups, schedules, checkpoint round trip, and the no-fallback rule.  No kernels run here."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import dig_oracle as O
+from dig_amd import utils as U
+from dig_amd.modeling_pretrain_moco_mim_ori import MoCo_ViT, ALIGN
+from dig_amd.optim_factory import create_optimizer, get_parameter_groups
+from dig_amd.registry import create_model
+
+KW = dict(pretrained=False, drop_path_rate=0.0, drop_block_rate=None, mlp_dim=4096, dim=256, T=0.2, num_windows=4,
+          encoder_type='vit', queue_size=65536, patchnet_name='no_patchtrans')
+
+
+@pytest.fixture(scope="module")
+def small():
+    torch.manual_seed(0)
+    return create_model("pretrain_simmim_moco_ori_vit_small_patch4_32x128", **KW)
+
+
+def tiny_model():
+    cfg = O.DiGConfig(**O.TINY)
+    return cfg, MoCo_ViT(encoder_embed_dim=cfg.embed_dim, encoder_depth=cfg.depth, encoder_num_heads=cfg.heads,
+                         decoder_embed_dim=cfg.dec_dim, mlp_dim=cfg.moco_mlp_dim, dim=cfg.moco_dim, T=cfg.T, num_windows=4,
+                         use_pixel_target=True, patchnet_name='no_patchtrans')
+
+
+def test_state_dict_layout_matches_reference_inventory(small):
+    cfg = O.make_config("pretrain_simmim_moco_ori_vit_small_patch4_32x128")
+    ref_p, ref_b = O.param_shapes(cfg), O.buffer_shapes(cfg)
+    named = list(small.named_parameters())
+    assert [n for n, _ in named] == list(ref_p.keys())                       # names AND order
+    assert all(tuple(p.shape) == ref_p[n] for n, p in named)
+    sd = small.state_dict()
+    assert len(sd) == 398
+    for n, shp in ref_b.items():
+        assert tuple(sd[n].shape) == shp, n
+    assert sd["encoder_projection_layer.1.num_batches_tracked"].dtype == torch.int64
+    assert [n for n, p in named if not p.requires_grad] == [n for n in ref_p if not O.is_trainable(n)]
+    assert sum(p.numel() for _, p in named if p.requires_grad) == 43606192
+    assert "pos_embed" not in " ".join(sd.keys()) and small.encoder.pos_embed.shape == (1, 256, 384)
+    assert small.encoder.patch_embed.patch_size == (4, 4) and small.no_weight_decay() == {'pos_embed', 'cls_token'}
+
+
+def test_pos_embed_equals_reference_formula(small):
+    assert torch.equal(small.encoder.pos_embed[0], O.sinusoid_table(256, 384))
+
+
+def test_arena_layout_invariants(small):
+    m = small
+    offs = sorted((s.offset, s.numel, n) for n, s in m.specs.items() if s.arena == "online")
+    for (o1, n1, a), (o2, n2, b) in zip(offs, offs[1:]):
+        assert o1 + n1 <= o2, (a, b)                                          # no overlap
+    for n, s in m.specs.items():
+        if not n.endswith("attn.v_bias"):
+            assert s.offset % ALIGN == 0, n                                   # 1 KiB granules (AdamW group table, 16-B GEMM alignment)
+        p = dict(m.named_parameters())[n]
+        assert p.data_ptr() == m._flat[s.arena].data_ptr() + 4 * s.offset     # parameters are views of the arena
+        if s.arena == "online":
+            assert p.grad is not None and p.grad.data_ptr() == m._flat["grad"].data_ptr() + 4 * s.offset
+    # q_bias | zeros | v_bias bundle = the fused-QKV bias vector
+    D = m.D
+    for i in range(m.depth):
+        q, v = m.specs[f"encoder.blocks.{i}.attn.q_bias"], m.specs[f"encoder.blocks.{i}.attn.v_bias"]
+        assert v.offset == q.offset + 2 * D
+        assert torch.count_nonzero(m._flat["online"][q.offset + D:q.offset + 2 * D]) == 0
+    # momentum arena mirrors the EMA-source prefix of the online arena
+    for src, dst in O.ema_pairs([n for n in m.specs if m.specs[n].arena == "online"]):
+        assert m.specs[src].offset == m.specs[dst].offset and m.specs[src].offset + m.specs[src].numel <= m.n_ema
+    # gradient buckets tile the online arena exactly, in backward order
+    rng = sorted(m.bucket_range(k) for k in m.bucket_names)
+    assert rng[0][0] == 0 and rng[-1][1] == m.n_online
+    assert all(a[1] == b[0] for a, b in zip(rng, rng[1:]))
+
+
+def test_param_groups_follow_reference_rule(small):
+    decay, no_decay = get_parameter_groups(small, 0.1, small.no_weight_decay())
+    od, ond = O.param_groups(OrderedDictLike(small), 0.1)
+    assert decay == od and no_decay == ond
+    groups = small.flat_groups
+    for n in decay + no_decay:
+        s = small.specs[n]
+        g = groups[s.offset // ALIGN:(s.offset + s.numel + ALIGN - 1) // ALIGN]
+        assert bool((g == (0 if n in decay else 1)).all()), n
+    assert "encoder.mask_token" in decay                                      # [1,1,D] is not 1-D: it decays in the reference
+
+
+class OrderedDictLike(dict):
+    def __init__(self, model):
+        super().__init__((n, p) for n, p in model.named_parameters())
+
+
+def test_optimizer_surface(small):
+    args = types.SimpleNamespace(opt="adamw", lr=3e-4, weight_decay=0.1, opt_eps=1e-8, opt_betas=[0.9, 0.999])
+    opt = create_optimizer(args, small)
+    assert len(opt.param_groups) == 2
+    g0, g1 = opt.param_groups
+    assert g0["weight_decay"] == 0.1 and g1["weight_decay"] == 0.0 and g0["lr_scale"] == g1["lr_scale"] == 1.0
+    assert g0["lr"] == 3e-4 and tuple(g0["betas"]) == (0.9, 0.999) and g0["eps"] == 1e-8
+    assert sum(p.numel() for g in opt.param_groups for p in g["params"]) == 43606192
+    with pytest.raises(NotImplementedError):
+        create_optimizer(types.SimpleNamespace(opt="sgd", lr=1.0, weight_decay=0.0), small)
+
+
+def test_schedules_bit_exact(golden_dir):
+    g = np.load(os.path.join(golden_dir, "masks_schedules.npz"))
+    assert np.array_equal(g["sched/lr"], U.cosine_scheduler(1.5e-4 * 4, 1e-5, 10, 50, warmup_epochs=1))
+    assert np.array_equal(g["sched/lr_ws"], U.cosine_scheduler(6e-4, 1e-5, 10, 50, warmup_epochs=1, warmup_steps=20))
+    assert np.array_equal(g["sched/wd"], U.cosine_scheduler(0.1, 0.1, 10, 50))
+    a = types.SimpleNamespace(epochs=10, moco_m=0.99)
+    assert np.array_equal(g["sched/moco_m"], np.array([U.adjust_moco_momentum(e / 7.0, a) for e in range(70)]))
+    with pytest.raises(AssertionError):                                       # the reference's quirk is kept
+        U.cosine_scheduler(6e-4, 1e-5, 10, 50, warmup_epochs=0, warmup_steps=20)
+
+
+def test_state_dict_roundtrip_and_checkpoint(tmp_path):
+    cfg, m = tiny_model()
+    P, S = O.det_state(cfg, 9)
+    m.load_state_dict({**P, **S})
+    sd = m.state_dict()
+    for k, v in {**P, **S}.items():
+        assert torch.equal(sd[k], v), k
+    args = types.SimpleNamespace(opt="adamw", lr=1e-3, weight_decay=0.1, opt_eps=1e-8, opt_betas=None, output_dir=str(tmp_path),
+                                 auto_resume=True, resume="", start_epoch=0)
+    opt = create_optimizer(args, m)
+    scaler = U.NativeScalerWithGradNormCount()
+    U.save_model(args, 3, m, m, opt, scaler)
+    U.save_model(args, 12, m, m, opt, scaler)
+    _, m2 = tiny_model()
+    opt2 = create_optimizer(args, m2)
+    U.auto_load_model(args, m2, m2, opt2, scaler)
+    assert args.resume.endswith("checkpoint-12.pth") and args.start_epoch == 13
+    for (n, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), n
+    ck = torch.load(args.resume, map_location="cpu", weights_only=False)
+    assert set(ck.keys()) == {"model", "optimizer", "epoch", "scaler", "args"} and ck["scaler"]["scale"] == 1.0
+
+
+def test_to_device_keeps_views_bound():
+    _, m = tiny_model()
+    m2 = m.to(torch.device("cpu"))
+    assert m2 is m
+    p = dict(m.named_parameters())["pix_decoder.4.bias"]
+    with torch.no_grad():
+        m.flat_params.fill_(0.25)
+    assert float(p[0]) == 0.25 and p.grad.data_ptr() == m.flat_grads.data_ptr() + 4 * m.specs["pix_decoder.4.bias"].offset
+
+
+def test_no_cpu_fallback():
+    cfg, m = tiny_model()
+    im, au, mk = O.synthetic_batch(2, cfg, 1)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(im, au, mk.bool(), 0.99, True)
+
+
+def test_unsupported_variants_fail_loudly():
+    with pytest.raises(NotImplementedError):
+        MoCo_ViT(use_pixel_target=False, patchnet_name='no_patchtrans')
+    with pytest.raises(NotImplementedError):
+        MoCo_ViT(use_pixel_target=True, patchnet_name='regular')
+    with pytest.raises(RuntimeError):
+        create_model("no_such_model")
+
+
+def test_product_package_never_imports_the_oracle():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for dirpath, _, files in os.walk(os.path.join(root, "dig_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "dig_oracle" not in src and "oracle" + "/" not in src, f
