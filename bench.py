@@ -119,8 +119,12 @@ def main():
     from dig_amd.engine_for_pretraining_moco import train_one_epoch
     from dig_amd.parallel import DistributedDataParallel
 
+    # logs (ours, and banners native libraries such as RCCL write to fd 1) -> stderr; stdout carries the single JSON line
+    sys.stdout.flush()
+    saved_fd1 = os.dup(1)
+    os.dup2(2, 1)
     stdout = sys.stdout
-    sys.stdout = sys.stderr                                # logs -> stderr; stdout carries the single JSON line
+    sys.stdout = sys.stderr
     dargs = types.SimpleNamespace()
     U.init_distributed_mode(dargs)
     world, rank = U.get_world_size(), U.get_rank()
@@ -133,7 +137,8 @@ def main():
     model = create_model(model_name, pretrained=False, drop_path_rate=0.0, drop_block_rate=None, mlp_dim=4096, dim=256, T=0.2,
                          num_windows=4, encoder_type='vit', queue_size=65536, patchnet_name='no_patchtrans')
     model.to(dev)
-    run_model = DistributedDataParallel(model) if world > 1 else model
+    force_dist = world > 1 or (os.environ.get("DIG_FORCE_DIST") == "1" and torch.distributed.is_initialized())
+    run_model = DistributedDataParallel(model) if force_dist else model
     B = a.batch
     args = types.SimpleNamespace(num_view=2, moco_m=0.99, use_moco_m_cos=1, epochs=10, contrast_start_epoch=0, contrast_warmup_steps=0,
                                  loss_weight_contrast=0.1, loss_weight_pixel=1.0, only_mim_on_ori_img=True, eval_freq=500, opt='adamw',
@@ -169,8 +174,10 @@ def main():
     # ---- roofline of the dominant kernel: one extra, instrumented step (outside the timed region)
     roof = None
     if rank == 0:
+        model.overlap_streams = False                 # kernels one at a time, so event brackets time single launches
         with GemmProbe() as probe:
             run(2, a.warmup + a.steps)
+        model.overlap_streams = True
         summ = probe.summary()
         dom = max(summ, key=lambda k: summ[k]["seconds"])
         d = summ[dom]
@@ -180,7 +187,13 @@ def main():
                 "avg_launch_us": d["seconds"] / d["launches"] * 1e6, "launches_per_step": d["launches"] // 2,
                 "by_variant": {k: {"TFLOP/s": v["flops"] / v["seconds"] / 1e12, "ms_per_step": v["seconds"] / 2 * 1e3,
                                    "launches_per_step": v["launches"] // 2} for k, v in summ.items()}}
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os.dup2(saved_fd1, 1)
     sys.stdout = stdout
+    if torch.distributed.is_initialized():
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
     if rank != 0:
         return
     value = a.steps * B * world / dt

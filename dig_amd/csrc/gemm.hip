@@ -97,7 +97,14 @@ struct TileCfg {
   static constexpr int NIT = TILE_BYTES / 16 / 256;     // 16-B pieces per thread per operand tile
 };
 
-template <bool TA, bool TB, int OUT, int BK>
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// NSTG-stage LDS ring: (NSTG-1) K-tiles of operand data are in flight while one is being multiplied; the hand-off is a
+// counted s_waitcnt vmcnt + raw s_barrier (a __syncthreads() would drain every LDS-DMA in flight).
+template <bool TA, bool TB, int OUT, int BK, bool RES, int NSTG>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
   constexpr int TILE_BYTES = TileCfg<BK>::TILE_BYTES;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -148,12 +155,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
-  if (nt > 0) {
-    stage(0);
-    __syncthreads();
+  {
+    constexpr int LA = NSTG - 1;                                   // look-ahead (stages in flight)
+    constexpr int LPS = 2 * TileCfg<BK>::NIT;                      // LDS-DMA instructions per thread per stage
+#pragma unroll
+    for (int q = 0; q < LA; ++q)
+      if (q < nt) stage(q);
     for (int t = 0; t < nt; ++t) {
-      if (t + 1 < nt) stage((t + 1) & 1);
-      const unsigned char* at = smem + (t & 1) * 2 * TILE_BYTES;
+      if (t + LA - 1 < nt) wait_vmcnt<(LA - 1) * LPS>(); else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();                                // stage t landed for every wave; slot (t-1)%NSTG is free
+      if (t + LA < nt) stage((t + LA) % NSTG);
+      const unsigned char* at = smem + (t % NSTG) * 2 * TILE_BYTES;
       const unsigned char* bt = at + TILE_BYTES;
 #pragma unroll
       for (int s = 0; s < BK / 16; ++s) {
@@ -169,8 +181,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
           for (int b = 0; b < 2; ++b)
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[b], af[a], acc[a][b], 0, 0, 0);
       }
-      __syncthreads();
     }
+    __syncthreads();                                               // every wave is done with the ring: reuse it as staging
   }
 
   // ---- epilogue: C-shuffle.  Each wave parks its 64x64 fp32 tile in its own 16 KiB of the (now idle) LDS with a
@@ -182,8 +194,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
   const bool jok = j < p.J;                                        // J % 8 == 0 (host-checked)
   const int jc = jok ? j : 0;
   // issue every global read of the epilogue up front (rows clamped, so the loads are unconditional and overlap)
-  uint4 rres[8];
-  if (OUT != 2 && p.resid) {
+  uint4 rres[RES ? 8 : 1];
+  if (RES) {
 #pragma unroll
     for (int ps = 0; ps < 8; ++ps) {
       const int i = min(i0 + wi * 64 + ps * 8 + (lane >> 3), p.I - 1);
@@ -217,9 +229,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
               make_float4(acc[a][b][g * 4], acc[a][b][g * 4 + 1], acc[a][b][g * 4 + 2], acc[a][b][g * 4 + 3]);
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    // wave-local LDS hand-off: only LDS ordering is needed (a memory fence here would also drain vmcnt, i.e. wait for
+    // the previous half's global stores to land)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int ps = a * 4 + q;
@@ -245,12 +258,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
               make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
-      } else if (p.act == 2) {                                     // multiply by gelu'(pre): fused GELU backward (fc2 dgrad)
+      } else if (RES && p.act == 2) {                              // multiply by gelu'(pre): fused GELU backward (fc2 dgrad)
         const unsigned w[4] = {rres[ps].x, rres[ps].y, rres[ps].z, rres[ps].w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) { v[2 * e] *= dgelu_f(bf2f((bf16_t)(w[e] & 0xffff))); v[2 * e + 1] *= dgelu_f(bf2f((bf16_t)(w[e] >> 16))); }
       }
-      if (p.resid && p.act != 2) {
+      if (RES && p.act != 2) {
         const unsigned w[4] = {rres[ps].x, rres[ps].y, rres[ps].z, rres[ps].w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) { v[2 * e] += bf2f((bf16_t)(w[e] & 0xffff)); v[2 * e + 1] += bf2f((bf16_t)(w[e] >> 16)); }
@@ -265,9 +278,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
         *reinterpret_cast<float4*>(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    // wave-local LDS hand-off: only LDS ordering is needed (a memory fence here would also drain vmcnt, i.e. wait for
+    // the previous half's global stores to land)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
 }
 
@@ -284,17 +298,17 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
   }
 }
 
-template <bool TA, bool TB, int OUT, int BK>
+template <bool TA, bool TB, int OUT, int BK, bool RES, int NSTG>
 int launch(const GemmParams& p, int splits, hipStream_t stream) {
-  constexpr int LDS = (4 * BI * BK * 2) > 32768 ? (4 * BI * BK * 2) : 32768;     // 2 stages x (A,B) tiles; >= epilogue staging
+  constexpr int LDS = (NSTG * 2 * BI * BK * 2) > 32768 ? (NSTG * 2 * BI * BK * 2) : 32768;   // ring; >= epilogue staging
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<TA, TB, OUT, BK>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<TA, TB, OUT, BK, RES, NSTG>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_set = true;
   }
   dim3 grid(p.tiles_i * p.tiles_j, 1, splits);
-  hipLaunchKernelGGL((gemm_kernel<TA, TB, OUT, BK>), grid, dim3(256), LDS, stream, p);
+  hipLaunchKernelGGL((gemm_kernel<TA, TB, OUT, BK, RES, NSTG>), grid, dim3(256), LDS, stream, p);
   return dig_check_launch();
 }
 
@@ -307,7 +321,7 @@ extern "C" int dig_gemm_bf16(const void* A, const void* B, void* C, int I, int J
                              int b_rows, int bk, hipStream_t stream) {
   if (!A || !B || !C || I <= 0 || J <= 0 || R <= 0 || splits < 1) return DIG_ERR_ARG;
   if (bias && !aligned16(bias)) return DIG_ERR_ALIGN;
-  if (out_kind < 0 || out_kind > 2 || act < 0 || act > 2 || (bk != 0 && bk != 32 && bk != 64)) return DIG_ERR_ARG;
+  if (out_kind < 0 || out_kind > 2 || act < 0 || act > 2 || (bk != 0 && bk != 32 && bk != 33 && bk != 34 && bk != 64)) return DIG_ERR_ARG;
   if (act == 2 && !resid) return DIG_ERR_ARG;                   // act 2: resid carries the saved pre-activation
   if (bk == 0) bk = 64;
   if (!aligned16(A) || !aligned16(B) || !aligned16(C) || (lda & 7) || (ldb & 7)) return DIG_ERR_ALIGN;
@@ -333,7 +347,10 @@ extern "C" int dig_gemm_bf16(const void* A, const void* B, void* C, int I, int J
   p.tiles_i = (I + BI - 1) / BI; p.tiles_j = (J + BJ - 1) / BJ;
 #define DIG_GEMM_CASE(ta, tb, o)                                                \
   if ((trans_a != 0) == ta && (trans_b != 0) == tb && out_kind == o)           \
-    return bk == 64 ? launch<ta, tb, o, 64>(p, splits, stream) : launch<ta, tb, o, 32>(p, splits, stream);
+    return bk == 64 ? (resid ? launch<ta, tb, o, 64, true, 2>(p, splits, stream) : launch<ta, tb, o, 64, false, 2>(p, splits, stream)) \
+         : bk == 32 ? (resid ? launch<ta, tb, o, 32, true, 2>(p, splits, stream) : launch<ta, tb, o, 32, false, 2>(p, splits, stream)) \
+         : bk == 33 ? (resid ? launch<ta, tb, o, 32, true, 3>(p, splits, stream) : launch<ta, tb, o, 32, false, 3>(p, splits, stream)) \
+                    : (resid ? launch<ta, tb, o, 32, true, 4>(p, splits, stream) : launch<ta, tb, o, 32, false, 4>(p, splits, stream));
   DIG_GEMM_CASE(false, false, 0)
   DIG_GEMM_CASE(false, false, 1)
   DIG_GEMM_CASE(false, true, 0)

@@ -198,6 +198,21 @@ class _Step:
         self.images, self.aug, self.mask_u8 = images, aug, mask_u8
         ew_on, ew_mo = _weights(M)
         ops.cast_f32_to_bf16(M._flat["online"], M.shadow("online"))
+        # ---- momentum branch (no grad) on a second HIP stream: it depends only on the pre-step online weights (fp32
+        # arena, read-only here) and the inputs, so it overlaps the online forward.  EMA with the current online weights
+        # comes first (:526).
+        main = torch.cuda.current_stream(dev)
+        side = M._side_stream(dev) if getattr(M, "overlap_streams", True) else main
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            ops.ema_update(M._flat["momentum"], M._flat["online"], M.shadow("momentum"), M.n_ema, m)
+            enc_m, _ = self.encoder_forward(ew_mo, images, aug, mask_u8, False)
+            masked_m, _ = self.mlp_forward(enc_m[:B * N], "pix_projector_m", "momentum", False)
+            pooled_m = torch.empty((2 * B * nw, D), device=dev, dtype=BF16)
+            ops.window_pool_fwd(masked_m, pooled_m[:B * nw], B, M.gh, M.gw, nw, D)
+            ops.window_pool_fwd(enc_m[B * N:], pooled_m[B * nw:], B, M.gh, M.gw, nw, D)
+            ks, _ = self.mlp_forward(pooled_m, "momentum_projection_layer", "momentum", False)
+            del enc_m, masked_m, pooled_m
         # ---- online branch
         enc, self.saved_enc = self.encoder_forward(ew_on, images, aug, mask_u8, True)
         self.enc = enc
@@ -207,15 +222,8 @@ class _Step:
         ops.window_pool_fwd(enc[B * N:], pooled[B * nw:], B, M.gh, M.gw, nw, D)
         qs, self.saved_proj = self.mlp_forward(pooled, "encoder_projection_layer", "online", True)
         qs, self.saved_pred = self.mlp_forward(qs, "predictor", "online", True)
-        # ---- momentum branch (no grad): EMA with the current online weights first (:526)
-        ops.ema_update(M._flat["momentum"], M._flat["online"], M.shadow("momentum"), M.n_ema, m)
-        enc_m, _ = self.encoder_forward(ew_mo, images, aug, mask_u8, False)
-        masked_m, _ = self.mlp_forward(enc_m[:B * N], "pix_projector_m", "momentum", False)
-        pooled_m = torch.empty((2 * B * nw, D), device=dev, dtype=BF16)
-        ops.window_pool_fwd(masked_m, pooled_m[:B * nw], B, M.gh, M.gw, nw, D)
-        ops.window_pool_fwd(enc_m[B * N:], pooled_m[B * nw:], B, M.gh, M.gw, nw, D)
-        ks, _ = self.mlp_forward(pooled_m, "momentum_projection_layer", "momentum", False)
-        del enc_m, masked_m, pooled_m
+        main.wait_stream(side)
+        ks.record_stream(main)
         M._flat["bn_count"] += 1                                            # all 14 BatchNorm layers ran once
         # ---- InfoNCE (:444-461): q1 vs gathered k2, q2 vs gathered k1, labels = arange + n*rank
         n = B * nw                                                          # rows of q1 / q2

@@ -383,6 +383,13 @@ class MoCo_ViT(nn.Module):
                             if s.arena == arena and len(s.shape) >= 2 and not n.endswith("mask_token")}
         return cache[arena]
 
+    def _side_stream(self, dev):
+        """Second HIP stream for the gradient-free momentum branch (overlaps the online forward)."""
+        st = getattr(self, "_side", None)
+        if st is None or st.device != dev:
+            st = self._side = torch.cuda.Stream(device=dev)
+        return st
+
     def _mask_count(self, mask_u8, B):
         """Masked tokens per sample of view 0 (the reference reshapes to [B, -1, C], so it is constant over the
         batch).  Read back once and cached: per-step validation happens where the engine synchronises anyway."""

@@ -40,10 +40,27 @@ def gemm(A, B, I, J, R, *, ta=False, tb=False, out=None, out_kind=OUT_BF16, bias
     return out
 
 
+USE_PANEL = False     # A-resident GEMM (csrc/gemm_panel.hip): correct but slower than the tile kernel at 4 waves/CU -- see DESIGN.md 4
+
+
+def gemm_panel(A, B, I, J, K, *, out=None, out_kind=OUT_BF16, bias=None, resid=None, pre=None, alpha=1.0, alpha_cols=0, act=0):
+    if out is None:
+        out = torch.empty((I, J), device=A.device, dtype=BF16 if out_kind == OUT_BF16 else F32)
+    L.call("dig_gemm_panel_bf16", L.ptr(A), L.ptr(B), L.ptr(out), I, J, K, A.stride(0), B.stride(0), out.stride(0), out_kind,
+           L.ptr(bias), L.ptr(resid), resid.stride(0) if resid is not None else 0, L.ptr(pre), pre.stride(0) if pre is not None else 0,
+           cf(alpha), alpha_cols, act, L.stream())
+    return out
+
+
 def linear_fwd(x, w, *, bias=None, resid=None, act=0, pre=None, alpha=1.0, alpha_cols=0, out=None, out_kind=OUT_BF16):
     """y[rows,out] = x[rows,in] @ w[out,in]^T (+bias)(gelu)(+resid)."""
+    K = w.shape[1]
+    if USE_PANEL and K % 128 == 0 and K <= 384 and x.shape[0] >= 1024 and not (pre is not None and resid is not None):
+        return gemm_panel(x, w, x.shape[0], w.shape[0], K, bias=bias, resid=resid, act=act, pre=pre, alpha=alpha,
+                          alpha_cols=alpha_cols, out=out, out_kind=out_kind)
+    bk = 32 if (act == 1 and pre is not None) else 0          # store-heavy epilogue: 4 workgroups/CU hide it better
     return gemm(x, w, x.shape[0], w.shape[0], w.shape[1], bias=bias, resid=resid, act=act, pre=pre, alpha=alpha,
-                alpha_cols=alpha_cols, out=out, out_kind=out_kind)
+                alpha_cols=alpha_cols, out=out, out_kind=out_kind, bk=bk)
 
 
 def linear_dgrad(dy, w, out=None, gelu_pre=None):

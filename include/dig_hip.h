@@ -45,6 +45,11 @@ int dig_gemm_bf16(const void* A, const void* B, void* C, int I, int J, int R, in
                   int trans_b, int out_kind, const float* bias, const void* resid, int ldr, void* pre_act, int ldp, float alpha,
                   int alpha_cols, int act, int splits, int a_rows, int b_rows, int bk, hipStream_t stream);
 int dig_gemm_effective_splits(int R, int splits);
+/* Forward-layout GEMM (trans_a = trans_b = 0, out_kind 0/1) with the 128-row A panel resident in LDS and the weight
+ * tiles streamed through a 3-stage ring across N-tiles; same epilogue contract.  K % 128 == 0 and K <= 384, else -4. */
+int dig_gemm_panel_bf16(const void* A, const void* B, void* C, int I, int J, int K, int lda, int ldb, int ldc, int out_kind,
+                        const float* bias, const void* resid, int ldr, void* pre_act, int ldp, float alpha, int alpha_cols,
+                        int act, hipStream_t stream);
 /* out[e] (+)= sum_s partials[s][e], e < n  (deterministic split-R combine; accumulate=1 adds into the gradient arena) */
 int dig_reduce_partials(const float* partials, int splits, long long n, float* out, int accumulate, hipStream_t stream);
 
