@@ -100,38 +100,58 @@ class _Step:
         return x, saved
 
     def encoder_backward(self, ew, saved, dx, images, aug, mask_u8):
-        """dx: bf16 [R, D] gradient w.r.t. the encoder output (consumed)."""
+        """dx: bf16 [R, D] gradient w.r.t. the encoder output (consumed).
+        The data-gradient chain (dgrad GEMMs, attention backward, LayerNorm backward) runs on the caller's stream; the
+        weight-gradient GEMMs and bias column sums only consume (dy, saved activation) pairs, so they are issued on a
+        second HIP stream and overlap the chain (both are latency-bound kernels that leave CU resources idle)."""
         M = self.m
         B, D, H, N = images.shape[0], M.D, M.H, M.N
         scale = (D // H) ** -0.5
+        dev = dx.device
+        main = torch.cuda.current_stream(dev)
+        side = M._side_stream(dev) if getattr(M, "overlap_streams", True) else main
+
+        def on_side(fn, *tensors):
+            if side is main:
+                fn()
+                return
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                fn()
+            for t in tensors:
+                t.record_stream(side)
+
         for i in reversed(range(M.depth)):
             blk, g = ew.blocks[i], ew.blocks[i]["g"]
             x, ln1, mu1, rs1, qkv, ctx, lse, x_mid, ln2, mu2, rs2, pre, act = saved[i]
             saved[i] = None
             # x_out = x_mid + fc2(gelu(fc1(ln2)))
-            ops.linear_wgrad(dx, act, g["mlp.fc2.weight"])
+            on_side(lambda: ops.linear_wgrad(dx, act, g["mlp.fc2.weight"]), dx, act)
             dact = ops.linear_dgrad(dx, blk["mlp.fc2.weight"], gelu_pre=pre)       # d(pre-activation), GELU' fused
-            ops.linear_wgrad(dact, ln2, g["mlp.fc1.weight"])
-            ops.colsum(dact, g["mlp.fc1.bias"])
+            on_side(lambda: (ops.linear_wgrad(dact, ln2, g["mlp.fc1.weight"]), ops.colsum(dact, g["mlp.fc1.bias"])), dact, ln2)
             dln2 = ops.linear_dgrad(dact, blk["mlp.fc1.weight"])
-            del dact, pre, act
             dx_mid = ops.layernorm_bwd(dln2, x_mid, blk["norm2.weight"], blk["norm2.bias"], mu2, rs2, dx, g["norm2.weight"], g["norm2.bias"],
                                        out=dln2, dres_colsum=g["mlp.fc2.bias"])      # colsum(dx) = fc2 bias grad, fused
             # x_mid = x + proj(attn(ln1))
-            ops.linear_wgrad(dx_mid, ctx, g["attn.proj.weight"])
+            on_side(lambda: ops.linear_wgrad(dx_mid, ctx, g["attn.proj.weight"]), dx_mid, ctx)
             dctx = ops.linear_dgrad(dx_mid, blk["attn.proj.weight"])
             dqkv = ops.attn_bwd(qkv, ctx, dctx, lse, 2 * B, H, D, scale)
-            ops.linear_wgrad(dqkv, ln1, g["attn.qkv.weight"])
             gb = g["qkv_bias"]
-            ops.colsum(dqkv, gb[:D], cols=D)                              # q_bias (dq already carries the q scale)
-            ops.colsum(dqkv[:, 2 * D:], gb[2 * D:], cols=D)               # v_bias; K has no bias
+            on_side(lambda: (ops.linear_wgrad(dqkv, ln1, g["attn.qkv.weight"]),
+                             ops.colsum(dqkv, gb[:D], cols=D),                 # q_bias (dq already carries the q scale)
+                             ops.colsum(dqkv[:, 2 * D:], gb[2 * D:], cols=D)),  # v_bias; K has no bias
+                    dqkv, ln1)
             dln1 = ops.linear_dgrad(dqkv, blk["attn.qkv.weight"], out=dctx)
             dx = ops.layernorm_bwd(dln1, x, blk["norm1.weight"], blk["norm1.bias"], mu1, rs1, dx_mid, g["norm1.weight"], g["norm1.bias"],
                                    out=dln1, dres_colsum=g["attn.proj.bias"])            # colsum(dx_mid) = proj bias grad, fused
+            del dact, pre, act, dln2, dqkv, dctx
+            if self.comm.world > 1:
+                main.wait_stream(side)                                        # this block's gradients are final on both streams
             self.comm.grad_ready(M, f"encoder.blocks.{i}")
         for half, im in enumerate((images, aug)):
             ops.patch_embed_bwd_mfma(dx[half * B * N:(half + 1) * B * N], im, mask_u8[half * B:(half + 1) * B], ew.g_pe_w, ew.g_pe_b,
                                      ew.g_mask_token, D, M.gh, M.gw)
+        main.wait_stream(side)
         self.comm.grad_ready(M, "encoder.embed")
 
     # ------------------------------------------------------------------ BN-MLP heads

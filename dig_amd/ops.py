@@ -20,9 +20,10 @@ _ws = {}
 
 def _workspace(dev, numel):
     """Per-device fp32 scratch for split-R partial slabs (grown on demand, reused across launches on one stream)."""
-    w = _ws.get(dev)
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)        # one scratch per stream: launches on a stream are ordered
+    w = _ws.get(key)
     if w is None or w.numel() < numel:
-        w = _ws[dev] = torch.empty(max(numel, 1 << 22), device=dev, dtype=F32)
+        w = _ws[key] = torch.empty(max(numel, 1 << 22), device=dev, dtype=F32)
     return w
 
 
@@ -96,9 +97,10 @@ _ws2 = {}
 
 def _workspace2(dev, numel):
     """Second fp32 scratch (column-sum / LayerNorm-backward partials)."""
-    w = _ws2.get(dev)
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    w = _ws2.get(key)
     if w is None or w.numel() < numel:
-        w = _ws2[dev] = torch.empty(max(numel, 1 << 20), device=dev, dtype=F32)
+        w = _ws2[key] = torch.empty(max(numel, 1 << 20), device=dev, dtype=F32)
     return w
 
 
