@@ -504,6 +504,237 @@ int launch_persist(const GemmParams& p, int splits, hipStream_t stream) {
   return dig_check_launch();
 }
 
+// ----------------------------------------------------------------------------------------------------------------
+// Wide-tile variant: WM x WN waves of 64x64 each (256x256, 256x128 or 128x256 outputs per workgroup, BK = 64, 2 stages).
+// Per-wave code is the same as gemm_kernel; what changes is the operand traffic: a 256x256 tile moves half the L2->LDS
+// bytes per FLOP of a 128x128 tile, and that traffic (measured ~55 GB/s per CU) is what bounds the K-loop on MI355X.
+template <bool T, int COLS>
+__device__ __forceinline__ unsigned wstage_offset(int piece, int row0, int r0, int ld) {
+  if (!T) {
+    const int row = piece >> 3, pc = piece & 7;
+    const int c = pc ^ ((row >> 1) & 7);
+    return (unsigned)(((row0 + row) * ld + r0 + c * 8) * 2);
+  } else {
+    constexpr int NBLK = COLS / 16;
+    const int block = piece >> 3, w = piece & 7;
+    const int rr = w >> 1, half = w & 1;
+    const int rb = block / NBLK, nb = block % NBLK;
+    return (unsigned)(((r0 + rb * 4 + rr) * ld + row0 + nb * 16 + half * 8) * 2);
+  }
+}
+
+template <bool T, int COLS>
+__device__ __forceinline__ bf16x8 wload_frag(const unsigned char* tile, int rowoff, int s, int lane) {
+  if (!T) {
+    const int row = rowoff + (lane & 31);
+    const int chunk = 2 * s + (lane >> 5);
+    return *reinterpret_cast<const bf16x8*>(tile + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+  } else {
+    constexpr int NBLK = COLS / 16;
+    const int hi = lane >> 5;
+    const int nb = (rowoff >> 4) + ((lane >> 4) & 1);
+    const int rb = s * 4 + hi * 2;
+    const unsigned char* p0 = tile + (rb * NBLK + nb) * 128 + (lane & 15) * 8;
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(p0));
+    bf16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(p0 + NBLK * 128));
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi4[0]; r[5] = hi4[1]; r[6] = hi4[2]; r[7] = hi4[3];
+    return r;
+  }
+}
+
+template <int WM, int WN>
+struct WideCfg {
+  static constexpr int NT = 64 * WM * WN;
+  static constexpr int TBI = 64 * WM, TBJ = 64 * WN;
+  static constexpr int A_BYTES = TBI * 64 * 2, B_BYTES = TBJ * 64 * 2;
+  static constexpr int STAGE = A_BYTES + B_BYTES;
+  static constexpr int NITA = A_BYTES / 16 / NT, NITB = B_BYTES / 16 / NT;
+  static constexpr int LDS = (2 * STAGE > (NT / 64) * 8192) ? 2 * STAGE : (NT / 64) * 8192;
+};
+
+template <bool TA, bool TB, int OUT, int WM, int WN, bool RES>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_wide_kernel(GemmParams p) {
+  using Cfg = WideCfg<WM, WN>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wi = wave / WN, wj = wave % WN;
+
+  const int nblk = p.tiles_i * p.tiles_j;
+  const int bid = blockIdx.x;
+  const int q = nblk >> 3, rm = nblk & 7, xcd = bid & 7;
+  const int logical = (xcd < rm ? xcd * (q + 1) : rm * (q + 1) + (xcd - rm) * q) + (bid >> 3);
+  const int ti = logical / p.tiles_j, tj = logical - ti * p.tiles_j;
+  const int i0 = ti * Cfg::TBI, j0 = tj * Cfg::TBJ;
+  const int rbeg = blockIdx.z * p.r_per_split;
+  const int rend = min(p.R, rbeg + p.r_per_split);
+  const int nt = (rend - rbeg + 63) / 64;
+
+  const auto ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
+  const auto rb_ = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.b_bytes, 0x00020000);
+  unsigned offA[4], offB[4];
+#pragma unroll
+  for (int it = 0; it < Cfg::NITA; ++it) offA[it] = wstage_offset<TA, Cfg::TBI>(it * Cfg::NT + tid, i0, rbeg, p.lda);
+#pragma unroll
+  for (int it = 0; it < Cfg::NITB; ++it) offB[it] = wstage_offset<TB, Cfg::TBJ>(it * Cfg::NT + tid, j0, rbeg, p.ldb);
+  const unsigned stepA = TA ? (unsigned)(64 * p.lda * 2) : 128u;
+  const unsigned stepB = TB ? (unsigned)(64 * p.ldb * 2) : 128u;
+  auto stage = [&](int slot) {
+    unsigned char* a = smem + slot * Cfg::STAGE + wave * 1024;
+    unsigned char* b = a + Cfg::A_BYTES;
+#pragma unroll
+    for (int it = 0; it < Cfg::NITA; ++it) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, LDS_PTR(a + it * Cfg::NT * 16), 16, offA[it], 0, 0, 0);
+      offA[it] += stepA;
+    }
+#pragma unroll
+    for (int it = 0; it < Cfg::NITB; ++it) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_, LDS_PTR(b + it * Cfg::NT * 16), 16, offB[it], 0, 0, 0);
+      offB[it] += stepB;
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+  if (nt > 0) stage(0);
+  for (int t = 0; t < nt; ++t) {
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (t + 1 < nt) stage((t + 1) & 1);
+    const unsigned char* at = smem + (t & 1) * Cfg::STAGE;
+    const unsigned char* bt = at + Cfg::A_BYTES;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      bf16x8 af[2], bfr[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        af[u] = wload_frag<TA, Cfg::TBI>(at, wi * 64 + u * 32, s, lane);
+        bfr[u] = wload_frag<TB, Cfg::TBJ>(bt, wj * 64 + u * 32, s, lane);
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[b], af[a], acc[a][b], 0, 0, 0);
+    }
+  }
+  __syncthreads();
+
+  // ---- epilogue (C-shuffle per wave, two 32-row halves; same contract as gemm_kernel)
+  const int cg = lane & 7;
+  const int j = j0 + wj * 64 + cg * 8;
+  const bool jok = j < p.J;
+  const int jc = jok ? j : 0;
+  float bias8[8];
+  if (OUT != 2 && p.bias) {
+    const float4 b0 = *reinterpret_cast<const float4*>(p.bias + jc);
+    const float4 b1 = *reinterpret_cast<const float4*>(p.bias + jc + 4);
+    bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w;
+    bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
+  }
+  float* stg = reinterpret_cast<float*>(smem + wave * 8192);
+  const float al = (j < p.alpha_cols) ? p.alpha : 1.0f;
+  float* cpart = reinterpret_cast<float*>(p.C);
+  if (OUT == 2) cpart += (size_t)blockIdx.z * p.I * p.ldc;
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    uint4 rres[RES ? 4 : 1];
+    if (RES) {
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const int i = min(i0 + wi * 64 + a * 32 + q4 * 8 + (lane >> 3), p.I - 1);
+        rres[q4] = *reinterpret_cast<const uint4*>(p.resid + (size_t)i * p.ldr + jc);
+      }
+    }
+    {
+      const int hi = lane >> 5, row = lane & 31;
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int chunk = (b * 32 + 8 * g + 4 * hi) >> 2;
+          *reinterpret_cast<float4*>(stg + row * 64 + ((chunk ^ (row & 15)) << 2)) =
+              make_float4(acc[a][b][g * 4], acc[a][b][g * 4 + 1], acc[a][b][g * 4 + 2], acc[a][b][g * 4 + 3]);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const int row = q4 * 8 + (lane >> 3);
+      const int i = i0 + wi * 64 + a * 32 + row;
+      const float4 x0 = *reinterpret_cast<const float4*>(stg + row * 64 + (((2 * cg) ^ (row & 15)) << 2));
+      const float4 x1 = *reinterpret_cast<const float4*>(stg + row * 64 + (((2 * cg + 1) ^ (row & 15)) << 2));
+      const bool live = (i < p.I) && jok;
+      float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+      if (OUT == 2) {
+        if (live) {
+          float* c = cpart + (size_t)i * p.ldc + j;
+          *reinterpret_cast<float4*>(c) = x0;
+          *reinterpret_cast<float4*>(c + 4) = x1;
+        }
+        continue;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (v[e] + bias8[e]) * al;
+      if (p.act == 1) {
+        if (p.pre && live)
+          *reinterpret_cast<uint4*>(p.pre + (size_t)i * p.ldp + j) =
+              make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+      } else if (RES && p.act == 2) {
+        const unsigned w[4] = {rres[q4].x, rres[q4].y, rres[q4].z, rres[q4].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[2 * e] *= dgelu_f(bf2f((bf16_t)(w[e] & 0xffff))); v[2 * e + 1] *= dgelu_f(bf2f((bf16_t)(w[e] >> 16))); }
+      }
+      if (RES && p.act != 2) {
+        const unsigned w[4] = {rres[q4].x, rres[q4].y, rres[q4].z, rres[q4].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[2 * e] += bf2f((bf16_t)(w[e] & 0xffff)); v[2 * e + 1] += bf2f((bf16_t)(w[e] >> 16)); }
+      }
+      if (!live) continue;
+      if (OUT == 0) {
+        *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)i * p.ldc + j) =
+            make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+      } else {
+        float* c = reinterpret_cast<float*>(p.C) + (size_t)i * p.ldc + j;
+        *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <bool TA, bool TB, int OUT, int WM, int WN, bool RES>
+int launch_wide(GemmParams p, int splits, hipStream_t stream) {
+  using Cfg = WideCfg<WM, WN>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wide_kernel<TA, TB, OUT, WM, WN, RES>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
+    attr_set = true;
+  }
+  p.tiles_i = (p.I + Cfg::TBI - 1) / Cfg::TBI;
+  p.tiles_j = (p.J + Cfg::TBJ - 1) / Cfg::TBJ;
+  dim3 grid(p.tiles_i * p.tiles_j, 1, splits);
+  hipLaunchKernelGGL((gemm_wide_kernel<TA, TB, OUT, WM, WN, RES>), grid, dim3(Cfg::NT), Cfg::LDS, stream, p);
+  return dig_check_launch();
+}
+
 // out[e] (+)= sum_s part[s][e]   (deterministic split-R combine; also the "+=" into the gradient arena)
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int splits, long long n4,
                                                               float* __restrict__ out, int accumulate) {
@@ -540,9 +771,9 @@ extern "C" int dig_gemm_bf16(const void* A, const void* B, void* C, int I, int J
                              int b_rows, int bk, hipStream_t stream) {
   if (!A || !B || !C || I <= 0 || J <= 0 || R <= 0 || splits < 1) return DIG_ERR_ARG;
   if (bias && !aligned16(bias)) return DIG_ERR_ALIGN;
-  if (out_kind < 0 || out_kind > 2 || act < 0 || act > 2 || (bk != 0 && bk != 32 && bk != 33 && bk != 34 && bk != 64 && bk != 132 && bk != 164)) return DIG_ERR_ARG;
+  if (out_kind < 0 || out_kind > 2 || act < 0 || act > 2 || (bk != 0 && bk != 32 && bk != 33 && bk != 34 && bk != 64 && bk != 132 && bk != 164 && bk != 244 && bk != 242 && bk != 224)) return DIG_ERR_ARG;
   if (act == 2 && !resid) return DIG_ERR_ARG;                   // act 2: resid carries the saved pre-activation
-  if (bk >= 100 && resid && pre_act) return DIG_ERR_UNSUPPORTED;
+  if (bk >= 100 && bk < 200 && resid && pre_act) return DIG_ERR_UNSUPPORTED;
   if (bk == 0) bk = 64;
   if (!aligned16(A) || !aligned16(B) || !aligned16(C) || (lda & 7) || (ldb & 7)) return DIG_ERR_ALIGN;
   if ((J & 7) || (ldc & 7) || (resid && ((ldr & 7) || !aligned16(resid))) || (pre_act && ((ldp & 7) || !aligned16(pre_act)))) return DIG_ERR_ALIGN;
@@ -565,6 +796,17 @@ extern "C" int dig_gemm_bf16(const void* A, const void* B, void* C, int I, int J
   p.r_per_split = ((rtiles + splits - 1) / splits) * BR;
   if ((R + p.r_per_split - 1) / p.r_per_split != splits) return DIG_ERR_ARG;   // use dig_gemm_effective_splits()
   p.tiles_i = (I + BI - 1) / BI; p.tiles_j = (J + BJ - 1) / BJ;
+#define DIG_GEMM_WCASE(ta, tb, o)                                                                                   \
+  if ((trans_a != 0) == ta && (trans_b != 0) == tb && out_kind == o && bk >= 200) {                                  \
+    if (bk == 244) return resid ? launch_wide<ta, tb, o, 4, 4, true>(p, splits, stream) : launch_wide<ta, tb, o, 4, 4, false>(p, splits, stream); \
+    if (bk == 242) return resid ? launch_wide<ta, tb, o, 4, 2, true>(p, splits, stream) : launch_wide<ta, tb, o, 4, 2, false>(p, splits, stream); \
+    return resid ? launch_wide<ta, tb, o, 2, 4, true>(p, splits, stream) : launch_wide<ta, tb, o, 2, 4, false>(p, splits, stream);               \
+  }
+  DIG_GEMM_WCASE(false, false, 0)
+  DIG_GEMM_WCASE(false, false, 1)
+  DIG_GEMM_WCASE(false, true, 0)
+  DIG_GEMM_WCASE(true, true, 2)
+#undef DIG_GEMM_WCASE
 #define DIG_GEMM_PCASE(ta, tb, o)                                                                                   \
   if ((trans_a != 0) == ta && (trans_b != 0) == tb && out_kind == o && bk >= 100) {                                  \
     const bool pre_ = pre_act != nullptr;                                                                            \

@@ -59,7 +59,16 @@ def linear_fwd(x, w, *, bias=None, resid=None, act=0, pre=None, alpha=1.0, alpha
     if USE_PANEL and K % 128 == 0 and K <= 384 and x.shape[0] >= 1024 and not (pre is not None and resid is not None):
         return gemm_panel(x, w, x.shape[0], w.shape[0], K, bias=bias, resid=resid, act=act, pre=pre, alpha=alpha,
                           alpha_cols=alpha_cols, out=out, out_kind=out_kind)
-    bk = 32 if (act == 1 and pre is not None) else 0          # store-heavy epilogue: 4 workgroups/CU hide it better
+    # tile variant per layer shape, measured on MI355X (profiles/r01_gemm_variants.txt, tools/gpu_bk_probe.py):
+    #   tall layers: 256x256 tiles (16 waves) halve the L2->LDS operand traffic per FLOP;  small GELU layers: BK=32,
+    #   4 workgroups/CU hide the VALU + double-store epilogue;  everything else: the default 128x128 / BK=64.
+    rows = x.shape[0]
+    if rows >= 8192 and w.shape[0] >= 384 and rows * w.shape[0] >= (1 << 24):
+        bk = 244
+    elif act == 1:
+        bk = 32
+    else:
+        bk = 0
     return gemm(x, w, x.shape[0], w.shape[0], w.shape[1], bias=bias, resid=resid, act=act, pre=pre, alpha=alpha,
                 alpha_cols=alpha_cols, out=out, out_kind=out_kind, bk=bk)
 
