@@ -182,8 +182,16 @@ def main():
         dom = max(summ, key=lambda k: summ[k]["seconds"])
         d = summ[dom]
         ach = d["flops"] / d["seconds"] / 1e12
-        roof = {"bound": "mfma", "kernel": f"gemm_kernel[{dom}] (dig_gemm_bf16, 128x128x64 v_mfma_f32_32x32x16_bf16)",
-                "achieved": ach, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": ach / (PEAK_BF16 / 1e12), "traffic": None,
+        traffic = None
+        try:                                   # HBM bytes per launch from the committed PMC profile of this same command
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                traffic = json.load(f)["kernels"][dom]["hbm_bytes_per_launch"]
+        except Exception:
+            pass
+        roof = {"bound": "mfma", "kernel": f"dig_gemm_bf16[{dom}] (gemm_kernel / gemm_wide_kernel, v_mfma_f32_32x32x16_bf16)",
+                "achieved": ach, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": ach / (PEAK_BF16 / 1e12), "traffic": traffic,
+                "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 gfx950 correction)" if traffic else None,
+                "flops_per_launch": d["flops"] / d["launches"],
                 "avg_launch_us": d["seconds"] / d["launches"] * 1e6, "launches_per_step": d["launches"] // 2,
                 "by_variant": {k: {"TFLOP/s": v["flops"] / v["seconds"] / 1e12, "ms_per_step": v["seconds"] / 2 * 1e3,
                                    "launches_per_step": v["launches"] // 2} for k, v in summ.items()}}

@@ -291,17 +291,31 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
   }
 }
 
-// out[c] += sum_b partial[b][c]; 32 columns x 8 row-groups per block
+// out[c] += sum_b partial[b][c]; a block owns 8 columns: 2 float4 lanes x 128 row-groups (C % 8 == 0)
 __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ partial, int nb, int C, float* __restrict__ out) {
-  __shared__ float red[8][32];
-  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cx;
-  float a = 0.f;
-  if (c < C)
-    for (int b = ry; b < nb; b += 8) a += partial[(size_t)b * C + c];
+  __shared__ float4 red[128][2];
+  const int cx = threadIdx.x & 1, ry = threadIdx.x >> 1;
+  const int c = blockIdx.x * 8 + cx * 4;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int b = ry; b < nb; b += 128) {
+    const float4 v = *reinterpret_cast<const float4*>(partial + (size_t)b * C + c);
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  }
   red[ry][cx] = a;
   __syncthreads();
-  if (ry == 0 && c < C) out[c] += red[0][cx] + red[1][cx] + red[2][cx] + red[3][cx] + red[4][cx] + red[5][cx] + red[6][cx] + red[7][cx];
+  for (int st = 64; st > 0; st >>= 1) {
+    if (ry < st) {
+      const float4 o = red[ry + st][cx];
+      float4 m = red[ry][cx];
+      m.x += o.x; m.y += o.y; m.z += o.z; m.w += o.w;
+      red[ry][cx] = m;
+    }
+    __syncthreads();
+  }
+  if (ry == 0) {
+    const float4 m = red[0][cx];
+    out[c] += m.x; out[c + 1] += m.y; out[c + 2] += m.z; out[c + 3] += m.w;
+  }
 }
 
 // P[t, k] (bf16, ld 64) = masked ? 0 : img patch element k (conv order c,p1,p2), k < 48; pad columns 48..63 = 0.
@@ -475,7 +489,7 @@ extern "C" int dig_colsum(const void* x, float* out, float* workspace, int rows,
   const int rpb = colsum_rows_per_block(rows, C);
   const int nb = (rows + rpb - 1) / rpb;
   hipLaunchKernelGGL(colsum_kernel, dim3(cb, nb), dim3(256), 0, stream, (const bf16_t*)x, workspace, rows, C, ld, rpb);
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, stream, workspace, nb, C, out);
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(C / 8), dim3(256), 0, stream, workspace, nb, C, out);
   return dig_check_launch();
 }
 

@@ -508,11 +508,12 @@ int launch_persist(const GemmParams& p, int splits, hipStream_t stream) {
 // Wide-tile variant: WM x WN waves of 64x64 each (256x256, 256x128 or 128x256 outputs per workgroup, BK = 64, 2 stages).
 // Per-wave code is the same as gemm_kernel; what changes is the operand traffic: a 256x256 tile moves half the L2->LDS
 // bytes per FLOP of a 128x128 tile, and that traffic (measured ~55 GB/s per CU) is what bounds the K-loop on MI355X.
-template <bool T, int COLS>
+template <bool T, int COLS, int BK>
 __device__ __forceinline__ unsigned wstage_offset(int piece, int row0, int r0, int ld) {
   if (!T) {
-    const int row = piece >> 3, pc = piece & 7;
-    const int c = pc ^ ((row >> 1) & 7);
+    constexpr int CPR = BK / 8;
+    const int row = piece / CPR, pc = piece % CPR;
+    const int c = pc ^ dswz<BK>(row);
     return (unsigned)(((row0 + row) * ld + r0 + c * 8) * 2);
   } else {
     constexpr int NBLK = COLS / 16;
@@ -523,12 +524,12 @@ __device__ __forceinline__ unsigned wstage_offset(int piece, int row0, int r0, i
   }
 }
 
-template <bool T, int COLS>
+template <bool T, int COLS, int BK>
 __device__ __forceinline__ bf16x8 wload_frag(const unsigned char* tile, int rowoff, int s, int lane) {
   if (!T) {
     const int row = rowoff + (lane & 31);
     const int chunk = 2 * s + (lane >> 5);
-    return *reinterpret_cast<const bf16x8*>(tile + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+    return *reinterpret_cast<const bf16x8*>(tile + row * (BK * 2) + ((chunk ^ dswz<BK>(row)) << 4));
   } else {
     constexpr int NBLK = COLS / 16;
     const int hi = lane >> 5;
@@ -544,19 +545,22 @@ __device__ __forceinline__ bf16x8 wload_frag(const unsigned char* tile, int rowo
   }
 }
 
-template <int WM, int WN>
+template <int WM, int WN, int BK, int NSTG>
 struct WideCfg {
   static constexpr int NT = 64 * WM * WN;
   static constexpr int TBI = 64 * WM, TBJ = 64 * WN;
-  static constexpr int A_BYTES = TBI * 64 * 2, B_BYTES = TBJ * 64 * 2;
+  static constexpr int A_BYTES = TBI * BK * 2, B_BYTES = TBJ * BK * 2;
   static constexpr int STAGE = A_BYTES + B_BYTES;
   static constexpr int NITA = A_BYTES / 16 / NT, NITB = B_BYTES / 16 / NT;
-  static constexpr int LDS = (2 * STAGE > (NT / 64) * 8192) ? 2 * STAGE : (NT / 64) * 8192;
+  static constexpr int LDS = (NSTG * STAGE > (NT / 64) * 8192) ? NSTG * STAGE : (NT / 64) * 8192;
 };
 
-template <bool TA, bool TB, int OUT, int WM, int WN, bool RES>
+// BK = 64 / NSTG = 2: one stage in flight (wait-all hand-off).  BK = 32 / NSTG = 4: three half-depth stages in flight with a
+// counted s_waitcnt vmcnt -- a 256x256x32 step is long enough (about 0.4 us of MFMA) for that look-ahead to cover the
+// L2/HBM -> LDS latency, which a 128x128 tile's step is not.
+template <bool TA, bool TB, int OUT, int WM, int WN, bool RES, int BK, int NSTG>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_wide_kernel(GemmParams p) {
-  using Cfg = WideCfg<WM, WN>;
+  using Cfg = WideCfg<WM, WN, BK, NSTG>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -570,17 +574,17 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_wide_kernel(GemmParams p) {
   const int i0 = ti * Cfg::TBI, j0 = tj * Cfg::TBJ;
   const int rbeg = blockIdx.z * p.r_per_split;
   const int rend = min(p.R, rbeg + p.r_per_split);
-  const int nt = (rend - rbeg + 63) / 64;
+  const int nt = (rend - rbeg + BK - 1) / BK;
 
   const auto ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
   const auto rb_ = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.b_bytes, 0x00020000);
   unsigned offA[4], offB[4];
 #pragma unroll
-  for (int it = 0; it < Cfg::NITA; ++it) offA[it] = wstage_offset<TA, Cfg::TBI>(it * Cfg::NT + tid, i0, rbeg, p.lda);
+  for (int it = 0; it < Cfg::NITA; ++it) offA[it] = wstage_offset<TA, Cfg::TBI, BK>(it * Cfg::NT + tid, i0, rbeg, p.lda);
 #pragma unroll
-  for (int it = 0; it < Cfg::NITB; ++it) offB[it] = wstage_offset<TB, Cfg::TBJ>(it * Cfg::NT + tid, j0, rbeg, p.ldb);
-  const unsigned stepA = TA ? (unsigned)(64 * p.lda * 2) : 128u;
-  const unsigned stepB = TB ? (unsigned)(64 * p.ldb * 2) : 128u;
+  for (int it = 0; it < Cfg::NITB; ++it) offB[it] = wstage_offset<TB, Cfg::TBJ, BK>(it * Cfg::NT + tid, j0, rbeg, p.ldb);
+  const unsigned stepA = TA ? (unsigned)(BK * p.lda * 2) : (unsigned)(BK * 2);
+  const unsigned stepB = TB ? (unsigned)(BK * p.ldb * 2) : (unsigned)(BK * 2);
   auto stage = [&](int slot) {
     unsigned char* a = smem + slot * Cfg::STAGE + wave * 1024;
     unsigned char* b = a + Cfg::A_BYTES;
@@ -604,20 +608,24 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_wide_kernel(GemmParams p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
-  if (nt > 0) stage(0);
+  constexpr int LA = NSTG - 1;
+  constexpr int LPS = Cfg::NITA + Cfg::NITB;
+#pragma unroll
+  for (int q = 0; q < LA; ++q)
+    if (q < nt) stage(q);
   for (int t = 0; t < nt; ++t) {
-    wait_vmcnt<0>();
+    if (t + LA - 1 < nt) wait_vmcnt<(LA - 1) * LPS>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
-    if (t + 1 < nt) stage((t + 1) & 1);
-    const unsigned char* at = smem + (t & 1) * Cfg::STAGE;
+    if (t + LA < nt) stage((t + LA) % NSTG);
+    const unsigned char* at = smem + (t % NSTG) * Cfg::STAGE;
     const unsigned char* bt = at + Cfg::A_BYTES;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < BK / 16; ++s) {
       bf16x8 af[2], bfr[2];
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
-        af[u] = wload_frag<TA, Cfg::TBI>(at, wi * 64 + u * 32, s, lane);
-        bfr[u] = wload_frag<TB, Cfg::TBJ>(bt, wj * 64 + u * 32, s, lane);
+        af[u] = wload_frag<TA, Cfg::TBI, BK>(at, wi * 64 + u * 32, s, lane);
+        bfr[u] = wload_frag<TB, Cfg::TBJ, BK>(bt, wj * 64 + u * 32, s, lane);
       }
 #pragma unroll
       for (int a = 0; a < 2; ++a)
@@ -719,19 +727,19 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_wide_kernel(GemmParams p) {
   }
 }
 
-template <bool TA, bool TB, int OUT, int WM, int WN, bool RES>
+template <bool TA, bool TB, int OUT, int WM, int WN, bool RES, int BK, int NSTG>
 int launch_wide(GemmParams p, int splits, hipStream_t stream) {
-  using Cfg = WideCfg<WM, WN>;
+  using Cfg = WideCfg<WM, WN, BK, NSTG>;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wide_kernel<TA, TB, OUT, WM, WN, RES>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wide_kernel<TA, TB, OUT, WM, WN, RES, BK, NSTG>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
     attr_set = true;
   }
   p.tiles_i = (p.I + Cfg::TBI - 1) / Cfg::TBI;
   p.tiles_j = (p.J + Cfg::TBJ - 1) / Cfg::TBJ;
   dim3 grid(p.tiles_i * p.tiles_j, 1, splits);
-  hipLaunchKernelGGL((gemm_wide_kernel<TA, TB, OUT, WM, WN, RES>), grid, dim3(Cfg::NT), Cfg::LDS, stream, p);
+  hipLaunchKernelGGL((gemm_wide_kernel<TA, TB, OUT, WM, WN, RES, BK, NSTG>), grid, dim3(Cfg::NT), Cfg::LDS, stream, p);
   return dig_check_launch();
 }
 
@@ -771,7 +779,7 @@ extern "C" int dig_gemm_bf16(const void* A, const void* B, void* C, int I, int J
                              int b_rows, int bk, hipStream_t stream) {
   if (!A || !B || !C || I <= 0 || J <= 0 || R <= 0 || splits < 1) return DIG_ERR_ARG;
   if (bias && !aligned16(bias)) return DIG_ERR_ALIGN;
-  if (out_kind < 0 || out_kind > 2 || act < 0 || act > 2 || (bk != 0 && bk != 32 && bk != 33 && bk != 34 && bk != 64 && bk != 132 && bk != 164 && bk != 244 && bk != 242 && bk != 224)) return DIG_ERR_ARG;
+  if (out_kind < 0 || out_kind > 2 || act < 0 || act > 2 || (bk != 0 && bk != 32 && bk != 33 && bk != 34 && bk != 64 && bk != 132 && bk != 164 && bk != 244 && bk != 242 && bk != 224 && bk != 344 && bk != 343)) return DIG_ERR_ARG;
   if (act == 2 && !resid) return DIG_ERR_ARG;                   // act 2: resid carries the saved pre-activation
   if (bk >= 100 && bk < 200 && resid && pre_act) return DIG_ERR_UNSUPPORTED;
   if (bk == 0) bk = 64;
@@ -798,9 +806,11 @@ extern "C" int dig_gemm_bf16(const void* A, const void* B, void* C, int I, int J
   p.tiles_i = (I + BI - 1) / BI; p.tiles_j = (J + BJ - 1) / BJ;
 #define DIG_GEMM_WCASE(ta, tb, o)                                                                                   \
   if ((trans_a != 0) == ta && (trans_b != 0) == tb && out_kind == o && bk >= 200) {                                  \
-    if (bk == 244) return resid ? launch_wide<ta, tb, o, 4, 4, true>(p, splits, stream) : launch_wide<ta, tb, o, 4, 4, false>(p, splits, stream); \
-    if (bk == 242) return resid ? launch_wide<ta, tb, o, 4, 2, true>(p, splits, stream) : launch_wide<ta, tb, o, 4, 2, false>(p, splits, stream); \
-    return resid ? launch_wide<ta, tb, o, 2, 4, true>(p, splits, stream) : launch_wide<ta, tb, o, 2, 4, false>(p, splits, stream);               \
+    if (bk == 244) return resid ? launch_wide<ta, tb, o, 4, 4, true, 64, 2>(p, splits, stream) : launch_wide<ta, tb, o, 4, 4, false, 64, 2>(p, splits, stream); \
+    if (bk == 344) return resid ? launch_wide<ta, tb, o, 4, 4, true, 32, 4>(p, splits, stream) : launch_wide<ta, tb, o, 4, 4, false, 32, 4>(p, splits, stream); \
+    if (bk == 343) return resid ? launch_wide<ta, tb, o, 4, 4, true, 32, 3>(p, splits, stream) : launch_wide<ta, tb, o, 4, 4, false, 32, 3>(p, splits, stream); \
+    if (bk == 242) return resid ? launch_wide<ta, tb, o, 4, 2, true, 64, 2>(p, splits, stream) : launch_wide<ta, tb, o, 4, 2, false, 64, 2>(p, splits, stream); \
+    return resid ? launch_wide<ta, tb, o, 2, 4, true, 64, 2>(p, splits, stream) : launch_wide<ta, tb, o, 2, 4, false, 64, 2>(p, splits, stream);               \
   }
   DIG_GEMM_WCASE(false, false, 0)
   DIG_GEMM_WCASE(false, false, 1)

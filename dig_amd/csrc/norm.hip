@@ -132,22 +132,37 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
 }
 
 // dgamma += sum_b partial[b][0], dbeta += sum_b partial[b][1], dcol (optional) += sum_b partial[b][2]   (deterministic).
-// 32 columns x 8 row-groups per block so the nb-long sum is 8-way parallel with independent loads in flight.
+// A block owns 16 columns: 4 float4 lanes x 64 row-groups, so the nb-long sum runs 64-way parallel with 16-B loads,
+// then one LDS tree over the row-groups (this kernel sits on the backward critical path: latency matters, not bytes).
 __global__ __launch_bounds__(256) void ln_bwd_finalize_kernel(const float* __restrict__ partial, int nblocks, int D,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                               float* __restrict__ dcol) {
-  __shared__ float red[8][32];
-  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cx;
-  float a = 0.f;
-  if (c < 3 * D)
-    for (int b = ry; b < nblocks; b += 8) a += partial[(size_t)b * 3 * D + c];
+  __shared__ float4 red[64][4];
+  const int cx = threadIdx.x & 3, ry = threadIdx.x >> 2;
+  const int c = blockIdx.x * 16 + cx * 4;                       // 3*D % 16 == 0 for every supported D
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int b = ry; b < nblocks; b += 64) {
+    const float4 v = *reinterpret_cast<const float4*>(partial + (size_t)b * 3 * D + c);
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  }
   red[ry][cx] = a;
   __syncthreads();
-  if (ry == 0 && c < 3 * D) {
-    const int w = c / D, cc = c - w * D;
+  for (int st = 32; st > 0; st >>= 1) {
+    if (ry < st) {
+      const float4 o = red[ry + st][cx];
+      float4 m = red[ry][cx];
+      m.x += o.x; m.y += o.y; m.z += o.z; m.w += o.w;
+      red[ry][cx] = m;
+    }
+    __syncthreads();
+  }
+  if (ry == 0) {
+    const int w = c / D, cc = c - w * D;                        // a float4 never straddles two of the three vectors (D % 4 == 0)
     float* dst = w == 0 ? dgamma : (w == 1 ? dbeta : dcol);
-    if (dst) dst[cc] += red[0][cx] + red[1][cx] + red[2][cx] + red[3][cx] + red[4][cx] + red[5][cx] + red[6][cx] + red[7][cx];
+    if (dst) {
+      const float4 m = red[0][cx];
+      dst[cc] += m.x; dst[cc + 1] += m.y; dst[cc + 2] += m.z; dst[cc + 3] += m.w;
+    }
   }
 }
 
@@ -298,7 +313,7 @@ extern "C" int dig_layernorm_bwd(const void* dy, const void* x, const float* gam
   const int grid = std::max(1, std::min(1024, (rows + 15) / 16));
   if (fuse_gelu) { LN_DISPATCH(D, true, ln_bwd_kernel, (const bf16_t*)dy, (const bf16_t*)x, gamma, beta, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, workspace, rows) }
   else { LN_DISPATCH(D, false, ln_bwd_kernel, (const bf16_t*)dy, (const bf16_t*)x, gamma, beta, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, workspace, rows) }
-  hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((3 * D + 31) / 32), dim3(256), 0, stream, workspace, grid, D, dgamma, dbeta, dcolsum);
+  hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((3 * D) / 16), dim3(256), 0, stream, workspace, grid, D, dgamma, dbeta, dcolsum);
   return dig_check_launch();
 }
 

@@ -18,7 +18,7 @@ def run(name, J, R, **kw):
     if kw.get("act"): args["act"] = 1
     if kw.get("alpha"): args.update(alpha=0.125, alpha_cols=J // 3)
     out = []
-    for bk in (64, 32, 244, 242):
+    for bk in (64, 244, 344, 343):
         out.append(f"bk{bk} {bench(lambda: ops.gemm(x, w, I, J, R, bk=bk, **args)):.1f}")
     print(name, " | ".join(out))
 run("qkv bias+alpha    ", 1152, 384, alpha=True)
@@ -30,3 +30,9 @@ run("fc2 bias+resid    ", 384, 1536, resid=True)
 I = 32768
 run("pixproj 384->512  ", 512, 384)
 run("pixproj 512->512  ", 512, 512)
+
+I = 8192
+x = torch.randn(I, I, device=dev).bfloat16(); w = torch.randn(I, I, device=dev).bfloat16(); y = torch.empty(I, I, device=dev, dtype=torch.bfloat16)
+for bk in (64, 244, 344, 343):
+    t = bench(lambda: ops.gemm(x, w, I, I, I, out=y, bk=bk), n=10)
+    print(f"8k^3 bk{bk}: {t:.1f} us {2*I**3/t/1e6:.0f} TF")
