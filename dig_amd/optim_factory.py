@@ -70,17 +70,59 @@ class FusedAdamW(torch.optim.Optimizer):
         ops.adamw_step(M.flat_params, M.flat_grads, self.exp_avg, self.exp_avg_sq, None, M.flat_groups,
                        g0["lr"], g0["weight_decay"], g1["lr"], g1["weight_decay"], b1, b2, g0["eps"], self._step, grad_scale)
 
+    # ---- checkpoint format: the reference's torch-Optimizer layout (custom_optim/optimizer.py state_dict):
+    #   {'state': {i: {'step', 'exp_avg', 'exp_avg_sq'}}, 'param_groups': [{..., 'params': [i, ...]}, ...]}
+    # with i enumerating the parameters group by group (decay first), so checkpoints interchange with the reference.
+    def _named_specs(self):
+        out = []
+        for g in self.param_groups:
+            out.extend(g["names"])
+        return out
+
     def state_dict(self):
-        return {"step": self._step, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,
-                "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
+        names = self._named_specs()
+        state = {}
+        if self._step > 0:
+            for i, n in enumerate(names):
+                sp = self.model.specs[n]
+                state[i] = {"step": self._step,
+                            "exp_avg": self.exp_avg[sp.offset:sp.offset + sp.numel].view(sp.shape),
+                            "exp_avg_sq": self.exp_avg_sq[sp.offset:sp.offset + sp.numel].view(sp.shape)}
+        groups, k = [], 0
+        for g in self.param_groups:
+            d = {key: v for key, v in g.items() if key not in ("params", "names")}
+            d.setdefault("amsgrad", False)
+            d["params"] = list(range(k, k + len(g["names"])))
+            k += len(g["names"])
+            groups.append(d)
+        return {"state": state, "param_groups": groups}
 
     def load_state_dict(self, sd):
-        self._step = int(sd["step"])
         self._bind()
-        self.exp_avg.copy_(sd["exp_avg"])
-        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
-        for g, s in zip(self.param_groups, sd["param_groups"]):
-            g.update({k: v for k, v in s.items() if k != "names"})
+        names = self._named_specs()
+        if "state" not in sd:                                   # round-0 flat format of this package
+            self._step = int(sd["step"])
+            self.exp_avg.copy_(sd["exp_avg"])
+            self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+            return
+        if len(sd["param_groups"]) != len(self.param_groups) or \
+                [len(g["params"]) for g in sd["param_groups"]] != [len(g["names"]) for g in self.param_groups]:
+            raise ValueError("loaded state dict has different parameter groups")
+        steps = set()
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        for i, st in sd["state"].items():
+            sp = self.model.specs[names[int(i)]]
+            if tuple(st["exp_avg"].shape) != sp.shape:
+                raise ValueError(f"optimizer state {i} ({names[int(i)]}): shape {tuple(st['exp_avg'].shape)} != {sp.shape}")
+            self.exp_avg[sp.offset:sp.offset + sp.numel].view(sp.shape).copy_(st["exp_avg"])
+            self.exp_avg_sq[sp.offset:sp.offset + sp.numel].view(sp.shape).copy_(st["exp_avg_sq"])
+            steps.add(int(st["step"]))
+        if len(steps) > 1:
+            raise ValueError("per-parameter step counts differ; the fused optimizer keeps one step counter")
+        self._step = steps.pop() if steps else 0
+        for g, s_ in zip(self.param_groups, sd["param_groups"]):
+            g.update({k: v for k, v in s_.items() if k not in ("params", "names", "amsgrad")})
 
 
 def create_optimizer(args, model, get_num_layer=None, get_layer_scale=None, filter_bias_and_bn=True, skip_list=None):

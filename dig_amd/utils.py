@@ -205,6 +205,16 @@ class MetricLogger:
 
 
 # ------------------------------------------------------------------------------------------------ checkpoints
+def _to_cpu(obj):
+    if isinstance(obj, torch.Tensor):
+        return obj.detach().cpu().clone()
+    if isinstance(obj, dict):
+        return {k: _to_cpu(v) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_to_cpu(v) for v in obj)
+    return obj
+
+
 def save_model(args, epoch, model, model_without_ddp, optimizer, loss_scaler, model_ema=None):
     """checkpoint-{epoch}.pth with the reference's top-level keys {model, optimizer, epoch, scaler, args}."""
     if not is_main_process():
@@ -212,7 +222,7 @@ def save_model(args, epoch, model, model_without_ddp, optimizer, loss_scaler, mo
     os.makedirs(args.output_dir, exist_ok=True)
     path = os.path.join(args.output_dir, 'checkpoint-%s.pth' % str(epoch))
     torch.save({'model': {k: v.detach().cpu() for k, v in model_without_ddp.state_dict().items()},
-                'optimizer': {k: (v.detach().cpu() if isinstance(v, torch.Tensor) else v) for k, v in optimizer.state_dict().items()},
+                'optimizer': _to_cpu(optimizer.state_dict()),
                 'epoch': epoch, 'scaler': loss_scaler.state_dict(), 'args': vars(args) if hasattr(args, "__dict__") else args}, path)
 
 

@@ -309,11 +309,50 @@ def gen_multi(world, cfg, seed, B, n_steps, hp):
     print("wrote multi-rank fixtures, world", world)
 
 
+def gen_checkpoint_structure():
+    """Structure (not values) of the reference optimizer's state_dict after one step of the tiny model: per-index tensor
+    shapes and the parameter index lists of each group -- what a checkpoint interchange has to reproduce."""
+    cfg = O.DiGConfig(**O.TINY)
+    hp = O.StepHyper(lr=1e-3)
+    ref_utils = refenv.setup()
+    import engine_for_pretraining_moco as E
+    import optim_factory
+    model = build_ref_model(cfg)
+    P, S = O.det_state(cfg, 3)
+    sd = model.state_dict()
+    for k, v in P.items():
+        sd[k].copy_(v)
+    args = ref_args(hp)
+    opt = optim_factory.create_optimizer(args, model)
+    im, au, mk = O.synthetic_batch(2, cfg, 5)
+    E.train_one_epoch(model, None, None, [([im, au, mk], torch.ones(1), torch.ones(1))], None, opt, torch.device('cpu'), 0,
+                      ScalerCPU(ref_utils), None, patch_size=cfg.patch, normlize_target=False, start_steps=0,
+                      lr_schedule_values=np.full(2, hp.lr), wd_schedule_values=np.full(2, hp.weight_decay), args=args)
+    osd = opt.state_dict()
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    name_of = {id(p): n for n, p in model.named_parameters()}
+    idx_names = [name_of[id(p)] for g in opt.param_groups for p in g["params"]]
+    d = {"n_state": np.int64(len(osd["state"])), "group_sizes": np.array([len(g["params"]) for g in osd["param_groups"]]),
+         "group_wd": np.array([g["weight_decay"] for g in osd["param_groups"]]),
+         "group_keys": np.array(sorted(osd["param_groups"][0].keys())),
+         "idx_names": np.array(idx_names), "steps": np.array([osd["state"][i]["step"] for i in range(len(idx_names))]),
+         "exp_avg_norms": np.array([osd["state"][i]["exp_avg"].double().norm().item() for i in range(len(idx_names))])}
+    assert all(tuple(osd["state"][i]["exp_avg"].shape) == tuple(P[n].shape) for i, n in enumerate(idx_names))
+    np.savez_compressed(os.path.join(GOLD, "optimizer_state_structure.npz"), **d)
+    print("wrote optimizer_state_structure")
+
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--world", type=int, default=1)
     ap.add_argument("--only", default="")
+    ap.add_argument("--ckpt-structure", action="store_true")
     a = ap.parse_args()
+    if a.ckpt_structure:
+        torch.manual_seed(0)
+        gen_checkpoint_structure()
+        sys.exit(0)
     torch.manual_seed(0)
     torch.set_num_threads(8)
     tiny = O.DiGConfig(**O.TINY)

@@ -174,3 +174,37 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "dig_oracle" not in src and "oracle" + "/" not in src, f
+
+
+def test_optimizer_state_dict_interchanges_with_reference_layout(golden_dir, tmp_path):
+    """N2: the fused optimizer's state_dict has the reference optimizer's structure (fixture produced by the
+    reference's own custom_optim.AdamW after one step: parameter index order, group sizes / keys, per-index shapes)."""
+    g = np.load(os.path.join(golden_dir, "optimizer_state_structure.npz"))
+    cfg, m = tiny_model()
+    args = types.SimpleNamespace(opt="adamw", lr=1e-3, weight_decay=0.1, opt_eps=1e-8, opt_betas=None)
+    opt = create_optimizer(args, m)
+    assert opt.state_dict()["state"] == {}                                   # like torch: empty before the first step
+    opt._step = 1
+    opt.exp_avg.normal_()
+    opt.exp_avg_sq.uniform_()
+    sd = opt.state_dict()
+    idx_names = g["idx_names"].tolist()
+    assert len(sd["state"]) == int(g["n_state"]) and [len(x["params"]) for x in sd["param_groups"]] == g["group_sizes"].tolist()
+    assert [x["weight_decay"] for x in sd["param_groups"]] == g["group_wd"].tolist()
+    assert set(g["group_keys"].tolist()) <= set(sd["param_groups"][0].keys())
+    assert opt._named_specs() == idx_names                                    # same parameter <-> index mapping
+    named = dict(m.named_parameters())
+    for i, n in enumerate(idx_names):
+        assert tuple(sd["state"][i]["exp_avg"].shape) == tuple(named[n].shape) and sd["state"][i]["step"] == 1
+    # round trip through a torch.save'd checkpoint into a fresh optimizer
+    torch.save({"optimizer": U._to_cpu(sd)}, tmp_path / "o.pth")
+    _, m2 = tiny_model()
+    opt2 = create_optimizer(args, m2)
+    opt2.load_state_dict(torch.load(tmp_path / "o.pth", weights_only=False)["optimizer"])
+    used = torch.zeros(m.n_online, dtype=torch.bool)
+    for n in idx_names:
+        sp = m.specs[n]
+        used[sp.offset:sp.offset + sp.numel] = True
+    assert opt2._step == 1 and torch.equal(opt2.exp_avg[used], opt.exp_avg[used]) and torch.equal(opt2.exp_avg_sq[used], opt.exp_avg_sq[used])
+    # pads of the flat moment buffers are not part of any parameter: a load leaves them zero
+    assert float(opt2.exp_avg[~used].abs().max()) == 0.0
