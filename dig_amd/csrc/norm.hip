@@ -92,34 +92,44 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
   float g[EPL], bt[EPL], dg[EPL], db[EPL], dc[EPL];
 #pragma unroll
   for (int k = 0; k < EPL; ++k) { g[k] = gamma[lane * EPL + k]; bt[k] = GELU ? beta[lane * EPL + k] : 0.f; dg[k] = 0.f; db[k] = 0.f; dc[k] = 0.f; }
-  for (int r = w; r < rows; r += nw) {
-    float v[EPL], d[EPL];
-    load_row<EPL>(x + (size_t)r * D + lane * EPL, v);
-    load_row<EPL>(dy + (size_t)r * D + lane * EPL, d);
-    const float mu = mean[r], rs = rstd[r];
-    float c1 = 0.f, c2 = 0.f;
+  // two rows per iteration: all six row loads are issued before the first reduction, so each wave keeps twice the bytes
+  // in flight (the kernel is latency-bound per row: 3 loads -> 2 wave reductions -> 1 store)
+  for (int r0 = w * 2; r0 < rows; r0 += nw * 2) {
+    float v[2][EPL], d[2][EPL], e[2][EPL];
+    float mu[2], rs[2];
 #pragma unroll
-    for (int k = 0; k < EPL; ++k) {
-      v[k] = (v[k] - mu) * rs;                     // xhat
-      if (GELU) d[k] *= dgelu_f(v[k] * g[k] + bt[k]);
-      dg[k] += d[k] * v[k];
-      db[k] += d[k];
-      d[k] *= g[k];
-      c1 += d[k];
-      c2 += d[k] * v[k];
+    for (int u = 0; u < 2; ++u) {
+      const int r = min(r0 + u, rows - 1);
+      load_row<EPL>(x + (size_t)r * D + lane * EPL, v[u]);
+      load_row<EPL>(dy + (size_t)r * D + lane * EPL, d[u]);
+      if (dres) load_row<EPL>(dres + (size_t)r * D + lane * EPL, e[u]);
+      mu[u] = mean[r]; rs[u] = rstd[r];
     }
-    c1 = wave_sum(c1) * (1.0f / D);
-    c2 = wave_sum(c2) * (1.0f / D);
-    float o[EPL];
 #pragma unroll
-    for (int k = 0; k < EPL; ++k) o[k] = rs * (d[k] - c1 - v[k] * c2);
-    if (dres) {
-      float e[EPL];
-      load_row<EPL>(dres + (size_t)r * D + lane * EPL, e);
+    for (int u = 0; u < 2; ++u) {
+      if (r0 + u >= rows) break;
+      float c1 = 0.f, c2 = 0.f;
 #pragma unroll
-      for (int k = 0; k < EPL; ++k) { o[k] += e[k]; dc[k] += e[k]; }       // dc: column sums of the skip-path gradient
+      for (int k = 0; k < EPL; ++k) {
+        v[u][k] = (v[u][k] - mu[u]) * rs[u];                     // xhat
+        if (GELU) d[u][k] *= dgelu_f(v[u][k] * g[k] + bt[k]);
+        dg[k] += d[u][k] * v[u][k];
+        db[k] += d[u][k];
+        d[u][k] *= g[k];
+        c1 += d[u][k];
+        c2 += d[u][k] * v[u][k];
+      }
+      c1 = wave_sum(c1) * (1.0f / D);
+      c2 = wave_sum(c2) * (1.0f / D);
+      float o[EPL];
+#pragma unroll
+      for (int k = 0; k < EPL; ++k) o[k] = rs[u] * (d[u][k] - c1 - v[u][k] * c2);
+      if (dres) {
+#pragma unroll
+        for (int k = 0; k < EPL; ++k) { o[k] += e[u][k]; dc[k] += e[u][k]; }   // dc: column sums of the skip-path gradient
+      }
+      store_row<EPL>(dx + (size_t)(r0 + u) * D + lane * EPL, o);
     }
-    store_row<EPL>(dx + (size_t)r * D + lane * EPL, o);
   }
 #pragma unroll
   for (int k = 0; k < EPL; ++k) { red[0][wv][lane * EPL + k] = dg[k]; red[1][wv][lane * EPL + k] = db[k]; red[2][wv][lane * EPL + k] = dc[k]; }
