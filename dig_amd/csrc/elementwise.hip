@@ -339,7 +339,7 @@ __global__ __launch_bounds__(256) void patchify_bf16_kernel(const float* __restr
 
 // out0[c] += sum over rows with mask==0 of x[r,c]; out1[c] += sum over rows with mask!=0   (patch-embed bias / mask_token grads)
 __global__ __launch_bounds__(256) void colsum_masked_kernel(const bf16_t* __restrict__ x, const unsigned char* __restrict__ mask,
-                                                            float* __restrict__ out0, float* __restrict__ out1, int rows, int C,
+                                                            float* __restrict__ part0, float* __restrict__ part1, int rows, int C,
                                                             int rows_per_block) {
   __shared__ float red[2][4][64][8 + 1];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256) void colsum_masked_kernel(const bf16_t* __rest
   for (int e = threadIdx.x; e < 1024; e += 256) {
     const int which = e >> 9, l = (e & 511) >> 3, k = e & 7;
     const int cc = blockIdx.x * 512 + (e & 511);
-    if (cc < C) atomicAdd((which ? out1 : out0) + cc, red[which][0][l][k] + red[which][1][l][k] + red[which][2][l][k] + red[which][3][l][k]);
+    if (cc < C) (which ? part1 : part0)[(size_t)blockIdx.y * C + cc] = red[which][0][l][k] + red[which][1][l][k] + red[which][2][l][k] + red[which][3][l][k];
   }
 }
 
@@ -502,14 +502,17 @@ extern "C" int dig_patchify_bf16(const float* img, const unsigned char* mask, vo
   return dig_check_launch();
 }
 
-extern "C" int dig_colsum_masked(const void* x, const unsigned char* mask, float* out_unmasked, float* out_masked, int rows, int C,
-                                 hipStream_t stream) {
-  if (!x || !mask || !out_unmasked || !out_masked || rows <= 0 || C <= 0 || (C & 7)) return DIG_ERR_ARG;
+extern "C" int dig_colsum_masked(const void* x, const unsigned char* mask, float* out_unmasked, float* out_masked,
+                                 float* workspace /* 2 x dig_colsum_workspace_bytes(rows, C) */, int rows, int C, hipStream_t stream) {
+  if (!x || !mask || !out_unmasked || !out_masked || !workspace || rows <= 0 || C <= 0 || (C & 7)) return DIG_ERR_ARG;
   if (!aligned16(x)) return DIG_ERR_ALIGN;
   const int cb = (C + 511) / 512;
-  int rpb = 32;
-  while ((long)cb * ((rows + rpb - 1) / rpb) > 2048) rpb *= 2;
-  hipLaunchKernelGGL(colsum_masked_kernel, dim3(cb, (rows + rpb - 1) / rpb), dim3(256), 0, stream, (const bf16_t*)x, mask, out_unmasked,
-                     out_masked, rows, C, rpb);
+  const int rpb = colsum_rows_per_block(rows, C);
+  const int nb = (rows + rpb - 1) / rpb;
+  float* p0 = workspace;
+  float* p1 = workspace + (size_t)nb * C;
+  hipLaunchKernelGGL(colsum_masked_kernel, dim3(cb, nb), dim3(256), 0, stream, (const bf16_t*)x, mask, p0, p1, rows, C, rpb);
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(C / 8), dim3(256), 0, stream, p0, nb, C, out_unmasked);
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(C / 8), dim3(256), 0, stream, p1, nb, C, out_masked);
   return dig_check_launch();
 }

@@ -215,12 +215,26 @@ __global__ __launch_bounds__(256) void bn_colstats_kernel(const bf16_t* __restri
   }
   red[0][wv][lane] = a0; red[1][wv][lane] = a1; red[2][wv][lane] = b0; red[3][wv][lane] = b1;
   __syncthreads();
-  if (wv == 0 && c < C) {
-    atomicAdd(out + c, red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane]);
-    atomicAdd(out + c + 1, red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane]);
-    atomicAdd(out + C + c, red[2][0][lane] + red[2][1][lane] + red[2][2][lane] + red[2][3][lane]);
-    atomicAdd(out + C + c + 1, red[3][0][lane] + red[3][1][lane] + red[3][2][lane] + red[3][3][lane]);
+  if (wv == 0 && c < C) {                       // per-row-strip partials (no atomics: statistics are bit-reproducible)
+    float* o = out + (size_t)blockIdx.y * 2 * C;
+    o[c] = red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane];
+    o[c + 1] = red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane];
+    o[C + c] = red[2][0][lane] + red[2][1][lane] + red[2][2][lane] + red[2][3][lane];
+    o[C + c + 1] = red[3][0][lane] + red[3][1][lane] + red[3][2][lane] + red[3][3][lane];
   }
+}
+
+// sums[e] = sum_b partial[b][e], e < 2*C  (fixed order)
+__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __restrict__ partial, int nb, int n, float* __restrict__ sums) {
+  __shared__ float red[8][32];
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cx;
+  float a = 0.f;
+  if (c < n)
+    for (int b = ry; b < nb; b += 8) a += partial[(size_t)b * n + c];
+  red[ry][cx] = a;
+  __syncthreads();
+  if (ry == 0 && c < n) sums[c] = ((red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx])) + ((red[4][cx] + red[5][cx]) + (red[6][cx] + red[7][cx]));
 }
 
 // y = [relu]( gamma * (x - mean) * rstd + beta );  mean/rstd derived from global sums (sum, sumsq) and 1/n.
@@ -327,14 +341,27 @@ extern "C" int dig_layernorm_bwd(const void* dy, const void* x, const float* gam
   return dig_check_launch();
 }
 
-extern "C" int dig_bn_stats(const void* x, float* sums /*[2,C], accumulated into*/, int rows, int C, hipStream_t stream) {
-  if (!x || !sums || rows <= 0 || C <= 0 || (C & 7)) return DIG_ERR_ARG;
+static inline int bn_rows_per_block(int rows, int C) {
   const int cb = (C + 127) / 128;
   int rpb = 64;
-  while ((long)cb * ((rows + rpb - 1) / rpb) > 4096) rpb *= 2;
-  dim3 grid(cb, (rows + rpb - 1) / rpb);
-  hipLaunchKernelGGL(bn_colstats_kernel<0>, grid, dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)nullptr, nullptr,
-                     nullptr, nullptr, nullptr, 0, sums, rows, C, rpb);
+  while ((long)cb * ((rows + rpb - 1) / rpb) > 2048) rpb *= 2;
+  return rpb;
+}
+
+extern "C" long long dig_bn_stats_workspace_bytes(int rows, int C) {
+  const int rpb = bn_rows_per_block(rows, C);
+  return (long long)((rows + rpb - 1) / rpb) * 2 * C * sizeof(float);
+}
+
+// sums[2,C] = (sum_r x, sum_r x^2), overwritten; two-stage and deterministic
+extern "C" int dig_bn_stats(const void* x, float* sums, float* workspace, int rows, int C, hipStream_t stream) {
+  if (!x || !sums || !workspace || rows <= 0 || C <= 0 || (C & 7)) return DIG_ERR_ARG;
+  const int cb = (C + 127) / 128;
+  const int rpb = bn_rows_per_block(rows, C);
+  const int nb = (rows + rpb - 1) / rpb;
+  hipLaunchKernelGGL(bn_colstats_kernel<0>, dim3(cb, nb), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)nullptr, nullptr,
+                     nullptr, nullptr, nullptr, 0, workspace, rows, C, rpb);
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((2 * C + 31) / 32), dim3(256), 0, stream, workspace, nb, 2 * C, sums);
   return dig_check_launch();
 }
 
@@ -352,14 +379,14 @@ extern "C" int dig_bn_fwd_apply(const void* x, const float* sums, float n_total,
 }
 
 extern "C" int dig_bn_bwd_stats(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
-                                const float* beta, int relu, float* sums, int rows, int C, hipStream_t stream) {
-  if (!dy || !x || !mean || !rstd || !sums || rows <= 0 || (C & 7)) return DIG_ERR_ARG;
+                                const float* beta, int relu, float* sums, float* workspace, int rows, int C, hipStream_t stream) {
+  if (!dy || !x || !mean || !rstd || !sums || !workspace || rows <= 0 || (C & 7)) return DIG_ERR_ARG;
   const int cb = (C + 127) / 128;
-  int rpb = 64;
-  while ((long)cb * ((rows + rpb - 1) / rpb) > 4096) rpb *= 2;
-  dim3 grid(cb, (rows + rpb - 1) / rpb);
-  hipLaunchKernelGGL(bn_colstats_kernel<1>, grid, dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)dy, mean, rstd, gamma,
-                     beta, relu, sums, rows, C, rpb);
+  const int rpb = bn_rows_per_block(rows, C);
+  const int nb = (rows + rpb - 1) / rpb;
+  hipLaunchKernelGGL(bn_colstats_kernel<1>, dim3(cb, nb), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)dy, mean, rstd, gamma,
+                     beta, relu, workspace, rows, C, rpb);
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((2 * C + 31) / 32), dim3(256), 0, stream, workspace, nb, 2 * C, sums);
   return dig_check_launch();
 }
 

@@ -145,7 +145,7 @@ class _Step:
             dx = ops.layernorm_bwd(dln1, x, blk["norm1.weight"], blk["norm1.bias"], mu1, rs1, dx_mid, g["norm1.weight"], g["norm1.bias"],
                                    out=dln1, dres_colsum=g["attn.proj.bias"])            # colsum(dx_mid) = proj bias grad, fused
             del dact, pre, act, dln2, dqkv, dctx
-            if self.comm.world > 1:
+            if self.comm.world > 1 or getattr(self.comm, "world_override", False):
                 main.wait_stream(side)                                        # this block's gradients are final on both streams
             self.comm.grad_ready(M, f"encoder.blocks.{i}")
         for half, im in enumerate((images, aug)):
@@ -167,7 +167,7 @@ class _Step:
         for l, (d1, d2) in enumerate(dims):
             last = l == len(dims) - 1
             h = ops.linear_fwd(x, w16[f"{pre}.{3 * l}.weight"])
-            sums = torch.zeros((2, d2), device=x.device, dtype=F32)
+            sums = torch.empty((2, d2), device=x.device, dtype=F32)
             ops.bn_stats(h, sums)
             self.comm.all_reduce_(sums)
             gamma = None if last else f32[f"{pre}.{3 * l + 1}.weight"]
@@ -192,7 +192,7 @@ class _Step:
             x, h, mean, rstd = saved[l]
             gamma = None if last else f32[f"{pre}.{3 * l + 1}.weight"]
             beta = None if last else f32[f"{pre}.{3 * l + 1}.bias"]
-            sums = torch.zeros((2, d2), device=dy.device, dtype=F32)
+            sums = torch.empty((2, d2), device=dy.device, dtype=F32)
             ops.bn_bwd_stats(dy, h, mean, rstd, gamma, beta, not last, sums)
             if not last:                                                   # local sums are the affine gradients
                 ops.axpy_f32(g32[f"{pre}.{3 * l + 1}.bias"], sums[0])
@@ -255,7 +255,7 @@ class _Step:
         qn, self.q_inv = ops.l2norm_fwd(qf)
         kn, _ = ops.l2norm_fwd(kf)
         self.qn = qn
-        if comm.world > 1:
+        if comm.world > 1 or getattr(comm, "world_override", False):
             kall = comm.all_gather_cat(kn.view(1, 2, n, dim))               # [W, 2, n, dim], rank order (:586-590)
             k1_all = kall[:, 0].reshape(comm.world * n, dim).contiguous()
             k2_all = kall[:, 1].reshape(comm.world * n, dim).contiguous()

@@ -175,7 +175,8 @@ def patch_embed_bwd_mfma(dy, img, mask_u8, dW, dbias, dmask_token, D, gh, gw):
     P = torch.empty((n_tok, 64), device=img.device, dtype=BF16)
     L.call("dig_patchify_bf16", L.ptr(img), L.ptr(mask_u8), L.ptr(P), img.shape[0], gh, gw, L.stream())
     wgrad(dy, P, dW, D, 48, n_tok)
-    L.call("dig_colsum_masked", L.ptr(dy), L.ptr(mask_u8), L.ptr(dbias), L.ptr(dmask_token), n_tok, D, L.stream())
+    ws = _workspace2(dy.device, 2 * 1024 * D)
+    L.call("dig_colsum_masked", L.ptr(dy), L.ptr(mask_u8), L.ptr(dbias), L.ptr(dmask_token), L.ptr(ws), n_tok, D, L.stream())
 
 
 def window_pool_fwd(x, out, n_img, gh, gw, nwin, D):
@@ -224,7 +225,9 @@ def gelu_bwd(dact, pre, out):
 
 
 def bn_stats(x, sums):
-    L.call("dig_bn_stats", L.ptr(x), L.ptr(sums), x.shape[0], x.shape[1], L.stream())
+    """sums[2,C] = (sum_r x, sum_r x^2) -- overwritten, deterministic."""
+    ws = _workspace2(x.device, 2048 * 2 * 128 + 64 * 2 * x.shape[1])
+    L.call("dig_bn_stats", L.ptr(x), L.ptr(sums), L.ptr(ws), x.shape[0], x.shape[1], L.stream())
 
 
 def bn_fwd_apply(x, sums, n_total, eps, gamma, beta, relu):
@@ -242,8 +245,9 @@ def bn_update_running(sums, n_total, momentum, rm, rv):
 
 
 def bn_bwd_stats(dy, x, mean, rstd, gamma, beta, relu, sums):
+    ws = _workspace2(x.device, 2048 * 2 * 128 + 64 * 2 * x.shape[1])
     L.call("dig_bn_bwd_stats", L.ptr(dy), L.ptr(x), L.ptr(mean), L.ptr(rstd), L.ptr(gamma), L.ptr(beta), int(relu), L.ptr(sums),
-           x.shape[0], x.shape[1], L.stream())
+           L.ptr(ws), x.shape[0], x.shape[1], L.stream())
 
 
 def bn_bwd_apply(dy, x, mean, rstd, gamma, beta, relu, sums, n_total):

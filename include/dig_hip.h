@@ -80,20 +80,22 @@ int dig_layernorm_bwd(const void* dy, const void* x, const float* gamma, const f
  * BatchNorm1d in training mode, split so that the [2,C] statistics vector can be all-reduced between the halves
  * (nn.BatchNorm1d in _build_mlp, modeling_pretrain_moco_mim_ori.py:463-482, under SyncBatchNorm,
  * run_mae_pretraining_moco.py:390).  x, y, dy, dx: bf16 [rows, C], C % 8 == 0.
- *   dig_bn_stats:      sums[0][c] += sum_r x, sums[1][c] += sum_r x^2          (caller zeroes sums)
+ *   dig_bn_stats:      sums[0][c] = sum_r x, sums[1][c] = sum_r x^2   (two-stage, deterministic; workspace from
+ *                      dig_bn_stats_workspace_bytes, also used by dig_bn_bwd_stats)
  *   dig_bn_fwd_apply:  mean/var from sums / n_total (biased var); y = [relu](gamma * xhat + beta); gamma == beta == NULL
  *                      for the affine=False last layer; writes mean_out / rstd_out [C]
  *   dig_bn_update_running: running_mean/var <- (1-momentum) * old + momentum * (mean, var * n/(n-1))
- *   dig_bn_bwd_stats:  g = dy * relu_mask; sums[0][c] += sum g (= dbeta), sums[1][c] += sum g*xhat (= dgamma)
+ *   dig_bn_bwd_stats:  g = dy * relu_mask; sums[0][c] = sum g (= dbeta), sums[1][c] = sum g*xhat (= dgamma)
  *   dig_bn_bwd_apply:  dx = gamma * rstd * (g - S0/n_total - xhat * S1/n_total) with S the all-rank sums
  */
-int dig_bn_stats(const void* x, float* sums, int rows, int C, hipStream_t stream);
+long long dig_bn_stats_workspace_bytes(int rows, int C);
+int dig_bn_stats(const void* x, float* sums, float* workspace, int rows, int C, hipStream_t stream);
 int dig_bn_fwd_apply(const void* x, const float* sums, float n_total, float eps, const float* gamma, const float* beta, int relu,
                      void* y, float* mean_out, float* rstd_out, int rows, int C, hipStream_t stream);
 int dig_bn_update_running(const float* sums, float n_total, float momentum, float* running_mean, float* running_var, int C,
                           hipStream_t stream);
 int dig_bn_bwd_stats(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
-                     int relu, float* sums, int rows, int C, hipStream_t stream);
+                     int relu, float* sums, float* workspace, int rows, int C, hipStream_t stream);
 int dig_bn_bwd_apply(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
                      int relu, const float* sums, float n_total, void* dx, int rows, int C, hipStream_t stream);
 
@@ -110,8 +112,8 @@ int dig_patch_embed_fwd(const float* img, const float* W, const float* bias, con
 int dig_patch_embed_bwd(const void* dy, const float* img, const unsigned char* mask, float* dW, float* dbias, float* dmask_token,
                         int n_img, int gh, int gw, int D, hipStream_t stream);
 int dig_patchify_bf16(const float* img, const unsigned char* mask, void* out, int n_img, int gh, int gw, hipStream_t stream);
-int dig_colsum_masked(const void* x, const unsigned char* mask, float* out_unmasked, float* out_masked, int rows, int C,
-                      hipStream_t stream);
+int dig_colsum_masked(const void* x, const unsigned char* mask, float* out_unmasked, float* out_masked, float* workspace,
+                      int rows, int C, hipStream_t stream);   /* workspace: 2 x dig_colsum_workspace_bytes(rows, C) */
 
 /* PatchNet 'no_patchtrans' = adaptive_avg_pool2d of the gh x gw token grid to (1, nwin)
  * (modeling_pretrain_moco_mim_ori.py:189-193) and its gradient (accumulate=1 adds into dx). */

@@ -107,7 +107,7 @@ def test_batchnorm(dev, rows, C, affine, relu):
     x = (torch.randn(rows, C, device=dev) * 2 + 0.5).bfloat16()
     gamma = (torch.randn(C, device=dev) * 0.2 + 1) if affine else None
     beta = (torch.randn(C, device=dev) * 0.1) if affine else None
-    sums = torch.zeros(2, C, device=dev)
+    sums = torch.empty(2, C, device=dev)
     ops.bn_stats(x, sums)
     y, mean, rstd = ops.bn_fwd_apply(x, sums, float(rows), 1e-5, gamma, beta, relu)
     rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
@@ -120,7 +120,7 @@ def test_batchnorm(dev, rows, C, affine, relu):
     ref = F.relu(ref) if relu else ref
     dy = torch.randn(rows, C, device=dev).bfloat16()
     ref.backward(dy.float())
-    s2 = torch.zeros(2, C, device=dev)
+    s2 = torch.empty(2, C, device=dev)
     ops.bn_bwd_stats(dy, x, mean, rstd, gamma, beta, relu, s2)
     dx = ops.bn_bwd_apply(dy, x, mean, rstd, gamma, beta, relu, s2, float(rows))
     assert rel(y, ref) < 1e-2 and rel(dx, xf.grad) < 1.5e-2

@@ -167,8 +167,57 @@ def test_full_size_loss_decreases_and_is_reproducible(full_size):
     hp = O.StepHyper(lr=1.5e-4 * 128 / 256)
     stats, _ = run_engine_steps(model, [(im, au, mk)] * 4, hp, start=1)
     assert stats[-1]["loss_pixel"] < stats[0]["loss_pixel"]            # same batch 4x: the MIM loss must go down
-    # same weights, same batch, no_grad forward twice: identical outputs (kernels are deterministic up to BN-stat atomics)
+    # same weights, same batch, no_grad forward twice: bit-identical outputs (no atomics on the data path)
     with torch.no_grad():
-        o1 = model(im.cuda(), au.cuda(), O.mim_targets(im, mk, cfg)[0].cuda(), 0.99, True)
-        sd1 = float(o1["contra_loss"])
-    assert np.isfinite(sd1)
+        msk = O.mim_targets(im, mk, cfg)[0].cuda()
+        mom = model._flat["momentum"].clone()
+        o1 = model(im.cuda(), au.cuda(), msk, 1.0, True)                # m = 1.0: the EMA leaves the momentum weights unchanged
+        v1 = o1["vis_out"][0].clone()
+        o2 = model(im.cuda(), au.cuda(), msk, 1.0, True)
+    assert torch.equal(mom, model._flat["momentum"])
+    assert torch.equal(v1, o2["vis_out"][0])
+    assert abs(float(o1["contra_loss"]) - float(o2["contra_loss"])) <= 1e-6 * abs(float(o1["contra_loss"]))
+
+
+def test_rccl_path_world1_matches_local_path():
+    """The data-parallel wrapper on a one-rank 'nccl' (= RCCL) group: every collective of the N>1 path is issued
+    (BN-statistics all-reduce, key all-gather, 17 gradient-bucket all-reduces, 1/world averaging) and the step must equal
+    the plain single-process step."""
+    import torch.distributed as dist
+    from dig_amd.parallel import DistributedDataParallel
+    cfg = O.DiGConfig(**O.TINY)
+    seed, B = 21, 4
+    hp = O.StepHyper(lr=1e-3)
+    im, au, mk = O.synthetic_batch(B, cfg, 900)
+    base = build_model(cfg, *O.det_state(cfg, seed))
+    (s0,), _ = run_engine_steps(base, [(im, au, mk)], hp)
+    g0 = base.flat_grads.clone()
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29633")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        m = build_model(cfg, *O.det_state(cfg, seed))
+        ddp = DistributedDataParallel(m)
+        assert m.comm.world == 1
+        from gpu_util import engine_args
+        from dig_amd.optim_factory import create_optimizer
+        from dig_amd.engine_for_pretraining_moco import train_one_epoch
+        from dig_amd.utils import NativeScalerWithGradNormCount
+        args = engine_args(hp)
+        opt = create_optimizer(args, ddp)
+        # force the collective code paths even though world == 1
+        m.comm.world_override = True
+        s1 = train_one_epoch(ddp, None, None, [([im, au, mk], torch.ones(1), torch.ones(1))], None, opt, torch.device("cuda:0"), 0,
+                             NativeScalerWithGradNormCount(), None, patch_size=4, normlize_target=False, start_steps=0,
+                             lr_schedule_values=np.full(2, hp.lr), wd_schedule_values=np.full(2, hp.weight_decay), args=args)
+        for k in ("loss", "loss_pixel", "loss_contrast", "grad_norm"):
+            assert abs(s1[k] - s0[k]) <= 1e-3 * abs(s0[k]) + 1e-5, (k, s1[k], s0[k])
+        assert not m.comm._pending
+        rel = ((m.flat_grads - g0).norm() / g0.norm()).item()
+        assert rel < 1e-6, rel                                           # every reduction on the gradient path is deterministic
+    finally:
+        if created:
+            dist.destroy_process_group()

@@ -51,8 +51,8 @@ for rows, C, affine, relu in [(1024, 4096, 1, 1), (4096, 512, 1, 1), (333, 256, 
     x = (torch.randn(rows, C, device=dev) * 2 + 0.5).bfloat16()
     gamma = (torch.randn(C, device=dev) * 0.2 + 1) if affine else None
     beta = (torch.randn(C, device=dev) * 0.1) if affine else None
-    sums = torch.zeros(2, C, device=dev)
-    L.call("dig_bn_stats", L.ptr(x), L.ptr(sums), rows, C, L.stream())
+    sums = torch.empty(2, C, device=dev)
+    _ops.bn_stats(x, sums)
     y = torch.empty_like(x); mean = torch.empty(C, device=dev); rstd = torch.empty(C, device=dev)
     L.call("dig_bn_fwd_apply", L.ptr(x), L.ptr(sums), cf(rows), cf(1e-5), L.ptr(gamma), L.ptr(beta), relu, L.ptr(y), L.ptr(mean), L.ptr(rstd), rows, C, L.stream())
     xf = x.float().requires_grad_(True)
@@ -63,8 +63,8 @@ for rows, C, affine, relu in [(1024, 4096, 1, 1), (4096, 512, 1, 1), (333, 256, 
         ref = F.relu(ref)
     dy = torch.randn(rows, C, device=dev).bfloat16()
     ref.backward(dy.float())
-    s2 = torch.zeros(2, C, device=dev)
-    L.call("dig_bn_bwd_stats", L.ptr(dy), L.ptr(x), L.ptr(mean), L.ptr(rstd), L.ptr(gamma), L.ptr(beta), relu, L.ptr(s2), rows, C, L.stream())
+    s2 = torch.empty(2, C, device=dev)
+    _ops.bn_bwd_stats(dy, x, mean, rstd, gamma, beta, relu, s2)
     s2g = s2.clone()
     dx = torch.empty_like(x)
     L.call("dig_bn_bwd_apply", L.ptr(dy), L.ptr(x), L.ptr(mean), L.ptr(rstd), L.ptr(gamma), L.ptr(beta), relu, L.ptr(s2g), cf(rows), L.ptr(dx), rows, C, L.stream())
