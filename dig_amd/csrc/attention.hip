@@ -67,10 +67,9 @@ __device__ __forceinline__ bf16x8 frag_tr(const unsigned char* tile, int r0, int
 }
 
 __device__ __forceinline__ bf16x8 pack8(const f32x16& a, int u) {
-  bf16x8 r;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) r[e] = (short)f2bf(a[u * 8 + e]);
-  return r;
+  const uint4 w = make_uint4(pack_bf2(a[u * 8], a[u * 8 + 1]), pack_bf2(a[u * 8 + 2], a[u * 8 + 3]),
+                             pack_bf2(a[u * 8 + 4], a[u * 8 + 5]), pack_bf2(a[u * 8 + 6], a[u * 8 + 7]));
+  return __builtin_bit_cast(bf16x8, w);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -22,16 +22,15 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
-// round-to-nearest-even fp32 -> bf16 (NaN preserved as quiet NaN)
-__device__ __forceinline__ bf16_t f2bf(float f) {
-  unsigned u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
-}
+// fp32 -> bf16, round-to-nearest-even, via the gfx950 packed converter (v_cvt_pk_bf16_f32: one instruction per PAIR;
+// a hand-rolled integer rounding costs ~10 VALU ops per value and was the largest VALU item of every epilogue)
+typedef __bf16 dig_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float dig_f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
-  return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+  const dig_f32x2 v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, dig_bf16x2));
 }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf2(f, 0.f) & 0xffffu); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
