@@ -48,6 +48,7 @@ struct GemmParams {
   int act;
   int r_per_split;
   int tiles_i, tiles_j;
+  int splits_x;                           // >0: 1-D grid of tiles*splits blocks, every R-split pinned to one XCD
 };
 
 constexpr int BI = 128, BJ = 128;
@@ -118,11 +119,23 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
 
   const int nblk = p.tiles_i * p.tiles_j;
   const int bid = blockIdx.x;
-  const int q = nblk >> 3, rm = nblk & 7, xcd = bid & 7;
-  const int logical = (xcd < rm ? xcd * (q + 1) : rm * (q + 1) + (xcd - rm) * q) + (bid >> 3);
+  int logical, split;
+  if (p.splits_x > 0) {
+    // split-R (weight-gradient) launches: all tiles of one R-split run back-to-back on ONE XCD (block b -> XCD b%8), so the
+    // row window of both operands that the split streams is fetched from HBM once and re-read from that XCD's L2 by the
+    // other tiles.  (Spreading a split's tiles over the XCDs fetched every operand ~2.3x: profiles/r01_pmc_traffic.json.)
+    const int k = bid >> 3;
+    const int round = k / nblk;
+    split = (bid & 7) + 8 * round;
+    logical = k - round * nblk;
+  } else {
+    const int q = nblk >> 3, rm = nblk & 7, xcd = bid & 7;
+    logical = (xcd < rm ? xcd * (q + 1) : rm * (q + 1) + (xcd - rm) * q) + (bid >> 3);
+    split = blockIdx.z;
+  }
   const int ti = logical / p.tiles_j, tj = logical - ti * p.tiles_j;
   const int i0 = ti * BI, j0 = tj * BJ;
-  const int rbeg = blockIdx.z * p.r_per_split;
+  const int rbeg = split * p.r_per_split;
   const int rend = min(p.R, rbeg + p.r_per_split);
   const int nt = (rend - rbeg + BK - 1) / BK;
 
@@ -219,7 +232,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
   float* stg = reinterpret_cast<float*>(smem + wave * 8192);      // 32 rows x 64 fp32 per wave, per half
   const float al = (j < p.alpha_cols) ? p.alpha : 1.0f;
   float* cpart = reinterpret_cast<float*>(p.C);
-  if (OUT == 2) cpart += (size_t)blockIdx.z * p.I * p.ldc;         // split-R partial slab
+  if (OUT == 2) cpart += (size_t)split * p.I * p.ldc;         // split-R partial slab
 #pragma unroll
   for (int a = 0; a < 2; ++a) {
     {
@@ -765,8 +778,10 @@ int launch(const GemmParams& p, int splits, hipStream_t stream) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_set = true;
   }
-  dim3 grid(p.tiles_i * p.tiles_j, 1, splits);
-  hipLaunchKernelGGL((gemm_kernel<TA, TB, OUT, BK, RES, NSTG>), grid, dim3(256), LDS, stream, p);
+  GemmParams q = p;
+  q.splits_x = (splits > 1 && splits % 8 == 0) ? splits : 0;
+  dim3 grid(p.tiles_i * p.tiles_j * (q.splits_x ? splits : 1), 1, q.splits_x ? 1 : splits);
+  hipLaunchKernelGGL((gemm_kernel<TA, TB, OUT, BK, RES, NSTG>), grid, dim3(256), LDS, stream, q);
   return dig_check_launch();
 }
 
@@ -791,6 +806,7 @@ extern "C" int dig_gemm_bf16(const void* A, const void* B, void* C, int I, int J
   if (out_kind != 2 && splits != 1) return DIG_ERR_ARG;
   if (out_kind == 2 && ldc != J) return DIG_ERR_ARG;            // partial slabs are dense [splits][I][J]
   GemmParams p;
+  p.splits_x = 0;
   p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C;
   p.I = I; p.J = J; p.R = R; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
   // a_rows / b_rows (0 = default) bound the rows that really exist in memory; rows past them read as zero.

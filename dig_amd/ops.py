@@ -81,17 +81,26 @@ def linear_dgrad(dy, w, out=None, gelu_pre=None):
 
 
 def wgrad_splits(rows, tiles):
-    s = max(1, min(rows // 512, (512 + tiles - 1) // tiles))
-    return L.lib().dig_gemm_effective_splits(rows, s)
+    """(R-splits, BK) of a weight-gradient GEMM.  Splits come in multiples of 8 so that every split is pinned to one XCD
+    (csrc/gemm.hip: its tiles then share the operand rows through that XCD's L2 instead of re-fetching them from HBM);
+    measured on MI355X with tools/gpu_gemm_shapes.py wgrad: 36 tiles -> 24 splits / BK 32, 9 tiles -> 40 / BK 64."""
+    if tiles >= 24:
+        want, bk = 24, 32
+    else:
+        want, bk = min(40, 8 * max(1, round(360 / tiles / 8))), 64
+    cap = max(1, rows // 512)
+    if cap < want:
+        want = max(1, (cap // 8) * 8 or cap)
+    return L.lib().dig_gemm_effective_splits(rows, want), bk
 
 
 def wgrad(dy, x, dw, I, J, rows):
     """dw[I,J] += dy[rows, :I]^T @ x[rows, :J]: split over rows into fp32 slabs, then one deterministic reduce that
     also performs the += into the gradient arena."""
     tiles = ((I + 127) // 128) * ((J + 127) // 128)
-    sp = wgrad_splits(rows, tiles)
+    sp, bk = wgrad_splits(rows, tiles)
     ws = _workspace(dy.device, sp * I * J)
-    gemm(dy, x, I, J, rows, ta=True, tb=True, out=ws, out_kind=OUT_F32_PARTIAL, splits=sp, ldc=J)
+    gemm(dy, x, I, J, rows, ta=True, tb=True, out=ws, out_kind=OUT_F32_PARTIAL, splits=sp, ldc=J, bk=bk)
     L.call("dig_reduce_partials", L.ptr(ws), sp, cll(I * J), L.ptr(dw), 1, L.stream())
 
 
@@ -189,7 +198,7 @@ def window_pool_bwd(dpool, dx, n_img, gh, gw, nwin, D, accumulate):
 
 def mask_to_index(mask_u8, max_per_sample):
     B, N = mask_u8.shape
-    idx = torch.empty((B, max_per_sample), device=mask_u8.device, dtype=torch.int32)
+    idx = torch.zeros((B, max_per_sample), device=mask_u8.device, dtype=torch.int32)   # ragged masks are reported one step late
     cnt = torch.empty((B,), device=mask_u8.device, dtype=torch.int32)
     L.call("dig_mask_to_index", L.ptr(mask_u8), L.ptr(idx), L.ptr(cnt), B, N, max_per_sample, L.stream())
     return idx, cnt
