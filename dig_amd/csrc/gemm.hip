@@ -558,10 +558,13 @@ __device__ __forceinline__ bf16x8 wload_frag(const unsigned char* tile, int rowo
   }
 }
 
-template <int WM, int WN, int BK, int NSTG>
+// WM x WN waves, each owning an (FM*32) x (FN*32) block of the tile as FM x FN MFMA accumulators.  Per 16-deep K step a wave
+// reads FM + FN operand fragments from LDS for FM*FN MFMAs: 2x2 -> 1 read per MFMA, 4x2 -> 0.75, 4x4 -> 0.5 (the LDS pipe, not
+// the matrix core, bounds the 2x2 shape: MI355X_MICROARCH.md LDS table, 256 B/clk).
+template <int WM, int WN, int FM, int FN, int BK, int NSTG>
 struct WideCfg {
   static constexpr int NT = 64 * WM * WN;
-  static constexpr int TBI = 64 * WM, TBJ = 64 * WN;
+  static constexpr int TBI = 32 * FM * WM, TBJ = 32 * FN * WN;
   static constexpr int A_BYTES = TBI * BK * 2, B_BYTES = TBJ * BK * 2;
   static constexpr int STAGE = A_BYTES + B_BYTES;
   static constexpr int NITA = A_BYTES / 16 / NT, NITB = B_BYTES / 16 / NT;
@@ -571,9 +574,10 @@ struct WideCfg {
 // BK = 64 / NSTG = 2: one stage in flight (wait-all hand-off).  BK = 32 / NSTG = 4: three half-depth stages in flight with a
 // counted s_waitcnt vmcnt -- a 256x256x32 step is long enough (about 0.4 us of MFMA) for that look-ahead to cover the
 // L2/HBM -> LDS latency, which a 128x128 tile's step is not.
-template <bool TA, bool TB, int OUT, int WM, int WN, bool RES, int BK, int NSTG>
+template <bool TA, bool TB, int OUT, int WM, int WN, int FM, int FN, bool RES, int BK, int NSTG>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_wide_kernel(GemmParams p) {
-  using Cfg = WideCfg<WM, WN, BK, NSTG>;
+  using Cfg = WideCfg<WM, WN, FM, FN, BK, NSTG>;
+  static_assert(FN % 2 == 0 && Cfg::NITA <= 8 && Cfg::NITB <= 8, "tile shape");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -591,7 +595,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_wide_kernel(GemmParams p) {
 
   const auto ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
   const auto rb_ = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.b_bytes, 0x00020000);
-  unsigned offA[4], offB[4];
+  unsigned offA[8], offB[8];
 #pragma unroll
   for (int it = 0; it < Cfg::NITA; ++it) offA[it] = wstage_offset<TA, Cfg::TBI, BK>(it * Cfg::NT + tid, i0, rbeg, p.lda);
 #pragma unroll
@@ -613,11 +617,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_wide_kernel(GemmParams p) {
     }
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[FM][FN];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < FM; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < FN; ++b)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
@@ -634,24 +638,28 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_wide_kernel(GemmParams p) {
     const unsigned char* bt = at + Cfg::A_BYTES;
 #pragma unroll
     for (int s = 0; s < BK / 16; ++s) {
-      bf16x8 af[2], bfr[2];
+      bf16x8 af[FM], bfr[FN];
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        af[u] = wload_frag<TA, Cfg::TBI, BK>(at, wi * 64 + u * 32, s, lane);
-        bfr[u] = wload_frag<TB, Cfg::TBJ, BK>(bt, wj * 64 + u * 32, s, lane);
-      }
+      for (int u = 0; u < FM; ++u) af[u] = wload_frag<TA, Cfg::TBI, BK>(at, wi * (32 * FM) + u * 32, s, lane);
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+      for (int u = 0; u < FN; ++u) bfr[u] = wload_frag<TB, Cfg::TBJ, BK>(bt, wj * (32 * FN) + u * 32, s, lane);
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+      for (int a = 0; a < FM; ++a)
+#pragma unroll
+        for (int b = 0; b < FN; ++b)
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[b], af[a], acc[a][b], 0, 0, 0);
     }
   }
   __syncthreads();
 
-  // ---- epilogue (C-shuffle per wave, two 32-row halves; same contract as gemm_kernel)
+  // ---- epilogue (C-shuffle per wave in 32-row x 64-column pieces; same contract as gemm_kernel)
   const int cg = lane & 7;
-  const int j = j0 + wj * 64 + cg * 8;
+  float* stg = reinterpret_cast<float*>(smem + wave * 8192);
+  float* cpart = reinterpret_cast<float*>(p.C);
+  if (OUT == 2) cpart += (size_t)blockIdx.z * p.I * p.ldc;
+#pragma unroll
+  for (int bh = 0; bh < FN / 2; ++bh) {
+  const int j = j0 + wj * (32 * FN) + bh * 64 + cg * 8;
   const bool jok = j < p.J;
   const int jc = jok ? j : 0;
   float bias8[8];
@@ -664,17 +672,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_wide_kernel(GemmParams p) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
   }
-  float* stg = reinterpret_cast<float*>(smem + wave * 8192);
   const float al = (j < p.alpha_cols) ? p.alpha : 1.0f;
-  float* cpart = reinterpret_cast<float*>(p.C);
-  if (OUT == 2) cpart += (size_t)blockIdx.z * p.I * p.ldc;
 #pragma unroll
-  for (int a = 0; a < 2; ++a) {
+  for (int a = 0; a < FM; ++a) {
     uint4 rres[RES ? 4 : 1];
     if (RES) {
 #pragma unroll
       for (int q4 = 0; q4 < 4; ++q4) {
-        const int i = min(i0 + wi * 64 + a * 32 + q4 * 8 + (lane >> 3), p.I - 1);
+        const int i = min(i0 + wi * (32 * FM) + a * 32 + q4 * 8 + (lane >> 3), p.I - 1);
         rres[q4] = *reinterpret_cast<const uint4*>(p.resid + (size_t)i * p.ldr + jc);
       }
     }
@@ -686,7 +691,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_wide_kernel(GemmParams p) {
         for (int g = 0; g < 4; ++g) {
           const int chunk = (b * 32 + 8 * g + 4 * hi) >> 2;
           *reinterpret_cast<float4*>(stg + row * 64 + ((chunk ^ (row & 15)) << 2)) =
-              make_float4(acc[a][b][g * 4], acc[a][b][g * 4 + 1], acc[a][b][g * 4 + 2], acc[a][b][g * 4 + 3]);
+              make_float4(acc[a][2 * bh + b][g * 4], acc[a][2 * bh + b][g * 4 + 1], acc[a][2 * bh + b][g * 4 + 2], acc[a][2 * bh + b][g * 4 + 3]);
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -694,7 +699,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_wide_kernel(GemmParams p) {
 #pragma unroll
     for (int q4 = 0; q4 < 4; ++q4) {
       const int row = q4 * 8 + (lane >> 3);
-      const int i = i0 + wi * 64 + a * 32 + row;
+      const int i = i0 + wi * (32 * FM) + a * 32 + row;
       const float4 x0 = *reinterpret_cast<const float4*>(stg + row * 64 + (((2 * cg) ^ (row & 15)) << 2));
       const float4 x1 = *reinterpret_cast<const float4*>(stg + row * 64 + (((2 * cg + 1) ^ (row & 15)) << 2));
       const bool live = (i < p.I) && jok;
@@ -738,21 +743,22 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_wide_kernel(GemmParams p) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
   }
+  }
 }
 
-template <bool TA, bool TB, int OUT, int WM, int WN, bool RES, int BK, int NSTG>
+template <bool TA, bool TB, int OUT, int WM, int WN, int FM, int FN, bool RES, int BK, int NSTG>
 int launch_wide(GemmParams p, int splits, hipStream_t stream) {
-  using Cfg = WideCfg<WM, WN, BK, NSTG>;
+  using Cfg = WideCfg<WM, WN, FM, FN, BK, NSTG>;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wide_kernel<TA, TB, OUT, WM, WN, RES, BK, NSTG>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wide_kernel<TA, TB, OUT, WM, WN, FM, FN, RES, BK, NSTG>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
     attr_set = true;
   }
   p.tiles_i = (p.I + Cfg::TBI - 1) / Cfg::TBI;
   p.tiles_j = (p.J + Cfg::TBJ - 1) / Cfg::TBJ;
   dim3 grid(p.tiles_i * p.tiles_j, 1, splits);
-  hipLaunchKernelGGL((gemm_wide_kernel<TA, TB, OUT, WM, WN, RES, BK, NSTG>), grid, dim3(Cfg::NT), Cfg::LDS, stream, p);
+  hipLaunchKernelGGL((gemm_wide_kernel<TA, TB, OUT, WM, WN, FM, FN, RES, BK, NSTG>), grid, dim3(Cfg::NT), Cfg::LDS, stream, p);
   return dig_check_launch();
 }
 
@@ -794,7 +800,7 @@ extern "C" int dig_gemm_bf16(const void* A, const void* B, void* C, int I, int J
                              int b_rows, int bk, hipStream_t stream) {
   if (!A || !B || !C || I <= 0 || J <= 0 || R <= 0 || splits < 1) return DIG_ERR_ARG;
   if (bias && !aligned16(bias)) return DIG_ERR_ALIGN;
-  if (out_kind < 0 || out_kind > 2 || act < 0 || act > 2 || (bk != 0 && bk != 32 && bk != 33 && bk != 34 && bk != 64 && bk != 132 && bk != 164 && bk != 244 && bk != 242 && bk != 224 && bk != 344 && bk != 343)) return DIG_ERR_ARG;
+  if (out_kind < 0 || out_kind > 2 || act < 0 || act > 2 || (bk != 0 && bk != 32 && bk != 33 && bk != 34 && bk != 64 && bk != 132 && bk != 164 && bk != 244 && bk != 242 && bk != 224 && bk != 344 && bk != 343 && bk != 448 && bk != 484 && bk != 444 && bk != 432)) return DIG_ERR_ARG;
   if (act == 2 && !resid) return DIG_ERR_ARG;                   // act 2: resid carries the saved pre-activation
   if (bk >= 100 && bk < 200 && resid && pre_act) return DIG_ERR_UNSUPPORTED;
   if (bk == 0) bk = 64;
@@ -822,11 +828,15 @@ extern "C" int dig_gemm_bf16(const void* A, const void* B, void* C, int I, int J
   p.tiles_i = (I + BI - 1) / BI; p.tiles_j = (J + BJ - 1) / BJ;
 #define DIG_GEMM_WCASE(ta, tb, o)                                                                                   \
   if ((trans_a != 0) == ta && (trans_b != 0) == tb && out_kind == o && bk >= 200) {                                  \
-    if (bk == 244) return resid ? launch_wide<ta, tb, o, 4, 4, true, 64, 2>(p, splits, stream) : launch_wide<ta, tb, o, 4, 4, false, 64, 2>(p, splits, stream); \
-    if (bk == 344) return resid ? launch_wide<ta, tb, o, 4, 4, true, 32, 4>(p, splits, stream) : launch_wide<ta, tb, o, 4, 4, false, 32, 4>(p, splits, stream); \
-    if (bk == 343) return resid ? launch_wide<ta, tb, o, 4, 4, true, 32, 3>(p, splits, stream) : launch_wide<ta, tb, o, 4, 4, false, 32, 3>(p, splits, stream); \
-    if (bk == 242) return resid ? launch_wide<ta, tb, o, 4, 2, true, 64, 2>(p, splits, stream) : launch_wide<ta, tb, o, 4, 2, false, 64, 2>(p, splits, stream); \
-    return resid ? launch_wide<ta, tb, o, 2, 4, true, 64, 2>(p, splits, stream) : launch_wide<ta, tb, o, 2, 4, false, 64, 2>(p, splits, stream);               \
+    if (bk == 448) return resid ? launch_wide<ta, tb, o, 2, 4, 4, 2, true, 64, 2>(p, splits, stream) : launch_wide<ta, tb, o, 2, 4, 4, 2, false, 64, 2>(p, splits, stream); \
+    if (bk == 484) return resid ? launch_wide<ta, tb, o, 4, 2, 2, 4, true, 64, 2>(p, splits, stream) : launch_wide<ta, tb, o, 4, 2, 2, 4, false, 64, 2>(p, splits, stream); \
+    if (bk == 444) return resid ? launch_wide<ta, tb, o, 2, 2, 4, 4, true, 64, 2>(p, splits, stream) : launch_wide<ta, tb, o, 2, 2, 4, 4, false, 64, 2>(p, splits, stream); \
+    if (bk == 432) return resid ? launch_wide<ta, tb, o, 2, 2, 4, 4, true, 32, 2>(p, splits, stream) : launch_wide<ta, tb, o, 2, 2, 4, 4, false, 32, 2>(p, splits, stream); \
+    if (bk == 244) return resid ? launch_wide<ta, tb, o, 4, 4, 2, 2, true, 64, 2>(p, splits, stream) : launch_wide<ta, tb, o, 4, 4, 2, 2, false, 64, 2>(p, splits, stream); \
+    if (bk == 344) return resid ? launch_wide<ta, tb, o, 4, 4, 2, 2, true, 32, 4>(p, splits, stream) : launch_wide<ta, tb, o, 4, 4, 2, 2, false, 32, 4>(p, splits, stream); \
+    if (bk == 343) return resid ? launch_wide<ta, tb, o, 4, 4, 2, 2, true, 32, 3>(p, splits, stream) : launch_wide<ta, tb, o, 4, 4, 2, 2, false, 32, 3>(p, splits, stream); \
+    if (bk == 242) return resid ? launch_wide<ta, tb, o, 4, 2, 2, 2, true, 64, 2>(p, splits, stream) : launch_wide<ta, tb, o, 4, 2, 2, 2, false, 64, 2>(p, splits, stream); \
+    return resid ? launch_wide<ta, tb, o, 2, 4, 2, 2, true, 64, 2>(p, splits, stream) : launch_wide<ta, tb, o, 2, 4, 2, 2, false, 64, 2>(p, splits, stream);               \
   }
   DIG_GEMM_WCASE(false, false, 0)
   DIG_GEMM_WCASE(false, false, 1)

@@ -59,6 +59,31 @@ def test_gemm_fwd_dgrad_wgrad(dev, I, J, R, bk):
         ops.GEMM_BK_FWD, ops.GEMM_BK_BWD = 64, 32
 
 
+@pytest.mark.parametrize("I,J,R", [(2048, 1152, 384), (716, 200, 192), (8192, 1536, 384), (300, 520, 64)])
+@pytest.mark.parametrize("bk", [244, 242, 224, 344, 343, 448, 484, 444, 432])
+def test_gemm_wide_tile_variants(dev, I, J, R, bk):
+    """Every multi-wave tile shape of gemm_wide_kernel (WM x WN waves of FM x FN MFMA blocks) on full and ragged tiles:
+    forward epilogues, transposed-B (dgrad) and split-R partial slabs (wgrad)."""
+    from dig_amd import ops
+    x = torch.randn(I, R, device=dev).bfloat16()
+    w = (torch.randn(J, R, device=dev) * 0.05).bfloat16()
+    bias = torch.randn(J, device=dev)
+    res = torch.randn(I, J, device=dev).bfloat16()
+    h = x.float() @ w.float().t() + bias
+    assert rel(ops.gemm(x, w, I, J, R, bias=bias, resid=res, bk=bk), h + res.float()) < 1e-2
+    pre = torch.empty(I, J, device=dev, dtype=torch.bfloat16)
+    y = ops.gemm(x, w, I, J, R, bias=bias, pre=pre, act=1, bk=bk)
+    assert rel(y, F.gelu(h)) < 1e-2 and rel(pre, h) < 1e-2
+    assert rel(ops.gemm(x, w, I, J, R, bias=bias, out_kind=ops.OUT_F32, bk=bk), h) < 1e-5
+    dy = torch.randn(I, J, device=dev).bfloat16()
+    if J % 64 == 0:
+        assert rel(ops.gemm(dy, w, I, R, J, tb=True, bk=bk), dy.float() @ w.float()) < 1e-2
+    sp = ops.L.lib().dig_gemm_effective_splits(I, 3)
+    ws = torch.empty(sp, J, R, device=dev)
+    ops.gemm(dy, x, J, R, I, ta=True, tb=True, out=ws, out_kind=ops.OUT_F32_PARTIAL, splits=sp, ldc=R, bk=bk)
+    assert rel(ws.sum(0), dy.float().t() @ x.float()) < 2e-5
+
+
 @pytest.mark.parametrize("Bn,H,scale,spike", [(2, 2, 1.0, False), (4, 6, 0.125, False), (3, 8, 0.125, True)])
 def test_attention_fwd_bwd(dev, Bn, H, scale, spike):
     from dig_amd import ops
