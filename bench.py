@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--batch", type=int, default=128, help="samples per GPU")
     ap.add_argument("--model", default="small", choices=["tiny", "small", "base"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-mim-only", action="store_true", help="skip the extra BASELINE configs[1] (MIM-only) measurement")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     a = ap.parse_args()
 
@@ -145,7 +146,7 @@ def main():
                                  lr=1.5e-4 * B * world / 256, weight_decay=0.1, opt_eps=1e-8, opt_betas=[0.9, 0.999])
     opt = create_optimizer(args, model)
     scaler = U.NativeScalerWithGradNormCount()
-    total = a.warmup + a.steps + 4
+    total = a.warmup + 2 * a.steps + 8
     lr_s, wd_s = np.full(total + 8, args.lr), np.full(total + 8, 0.1)
     batches = synth_batches(4, B, dev, 1234 + rank)
 
@@ -171,6 +172,29 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
+    # ---- BASELINE configs[1] (MIM-only, loss_weight_contrast = 0) on the same model state: reported beside the headline
+    mim_only = None
+    if not a.no_mim_only:
+        args.loss_weight_contrast = 0.0
+        run(2, a.warmup + a.steps)
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run(a.steps, a.warmup + a.steps + 2)
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        dt1 = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([dt1], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt1 = float(t.item())
+        args.loss_weight_contrast = 0.1
+        mim_only = {"workload": "BASELINE configs[1]: same model/batch, loss_weight_contrast=0 (contrastive forward still runs for the "
+                                "loss_contrast/accuracy meters; its backward and the augmented view's encoder backward are exact zeros "
+                                "in the reference and are not launched)",
+                    "value": a.steps * B * world / dt1, "unit": "images/sec", "ms_per_step": dt1 / a.steps * 1e3, "steps": a.steps}
     # ---- roofline of the dominant kernel: one extra, instrumented step (outside the timed region)
     roof = None
     if rank == 0:
@@ -213,7 +237,7 @@ def main():
                                    f"T 0.2, 4 windows, mask 0.7, 2 views, AdamW wd 0.1), {B} samples/GPU, random-init weights",
                        "global_batch": B * world, "parallelism": f"dp{world}", "loss": float(stats.get("loss", float('nan')))},
             "step_mfma_frac": (value / world * fl / PEAK_BF16) if fl else None,
-            "roofline": roof}
+            "roofline": roof, "mim_only": mim_only}
     if not a.no_cpu_baseline and world == 1:
         line["cpu_baseline"] = cpu_baseline(model_name, a.cpu_budget)
     print(json.dumps(line), flush=True)

@@ -636,18 +636,26 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_wide_kernel(GemmParams p) {
     if (t + LA < nt) stage((t + LA) % NSTG);
     const unsigned char* at = smem + (t % NSTG) * Cfg::STAGE;
     const unsigned char* bt = at + Cfg::A_BYTES;
+    // fragments of K-step s+1 are fetched from LDS while the MFMAs of step s run (register double buffer)
+    bf16x8 af[2][FM], bfr[2][FN];
+#pragma unroll
+    for (int u = 0; u < FM; ++u) af[0][u] = wload_frag<TA, Cfg::TBI, BK>(at, wi * (32 * FM) + u * 32, 0, lane);
+#pragma unroll
+    for (int u = 0; u < FN; ++u) bfr[0][u] = wload_frag<TB, Cfg::TBJ, BK>(bt, wj * (32 * FN) + u * 32, 0, lane);
 #pragma unroll
     for (int s = 0; s < BK / 16; ++s) {
-      bf16x8 af[FM], bfr[FN];
+      if (s + 1 < BK / 16) {
 #pragma unroll
-      for (int u = 0; u < FM; ++u) af[u] = wload_frag<TA, Cfg::TBI, BK>(at, wi * (32 * FM) + u * 32, s, lane);
+        for (int u = 0; u < FM; ++u) af[(s + 1) & 1][u] = wload_frag<TA, Cfg::TBI, BK>(at, wi * (32 * FM) + u * 32, s + 1, lane);
 #pragma unroll
-      for (int u = 0; u < FN; ++u) bfr[u] = wload_frag<TB, Cfg::TBJ, BK>(bt, wj * (32 * FN) + u * 32, s, lane);
+        for (int u = 0; u < FN; ++u) bfr[(s + 1) & 1][u] = wload_frag<TB, Cfg::TBJ, BK>(bt, wj * (32 * FN) + u * 32, s + 1, lane);
+      }
+      __builtin_amdgcn_sched_barrier(0);             // keep the LDS reads ahead of the MFMAs they overlap with
 #pragma unroll
       for (int a = 0; a < FM; ++a)
 #pragma unroll
         for (int b = 0; b < FN; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[b], af[a], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[s & 1][b], af[s & 1][a], acc[a][b], 0, 0, 0);
     }
   }
   __syncthreads();

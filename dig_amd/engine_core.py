@@ -99,7 +99,7 @@ class _Step:
             x = x_out
         return x, saved
 
-    def encoder_backward(self, ew, saved, dx, images, aug, mask_u8):
+    def encoder_backward(self, ew, saved, dx, images, aug, mask_u8, views=2):
         """dx: bf16 [R, D] gradient w.r.t. the encoder output (consumed).
         The data-gradient chain (dgrad GEMMs, attention backward, LayerNorm backward) runs on the caller's stream; the
         weight-gradient GEMMs and bias column sums only consume (dy, saved activation) pairs, so they are issued on a
@@ -125,6 +125,10 @@ class _Step:
             blk, g = ew.blocks[i], ew.blocks[i]["g"]
             x, ln1, mu1, rs1, qkv, ctx, lse, x_mid, ln2, mu2, rs2, pre, act = saved[i]
             saved[i] = None
+            if views == 1:            # only view 0 carries a gradient (zero contrastive weight): rows [0, B*N) of everything
+                Rh = B * N
+                x, ln1, mu1, rs1, qkv, ctx, x_mid, ln2, mu2, rs2, pre, act = (t[:Rh] for t in (x, ln1, mu1, rs1, qkv, ctx, x_mid, ln2, mu2, rs2, pre, act))
+                lse = lse[:B * H]
             # x_out = x_mid + fc2(gelu(fc1(ln2)))
             on_side(lambda: ops.linear_wgrad(dx, act, g["mlp.fc2.weight"]), dx, act)
             dact = ops.linear_dgrad(dx, blk["mlp.fc2.weight"], gelu_pre=pre)       # d(pre-activation), GELU' fused
@@ -135,7 +139,7 @@ class _Step:
             # x_mid = x + proj(attn(ln1))
             on_side(lambda: ops.linear_wgrad(dx_mid, ctx, g["attn.proj.weight"]), dx_mid, ctx)
             dctx = ops.linear_dgrad(dx_mid, blk["attn.proj.weight"])
-            dqkv = ops.attn_bwd(qkv, ctx, dctx, lse, 2 * B, H, D, scale)
+            dqkv = ops.attn_bwd(qkv, ctx, dctx, lse, views * B, H, D, scale)
             gb = g["qkv_bias"]
             on_side(lambda: (ops.linear_wgrad(dqkv, ln1, g["attn.qkv.weight"]),
                              ops.colsum(dqkv, gb[:D], cols=D),                 # q_bias (dq already carries the q scale)
@@ -148,7 +152,7 @@ class _Step:
             if self.comm.world > 1 or getattr(self.comm, "world_override", False):
                 main.wait_stream(side)                                        # this block's gradients are final on both streams
             self.comm.grad_ready(M, f"encoder.blocks.{i}")
-        for half, im in enumerate((images, aug)):
+        for half, im in enumerate((images, aug)[:views]):
             ops.patch_embed_bwd_mfma(dx[half * B * N:(half + 1) * B * N], im, mask_u8[half * B:(half + 1) * B], ew.g_pe_w, ew.g_pe_b,
                                      ew.g_mask_token, D, M.gh, M.gw)
         main.wait_stream(side)
@@ -297,26 +301,31 @@ class _Step:
         B, D, N, nw = self.B, M.D, M.N, M.num_windows
         dev = self.enc.device
         w16, f32, g32 = M._w("online"), M._f32, M._g32
-        d_enc = torch.empty_like(self.enc)
-        # ---- contrastive path
+        # ---- contrastive path.  g_contra is None when the loss did not use contra_loss (zero contrastive weight: epochs before
+        # contrast_start_epoch, BASELINE config 2): every gradient of that branch -- predictor, projector, pix_projector and
+        # the whole augmented view -- is exactly zero in the reference, so nothing is launched for it and the encoder
+        # backward runs on view 0's rows only (the gradient arena was zero-filled by optimizer.zero_grad()).
+        views = 2 if g_contra is not None else 1
+        d_enc = torch.empty_like(self.enc) if views == 2 else torch.zeros((B * N, D), device=dev, dtype=BF16)
         n = B * nw
-        dqn = self.dqn
-        if g_contra is not None:
+        if views == 2:
+            dqn = self.dqn
             ops.scale_by_device_scalar(dqn, g_contra.reshape(1).float())
+            dq = ops.l2norm_bwd(dqn, self.qn, self.q_inv)
+            dq16 = torch.empty(dq.shape, device=dev, dtype=BF16)
+            ops.cast_f32_to_bf16(dq, dq16)
+            dproj = self.mlp_backward(dq16, "predictor", self.saved_pred)
+            self.comm.grad_ready(M, "predictor")
+            dpool = self.mlp_backward(dproj, "encoder_projection_layer", self.saved_proj)
+            self.comm.grad_ready(M, "encoder_projection_layer")
+            dmasked2 = torch.empty((B * N, D), device=dev, dtype=BF16)
+            ops.window_pool_bwd(dpool[:n], dmasked2, B, M.gh, M.gw, nw, D, False)
+            ops.window_pool_bwd(dpool[n:], d_enc[B * N:], B, M.gh, M.gw, nw, D, False)
+            self.mlp_backward(dmasked2, "pix_projector", self.saved_pix, dx_out=d_enc[:B * N])
+            self.comm.grad_ready(M, "pix_projector")
         else:
-            ops.fill_f32(dqn, 0.0)
-        dq = ops.l2norm_bwd(dqn, self.qn, self.q_inv)
-        dq16 = torch.empty(dq.shape, device=dev, dtype=BF16)
-        ops.cast_f32_to_bf16(dq, dq16)
-        dproj = self.mlp_backward(dq16, "predictor", self.saved_pred)
-        self.comm.grad_ready(M, "predictor")
-        dpool = self.mlp_backward(dproj, "encoder_projection_layer", self.saved_proj)
-        self.comm.grad_ready(M, "encoder_projection_layer")
-        dmasked2 = torch.empty((B * N, D), device=dev, dtype=BF16)
-        ops.window_pool_bwd(dpool[:n], dmasked2, B, M.gh, M.gw, nw, D, False)
-        ops.window_pool_bwd(dpool[n:], d_enc[B * N:], B, M.gh, M.gw, nw, D, False)
-        self.mlp_backward(dmasked2, "pix_projector", self.saved_pix, dx_out=d_enc[:B * N])
-        self.comm.grad_ready(M, "pix_projector")
+            for name in ("predictor", "encoder_projection_layer", "pix_projector"):
+                self.comm.grad_ready(M, name)
         # ---- SimMIM decoder path
         if g_vis is not None:
             gath, h0, h1, h2, mu, rs = self.saved_dec
@@ -336,7 +345,12 @@ class _Step:
         self.comm.grad_ready(M, "pix_decoder")
         # ---- encoder
         ew_on, _ = _weights(M)
-        self.encoder_backward(ew_on, self.saved_enc, d_enc, self.images, self.aug, self.mask_u8)
+        if views == 2 or g_vis is not None:
+            self.encoder_backward(ew_on, self.saved_enc, d_enc, self.images, self.aug, self.mask_u8, views=views)
+        else:
+            for i in reversed(range(M.depth)):
+                self.comm.grad_ready(M, f"encoder.blocks.{i}")
+            self.comm.grad_ready(M, "encoder.embed")
         self.saved_enc = self.saved_pix = self.saved_proj = self.saved_pred = self.saved_dec = None
 
 
@@ -346,6 +360,7 @@ class _DigFn(torch.autograd.Function):
         step = _Step(model)
         contra, accs, vis_out = step.forward(images, aug, mask, m)
         ctx.step = step
+        ctx.set_materialize_grads(False)          # an unused output arrives as None, not as a zero tensor (host-visible)
         ctx.mark_non_differentiable(accs)
         return contra, accs, vis_out
 

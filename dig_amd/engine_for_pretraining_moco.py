@@ -69,6 +69,8 @@ class _StepReadback:
             ev.synchronize()
             host = buf.tolist()
             loss_value = host[0]
+            if hv["w_contrast"] == 0.0 and not math.isfinite(host[1]):
+                loss_value = float('nan')
             if host[7] != host[8] or int(host[7]) != self.core._per_sample_mask:
                 raise RuntimeError("masks must select the same number of tokens in every sample "
                                    f"(got {int(host[7])}..{int(host[8])}, expected {self.core._per_sample_mask})")
@@ -147,7 +149,12 @@ def train_one_epoch(model: torch.nn.Module, teacher_model, teacher_model_without
         out_dict = model(images, aug_images, bool_vis_masked_pos, moco_m, args.only_mim_on_ori_img)
         loss = 0.
         contra_loss = out_dict['contra_loss']
-        loss = loss + contra_loss * float(contrast_loss_weights[step])
+        w_contrast = float(contrast_loss_weights[step])
+        if w_contrast != 0.0:
+            loss = loss + contra_loss * w_contrast
+        # else: the reference adds 0 * contra_loss (:137), which leaves the value unchanged and back-propagates exact zeros
+        # through the whole contrastive branch; leaving the term out lets the engine skip those launches (engine_core.backward).
+        # A non-finite contra_loss would have poisoned the reference's loss (0 * inf = nan): the readback keeps that exit.
         vis_out = out_dict['vis_out']
         loss_pixel = mim_mse_loss(vis_out[0], core._last_images, core._last_idx)
         loss = loss + loss_pixel * args.loss_weight_pixel
@@ -174,7 +181,7 @@ def train_one_epoch(model: torch.nn.Module, teacher_model, teacher_model_without
             if group["weight_decay"] > 0:
                 weight_decay_value = group["weight_decay"]
         readback.push(dev_vals, dict(loss_scale=loss_scale_value, lr=max_lr, min_lr=min_lr, weight_decay=weight_decay_value,
-                                     has_grad_norm=grad_norm is not None))
+                                     has_grad_norm=grad_norm is not None, w_contrast=w_contrast))
         readback.resolve(keep=1)
         if lr_scheduler is not None:
             lr_scheduler.step_update(start_steps + step)

@@ -57,6 +57,38 @@ def test_tiny_step_vs_oracle_with_bf16_yardstick():
             assert (p.detach().cpu() - tr.P[n]).abs().max().item() < 1e-6, n
 
 
+def test_zero_contrast_weight_skips_branch_but_matches_oracle():
+    """BASELINE config 2 / epochs before contrast_start_epoch: loss_weight_contrast = 0.  The reference back-propagates
+    exact zeros through the contrastive branch; the engine launches nothing for it and runs the encoder backward on
+    view 0 only.  Same losses/meters, same gradients (zero where the reference's are zero), same parameters after AdamW."""
+    cfg = O.DiGConfig(**O.TINY)
+    seed, B = 5, 4
+    hp = O.StepHyper(lr=1e-3, w_contrast=0.0)
+    im, au, mk = O.synthetic_batch(B, cfg, seed * 1000)
+    model = build_model(cfg, *O.det_state(cfg, seed))
+    (stats,), _ = run_engine_steps(model, [(im, au, mk)], hp)
+    grads = {n: p.grad.detach().float().cpu().clone() for n, p in model.named_parameters() if p.requires_grad}
+    hp0 = dataclasses.replace(hp, moco_m=O.adjust_moco_momentum(0.0, 10, hp.moco_m))
+    ref_m, ref_g, _, _ = O.OracleTrainer(cfg, *O.det_state(cfg, seed)).loss_and_grads(im, au, mk, hp0)
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        _, bf_g, _, _ = O.OracleTrainer(cfg, *O.det_state(cfg, seed)).loss_and_grads(im, au, mk, hp0)
+    for k in ("loss", "loss_pixel", "loss_contrast", "grad_norm"):
+        assert close(stats[k], ref_m[k]), (k, stats[k], ref_m[k])
+    assert close(stats["loss"], stats["loss_pixel"], rtol=1e-6, atol=1e-7)
+    cos = torch.nn.functional.cosine_similarity
+    n_zero = 0
+    for n, g in grads.items():
+        r = ref_g[n].reshape(1, -1)
+        if r.abs().max() == 0:                                            # contrastive-only parameters: exact zeros on both sides
+            assert g.abs().max().item() == 0.0, n
+            n_zero += 1
+            continue
+        c_hip, c_bf = cos(g.reshape(1, -1), r).item(), cos(bf_g[n].float().reshape(1, -1), r).item()
+        q_hip, q_bf = (g.norm() / r.norm()).item(), (bf_g[n].float().norm() / r.norm()).item()
+        assert (1 - c_hip) <= 2 * (1 - c_bf) + 5e-3 and abs(q_hip - 1) <= 2 * abs(q_bf - 1) + 3e-2, (n, c_hip, c_bf, q_hip, q_bf)
+    assert n_zero >= 10, n_zero                                           # predictor + projector + pix_projector weights
+
+
 def _fixture_step0(name):
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
     kw = {k: v for k, v in zip(g["cfg_keys"].tolist(), g["cfg_vals"].tolist())}
