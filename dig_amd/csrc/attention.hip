@@ -163,6 +163,31 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
 // ------------------------------------------------------------------------------------------------
 // backward: dqkv = d/d(qkv) given d(ctx); 8 waves, phase A (dQ, wave = query block), phase B (dK,dV, wave = key block)
 // ------------------------------------------------------------------------------------------------
+// Store one lane-row of a 32 x 64 result held as two 32x32 MFMA accumulators (lane = row, registers = 4-column groups
+// interleaved between the two lane halves).  v_permlane32_swap trades column groups between lane l and l+32 so that each
+// lane owns 16 contiguous columns per accumulator: 4 x 16-byte stores per row instead of 8 x 8-byte ones.
+__device__ __forceinline__ void store_rows(bf16_t* row, const f32x16 (&acc)[2], int hi) {
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt) {
+    unsigned P[4][2];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      P[g][0] = pack_bf2(acc[dt][g * 4], acc[dt][g * 4 + 1]);
+      P[g][1] = pack_bf2(acc[dt][g * 4 + 2], acc[dt][g * 4 + 3]);
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const auto r0 = __builtin_amdgcn_permlane32_swap(P[0][k], P[2][k], false, false);
+      P[0][k] = r0[0]; P[2][k] = r0[1];
+      const auto r1 = __builtin_amdgcn_permlane32_swap(P[1][k], P[3][k], false, false);
+      P[1][k] = r1[0]; P[3][k] = r1[1];
+    }
+    bf16_t* o = row + dt * 32 + hi * 16;
+    *reinterpret_cast<uint4*>(o) = make_uint4(P[0][0], P[0][1], P[2][0], P[2][1]);
+    *reinterpret_cast<uint4*>(o + 8) = make_uint4(P[1][0], P[1][1], P[3][0], P[3][1]);
+  }
+}
+
 __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ ctx,
                                                           const bf16_t* __restrict__ dctx, const float* __restrict__ lse,
                                                           bf16_t* __restrict__ dqkv, int D, int H, float scale,
@@ -224,16 +249,39 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(const bf16_t* __restri
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int e = 0; e < 16; ++e) dq[dt][e] = 0.f;
+    // Software pipeline over the 8 key tiles: operand fragments of tile kt+1 are requested from LDS right after the
+    // S / dP MFMAs of tile kt have issued, and the transposed K fragments of tile kt while its softmax arithmetic runs, so
+    // no MFMA waits on an LDS round trip (the compiler's own schedule put every ds_read directly in front of its MFMA).
+    bf16x8 kfr[4], vfr[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      kfr[s] = frag_direct(Kt, 0, s, lane);
+      vfr[s] = frag_direct(Vt, 0, s, lane);
+    }
 #pragma unroll 2
     for (int kt = 0; kt < 8; ++kt) {
       f32x16 st, dp;
 #pragma unroll
       for (int e = 0; e < 16; ++e) { st[e] = 0.f; dp[e] = 0.f; }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_direct(Kt, kt * 32, s, lane), qf[s], st, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_direct(Vt, kt * 32, s, lane), gf[s], dp, 0, 0, 0);
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[s], qf[s], st, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[s], gf[s], dp, 0, 0, 0);
       }
+      __builtin_amdgcn_sched_barrier(0);
+      bf16x8 ktr[2][2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) ktr[u][dt] = frag_tr(Kt, kt * 32 + u * 16, dt * 32, lane);
+      const int ktn = (kt + 1) & 7;                                        // (the wrap-around load of the last tile is unused)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        kfr[s] = frag_direct(Kt, ktn * 32, s, lane);
+        vfr[s] = frag_direct(Vt, ktn * 32, s, lane);
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int e = 0; e < 16; ++e) st[e] = __expf(st[e] - my_lse) * (dp[e] - my_del);   // dS^T
 #pragma unroll
@@ -241,18 +289,14 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(const bf16_t* __restri
         const bf16x8 ds = pack8(st, u);
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
-          dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Kt, kt * 32 + u * 16, dt * 32, lane), ds, dq[dt], 0, 0, 0);
+          dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktr[u][dt], ds, dq[dt], 0, 0, 0);
       }
     }
-    bf16_t* op = dqkv + (tok0 + q) * ld + h * DH;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int d = dt * 32 + 8 * g + 4 * hi;
-        *reinterpret_cast<uint2*>(op + d) = make_uint2(pack_bf2(dq[dt][g * 4] * scale, dq[dt][g * 4 + 1] * scale),
-                                                       pack_bf2(dq[dt][g * 4 + 2] * scale, dq[dt][g * 4 + 3] * scale));
-      }
+      for (int e = 0; e < 16; ++e) dq[dt][e] *= scale;
+    store_rows(dqkv + (tok0 + q) * ld + h * DH, dq, hi);
   }
 
   // ---------------- phase B: dK, dV for key block `wave` ----------------
@@ -270,51 +314,70 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(const bf16_t* __restri
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int e = 0; e < 16; ++e) { dk[dt][e] = 0.f; dv[dt][e] = 0.f; }
+    bf16x8 qfr[4], gfr[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      qfr[s] = frag_direct(Qt, 0, s, lane);
+      gfr[s] = frag_direct(Gt, 0, s, lane);
+    }
 #pragma unroll 2
     for (int qt = 0; qt < 8; ++qt) {
       f32x16 st, dp;   // rows = queries qt*32 + (e&3) + 8*(e>>2) + 4*hi, col = key
 #pragma unroll
       for (int e = 0; e < 16; ++e) { st[e] = 0.f; dp[e] = 0.f; }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_direct(Qt, qt * 32, s, lane), kf[s], st, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_direct(Gt, qt * 32, s, lane), vf[s], dp, 0, 0, 0);
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr[s], kf[s], st, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gfr[s], vf[s], dp, 0, 0, 0);
       }
+      __builtin_amdgcn_sched_barrier(0);
+      bf16x8 gtr[2][2], qtr[2][2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          gtr[u][dt] = frag_tr(Gt, qt * 32 + u * 16, dt * 32, lane);
+          qtr[u][dt] = frag_tr(Qt, qt * 32 + u * 16, dt * 32, lane);
+        }
+      float ls[4][4], dl[4][4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int qr = qt * 32 + 8 * g + 4 * hi;
         const float4 l4 = *reinterpret_cast<const float4*>(lse_s + qr);
         const float4 d4 = *reinterpret_cast<const float4*>(del_s + qr);
-        const float ls[4] = {l4.x, l4.y, l4.z, l4.w};
-        const float dl[4] = {d4.x, d4.y, d4.z, d4.w};
+        ls[g][0] = l4.x; ls[g][1] = l4.y; ls[g][2] = l4.z; ls[g][3] = l4.w;
+        dl[g][0] = d4.x; dl[g][1] = d4.y; dl[g][2] = d4.z; dl[g][3] = d4.w;
+      }
+      const int qtn = (qt + 1) & 7;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        qfr[s] = frag_direct(Qt, qtn * 32, s, lane);
+        gfr[s] = frag_direct(Gt, qtn * 32, s, lane);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float p = __expf(st[g * 4 + e] - ls[e]);
+          const float p = __expf(st[g * 4 + e] - ls[g][e]);
           st[g * 4 + e] = p;
-          dp[g * 4 + e] = p * (dp[g * 4 + e] - dl[e]);
+          dp[g * 4 + e] = p * (dp[g * 4 + e] - dl[g][e]);
         }
-      }
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const bf16x8 pf = pack8(st, u);
         const bf16x8 ds = pack8(dp, u);
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
-          dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Gt, qt * 32 + u * 16, dt * 32, lane), pf, dv[dt], 0, 0, 0);
-          dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Qt, qt * 32 + u * 16, dt * 32, lane), ds, dk[dt], 0, 0, 0);
+          dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gtr[u][dt], pf, dv[dt], 0, 0, 0);
+          dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtr[u][dt], ds, dk[dt], 0, 0, 0);
         }
       }
     }
     bf16_t* okp = dqkv + (tok0 + key) * ld + D + h * DH;
-    bf16_t* ovp = okp + D;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int d = dt * 32 + 8 * g + 4 * hi;
-        *reinterpret_cast<uint2*>(okp + d) = make_uint2(pack_bf2(dk[dt][g * 4], dk[dt][g * 4 + 1]), pack_bf2(dk[dt][g * 4 + 2], dk[dt][g * 4 + 3]));
-        *reinterpret_cast<uint2*>(ovp + d) = make_uint2(pack_bf2(dv[dt][g * 4], dv[dt][g * 4 + 1]), pack_bf2(dv[dt][g * 4 + 2], dv[dt][g * 4 + 3]));
-      }
+    store_rows(okp, dk, hi);
+    store_rows(okp + D, dv, hi);
   }
 }
 
