@@ -493,6 +493,14 @@ extern "C" int dig_colsum(const void* x, float* out, float* workspace, int rows,
   return dig_check_launch();
 }
 
+// out[c] += sum_b partials[b][c]  (the per-64-row column sums dig_gemm_bf16 writes with colsum_partials)
+extern "C" int dig_colsum_partials(const float* partials, int n_parts, int C, float* out, hipStream_t stream) {
+  if (!partials || !out || n_parts <= 0 || C <= 0 || (C & 7)) return DIG_ERR_ARG;
+  if (!aligned16(partials)) return DIG_ERR_ALIGN;
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(C / 8), dim3(256), 0, stream, partials, n_parts, C, out);
+  return dig_check_launch();
+}
+
 extern "C" int dig_patchify_bf16(const float* img, const unsigned char* mask, void* out, int n_img, int gh, int gw, hipStream_t stream) {
   if (!img || !out || n_img <= 0) return DIG_ERR_ARG;
   if (!aligned16(img) || !aligned16(out)) return DIG_ERR_ALIGN;

@@ -48,6 +48,7 @@ struct GemmParams {
   int act;
   int r_per_split;
   int tiles_i, tiles_j;
+  float* colsum;                          // act 2 only: [ceil(I/64)][J] per-64-row column sums of the result (fp32), or null
   int splits_x;                           // >0: 1-D grid of tiles*splits blocks, every R-split pinned to one XCD
 };
 
@@ -233,6 +234,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
   const float al = (j < p.alpha_cols) ? p.alpha : 1.0f;
   float* cpart = reinterpret_cast<float*>(p.C);
   if (OUT == 2) cpart += (size_t)split * p.I * p.ldc;         // split-R partial slab
+  float csum[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) csum[e] = 0.f;
 #pragma unroll
   for (int a = 0; a < 2; ++a) {
     {
@@ -279,6 +283,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
         const unsigned w[4] = {rres[ps].x, rres[ps].y, rres[ps].z, rres[ps].w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) { v[2 * e] *= dgelu_f(bf2f((bf16_t)(w[e] & 0xffff))); v[2 * e + 1] *= dgelu_f(bf2f((bf16_t)(w[e] >> 16))); }
+        if (live) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) csum[e] += v[e];
+        }
       }
       if (RES && p.act != 2) {
         const unsigned w[4] = {rres[ps].x, rres[ps].y, rres[ps].z, rres[ps].w};
@@ -299,6 +307,20 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
     // the previous half's global stores to land)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
+  }
+  // fused bias gradient of the layer below (fc1): column sums of this wave's 64 rows, one partial row per 64 output rows
+  if (RES && OUT == 0 && p.act == 2 && p.colsum) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      csum[e] += __shfl_xor(csum[e], 8, 64);
+      csum[e] += __shfl_xor(csum[e], 16, 64);
+      csum[e] += __shfl_xor(csum[e], 32, 64);
+    }
+    if (lane < 8 && jok && i0 + wi * 64 < p.I) {
+      float* c = p.colsum + (size_t)(ti * 2 + wi) * p.J + j;
+      *reinterpret_cast<float4*>(c) = make_float4(csum[0], csum[1], csum[2], csum[3]);
+      *reinterpret_cast<float4*>(c + 4) = make_float4(csum[4], csum[5], csum[6], csum[7]);
+    }
   }
 }
 
@@ -805,7 +827,7 @@ int launch(const GemmParams& p, int splits, hipStream_t stream) {
 extern "C" int dig_gemm_bf16(const void* A, const void* B, void* C, int I, int J, int R, int lda, int ldb, int ldc,
                              int trans_a, int trans_b, int out_kind, const float* bias, const void* resid, int ldr,
                              void* pre_act, int ldp, float alpha, int alpha_cols, int act, int splits, int a_rows,
-                             int b_rows, int bk, hipStream_t stream) {
+                             int b_rows, int bk, float* colsum_partials, hipStream_t stream) {
   if (!A || !B || !C || I <= 0 || J <= 0 || R <= 0 || splits < 1) return DIG_ERR_ARG;
   if (bias && !aligned16(bias)) return DIG_ERR_ALIGN;
   if (out_kind < 0 || out_kind > 2 || act < 0 || act > 2 || (bk != 0 && bk != 32 && bk != 33 && bk != 34 && bk != 64 && bk != 132 && bk != 164 && bk != 244 && bk != 242 && bk != 224 && bk != 344 && bk != 343 && bk != 448 && bk != 484 && bk != 444 && bk != 432 && bk != 232 && bk != 332 && bk != 223)) return DIG_ERR_ARG;
@@ -819,8 +841,11 @@ extern "C" int dig_gemm_bf16(const void* A, const void* B, void* C, int I, int J
   if (out_kind == 2 && (bias || resid || act)) return DIG_ERR_ARG;
   if (out_kind != 2 && splits != 1) return DIG_ERR_ARG;
   if (out_kind == 2 && ldc != J) return DIG_ERR_ARG;            // partial slabs are dense [splits][I][J]
+  if (colsum_partials && !(act == 2 && out_kind == 0 && trans_b && !trans_a && bk < 100)) return DIG_ERR_UNSUPPORTED;
+  if (colsum_partials && !aligned16(colsum_partials)) return DIG_ERR_ALIGN;
   GemmParams p;
   p.splits_x = 0;
+  p.colsum = colsum_partials;
   p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C;
   p.I = I; p.J = J; p.R = R; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
   // a_rows / b_rows (0 = default) bound the rows that really exist in memory; rows past them read as zero.

@@ -131,8 +131,9 @@ class _Step:
                 lse = lse[:B * H]
             # x_out = x_mid + fc2(gelu(fc1(ln2)))
             on_side(lambda: ops.linear_wgrad(dx, act, g["mlp.fc2.weight"]), dx, act)
-            dact = ops.linear_dgrad(dx, blk["mlp.fc2.weight"], gelu_pre=pre)       # d(pre-activation), GELU' fused
-            on_side(lambda: (ops.linear_wgrad(dact, ln2, g["mlp.fc1.weight"]), ops.colsum(dact, g["mlp.fc1.bias"])), dact, ln2)
+            dact, bparts = ops.linear_dgrad(dx, blk["mlp.fc2.weight"], gelu_pre=pre, colsum=True)   # d(pre-activation): GELU' and
+            on_side(lambda: (ops.linear_wgrad(dact, ln2, g["mlp.fc1.weight"]),                       # the fc1 bias sums fused
+                             ops.colsum_partials(bparts, g["mlp.fc1.bias"])), dact, ln2, bparts)
             dln2 = ops.linear_dgrad(dact, blk["mlp.fc1.weight"])
             dx_mid = ops.layernorm_bwd(dln2, x_mid, blk["norm2.weight"], blk["norm2.bias"], mu2, rs2, dx, g["norm2.weight"], g["norm2.bias"],
                                        out=dln2, dres_colsum=g["mlp.fc2.bias"])      # colsum(dx) = fc2 bias grad, fused

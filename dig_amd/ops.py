@@ -28,7 +28,7 @@ def _workspace(dev, numel):
 
 
 def gemm(A, B, I, J, R, *, ta=False, tb=False, out=None, out_kind=OUT_BF16, bias=None, resid=None, pre=None, alpha=1.0,
-         alpha_cols=0, act=0, splits=1, ldc=None, a_rows=0, b_rows=0, bk=0):
+         alpha_cols=0, act=0, splits=1, ldc=None, a_rows=0, b_rows=0, bk=0, colsum_partials=None):
     """C[I,J] = sum_r opA(i,r) opB(j,r); see csrc/gemm.hip for the operand conventions."""
     if out is None:
         out = torch.empty((I, J), device=A.device, dtype=BF16 if out_kind == OUT_BF16 else F32)
@@ -37,7 +37,7 @@ def gemm(A, B, I, J, R, *, ta=False, tb=False, out=None, out_kind=OUT_BF16, bias
     L.call("dig_gemm_bf16", L.ptr(A), L.ptr(B), L.ptr(out), I, J, R, A.stride(0), B.stride(0),
            out.stride(0) if ldc is None else ldc, int(ta), int(tb), out_kind, L.ptr(bias), L.ptr(resid),
            resid.stride(0) if resid is not None else 0, L.ptr(pre), pre.stride(0) if pre is not None else 0, cf(alpha),
-           alpha_cols, act, splits, a_rows, b_rows, bk, L.stream())
+           alpha_cols, act, splits, a_rows, b_rows, bk, L.ptr(colsum_partials), L.stream())
     return out
 
 
@@ -73,11 +73,20 @@ def linear_fwd(x, w, *, bias=None, resid=None, act=0, pre=None, alpha=1.0, alpha
                 alpha_cols=alpha_cols, out=out, out_kind=out_kind, bk=bk)
 
 
-def linear_dgrad(dy, w, out=None, gelu_pre=None):
-    """dx[rows,in] = dy[rows,out] @ w[out,in]  (* gelu'(gelu_pre) when the input of this layer was a GELU output)."""
+def linear_dgrad(dy, w, out=None, gelu_pre=None, colsum=False):
+    """dx[rows,in] = dy[rows,out] @ w[out,in]  (* gelu'(gelu_pre) when the input of this layer was a GELU output).
+    colsum=True (GELU' form only) also returns the [ceil(rows/64), in] fp32 column sums of dx per 64-row group, i.e. the
+    bias gradient of the layer that produced gelu_pre, for colsum_partials()."""
     if gelu_pre is not None:
-        return gemm(dy, w, dy.shape[0], w.shape[1], w.shape[0], tb=True, out=out, act=2, resid=gelu_pre)
+        parts = torch.empty(((dy.shape[0] + 63) // 64, w.shape[1]), device=dy.device, dtype=F32) if colsum else None
+        dx = gemm(dy, w, dy.shape[0], w.shape[1], w.shape[0], tb=True, out=out, act=2, resid=gelu_pre, bk=32, colsum_partials=parts)
+        return (dx, parts) if colsum else dx
     return gemm(dy, w, dy.shape[0], w.shape[1], w.shape[0], tb=True, out=out)
+
+
+def colsum_partials(parts, out):
+    """out[c] += sum_b parts[b, c]."""
+    L.call("dig_colsum_partials", L.ptr(parts), parts.shape[0], parts.shape[1], L.ptr(out), L.stream())
 
 
 def wgrad_splits(rows, tiles):

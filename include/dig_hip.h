@@ -43,7 +43,8 @@ typedef struct ihipStream_t* hipStream_t;
  */
 int dig_gemm_bf16(const void* A, const void* B, void* C, int I, int J, int R, int lda, int ldb, int ldc, int trans_a,
                   int trans_b, int out_kind, const float* bias, const void* resid, int ldr, void* pre_act, int ldp, float alpha,
-                  int alpha_cols, int act, int splits, int a_rows, int b_rows, int bk, hipStream_t stream);
+                  int alpha_cols, int act, int splits, int a_rows, int b_rows, int bk, float* colsum_partials,
+                  hipStream_t stream);
 int dig_gemm_effective_splits(int R, int splits);
 /* Forward-layout GEMM (trans_a = trans_b = 0, out_kind 0/1) with the 128-row A panel resident in LDS and the weight
  * tiles streamed through a 3-stage ring across N-tiles; same epilogue contract.  K % 128 == 0 and K <= 384, else -4. */
@@ -168,6 +169,9 @@ int dig_sumsq(const float* x, long long n, float* workspace, float* out, hipStre
  */
 long long dig_colsum_workspace_bytes(int rows, int C);
 int dig_colsum(const void* x, float* out, float* workspace, int rows, int C, int ld, hipStream_t stream);
+/* out[c] += sum_b partials[b][c]: finishes the [ceil(I/64)][J] column sums that dig_gemm_bf16(act 2, colsum_partials) leaves
+ * (the fc1 bias gradient fused into the fc2 data-gradient GEMM; reference: autograd of nn.Linear bias, modeling_pretrain_vit.py:60-76) */
+int dig_colsum_partials(const float* partials, int n_parts, int C, float* out, hipStream_t stream);
 int dig_gelu_bwd(const void* dact, const void* pre, void* dpre, long long n, hipStream_t stream);
 int dig_add_bf16(const void* a, const void* b, void* out, long long n, hipStream_t stream);
 int dig_cast_f32_to_bf16(const float* x, void* y, long long n, hipStream_t stream);
