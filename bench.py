@@ -24,6 +24,7 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_SAMPLE = {"small": 99.6e9, "base": 171e9, "tiny": None}      # SURVEY.md §8(d), MIM+MoCo
 PEAK_BF16 = 2.5e15
+PEAK_HBM = 8.0e12                                                      # /opt/skills/guides/MI355X_MICROARCH.md
 
 
 def synth_batches(n, B, device, seed):
@@ -62,7 +63,15 @@ class GemmProbe:
             out = self._orig(A, B, I, J, R, **kw)
             e1.record()
             variant = ("wgrad" if kw.get("ta") else ("dgrad" if kw.get("tb") else "fwd"))
-            self.rec.append((variant, 2.0 * I * J * R, e0, e1))
+            # algorithmic HBM bytes of the launch: both operands once, every output / residual / saved pre-activation once
+            # (weight gradients: fp32 read-modify-write of dW; the split-R slabs are implementation traffic, not counted)
+            byt = 2.0 * I * R + 2.0 * J * R
+            if kw.get("ta"):
+                byt += 8.0 * I * J
+            else:
+                byt += I * J * (4.0 if kw.get("out_kind") == ops.OUT_F32 else 2.0)
+                byt += 2.0 * I * J * ((kw.get("pre") is not None) + (kw.get("resid") is not None))
+            self.rec.append((variant, 2.0 * I * J * R, byt, e0, e1))
             return out
         ops.gemm = timed
         return self
@@ -73,12 +82,13 @@ class GemmProbe:
     def summary(self):
         torch.cuda.synchronize()
         agg = {}
-        for variant, fl, e0, e1 in self.rec:
-            d = agg.setdefault(variant, [0.0, 0.0, 0])
+        for variant, fl, byt, e0, e1 in self.rec:
+            d = agg.setdefault(variant, [0.0, 0.0, 0, 0.0])
             d[0] += fl
             d[1] += e0.elapsed_time(e1) * 1e-3
             d[2] += 1
-        return {k: {"flops": v[0], "seconds": v[1], "launches": v[2]} for k, v in agg.items()}
+            d[3] += byt
+        return {k: {"flops": v[0], "seconds": v[1], "launches": v[2], "bytes": v[3]} for k, v in agg.items()}
 
 
 def cpu_baseline(model_name, budget_s=20.0):
@@ -205,20 +215,27 @@ def main():
         summ = probe.summary()
         dom = max(summ, key=lambda k: summ[k]["seconds"])
         d = summ[dom]
-        ach = d["flops"] / d["seconds"] / 1e12
+        tf = d["flops"] / d["seconds"] / 1e12
+        gbs = d["bytes"] / d["seconds"] / 1e9
         traffic = None
         try:                                   # HBM bytes per launch from the committed PMC profile of this same command
             with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
                 traffic = json.load(f)["kernels"][dom]["hbm_bytes_per_launch"]
         except Exception:
             pass
-        roof = {"bound": "mfma", "kernel": f"dig_gemm_bf16[{dom}] (gemm_kernel / gemm_wide_kernel, v_mfma_f32_32x32x16_bf16)",
-                "achieved": ach, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": ach / (PEAK_BF16 / 1e12), "traffic": traffic,
+        # which roof binds this kernel family: the larger of (FLOPs / MFMA peak) and (algorithmic bytes / HBM peak)
+        hbm_bound = d["bytes"] / PEAK_HBM > d["flops"] / PEAK_BF16
+        mfma_view = {"achieved": tf, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": tf / (PEAK_BF16 / 1e12)}
+        hbm_view = {"achieved": gbs, "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": gbs / (PEAK_HBM / 1e9)}
+        roof = {"bound": "hbm" if hbm_bound else "mfma", **(hbm_view if hbm_bound else mfma_view), "traffic": traffic,
+                "kernel": f"dig_gemm_bf16[{dom}] (gemm_kernel / gemm_wide_kernel, v_mfma_f32_32x32x16_bf16, fused bias/GELU/residual epilogues)",
                 "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 gfx950 correction)" if traffic else None,
-                "flops_per_launch": d["flops"] / d["launches"],
+                "mfma": mfma_view, "hbm": hbm_view,
+                "flops_per_launch": d["flops"] / d["launches"], "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
                 "avg_launch_us": d["seconds"] / d["launches"] * 1e6, "launches_per_step": d["launches"] // 2,
-                "by_variant": {k: {"TFLOP/s": v["flops"] / v["seconds"] / 1e12, "ms_per_step": v["seconds"] / 2 * 1e3,
-                                   "launches_per_step": v["launches"] // 2} for k, v in summ.items()}}
+                "by_variant": {k: {"TFLOP/s": v["flops"] / v["seconds"] / 1e12, "GB/s": v["bytes"] / v["seconds"] / 1e9,
+                                   "ms_per_step": v["seconds"] / 2 * 1e3, "launches_per_step": v["launches"] // 2}
+                               for k, v in summ.items()}}
     sys.stdout.flush()
     sys.stderr.flush()
     os.dup2(saved_fd1, 1)

@@ -1,0 +1,42 @@
+"""HBM traffic per launch by kernel family from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over bench.py.
+
+usage: pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json>
+FETCH_SIZE / WRITE_SIZE are in KB; gfx950 tallies 128-byte read requests as 64 B, so fetch is doubled
+(/opt/skills/guides/MI355X_MICROARCH.md, HBM / rocprofv3 section)."""
+import csv, json, re, sys, collections
+
+
+def family(name):
+    m = re.search(r"gemm(?:_wide|_persist)?_kernel<(true|false), (true|false)", name)
+    if m:
+        return {"falsefalse": "fwd", "falsetrue": "dgrad", "truetrue": "wgrad"}.get(m.group(1) + m.group(2), "gemm_other")
+    for k in ("attn_fwd", "attn_bwd", "ln_bwd_kernel", "ln_fwd_kernel", "reduce_partials", "colsum_kernel", "bn_fwd_apply", "bn_bwd_apply", "adamw", "ema_kernel"):
+        if k in name:
+            return k.replace("_kernel", "")
+    return None
+
+
+def load(path, counter):
+    acc = collections.defaultdict(lambda: [0.0, 0])
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        f = family(r["Kernel_Name"])
+        if f:
+            acc[f][0] += float(r["Counter_Value"]) * 1024.0
+            acc[f][1] += 1
+    return acc
+
+
+fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
+out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `bench.py --steps 2 --warmup 1 --no-cpu-baseline "
+               "--no-mim-only`; bytes per launch averaged over all launches of the kernel family; FETCH_SIZE doubled per "
+               "MI355X_MICROARCH.md (gfx950 tallies 128-B requests as 64 B)", "kernels": {}}
+for f in sorted(set(fetch) | set(write)):
+    fb = 2.0 * fetch[f][0] / max(fetch[f][1], 1)
+    wb = write[f][0] / max(write[f][1], 1)
+    out["kernels"][f] = {"launches": fetch[f][1], "fetch_bytes_per_launch_corrected": fb, "write_bytes_per_launch": wb,
+                         "hbm_bytes_per_launch": fb + wb}
+json.dump(out, open(sys.argv[3], "w"), indent=1)
+for f, v in out["kernels"].items():
+    print(f"{f:18s} launches {v['launches']:5d}  fetch {v['fetch_bytes_per_launch_corrected']/1e6:8.1f} MB  write {v['write_bytes_per_launch']/1e6:8.1f} MB")
