@@ -16,6 +16,8 @@ import sys
 import time
 import types
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")        # before HIP initialises: see dig_amd/__init__.py
+
 import numpy as np
 import torch
 

@@ -150,9 +150,14 @@ class _Step:
             dx = ops.layernorm_bwd(dln1, x, blk["norm1.weight"], blk["norm1.bias"], mu1, rs1, dx_mid, g["norm1.weight"], g["norm1.bias"],
                                    out=dln1, dres_colsum=g["attn.proj.bias"])            # colsum(dx_mid) = proj bias grad, fused
             del dact, pre, act, dln2, dqkv, dctx
-            if self.comm.world > 1 or getattr(self.comm, "world_override", False):
-                main.wait_stream(side)                                        # this block's gradients are final on both streams
-            self.comm.grad_ready(M, f"encoder.blocks.{i}")
+            # this block's gradients are final once BOTH streams pass this point: the bucket's all-reduce is issued from the
+            # side stream after it has waited for the main chain, so the main chain itself never stalls on the collective
+            if side is not main and (self.comm.world > 1 or getattr(self.comm, "world_override", False)):
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    self.comm.grad_ready(M, f"encoder.blocks.{i}")
+            else:
+                self.comm.grad_ready(M, f"encoder.blocks.{i}")
         for half, im in enumerate((images, aug)[:views]):
             ops.patch_embed_bwd_mfma(dx[half * B * N:(half + 1) * B * N], im, mask_u8[half * B:(half + 1) * B], ew.g_pe_w, ew.g_pe_b,
                                      ew.g_mask_token, D, M.gh, M.gw)
