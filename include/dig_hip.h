@@ -182,6 +182,18 @@ int dig_scale_f32(float* x, long long n, float s, hipStream_t stream);
 int dig_scale_by_device_scalar(float* x, long long n, const float* scalar, float extra, hipStream_t stream);
 int dig_axpy_f32(float* y, const float* x, long long n, float a, hipStream_t stream);
 
+/* ---- input transform on the device (dataset/datasets.py:27-42, masking_generator.py:12-49)
+ * dig_resize_bicubic_normalize_u8: n_img uint8 RGB crops (HWC, image i at packed + offsets[i], heights[i] x widths[i]; all
+ * three arrays in device memory) -> out[n_img][3][out_h][out_w] fp32 = Normalize(ToTensor(Resize((out_h,out_w), BICUBIC))),
+ * bit-exact with Pillow's ImagingResample.  max_h / max_w bound the crop sizes (they size the LDS coefficient tables). */
+int dig_resize_bicubic_normalize_u8(const unsigned char* packed, const long long* offsets, const int* heights, const int* widths,
+                                    int n_img, float* out, int out_h, int out_w, float mean, float std_, int max_h, int max_w,
+                                    hipStream_t stream);
+/* mask[n_rows][n_patches] uint8, exactly num_mask ones per row (RandomMaskingGenerator.__call__); row r, patch p gets the
+ * Philox4x32-10 key of counter (r, p, step, 0) under key (seed), the num_mask smallest (key, p) are masked. */
+int dig_random_masks(unsigned char* mask, int n_rows, int n_patches, int num_mask, unsigned long long seed, unsigned step,
+                     hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
