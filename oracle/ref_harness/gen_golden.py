@@ -367,3 +367,8 @@ if __name__ == "__main__":
         if a.only in ("", "small"):
             small = O.make_config("pretrain_simmim_moco_ori_vit_small_patch4_32x128")
             gen_single("vit_small_b4_w1", small, 7, 4, 1, O.StepHyper(lr=1.5e-4 * 4 / 256))
+        if a.only in ("", "base"):                  # BASELINE configs[3]'s model (D=512, 8 heads), smallest batch BatchNorm accepts
+            base = O.make_config("pretrain_simmim_moco_ori_vit_base_patch4_32x128")
+            gen_single("vit_base_b2_w1", base, 11, 2, 1, O.StepHyper(lr=1.5e-4 * 2 / 256))
+        if a.only in ("", "c0"):                    # BASELINE configs[1]'s loss: loss_weight_contrast = 0 (MIM-only gradients)
+            gen_single("tiny_w1_c0", tiny, 5, 4, 1, O.StepHyper(lr=1e-3, w_contrast=0.0))

@@ -100,10 +100,11 @@ def _fixture_step0(name):
     return g, cfg, O.StepHyper(**hpk), int(g["seed"]), int(g["B"])
 
 
-@pytest.mark.parametrize("name", ["tiny_w1", "vit_small_b4_w1"])
+@pytest.mark.parametrize("name", ["tiny_w1", "vit_small_b4_w1", "vit_base_b2_w1", "tiny_w1_c0"])
 def test_step_vs_reference_golden_fixture(name):
     """Fixtures come from the UNMODIFIED reference engine (tests/golden, oracle/ref_harness/gen_golden.py).
-    vit_small_b4_w1 is BASELINE.json configs[0]: the reference's own CPU-runnable case."""
+    vit_small_b4_w1 is BASELINE.json configs[0] (the reference's own CPU-runnable case), vit_base_b2_w1 the model of
+    configs[3], tiny_w1_c0 the loss of configs[1] (loss_weight_contrast = 0: the engine skips the contrastive backward)."""
     g, cfg, hp, seed, B = _fixture_step0(name)
     im, au, mk = O.synthetic_batch(B, cfg, seed * 1000)
     model = build_model(cfg, *O.det_state(cfg, seed))

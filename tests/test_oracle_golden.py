@@ -79,6 +79,23 @@ def test_vit_small_b4_step_matches_reference(golden_dir):
     check_step0(load(golden_dir, "vit_small_b4_w1"))
 
 
+def test_vit_base_b2_step_matches_reference(golden_dir):
+    """BASELINE.json configs[3]'s model (pretrain_simmim_moco_ori_vit_base_patch4_32x128: D=512, 8 heads), bs=2, CPU."""
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    check_step0(load(golden_dir, "vit_base_b2_w1"))
+
+
+def test_zero_contrast_weight_step_matches_reference(golden_dir):
+    """BASELINE.json configs[1]'s loss (loss_weight_contrast = 0): contrastive-only parameters get exactly-zero gradients
+    in the reference, the logged loss_contrast / accuracies are still computed."""
+    g = load(golden_dir, "tiny_w1_c0")
+    check_step0(g)
+    names, norms = g["s0/grad_names"].tolist(), g["s0/grad_norms"]
+    zero = [n for n, v in zip(names, norms) if v == 0.0]
+    assert any(n.startswith("predictor.") for n in zero) and any(n.startswith("pix_projector.") for n in zero)
+    assert float(g["s0/stat/loss"]) == pytest.approx(float(g["s0/stat/loss_pixel"]), rel=1e-6) and float(g["s0/stat/loss_contrast"]) > 0
+
+
 def test_param_inventory_matches_reference_counts():
     cfg = O.make_config("pretrain_simmim_moco_ori_vit_small_patch4_32x128")
     shapes = O.param_shapes(cfg)
