@@ -153,6 +153,76 @@ def test_two_steps_carry_state():
         assert c > 0.7, (n, c)
 
 
+@pytest.mark.parametrize("B", [1, 3, 5])
+def test_ragged_batch_sizes_vs_oracle(B):
+    """Batch sizes that leave ragged tiles everywhere (rows = 2*B*256 tokens, 8*B pooled rows, B*179 decoder rows)."""
+    cfg = O.DiGConfig(**O.TINY)
+    seed = 20 + B
+    hp = O.StepHyper(lr=1e-3)
+    im, au, mk = O.synthetic_batch(B, cfg, seed * 1000)
+    model = build_model(cfg, *O.det_state(cfg, seed))
+    (stats,), _ = run_engine_steps(model, [(im, au, mk)], hp)
+    hp0 = dataclasses.replace(hp, moco_m=O.adjust_moco_momentum(0.0, 10, hp.moco_m))
+    ref_m, ref_g, _, _ = O.OracleTrainer(cfg, *O.det_state(cfg, seed)).loss_and_grads(im, au, mk, hp0)
+    for k in ("loss", "loss_pixel", "loss_contrast", "grad_norm"):
+        assert close(stats[k], ref_m[k], rtol=3e-2, atol=2e-3), (k, stats[k], ref_m[k])
+    with torch.autocast("cpu", dtype=torch.bfloat16):                      # noise yardstick: the same oracle in bf16
+        _, bf_g, _, _ = O.OracleTrainer(cfg, *O.det_state(cfg, seed)).loss_and_grads(im, au, mk, hp0)
+    grads = {n: p.grad.detach().float().cpu() for n, p in model.named_parameters() if p.requires_grad}
+    cos = torch.nn.functional.cosine_similarity
+    tot = float(torch.sqrt(sum((g.double() ** 2).sum() for g in ref_g.values())))
+    for n, r in ref_g.items():
+        if r.norm() > 2e-2 * tot:                                         # the tensors that carry the gradient
+            c_hip = cos(grads[n].reshape(1, -1), r.reshape(1, -1)).item()
+            c_bf = cos(bf_g[n].float().reshape(1, -1), r.reshape(1, -1)).item()
+            assert (1 - c_hip) <= 2 * (1 - c_bf) + 5e-3, (n, c_hip, c_bf)
+
+
+def test_error_behaviour_matches_reference_engine():
+    """engine_for_pretraining_moco.py:146-150: a non-finite loss prints and sys.exit(1)s; masks that do not select the same
+    number of tokens per sample cannot be reshaped to [B, -1, C] (:107-111) -- here a RuntimeError.  Both surface from
+    train_one_epoch (one step late inside an epoch, at the latest at its end)."""
+    cfg = O.DiGConfig(**O.TINY)
+    hp = O.StepHyper(lr=1e-3)
+    im, au, mk = O.synthetic_batch(4, cfg, 77)
+    model = build_model(cfg, *O.det_state(cfg, 1))
+    bad = im.clone(); bad[1, 0, 3, 5] = float("nan")
+    with pytest.raises(SystemExit) as e:
+        run_engine_steps(model, [(bad, au, mk)], hp)
+    assert e.value.code == 1
+    model = build_model(cfg, *O.det_state(cfg, 1))
+    run_engine_steps(model, [(im, au, mk)], hp)                            # caches the per-sample mask count (179)
+    ragged = mk.clone(); ragged[2, 0, int(torch.nonzero(ragged[2, 0])[0])] = 0
+    with pytest.raises(RuntimeError, match="same number of tokens"):
+        run_engine_steps(model, [(im, au, ragged)], hp)
+
+
+def test_checkpoint_resume_is_bit_exact(tmp_path):
+    """save_model / auto_load_model (utils/utils.py:546-651 layout): resuming after step 1 reproduces step 2 of the
+    uninterrupted run bit for bit (deterministic kernels, optimizer state and BN buffers carried through the file)."""
+    import types
+    from dig_amd import utils as U
+    from dig_amd.optim_factory import create_optimizer
+    from gpu_util import engine_args
+    cfg = O.DiGConfig(**O.TINY)
+    hp = O.StepHyper(lr=1e-3)
+    batches = [O.synthetic_batch(4, cfg, 900 + s) for s in range(2)]
+    ref = build_model(cfg, *O.det_state(cfg, 2))
+    _, _ = run_engine_steps(ref, batches, hp)
+    a = build_model(cfg, *O.det_state(cfg, 2))
+    _, opt = run_engine_steps(a, batches[:1], hp)
+    args = types.SimpleNamespace(output_dir=str(tmp_path), auto_resume=True, resume="")
+    U.save_model(args=args, epoch=0, model=a, model_without_ddp=a, optimizer=opt, loss_scaler=U.NativeScalerWithGradNormCount())
+    b = build_model(cfg)                                                    # fresh (random) model + optimizer, then resume
+    opt_b = create_optimizer(engine_args(hp), b)
+    U.auto_load_model(args=args, model=b, model_without_ddp=b, optimizer=opt_b, loss_scaler=U.NativeScalerWithGradNormCount())
+    assert args.start_epoch == 1
+    run_engine_steps(b, batches[1:], hp, start=1, opt=opt_b)
+    sd_ref, sd_b = ref.state_dict(), b.state_dict()
+    for k in sd_ref:
+        assert torch.equal(sd_ref[k], sd_b[k]), k
+
+
 @pytest.fixture(scope="module")
 def full_size():
     """BASELINE.json configs[1]/[2] per-GPU shape: ViT-S, 128 samples (256 images) per step."""
