@@ -223,7 +223,10 @@ __global__ void mse_fwd_bwd_kernel(const float* __restrict__ pred, int ld_p, con
     if (dpred) dpred[e] = f2bf(g);
   }
   acc = wave_sum(acc);
-  if ((threadIdx.x & 63) == 0 && loss) atomicAdd(loss, acc * inv_count);
+  __shared__ float part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0 && loss) atomicAdd(loss, (part[0] + part[1] + part[2] + part[3]) * inv_count);   // one atomic per block
 }
 
 __global__ void add_bf16_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, bf16_t* __restrict__ o, size_t n8) {
@@ -447,7 +450,7 @@ extern "C" int dig_mse_fwd_bwd(const float* pred, int ld_pred, const float* targ
   if (!pred || !target || M <= 0 || C <= 0 || ld_pred < C || (dpred && ld_dpred < C)) return DIG_ERR_ARG;
   const int ldd = dpred ? ld_dpred : C;
   const int total = M * ldd;
-  hipLaunchKernelGGL(mse_fwd_bwd_kernel, dim3(std::min(1024, (total + 255) / 256)), dim3(256), 0, stream, pred, ld_pred, target, M, C,
+  hipLaunchKernelGGL(mse_fwd_bwd_kernel, dim3(std::min(256, (total + 255) / 256)), dim3(256), 0, stream, pred, ld_pred, target, M, C,
                      1.0f / ((float)M * C), gscale, loss, (bf16_t*)dpred, ldd);
   return dig_check_launch();
 }

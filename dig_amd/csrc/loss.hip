@@ -33,47 +33,46 @@ __global__ void l2norm_bwd_kernel(const float* __restrict__ dy, const float* __r
   for (int c = lane; c < C; c += 64) dx[(size_t)r * C + c] = (dy[(size_t)r * C + c] - y[(size_t)r * C + c] * s) * inv;
 }
 
-// fp32 GEMM, 64x64 tile, 256 threads, 4x4 per thread.  TB=false: C = alpha * A[I,R] * B[J,R]^T ; TB=true: C = alpha * A[I,R] * B[R,J]
+// fp32 GEMM for the InfoNCE logits and their gradient (a few hundred rows: launch- and latency-bound, so small 32x32 tiles
+// for parallelism and a 64-deep K step for few barrier round trips).  256 threads, 2x2 outputs per thread.
+// TB=false: C = alpha * A[I,R] * B[J,R]^T ; TB=true: C = alpha * A[I,R] * B[R,J]
 template <bool TB>
 __global__ __launch_bounds__(256) void sgemm_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
-                                                    int I, int J, int R, int lda, int ldb, int ldc, float alpha) {
-  __shared__ float As[16][64 + 4];
-  __shared__ float Bs[16][64 + 4];
+                                                    int I, int J, int R, int lda, int ldb, int ldc, float alpha, int r_per_split) {
+  constexpr int TS = 32, KS = 64;
+  __shared__ float As[KS][TS + 1];
+  __shared__ float Bs[KS][TS + 1];
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-  const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
-  float acc[4][4] = {};
-  for (int r0 = 0; r0 < R; r0 += 16) {
-    for (int e = threadIdx.x; e < 64 * 16; e += 256) {
-      const int rr = e & 15, ii = e >> 4;
+  const int i0 = blockIdx.y * TS, j0 = blockIdx.x * TS;
+  float acc[2][2] = {};
+  const int rbeg = blockIdx.z * r_per_split;                           // R-split z writes slab z of C ([splits][I][ldc])
+  R = min(R, rbeg + r_per_split);
+  C += (size_t)blockIdx.z * I * ldc;
+  for (int r0 = rbeg; r0 < R; r0 += KS) {
+    for (int e = threadIdx.x; e < TS * KS; e += 256) {
+      const int rr = e & (KS - 1), ii = e >> 6;                       // consecutive threads walk K (contiguous in A, and in B^T)
       As[rr][ii] = (i0 + ii < I && r0 + rr < R) ? A[(size_t)(i0 + ii) * lda + r0 + rr] : 0.f;
-      if (!TB) {
-        Bs[rr][ii] = (j0 + ii < J && r0 + rr < R) ? B[(size_t)(j0 + ii) * ldb + r0 + rr] : 0.f;
-      }
+      if (!TB) Bs[rr][ii] = (j0 + ii < J && r0 + rr < R) ? B[(size_t)(j0 + ii) * ldb + r0 + rr] : 0.f;
     }
     if (TB) {
-      for (int e = threadIdx.x; e < 64 * 16; e += 256) {
-        const int jj = e & 63, rr = e >> 6;
+      for (int e = threadIdx.x; e < TS * KS; e += 256) {
+        const int jj = e & (TS - 1), rr = e >> 5;                     // consecutive threads walk J (contiguous in B)
         Bs[rr][jj] = (j0 + jj < J && r0 + rr < R) ? B[(size_t)(r0 + rr) * ldb + j0 + jj] : 0.f;
       }
     }
     __syncthreads();
-#pragma unroll
-    for (int rr = 0; rr < 16; ++rr) {
-      float a[4], b[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) { a[u] = As[rr][ty * 4 + u]; b[u] = Bs[rr][tx * 4 + u]; }
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int v = 0; v < 4; ++v) acc[u][v] += a[u] * b[v];
+#pragma unroll 16
+    for (int rr = 0; rr < KS; ++rr) {
+      const float a0 = As[rr][ty * 2], a1 = As[rr][ty * 2 + 1], b0 = Bs[rr][tx * 2], b1 = Bs[rr][tx * 2 + 1];
+      acc[0][0] += a0 * b0; acc[0][1] += a0 * b1; acc[1][0] += a1 * b0; acc[1][1] += a1 * b1;
     }
     __syncthreads();
   }
 #pragma unroll
-  for (int u = 0; u < 4; ++u)
+  for (int u = 0; u < 2; ++u)
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const int i = i0 + ty * 4 + u, j = j0 + tx * 4 + v;
+    for (int v = 0; v < 2; ++v) {
+      const int i = i0 + ty * 2 + u, j = j0 + tx * 2 + v;
       if (i < I && j < J) C[(size_t)i * ldc + j] = acc[u][v] * alpha;
     }
 }
@@ -134,13 +133,15 @@ extern "C" int dig_l2norm_bwd(const float* dy, const float* y, const float* inv_
 }
 
 extern "C" int dig_sgemm(const float* A, const float* B, float* C, int I, int J, int R, int lda, int ldb, int ldc, int trans_b,
-                         float alpha, hipStream_t stream) {
-  if (!A || !B || !C || I <= 0 || J <= 0 || R <= 0) return DIG_ERR_ARG;
-  dim3 grid((J + 63) / 64, (I + 63) / 64);
+                         float alpha, int r_splits, hipStream_t stream) {
+  if (!A || !B || !C || I <= 0 || J <= 0 || R <= 0 || r_splits < 1) return DIG_ERR_ARG;
+  const int per = ((R + r_splits - 1) / r_splits + 63) / 64 * 64;      // whole 64-deep K steps per split
+  if ((R + per - 1) / per != r_splits) return DIG_ERR_ARG;             // (callers pick r_splits with R % (64 * r_splits) == 0)
+  dim3 grid((J + 31) / 32, (I + 31) / 32, r_splits);
   if (trans_b)
-    hipLaunchKernelGGL(sgemm_kernel<true>, grid, dim3(256), 0, stream, A, B, C, I, J, R, lda, ldb, ldc, alpha);
+    hipLaunchKernelGGL(sgemm_kernel<true>, grid, dim3(256), 0, stream, A, B, C, I, J, R, lda, ldb, ldc, alpha, per);
   else
-    hipLaunchKernelGGL(sgemm_kernel<false>, grid, dim3(256), 0, stream, A, B, C, I, J, R, lda, ldb, ldc, alpha);
+    hipLaunchKernelGGL(sgemm_kernel<false>, grid, dim3(256), 0, stream, A, B, C, I, J, R, lda, ldb, ldc, alpha, per);
   return dig_check_launch();
 }
 

@@ -67,6 +67,8 @@ def linear_fwd(x, w, *, bias=None, resid=None, act=0, pre=None, alpha=1.0, alpha
         bk = 244
     elif act == 1:
         bk = 32
+    elif rows <= 2048 and w.shape[0] <= 512 and K >= 2048:
+        bk = 212                                        # few output tiles, long K: 64x128 tiles for more workgroups
     else:
         bk = 0
     return gemm(x, w, x.shape[0], w.shape[0], w.shape[1], bias=bias, resid=resid, act=act, pre=pre, alpha=alpha,
@@ -81,7 +83,8 @@ def linear_dgrad(dy, w, out=None, gelu_pre=None, colsum=False):
         parts = torch.empty(((dy.shape[0] + 63) // 64, w.shape[1]), device=dy.device, dtype=F32) if colsum else None
         dx = gemm(dy, w, dy.shape[0], w.shape[1], w.shape[0], tb=True, out=out, act=2, resid=gelu_pre, bk=32, colsum_partials=parts)
         return (dx, parts) if colsum else dx
-    return gemm(dy, w, dy.shape[0], w.shape[1], w.shape[0], tb=True, out=out)
+    # few rows (the BN-MLP heads on pooled features): 128x64 tiles double the workgroup count (tools/gpu_head_gemm_probe.py)
+    return gemm(dy, w, dy.shape[0], w.shape[1], w.shape[0], tb=True, out=out, bk=221 if dy.shape[0] <= 2048 else 0)
 
 
 def colsum_partials(parts, out):
@@ -289,7 +292,19 @@ def l2norm_bwd(dy, y, inv):
 
 
 def sgemm(A, B, C, I, J, R, trans_b, alpha):
-    L.call("dig_sgemm", L.ptr(A), L.ptr(B), L.ptr(C), I, J, R, A.stride(0), B.stride(0), C.stride(0), int(trans_b), cf(alpha), L.stream())
+    """fp32 C = alpha * A[I,R] * (B[R,J] if trans_b else B[J,R]^T).  A long reduction (the logit gradient against keys gathered
+    from many ranks) is split into fp32 slabs and summed in a fixed order (deterministic)."""
+    sp = 1
+    if R >= 2048 and C.stride(0) == J:
+        sp = R // 512
+        while sp > 1 and R % (64 * sp):
+            sp -= 1
+    if sp > 1:
+        ws = _workspace(A.device, sp * I * J)
+        L.call("dig_sgemm", L.ptr(A), L.ptr(B), L.ptr(ws), I, J, R, A.stride(0), B.stride(0), J, int(trans_b), cf(alpha), sp, L.stream())
+        L.call("dig_reduce_partials", L.ptr(ws), sp, cll(I * J), L.ptr(C), 0, L.stream())
+    else:
+        L.call("dig_sgemm", L.ptr(A), L.ptr(B), L.ptr(C), I, J, R, A.stride(0), B.stride(0), C.stride(0), int(trans_b), cf(alpha), 1, L.stream())
 
 
 def ce_rows(logits, label_offset, gscale, out3):

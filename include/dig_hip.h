@@ -145,7 +145,7 @@ int dig_mse_fwd_bwd(const float* pred, int ld_pred, const float* target, int M, 
 int dig_l2norm_fwd(const float* x, float* y, float* inv_norm, int n, int C, float eps, hipStream_t stream);
 int dig_l2norm_bwd(const float* dy, const float* y, const float* inv_norm, float* dx, int n, int C, hipStream_t stream);
 int dig_sgemm(const float* A, const float* B, float* C, int I, int J, int R, int lda, int ldb, int ldc, int trans_b, float alpha,
-              hipStream_t stream);
+              int r_splits /* >1: C is [r_splits][I][ldc] partial slabs over R, summed by dig_reduce_partials */, hipStream_t stream);
 int dig_ce_rows(float* logits, int n, int m, int label_offset, float gscale, float* out3, hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
