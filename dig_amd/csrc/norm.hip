@@ -243,21 +243,30 @@ __global__ __launch_bounds__(256) void bn_fwd_apply_kernel(const bf16_t* __restr
                                                            const float* __restrict__ beta, int relu, bf16_t* __restrict__ y,
                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                                            size_t total8, int C) {
+  // the launch makes (gridDim.x * 256) a multiple of C/8, so a thread keeps one 8-column group for its whole row walk and the
+  // per-column scale / shift are computed once (they used to be re-derived, with a 64-bit modulo, for every element)
   const int c8 = C >> 3;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total8; i += (size_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % c8) * 8;
+  const unsigned t0 = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = (int)(t0 % (unsigned)c8) * 8;
+  float mu[8], rs[8], gm[8], bt[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    mu[k] = sums[c + k] * inv_n;
+    const float var = fmaxf(sums[C + c + k] * inv_n - mu[k] * mu[k], 0.f);
+    rs[k] = rsqrtf(var + eps);
+    gm[k] = gamma ? gamma[c + k] : 1.f;
+    bt[k] = gamma ? beta[c + k] : 0.f;
+    if (t0 < (unsigned)c8) { mean_out[c + k] = mu[k]; rstd_out[c + k] = rs[k]; }
+  }
+  for (size_t i = t0; i < total8; i += (size_t)gridDim.x * blockDim.x) {
     float v[8];
     load_row<8>(x + i * 8, v);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const float mu = sums[c + k] * inv_n;
-      const float var = fmaxf(sums[C + c + k] * inv_n - mu * mu, 0.f);
-      const float rs = rsqrtf(var + eps);
-      float o = (v[k] - mu) * rs;
-      if (gamma) o = o * gamma[c + k] + beta[c + k];
+      float o = (v[k] - mu[k]) * rs[k];                                 // same expression as the backward's xhat (ReLU mask)
+      if (gamma) o = o * gm[k] + bt[k];
       if (relu) o = fmaxf(o, 0.f);
       v[k] = o;
-      if (i < (size_t)c8) { mean_out[c + k] = mu; rstd_out[c + k] = rs; }
     }
     store_row<8>(y + i * 8, v);
   }
@@ -270,19 +279,25 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t* __restr
                                                            int relu, const float* __restrict__ sums, float inv_n,
                                                            bf16_t* __restrict__ dx, size_t total8, int C) {
   const int c8 = C >> 3;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total8; i += (size_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % c8) * 8;
+  const unsigned t0 = blockIdx.x * blockDim.x + threadIdx.x;          // (gridDim.x * 256) % (C/8) == 0: fixed column group
+  const int c = (int)(t0 % (unsigned)c8) * 8;
+  float mu[8], rs[8], gm[8], bt[8], s1[8], s2[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    mu[k] = mean[c + k]; rs[k] = rstd[c + k];
+    gm[k] = gamma ? gamma[c + k] : 1.f; bt[k] = gamma ? beta[c + k] : 0.f;
+    s1[k] = sums[c + k] * inv_n; s2[k] = sums[C + c + k] * inv_n;
+  }
+  for (size_t i = t0; i < total8; i += (size_t)gridDim.x * blockDim.x) {
     float v[8], d[8];
     load_row<8>(x + i * 8, v);
     load_row<8>(dy + i * 8, d);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const float rs = rstd[c + k];
-      const float xh = (v[k] - mean[c + k]) * rs;
-      const float gm = gamma ? gamma[c + k] : 1.f;
+      const float xh = (v[k] - mu[k]) * rs[k];
       float g = d[k];
-      if (relu && !(gm * xh + (gamma ? beta[c + k] : 0.f) > 0.f)) g = 0.f;
-      v[k] = gm * rs * (g - sums[c + k] * inv_n - xh * sums[C + c + k] * inv_n);
+      if (relu && !(gm[k] * xh + bt[k] > 0.f)) g = 0.f;
+      v[k] = gm[k] * rs[k] * (g - s1[k] - xh * s2[k]);
     }
     store_row<8>(dx + i * 8, v);
   }
@@ -365,6 +380,17 @@ extern "C" int dig_bn_stats(const void* x, float* sums, float* workspace, int ro
   return dig_check_launch();
 }
 
+// grid for the BN apply kernels: enough blocks to fill the chip, with (grid * 256) a multiple of C/8 so that every thread
+// keeps one 8-column group (see bn_fwd_apply_kernel)
+static inline int bn_apply_grid(size_t total8, int C) {
+  const int c8 = C >> 3;
+  int a = c8, b = 256;
+  while (b) { const int t = a % b; a = b; b = t; }                     // a = gcd(c8, 256)
+  const int unit = c8 / a;                                             // blocks per whole column period
+  const size_t want = std::min<size_t>(2048, (total8 + 255) / 256);
+  return (int)std::max<size_t>(1, (want + unit - 1) / unit) * unit;
+}
+
 extern "C" int dig_bn_fwd_apply(const void* x, const float* sums, float n_total, float eps, const float* gamma,
                                 const float* beta, int relu, void* y, float* mean_out, float* rstd_out, int rows, int C,
                                 hipStream_t stream) {
@@ -372,7 +398,7 @@ extern "C" int dig_bn_fwd_apply(const void* x, const float* sums, float n_total,
   if ((gamma == nullptr) != (beta == nullptr)) return DIG_ERR_ARG;
   if (!aligned16(x) || !aligned16(y)) return DIG_ERR_ALIGN;
   const size_t total8 = (size_t)rows * C / 8;
-  const int grid = (int)std::min<size_t>(2048, (total8 + 255) / 256);
+  const int grid = bn_apply_grid(total8, C);
   hipLaunchKernelGGL(bn_fwd_apply_kernel, dim3(grid), dim3(256), 0, stream, (const bf16_t*)x, sums, 1.0f / n_total, eps, gamma,
                      beta, relu, (bf16_t*)y, mean_out, rstd_out, total8, C);
   return dig_check_launch();
@@ -396,7 +422,7 @@ extern "C" int dig_bn_bwd_apply(const void* dy, const void* x, const float* mean
   if (!dy || !x || !mean || !rstd || !sums || !dx || rows <= 0 || (C & 7) || n_total <= 0.f) return DIG_ERR_ARG;
   if (!aligned16(x) || !aligned16(dy) || !aligned16(dx)) return DIG_ERR_ALIGN;
   const size_t total8 = (size_t)rows * C / 8;
-  const int grid = (int)std::min<size_t>(2048, (total8 + 255) / 256);
+  const int grid = bn_apply_grid(total8, C);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)x, mean, rstd,
                      gamma, beta, relu, sums, 1.0f / n_total, (bf16_t*)dx, total8, C);
   return dig_check_launch();
