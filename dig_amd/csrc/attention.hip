@@ -188,10 +188,24 @@ __device__ __forceinline__ void store_rows(bf16_t* row, const f32x16 (&acc)[2], 
   }
 }
 
+// Column sums of a 32 x 64 block held as two 32x32 accumulators (lane & 31 = row; registers = columns): reduce over the 32
+// rows of each lane half, then lanes 0 and 32 write their 2 x 16 columns into out[64].
+__device__ __forceinline__ void wave_colsum(const f32x16 (&acc)[2], float* out, int lane) {
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      float v = acc[dt][e];
+      v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+      v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64);
+      if ((lane & 31) == 0) out[dt * 32 + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3)] = v;
+    }
+}
+
 __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ ctx,
                                                           const bf16_t* __restrict__ dctx, const float* __restrict__ lse,
                                                           bf16_t* __restrict__ dqkv, int D, int H, float scale,
-                                                          unsigned qkv_bytes, unsigned ctx_bytes) {
+                                                          unsigned qkv_bytes, unsigned ctx_bytes, float* __restrict__ qsum, float* __restrict__ vsum) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* Qt = smem;
   unsigned char* Kt = smem + TILE;
@@ -199,6 +213,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(const bf16_t* __restri
   unsigned char* Gt = smem + 3 * TILE;                                   // dO
   float* lse_s = reinterpret_cast<float*>(smem + 4 * TILE);              // [256]
   float* del_s = lse_s + N_TOK;                                          // [256]
+  float* csum_s = del_s + N_TOK;                                         // [8 waves][2][64]: column sums of dQ and dV
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int img = blockIdx.x / H, h = blockIdx.x - img * H;
@@ -297,6 +312,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(const bf16_t* __restri
 #pragma unroll
       for (int e = 0; e < 16; ++e) dq[dt][e] *= scale;
     store_rows(dqkv + (tok0 + q) * ld + h * DH, dq, hi);
+    if (qsum) wave_colsum(dq, csum_s + wave * 128, lane);
   }
 
   // ---------------- phase B: dK, dV for key block `wave` ----------------
@@ -378,6 +394,18 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(const bf16_t* __restri
     bf16_t* okp = dqkv + (tok0 + key) * ld + D + h * DH;
     store_rows(okp, dk, hi);
     store_rows(okp + D, dv, hi);
+    if (vsum) wave_colsum(dv, csum_s + wave * 128 + 64, lane);
+  }
+  // fused q_bias / v_bias gradients: this (image, head)'s column sums of dQ and dV, one partial row per image
+  if (qsum) {
+    __syncthreads();
+    if (tid < 128) {
+      float a = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) a += csum_s[w * 128 + tid];
+      float* dst = tid < 64 ? qsum : vsum;
+      dst[(size_t)img * D + h * DH + (tid & 63)] = a;
+    }
   }
 }
 
@@ -400,18 +428,20 @@ extern "C" int dig_attn_fwd(const void* qkv, void* ctx, float* lse, int n_img, i
 }
 
 extern "C" int dig_attn_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse, void* dqkv, int n_img,
-                            int heads, int embed_dim, float scale, hipStream_t stream) {
+                            int heads, int embed_dim, float scale, float* q_colsum, float* v_colsum, hipStream_t stream) {
   if (!qkv || !ctx || !dctx || !lse || !dqkv || n_img <= 0 || heads <= 0 || embed_dim != heads * DH) return DIG_ERR_ARG;
+  if ((q_colsum == nullptr) != (v_colsum == nullptr)) return DIG_ERR_ARG;
   if (!aligned16(qkv) || !aligned16(ctx) || !aligned16(dctx) || !aligned16(dqkv)) return DIG_ERR_ALIGN;
   const size_t qb = (size_t)n_img * N_TOK * 3 * embed_dim * 2;
   if (qb >= (1ull << 32)) return DIG_ERR_ARG;
-  const int lds = 4 * TILE + 2 * N_TOK * 4;
+  const int lds = 4 * TILE + 2 * N_TOK * 4 + 8 * 128 * 4;
   static bool attr = false;
   if (!attr) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr = true;
   }
   hipLaunchKernelGGL(attn_bwd_kernel, dim3(n_img * heads), dim3(512), lds, stream, (const bf16_t*)qkv, (const bf16_t*)ctx,
-                     (const bf16_t*)dctx, lse, (bf16_t*)dqkv, embed_dim, heads, scale, (unsigned)qb, (unsigned)(qb / 3));
+                     (const bf16_t*)dctx, lse, (bf16_t*)dqkv, embed_dim, heads, scale, (unsigned)qb, (unsigned)(qb / 3), q_colsum,
+                     v_colsum);
   return dig_check_launch();
 }

@@ -170,10 +170,15 @@ def attn_fwd(qkv, n_img, heads, D):
     return ctx, lse
 
 
-def attn_bwd(qkv, ctx, dctx, lse, n_img, heads, D, scale):
+def attn_bwd(qkv, ctx, dctx, lse, n_img, heads, D, scale, bias_sums=False):
+    """dqkv (dq pre-multiplied by `scale`).  bias_sums=True also returns the per-image column sums of the dq and dv parts
+    ([n_img, D] fp32 each): the q_bias / v_bias gradient partials for colsum_partials()."""
     dqkv = torch.empty_like(qkv)
-    L.call("dig_attn_bwd", L.ptr(qkv), L.ptr(ctx), L.ptr(dctx), L.ptr(lse), L.ptr(dqkv), n_img, heads, D, cf(scale), L.stream())
-    return dqkv
+    qs = torch.empty((n_img, D), device=qkv.device, dtype=F32) if bias_sums else None
+    vs = torch.empty((n_img, D), device=qkv.device, dtype=F32) if bias_sums else None
+    L.call("dig_attn_bwd", L.ptr(qkv), L.ptr(ctx), L.ptr(dctx), L.ptr(lse), L.ptr(dqkv), n_img, heads, D, cf(scale), L.ptr(qs), L.ptr(vs),
+           L.stream())
+    return (dqkv, qs, vs) if bias_sums else dqkv
 
 
 def patch_embed_fwd(img, W, bias, mask_u8, mask_token, pos, D, gh, gw):

@@ -61,8 +61,10 @@ int dig_reduce_partials(const float* partials, int splits, long long n, float* o
  * bwd: dqkv = gradient w.r.t. qkv given dctx; the dq part is multiplied by `scale` (chain rule through the q scaling).
  */
 int dig_attn_fwd(const void* qkv, void* ctx, float* lse, int n_img, int heads, int embed_dim, hipStream_t stream);
+/* q_colsum / v_colsum (both or neither; fp32 [n_img][embed_dim]): per-image column sums of the dq (scaled) and dv parts,
+ * i.e. the q_bias / v_bias gradient partials, finished by dig_colsum_partials(.., n_img, embed_dim, ..). */
 int dig_attn_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse, void* dqkv, int n_img, int heads,
-                 int embed_dim, float scale, hipStream_t stream);
+                 int embed_dim, float scale, float* q_colsum, float* v_colsum, hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * LayerNorm over the last dim D in {64,128,192,256,384,512} (nn.LayerNorm(eps=1e-6): modeling_finetune.py:134,140;

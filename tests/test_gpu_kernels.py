@@ -109,6 +109,12 @@ def test_attention_fwd_bwd(dev, Bn, H, scale, spike):
     dqkv = ops.attn_bwd(qkv, ctx, dctx, lse, Bn, H, D, scale)
     for lo in (0, D, 2 * D):
         assert rel(dqkv[:, lo:lo + D], g[:, lo:lo + D]) < 2e-2
+    dqkv2, qs, vs = ops.attn_bwd(qkv, ctx, dctx, lse, Bn, H, D, scale, bias_sums=True)      # fused q_bias / v_bias gradients
+    assert torch.equal(dqkv2, dqkv)
+    bq, bv = torch.randn(D, device=dev), torch.randn(D, device=dev)
+    bq0, bv0 = bq.clone(), bv.clone()
+    ops.colsum_partials(qs, bq); ops.colsum_partials(vs, bv)
+    assert rel(bq - bq0, g[:, :D].sum(0)) < 2e-2 and rel(bv - bv0, g[:, 2 * D:].sum(0)) < 2e-2     # same tolerance as dq, dv
 
 
 @pytest.mark.parametrize("D,gelu", [(384, 0), (512, 0), (128, 0), (192, 1), (64, 1), (256, 0)])

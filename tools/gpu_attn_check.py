@@ -38,7 +38,7 @@ def run(Bn, H, scale, spike=False):
     g = x.grad.clone()
     g[:, :D] *= scale
     dqkv = torch.empty_like(qkv)
-    L.call("dig_attn_bwd", L.ptr(qkv), L.ptr(ctx), L.ptr(dctx), L.ptr(lse), L.ptr(dqkv), Bn, H, D, ctypes.c_float(scale), L.stream())
+    L.call("dig_attn_bwd", L.ptr(qkv), L.ptr(ctx), L.ptr(dctx), L.ptr(lse), L.ptr(dqkv), Bn, H, D, ctypes.c_float(scale), None, None, L.stream())
     e_q, e_k, e_v = rel(dqkv[:, :D], g[:, :D]), rel(dqkv[:, D:2 * D], g[:, D:2 * D]), rel(dqkv[:, 2 * D:], g[:, 2 * D:])
     ok = max(e_o, e_q, e_k, e_v) < 2e-2 and e_l < 2e-2
     print(f"Bn={Bn} H={H} scale={scale} spike={spike}: ctx {e_o:.2e} lse {e_l:.2e} dq {e_q:.2e} dk {e_k:.2e} dv {e_v:.2e} {'OK' if ok else 'FAIL'}")
@@ -67,7 +67,7 @@ dctx = torch.randn(Bn * 256, D, device=dev).bfloat16()
 dqkv = torch.empty_like(qkv)
 lse = torch.empty(Bn * H, 256, device=dev)
 tf = bench(lambda: L.call("dig_attn_fwd", L.ptr(qkv), L.ptr(ctx), L.ptr(lse), Bn, H, D, L.stream()))
-tb = bench(lambda: L.call("dig_attn_bwd", L.ptr(qkv), L.ptr(ctx), L.ptr(dctx), L.ptr(lse), L.ptr(dqkv), Bn, H, D, ctypes.c_float(0.125), L.stream()))
+tb = bench(lambda: L.call("dig_attn_bwd", L.ptr(qkv), L.ptr(ctx), L.ptr(dctx), L.ptr(lse), L.ptr(dqkv), Bn, H, D, ctypes.c_float(0.125), None, None, L.stream()))
 fl = 4.0 * 256 * 256 * 64 * Bn * H
 print(f"attn fwd {tf*1e6:.1f} us {fl/tf/1e12:.0f} TF | bwd {tb*1e6:.1f} us {2.5*fl/tb/1e12:.0f} TF (algorithmic 2.5x fwd)")
 qq = qkv.view(Bn, 256, 3, H, 64).permute(2, 0, 3, 1, 4)
