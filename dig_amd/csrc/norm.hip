@@ -343,17 +343,38 @@ extern "C" long long dig_layernorm_bwd_workspace_bytes(int rows, int D) {
 }
 
 // dcolsum (nullable): receives += column sums of dres (the bias gradient of the layer that produced the skip-path sum)
+// number of partial rows ([parts][3][D] fp32) the LayerNorm backward leaves in its workspace
+extern "C" int dig_layernorm_bwd_parts(int rows) { return std::max(1, std::min(1024, (rows + 15) / 16)); }
+
+// dx only; dgamma / dbeta / dres column-sum partials stay in `workspace` for dig_layernorm_bwd_finalize (which a caller may
+// run on another stream: nothing on the data-gradient chain depends on it)
+extern "C" int dig_layernorm_bwd_partials(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean,
+                                          const float* rstd, const void* dres, void* dx, float* workspace, int rows, int D,
+                                          int fuse_gelu, hipStream_t stream) {
+  if (!dy || !x || !gamma || !mean || !rstd || !dx || !workspace || rows <= 0) return DIG_ERR_ARG;
+  if (fuse_gelu && !beta) return DIG_ERR_ARG;
+  if (!aligned16(x) || !aligned16(dy) || !aligned16(dx) || (dres && !aligned16(dres))) return DIG_ERR_ALIGN;
+  const int grid = dig_layernorm_bwd_parts(rows);
+  if (fuse_gelu) { LN_DISPATCH(D, true, ln_bwd_kernel, (const bf16_t*)dy, (const bf16_t*)x, gamma, beta, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, workspace, rows) }
+  else { LN_DISPATCH(D, false, ln_bwd_kernel, (const bf16_t*)dy, (const bf16_t*)x, gamma, beta, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, workspace, rows) }
+  return dig_check_launch();
+}
+
+extern "C" int dig_layernorm_bwd_finalize(const float* workspace, int rows, int D, float* dgamma, float* dbeta, float* dcolsum,
+                                          hipStream_t stream) {
+  if (!workspace || !dgamma || !dbeta || rows <= 0 || D <= 0 || (D & 15)) return DIG_ERR_ARG;
+  hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((3 * D) / 16), dim3(256), 0, stream, workspace, dig_layernorm_bwd_parts(rows), D, dgamma,
+                     dbeta, dcolsum);
+  return dig_check_launch();
+}
+
 extern "C" int dig_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean,
                                  const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta, float* dcolsum,
                                  float* workspace, int rows, int D, int fuse_gelu, hipStream_t stream) {
-  if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || !workspace || rows <= 0) return DIG_ERR_ARG;
-  if ((fuse_gelu && !beta) || (dcolsum && !dres)) return DIG_ERR_ARG;
-  if (!aligned16(x) || !aligned16(dy) || !aligned16(dx) || (dres && !aligned16(dres))) return DIG_ERR_ALIGN;
-  const int grid = std::max(1, std::min(1024, (rows + 15) / 16));
-  if (fuse_gelu) { LN_DISPATCH(D, true, ln_bwd_kernel, (const bf16_t*)dy, (const bf16_t*)x, gamma, beta, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, workspace, rows) }
-  else { LN_DISPATCH(D, false, ln_bwd_kernel, (const bf16_t*)dy, (const bf16_t*)x, gamma, beta, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, workspace, rows) }
-  hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((3 * D) / 16), dim3(256), 0, stream, workspace, grid, D, dgamma, dbeta, dcolsum);
-  return dig_check_launch();
+  if (!dgamma || !dbeta || (dcolsum && !dres)) return DIG_ERR_ARG;
+  const int rc = dig_layernorm_bwd_partials(dy, x, gamma, beta, mean, rstd, dres, dx, workspace, rows, D, fuse_gelu, stream);
+  if (rc != DIG_OK) return rc;
+  return dig_layernorm_bwd_finalize(workspace, rows, D, dgamma, dbeta, dcolsum, stream);
 }
 
 static inline int bn_rows_per_block(int rows, int C) {

@@ -99,6 +99,37 @@ class _Step:
             x = x_out
         return x, saved
 
+    # ------------------------------------------------------------------ two-stream helpers (backward)
+    def _streams(self, dev):
+        M = self.m
+        main = torch.cuda.current_stream(dev)
+        side = M._side_stream(dev) if getattr(M, "overlap_streams", True) else main
+        return main, side
+
+    def _on_side(self, dev, fn, *tensors):
+        """Run fn (weight-gradient GEMMs, column sums: consumers of tensors the main chain has just produced) on the side
+        stream, after everything the main stream has queued so far."""
+        main, side = self._streams(dev)
+        if side is main:
+            fn()
+            return
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            fn()
+        for t in tensors:
+            t.record_stream(side)
+
+    def _grad_ready(self, dev, key):
+        """Bucket `key` is final once both streams pass this point.  With a process group the all-reduce is issued from the
+        side stream after it has waited for the main chain, so the main chain never stalls on a collective."""
+        main, side = self._streams(dev)
+        if side is not main and (self.comm.world > 1 or getattr(self.comm, "world_override", False)):
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self.comm.grad_ready(self.m, key)
+        else:
+            self.comm.grad_ready(self.m, key)
+
     def encoder_backward(self, ew, saved, dx, images, aug, mask_u8, views=2):
         """dx: bf16 [R, D] gradient w.r.t. the encoder output (consumed).
         The data-gradient chain (dgrad GEMMs, attention backward, LayerNorm backward) runs on the caller's stream; the
@@ -108,18 +139,10 @@ class _Step:
         B, D, H, N = images.shape[0], M.D, M.H, M.N
         scale = (D // H) ** -0.5
         dev = dx.device
-        main = torch.cuda.current_stream(dev)
-        side = M._side_stream(dev) if getattr(M, "overlap_streams", True) else main
+        main, side = self._streams(dev)
 
         def on_side(fn, *tensors):
-            if side is main:
-                fn()
-                return
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                fn()
-            for t in tensors:
-                t.record_stream(side)
+            self._on_side(dev, fn, *tensors)
 
         for i in reversed(range(M.depth)):
             blk, g = ew.blocks[i], ew.blocks[i]["g"]
@@ -135,8 +158,9 @@ class _Step:
             on_side(lambda: (ops.linear_wgrad(dact, ln2, g["mlp.fc1.weight"]),                       # the fc1 bias sums fused
                              ops.colsum_partials(bparts, g["mlp.fc1.bias"])), dact, ln2, bparts)      # (0.3 ms/step vs a 201 MB pass)
             dln2 = ops.linear_dgrad(dact, blk["mlp.fc1.weight"])
-            dx_mid = ops.layernorm_bwd(dln2, x_mid, blk["norm2.weight"], blk["norm2.bias"], mu2, rs2, dx, g["norm2.weight"], g["norm2.bias"],
-                                       out=dln2, dres_colsum=g["mlp.fc2.bias"])      # colsum(dx) = fc2 bias grad, fused
+            dx_mid, fin2, ws2 = ops.layernorm_bwd(dln2, x_mid, blk["norm2.weight"], blk["norm2.bias"], mu2, rs2, dx, g["norm2.weight"],
+                                                  g["norm2.bias"], out=dln2, dres_colsum=g["mlp.fc2.bias"], defer=True)
+            on_side(fin2, ws2)                                                # norm2 grads + colsum(dx) = fc2 bias grad: off the chain
             # x_mid = x + proj(attn(ln1))
             on_side(lambda: ops.linear_wgrad(dx_mid, ctx, g["attn.proj.weight"]), dx_mid, ctx)
             dctx = ops.linear_dgrad(dx_mid, blk["attn.proj.weight"])
@@ -149,17 +173,13 @@ class _Step:
                              ops.colsum(dqkv[:, 2 * D:], gb[2 * D:], cols=D)),  # v_bias; K has no bias
                     dqkv, ln1)
             dln1 = ops.linear_dgrad(dqkv, blk["attn.qkv.weight"], out=dctx)
-            dx = ops.layernorm_bwd(dln1, x, blk["norm1.weight"], blk["norm1.bias"], mu1, rs1, dx_mid, g["norm1.weight"], g["norm1.bias"],
-                                   out=dln1, dres_colsum=g["attn.proj.bias"])            # colsum(dx_mid) = proj bias grad, fused
+            dx, fin1, ws1 = ops.layernorm_bwd(dln1, x, blk["norm1.weight"], blk["norm1.bias"], mu1, rs1, dx_mid, g["norm1.weight"],
+                                              g["norm1.bias"], out=dln1, dres_colsum=g["attn.proj.bias"], defer=True)
+            on_side(fin1, ws1)                                                # norm1 grads + colsum(dx_mid) = proj bias grad
             del dact, pre, act, dln2, dqkv, dctx
             # this block's gradients are final once BOTH streams pass this point: the bucket's all-reduce is issued from the
             # side stream after it has waited for the main chain, so the main chain itself never stalls on the collective
-            if side is not main and (self.comm.world > 1 or getattr(self.comm, "world_override", False)):
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    self.comm.grad_ready(M, f"encoder.blocks.{i}")
-            else:
-                self.comm.grad_ready(M, f"encoder.blocks.{i}")
+            self._grad_ready(dev, f"encoder.blocks.{i}")
         for half, im in enumerate((images, aug)[:views]):
             ops.patch_embed_bwd_mfma(dx[half * B * N:(half + 1) * B * N], im, mask_u8[half * B:(half + 1) * B], ew.g_pe_w, ew.g_pe_b,
                                      ew.g_mask_token, D, M.gh, M.gw)
@@ -211,7 +231,7 @@ class _Step:
                 ops.axpy_f32(g32[f"{pre}.{3 * l + 1}.weight"], sums[1])
             self.comm.all_reduce_(sums)
             dh = ops.bn_bwd_apply(dy, h, mean, rstd, gamma, beta, not last, sums, n_total)
-            ops.linear_wgrad(dh, x, g32[f"{pre}.{3 * l}.weight"])
+            self._on_side(dy.device, lambda: ops.linear_wgrad(dh, x, g32[f"{pre}.{3 * l}.weight"]), dh, x)
             if l > 0 or need_dx:
                 dy = ops.linear_dgrad(dh, w16[f"{pre}.{3 * l}.weight"], out=dx_out if l == 0 else None)
         return dy
@@ -323,14 +343,14 @@ class _Step:
             dq16 = torch.empty(dq.shape, device=dev, dtype=BF16)
             ops.cast_f32_to_bf16(dq, dq16)
             dproj = self.mlp_backward(dq16, "predictor", self.saved_pred)
-            self.comm.grad_ready(M, "predictor")
+            self._grad_ready(dev, "predictor")
             dpool = self.mlp_backward(dproj, "encoder_projection_layer", self.saved_proj)
-            self.comm.grad_ready(M, "encoder_projection_layer")
+            self._grad_ready(dev, "encoder_projection_layer")
             dmasked2 = torch.empty((B * N, D), device=dev, dtype=BF16)
             ops.window_pool_bwd(dpool[:n], dmasked2, B, M.gh, M.gw, nw, D, False)
             ops.window_pool_bwd(dpool[n:], d_enc[B * N:], B, M.gh, M.gw, nw, D, False)
             self.mlp_backward(dmasked2, "pix_projector", self.saved_pix, dx_out=d_enc[:B * N])
-            self.comm.grad_ready(M, "pix_projector")
+            self._grad_ready(dev, "pix_projector")
         else:
             for name in ("predictor", "encoder_projection_layer", "pix_projector"):
                 self.comm.grad_ready(M, name)
@@ -340,17 +360,17 @@ class _Step:
             Mrows, Mp, C, Dd = self.Mrows, self.Mp, M.dec_classes, M.dec_dim
             dpred = torch.empty((Mp, 64), device=dev, dtype=BF16)
             ops.pad_cast_rows(g_vis.reshape(Mrows, C).contiguous().float(), dpred, Mrows, C)
-            ops.wgrad(dpred, h2, g32["pix_decoder.4.weight"], C, Dd, Mp)
-            ops.colsum(dpred, g32["pix_decoder.4.bias"], cols=C)
+            self._on_side(dev, lambda: (ops.wgrad(dpred, h2, g32["pix_decoder.4.weight"], C, Dd, Mp),
+                                        ops.colsum(dpred, g32["pix_decoder.4.bias"], cols=C)), dpred, h2)
             dh2 = ops.gemm(dpred, w16["pix_decoder.4.weight"], Mp, Dd, 64, tb=True, b_rows=C)
             dh1 = ops.layernorm_bwd(dh2, h1, f32["pix_decoder.2.weight"], f32["pix_decoder.2.bias"], mu, rs, None,
                                     g32["pix_decoder.2.weight"], g32["pix_decoder.2.bias"], gelu=True)
-            ops.linear_wgrad(dh1, h0, g32["pix_decoder.1.weight"])
+            self._on_side(dev, lambda: ops.linear_wgrad(dh1, h0, g32["pix_decoder.1.weight"]), dh1, h0)
             dh0 = ops.linear_dgrad(dh1, w16["pix_decoder.1.weight"])
-            ops.linear_wgrad(dh0, gath, g32["pix_decoder.0.weight"])
+            self._on_side(dev, lambda: ops.linear_wgrad(dh0, gath, g32["pix_decoder.0.weight"]), dh0, gath)
             dgath = ops.linear_dgrad(dh0, w16["pix_decoder.0.weight"])
             ops.scatter_rows_add(dgath, self.idx, d_enc, Mrows)
-        self.comm.grad_ready(M, "pix_decoder")
+        self._grad_ready(dev, "pix_decoder")
         # ---- encoder
         ew_on, _ = _weights(M)
         if views == 2 or g_vis is not None:
@@ -359,6 +379,9 @@ class _Step:
             for i in reversed(range(M.depth)):
                 self.comm.grad_ready(M, f"encoder.blocks.{i}")
             self.comm.grad_ready(M, "encoder.embed")
+        main, side = self._streams(dev)
+        if side is not main:
+            main.wait_stream(side)                  # every gradient is final on the caller's stream (grad norm / AdamW follow)
         self.saved_enc = self.saved_pix = self.saved_proj = self.saved_pred = self.saved_dec = None
 
 

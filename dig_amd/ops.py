@@ -152,15 +152,25 @@ def layernorm_fwd(x, gamma, beta, eps, gelu=False):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, beta, mean, rstd, dres, dgamma, dbeta, gelu=False, out=None, dres_colsum=None):
+def layernorm_bwd(dy, x, gamma, beta, mean, rstd, dres, dgamma, dbeta, gelu=False, out=None, dres_colsum=None, defer=False):
     """dx = [dres +] LN'(dy); dgamma/dbeta accumulated; dres_colsum (optional) += column sums of dres, i.e. the bias
-    gradient of the layer whose output fed the residual sum -- read for free while dres streams through."""
+    gradient of the layer whose output fed the residual sum -- read for free while dres streams through.
+    defer=True returns (dx, finish, workspace): `finish()` launches the parameter-gradient reduction (callable on another
+    stream; keep `workspace` alive / record_stream it there)."""
     rows, D = x.shape
     dx = torch.empty_like(x) if out is None else out
-    ws = _workspace2(x.device, 1024 * 3 * D)
-    L.call("dig_layernorm_bwd", L.ptr(dy), L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(mean), L.ptr(rstd), L.ptr(dres), L.ptr(dx),
-           L.ptr(dgamma), L.ptr(dbeta), L.ptr(dres_colsum), L.ptr(ws), rows, D, int(gelu), L.stream())
-    return dx
+    if not defer:
+        ws = _workspace2(x.device, 1024 * 3 * D)
+        L.call("dig_layernorm_bwd", L.ptr(dy), L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(mean), L.ptr(rstd), L.ptr(dres), L.ptr(dx),
+               L.ptr(dgamma), L.ptr(dbeta), L.ptr(dres_colsum), L.ptr(ws), rows, D, int(gelu), L.stream())
+        return dx
+    ws = torch.empty(L.lib().dig_layernorm_bwd_parts(rows) * 3 * D, device=x.device, dtype=F32)
+    L.call("dig_layernorm_bwd_partials", L.ptr(dy), L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(mean), L.ptr(rstd), L.ptr(dres),
+           L.ptr(dx), L.ptr(ws), rows, D, int(gelu), L.stream())
+
+    def finish():
+        L.call("dig_layernorm_bwd_finalize", L.ptr(ws), rows, D, L.ptr(dgamma), L.ptr(dbeta), L.ptr(dres_colsum), L.stream())
+    return dx, finish, ws
 
 
 def attn_fwd(qkv, n_img, heads, D):

@@ -78,6 +78,15 @@ long long dig_layernorm_bwd_workspace_bytes(int rows, int D);
 int dig_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean, const float* rstd,
                       const void* dres, void* dx, float* dgamma, float* dbeta, float* dcolsum, float* workspace, int rows, int D,
                       int fuse_gelu, hipStream_t stream);
+/* The same in two launches: dig_layernorm_bwd_partials writes dx and leaves [dig_layernorm_bwd_parts(rows)][3][D] fp32 partial
+ * sums (dgamma, dbeta, column sums of dres) in `workspace`; dig_layernorm_bwd_finalize accumulates them into dgamma / dbeta /
+ * dcolsum.  Nothing on the data-gradient chain depends on the second launch, so a caller may put it on another stream. */
+int dig_layernorm_bwd_parts(int rows);
+int dig_layernorm_bwd_partials(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean,
+                               const float* rstd, const void* dres, void* dx, float* workspace, int rows, int D, int fuse_gelu,
+                               hipStream_t stream);
+int dig_layernorm_bwd_finalize(const float* workspace, int rows, int D, float* dgamma, float* dbeta, float* dcolsum,
+                               hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * BatchNorm1d in training mode, split so that the [2,C] statistics vector can be all-reduced between the halves
