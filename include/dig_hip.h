@@ -205,6 +205,25 @@ int dig_resize_bicubic_normalize_u8(const unsigned char* packed, const long long
 int dig_random_masks(unsigned char* mask, int n_rows, int n_patches, int num_mask, unsigned long long seed, unsigned step,
                      hipStream_t stream);
 
+/* ---- greedy decode with a K/V cache (models/decoder.py:173-252, models/transformer_layer.py:238-281)
+ * One decode step of TFDecoder.forward_test per call sequence: dig_decode_embed (token embedding + position row t), then per
+ * layer LayerNorm / dig_gemm_bf16 for the projections (the fused q|k|v GEMM writes row t of the [B, T, 3*heads*64] cache in
+ * place), dig_decode_self_attn (row t against rows 0..t), dig_decode_cross_attn (against [B, n_mem, 2*heads*64] = k|v of the
+ * encoder memory, projected once; `weights` optional [B, heads, n_mem] fp32), and dig_softmax_argmax on the classifier logits.
+ * head_dim must be 64. */
+int dig_decode_embed(const long long* tokens, const float* emb, const float* pe_row, void* x, int B, int d, int vocab,
+                     hipStream_t stream);
+int dig_decode_self_attn(const void* qkv_cache, void* out, int B, int T, int heads, int head_dim, int t, float scale,
+                         hipStream_t stream);
+int dig_decode_cross_attn(const void* q, const void* kv_mem, void* out, float* weights, int B, int n_mem, int heads, int head_dim,
+                          float scale, hipStream_t stream);
+int dig_softmax_argmax(const float* logits, int ld, float* probs, long long* tokens, int B, int C, hipStream_t stream);
+/* Accuracy of evaluation_metric/metrics.py:19-81 on the device: rows of pred / target ([B][T] int64 class ids) are cut at `eos`;
+ * canon[c] (uint8, n_classes entries) is the canonical code of class c -- 0 for classes the metric drops (UNKNOWN, anything that
+ * is not a digit or letter), otherwise the same code for upper and lower case; match[b] = 1 when the normalised strings agree. */
+int dig_string_match(const long long* pred, const long long* target, const unsigned char* canon, int n_classes, int eos, int B, int T,
+                     unsigned char* match, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

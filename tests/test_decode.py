@@ -1,0 +1,169 @@
+"""Row N4 (recognition forward + greedy decode): the fp32 oracle against fixtures written by the unmodified reference classes
+(CPU), and the device path (K/V-cached decode, bf16) against the oracle / fixtures (GPU)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import decode_oracle as D
+import dig_oracle as O
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _tiny():
+    g = np.load(os.path.join(GOLD, "decode_tiny.npz"))
+    c = D.DecoderConfig(**{k: int(v) for k, v in zip(g["cfg_keys"].tolist(), g["cfg_vals"].tolist())})
+    return g, c
+
+
+def test_oracle_decode_matches_reference_fixture():
+    g, c = _tiny()
+    P = D.det_decoder_state(c, int(g["seed"]))
+    mem = O.det_tensor("memory", (int(g["B"]), int(g["Nm"]), c.d_model), 4, 1.0)
+    for fn in (D.greedy_decode, D.greedy_decode_cached):                 # literal forward_test, and the K/V-cache form
+        probs, maps, toks = fn(P, c, mem)
+        assert np.array_equal(toks.numpy(), g["tokens"])
+        np.testing.assert_allclose(probs.numpy(), g["probs"], atol=3e-6)
+        np.testing.assert_allclose(maps.numpy(), g["maps"], atol=3e-6)
+
+
+def test_oracle_recognizer_matches_reference_fixture():
+    g = np.load(os.path.join(GOLD, "recognize_tiny.npz"))
+    _, c = _tiny()
+    ecfg = O.DiGConfig(**O.TINY)
+    P = {**D.det_encoder_state(ecfg, int(g["seed_enc"])), **D.det_decoder_state(c, int(g["seed_dec"]))}
+    images = O.synthetic_batch(int(g["B"]), ecfg, int(g["batch_seed"]))[0]
+    probs, maps, toks = D.recognize(P, ecfg, c, images)
+    assert np.array_equal(toks.numpy(), g["tokens"])
+    np.testing.assert_allclose(probs.numpy(), g["probs"], atol=1e-5)
+    np.testing.assert_allclose(maps.numpy(), g["maps"], atol=1e-5)
+
+
+def test_recmodel_state_dict_inventory_matches_reference():
+    """Keys / shapes of the real reference RecModel (simmim_vit_small_patch4_32x128 + tf_decoder, 97 classes, max_len 25)."""
+    import types
+    from dig_amd.recognizer import RecModel
+    keys = np.load(os.path.join(GOLD, "recmodel_keys.npz"))["keys"].tolist()
+    args = types.SimpleNamespace(model="simmim_vit_small_patch4_32x128", decoder_name="tf_decoder", nb_classes=97, max_len=25)
+    mine = RecModel(args).param_shapes()
+    ref = [k for k in keys if not k.endswith("position_table") and not k.startswith("patch_embed.")]
+    assert sorted(mine.keys()) == sorted(ref)
+    assert mine["decoder.trg_word_emb.weight"] == (98, 512) and mine["decoder.classifier.weight"] == (97, 512)
+    want = {**D.finetune_encoder_shapes(O.make_config("pretrain_simmim_moco_ori_vit_small_patch4_32x128")), **D.decoder_param_shapes(D.DecoderConfig())}
+    assert {k: tuple(v) for k, v in mine.items()} == {k: tuple(v) for k, v in want.items()}
+
+
+# ------------------------------------------------------------------------------------------------ device
+def _tiny_model(c, ecfg, P):
+    from dig_amd.recognizer import RecModel
+    m = RecModel(embed_dim=ecfg.embed_dim, depth=ecfg.depth, num_heads=ecfg.heads, n_layers=c.n_layers, d_model=c.d_model, n_head=c.n_head,
+                 d_k=c.d_k, d_inner=c.d_inner, nb_classes=c.num_classes, max_len=c.max_seq_len).eval()
+    m.load_state_dict(P)
+    m._prepare(torch.device("cuda:0"))
+    return m
+
+
+@pytest.mark.gpu
+def test_device_decode_steps_vs_reference_fixture():
+    g, c = _tiny()
+    ecfg = O.DiGConfig(**O.TINY)
+    P = {**D.det_encoder_state(ecfg, 22), **D.det_decoder_state(c, int(g["seed"]))}
+    m = _tiny_model(c, ecfg, P)
+    B, Nm = int(g["B"]), int(g["Nm"])
+    mem = O.det_tensor("memory", (B, Nm, c.d_model), 4, 1.0).to("cuda:0").to(torch.bfloat16).reshape(B * Nm, c.d_model).contiguous()
+    ref_tok = torch.from_numpy(g["tokens"]).to("cuda:0")
+    probs, maps, toks = m.greedy_decode(mem, Nm, force_tokens=ref_tok)          # teacher-forced: every step comparable
+    p, r = probs.cpu().numpy(), g["probs"]
+    assert np.abs(p - r).max() < 3e-2 and np.abs(p[:, 0] - r[:, 0]).max() < 2e-2
+    assert np.abs(maps.cpu().numpy() - g["maps"]).max() < 5e-3
+    top2 = np.sort(r, -1)[..., -2:]
+    clear = (top2[..., 1] - top2[..., 0]) > 2.5 * np.abs(p - r).max()             # steps whose arg-max is not a near tie
+    assert clear.any() and np.array_equal(toks.cpu().numpy()[clear], g["tokens"][clear])
+    probs2, _, toks2 = m.greedy_decode(mem, Nm)                                   # free running: identical while tokens agree
+    same = (toks2.cpu().numpy() == g["tokens"]).all(1)
+    assert same.any() and np.abs(probs2.cpu().numpy()[same] - r[same]).max() < 3e-2
+
+
+@pytest.mark.gpu
+def test_device_recognizer_vs_reference_fixture():
+    g = np.load(os.path.join(GOLD, "recognize_tiny.npz"))
+    _, c = _tiny()
+    ecfg = O.DiGConfig(**O.TINY)
+    P = {**D.det_encoder_state(ecfg, int(g["seed_enc"])), **D.det_decoder_state(c, int(g["seed_dec"]))}
+    m = _tiny_model(c, ecfg, P)
+    images = O.synthetic_batch(int(g["B"]), ecfg, int(g["batch_seed"]))[0].to("cuda:0")
+    enc = m.encoder_features(images)
+    mem = m.memory(enc)
+    want_enc = D.encoder_features(P, ecfg, images.cpu())
+    assert ((enc.float().cpu().reshape(want_enc.shape) - want_enc).norm() / want_enc.norm()).item() < 1e-2
+    assert abs(mem.float().norm().item() - float(g["memory_norm"])) < 1e-2 * float(g["memory_norm"])
+    probs, maps, toks = m.greedy_decode(mem, 256, force_tokens=torch.from_numpy(g["tokens"]).to("cuda:0"))
+    assert np.abs(probs.cpu().numpy() - g["probs"]).max() < 4e-2 and np.abs(maps.cpu().numpy() - g["maps"]).max() < 5e-3
+    out = m((images, None, None))                                                 # the RecModel.forward surface
+    assert out[0].shape == (int(g["B"]), c.max_seq_len, c.num_classes) and out[3].shape == (int(g["B"]), c.max_seq_len, 256)
+    assert abs(float(out[0].sum(-1).mean()) - 1.0) < 1e-4
+
+
+@pytest.mark.gpu
+def test_decode_attention_kernels_vs_torch():
+    import ctypes
+    from dig_amd import _lib as L
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    B, T, H, Nm, hk = 7, 9, 3, 200, 192
+    qkv = torch.randn(B, T, 3 * hk, device=dev).to(torch.bfloat16)
+    out = torch.empty(B, hk, device=dev, dtype=torch.bfloat16)
+    for t in (0, 4, 8):
+        L.call("dig_decode_self_attn", L.ptr(qkv), L.ptr(out), B, T, H, 64, t, ctypes.c_float(0.125), L.stream())
+        q = qkv[:, t, :hk].float().view(B, H, 1, 64)
+        k = qkv[:, :t + 1, hk:2 * hk].float().view(B, t + 1, H, 64).permute(0, 2, 1, 3)
+        v = qkv[:, :t + 1, 2 * hk:].float().view(B, t + 1, H, 64).permute(0, 2, 1, 3)
+        ref = ((q @ k.transpose(-1, -2) * 0.125).softmax(-1) @ v).reshape(B, hk)
+        assert (out.float() - ref).abs().max().item() < 2e-2
+    q = torch.randn(B, hk, device=dev).to(torch.bfloat16)
+    kv = torch.randn(B, Nm, 2 * hk, device=dev).to(torch.bfloat16)
+    w = torch.empty(B, H, Nm, device=dev)
+    L.call("dig_decode_cross_attn", L.ptr(q), L.ptr(kv), L.ptr(out), L.ptr(w), B, Nm, H, 64, ctypes.c_float(0.125), L.stream())
+    qf = q.float().view(B, H, 1, 64)
+    kf = kv[:, :, :hk].float().view(B, Nm, H, 64).permute(0, 2, 1, 3)
+    vf = kv[:, :, hk:].float().view(B, Nm, H, 64).permute(0, 2, 1, 3)
+    wr = (qf @ kf.transpose(-1, -2) * 0.125).softmax(-1)
+    assert (w - wr[:, :, 0]).abs().max().item() < 1e-4 and (out.float() - (wr @ vf).reshape(B, hk)).abs().max().item() < 2e-2
+    logits = torch.randn(B, 104, device=dev); logits[2, 5] = logits[2, 50] = 9.0       # tie: first index wins (torch.max)
+    probs = torch.empty(B, 97, device=dev); tok = torch.empty(B, dtype=torch.int64, device=dev)
+    L.call("dig_softmax_argmax", L.ptr(logits), 104, L.ptr(probs), L.ptr(tok), B, 97, L.stream())
+    assert (probs - logits[:, :97].softmax(-1)).abs().max().item() < 1e-6 and torch.equal(tok, logits[:, :97].argmax(-1)) and int(tok[2]) == 5
+
+
+def test_oracle_string_accuracy_rules():
+    voc = D.vocabulary()
+    assert len(voc) == 97 and voc[94:] == ["EOS", "PADDING", "UNKNOWN"]
+    enc = lambda w, n=8: [voc.index(c) for c in w] + [94] + [95] * (n - len(w) - 1)
+    pred = np.array([enc("Hello"), enc("a-b!"), enc("xyz"), [voc.index("q"), 96, voc.index("r"), 94, 1, 2, 3, 4]])
+    targ = np.array([enc("hello"), enc("AB"), enc("xy"), enc("qr")])
+    assert D.str_list(pred, voc) == ["hello", "ab", "xyz", "qr"] and D.accuracy(pred, targ, voc) == 0.75
+
+
+@pytest.mark.gpu
+def test_device_string_accuracy_matches_oracle():
+    from dig_amd.recognizer import accuracy
+    voc = D.vocabulary()
+    rng = np.random.RandomState(0)
+    B, T = 512, 25
+    targ = rng.randint(0, 97, size=(B, T))
+    pred = targ.copy()
+    flip = rng.rand(B, T) < 0.03
+    pred[flip] = rng.randint(0, 97, size=int(flip.sum()))
+    pred[::7, 3] = 94; targ[::5, 6] = 94                                         # early EOS on either side
+    want = D.accuracy(pred, targ, voc)
+    got = accuracy(torch.from_numpy(pred).to("cuda:0"), torch.from_numpy(targ).to("cuda:0"), voc).item()
+    assert 0.05 < want < 0.95 and abs(got - want) < 1e-7
+    p1, t1 = D.str_list(pred, voc), D.str_list(targ, voc)                        # and sample by sample
+    from dig_amd import _lib as L
+    from dig_amd.recognizer import class_canon
+    match = torch.empty(B, dtype=torch.uint8, device="cuda:0")
+    pd, td, cn = torch.from_numpy(pred).to("cuda:0"), torch.from_numpy(targ).to("cuda:0"), class_canon(voc).to("cuda:0")
+    L.call("dig_string_match", L.ptr(pd), L.ptr(td), L.ptr(cn), 97, 94, B, T, L.ptr(match), L.stream())
+    assert match.cpu().numpy().astype(bool).tolist() == [a == b for a, b in zip(p1, t1)]
