@@ -607,11 +607,19 @@ __global__ __launch_bounds__(64 * WM * WN, (BK == 32 && WM * WN == 8 && FM * FN 
 
   const int nblk = p.tiles_i * p.tiles_j;
   const int bid = blockIdx.x;
-  const int q = nblk >> 3, rm = nblk & 7, xcd = bid & 7;
-  const int logical = (xcd < rm ? xcd * (q + 1) : rm * (q + 1) + (xcd - rm) * q) + (bid >> 3);
+  int logical, split;
+  if (p.splits_x > 0) {                        // split-R: every split pinned to one XCD (see gemm_kernel)
+    const int k = bid >> 3, round = k / nblk;
+    split = (bid & 7) + 8 * round;
+    logical = k - round * nblk;
+  } else {
+    const int q = nblk >> 3, rm = nblk & 7, xcd = bid & 7;
+    logical = (xcd < rm ? xcd * (q + 1) : rm * (q + 1) + (xcd - rm) * q) + (bid >> 3);
+    split = blockIdx.z;
+  }
   const int ti = logical / p.tiles_j, tj = logical - ti * p.tiles_j;
   const int i0 = ti * Cfg::TBI, j0 = tj * Cfg::TBJ;
-  const int rbeg = blockIdx.z * p.r_per_split;
+  const int rbeg = split * p.r_per_split;
   const int rend = min(p.R, rbeg + p.r_per_split);
   const int nt = (rend - rbeg + BK - 1) / BK;
 
@@ -686,7 +694,7 @@ __global__ __launch_bounds__(64 * WM * WN, (BK == 32 && WM * WN == 8 && FM * FN 
   const int cg = lane & 7;
   float* stg = reinterpret_cast<float*>(smem + wave * 8192);
   float* cpart = reinterpret_cast<float*>(p.C);
-  if (OUT == 2) cpart += (size_t)blockIdx.z * p.I * p.ldc;
+  if (OUT == 2) cpart += (size_t)split * p.I * p.ldc;
 #pragma unroll
   for (int bh = 0; bh < FN / 2; ++bh) {
   const int j = j0 + wj * (32 * FN) + bh * 64 + cg * 8;
@@ -787,7 +795,8 @@ int launch_wide(GemmParams p, int splits, hipStream_t stream) {
   }
   p.tiles_i = (p.I + Cfg::TBI - 1) / Cfg::TBI;
   p.tiles_j = (p.J + Cfg::TBJ - 1) / Cfg::TBJ;
-  dim3 grid(p.tiles_i * p.tiles_j, 1, splits);
+  p.splits_x = (splits > 1 && splits % 8 == 0) ? splits : 0;
+  dim3 grid(p.tiles_i * p.tiles_j * (p.splits_x ? splits : 1), 1, p.splits_x ? 1 : splits);
   hipLaunchKernelGGL((gemm_wide_kernel<TA, TB, OUT, WM, WN, FM, FN, RES, BK, NSTG>), grid, dim3(Cfg::NT), Cfg::LDS, stream, p);
   return dig_check_launch();
 }
