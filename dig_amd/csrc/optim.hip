@@ -1,7 +1,8 @@
 // Flat-arena optimizer kernels (HBM-bound, 16 B per lane per stream):
 //   adamw_step: decoupled-weight-decay Adam exactly as custom_optim/_functional.py:115-140 computes it, over a
-//       contiguous fp32 range of the parameter arena, with up to 4 (begin,end,weight_decay) segments so one launch
-//       covers the decay / no-decay groups of optim_factory.py:57-100; also refreshes the bf16 shadow the GEMMs read.
+//       contiguous fp32 range of the parameter arena; a uint8 table with one entry per 256-element granule (parameters are
+//       padded to 256) selects the decay / no-decay group of optim_factory.py:57-100, so one launch covers both groups; it
+//       also refreshes the bf16 shadow the GEMMs read.
 //       Traffic: read p,g,m,v + write p,m,v (28 B/param) + 2 B/param bf16 shadow.
 //   ema_update: p_m = p_m*m + p*(1-m)  (modeling_pretrain_moco_mim_ori.py:428-442) + bf16 shadow: 12 + 2 B/param.
 //   sumsq_partial / sumsq_final: deterministic two-stage sum of squares for the global gradient norm
