@@ -597,7 +597,7 @@ struct WideCfg {
 // counted s_waitcnt vmcnt -- a 256x256x32 step is long enough (about 0.4 us of MFMA) for that look-ahead to cover the
 // L2/HBM -> LDS latency, which a 128x128 tile's step is not.
 template <bool TA, bool TB, int OUT, int WM, int WN, int FM, int FN, bool RES, int BK, int NSTG>
-__global__ __launch_bounds__(64 * WM * WN, (BK == 32 && WM * WN == 8 && FM * FN == 4) ? 4 : 1) void gemm_wide_kernel(GemmParams p) {
+__global__ __launch_bounds__(64 * WM * WN, (BK == 32 && WM * WN == 8 && FM * FN == 4) ? 4 : ((BK == 32 && WM * WN == 4) ? 2 : 1)) void gemm_wide_kernel(GemmParams p) {
   using Cfg = WideCfg<WM, WN, FM, FN, BK, NSTG>;
   static_assert(FN % 2 == 0 && Cfg::NITA <= 8 && Cfg::NITB <= 8, "tile shape");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -839,7 +839,7 @@ extern "C" int dig_gemm_bf16(const void* A, const void* B, void* C, int I, int J
                              int b_rows, int bk, float* colsum_partials, hipStream_t stream) {
   if (!A || !B || !C || I <= 0 || J <= 0 || R <= 0 || splits < 1) return DIG_ERR_ARG;
   if (bias && !aligned16(bias)) return DIG_ERR_ALIGN;
-  if (out_kind < 0 || out_kind > 2 || act < 0 || act > 2 || (bk != 0 && bk != 32 && bk != 33 && bk != 34 && bk != 64 && bk != 132 && bk != 164 && bk != 244 && bk != 242 && bk != 224 && bk != 344 && bk != 343 && bk != 448 && bk != 484 && bk != 444 && bk != 432 && bk != 232 && bk != 332 && bk != 223 && bk != 212 && bk != 221)) return DIG_ERR_ARG;
+  if (out_kind < 0 || out_kind > 2 || act < 0 || act > 2 || (bk != 0 && bk != 32 && bk != 33 && bk != 34 && bk != 64 && bk != 132 && bk != 164 && bk != 244 && bk != 242 && bk != 224 && bk != 344 && bk != 343 && bk != 448 && bk != 484 && bk != 444 && bk != 432 && bk != 232 && bk != 332 && bk != 223 && bk != 212 && bk != 221 && bk != 422 && bk != 424 && bk != 423)) return DIG_ERR_ARG;
   if (act == 2 && !resid) return DIG_ERR_ARG;                   // act 2: resid carries the saved pre-activation
   if (bk >= 100 && bk < 200 && resid && pre_act) return DIG_ERR_UNSUPPORTED;
   if (bk == 0) bk = 64;
@@ -870,6 +870,9 @@ extern "C" int dig_gemm_bf16(const void* A, const void* B, void* C, int I, int J
   p.tiles_i = (I + BI - 1) / BI; p.tiles_j = (J + BJ - 1) / BJ;
 #define DIG_GEMM_WCASE(ta, tb, o)                                                                                   \
   if ((trans_a != 0) == ta && (trans_b != 0) == tb && out_kind == o && bk >= 200) {                                  \
+    if (bk == 422) return resid ? launch_wide<ta, tb, o, 2, 2, 4, 2, true, 32, 2>(p, splits, stream) : launch_wide<ta, tb, o, 2, 2, 4, 2, false, 32, 2>(p, splits, stream); \
+    if (bk == 424) return resid ? launch_wide<ta, tb, o, 2, 2, 2, 4, true, 32, 2>(p, splits, stream) : launch_wide<ta, tb, o, 2, 2, 2, 4, false, 32, 2>(p, splits, stream); \
+    if (bk == 423) return resid ? launch_wide<ta, tb, o, 2, 2, 4, 2, true, 32, 3>(p, splits, stream) : launch_wide<ta, tb, o, 2, 2, 4, 2, false, 32, 3>(p, splits, stream); \
     if (bk == 212) return resid ? launch_wide<ta, tb, o, 1, 2, 2, 2, true, 64, 2>(p, splits, stream) : launch_wide<ta, tb, o, 1, 2, 2, 2, false, 64, 2>(p, splits, stream); \
     if (bk == 221) return resid ? launch_wide<ta, tb, o, 2, 1, 2, 2, true, 64, 2>(p, splits, stream) : launch_wide<ta, tb, o, 2, 1, 2, 2, false, 64, 2>(p, splits, stream); \
     if (bk == 232) return resid ? launch_wide<ta, tb, o, 4, 2, 2, 2, true, 32, 2>(p, splits, stream) : launch_wide<ta, tb, o, 4, 2, 2, 2, false, 32, 2>(p, splits, stream); \
