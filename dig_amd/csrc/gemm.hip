@@ -711,6 +711,9 @@ __global__ __launch_bounds__(64 * WM * WN, (BK == 32 && WM * WN == 8 && FM * FN 
     for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
   }
   const float al = (j < p.alpha_cols) ? p.alpha : 1.0f;
+  float csum[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) csum[e] = 0.f;
 #pragma unroll
   for (int a = 0; a < FM; ++a) {
     uint4 rres[RES ? 4 : 1];
@@ -762,6 +765,10 @@ __global__ __launch_bounds__(64 * WM * WN, (BK == 32 && WM * WN == 8 && FM * FN 
         const unsigned w[4] = {rres[q4].x, rres[q4].y, rres[q4].z, rres[q4].w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) { v[2 * e] *= dgelu_f(bf2f((bf16_t)(w[e] & 0xffff))); v[2 * e + 1] *= dgelu_f(bf2f((bf16_t)(w[e] >> 16))); }
+        if (live) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) csum[e] += v[e];
+        }
       }
       if (RES && p.act != 2) {
         const unsigned w[4] = {rres[q4].x, rres[q4].y, rres[q4].z, rres[q4].w};
@@ -780,6 +787,21 @@ __global__ __launch_bounds__(64 * WM * WN, (BK == 32 && WM * WN == 8 && FM * FN 
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
+  }
+  // fused bias gradient of the layer below (see gemm_kernel): column sums of this wave's 32*FM rows; FM == 2 only, so that
+  // the partial rows have the same 64-row granularity as the 128x128 kernel's
+  if (RES && OUT == 0 && FM == 2 && p.act == 2 && p.colsum) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      csum[e] += __shfl_xor(csum[e], 8, 64);
+      csum[e] += __shfl_xor(csum[e], 16, 64);
+      csum[e] += __shfl_xor(csum[e], 32, 64);
+    }
+    if (lane < 8 && jok && i0 + wi * 64 < p.I) {
+      float* c = p.colsum + (size_t)(ti * WM + wi) * p.J + j;
+      *reinterpret_cast<float4*>(c) = make_float4(csum[0], csum[1], csum[2], csum[3]);
+      *reinterpret_cast<float4*>(c + 4) = make_float4(csum[4], csum[5], csum[6], csum[7]);
+    }
   }
   }
 }
@@ -850,7 +872,8 @@ extern "C" int dig_gemm_bf16(const void* A, const void* B, void* C, int I, int J
   if (out_kind == 2 && (bias || resid || act)) return DIG_ERR_ARG;
   if (out_kind != 2 && splits != 1) return DIG_ERR_ARG;
   if (out_kind == 2 && ldc != J) return DIG_ERR_ARG;            // partial slabs are dense [splits][I][J]
-  if (colsum_partials && !(act == 2 && out_kind == 0 && trans_b && !trans_a && bk < 100)) return DIG_ERR_UNSUPPORTED;
+  if (colsum_partials && !(act == 2 && out_kind == 0 && trans_b && !trans_a && (bk < 100 || bk == 244 || bk == 242 || bk == 224 || bk == 344 || bk == 343)))
+    return DIG_ERR_UNSUPPORTED;                                  // 128x128 kernel and the 64x64-per-wave wide tiles
   if (colsum_partials && !aligned16(colsum_partials)) return DIG_ERR_ALIGN;
   GemmParams p;
   p.splits_x = 0;

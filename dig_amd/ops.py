@@ -41,6 +41,7 @@ def gemm(A, B, I, J, R, *, ta=False, tb=False, out=None, out_kind=OUT_BF16, bias
     return out
 
 
+DGRAD_GELU_BK = 32    # tile of the fc2 dgrad + GELU' + bias-sum GEMM: 128x128/BK32 beats the 256x256 tile inside the step (A/B: 25.9 vs 26.1 ms)
 USE_PANEL = False     # A-resident GEMM (csrc/gemm_panel.hip): correct but slower than the tile kernel at 4 waves/CU -- see DESIGN.md 4
 
 
@@ -81,7 +82,7 @@ def linear_dgrad(dy, w, out=None, gelu_pre=None, colsum=False):
     bias gradient of the layer that produced gelu_pre, for colsum_partials()."""
     if gelu_pre is not None:
         parts = torch.empty(((dy.shape[0] + 63) // 64, w.shape[1]), device=dy.device, dtype=F32) if colsum else None
-        dx = gemm(dy, w, dy.shape[0], w.shape[1], w.shape[0], tb=True, out=out, act=2, resid=gelu_pre, bk=32, colsum_partials=parts)
+        dx = gemm(dy, w, dy.shape[0], w.shape[1], w.shape[0], tb=True, out=out, act=2, resid=gelu_pre, bk=DGRAD_GELU_BK, colsum_partials=parts)
         return (dx, parts) if colsum else dx
     # few rows (the BN-MLP heads on pooled features): 128x64 tiles double the workgroup count (tools/gpu_head_gemm_probe.py)
     return gemm(dy, w, dy.shape[0], w.shape[1], w.shape[0], tb=True, out=out, bk=221 if dy.shape[0] <= 2048 else 0)

@@ -49,10 +49,15 @@ def test_gemm_fwd_dgrad_wgrad(dev, I, J, R, bk):
             pp = prex.float().requires_grad_(True)
             F.gelu(pp).backward(dy.float() @ w.float())
             assert rel(ops.linear_dgrad(dy, w, gelu_pre=prex), pp.grad) < 1e-2
-            dxg, parts = ops.linear_dgrad(dy, w, gelu_pre=prex, colsum=True)       # fused bias gradient of the layer below
-            bsum = torch.randn(R, device=dev); b0 = bsum.clone()
-            ops.colsum_partials(parts, bsum)
-            assert rel(dxg, pp.grad) < 1e-2 and rel(bsum - b0, pp.grad.sum(0)) < 1e-3
+            for tile in (32, 244):                                                  # 128x128 kernel and the 256x256 wide kernel
+                saved, ops.DGRAD_GELU_BK = ops.DGRAD_GELU_BK, tile
+                try:
+                    dxg, parts = ops.linear_dgrad(dy, w, gelu_pre=prex, colsum=True)   # fused bias gradient of the layer below
+                finally:
+                    ops.DGRAD_GELU_BK = saved
+                bsum = torch.randn(R, device=dev); b0 = bsum.clone()
+                ops.colsum_partials(parts, bsum)
+                assert rel(dxg, pp.grad) < 1e-2 and rel(bsum - b0, pp.grad.sum(0)) < 1e-3
         dW = torch.randn(J, R, device=dev); dW0 = dW.clone()
         ops.linear_wgrad(dy, x, dW)
         assert rel(dW, dW0 + dy.float().t() @ x.float()) < 2e-5        # fp32 accumulate, deterministic
