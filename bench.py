@@ -25,6 +25,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FLOP_PER_SAMPLE = {"small": 99.6e9, "base": 171e9, "tiny": None}      # SURVEY.md §8(d), MIM+MoCo
+WORKLOAD_TEXT = {
+    "mim_moco": "BASELINE configs[2]'s step on this many GPUs: SimMIM (w=1.0) + MoCo-v3 (w=0.1)",
+    "mim_only": "BASELINE configs[1]: loss_weight_contrast=0 (the contrastive forward still runs for the loss_contrast / accuracy meters; "
+                "its backward and the augmented view's encoder backward are exact zeros in the reference and are not launched)",
+}
 PEAK_BF16 = 2.5e15
 PEAK_HBM = 8.0e12                                                      # /opt/skills/guides/MI355X_MICROARCH.md
 
@@ -122,7 +127,11 @@ def main():
     ap.add_argument("--batch", type=int, default=128, help="samples per GPU")
     ap.add_argument("--model", default="small", choices=["tiny", "small", "base"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-mim-only", action="store_true", help="skip the extra BASELINE configs[1] (MIM-only) measurement")
+    ap.add_argument("--no-mim-only", action="store_true", help="skip the extra measurement of the other workload")
+    ap.add_argument("--workload", default="mim_moco", choices=["mim_moco", "mim_only"],
+                    help="headline workload: mim_moco = BASELINE configs[2]'s step (SimMIM + MoCo-v3, the default at every N so that the "
+                         "N=1/2/4/8 series is one workload); mim_only = configs[1] (loss_weight_contrast=0).  The other one is reported "
+                         "in the same JSON line under `mim_only` / `mim_moco`.")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     a = ap.parse_args()
 
@@ -153,8 +162,9 @@ def main():
     force_dist = world > 1 or (os.environ.get("DIG_FORCE_DIST") == "1" and torch.distributed.is_initialized())
     run_model = DistributedDataParallel(model) if force_dist else model
     B = a.batch
+    W_MAIN, W_OTHER = (0.1, 0.0) if a.workload == "mim_moco" else (0.0, 0.1)
     args = types.SimpleNamespace(num_view=2, moco_m=0.99, use_moco_m_cos=1, epochs=10, contrast_start_epoch=0, contrast_warmup_steps=0,
-                                 loss_weight_contrast=0.1, loss_weight_pixel=1.0, only_mim_on_ori_img=True, eval_freq=500, opt='adamw',
+                                 loss_weight_contrast=W_MAIN, loss_weight_pixel=1.0, only_mim_on_ori_img=True, eval_freq=500, opt='adamw',
                                  lr=1.5e-4 * B * world / 256, weight_decay=0.1, opt_eps=1e-8, opt_betas=[0.9, 0.999])
     opt = create_optimizer(args, model)
     scaler = U.NativeScalerWithGradNormCount()
@@ -184,10 +194,10 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
-    # ---- BASELINE configs[1] (MIM-only, loss_weight_contrast = 0) on the same model state: reported beside the headline
+    # ---- the other BASELINE workload on the same model state: reported beside the headline
     mim_only = None
     if not a.no_mim_only:
-        args.loss_weight_contrast = 0.0
+        args.loss_weight_contrast = W_OTHER
         run(2, a.warmup + a.steps)
         if world > 1:
             torch.distributed.barrier()
@@ -202,10 +212,8 @@ def main():
             t = torch.tensor([dt1], device=dev, dtype=torch.float64)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             dt1 = float(t.item())
-        args.loss_weight_contrast = 0.1
-        mim_only = {"workload": "BASELINE configs[1]: same model/batch, loss_weight_contrast=0 (contrastive forward still runs for the "
-                                "loss_contrast/accuracy meters; its backward and the augmented view's encoder backward are exact zeros "
-                                "in the reference and are not launched)",
+        args.loss_weight_contrast = W_MAIN
+        mim_only = {"workload": WORKLOAD_TEXT["mim_only" if a.workload == "mim_moco" else "mim_moco"],
                     "value": a.steps * B * world / dt1, "unit": "images/sec", "ms_per_step": dt1 / a.steps * 1e3, "steps": a.steps}
     # ---- roofline of the dominant kernel: one extra, instrumented step (outside the timed region)
     roof = None
@@ -252,11 +260,11 @@ def main():
     line = {"metric": "pretrain images/sec (32x128, 2-view, mask 0.7) ViT-S/4", "value": value, "unit": "images/sec",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"{model_name}: full train_one_epoch step (SimMIM w=1.0 + MoCo-v3 w=0.1, dim 256, mlp 4096, m 0.99 cos, "
-                                   f"T 0.2, 4 windows, mask 0.7, 2 views, AdamW wd 0.1), {B} samples/GPU, random-init weights",
+            "config": {"workload": f"{model_name}: full train_one_epoch step, {WORKLOAD_TEXT[a.workload]}; dim 256, mlp 4096, m 0.99 cos, "
+                                   f"T 0.2, 4 windows, mask 0.7, 2 views, AdamW wd 0.1, {B} samples/GPU, random-init weights",
                        "global_batch": B * world, "parallelism": f"dp{world}", "loss": float(stats.get("loss", float('nan')))},
             "step_mfma_frac": (value / world * fl / PEAK_BF16) if fl else None,
-            "roofline": roof, "mim_only": mim_only}
+            "roofline": roof, ("mim_only" if a.workload == "mim_moco" else "mim_moco"): mim_only}
     if not a.no_cpu_baseline and world == 1:
         line["cpu_baseline"] = cpu_baseline(model_name, a.cpu_budget)
     print(json.dumps(line), flush=True)
