@@ -175,6 +175,68 @@ __global__ void string_match_kernel(const long long* __restrict__ pred, const lo
   match[b] = ok ? 1 : 0;
 }
 
+// SeqCrossEntropyLoss.forward (loss/seqCrossEntropyLoss.py:47-63): row (b,t) contributes -log_softmax(input[b,t])[target[b,t]]
+// when t < length[b].  One wave per row writes its term; a single block then adds the B*T terms in a fixed order.
+__global__ __launch_bounds__(64) void seq_ce_rows_kernel(const float* __restrict__ input, const long long* __restrict__ target,
+                                                         const long long* __restrict__ length, int T, int C, float* __restrict__ rowloss) {
+  const int row = blockIdx.x, b = row / T, t = row - b * T, lane = threadIdx.x;
+  if (t >= length[b]) {
+    if (lane == 0) rowloss[row] = 0.f;
+    return;
+  }
+  const float* x = input + (size_t)row * C;
+  float m = -INFINITY;
+  for (int c = lane; c < C; c += 64) m = fmaxf(m, x[c]);
+  m = wave_max(m);
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s += __expf(x[c] - m);
+  s = wave_sum(s);
+  if (lane == 0) {
+    long long y = target[row];
+    y = y < 0 ? 0 : (y >= C ? C - 1 : y);
+    rowloss[row] = -(x[y] - m - __logf(s));
+  }
+}
+
+__global__ __launch_bounds__(256) void fixed_order_sum_kernel(const float* __restrict__ v, int n, float scale, float* __restrict__ out) {
+  __shared__ float red[256];
+  float a = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) a += v[i];
+  red[threadIdx.x] = a;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = red[0] * scale;
+}
+
+// recognition_f_measure (evaluation_metric/metrics.py:83-100): per sample, the SETS of kept characters of prediction and target
+// (same cut / drop / case-fold rules as the accuracy; canon codes 1..63 -> one bit each), p = n/(|P|+1e-5), r = n/(|T|+1e-5),
+// f = 2pr/(p+r+1e-5), all in double as the reference's Python floats.
+__global__ void char_fmeasure_kernel(const long long* __restrict__ pred, const long long* __restrict__ target,
+                                     const unsigned char* __restrict__ canon, int n_classes, int eos, int B, int T,
+                                     double* __restrict__ f_out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  unsigned long long ps = 0, ts = 0;
+  for (int i = 0; i < T; ++i) {
+    const long long v = pred[(size_t)b * T + i];
+    if (v == eos) break;
+    const unsigned char c = (v >= 0 && v < n_classes) ? canon[v] : 0;
+    if (c) ps |= 1ull << (c & 63);
+  }
+  for (int i = 0; i < T; ++i) {
+    const long long v = target[(size_t)b * T + i];
+    if (v == eos) break;
+    const unsigned char c = (v >= 0 && v < n_classes) ? canon[v] : 0;
+    if (c) ts |= 1ull << (c & 63);
+  }
+  const double n = (double)__popcll(ps & ts);
+  const double p = n / ((double)__popcll(ps) + 1e-5), r = n / ((double)__popcll(ts) + 1e-5);
+  f_out[b] = 2 * p * r / (p + r + 1e-5);
+}
+
 }  // namespace
 
 // C-ABI: see include/dig_hip.h
@@ -214,5 +276,20 @@ extern "C" int dig_string_match(const long long* pred, const long long* target, 
                                 int B, int T, unsigned char* match, hipStream_t stream) {
   if (!pred || !target || !canon || !match || n_classes <= 0 || B <= 0 || T <= 0) return DIG_ERR_ARG;
   hipLaunchKernelGGL(string_match_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, pred, target, canon, n_classes, eos, B, T, match);
+  return dig_check_launch();
+}
+
+extern "C" int dig_seq_cross_entropy(const float* input, const long long* target, const long long* length, int B, int T, int C,
+                                     float* row_workspace, float* loss, hipStream_t stream) {
+  if (!input || !target || !length || !row_workspace || !loss || B <= 0 || T <= 0 || C <= 0) return DIG_ERR_ARG;
+  hipLaunchKernelGGL(seq_ce_rows_kernel, dim3(B * T), dim3(64), 0, stream, input, target, length, T, C, row_workspace);
+  hipLaunchKernelGGL(fixed_order_sum_kernel, dim3(1), dim3(256), 0, stream, row_workspace, B * T, 1.0f / (float)B, loss);
+  return dig_check_launch();
+}
+
+extern "C" int dig_char_fmeasure(const long long* pred, const long long* target, const unsigned char* canon, int n_classes, int eos,
+                                 int B, int T, double* f_per_sample, hipStream_t stream) {
+  if (!pred || !target || !canon || !f_per_sample || n_classes <= 0 || B <= 0 || T <= 0) return DIG_ERR_ARG;
+  hipLaunchKernelGGL(char_fmeasure_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, pred, target, canon, n_classes, eos, B, T, f_per_sample);
   return dig_check_launch();
 }

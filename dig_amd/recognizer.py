@@ -291,3 +291,28 @@ def accuracy(pred_tokens, target_tokens, voc):
     L.call("dig_string_match", L.ptr(pred_tokens.contiguous()), L.ptr(target_tokens.to(dev).contiguous()), L.ptr(canon), len(voc),
            voc.index("EOS"), B, T, L.ptr(match), L.stream())
     return match.float().mean()
+
+
+def recognition_f_measure(pred_tokens, target_tokens, voc):
+    """`recognition_f_measure` (evaluation_metric/metrics.py:83-100) on device tensors; returns a 0-dim float64 tensor."""
+    B, T = pred_tokens.shape
+    dev = pred_tokens.device
+    f = torch.empty(B, device=dev, dtype=torch.float64)
+    L.call("dig_char_fmeasure", L.ptr(pred_tokens.contiguous()), L.ptr(target_tokens.to(dev).contiguous()), L.ptr(class_canon(voc).to(dev)),
+           len(voc), voc.index("EOS"), B, T, L.ptr(f), L.stream())
+    return f.mean()
+
+
+class SeqCrossEntropyLoss(torch.nn.Module):
+    """loss/seqCrossEntropyLoss.py (sample_normalize): forward(input [B,T,C] fp32, target [B,T], length [B]) -> 0-dim loss.
+    Forward only (evaluation); the training loss with its gradient belongs to row N1."""
+
+    def forward(self, input, target, length):
+        B, T, C = input.shape
+        dev = input.device
+        inp = input.detach().float().contiguous()
+        rows = torch.empty(B * T, device=dev, dtype=F32)
+        loss = torch.empty(1, device=dev, dtype=F32)
+        L.call("dig_seq_cross_entropy", L.ptr(inp), L.ptr(target.to(dev).long().contiguous()), L.ptr(length.to(dev).long().contiguous()), B, T, C,
+               L.ptr(rows), L.ptr(loss), L.stream())
+        return loss[0]

@@ -223,6 +223,13 @@ int dig_softmax_argmax(const float* logits, int ld, float* probs, long long* tok
  * is not a digit or letter), otherwise the same code for upper and lower case; match[b] = 1 when the normalised strings agree. */
 int dig_string_match(const long long* pred, const long long* target, const unsigned char* canon, int n_classes, int eos, int B, int T,
                      unsigned char* match, hipStream_t stream);
+/* SeqCrossEntropyLoss.forward (loss/seqCrossEntropyLoss.py:47-63, sample_normalize): loss[0] = -sum_{b, t < length[b]}
+ * log_softmax(input[b,t,:])[target[b,t]] / B; row_workspace: B*T floats; fixed summation order. */
+int dig_seq_cross_entropy(const float* input, const long long* target, const long long* length, int B, int T, int C,
+                          float* row_workspace, float* loss, hipStream_t stream);
+/* recognition_f_measure (evaluation_metric/metrics.py:83-100) per sample, double precision; same canon table as dig_string_match. */
+int dig_char_fmeasure(const long long* pred, const long long* target, const unsigned char* canon, int n_classes, int eos, int B, int T,
+                      double* f_per_sample, hipStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -246,3 +246,23 @@ def accuracy(pred_tokens, target_tokens, voc):
     """metrics.py:76-81 `Accuracy`: fraction of samples whose normalised strings are equal."""
     p, t = str_list(pred_tokens, voc), str_list(target_tokens, voc)
     return sum(a == b for a, b in zip(p, t)) / len(p)
+
+
+def seq_cross_entropy(inp, target, length):
+    """loss/seqCrossEntropyLoss.py:47-63 with the default sample_normalize=True.  (engine_for_finetuning.evaluate, :249, feeds it
+    the soft-max PROBABILITIES forward_test returns, so in evaluation the log-softmax is taken of probabilities -- kept as is.)"""
+    B, T, C = inp.shape
+    mask = (torch.arange(T)[None, :] < length[:, None]).reshape(-1, 1)
+    lp = F.log_softmax(inp.reshape(-1, C), dim=1)
+    return torch.sum(-lp.gather(1, target.reshape(-1, 1).long()) * mask) / B
+
+
+def recognition_f_measure(pred_tokens, target_tokens, voc):
+    """metrics.py:83-100."""
+    fs = []
+    for pred, targ in zip(str_list(pred_tokens, voc), str_list(target_tokens, voc)):
+        pc, tc = set(pred), set(targ)
+        n = float(sum(1 for ch in pc if ch in tc))
+        p, r = n / (len(pc) + 1e-5), n / (len(tc) + 1e-5)
+        fs.append(2 * p * r / (p + r + 1e-5))
+    return sum(fs) / len(fs)

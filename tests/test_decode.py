@@ -167,3 +167,51 @@ def test_device_string_accuracy_matches_oracle():
     pd, td, cn = torch.from_numpy(pred).to("cuda:0"), torch.from_numpy(targ).to("cuda:0"), class_canon(voc).to("cuda:0")
     L.call("dig_string_match", L.ptr(pd), L.ptr(td), L.ptr(cn), 97, 94, B, T, L.ptr(match), L.stream())
     assert match.cpu().numpy().astype(bool).tolist() == [a == b for a, b in zip(p1, t1)]
+
+
+def test_oracle_seq_ce_and_fmeasure_rules():
+    voc = D.vocabulary()
+    inp = torch.randn(3, 5, 97)
+    tgt = torch.randint(0, 97, (3, 5)); lens = torch.tensor([5, 2, 0])
+    want = sum(-torch.log_softmax(inp[b, t], -1)[tgt[b, t]] for b in range(3) for t in range(int(lens[b]))) / 3
+    assert abs(D.seq_cross_entropy(inp, tgt, lens).item() - want.item()) < 1e-5
+    enc = lambda w, n=8: [voc.index(c) for c in w] + [94] + [95] * (n - len(w) - 1)
+    f = D.recognition_f_measure(np.array([enc("aab"), enc("xyz")]), np.array([enc("ab"), enc("xw")]), voc)
+    assert abs(f - (1.0 * 2 / (2 + 1e-5) * 2 / (2 + 1e-5) * 2 / (2 * 2 / (2 + 1e-5) + 1e-5) + 2 * (1 / (3 + 1e-5)) * (1 / (2 + 1e-5)) / (1 / (3 + 1e-5) + 1 / (2 + 1e-5) + 1e-5)) / 2) < 1e-9
+
+
+@pytest.mark.gpu
+def test_device_evaluate_loop_matches_oracle():
+    """dig_amd.engine_for_finetuning.evaluate (greedy decode + SeqCrossEntropyLoss + Accuracy + recognition_f_measure on the
+    device) against the same quantities computed by the oracle functions from the device's own decode output."""
+    import types
+    from dig_amd.engine_for_finetuning import evaluate
+    _, c = _tiny()
+    ecfg = O.DiGConfig(**O.TINY)
+    P = {**D.det_encoder_state(ecfg, 22), **D.det_decoder_state(c, 21)}
+    m = _tiny_model(c, ecfg, P)
+    voc = D.vocabulary()
+    rng = np.random.RandomState(5)
+    batches = []
+    for i in range(3):
+        B = 6 + i
+        images = O.synthetic_batch(B, ecfg, 300 + i)[0]
+        target = torch.from_numpy(rng.randint(0, 94, size=(B, c.max_seq_len)))
+        lens = torch.from_numpy(rng.randint(1, c.max_seq_len + 1, size=B))
+        for b in range(B):
+            target[b, int(lens[b]) - 1] = 94
+            target[b, int(lens[b]):] = 95
+        batches.append((images, target, lens))
+    loader = types.SimpleNamespace(dataset=types.SimpleNamespace(idx_to_class={i: ch for i, ch in enumerate(voc)}))
+    loader = type("L", (list,), {})(batches); loader.dataset = types.SimpleNamespace(idx_to_class={i: ch for i, ch in enumerate(voc)})
+    stats = evaluate(loader, m, torch.device("cuda:0"), types.SimpleNamespace(beam_width=0))
+    tot = sum(b[0].shape[0] for b in batches)
+    want_loss, want_acc, want_f = [], 0.0, 0.0
+    for images, target, lens in batches:
+        probs = m((images.to("cuda:0"), None, None))[0].cpu()
+        pred = probs.argmax(-1).numpy()
+        want_loss.append(D.seq_cross_entropy(probs, target, lens).item())
+        want_acc += D.accuracy(pred, target.numpy(), voc) * images.shape[0]
+        want_f += D.recognition_f_measure(pred, target.numpy(), voc) * images.shape[0]
+    assert abs(stats["loss"] - np.mean(want_loss)) < 1e-4 * abs(np.mean(want_loss))
+    assert abs(stats["acc"] - want_acc / tot) < 1e-9 and abs(stats["recognition_fmeasure"] - want_f / tot) < 1e-9
