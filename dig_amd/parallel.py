@@ -28,7 +28,10 @@ class DistComm:
 
     def all_gather_cat(self, t):
         out = torch.empty((self.world,) + tuple(t.shape[1:]), device=t.device, dtype=t.dtype)
-        dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
+        if dist.get_backend(self.group) == "gloo":           # (test backend: no all_gather_into_tensor for device tensors)
+            dist.all_gather(list(out.unsqueeze(1).unbind(0)), t.contiguous(), group=self.group)
+        else:
+            dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
         return out
 
     def grad_ready(self, model, key):

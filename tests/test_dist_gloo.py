@@ -132,3 +132,56 @@ def test_multirank_oracle_matches_reference_fixtures(golden_dir):
 
 def test_comm_layer_world2():
     _run(_comm_worker, 2)
+
+
+def _engine_worker(rank, world, port, golden_dir, q):
+    """The PRODUCT engine on `world` ranks sharing one MI355X (gloo moves the device tensors through the host): the same
+    DistComm / bucket / SyncBN / key-gather code that runs over RCCL, checked against the fixtures the unmodified reference
+    produced under world-size-2 DDP."""
+    try:
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from gpu_util import build_model, engine_args
+        from dig_amd.parallel import DistributedDataParallel
+        from dig_amd.optim_factory import create_optimizer
+        from dig_amd.engine_for_pretraining_moco import train_one_epoch
+        from dig_amd.utils import NativeScalerWithGradNormCount
+        g = np.load(os.path.join(golden_dir, f"tiny_w{world}_rank{rank}.npz"))
+        cfg = O.DiGConfig(**O.TINY)
+        seed, B = int(g["seed"]), int(g["B"])
+        hp = O.StepHyper(lr=1e-3)
+        model = build_model(cfg, *O.det_state(cfg, seed))
+        ddp = DistributedDataParallel(model)
+        args = engine_args(hp)
+        opt = create_optimizer(args, model)
+        im, au, mk = O.synthetic_batch(B, cfg, seed * 1000 + rank)
+        st = train_one_epoch(ddp, None, None, [([im, au, mk], torch.ones(1), torch.ones(1))], None, opt, torch.device("cuda:0"), 0,
+                             NativeScalerWithGradNormCount(), None, patch_size=4, normlize_target=False, start_steps=0,
+                             lr_schedule_values=np.full(3, hp.lr), wd_schedule_values=np.full(3, hp.weight_decay), args=args)
+        for k in ("loss_pixel", "loss_contrast", "grad_norm"):                  # per-rank meters of the reference (loss is rank-local too)
+            want = float(g[f"s0/stat/{k}"])
+            assert abs(st[k] - want) <= 3e-2 * abs(want) + 2e-3, (k, st[k], want)
+        grads = {n: p.grad.detach().float().cpu() for n, p in model.named_parameters() if p.requires_grad}
+        names, norms = g["s0/grad_names"].tolist(), g["s0/grad_norms"]
+        tot = float(np.sqrt((norms ** 2).sum()))
+        for i, n in enumerate(names):
+            if norms[i] > 1e-2 * tot:                                            # averaged (DDP) gradients, identical on both ranks
+                assert abs(grads[n].norm().item() / norms[i] - 1) < 8e-2, (n, grads[n].norm().item(), norms[i])
+        flat = model.flat_grads.detach().clone()
+        other = flat.clone()
+        dist.broadcast(other, src=0)
+        assert torch.equal(flat, other)                                          # bit-identical across ranks after the all-reduce
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_engine_two_ranks_on_one_gpu_matches_reference_ddp_fixtures(golden_dir):
+    _run(_engine_worker, 2, golden_dir)
