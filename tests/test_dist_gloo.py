@@ -173,6 +173,19 @@ def _engine_worker(rank, world, port, golden_dir, q):
         other = flat.clone()
         dist.broadcast(other, src=0)
         assert torch.equal(flat, other)                                          # bit-identical across ranks after the all-reduce
+        # data-parallel invariance: `world` ranks x B samples == one process on the rank-major concatenation of the batches
+        # (SyncBN statistics, the key gather with label offsets and the gradient averaging all have to be right for this)
+        if True:                               # (every rank: train_one_epoch ends with a collective on the meters)
+            parts = [O.synthetic_batch(B, cfg, seed * 1000 + r) for r in range(world)]
+            big = tuple(torch.cat([p[i] for p in parts]) for i in range(3))
+            solo = build_model(cfg, *O.det_state(cfg, seed))
+            opt2 = create_optimizer(engine_args(hp), solo)
+            train_one_epoch(solo, None, None, [(list(big), torch.ones(1), torch.ones(1))], None, opt2, torch.device("cuda:0"), 0,
+                            NativeScalerWithGradNormCount(), None, patch_size=4, normlize_target=False, start_steps=0,
+                            lr_schedule_values=np.full(3, hp.lr), wd_schedule_values=np.full(3, hp.weight_decay), args=engine_args(hp))
+            a, b = flat.double(), solo.flat_grads.detach().double()
+            cosv = float((a * b).sum() / (a.norm() * b.norm()))
+            assert cosv > 0.999 and abs(float(a.norm() / b.norm()) - 1) < 1e-2, (cosv, float(a.norm() / b.norm()))
         q.put((rank, "ok"))
     except Exception:  # noqa: BLE001
         import traceback
