@@ -9,7 +9,7 @@ def bench(fn, n=20):
     for _ in range(n): fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t) / n * 1e6
 ROWS = 65536
-def fwd(name, J, R, bks=(64, 244, 448, 422, 424, 423), **kw):
+def fwd(name, J, R, bks=(64, 244, 448), **kw):
     I = kw.pop("rows", ROWS)
     x = torch.randn(I, R, device=dev).bfloat16(); w = torch.randn(J, R, device=dev).bfloat16()
     bias = torch.randn(J, device=dev); res = torch.randn(I, J, device=dev).bfloat16()
