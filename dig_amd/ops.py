@@ -42,24 +42,9 @@ def gemm(A, B, I, J, R, *, ta=False, tb=False, out=None, out_kind=OUT_BF16, bias
 
 
 DGRAD_GELU_BK = 32    # tile of the fc2 dgrad + GELU' + bias-sum GEMM: 128x128/BK32 beats the 256x256 tile inside the step (A/B: 25.9 vs 26.1 ms)
-USE_PANEL = False     # A-resident GEMM (csrc/gemm_panel.hip): correct but slower than the tile kernel at 4 waves/CU -- see DESIGN.md 4
-
-
-def gemm_panel(A, B, I, J, K, *, out=None, out_kind=OUT_BF16, bias=None, resid=None, pre=None, alpha=1.0, alpha_cols=0, act=0):
-    if out is None:
-        out = torch.empty((I, J), device=A.device, dtype=BF16 if out_kind == OUT_BF16 else F32)
-    L.call("dig_gemm_panel_bf16", L.ptr(A), L.ptr(B), L.ptr(out), I, J, K, A.stride(0), B.stride(0), out.stride(0), out_kind,
-           L.ptr(bias), L.ptr(resid), resid.stride(0) if resid is not None else 0, L.ptr(pre), pre.stride(0) if pre is not None else 0,
-           cf(alpha), alpha_cols, act, L.stream())
-    return out
-
-
 def linear_fwd(x, w, *, bias=None, resid=None, act=0, pre=None, alpha=1.0, alpha_cols=0, out=None, out_kind=OUT_BF16):
     """y[rows,out] = x[rows,in] @ w[out,in]^T (+bias)(gelu)(+resid)."""
     K = w.shape[1]
-    if USE_PANEL and K % 128 == 0 and K <= 384 and x.shape[0] >= 1024 and not (pre is not None and resid is not None):
-        return gemm_panel(x, w, x.shape[0], w.shape[0], K, bias=bias, resid=resid, act=act, pre=pre, alpha=alpha,
-                          alpha_cols=alpha_cols, out=out, out_kind=out_kind)
     # tile variant per layer shape, measured on MI355X (profiles/r01_gemm_variants.txt, tools/gpu_bk_probe.py):
     #   tall layers: 256x256 tiles (16 waves) halve the L2->LDS operand traffic per FLOP;  small GELU layers: BK=32,
     #   4 workgroups/CU hide the VALU + double-store epilogue;  everything else: the default 128x128 / BK=64.

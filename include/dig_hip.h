@@ -39,18 +39,16 @@ typedef struct ihipStream_t* hipStream_t;
  *               act 1: store v to pre_act (bf16, optional) then v = gelu_erf(v);  act 2: v *= gelu'(resid[i,j]);
  *               resid (bf16, act != 2): v += resid[i,j]
  *   requirements: J % 8 == 0; lda, ldb, ldc, ldr, ldp % 8 == 0; 16-byte aligned pointers; R % 64 == 0 for a non-transposed
- *   operand; a_rows / b_rows (0 = default) = rows of A / B that exist in memory (rows beyond read as zero); bk in {0,32,64}.
+ *   operand; a_rows / b_rows (0 = default) = rows of A / B that exist in memory (rows beyond read as zero).
+ *   bk selects the tile variant (csrc/gemm.hip): 0/32/64 = 128x128 tile with that K step (33/34: 3-/4-stage ring; 132/164:
+ *   persistent); 2xx/3xx/4xx = multi-wave tiles of gemm_wide_kernel (244 = 256x256, 16 waves, the default for tall layers).
+ *   colsum_partials (act 2 only): [ceil(I/64)][J] fp32 column sums of the result per 64-row group, or null.
  */
 int dig_gemm_bf16(const void* A, const void* B, void* C, int I, int J, int R, int lda, int ldb, int ldc, int trans_a,
                   int trans_b, int out_kind, const float* bias, const void* resid, int ldr, void* pre_act, int ldp, float alpha,
                   int alpha_cols, int act, int splits, int a_rows, int b_rows, int bk, float* colsum_partials,
                   hipStream_t stream);
 int dig_gemm_effective_splits(int R, int splits);
-/* Forward-layout GEMM (trans_a = trans_b = 0, out_kind 0/1) with the 128-row A panel resident in LDS and the weight
- * tiles streamed through a 3-stage ring across N-tiles; same epilogue contract.  K % 128 == 0 and K <= 384, else -4. */
-int dig_gemm_panel_bf16(const void* A, const void* B, void* C, int I, int J, int K, int lda, int ldb, int ldc, int out_kind,
-                        const float* bias, const void* resid, int ldr, void* pre_act, int ldp, float alpha, int alpha_cols,
-                        int act, hipStream_t stream);
 /* out[e] (+)= sum_s partials[s][e], e < n  (deterministic split-R combine; accumulate=1 adds into the gradient arena) */
 int dig_reduce_partials(const float* partials, int splits, long long n, float* out, int accumulate, hipStream_t stream);
 
