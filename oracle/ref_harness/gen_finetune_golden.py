@@ -1,0 +1,134 @@
+"""Golden vectors for the fine-tune training step (row N1, drop rates 0) from the UNMODIFIED reference: the reference encoder /
+TFDecoder classes wired as RecModel.forward does in train mode, the two lines of engine_for_finetuning.train_class_batch, the
+reference SeqCrossEntropyLoss, and
+optim_factory.create_optimizer with LayerDecayValueAssigner (run_class_finetuning.py:471-520).  Asserts oracle/finetune_oracle.py
+== reference (loss, logits, every gradient, parameters after one AdamW step given the same gradients), writes
+tests/golden/finetune_tiny.npz.
+
+    python oracle/ref_harness/gen_finetune_golden.py        # needs /root/reference (build container only)"""
+import os
+import sys
+import types
+from functools import partial
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, HERE)
+import dig_oracle as O
+import decode_oracle as D
+import finetune_oracle as F
+import refenv
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def sample_index(numel, k=8):
+    if numel <= k:
+        return np.arange(numel)
+    return (np.arange(k, dtype=np.int64) * 2654435761 + 12345) % numel
+
+
+class TinyRec(nn.Module):
+    """RecModel (models/model_builder.py:74-160) with the reference's own sub-modules at test widths."""
+
+    def __init__(self, enc, ln, dec):
+        super().__init__()
+        self.encoder, self.decoder, self.linear_norm = enc, dec, ln
+
+    def forward(self, x):
+        x, tgt, tgt_lens = x
+        dec_in = self.linear_norm(self.encoder(x))
+        out, maps = self.decoder(dec_in, dec_in, targets=tgt, tgt_lens=tgt_lens, train_mode=self.training, cls_query_attn_maps=None,
+                                 trg_word_emb=None, beam_width=0)
+        return out, None, None, maps
+
+    def get_num_layers(self):
+        return self.encoder.get_num_layers()
+
+    def no_weight_decay(self):
+        return {'encoder.' + i for i in self.encoder.no_weight_decay()}
+
+
+def main():
+    refenv.setup()
+    torch.manual_seed(0)
+    from models.decoder import TFDecoder
+    import modeling_pretrain_vit as V
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_seq_ce", os.path.join(refenv.REF, "loss", "seqCrossEntropyLoss.py"))
+    ref_ce = importlib.util.module_from_spec(spec); spec.loader.exec_module(ref_ce)      # (the package __init__ pulls unrelated deps)
+    SeqCrossEntropyLoss = ref_ce.SeqCrossEntropyLoss
+    import optim_factory
+    c = D.DecoderConfig(**D.TINY)
+    ecfg = O.DiGConfig(**O.TINY)
+    enc = V.PretrainVisionTransformerEncoder(img_size=(32, 128), patch_size=4, embed_dim=ecfg.embed_dim, depth=ecfg.depth,
+                                             num_heads=ecfg.heads, mlp_ratio=4, qkv_bias=True, norm_layer=partial(nn.LayerNorm, eps=1e-6),
+                                             num_classes=0, drop_rate=0.0, attn_drop_rate=0.0, drop_path_rate=0.0)
+    dec = TFDecoder(n_layers=c.n_layers, d_embedding=c.d_model, n_head=c.n_head, d_k=c.d_k, d_v=c.d_k, d_model=c.d_model, d_inner=c.d_inner,
+                    num_classes=c.num_classes, max_seq_len=c.max_seq_len, dropout=0.0)
+    ln = nn.Sequential(nn.Linear(ecfg.embed_dim, c.d_model), nn.LayerNorm(c.d_model))
+    model = TinyRec(enc, ln, dec).train()
+    P = {**D.det_encoder_state(ecfg, 32), **D.det_decoder_state(c, 31)}
+    sd = model.state_dict()
+    for k, v in P.items():
+        sd[k].copy_(v)
+    B = 6
+    images = O.synthetic_batch(B, ecfg, 555)[0]
+    rng = np.random.RandomState(9)
+    lens = torch.from_numpy(rng.randint(1, c.max_seq_len + 1, size=B))
+    targets = torch.from_numpy(rng.randint(0, 94, size=(B, c.max_seq_len)))
+    for b in range(B):
+        targets[b, int(lens[b]) - 1] = 94
+        targets[b, int(lens[b]):] = 95
+    args = types.SimpleNamespace(use_seq_cls_token=False, opt='adamw', lr=1e-3, weight_decay=0.05, opt_eps=1e-8, opt_betas=None, momentum=0.9)
+    layer_decay = 0.75
+    num_layers = model.get_num_layers()
+    assigner = optim_factory.LayerDecayValueAssigner(list(layer_decay ** (num_layers + 1 - i) for i in range(num_layers + 2)))
+    opt = optim_factory.create_optimizer(args, model, skip_list=model.no_weight_decay(), get_num_layer=assigner.get_layer_id,
+                                         get_layer_scale=assigner.get_scale)
+    for g in opt.param_groups:
+        g["lr"] = args.lr * g["lr_scale"]                                       # what train_one_epoch does each step (:73-78)
+    # engine_for_finetuning.train_class_batch (:26-46; the module itself needs torchvision / editdistance, absent here):
+    outputs, _, _, _ = model((images, targets, lens))
+    loss = SeqCrossEntropyLoss()(outputs, targets, lens)
+    opt.zero_grad()
+    loss.backward()
+    ref_grads = {n: (p.grad.detach().clone() if p.grad is not None else None) for n, p in model.named_parameters()}
+    opt.step()
+    # ---- oracle
+    o_loss, o_grads, o_logits = F.loss_and_grads(P, ecfg, c, images, targets, lens)
+    assert abs(o_loss - loss.item()) < 1e-5 * abs(loss.item()), (o_loss, loss.item())
+    assert (o_logits - outputs.detach()).abs().max() < 2e-5
+    worst = 0.0
+    for n, g in ref_grads.items():
+        if g is None:
+            assert n == "encoder.mask_token", n
+            continue
+        e = (o_grads[n] - g).abs().max().item() / (g.abs().max().item() + 1e-12)
+        worst = max(worst, e)
+        assert e < 2e-3, (n, e)
+    groups = F.param_groups(P, num_layers, layer_decay, args.weight_decay)
+    Pn = {k: v.clone() for k, v in P.items()}
+    F.adamw_step(Pn, {k: (v if v is not None else torch.zeros_like(P[k])) for k, v in ref_grads.items()}, {}, 1, args.lr, groups)
+    sd2 = model.state_dict()
+    for n in Pn:
+        assert (Pn[n] - sd2[n]).abs().max() < 1e-6, n
+    print(f"fine-tune step: oracle == reference (loss {o_loss:.6f}, worst gradient rel-to-max err {worst:.2e}); AdamW + layer decay restatement exact")
+    names = [n for n in P if ref_grads.get(n) is not None]
+    np.savez_compressed(os.path.join(GOLD, "finetune_tiny.npz"), seed_enc=32, seed_dec=31, B=B, batch_seed=555, targets=targets.numpy(),
+                        lens=lens.numpy(), loss=np.float64(loss.item()), logits=outputs.detach().numpy(), lr=args.lr, weight_decay=args.weight_decay,
+                        layer_decay=layer_decay, grad_names=np.array(names),
+                        grad_norms=np.array([ref_grads[n].double().norm().item() for n in names]),
+                        grad_samples=np.stack([np.resize(ref_grads[n].reshape(-1)[sample_index(ref_grads[n].numel())].numpy(), 8) for n in names]),
+                        param_norms=np.array([sd2[n].double().norm().item() for n in names]),
+                        group_scale=np.array([groups[n][0] for n in names]), group_wd=np.array([groups[n][1] for n in names]))
+    print("wrote tests/golden/finetune_tiny.npz")
+
+
+if __name__ == "__main__":
+    main()
