@@ -229,6 +229,25 @@ int dig_seq_cross_entropy(const float* input, const long long* target, const lon
 int dig_char_fmeasure(const long long* pred, const long long* target, const unsigned char* canon, int n_classes, int eos, int B, int T,
                       double* f_per_sample, hipStream_t stream);
 
+/* ---- fine-tune training step (drop rates 0)
+ * Whole-sequence attention of the recognition decoder and its gradient (models/transformer_layer.py:238-281 under teacher forcing,
+ * models/decoder.py:173-222): per (sample, head), Lq <= 32 queries against Lk <= 512 keys, head dim 64, logits = q.k * scale,
+ * mask = (causal ? key <= query : 1) & (lens ? key < lens[sample] : 1).  q / k / v / out rows are (sample, position) with the
+ * given leading dimensions (elements), head h at columns [64h, 64h+64); lse: fp32 [B][heads][Lq]. */
+int dig_seq_attn_fwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out, int ldo, float* lse, int B,
+                     int heads, int Lq, int Lk, float scale, int causal, const long long* lens, hipStream_t stream);
+int dig_seq_attn_bwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* dout, int ldo, const float* lse,
+                     void* dq, int lddq, void* dk, int lddk, void* dv, int lddv, int B, int heads, int Lq, int Lk, float scale, int causal,
+                     const long long* lens, hipStream_t stream);
+/* Token embedding + positional table for whole sequences (decoder.py:173-181) and its (deterministic) gradient into the fp32
+ * embedding-gradient table; gradient of SeqCrossEntropyLoss w.r.t. the logits (bf16 rows of ldd >= C columns, pad columns zero),
+ * scaled by the device scalar *gscalar (null = 1). */
+int dig_seq_embed_fwd(const long long* tokens, const float* emb, const float* pos_table, void* x, int B, int T, int d, int vocab,
+                      hipStream_t stream);
+int dig_seq_embed_bwd(const long long* tokens, const void* dx, float* demb, int n_tok, int d, int vocab, hipStream_t stream);
+int dig_seq_cross_entropy_bwd(const float* logits, int ld, const long long* target, const long long* length, const float* gscalar, int B,
+                              int T, int C, void* dlogits, int ldd, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
