@@ -43,6 +43,42 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   }
 }
 
+// The same update with any number of parameter groups (layer-wise lr decay of the fine-tune recipe, optim_factory.py:33-100 /
+// run_class_finetuning.py:471-520): group_idx[i >> 8] selects (lr, weight_decay) from two small device tables; index 255 marks a
+// granule without a gradient, which is left untouched exactly as the reference's AdamW skips `p.grad is None`.
+__global__ __launch_bounds__(256) void adamw_groups_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                           float* __restrict__ v, bf16_t* __restrict__ shadow, long long n4,
+                                                           const unsigned char* __restrict__ group_idx, const float* __restrict__ lr_tab,
+                                                           const float* __restrict__ wd_tab, float beta1, float beta2, float eps, float inv_bc1,
+                                                           float inv_sqrt_bc2, float grad_scale) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const int grp = group_idx[i >> 6];
+    float4 pp = reinterpret_cast<float4*>(p)[i];
+    float P[4] = {pp.x, pp.y, pp.z, pp.w};
+    if (grp != 255) {
+      const float lr = lr_tab[grp], wd = wd_tab[grp];
+      float4 gg = reinterpret_cast<const float4*>(g)[i];
+      float4 mm = reinterpret_cast<float4*>(m)[i];
+      float4 vv = reinterpret_cast<float4*>(v)[i];
+      float G[4] = {gg.x, gg.y, gg.z, gg.w}, M[4] = {mm.x, mm.y, mm.z, mm.w}, V[4] = {vv.x, vv.y, vv.z, vv.w};
+      const float decay = 1.0f - lr * wd, step_size = lr * inv_bc1;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float gk = G[k] * grad_scale;
+        P[k] *= decay;
+        M[k] = M[k] * beta1 + gk * (1.0f - beta1);
+        V[k] = V[k] * beta2 + gk * gk * (1.0f - beta2);
+        const float denom = sqrtf(V[k]) * inv_sqrt_bc2 + eps;
+        P[k] -= step_size * (M[k] / denom);
+      }
+      reinterpret_cast<float4*>(p)[i] = make_float4(P[0], P[1], P[2], P[3]);
+      reinterpret_cast<float4*>(m)[i] = make_float4(M[0], M[1], M[2], M[3]);
+      reinterpret_cast<float4*>(v)[i] = make_float4(V[0], V[1], V[2], V[3]);
+    }
+    if (shadow) reinterpret_cast<uint2*>(shadow)[i] = make_uint2(pack_bf2(P[0], P[1]), pack_bf2(P[2], P[3]));
+  }
+}
+
 __global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ pm, const float* __restrict__ p, bf16_t* __restrict__ shadow,
                                                   long long n4, float m, float one_minus_m) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
@@ -136,6 +172,18 @@ extern "C" int dig_adamw_step(float* p, const float* g, float* m, float* v, void
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
   hipLaunchKernelGGL(adamw_kernel, dim3(flat_grid(n / 4)), dim3(256), 0, stream, p, g, m, v, (bf16_t*)bf16_shadow, n / 4,
                      group_flags, lr0, wd0, lr1, wd1, beta1, beta2, eps, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)), grad_scale);
+  return dig_check_launch();
+}
+
+extern "C" int dig_adamw_step_groups(float* p, const float* g, float* m, float* v, void* bf16_shadow, long long n,
+                                     const unsigned char* group_idx, const float* lr_tab, const float* wd_tab, float beta1, float beta2,
+                                     float eps, int step, float grad_scale, hipStream_t stream) {
+  if (!p || !g || !m || !v || !group_idx || !lr_tab || !wd_tab || n <= 0 || (n & 255) || step < 1) return DIG_ERR_ARG;
+  if (!aligned16(p) || !aligned16(g) || !aligned16(m) || !aligned16(v) || (bf16_shadow && (((uintptr_t)bf16_shadow) & 7))) return DIG_ERR_ALIGN;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  hipLaunchKernelGGL(adamw_groups_kernel, dim3(flat_grid(n / 4)), dim3(256), 0, stream, p, g, m, v, (bf16_t*)bf16_shadow, n / 4, group_idx,
+                     lr_tab, wd_tab, beta1, beta2, eps, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)), grad_scale);
   return dig_check_launch();
 }
 

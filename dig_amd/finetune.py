@@ -1,0 +1,479 @@
+"""Fine-tune TRAINING step of the recognition model on the MI355X -- SURVEY.md 8(f) row N1, deterministic part.
+
+Mirrors, for `--drop 0 --attn_drop_rate 0 --drop_path 0 --smoothing 0` (anything else raises: the stochastic regularisers are
+not built yet):
+  * `RecModel.forward` in train mode (models/model_builder.py:124-160) -> `TFDecoder.forward_train` (models/decoder.py:196-222):
+    `model((images, targets, tgt_lens))` returns the logits [B, max_len, nb_classes] (+ three Nones, as the reference does);
+  * `SeqCrossEntropyLoss` (loss/seqCrossEntropyLoss.py) with its gradient;
+  * `create_optimizer(args, model, get_num_layer=..., get_layer_scale=...)` (optim_factory.py:33-100, layer-wise lr decay as in
+    run_class_finetuning.py:471-520) as one fused AdamW launch over a flat parameter arena.
+Parameters, gradients, Adam moments and the bf16 GEMM operands live in flat arenas (each tensor padded to 256 elements) whose
+layout keeps q|k|v (and k|v) projection weights adjacent, so the fused projections are views.  The whole model is ONE autograd
+node with a hand-written backward on the hot-path kernels (encoder: the pre-training kernels; decoder: `dig_seq_attn_*`,
+`dig_seq_embed_*`, `dig_gemm_bf16`, `dig_layernorm_*`).  Oracle: oracle/finetune_oracle.py, pinned to the reference."""
+import ctypes
+import math
+from collections import OrderedDict
+
+import torch
+
+from . import _lib as L
+from . import ops
+from .recognizer import RecModel, _encoder_pos, _sinusoid
+
+BF16, F32 = torch.bfloat16, torch.float32
+cf = ctypes.c_float
+CLS_PAD = 128                     # classifier rows padded to a multiple of 64 (it is a non-transposed GEMM operand in backward)
+
+
+def _pad256(n):
+    return (n + 255) // 256 * 256
+
+
+class RecModelTrain(RecModel):
+    """`RecModel` with trainable flat arenas.  `.train()` forward = teacher-forced logits with autograd; `.eval()` = greedy decode."""
+
+    def __init__(self, args=None, **kw):
+        super().__init__(args, **kw)
+        if args is not None:
+            for name in ("drop", "attn_drop_rate", "drop_path"):
+                if getattr(args, name, 0.0):
+                    raise NotImplementedError(f"--{name} > 0 is not built yet (SURVEY.md 8f row N1 covers the deterministic step)")
+        self.comm = None
+        self._dev = None
+        self._offsets = OrderedDict()
+        off = 0
+        for k, s in self.param_shapes().items():
+            n = 1
+            for d_ in s:
+                n *= d_
+            self._offsets[k] = (off, n, tuple(s))
+            off += _pad256(n)
+        self.n_flat = off
+        self.flat_params = torch.zeros(off, dtype=F32)
+        self.flat_grads = torch.zeros(off, dtype=F32)
+        self._shadow = None
+
+    # ------------------------------------------------------------------ state
+    def _view(self, flat, k, dtype_shape=True):
+        o, n, s = self._offsets[k]
+        return flat[o:o + n].view(s)
+
+    def load_state_dict(self, state_dict, strict=True):
+        super().load_state_dict(state_dict, strict)
+        for k in self._offsets:
+            if k in self._sd:
+                self._view(self.flat_params, k).copy_(self._sd[k])
+        self._ready = False
+
+    def state_dict(self, *a, **k):
+        return OrderedDict((n, self._view(self.flat_params, n).detach().cpu().clone()) for n in self._offsets)
+
+    def named_parameters(self, *a, **k):
+        for n in self._offsets:
+            if n == "encoder.mask_token":
+                continue
+            p = self._view(self.flat_params, n)
+            p.grad = self._view(self.flat_grads, n)
+            yield n, p
+
+    def parameters(self, *a, **k):
+        for _, p in self.named_parameters():
+            yield p
+
+    def get_num_layers(self):
+        return self.depth
+
+    def no_weight_decay(self):
+        return {"encoder.pos_embed", "encoder.cls_token"}
+
+    def to(self, device=None, *a, **k):
+        if device is not None:
+            dev = torch.device(device)
+            self.flat_params = self.flat_params.to(dev)
+            self.flat_grads = self.flat_grads.to(dev)
+            self._ready = False
+        return self
+
+    def _prepare_train(self, dev):
+        if self.flat_params.device != dev:
+            self.to(dev)
+        if self._shadow is None or self._shadow.device != dev:
+            self._shadow = torch.empty(self.n_flat, device=dev, dtype=BF16)
+        self._enc_pos = _encoder_pos(self.N, self.D).to(dev).contiguous()
+        self._pos = _sinusoid(self.n_position, self.d).to(dev).contiguous()
+        self._dev = dev
+
+    def refresh_shadow(self):
+        ops.cast_f32_to_bf16(self.flat_params, self._shadow)
+
+    # fused views
+    def _fused(self, flat, first, count):
+        o, n, s = self._offsets[first]
+        return flat[o:o + count * n].view(count * s[0], s[1])
+
+    def sync_eval_weights(self):
+        """Copy the arena back into the inference path's tensors (used by `.eval()` forward / checkpoints)."""
+        for k in self._offsets:
+            self._sd[k] = self._view(self.flat_params, k).detach().clone()
+        self._ready = False
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x):
+        if not self.training:
+            self.sync_eval_weights()
+            return super().forward(x)
+        images, targets, lens = x
+        if not images.is_cuda:
+            raise RuntimeError("dig_amd.RecModelTrain runs on an MI355X (cuda device) only; there is no CPU fallback")
+        if self._dev != images.device or self._shadow is None:
+            self._prepare_train(images.device)
+        anchor = getattr(self, "_anchor", None)
+        if anchor is None or anchor.device != images.device:
+            anchor = self._anchor = torch.zeros(1, device=images.device, requires_grad=True)
+        logits = _RecTrainFn.apply(anchor, self, images, targets.to(images.device), lens.to(images.device))
+        return logits, None, None, None
+
+
+class _TrainStep:
+    """One forward / backward of the model; all activations needed by the backward are kept on this object."""
+
+    def __init__(self, model):
+        self.m = model
+
+    def p(self, name):
+        return self.m._view(self.m.flat_params, name)
+
+    def w(self, name):
+        return self.m._view(self.m._shadow, name)
+
+    def g(self, name):
+        return self.m._view(self.m.flat_grads, name)
+
+    # ---------------------------------------------------------------- forward
+    def forward(self, images, targets, lens):
+        M = self.m
+        dev = images.device
+        M.refresh_shadow()
+        D, H, N = M.D, M.H, M.N
+        B = images.shape[0]
+        T, d, nh, dk = M.max_len, M.d, M.nh, M.dk
+        hk = nh * dk
+        self.B, self.images = B, images.contiguous().float()
+        self.zmask = torch.zeros((B, N), device=dev, dtype=torch.uint8)
+        # ---- encoder (PretrainVisionTransformerEncoder.forward_features, mask=None) -- the pre-training hot-path kernels
+        x = ops.patch_embed_fwd(self.images, self.p("encoder.patch_embed.proj.weight").view(D, 48), self.p("encoder.patch_embed.proj.bias"),
+                                self.zmask, self.p("encoder.mask_token").view(D), M._enc_pos, D, M.gh, M.gw)
+        scale = (D // H) ** -0.5
+        self.enc_saved = []
+        for i in range(M.depth):
+            b = f"encoder.blocks.{i}."
+            qkv_bias = torch.cat([self.p(b + "attn.q_bias"), torch.zeros(D, device=dev), self.p(b + "attn.v_bias")])
+            ln1, mu1, rs1 = ops.layernorm_fwd(x, self.p(b + "norm1.weight"), self.p(b + "norm1.bias"), 1e-6)
+            qkv = ops.linear_fwd(ln1, self.w(b + "attn.qkv.weight"), bias=qkv_bias, alpha=scale, alpha_cols=D)
+            ctx, lse = ops.attn_fwd(qkv, B, H, D)
+            x_mid = ops.linear_fwd(ctx, self.w(b + "attn.proj.weight"), bias=self.p(b + "attn.proj.bias"), resid=x)
+            ln2, mu2, rs2 = ops.layernorm_fwd(x_mid, self.p(b + "norm2.weight"), self.p(b + "norm2.bias"), 1e-6)
+            pre = torch.empty((B * N, M.F), device=dev, dtype=BF16)
+            act = ops.linear_fwd(ln2, self.w(b + "mlp.fc1.weight"), bias=self.p(b + "mlp.fc1.bias"), act=1, pre=pre)
+            x_out = ops.linear_fwd(act, self.w(b + "mlp.fc2.weight"), bias=self.p(b + "mlp.fc2.bias"), resid=x_mid)
+            self.enc_saved.append((x, ln1, mu1, rs1, qkv, ctx, lse, x_mid, ln2, mu2, rs2, pre, act))
+            x = x_out
+        enc, emu, ers = ops.layernorm_fwd(x, self.p("encoder.norm.weight"), self.p("encoder.norm.bias"), 1e-6)
+        self.enc_last = (x, emu, ers, enc)
+        # ---- linear_norm
+        h = ops.linear_fwd(enc, self.w("linear_norm.0.weight"), bias=self.p("linear_norm.0.bias"))
+        mem, mmu, mrs = ops.layernorm_fwd(h, self.p("linear_norm.1.weight"), self.p("linear_norm.1.bias"), 1e-5)
+        self.ln_saved = (h, mmu, mrs, mem)
+        # ---- decoder, teacher forcing (decoder.py:196-222)
+        bos = torch.full((B, 1), M.start_idx, device=dev, dtype=torch.int64)
+        query = torch.cat([bos, targets.long()], dim=-1)[:, :-1].contiguous()
+        self.query, self.targets, self.lens = query, targets.long().contiguous(), lens.long().contiguous()
+        x = torch.empty((B * T, d), device=dev, dtype=BF16)
+        L.call("dig_seq_embed_fwd", L.ptr(query), L.ptr(self.p("decoder.trg_word_emb.weight")), L.ptr(M._pos), L.ptr(x), B, T, d,
+               M.nb_classes + 1, L.stream())
+        sc = dk ** -0.5
+        self.dec_saved = []
+        for i in range(M.n_layers):
+            p = f"decoder.layer_stack.{i}."
+            h1, m1, r1 = ops.layernorm_fwd(x, self.p(p + "norm1.weight"), self.p(p + "norm1.bias"), 1e-5)
+            qkv = ops.linear_fwd(h1, M._fused(M._shadow, p + "self_attn.linear_q.weight", 3))
+            a = torch.empty((B * T, hk), device=dev, dtype=BF16)
+            lse1 = torch.empty((B, nh, T), device=dev, dtype=F32)
+            L.call("dig_seq_attn_fwd", L.ptr(qkv), 3 * hk, L.ptr(qkv[:, hk:]), 3 * hk, L.ptr(qkv[:, 2 * hk:]), 3 * hk, L.ptr(a), hk, L.ptr(lse1),
+                   B, nh, T, T, cf(sc), 1, L.ptr(self.lens), L.stream())
+            x1 = ops.linear_fwd(a, self.w(p + "self_attn.fc.weight"), resid=x)
+            h2, m2, r2 = ops.layernorm_fwd(x1, self.p(p + "norm2.weight"), self.p(p + "norm2.bias"), 1e-5)
+            q2 = ops.linear_fwd(h2, self.w(p + "enc_attn.linear_q.weight"))
+            o2, n2, s2 = M._offsets[p + "enc_attn.linear_k.weight"]
+            wkv = M._shadow[o2:o2 + 2 * n2].view(2 * hk, hk)
+            kvm = ops.linear_fwd(mem, wkv)
+            a2 = torch.empty((B * T, hk), device=dev, dtype=BF16)
+            lse2 = torch.empty((B, nh, T), device=dev, dtype=F32)
+            L.call("dig_seq_attn_fwd", L.ptr(q2), hk, L.ptr(kvm), 2 * hk, L.ptr(kvm[:, hk:]), 2 * hk, L.ptr(a2), hk, L.ptr(lse2), B, nh, T, N,
+                   cf(sc), 0, None, L.stream())
+            x2 = ops.linear_fwd(a2, self.w(p + "enc_attn.fc.weight"), resid=x1)
+            h3, m3, r3 = ops.layernorm_fwd(x2, self.p(p + "norm3.weight"), self.p(p + "norm3.bias"), 1e-5)
+            pre = torch.empty((B * T, M.d_inner), device=dev, dtype=BF16)
+            u = ops.linear_fwd(h3, self.w(p + "mlp.w_1.weight"), bias=self.p(p + "mlp.w_1.bias"), act=1, pre=pre)
+            x3 = ops.linear_fwd(u, self.w(p + "mlp.w_2.weight"), bias=self.p(p + "mlp.w_2.bias"), resid=x2)
+            self.dec_saved.append((x, h1, m1, r1, qkv, a, lse1, x1, h2, m2, r2, q2, kvm, a2, lse2, x2, h3, m3, r3, pre, u))
+            x = x3
+        o, fm, fr = ops.layernorm_fwd(x, self.p("decoder.layer_norm.weight"), self.p("decoder.layer_norm.bias"), 1e-6)
+        self.fin_saved = (x, fm, fr, o)
+        C = M.nb_classes
+        self.cls_w = torch.zeros((CLS_PAD, d), device=dev, dtype=BF16)
+        self.cls_w[:C] = self.w("decoder.classifier.weight")
+        cb = torch.zeros(CLS_PAD, device=dev, dtype=F32)
+        cb[:C] = self.p("decoder.classifier.bias")
+        logits = torch.empty((B * T, CLS_PAD), device=dev, dtype=F32)
+        ops.gemm(o, self.cls_w, B * T, CLS_PAD, d, out=logits, out_kind=ops.OUT_F32, bias=cb)
+        return logits[:, :C].reshape(B, T, C)
+
+    # ---------------------------------------------------------------- backward
+    def backward(self, dlogits_btc):
+        """dlogits_btc: fp32 [B, T, C] gradient w.r.t. the returned logits."""
+        M = self.m
+        dev = dlogits_btc.device
+        B, T, d, nh, dk, C, N, D, H = self.B, M.max_len, M.d, M.nh, M.dk, M.nb_classes, M.N, M.D, M.H
+        hk = nh * dk
+        rows = B * T
+        dl = torch.zeros((rows, CLS_PAD), device=dev, dtype=BF16)
+        dl[:, :C] = dlogits_btc.reshape(rows, C).to(BF16)
+        x, fm, fr, o = self.fin_saved
+        # classifier
+        ops.wgrad(dl, o, self.g("decoder.classifier.weight"), C, d, rows)
+        cs = torch.zeros(CLS_PAD, device=dev, dtype=F32)
+        ops.colsum(dl, cs, cols=CLS_PAD)
+        self.g("decoder.classifier.bias").add_(cs[:C])
+        do = ops.gemm(dl, self.cls_w, rows, d, CLS_PAD, tb=True)
+        dx = ops.layernorm_bwd(do, x, self.p("decoder.layer_norm.weight"), self.p("decoder.layer_norm.bias"), fm, fr, None,
+                               self.g("decoder.layer_norm.weight"), self.g("decoder.layer_norm.bias"))
+        dmem = None
+        sc = dk ** -0.5
+        mem = self.ln_saved[3]
+        for i in reversed(range(M.n_layers)):
+            p = f"decoder.layer_stack.{i}."
+            (x0, h1, m1, r1, qkv, a, lse1, x1, h2, m2, r2, q2, kvm, a2, lse2, x2, h3, m3, r3, pre, u) = self.dec_saved[i]
+            self.dec_saved[i] = None
+            # feed-forward
+            ops.linear_wgrad(dx, u, self.g(p + "mlp.w_2.weight"))
+            ops.colsum(dx, self.g(p + "mlp.w_2.bias"))
+            du, bparts = ops.linear_dgrad(dx, self.w(p + "mlp.w_2.weight"), gelu_pre=pre, colsum=True)
+            ops.colsum_partials(bparts, self.g(p + "mlp.w_1.bias"))
+            ops.linear_wgrad(du, h3, self.g(p + "mlp.w_1.weight"))
+            dh3 = ops.linear_dgrad(du, self.w(p + "mlp.w_1.weight"))
+            dx2 = ops.layernorm_bwd(dh3, x2, self.p(p + "norm3.weight"), self.p(p + "norm3.bias"), m3, r3, dx, self.g(p + "norm3.weight"),
+                                    self.g(p + "norm3.bias"))
+            # cross-attention over the encoder memory
+            ops.linear_wgrad(dx2, a2, self.g(p + "enc_attn.fc.weight"))
+            da2 = ops.linear_dgrad(dx2, self.w(p + "enc_attn.fc.weight"))
+            dq2 = torch.empty_like(q2)
+            dkvm = torch.empty_like(kvm)
+            L.call("dig_seq_attn_bwd", L.ptr(q2), hk, L.ptr(kvm), 2 * hk, L.ptr(kvm[:, hk:]), 2 * hk, L.ptr(da2), hk, L.ptr(lse2), L.ptr(dq2), hk,
+                   L.ptr(dkvm), 2 * hk, L.ptr(dkvm[:, hk:]), 2 * hk, B, nh, T, N, cf(sc), 0, None, L.stream())
+            ops.linear_wgrad(dq2, h2, self.g(p + "enc_attn.linear_q.weight"))
+            dh2 = ops.linear_dgrad(dq2, self.w(p + "enc_attn.linear_q.weight"))
+            o2, n2, _ = M._offsets[p + "enc_attn.linear_k.weight"]
+            ops.linear_wgrad(dkvm, mem, M.flat_grads[o2:o2 + 2 * n2].view(2 * hk, hk))
+            dm = ops.linear_dgrad(dkvm, M._shadow[o2:o2 + 2 * n2].view(2 * hk, hk))
+            if dmem is None:
+                dmem = dm
+            else:
+                ops.add_bf16(dmem, dm, dmem)
+            dx1 = ops.layernorm_bwd(dh2, x1, self.p(p + "norm2.weight"), self.p(p + "norm2.bias"), m2, r2, dx2, self.g(p + "norm2.weight"),
+                                    self.g(p + "norm2.bias"))
+            # masked self-attention
+            ops.linear_wgrad(dx1, a, self.g(p + "self_attn.fc.weight"))
+            da = ops.linear_dgrad(dx1, self.w(p + "self_attn.fc.weight"))
+            dqkv = torch.empty_like(qkv)
+            L.call("dig_seq_attn_bwd", L.ptr(qkv), 3 * hk, L.ptr(qkv[:, hk:]), 3 * hk, L.ptr(qkv[:, 2 * hk:]), 3 * hk, L.ptr(da), hk, L.ptr(lse1),
+                   L.ptr(dqkv), 3 * hk, L.ptr(dqkv[:, hk:]), 3 * hk, L.ptr(dqkv[:, 2 * hk:]), 3 * hk, B, nh, T, T, cf(sc), 1, L.ptr(self.lens),
+                   L.stream())
+            ops.linear_wgrad(dqkv, h1, M._fused(M.flat_grads, p + "self_attn.linear_q.weight", 3))
+            dh1 = ops.linear_dgrad(dqkv, M._fused(M._shadow, p + "self_attn.linear_q.weight", 3))
+            dx = ops.layernorm_bwd(dh1, x0, self.p(p + "norm1.weight"), self.p(p + "norm1.bias"), m1, r1, dx1, self.g(p + "norm1.weight"),
+                                   self.g(p + "norm1.bias"))
+        L.call("dig_seq_embed_bwd", L.ptr(self.query), L.ptr(dx), L.ptr(self.g("decoder.trg_word_emb.weight")), rows, d, C + 1, L.stream())
+        # ---- linear_norm
+        h, mmu, mrs, _ = self.ln_saved
+        x_last, emu, ers, enc = self.enc_last
+        dh = ops.layernorm_bwd(dmem, h, self.p("linear_norm.1.weight"), self.p("linear_norm.1.bias"), mmu, mrs, None, self.g("linear_norm.1.weight"),
+                               self.g("linear_norm.1.bias"))
+        ops.linear_wgrad(dh, enc, self.g("linear_norm.0.weight"))
+        ops.colsum(dh, self.g("linear_norm.0.bias"))
+        denc = ops.linear_dgrad(dh, self.w("linear_norm.0.weight"))
+        dx = ops.layernorm_bwd(denc, x_last, self.p("encoder.norm.weight"), self.p("encoder.norm.bias"), emu, ers, None, self.g("encoder.norm.weight"),
+                               self.g("encoder.norm.bias"))
+        # ---- encoder (same chain as the pre-training backward, one view, no masking)
+        scale = (D // H) ** -0.5
+        for i in reversed(range(M.depth)):
+            b = f"encoder.blocks.{i}."
+            x, ln1, mu1, rs1, qkv, ctx, lse, x_mid, ln2, mu2, rs2, pre, act = self.enc_saved[i]
+            self.enc_saved[i] = None
+            ops.linear_wgrad(dx, act, self.g(b + "mlp.fc2.weight"))
+            dact, bparts = ops.linear_dgrad(dx, self.w(b + "mlp.fc2.weight"), gelu_pre=pre, colsum=True)
+            ops.colsum_partials(bparts, self.g(b + "mlp.fc1.bias"))
+            ops.linear_wgrad(dact, ln2, self.g(b + "mlp.fc1.weight"))
+            dln2 = ops.linear_dgrad(dact, self.w(b + "mlp.fc1.weight"))
+            dx_mid = ops.layernorm_bwd(dln2, x_mid, self.p(b + "norm2.weight"), self.p(b + "norm2.bias"), mu2, rs2, dx, self.g(b + "norm2.weight"),
+                                       self.g(b + "norm2.bias"), out=dln2, dres_colsum=self.g(b + "mlp.fc2.bias"))
+            ops.linear_wgrad(dx_mid, ctx, self.g(b + "attn.proj.weight"))
+            dctx = ops.linear_dgrad(dx_mid, self.w(b + "attn.proj.weight"))
+            dqkv = ops.attn_bwd(qkv, ctx, dctx, lse, self.B, H, D, scale)
+            ops.linear_wgrad(dqkv, ln1, self.g(b + "attn.qkv.weight"))
+            ops.colsum(dqkv, self.g(b + "attn.q_bias"), cols=D)
+            ops.colsum(dqkv[:, 2 * D:], self.g(b + "attn.v_bias"), cols=D)
+            dln1 = ops.linear_dgrad(dqkv, self.w(b + "attn.qkv.weight"), out=dctx)
+            dx = ops.layernorm_bwd(dln1, x, self.p(b + "norm1.weight"), self.p(b + "norm1.bias"), mu1, rs1, dx_mid, self.g(b + "norm1.weight"),
+                                   self.g(b + "norm1.bias"), out=dln1, dres_colsum=self.g(b + "attn.proj.bias"))
+        gtok = torch.zeros(D, device=dev, dtype=F32)                          # mask_token takes no part at fine-tune: gradient discarded
+        ops.patch_embed_bwd_mfma(dx, self.images, self.zmask, self.g("encoder.patch_embed.proj.weight").view(D, 48),
+                                 self.g("encoder.patch_embed.proj.bias"), gtok, D, M.gh, M.gw)
+
+
+class _RecTrainFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, model, images, targets, lens):
+        step = _TrainStep(model)
+        logits = step.forward(images, targets, lens)
+        ctx.step = step
+        return logits
+
+    @staticmethod
+    def backward(ctx, g):
+        step, ctx.step = ctx.step, None
+        step.backward(g.contiguous().float())
+        return None, None, None, None, None
+
+
+class SeqCrossEntropyLoss(torch.nn.Module):
+    """loss/seqCrossEntropyLoss.py (sample_normalize) with its gradient: forward(logits [B,T,C] fp32, target [B,T], length [B])."""
+
+    def forward(self, input, target, length):
+        return _SeqCEFn.apply(input, target.to(input.device).long().contiguous(), length.to(input.device).long().contiguous())
+
+
+class _SeqCEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, length):
+        B, T, C = logits.shape
+        x = logits.detach().float().contiguous()
+        rows = torch.empty(B * T, device=x.device, dtype=F32)
+        loss = torch.empty(1, device=x.device, dtype=F32)
+        L.call("dig_seq_cross_entropy", L.ptr(x), L.ptr(target), L.ptr(length), B, T, C, L.ptr(rows), L.ptr(loss), L.stream())
+        ctx.save_for_backward(x, target, length)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        x, target, length = ctx.saved_tensors
+        B, T, C = x.shape
+        Cp = (C + 7) // 8 * 8
+        dl = torch.empty((B * T, Cp), device=x.device, dtype=BF16)
+        L.call("dig_seq_cross_entropy_bwd", L.ptr(x), C, L.ptr(target), L.ptr(length), L.ptr(g.reshape(1).float().contiguous()), B, T, C, L.ptr(dl),
+               Cp, L.stream())
+        return dl[:, :C].float().reshape(B, T, C), None, None
+
+
+# -------------------------------------------------------------------------------------------------- optimizer
+def get_num_layer_for_vit(var_name, num_max_layer):
+    """optim_factory.py:33-45."""
+    if var_name in ("cls_token", "mask_token", "pos_embed") or var_name.startswith("patch_embed"):
+        return 0
+    if var_name.startswith("rel_pos_bias"):
+        return num_max_layer - 1
+    if var_name.startswith("blocks"):
+        return int(var_name.split('.')[1]) + 1
+    return num_max_layer - 1
+
+
+class LayerDecayValueAssigner:
+    """optim_factory.py:48-57."""
+
+    def __init__(self, values):
+        self.values = values
+
+    def get_scale(self, layer_id):
+        return self.values[layer_id]
+
+    def get_layer_id(self, var_name):
+        return get_num_layer_for_vit(var_name, len(self.values))
+
+
+class FineTuneAdamW:
+    """custom_optim AdamW over `RecModelTrain`'s arena with the reference's parameter groups (get_parameter_groups,
+    optim_factory.py:57-100): `param_groups` carries lr / weight_decay / lr_scale per group exactly as the reference's list does (the
+    engine rewrites lr = schedule * lr_scale and weight_decay every step); the update itself is one launch."""
+
+    def __init__(self, model, lr, weight_decay, betas=(0.9, 0.999), eps=1e-8, get_num_layer=None, get_layer_scale=None, skip_list=()):
+        self.model = model
+        groups = OrderedDict()
+        self._name_group = {}
+        for name, p in model.named_parameters():
+            if p.ndim == 1 or name.endswith(".bias") or name in skip_list:
+                gname, wd = "no_decay", 0.0
+            else:
+                gname, wd = "decay", weight_decay
+            if get_num_layer is not None:
+                lid = get_num_layer(name.replace('encoder.', '') if name.startswith('encoder') else name)
+                gname = "layer_%d_%s" % (lid, gname)
+            else:
+                lid = None
+            if gname not in groups:
+                groups[gname] = {"weight_decay": wd, "names": [], "params": [], "lr_scale": get_layer_scale(lid) if get_layer_scale is not None else 1.0,
+                                 "lr": lr, "betas": betas, "eps": eps}
+            groups[gname]["names"].append(name)
+            groups[gname]["params"].append(p)
+            self._name_group[name] = gname
+        self.param_groups = list(groups.values())
+        self._gnames = list(groups.keys())
+        self._step = 0
+        self.exp_avg = self.exp_avg_sq = None
+        self._tab_dev = None
+
+    def zero_grad(self, set_to_none=False):
+        ops.fill_f32(self.model.flat_grads, 0.0) if self.model.flat_grads.is_cuda else self.model.flat_grads.zero_()
+
+    def _tables(self):
+        M = self.model
+        dev = M.flat_params.device
+        if self._tab_dev == dev:
+            return
+        idx = torch.full((M.n_flat // 256,), 255, dtype=torch.uint8)          # 255 = no gradient (mask_token, padding)
+        for gi, g in enumerate(self.param_groups):
+            for n in g["names"]:
+                o, cnt, _ = M._offsets[n]
+                idx[o // 256:(o + _pad256(cnt)) // 256] = gi
+        self._idx = idx.to(dev)
+        self._host_ring = [torch.empty(2, 256, dtype=F32).pin_memory() for _ in range(8)]   # the host may run steps ahead
+        self._dev_tab = torch.empty(2, 256, device=dev, dtype=F32)
+        self.exp_avg = torch.zeros(M.n_flat, device=dev, dtype=F32)
+        self.exp_avg_sq = torch.zeros(M.n_flat, device=dev, dtype=F32)
+        self._tab_dev = dev
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale: float = 1.0):
+        self._tables()
+        M = self.model
+        ng = len(self.param_groups)
+        assert ng < 255
+        host = self._host_ring[self._step % len(self._host_ring)]
+        for gi, g in enumerate(self.param_groups):                              # whatever the engine wrote into the groups this step
+            host[0, gi] = float(g["lr"])
+            host[1, gi] = float(g["weight_decay"])
+        self._dev_tab.copy_(host, non_blocking=True)
+        g0 = self.param_groups[0]
+        self._step += 1
+        L.call("dig_adamw_step_groups", L.ptr(M.flat_params), L.ptr(M.flat_grads), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq), None,
+               ctypes.c_longlong(M.n_flat), L.ptr(self._idx), L.ptr(self._dev_tab[0]), L.ptr(self._dev_tab[1]), cf(g0["betas"][0]),
+               cf(g0["betas"][1]), cf(g0["eps"]), self._step, cf(grad_scale), L.stream())
+
+
+def create_optimizer(args, model, get_num_layer=None, get_layer_scale=None, filter_bias_and_bn=True, skip_list=None):
+    """optim_factory.create_optimizer for `--opt adamw` on a RecModelTrain."""
+    if args.opt.lower() != "adamw":
+        raise NotImplementedError("only --opt adamw is built")
+    skip = skip_list if skip_list is not None else (model.no_weight_decay() if hasattr(model, "no_weight_decay") else ())
+    betas = tuple(args.opt_betas) if getattr(args, "opt_betas", None) else (0.9, 0.999)
+    return FineTuneAdamW(model, args.lr, args.weight_decay, betas, getattr(args, "opt_eps", 1e-8) or 1e-8, get_num_layer, get_layer_scale, skip)

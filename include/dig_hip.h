@@ -169,6 +169,12 @@ int dig_ce_rows(float* logits, int n, int m, int label_offset, float gscale, flo
 int dig_adamw_step(float* p, const float* g, float* m, float* v, void* bf16_shadow, long long n, const unsigned char* group_flags,
                    float lr0, float wd0, float lr1, float wd1, float beta1, float beta2, float eps, int step, float grad_scale,
                    hipStream_t stream);
+/* Same update with any number of parameter groups (layer-wise lr decay: optim_factory.py:33-100, run_class_finetuning.py:471-520):
+ * group_idx holds one uint8 per 256-element granule indexing the device tables lr_tab / wd_tab; index 255 = granule without a
+ * gradient, left untouched (the reference's AdamW skips p.grad is None). */
+int dig_adamw_step_groups(float* p, const float* g, float* m, float* v, void* bf16_shadow, long long n, const unsigned char* group_idx,
+                          const float* lr_tab, const float* wd_tab, float beta1, float beta2, float eps, int step, float grad_scale,
+                          hipStream_t stream);
 int dig_ema_update(float* pm, const float* p, void* bf16_shadow, long long n, float m, hipStream_t stream);
 long long dig_sumsq_workspace_bytes(long long n);
 int dig_sumsq(const float* x, long long n, float* workspace, float* out, hipStream_t stream);

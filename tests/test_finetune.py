@@ -123,3 +123,62 @@ def test_seq_embedding_and_cross_entropy_kernels_vs_torch():
     rows = torch.empty(B * T, device=dev); out = torch.empty(1, device=dev)
     L.call("dig_seq_cross_entropy", L.ptr(logits[..., :C].contiguous()), L.ptr(tgt), L.ptr(lens), B, T, C, L.ptr(rows), L.ptr(out), L.stream())
     assert abs(out.item() - loss.item()) < 1e-4 * abs(loss.item())
+
+
+def _device_model(c, ecfg, P):
+    from dig_amd.finetune import RecModelTrain
+    m = RecModelTrain(embed_dim=ecfg.embed_dim, depth=ecfg.depth, num_heads=ecfg.heads, n_layers=c.n_layers, d_model=c.d_model, n_head=c.n_head,
+                      d_k=c.d_k, d_inner=c.d_inner, nb_classes=c.num_classes, max_len=c.max_seq_len)
+    m.load_state_dict(P)
+    m.to("cuda:0")
+    return m.train()
+
+
+@pytest.mark.gpu
+def test_device_finetune_step_vs_reference_fixture():
+    """Forward (teacher-forced logits), SeqCrossEntropyLoss, hand-written backward and the layer-decay AdamW step of
+    dig_amd.finetune against the fixture written from the unmodified reference (bf16 kernels: the oracle under CPU bf16 autocast
+    is the noise yardstick for the gradients)."""
+    import types
+    from dig_amd.finetune import SeqCrossEntropyLoss, LayerDecayValueAssigner, create_optimizer
+    g, c, ecfg, P, images, targets, lens = _fixture()
+    m = _device_model(c, ecfg, P)
+    nl, ld = m.get_num_layers(), float(g["layer_decay"])
+    assigner = LayerDecayValueAssigner([ld ** (nl + 1 - i) for i in range(nl + 2)])
+    args = types.SimpleNamespace(opt="adamw", lr=float(g["lr"]), weight_decay=float(g["weight_decay"]), opt_eps=1e-8, opt_betas=None)
+    opt = create_optimizer(args, m, get_num_layer=assigner.get_layer_id, get_layer_scale=assigner.get_scale)
+    for grp in opt.param_groups:
+        grp["lr"] = args.lr * grp["lr_scale"]
+    opt.zero_grad()
+    out = m((images.to("cuda:0"), targets, lens))
+    logits = out[0]
+    loss = SeqCrossEntropyLoss()(logits, targets, lens)
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) < 2e-2 * float(g["loss"])
+    ref_logits = torch.from_numpy(g["logits"])
+    assert ((logits.detach().cpu() - ref_logits).norm() / ref_logits.norm()).item() < 2e-2
+    _, ref_g, _ = F.loss_and_grads(P, ecfg, c, images, targets, lens)
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        _, bf_g, _ = F.loss_and_grads(P, ecfg, c, images, targets, lens)
+    grads = {n: p.grad.detach().float().cpu() for n, p in m.named_parameters()}
+    cos = torch.nn.functional.cosine_similarity
+    names, norms = g["grad_names"].tolist(), g["grad_norms"]
+    tot = float(np.sqrt((norms ** 2).sum()))
+    bad = []
+    for i, n in enumerate(names):
+        if norms[i] < 1e-3 * tot:
+            continue
+        r = ref_g[n].reshape(1, -1)
+        c_hip, c_bf = cos(grads[n].reshape(1, -1), r).item(), cos(bf_g[n].float().reshape(1, -1), r).item()
+        q_hip, q_bf = grads[n].norm().item() / norms[i], bf_g[n].float().norm().item() / norms[i]
+        if (1 - c_hip) > 2 * (1 - c_bf) + 5e-3 or abs(q_hip - 1) > 2 * abs(q_bf - 1) + 3e-2:
+            bad.append((n, c_hip, c_bf, q_hip, q_bf))
+    assert not bad, bad
+    # AdamW with layer decay: feed the reference's own gradients into the device optimizer -> parameters after the step
+    for n, p in m.named_parameters():
+        p.grad.copy_(ref_g[n].to("cuda:0"))
+    opt.step()
+    sd = m.state_dict()
+    for i, n in enumerate(names):
+        assert abs(sd[n].double().norm().item() - g["param_norms"][i]) <= 2e-5 * g["param_norms"][i] + 1e-6, n
+    assert torch.equal(sd["encoder.mask_token"], P["encoder.mask_token"])        # no gradient: untouched, as in the reference
