@@ -135,6 +135,22 @@ class RecModelTrain(RecModel):
         return logits, None, None, None
 
 
+class FlatGradComm:
+    """Data parallelism for the fine-tune step: one all-reduce of the flat gradient arena after the backward (the hook
+    `NativeScalerWithGradNormCount` calls), parameters broadcast from rank 0 at construction -- what DistributedDataParallel does
+    for the reference (run_class_finetuning.py:522-526)."""
+
+    def __init__(self, model, process_group=None):
+        import torch.distributed as dist
+        self.dist, self.group = dist, process_group
+        self.world, self.rank = dist.get_world_size(process_group), dist.get_rank(process_group)
+        dist.broadcast(model.flat_params, src=0, group=process_group)
+
+    def finish_grad_sync(self, model):
+        self.dist.all_reduce(model.flat_grads, group=self.group)
+        ops.scale_f32(model.flat_grads, 1.0 / self.world) if model.flat_grads.is_cuda else model.flat_grads.mul_(1.0 / self.world)
+
+
 class _TrainStep:
     """One forward / backward of the model; all activations needed by the backward are kept on this object."""
 

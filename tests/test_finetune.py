@@ -182,3 +182,53 @@ def test_device_finetune_step_vs_reference_fixture():
     for i, n in enumerate(names):
         assert abs(sd[n].double().norm().item() - g["param_norms"][i]) <= 2e-5 * g["param_norms"][i] + 1e-6, n
     assert torch.equal(sd["encoder.mask_token"], P["encoder.mask_token"])        # no gradient: untouched, as in the reference
+
+
+@pytest.mark.gpu
+def test_device_finetune_engine_loop_vs_oracle():
+    """dig_amd.engine_for_finetuning.train_one_epoch (schedules x lr_scale, gradient accumulation, class accuracy, lagged meters)
+    over 4 micro-batches with update_freq=2, against the oracle running the same two optimizer steps."""
+    import types
+    from dig_amd.finetune import SeqCrossEntropyLoss, LayerDecayValueAssigner, create_optimizer
+    from dig_amd.engine_for_finetuning import train_one_epoch
+    from dig_amd.utils import NativeScalerWithGradNormCount
+    g, c, ecfg, P, _, _, _ = _fixture()
+    m = _device_model(c, ecfg, P)
+    nl, ld, lr, wd = m.get_num_layers(), 0.75, 1e-3, 0.05
+    assigner = LayerDecayValueAssigner([ld ** (nl + 1 - i) for i in range(nl + 2)])
+    args = types.SimpleNamespace(opt="adamw", lr=lr, weight_decay=wd, opt_eps=1e-8, opt_betas=None, eval_freq=1000)
+    opt = create_optimizer(args, m, get_num_layer=assigner.get_layer_id, get_layer_scale=assigner.get_scale)
+    voc = D.vocabulary()
+    rng = np.random.RandomState(3)
+    batches = []
+    for i in range(4):
+        B = 5
+        lens = torch.from_numpy(rng.randint(1, c.max_seq_len + 1, size=B))
+        tg = torch.from_numpy(rng.randint(0, 94, size=(B, c.max_seq_len)))
+        for b in range(B):
+            tg[b, int(lens[b]) - 1] = 94
+            tg[b, int(lens[b]):] = 95
+        batches.append((O.synthetic_batch(B, ecfg, 800 + i)[0], tg, lens))
+    loader = type("Ldr", (list,), {})(batches)
+    loader.dataset = types.SimpleNamespace(idx_to_class={i: ch for i, ch in enumerate(voc)})
+    stats = train_one_epoch(m, SeqCrossEntropyLoss(), loader, opt, torch.device("cuda:0"), 0, NativeScalerWithGradNormCount(), None, None, None,
+                            None, start_steps=0, lr_schedule_values=np.array([lr, 0.5 * lr]), wd_schedule_values=np.array([wd, wd]),
+                            num_training_steps_per_epoch=2, update_freq=2, args=args)
+    # oracle: two optimizer steps, each on the mean gradient of two micro-batches
+    Pn = {k: v.clone() for k, v in P.items()}
+    state, losses = {}, []
+    groups = F.param_groups(Pn, nl, ld, wd)
+    for s in range(2):
+        acc_g = None
+        for mb in batches[2 * s:2 * s + 2]:
+            l, gr, _ = F.loss_and_grads(Pn, ecfg, c, *mb)
+            losses.append(l)
+            acc_g = gr if acc_g is None else {k: acc_g[k] + gr[k] for k in gr}
+        F.adamw_step(Pn, {k: v / 2 for k, v in acc_g.items()}, state, s + 1, [lr, 0.5 * lr][s], groups)
+    assert abs(stats["loss"] - np.mean(losses)) < 3e-2 * np.mean(losses), (stats["loss"], losses)
+    assert 0.0 <= stats["class_acc"] <= 1.0 and stats["lr"] == pytest.approx(0.75 * lr) and opt._step == 2   # meters average over the 4 micro-steps
+    sd = m.state_dict()
+    for n in ("encoder.blocks.0.mlp.fc1.weight", "decoder.layer_stack.1.enc_attn.linear_k.weight", "linear_norm.0.weight", "decoder.trg_word_emb.weight"):
+        d_dev, d_ref = sd[n] - P[n], Pn[n] - P[n]
+        cosv = torch.nn.functional.cosine_similarity(d_dev.reshape(1, -1), d_ref.reshape(1, -1)).item()
+        assert cosv > 0.7 and abs(d_dev.norm().item() / d_ref.norm().item() - 1) < 0.2, (n, cosv)
