@@ -30,51 +30,90 @@ __device__ __forceinline__ bool key_ok(const SeqAttnParams& p, int i, int j, lon
   return (!p.causal || j <= i) && (!p.lens || j < len);
 }
 
-__device__ __forceinline__ void load_kv(const SeqAttnParams& p, int b, int h, bf16_t* Ks, bf16_t* Vs) {
-  for (int e = threadIdx.x; e < p.Lk * (DK / 2); e += blockDim.x) {
-    const int j = e / (DK / 2), c = e - j * (DK / 2);
-    const size_t row = (size_t)b * p.Lk + j;
-    reinterpret_cast<unsigned*>(Ks + j * KROW)[c] = reinterpret_cast<const unsigned*>(p.k + row * p.ldk + h * DK)[c];
-    reinterpret_cast<unsigned*>(Vs + j * KROW)[c] = reinterpret_cast<const unsigned*>(p.v + row * p.ldv + h * DK)[c];
+// Work split.  Score-shaped products (S = Q K^T, dP = dO V^T, dK = dS^T Q, dV = P^T dO): a thread owns ONE key, its K / V rows
+// (or dK / dV accumulators) live in registers and the query-side rows are read from LDS as broadcasts -- pure FMA streams.
+// Output-shaped products (O = P V, dQ = dS K): a thread owns one channel d and every 4th query, K / V come from LDS (bf16,
+// consecutive lanes = consecutive channels) and the probabilities are broadcast reads.
+
+__device__ __forceinline__ void load_row64(const bf16_t* __restrict__ src, float (&r)[DK]) {
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const uint4 v = reinterpret_cast<const uint4*>(src)[c];
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { r[c * 8 + 2 * e] = bf2f((bf16_t)(w[e] & 0xffff)); r[c * 8 + 2 * e + 1] = bf2f((bf16_t)(w[e] >> 16)); }
   }
 }
 
-// S[i][j] = masked logits -> P (unnormalised exp kept with the row max / sum), all in LDS
-__device__ __forceinline__ void scores(const SeqAttnParams& p, long long len, const float* Qs, const bf16_t* Ks, float* S) {
-  for (int e = threadIdx.x; e < p.Lq * p.Lk; e += blockDim.x) {
-    const int i = e / p.Lk, j = e - i * p.Lk;
-    float s = -INFINITY;
-    if (key_ok(p, i, j, len)) {
-      s = 0.f;
-      const float* qr = Qs + i * DK;
-      const bf16_t* kr = Ks + j * KROW;
-#pragma unroll 16
-      for (int d = 0; d < DK; ++d) s += qr[d] * bf2f(kr[d]);
-      s *= p.scale;
+__device__ __forceinline__ void store_row64(bf16_t* __restrict__ dst, const float (&r)[DK], float scale) {
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+    reinterpret_cast<uint4*>(dst)[c] = make_uint4(pack_bf2(r[c * 8] * scale, r[c * 8 + 1] * scale), pack_bf2(r[c * 8 + 2] * scale, r[c * 8 + 3] * scale),
+                                                 pack_bf2(r[c * 8 + 4] * scale, r[c * 8 + 5] * scale), pack_bf2(r[c * 8 + 6] * scale, r[c * 8 + 7] * scale));
+}
+
+__device__ __forceinline__ float dot64(const float* __restrict__ q, const float (&k)[DK]) {
+  float s = 0.f;
+#pragma unroll
+  for (int d4 = 0; d4 < DK / 4; ++d4) {
+    const float4 x = reinterpret_cast<const float4*>(q)[d4];
+    s += x.x * k[4 * d4] + x.y * k[4 * d4 + 1] + x.z * k[4 * d4 + 2] + x.w * k[4 * d4 + 3];
+  }
+  return s;
+}
+
+// stage one [Lk][64] bf16 operand of this (sample, head) into LDS, 16 bytes per thread and step
+__device__ __forceinline__ void stage64(const bf16_t* __restrict__ src, int ld, int b, int h, int Lk, bf16_t* __restrict__ dst) {
+  for (int e = threadIdx.x; e < Lk * 8; e += blockDim.x) {
+    const int j = e >> 3, c = e & 7;
+    reinterpret_cast<uint4*>(dst)[e] = reinterpret_cast<const uint4*>(src + ((size_t)b * Lk + j) * ld + h * DK)[c];
+  }
+}
+
+// out[i][d] = scale_i * sum_j W[i][j] * X[j][d] for the queries i = (tid>>6), +4, ...  (W fp32 [Lq][Lk] in LDS, X bf16 [Lk][64] in LDS)
+template <typename Store>
+__device__ __forceinline__ void rows_times_x(const float* __restrict__ W, const bf16_t* __restrict__ X, int Lq, int Lk, Store store) {
+  const int d = threadIdx.x & 63, g = threadIdx.x >> 6;
+  float acc[MAXQ / 4];
+#pragma unroll
+  for (int u = 0; u < MAXQ / 4; ++u) acc[u] = 0.f;
+  for (int j = 0; j < Lk; ++j) {
+    const float x = bf2f(X[j * DK + d]);
+#pragma unroll
+    for (int u = 0; u < MAXQ / 4; ++u) {
+      const int i = g + 4 * u;
+      if (i < Lq) acc[u] += W[i * Lk + j] * x;
     }
-    S[e] = s;
+  }
+#pragma unroll
+  for (int u = 0; u < MAXQ / 4; ++u) {
+    const int i = g + 4 * u;
+    if (i < Lq) store(i, d, acc[u]);
   }
 }
 
+// LDS: Qs [MAXQ][64] f32 | S [MAXQ][Lk] f32 | rowinv [MAXQ] f32 | Vs [Lk][64] bf16
 __global__ __launch_bounds__(256) void seq_attn_fwd_kernel(SeqAttnParams p, bf16_t* __restrict__ out, int ldo, float* __restrict__ lse) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);
-  bf16_t* Vs = Ks + p.Lk * KROW;
-  float* Qs = reinterpret_cast<float*>(Vs + p.Lk * KROW);
+  float* Qs = reinterpret_cast<float*>(smem);
   float* S = Qs + MAXQ * DK;
   float* rowinv = S + MAXQ * p.Lk;
-  const int b = blockIdx.x, h = blockIdx.y, tid = threadIdx.x;
+  bf16_t* Vs = reinterpret_cast<bf16_t*>(rowinv + MAXQ);
+  const int b = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long long len = p.lens ? p.lens[b] : (long long)p.Lk;
-  load_kv(p, b, h, Ks, Vs);
   for (int e = tid; e < p.Lq * DK; e += blockDim.x) {
     const int i = e / DK, d = e - i * DK;
-    Qs[e] = bf2f(p.q[((size_t)b * p.Lq + i) * p.ldq + h * DK + d]);
+    Qs[e] = bf2f(p.q[((size_t)b * p.Lq + i) * p.ldq + h * DK + d]) * p.scale;
+  }
+  stage64(p.v, p.ldv, b, h, p.Lk, Vs);
+  __syncthreads();
+  for (int j = tid; j < p.Lk; j += 256) {                                // logits of my key against every query
+    float kr[DK];
+    load_row64(p.k + ((size_t)b * p.Lk + j) * p.ldk + h * DK, kr);
+    for (int i = 0; i < p.Lq; ++i) S[i * p.Lk + j] = key_ok(p, i, j, len) ? dot64(Qs + i * DK, kr) : -INFINITY;
   }
   __syncthreads();
-  scores(p, len, Qs, Ks, S);
-  __syncthreads();
-  for (int i = tid >> 6; i < p.Lq; i += 4) {                            // one wave per query row: softmax statistics
-    const int lane = tid & 63;
+  for (int i = wave; i < p.Lq; i += 4) {                                 // one wave per query row: softmax statistics
     float m = -INFINITY;
     for (int j = lane; j < p.Lk; j += 64) m = fmaxf(m, S[i * p.Lk + j]);
     m = wave_max(m);
@@ -91,76 +130,71 @@ __global__ __launch_bounds__(256) void seq_attn_fwd_kernel(SeqAttnParams p, bf16
     }
   }
   __syncthreads();
-  for (int e = tid; e < p.Lq * DK; e += blockDim.x) {
-    const int i = e / DK, d = e - i * DK;
-    float a = 0.f;
-    for (int j = 0; j < p.Lk; ++j) a += S[i * p.Lk + j] * bf2f(Vs[j * KROW + d]);
-    out[((size_t)b * p.Lq + i) * ldo + h * DK + d] = f2bf(a * rowinv[i]);
-  }
+  rows_times_x(S, Vs, p.Lq, p.Lk, [&](int i, int d, float a) { out[((size_t)b * p.Lq + i) * ldo + h * DK + d] = f2bf(a * rowinv[i]); });
 }
 
+// LDS: Qs, Gs [MAXQ][64] f32 | P, dS [MAXQ][Lk] f32 | Ks [Lk][64] bf16
 __global__ __launch_bounds__(256) void seq_attn_bwd_kernel(SeqAttnParams p, const bf16_t* __restrict__ dout, int ldo, const float* __restrict__ lse,
                                                            bf16_t* __restrict__ dq, int lddq, bf16_t* __restrict__ dk, int lddk,
                                                            bf16_t* __restrict__ dv, int lddv) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);
-  bf16_t* Vs = Ks + p.Lk * KROW;
-  float* Qs = reinterpret_cast<float*>(Vs + p.Lk * KROW);
-  float* Gs = Qs + MAXQ * DK;                                           // dO
-  float* P = Gs + MAXQ * DK;                                            // probabilities
-  float* dS = P + MAXQ * p.Lk;                                          // dP, then dS
-  const int b = blockIdx.x, h = blockIdx.y, tid = threadIdx.x;
+  float* Qs = reinterpret_cast<float*>(smem);
+  float* Gs = Qs + MAXQ * DK;
+  float* P = Gs + MAXQ * DK;
+  float* dS = P + MAXQ * p.Lk;
+  bf16_t* Ks = reinterpret_cast<bf16_t*>(dS + MAXQ * p.Lk);
+  const int b = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long long len = p.lens ? p.lens[b] : (long long)p.Lk;
-  load_kv(p, b, h, Ks, Vs);
+  const float* lse_row = lse + ((size_t)b * gridDim.y + h) * p.Lq;
   for (int e = tid; e < p.Lq * DK; e += blockDim.x) {
     const int i = e / DK, d = e - i * DK;
     const size_t r = (size_t)b * p.Lq + i;
     Qs[e] = bf2f(p.q[r * p.ldq + h * DK + d]);
     Gs[e] = bf2f(dout[r * ldo + h * DK + d]);
   }
+  stage64(p.k, p.ldk, b, h, p.Lk, Ks);
   __syncthreads();
-  scores(p, len, Qs, Ks, P);
-  __syncthreads();
-  for (int e = tid; e < p.Lq * p.Lk; e += blockDim.x) {                 // P = exp(S - lse);  dP = dO . V
-    const int i = e / p.Lk, j = e - i * p.Lk;
-    const float s = P[e];
-    float pr = 0.f, dp = 0.f;
-    if (s != -INFINITY) {
-      pr = __expf(s - lse[((size_t)b * gridDim.y + h) * p.Lq + i]);
-      const float* gr = Gs + i * DK;
-      const bf16_t* vr = Vs + j * KROW;
-#pragma unroll 16
-      for (int d = 0; d < DK; ++d) dp += gr[d] * bf2f(vr[d]);
+  for (int j = tid; j < p.Lk; j += 256) {                                // my key: P[:, j] and dP[:, j]
+    float kr[DK], vr[DK];
+    load_row64(p.k + ((size_t)b * p.Lk + j) * p.ldk + h * DK, kr);
+    load_row64(p.v + ((size_t)b * p.Lk + j) * p.ldv + h * DK, vr);
+    for (int i = 0; i < p.Lq; ++i) {
+      float pr = 0.f, dp = 0.f;
+      if (key_ok(p, i, j, len)) {
+        pr = __expf(dot64(Qs + i * DK, kr) * p.scale - lse_row[i]);
+        dp = dot64(Gs + i * DK, vr);
+      }
+      P[i * p.Lk + j] = pr;
+      dS[i * p.Lk + j] = dp;
     }
-    P[e] = pr;
-    dS[e] = dp;
   }
   __syncthreads();
-  for (int i = tid >> 6; i < p.Lq; i += 4) {                            // dS = P * (dP - sum_j P dP)
-    const int lane = tid & 63;
+  for (int i = wave; i < p.Lq; i += 4) {                                 // dS = P * (dP - sum_j P dP)
     float del = 0.f;
     for (int j = lane; j < p.Lk; j += 64) del += P[i * p.Lk + j] * dS[i * p.Lk + j];
     del = wave_sum(del);
     for (int j = lane; j < p.Lk; j += 64) dS[i * p.Lk + j] = P[i * p.Lk + j] * (dS[i * p.Lk + j] - del);
   }
   __syncthreads();
-  for (int e = tid; e < p.Lq * DK; e += blockDim.x) {                   // dQ = scale * dS K
-    const int i = e / DK, d = e - i * DK;
-    float a = 0.f;
-    for (int j = 0; j < p.Lk; ++j) a += dS[i * p.Lk + j] * bf2f(Ks[j * KROW + d]);
-    dq[((size_t)b * p.Lq + i) * lddq + h * DK + d] = f2bf(a * p.scale);
-  }
-  for (int e = tid; e < p.Lk * DK; e += blockDim.x) {                   // dK = scale * dS^T Q ;  dV = P^T dO
-    const int j = e / DK, d = e - j * DK;
-    float ak = 0.f, av = 0.f;
+  for (int j = tid; j < p.Lk; j += 256) {                                // my key: dK[j, :] = scale * sum_i dS[i,j] Q[i,:], dV[j, :] = sum_i P[i,j] dO[i,:]
+    float ak[DK], av[DK];
+#pragma unroll
+    for (int d = 0; d < DK; ++d) { ak[d] = 0.f; av[d] = 0.f; }
     for (int i = 0; i < p.Lq; ++i) {
-      ak += dS[i * p.Lk + j] * Qs[i * DK + d];
-      av += P[i * p.Lk + j] * Gs[i * DK + d];
+      const float ds = dS[i * p.Lk + j], pr = P[i * p.Lk + j];
+#pragma unroll
+      for (int d4 = 0; d4 < DK / 4; ++d4) {
+        const float4 qv = reinterpret_cast<const float4*>(Qs + i * DK)[d4];
+        const float4 gv = reinterpret_cast<const float4*>(Gs + i * DK)[d4];
+        ak[4 * d4] += ds * qv.x; ak[4 * d4 + 1] += ds * qv.y; ak[4 * d4 + 2] += ds * qv.z; ak[4 * d4 + 3] += ds * qv.w;
+        av[4 * d4] += pr * gv.x; av[4 * d4 + 1] += pr * gv.y; av[4 * d4 + 2] += pr * gv.z; av[4 * d4 + 3] += pr * gv.w;
+      }
     }
     const size_t r = (size_t)b * p.Lk + j;
-    dk[r * lddk + h * DK + d] = f2bf(ak * p.scale);
-    dv[r * lddv + h * DK + d] = f2bf(av);
+    store_row64(dk + r * lddk + h * DK, ak, p.scale);
+    store_row64(dv + r * lddv + h * DK, av, 1.f);
   }
+  rows_times_x(dS, Ks, p.Lq, p.Lk, [&](int i, int d, float a) { dq[((size_t)b * p.Lq + i) * lddq + h * DK + d] = f2bf(a * p.scale); });
 }
 
 // x[b*T + t, :] = emb[token[b, t], :] + pos[t, :]   (decoder.py:173-181: trg_word_emb + PositionalEncoding; dropout p = 0)
@@ -175,15 +209,36 @@ __global__ __launch_bounds__(256) void seq_embed_fwd_kernel(const long long* __r
   x[i] = f2bf(emb[(size_t)t * d + c] + pos[(size_t)(r % T) * d + c]);
 }
 
-// demb[v, :] += sum over the tokens equal to v of dx[token row, :]; one block per vocabulary row, fixed scan order (deterministic)
+// demb[v, :] += sum over the tokens equal to v of dx[token row, :].  One block per vocabulary row: the matching token rows are
+// first collected IN ORDER (ballot + prefix per 256-token chunk), then every thread sums its channels over that list -- a fixed
+// summation order (deterministic) without scanning the whole token list once per channel.
 __global__ __launch_bounds__(256) void seq_embed_bwd_kernel(const long long* __restrict__ tok, const bf16_t* __restrict__ dx,
                                                             float* __restrict__ demb, int n_tok, int d) {
-  const int v = blockIdx.x;
-  for (int c = threadIdx.x; c < d; c += blockDim.x) {
+  extern __shared__ int list[];                                         // [n_tok] matching rows, ascending
+  __shared__ int wcount[4];
+  __shared__ int total;
+  const int v = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) total = 0;
+  __syncthreads();
+  for (int r0 = 0; r0 < n_tok; r0 += 256) {
+    const int r = r0 + tid;
+    const bool hit = r < n_tok && tok[r] == v;
+    const unsigned long long bal = __ballot(hit);
+    if (lane == 0) wcount[wave] = __popcll(bal);
+    __syncthreads();
+    int base = total;
+    for (int w = 0; w < wave; ++w) base += wcount[w];
+    if (hit) list[base + __popcll(bal & ((1ull << lane) - 1ull))] = r;
+    __syncthreads();
+    if (tid == 0) total += wcount[0] + wcount[1] + wcount[2] + wcount[3];
+    __syncthreads();
+  }
+  const int n = total;
+  if (n == 0) return;
+  for (int c = tid; c < d; c += 256) {
     float a = 0.f;
-    for (int r = 0; r < n_tok; ++r)
-      if (tok[r] == v) a += bf2f(dx[(size_t)r * d + c]);
-    if (a != 0.f) demb[(size_t)v * d + c] += a;
+    for (int k = 0; k < n; ++k) a += bf2f(dx[(size_t)list[k] * d + c]);
+    demb[(size_t)v * d + c] += a;
   }
 }
 
@@ -210,8 +265,8 @@ __global__ __launch_bounds__(64) void seq_ce_bwd_kernel(const float* __restrict_
   for (int c = lane; c < ldd; c += 64) out[c] = c < C ? f2bf(sc * (__expf(x[c] - m) * inv - (c == y ? 1.f : 0.f))) : (bf16_t)0;
 }
 
-size_t lds_fwd(int Lk) { return (size_t)2 * Lk * KROW * 2 + (size_t)MAXQ * DK * 4 + (size_t)MAXQ * Lk * 4 + MAXQ * 4; }
-size_t lds_bwd(int Lk) { return (size_t)2 * Lk * KROW * 2 + (size_t)2 * MAXQ * DK * 4 + (size_t)2 * MAXQ * Lk * 4; }
+size_t lds_fwd(int Lk) { return (size_t)MAXQ * DK * 4 + (size_t)MAXQ * Lk * 4 + MAXQ * 4 + (size_t)Lk * DK * 2; }
+size_t lds_bwd(int Lk) { return (size_t)2 * MAXQ * DK * 4 + (size_t)2 * MAXQ * Lk * 4 + (size_t)Lk * DK * 2; }
 
 }  // namespace
 
@@ -219,7 +274,7 @@ size_t lds_bwd(int Lk) { return (size_t)2 * Lk * KROW * 2 + (size_t)2 * MAXQ * D
 extern "C" int dig_seq_attn_fwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out, int ldo, float* lse, int B,
                                 int heads, int Lq, int Lk, float scale, int causal, const long long* lens, hipStream_t stream) {
   if (!q || !k || !v || !out || !lse || B <= 0 || heads <= 0 || Lq <= 0 || Lq > MAXQ || Lk <= 0 || Lk > 512) return DIG_ERR_ARG;
-  if ((ldk & 1) || (ldv & 1)) return DIG_ERR_ALIGN;
+  if ((ldk & 7) || (ldv & 7) || !aligned16(k) || !aligned16(v)) return DIG_ERR_ALIGN;   // 16-byte row reads
   SeqAttnParams p{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldq, ldk, ldv, Lq, Lk, scale, causal, lens};
   const size_t lds = lds_fwd(Lk);
   static size_t attr = 0;
@@ -232,7 +287,7 @@ extern "C" int dig_seq_attn_bwd(const void* q, int ldq, const void* k, int ldk, 
                                 const float* lse, void* dq, int lddq, void* dk, int lddk, void* dv, int lddv, int B, int heads, int Lq, int Lk,
                                 float scale, int causal, const long long* lens, hipStream_t stream) {
   if (!q || !k || !v || !dout || !lse || !dq || !dk || !dv || B <= 0 || heads <= 0 || Lq <= 0 || Lq > MAXQ || Lk <= 0 || Lk > 512) return DIG_ERR_ARG;
-  if ((ldk & 1) || (ldv & 1)) return DIG_ERR_ALIGN;
+  if ((ldk & 7) || (ldv & 7) || !aligned16(k) || !aligned16(v)) return DIG_ERR_ALIGN;   // 16-byte row reads
   SeqAttnParams p{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldq, ldk, ldv, Lq, Lk, scale, causal, lens};
   const size_t lds = lds_bwd(Lk);
   static size_t attr = 0;
@@ -252,7 +307,8 @@ extern "C" int dig_seq_embed_fwd(const long long* tokens, const float* emb, cons
 
 extern "C" int dig_seq_embed_bwd(const long long* tokens, const void* dx, float* demb, int n_tok, int d, int vocab, hipStream_t stream) {
   if (!tokens || !dx || !demb || n_tok <= 0 || d <= 0 || vocab <= 0) return DIG_ERR_ARG;
-  hipLaunchKernelGGL(seq_embed_bwd_kernel, dim3(vocab), dim3(256), 0, stream, tokens, (const bf16_t*)dx, demb, n_tok, d);
+  if ((size_t)n_tok * sizeof(int) > 60 * 1024) return DIG_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(seq_embed_bwd_kernel, dim3(vocab), dim3(256), (size_t)n_tok * sizeof(int), stream, tokens, (const bf16_t*)dx, demb, n_tok, d);
   return dig_check_launch();
 }
 
