@@ -53,13 +53,13 @@ __device__ __forceinline__ void store_row64(bf16_t* __restrict__ dst, const floa
 }
 
 __device__ __forceinline__ float dot64(const float* __restrict__ q, const float (&k)[DK]) {
-  float s = 0.f;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;                        // four independent chains (a single one is latency-bound)
 #pragma unroll
   for (int d4 = 0; d4 < DK / 4; ++d4) {
     const float4 x = reinterpret_cast<const float4*>(q)[d4];
-    s += x.x * k[4 * d4] + x.y * k[4 * d4 + 1] + x.z * k[4 * d4 + 2] + x.w * k[4 * d4 + 3];
+    s0 += x.x * k[4 * d4]; s1 += x.y * k[4 * d4 + 1]; s2 += x.z * k[4 * d4 + 2]; s3 += x.w * k[4 * d4 + 3];
   }
-  return s;
+  return (s0 + s1) + (s2 + s3);
 }
 
 // stage one [Lk][64] bf16 operand of this (sample, head) into LDS, 16 bytes per thread and step

@@ -223,11 +223,25 @@ class _TrainStep:
             q2 = ops.linear_fwd(h2, self.w(p + "enc_attn.linear_q.weight"))
             o2, n2, s2 = M._offsets[p + "enc_attn.linear_k.weight"]
             wkv = M._shadow[o2:o2 + 2 * n2].view(2 * hk, hk)
-            kvm = ops.linear_fwd(mem, wkv)
-            a2 = torch.empty((B * T, hk), device=dev, dtype=BF16)
-            lse2 = torch.empty((B, nh, T), device=dev, dtype=F32)
-            L.call("dig_seq_attn_fwd", L.ptr(q2), hk, L.ptr(kvm), 2 * hk, L.ptr(kvm[:, hk:]), 2 * hk, L.ptr(a2), hk, L.ptr(lse2), B, nh, T, N,
-                   cf(sc), 0, None, L.stream())
+            if N == 256 and dk == 64:
+                # cross-attention on the MFMA kernel of the encoder (256 keys, head dim 64): the T queries of a sample are padded
+                # to 256 rows of a fused q|k|v buffer.  Zero queries cost MFMA time but no new kernel; their output rows are
+                # dropped and, with a zero output gradient, contribute nothing in backward.  Measured 4x faster than the FMA
+                # kernel at 25 x 256 (tools/gpu_seqattn_probe.py).
+                fused = torch.empty((B * N, 3 * hk), device=dev, dtype=BF16)
+                ops.gemm(mem, wkv, B * N, 2 * hk, d, out=fused[:, hk:], ldc=3 * hk)
+                fq = fused.view(B, N, 3 * hk)[:, :, :hk]
+                fq[:, T:].zero_()
+                fq[:, :T] = (q2 * sc).view(B, T, hk)                              # sc = 2^-3: exact in bf16
+                ctx2, lse2 = ops.attn_fwd(fused, B, nh, hk)
+                a2 = ctx2.view(B, N, hk)[:, :T].reshape(B * T, hk)
+                kvm, lse2 = fused, (lse2, ctx2)
+            else:
+                kvm = ops.linear_fwd(mem, wkv)
+                a2 = torch.empty((B * T, hk), device=dev, dtype=BF16)
+                lse2 = torch.empty((B, nh, T), device=dev, dtype=F32)
+                L.call("dig_seq_attn_fwd", L.ptr(q2), hk, L.ptr(kvm), 2 * hk, L.ptr(kvm[:, hk:]), 2 * hk, L.ptr(a2), hk, L.ptr(lse2), B, nh, T, N,
+                       cf(sc), 0, None, L.stream())
             x2 = ops.linear_fwd(a2, self.w(p + "enc_attn.fc.weight"), resid=x1)
             h3, m3, r3 = ops.layernorm_fwd(x2, self.p(p + "norm3.weight"), self.p(p + "norm3.bias"), 1e-5)
             pre = torch.empty((B * T, M.d_inner), device=dev, dtype=BF16)
@@ -284,15 +298,23 @@ class _TrainStep:
             # cross-attention over the encoder memory
             ops.linear_wgrad(dx2, a2, self.g(p + "enc_attn.fc.weight"))
             da2 = ops.linear_dgrad(dx2, self.w(p + "enc_attn.fc.weight"))
-            dq2 = torch.empty_like(q2)
-            dkvm = torch.empty_like(kvm)
-            L.call("dig_seq_attn_bwd", L.ptr(q2), hk, L.ptr(kvm), 2 * hk, L.ptr(kvm[:, hk:]), 2 * hk, L.ptr(da2), hk, L.ptr(lse2), L.ptr(dq2), hk,
-                   L.ptr(dkvm), 2 * hk, L.ptr(dkvm[:, hk:]), 2 * hk, B, nh, T, N, cf(sc), 0, None, L.stream())
+            o2, n2, _ = M._offsets[p + "enc_attn.linear_k.weight"]
+            if isinstance(lse2, tuple):                                           # MFMA path (see forward)
+                lse2, ctx2 = lse2                                                 # padded rows: finite outputs, zero dO -> delta = 0
+                dctx2 = torch.zeros((B * N, hk), device=dev, dtype=BF16)
+                dctx2.view(B, N, hk)[:, :T] = da2.view(B, T, hk)
+                dfused = ops.attn_bwd(kvm, ctx2, dctx2, lse2, B, nh, hk, sc)      # kvm = the fused q|k|v buffer
+                dq2 = dfused.view(B, N, 3 * hk)[:, :T, :hk].reshape(B * T, hk)
+                dkvm = dfused[:, hk:]                                             # [B*N, 2hk] view, row stride 3hk
+            else:
+                dq2 = torch.empty_like(q2)
+                dkvm = torch.empty_like(kvm)
+                L.call("dig_seq_attn_bwd", L.ptr(q2), hk, L.ptr(kvm), 2 * hk, L.ptr(kvm[:, hk:]), 2 * hk, L.ptr(da2), hk, L.ptr(lse2), L.ptr(dq2),
+                       hk, L.ptr(dkvm), 2 * hk, L.ptr(dkvm[:, hk:]), 2 * hk, B, nh, T, N, cf(sc), 0, None, L.stream())
             ops.linear_wgrad(dq2, h2, self.g(p + "enc_attn.linear_q.weight"))
             dh2 = ops.linear_dgrad(dq2, self.w(p + "enc_attn.linear_q.weight"))
-            o2, n2, _ = M._offsets[p + "enc_attn.linear_k.weight"]
-            ops.linear_wgrad(dkvm, mem, M.flat_grads[o2:o2 + 2 * n2].view(2 * hk, hk))
-            dm = ops.linear_dgrad(dkvm, M._shadow[o2:o2 + 2 * n2].view(2 * hk, hk))
+            ops.wgrad(dkvm, mem, M.flat_grads[o2:o2 + 2 * n2].view(2 * hk, hk), 2 * hk, hk, B * N)
+            dm = ops.gemm(dkvm, M._shadow[o2:o2 + 2 * n2].view(2 * hk, hk), B * N, hk, 2 * hk, tb=True)
             if dmem is None:
                 dmem = dm
             else:
