@@ -75,8 +75,12 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& a, int u) {
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
+// DROP: attention dropout (Attention.attn_drop, modeling_finetune.py:116 / MultiHeadAttention.attn_drop,
+// transformer_layer.py:271): the probabilities are normalised by the FULL row sum, then masked and scaled by 1/(1-p); the mask
+// comes from dig_drop_keep(key, (query << 16) | key_index, image * H + head) and is regenerated in the backward.
+template <bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
-                                                          float* __restrict__ lse, int D, int H, unsigned qkv_bytes) {
+                                                          float* __restrict__ lse, int D, int H, unsigned qkv_bytes, dig_dropout_t drop) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* Kt = smem;
   unsigned char* Vt = smem + TILE;
@@ -130,6 +134,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
         l += p;
       }
     l += __shfl_xor(l, 32, 64);
+    if (DROP) {
+      const unsigned qa = (unsigned)(qb * 32 + (lane & 31)) << 16;
+#pragma unroll
+      for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const unsigned key = kt * 32 + 8 * (e >> 2) + 4 * hi + (e & 3);
+          if (!dig_drop_keep(drop.k0, drop.k1, qa | key, blockIdx.x, drop.thr)) sc[kt][e] = 0.f;
+        }
+    }
     f32x16 oa[2];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -145,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
           oa[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Vt, kt * 32 + u * 16, dt * 32, lane), pf, oa[dt], 0, 0, 0);
       }
     }
-    const float inv = 1.0f / l;
+    const float inv = (DROP ? drop.scale : 1.0f) / l;
     const int q = qb * 32 + (lane & 31);
     bf16_t* op = ctx + (tok0 + q) * D + h * DH;
 #pragma unroll
@@ -202,10 +216,12 @@ __device__ __forceinline__ void wave_colsum(const f32x16 (&acc)[2], float* out, 
     }
 }
 
+template <bool DROP>
 __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ ctx,
                                                           const bf16_t* __restrict__ dctx, const float* __restrict__ lse,
                                                           bf16_t* __restrict__ dqkv, int D, int H, float scale,
-                                                          unsigned qkv_bytes, unsigned ctx_bytes, float* __restrict__ qsum, float* __restrict__ vsum) {
+                                                          unsigned qkv_bytes, unsigned ctx_bytes, float* __restrict__ qsum, float* __restrict__ vsum,
+                                                          dig_dropout_t drop) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* Qt = smem;
   unsigned char* Kt = smem + TILE;
@@ -298,7 +314,14 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(const bf16_t* __restri
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int e = 0; e < 16; ++e) st[e] = __expf(st[e] - my_lse) * (dp[e] - my_del);   // dS^T
+      for (int e = 0; e < 16; ++e) {
+        float g = dp[e];
+        if (DROP) {                                                        // dP = mask * (dO V^T) / (1 - p)
+          const unsigned key = kt * 32 + 8 * (e >> 2) + 4 * hi + (e & 3);
+          g = dig_drop_keep(drop.k0, drop.k1, ((unsigned)q << 16) | key, blockIdx.x, drop.thr) ? g * drop.scale : 0.f;
+        }
+        st[e] = __expf(st[e] - my_lse) * (g - my_del);                     // dS^T
+      }
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const bf16x8 ds = pack8(st, u);
@@ -377,8 +400,13 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(const bf16_t* __restri
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float p = __expf(st[g * 4 + e] - ls[g][e]);
-          st[g * 4 + e] = p;
-          dp[g * 4 + e] = p * (dp[g * 4 + e] - dl[g][e]);
+          float m = 1.f;
+          if (DROP) {
+            const unsigned qi = qt * 32 + 8 * g + 4 * hi + e;
+            m = dig_drop_keep(drop.k0, drop.k1, (qi << 16) | (unsigned)key, blockIdx.x, drop.thr) ? drop.scale : 0.f;
+          }
+          st[g * 4 + e] = p * m;                                          // dropped probabilities (for dV)
+          dp[g * 4 + e] = p * (dp[g * 4 + e] * m - dl[g][e]);
         }
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
@@ -411,24 +439,34 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(const bf16_t* __restri
 
 }  // namespace
 
-extern "C" int dig_attn_fwd(const void* qkv, void* ctx, float* lse, int n_img, int heads, int embed_dim,
-                            hipStream_t stream) {
+extern "C" int dig_attn_fwd_dropout(const void* qkv, void* ctx, float* lse, int n_img, int heads, int embed_dim,
+                                    const dig_dropout_t* drop, hipStream_t stream) {
   if (!qkv || !ctx || !lse || n_img <= 0 || heads <= 0 || embed_dim != heads * DH) return DIG_ERR_ARG;
   if (!aligned16(qkv) || !aligned16(ctx)) return DIG_ERR_ALIGN;
   const size_t qb = (size_t)n_img * N_TOK * 3 * embed_dim * 2;
   if (qb >= (1ull << 32)) return DIG_ERR_ARG;
   static bool attr = false;
   if (!attr) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TILE);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TILE);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TILE);
     attr = true;
   }
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(n_img * heads), dim3(256), 2 * TILE, stream, (const bf16_t*)qkv, (bf16_t*)ctx,
-                     lse, embed_dim, heads, (unsigned)qb);
+  if (drop && drop->thr)
+    hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3(n_img * heads), dim3(256), 2 * TILE, stream, (const bf16_t*)qkv, (bf16_t*)ctx,
+                       lse, embed_dim, heads, (unsigned)qb, *drop);
+  else
+    hipLaunchKernelGGL(attn_fwd_kernel<false>, dim3(n_img * heads), dim3(256), 2 * TILE, stream, (const bf16_t*)qkv, (bf16_t*)ctx,
+                       lse, embed_dim, heads, (unsigned)qb, dig_dropout_t{});
   return dig_check_launch();
 }
 
-extern "C" int dig_attn_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse, void* dqkv, int n_img,
-                            int heads, int embed_dim, float scale, float* q_colsum, float* v_colsum, hipStream_t stream) {
+extern "C" int dig_attn_fwd(const void* qkv, void* ctx, float* lse, int n_img, int heads, int embed_dim, hipStream_t stream) {
+  return dig_attn_fwd_dropout(qkv, ctx, lse, n_img, heads, embed_dim, nullptr, stream);
+}
+
+extern "C" int dig_attn_bwd_dropout(const void* qkv, const void* ctx, const void* dctx, const float* lse, void* dqkv, int n_img,
+                                    int heads, int embed_dim, float scale, float* q_colsum, float* v_colsum,
+                                    const dig_dropout_t* drop, hipStream_t stream) {
   if (!qkv || !ctx || !dctx || !lse || !dqkv || n_img <= 0 || heads <= 0 || embed_dim != heads * DH) return DIG_ERR_ARG;
   if ((q_colsum == nullptr) != (v_colsum == nullptr)) return DIG_ERR_ARG;
   if (!aligned16(qkv) || !aligned16(ctx) || !aligned16(dctx) || !aligned16(dqkv)) return DIG_ERR_ALIGN;
@@ -437,11 +475,22 @@ extern "C" int dig_attn_bwd(const void* qkv, const void* ctx, const void* dctx, 
   const int lds = 4 * TILE + 2 * N_TOK * 4 + 8 * 128 * 4;
   static bool attr = false;
   if (!attr) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr = true;
   }
-  hipLaunchKernelGGL(attn_bwd_kernel, dim3(n_img * heads), dim3(512), lds, stream, (const bf16_t*)qkv, (const bf16_t*)ctx,
-                     (const bf16_t*)dctx, lse, (bf16_t*)dqkv, embed_dim, heads, scale, (unsigned)qb, (unsigned)(qb / 3), q_colsum,
-                     v_colsum);
+  if (drop && drop->thr)
+    hipLaunchKernelGGL(attn_bwd_kernel<true>, dim3(n_img * heads), dim3(512), lds, stream, (const bf16_t*)qkv, (const bf16_t*)ctx,
+                       (const bf16_t*)dctx, lse, (bf16_t*)dqkv, embed_dim, heads, scale, (unsigned)qb, (unsigned)(qb / 3), q_colsum,
+                       v_colsum, *drop);
+  else
+    hipLaunchKernelGGL(attn_bwd_kernel<false>, dim3(n_img * heads), dim3(512), lds, stream, (const bf16_t*)qkv, (const bf16_t*)ctx,
+                       (const bf16_t*)dctx, lse, (bf16_t*)dqkv, embed_dim, heads, scale, (unsigned)qb, (unsigned)(qb / 3), q_colsum,
+                       v_colsum, dig_dropout_t{});
   return dig_check_launch();
+}
+
+extern "C" int dig_attn_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse, void* dqkv, int n_img,
+                            int heads, int embed_dim, float scale, float* q_colsum, float* v_colsum, hipStream_t stream) {
+  return dig_attn_bwd_dropout(qkv, ctx, dctx, lse, dqkv, n_img, heads, embed_dim, scale, q_colsum, v_colsum, nullptr, stream);
 }

@@ -79,6 +79,47 @@ __device__ __forceinline__ float dgelu_f(float x) {
   return cdf + x * pdf;
 }
 
+// ---- dropout / stochastic depth --------------------------------------------------------------------------------------
+// Counter-based keep/drop decision: a keyed two-round multiply-xorshift hash of the element coordinates (a, b) under the
+// site key (k0, k1); the element is dropped when the 32-bit hash is below thr = floor(p * 2^32).  Stateless, so forward and
+// backward (and the CPU oracle, oracle/finetune_oracle.py `keep_mask`) regenerate the same mask from (key, coordinates)
+// and no mask tensor is ever stored.  ~9 integer ops per element; coordinates: elementwise tensors a = row * cols + col,
+// b = 0; attention probabilities a = (query << 16) | key, b = sample * heads + head; drop-path a = sample, b = 0.
+struct dig_dropout_t {
+  unsigned k0, k1;        // site key
+  unsigned thr;           // 0: no element dropout
+  float scale;            // 1 / (1 - p)
+  unsigned pk0, pk1;      // drop-path key
+  unsigned pthr;          // 0: no drop-path
+  float pscale;           // 1 / (1 - drop_path)
+  int rows_per_sample;    // drop-path: sample = row / rows_per_sample
+};
+__device__ __forceinline__ unsigned dig_drop_hash(unsigned k0, unsigned k1, unsigned a, unsigned b) {
+  unsigned x = a ^ k0;
+  x ^= x >> 16; x *= 0x7feb352du;
+  x += k1 + b * 0x9e3779b9u;
+  x ^= x >> 15; x *= 0x846ca68bu;
+  x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ bool dig_drop_keep(unsigned k0, unsigned k1, unsigned a, unsigned b, unsigned thr) {
+  return dig_drop_hash(k0, k1, a, b) >= thr;
+}
+// 8 consecutive elements of row i starting at column j of a [rows, cols] tensor: v *= element mask * scale * drop-path factor
+__device__ __forceinline__ void dig_drop_apply8(float (&v)[8], const dig_dropout_t& d, int i, int j, int cols) {
+  float s = 1.f;
+  if (d.pthr) s = dig_drop_keep(d.pk0, d.pk1, (unsigned)(i / d.rows_per_sample), 0u, d.pthr) ? d.pscale : 0.f;
+  if (d.thr) {
+    const unsigned base = (unsigned)i * (unsigned)cols + (unsigned)j;
+    s *= d.scale;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = dig_drop_keep(d.k0, d.k1, base + e, 0u, d.thr) ? v[e] * s : 0.f;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= s;
+  }
+}
+
 static inline int dig_check_launch() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? DIG_OK : DIG_ERR_LAUNCH;

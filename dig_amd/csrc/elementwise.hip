@@ -374,6 +374,23 @@ __global__ __launch_bounds__(256) void colsum_masked_kernel(const bf16_t* __rest
   }
 }
 
+// out = in * (element mask / (1-p)) * (drop-path factor of the row's sample): nn.Dropout / timm drop_path applied to a [rows, cols]
+// bf16 tensor, forward (pos_drop, decoder embedding dropout) or backward (the gradient of every dropped branch); 8 columns per thread
+__global__ __launch_bounds__(256) void dropout_apply_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, long long n8, int cols,
+                                                            dig_dropout_t d) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n8) return;
+  const int c8 = cols >> 3;
+  const int i = (int)(t / c8), j = (int)(t - (long long)i * c8) * 8;
+  const uint4 x = reinterpret_cast<const uint4*>(in)[t];
+  const unsigned w[4] = {x.x, x.y, x.z, x.w};
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { v[2 * e] = bf2f((bf16_t)(w[e] & 0xffff)); v[2 * e + 1] = bf2f((bf16_t)(w[e] >> 16)); }
+  dig_drop_apply8(v, d, i, j, cols);
+  reinterpret_cast<uint4*>(out)[t] = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+}
+
 }  // namespace
 
 extern "C" int dig_patch_embed_fwd(const float* img, const float* W, const float* bias, const unsigned char* mask,
@@ -525,5 +542,14 @@ extern "C" int dig_colsum_masked(const void* x, const unsigned char* mask, float
   hipLaunchKernelGGL(colsum_masked_kernel, dim3(cb, nb), dim3(256), 0, stream, (const bf16_t*)x, mask, p0, p1, rows, C, rpb);
   hipLaunchKernelGGL(colsum_finalize_kernel, dim3(C / 8), dim3(256), 0, stream, p0, nb, C, out_unmasked);
   hipLaunchKernelGGL(colsum_finalize_kernel, dim3(C / 8), dim3(256), 0, stream, p1, nb, C, out_masked);
+  return dig_check_launch();
+}
+
+extern "C" int dig_dropout_apply(const void* in, void* out, long long rows, int cols, const dig_dropout_t* drop, hipStream_t stream) {
+  if (!in || !out || !drop || rows <= 0 || cols <= 0 || (cols & 7) || rows * cols >= (1ll << 32)) return DIG_ERR_ARG;
+  if (drop->pthr && drop->rows_per_sample <= 0) return DIG_ERR_ARG;
+  if (!aligned16(in) || !aligned16(out)) return DIG_ERR_ALIGN;
+  const long long n8 = rows * cols / 8;
+  hipLaunchKernelGGL(dropout_apply_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)in, (bf16_t*)out, n8, cols, *drop);
   return dig_check_launch();
 }

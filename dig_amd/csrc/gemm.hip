@@ -50,6 +50,7 @@ struct GemmParams {
   int tiles_i, tiles_j;
   float* colsum;                          // act 2 only: [ceil(I/64)][J] per-64-row column sums of the result (fp32), or null
   int splits_x;                           // >0: 1-D grid of tiles*splits blocks, every R-split pinned to one XCD
+  dig_dropout_t drop;                     // dropout / drop-path of the result before the residual add (thr = pthr = 0: off)
 };
 
 constexpr int BI = 128, BJ = 128;
@@ -283,10 +284,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
         const unsigned w[4] = {rres[ps].x, rres[ps].y, rres[ps].z, rres[ps].w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) { v[2 * e] *= dgelu_f(bf2f((bf16_t)(w[e] & 0xffff))); v[2 * e + 1] *= dgelu_f(bf2f((bf16_t)(w[e] >> 16))); }
-        if (live) {
+      }
+      if (p.drop.thr | p.drop.pthr) dig_drop_apply8(v, p.drop, i, j, p.J);
+      if (RES && p.act == 2 && live) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) csum[e] += v[e];
-        }
+        for (int e = 0; e < 8; ++e) csum[e] += v[e];
       }
       if (RES && p.act != 2) {
         const unsigned w[4] = {rres[ps].x, rres[ps].y, rres[ps].z, rres[ps].w};
@@ -765,10 +767,11 @@ __global__ __launch_bounds__(64 * WM * WN, (BK == 32 && WM * WN == 8 && FM * FN 
         const unsigned w[4] = {rres[q4].x, rres[q4].y, rres[q4].z, rres[q4].w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) { v[2 * e] *= dgelu_f(bf2f((bf16_t)(w[e] & 0xffff))); v[2 * e + 1] *= dgelu_f(bf2f((bf16_t)(w[e] >> 16))); }
-        if (live) {
+      }
+      if (p.drop.thr | p.drop.pthr) dig_drop_apply8(v, p.drop, i, j, p.J);
+      if (RES && p.act == 2 && live) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) csum[e] += v[e];
-        }
+        for (int e = 0; e < 8; ++e) csum[e] += v[e];
       }
       if (RES && p.act != 2) {
         const unsigned w[4] = {rres[q4].x, rres[q4].y, rres[q4].z, rres[q4].w};
@@ -855,11 +858,16 @@ int launch(const GemmParams& p, int splits, hipStream_t stream) {
 }  // namespace
 
 // C-ABI: see include/dig_hip.h
-extern "C" int dig_gemm_bf16(const void* A, const void* B, void* C, int I, int J, int R, int lda, int ldb, int ldc,
-                             int trans_a, int trans_b, int out_kind, const float* bias, const void* resid, int ldr,
-                             void* pre_act, int ldp, float alpha, int alpha_cols, int act, int splits, int a_rows,
-                             int b_rows, int bk, float* colsum_partials, hipStream_t stream) {
+extern "C" int dig_gemm_bf16_dropout(const void* A, const void* B, void* C, int I, int J, int R, int lda, int ldb, int ldc,
+                                     int trans_a, int trans_b, int out_kind, const float* bias, const void* resid, int ldr,
+                                     void* pre_act, int ldp, float alpha, int alpha_cols, int act, int splits, int a_rows,
+                                     int b_rows, int bk, float* colsum_partials, const dig_dropout_t* drop,
+                                     hipStream_t stream) {
   if (!A || !B || !C || I <= 0 || J <= 0 || R <= 0 || splits < 1) return DIG_ERR_ARG;
+  if (drop && (drop->thr || drop->pthr)) {
+    if (out_kind == 2 || (bk >= 100 && bk < 200)) return DIG_ERR_UNSUPPORTED;      // the persistent variant has no dropout epilogue
+    if ((size_t)I * (size_t)J >= (1ull << 32) || (drop->pthr && drop->rows_per_sample <= 0)) return DIG_ERR_ARG;
+  }
   if (bias && !aligned16(bias)) return DIG_ERR_ALIGN;
   if (out_kind < 0 || out_kind > 2 || act < 0 || act > 2 || (bk != 0 && bk != 32 && bk != 33 && bk != 34 && bk != 64 && bk != 132 && bk != 164 && bk != 244 && bk != 242 && bk != 224 && bk != 344 && bk != 343 && bk != 448 && bk != 484 && bk != 444 && bk != 432 && bk != 232 && bk != 332 && bk != 223 && bk != 212 && bk != 221 && bk != 422 && bk != 424 && bk != 423)) return DIG_ERR_ARG;
   if (act == 2 && !resid) return DIG_ERR_ARG;                   // act 2: resid carries the saved pre-activation
@@ -878,6 +886,7 @@ extern "C" int dig_gemm_bf16(const void* A, const void* B, void* C, int I, int J
   GemmParams p;
   p.splits_x = 0;
   p.colsum = colsum_partials;
+  if (drop) p.drop = *drop; else { p.drop.thr = 0; p.drop.pthr = 0; }
   p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C;
   p.I = I; p.J = J; p.R = R; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
   // a_rows / b_rows (0 = default) bound the rows that really exist in memory; rows past them read as zero.
@@ -945,6 +954,14 @@ extern "C" int dig_gemm_bf16(const void* A, const void* B, void* C, int I, int J
   DIG_GEMM_CASE(true, true, 2)
 #undef DIG_GEMM_CASE
   return DIG_ERR_UNSUPPORTED;
+}
+
+extern "C" int dig_gemm_bf16(const void* A, const void* B, void* C, int I, int J, int R, int lda, int ldb, int ldc,
+                             int trans_a, int trans_b, int out_kind, const float* bias, const void* resid, int ldr,
+                             void* pre_act, int ldp, float alpha, int alpha_cols, int act, int splits, int a_rows,
+                             int b_rows, int bk, float* colsum_partials, hipStream_t stream) {
+  return dig_gemm_bf16_dropout(A, B, C, I, J, R, lda, ldb, ldc, trans_a, trans_b, out_kind, bias, resid, ldr, pre_act, ldp, alpha,
+                               alpha_cols, act, splits, a_rows, b_rows, bk, colsum_partials, nullptr, stream);
 }
 
 // Number of R-splits dig_gemm_bf16 will really use for a requested split count (slabs are whole 64-row K-tiles).

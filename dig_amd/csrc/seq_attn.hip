@@ -24,7 +24,13 @@ struct SeqAttnParams {
   float scale;
   int causal;
   const long long* lens;                       // per sample valid key count (self-attention), or null
+  dig_dropout_t drop;                          // attention dropout on the probabilities (thr = 0: off); see csrc/common.h
 };
+
+__device__ __forceinline__ float drop_factor(const SeqAttnParams& p, int bh, int i, int j) {
+  if (!p.drop.thr) return 1.f;
+  return dig_drop_keep(p.drop.k0, p.drop.k1, ((unsigned)i << 16) | (unsigned)j, (unsigned)bh, p.drop.thr) ? p.drop.scale : 0.f;
+}
 
 __device__ __forceinline__ bool key_ok(const SeqAttnParams& p, int i, int j, long long len) {
   return (!p.causal || j <= i) && (!p.lens || j < len);
@@ -120,12 +126,12 @@ __global__ __launch_bounds__(256) void seq_attn_fwd_kernel(SeqAttnParams p, bf16
     float s = 0.f;
     for (int j = lane; j < p.Lk; j += 64) {
       const float e = (S[i * p.Lk + j] == -INFINITY) ? 0.f : __expf(S[i * p.Lk + j] - m);
-      S[i * p.Lk + j] = e;
+      S[i * p.Lk + j] = e * drop_factor(p, b * gridDim.y + h, i, j);     // dropout after the normalisation by the full row sum
       s += e;
     }
     s = wave_sum(s);
     if (lane == 0) {
-      rowinv[i] = 1.f / s;
+      rowinv[i] = 1.f / s;                                              // (drop_factor already carries 1/(1-p))
       lse[((size_t)b * gridDim.y + h) * p.Lq + i] = m + __logf(s);
     }
   }
@@ -162,7 +168,7 @@ __global__ __launch_bounds__(256) void seq_attn_bwd_kernel(SeqAttnParams p, cons
       float pr = 0.f, dp = 0.f;
       if (key_ok(p, i, j, len)) {
         pr = __expf(dot64(Qs + i * DK, kr) * p.scale - lse_row[i]);
-        dp = dot64(Gs + i * DK, vr);
+        dp = dot64(Gs + i * DK, vr) * drop_factor(p, b * gridDim.y + h, i, j);   // dP = mask * (dO V^T) / (1 - p)
       }
       P[i * p.Lk + j] = pr;
       dS[i * p.Lk + j] = dp;
@@ -181,7 +187,7 @@ __global__ __launch_bounds__(256) void seq_attn_bwd_kernel(SeqAttnParams p, cons
 #pragma unroll
     for (int d = 0; d < DK; ++d) { ak[d] = 0.f; av[d] = 0.f; }
     for (int i = 0; i < p.Lq; ++i) {
-      const float ds = dS[i * p.Lk + j], pr = P[i * p.Lk + j];
+      const float ds = dS[i * p.Lk + j], pr = P[i * p.Lk + j] * drop_factor(p, b * gridDim.y + h, i, j);   // dV sees the dropped P
 #pragma unroll
       for (int d4 = 0; d4 < DK / 4; ++d4) {
         const float4 qv = reinterpret_cast<const float4*>(Qs + i * DK)[d4];
@@ -271,11 +277,12 @@ size_t lds_bwd(int Lk) { return (size_t)2 * MAXQ * DK * 4 + (size_t)2 * MAXQ * L
 }  // namespace
 
 // C-ABI: see include/dig_hip.h
-extern "C" int dig_seq_attn_fwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out, int ldo, float* lse, int B,
-                                int heads, int Lq, int Lk, float scale, int causal, const long long* lens, hipStream_t stream) {
+extern "C" int dig_seq_attn_fwd_dropout(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out, int ldo, float* lse,
+                                        int B, int heads, int Lq, int Lk, float scale, int causal, const long long* lens,
+                                        const dig_dropout_t* drop, hipStream_t stream) {
   if (!q || !k || !v || !out || !lse || B <= 0 || heads <= 0 || Lq <= 0 || Lq > MAXQ || Lk <= 0 || Lk > 512) return DIG_ERR_ARG;
   if ((ldk & 7) || (ldv & 7) || !aligned16(k) || !aligned16(v)) return DIG_ERR_ALIGN;   // 16-byte row reads
-  SeqAttnParams p{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldq, ldk, ldv, Lq, Lk, scale, causal, lens};
+  SeqAttnParams p{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldq, ldk, ldv, Lq, Lk, scale, causal, lens, drop ? *drop : dig_dropout_t{}};
   const size_t lds = lds_fwd(Lk);
   static size_t attr = 0;
   if (lds > attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(seq_attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = lds; }
@@ -283,18 +290,31 @@ extern "C" int dig_seq_attn_fwd(const void* q, int ldq, const void* k, int ldk, 
   return dig_check_launch();
 }
 
-extern "C" int dig_seq_attn_bwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* dout, int ldo,
-                                const float* lse, void* dq, int lddq, void* dk, int lddk, void* dv, int lddv, int B, int heads, int Lq, int Lk,
-                                float scale, int causal, const long long* lens, hipStream_t stream) {
+extern "C" int dig_seq_attn_fwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out, int ldo, float* lse, int B,
+                                int heads, int Lq, int Lk, float scale, int causal, const long long* lens, hipStream_t stream) {
+  return dig_seq_attn_fwd_dropout(q, ldq, k, ldk, v, ldv, out, ldo, lse, B, heads, Lq, Lk, scale, causal, lens, nullptr, stream);
+}
+
+extern "C" int dig_seq_attn_bwd_dropout(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* dout, int ldo,
+                                        const float* lse, void* dq, int lddq, void* dk, int lddk, void* dv, int lddv, int B, int heads, int Lq,
+                                        int Lk, float scale, int causal, const long long* lens, const dig_dropout_t* drop,
+                                        hipStream_t stream) {
   if (!q || !k || !v || !dout || !lse || !dq || !dk || !dv || B <= 0 || heads <= 0 || Lq <= 0 || Lq > MAXQ || Lk <= 0 || Lk > 512) return DIG_ERR_ARG;
   if ((ldk & 7) || (ldv & 7) || !aligned16(k) || !aligned16(v)) return DIG_ERR_ALIGN;   // 16-byte row reads
-  SeqAttnParams p{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldq, ldk, ldv, Lq, Lk, scale, causal, lens};
+  SeqAttnParams p{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldq, ldk, ldv, Lq, Lk, scale, causal, lens, drop ? *drop : dig_dropout_t{}};
   const size_t lds = lds_bwd(Lk);
   static size_t attr = 0;
   if (lds > attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(seq_attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = lds; }
   hipLaunchKernelGGL(seq_attn_bwd_kernel, dim3(B, heads), dim3(256), lds, stream, p, (const bf16_t*)dout, ldo, lse, (bf16_t*)dq, lddq, (bf16_t*)dk,
                      lddk, (bf16_t*)dv, lddv);
   return dig_check_launch();
+}
+
+extern "C" int dig_seq_attn_bwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* dout, int ldo,
+                                const float* lse, void* dq, int lddq, void* dk, int lddk, void* dv, int lddv, int B, int heads, int Lq, int Lk,
+                                float scale, int causal, const long long* lens, hipStream_t stream) {
+  return dig_seq_attn_bwd_dropout(q, ldq, k, ldk, v, ldv, dout, ldo, lse, dq, lddq, dk, lddk, dv, lddv, B, heads, Lq, Lk, scale, causal, lens,
+                                  nullptr, stream);
 }
 
 extern "C" int dig_seq_embed_fwd(const long long* tokens, const float* emb, const float* pos_table, void* x, int B, int T, int d, int vocab,

@@ -1,7 +1,8 @@
-"""Fine-tune TRAINING step of the recognition model on the MI355X -- SURVEY.md 8(f) row N1, deterministic part.
+"""Fine-tune TRAINING step of the recognition model on the MI355X -- SURVEY.md 8(f) row N1.
 
-Mirrors, for `--drop 0 --attn_drop_rate 0 --drop_path 0 --smoothing 0` (anything else raises: the stochastic regularisers are
-not built yet):
+Mirrors (label smoothing 0, as in README.md:92-118), including the stochastic regularisers `--drop`, `--attn_drop_rate`,
+`--drop_path` of the encoder and the recognition decoder's own dropout (0.1, hard-wired by models/decoder.py:13-18,141) -- masks
+come from a keyed counter hash instead of torch's generator, see dig_amd/dropout.py:
   * `RecModel.forward` in train mode (models/model_builder.py:124-160) -> `TFDecoder.forward_train` (models/decoder.py:196-222):
     `model((images, targets, tgt_lens))` returns the logits [B, max_len, nb_classes] (+ three Nones, as the reference does);
   * `SeqCrossEntropyLoss` (loss/seqCrossEntropyLoss.py) with its gradient;
@@ -18,12 +19,17 @@ from collections import OrderedDict
 import torch
 
 from . import _lib as L
+from . import dropout as DR
 from . import ops
 from .recognizer import RecModel, _encoder_pos, _sinusoid
 
 BF16, F32 = torch.bfloat16, torch.float32
 cf = ctypes.c_float
 CLS_PAD = 128                     # classifier rows padded to a multiple of 64 (it is a non-transposed GEMM operand in backward)
+
+
+def _ref(spec):
+    return ctypes.byref(spec) if spec is not None else None
 
 
 def _pad256(n):
@@ -33,12 +39,22 @@ def _pad256(n):
 class RecModelTrain(RecModel):
     """`RecModel` with trainable flat arenas.  `.train()` forward = teacher-forced logits with autograd; `.eval()` = greedy decode."""
 
-    def __init__(self, args=None, **kw):
+    def __init__(self, args=None, *, drop_rate=None, attn_drop_rate=None, drop_path_rate=None, decoder_dropout=0.1, drop_seed=None, **kw):
+        """Drop rates: from `args` (--drop / --attn_drop_rate / --drop_path, run_class_finetuning.py:69-74 -> create_model,
+        :300-313) unless given; `decoder_dropout` = 0.1 is what `create_decoder` builds (models/decoder.py:13-18: TFDecoder's
+        default, not configurable in the reference).  drop_seed: base seed of the mask keys (default: torch.initial_seed())."""
         super().__init__(args, **kw)
-        if args is not None:
-            for name in ("drop", "attn_drop_rate", "drop_path"):
-                if getattr(args, name, 0.0):
-                    raise NotImplementedError(f"--{name} > 0 is not built yet (SURVEY.md 8f row N1 covers the deterministic step)")
+        self.drop_rate = float(getattr(args, "drop", 0.0) if drop_rate is None else drop_rate)
+        self.attn_drop_rate = float(getattr(args, "attn_drop_rate", 0.0) if attn_drop_rate is None else attn_drop_rate)
+        self.drop_path_rate = float(getattr(args, "drop_path", 0.0) if drop_path_rate is None else drop_path_rate)
+        self.decoder_dropout = float(decoder_dropout)
+        for name in ("drop_rate", "attn_drop_rate", "drop_path_rate", "decoder_dropout"):
+            if not 0.0 <= getattr(self, name) < 1.0:
+                raise ValueError(f"{name} must be in [0, 1), got {getattr(self, name)}")
+        # stochastic depth decay rule (modeling_finetune.py:273)
+        self.dpr = [x.item() for x in torch.linspace(0, self.drop_path_rate, self.depth)]
+        self.drop_seed = torch.initial_seed() if drop_seed is None else int(drop_seed)
+        self.drop_step = 0                              # training forwards so far: every step draws fresh keys
         self.comm = None
         self._dev = None
         self._offsets = OrderedDict()
@@ -180,19 +196,34 @@ class _TrainStep:
         # ---- encoder (PretrainVisionTransformerEncoder.forward_features, mask=None) -- the pre-training hot-path kernels
         x = ops.patch_embed_fwd(self.images, self.p("encoder.patch_embed.proj.weight").view(D, 48), self.p("encoder.patch_embed.proj.bias"),
                                 self.zmask, self.p("encoder.mask_token").view(D), M._enc_pos, D, M.gh, M.gw)
+        # dropout / drop-path keys of this step (dig_amd/dropout.py); every spec is None when its rate is 0
+        plan = DR.DropPlan(M.drop_seed, M.drop_step)
+        M.drop_step += 1
+        pe, pa, pd = M.drop_rate, M.attn_drop_rate, M.decoder_dropout
+        self.ds_pos = None                              # PretrainVisionTransformerEncoder has no pos_drop (modeling_pretrain_vit.py:89-106)
+        self.ds_enc = [dict(attn=plan.spec(DR.enc_site(i, 0), pa),
+                            proj=plan.spec(DR.enc_site(i, 1), pe, DR.enc_site(i, 2), M.dpr[i], N),
+                            mlp=plan.spec(DR.enc_site(i, 3), pe, DR.enc_site(i, 4), M.dpr[i], N)) for i in range(M.depth)]
+        self.ds_tgt = plan.spec(DR.DEC_TGT, pd)
+        self.ds_dec = [dict(sattn=plan.spec(DR.dec_site(i, 0), pd), sproj=plan.spec(DR.dec_site(i, 1), pd),
+                            cattn=plan.spec(DR.dec_site(i, 2), pd), cproj=plan.spec(DR.dec_site(i, 3), pd),
+                            act=plan.spec(DR.dec_site(i, 4), pd), out=plan.spec(DR.dec_site(i, 5), pd)) for i in range(M.n_layers)]
+        x = ops.dropout_apply(x, self.ds_pos, out=x)
         scale = (D // H) ** -0.5
         self.enc_saved = []
         for i in range(M.depth):
             b = f"encoder.blocks.{i}."
+            ds = self.ds_enc[i]
             qkv_bias = torch.cat([self.p(b + "attn.q_bias"), torch.zeros(D, device=dev), self.p(b + "attn.v_bias")])
             ln1, mu1, rs1 = ops.layernorm_fwd(x, self.p(b + "norm1.weight"), self.p(b + "norm1.bias"), 1e-6)
             qkv = ops.linear_fwd(ln1, self.w(b + "attn.qkv.weight"), bias=qkv_bias, alpha=scale, alpha_cols=D)
-            ctx, lse = ops.attn_fwd(qkv, B, H, D)
-            x_mid = ops.linear_fwd(ctx, self.w(b + "attn.proj.weight"), bias=self.p(b + "attn.proj.bias"), resid=x)
+            ctx, lse = ops.attn_fwd(qkv, B, H, D, drop=ds["attn"])
+            # x + drop_path(proj_drop(proj(.))) / x + drop_path(drop(fc2(.))) (modeling_finetune.py:120,59,156-158): GEMM epilogue
+            x_mid = ops.linear_fwd(ctx, self.w(b + "attn.proj.weight"), bias=self.p(b + "attn.proj.bias"), resid=x, drop=ds["proj"])
             ln2, mu2, rs2 = ops.layernorm_fwd(x_mid, self.p(b + "norm2.weight"), self.p(b + "norm2.bias"), 1e-6)
             pre = torch.empty((B * N, M.F), device=dev, dtype=BF16)
             act = ops.linear_fwd(ln2, self.w(b + "mlp.fc1.weight"), bias=self.p(b + "mlp.fc1.bias"), act=1, pre=pre)
-            x_out = ops.linear_fwd(act, self.w(b + "mlp.fc2.weight"), bias=self.p(b + "mlp.fc2.bias"), resid=x_mid)
+            x_out = ops.linear_fwd(act, self.w(b + "mlp.fc2.weight"), bias=self.p(b + "mlp.fc2.bias"), resid=x_mid, drop=ds["mlp"])
             self.enc_saved.append((x, ln1, mu1, rs1, qkv, ctx, lse, x_mid, ln2, mu2, rs2, pre, act))
             x = x_out
         enc, emu, ers = ops.layernorm_fwd(x, self.p("encoder.norm.weight"), self.p("encoder.norm.bias"), 1e-6)
@@ -208,17 +239,19 @@ class _TrainStep:
         x = torch.empty((B * T, d), device=dev, dtype=BF16)
         L.call("dig_seq_embed_fwd", L.ptr(query), L.ptr(self.p("decoder.trg_word_emb.weight")), L.ptr(M._pos), L.ptr(x), B, T, d,
                M.nb_classes + 1, L.stream())
+        x = ops.dropout_apply(x, self.ds_tgt, out=x)                            # decoder.py:180
         sc = dk ** -0.5
         self.dec_saved = []
         for i in range(M.n_layers):
             p = f"decoder.layer_stack.{i}."
+            ds = self.ds_dec[i]
             h1, m1, r1 = ops.layernorm_fwd(x, self.p(p + "norm1.weight"), self.p(p + "norm1.bias"), 1e-5)
             qkv = ops.linear_fwd(h1, M._fused(M._shadow, p + "self_attn.linear_q.weight", 3))
             a = torch.empty((B * T, hk), device=dev, dtype=BF16)
             lse1 = torch.empty((B, nh, T), device=dev, dtype=F32)
-            L.call("dig_seq_attn_fwd", L.ptr(qkv), 3 * hk, L.ptr(qkv[:, hk:]), 3 * hk, L.ptr(qkv[:, 2 * hk:]), 3 * hk, L.ptr(a), hk, L.ptr(lse1),
-                   B, nh, T, T, cf(sc), 1, L.ptr(self.lens), L.stream())
-            x1 = ops.linear_fwd(a, self.w(p + "self_attn.fc.weight"), resid=x)
+            L.call("dig_seq_attn_fwd_dropout", L.ptr(qkv), 3 * hk, L.ptr(qkv[:, hk:]), 3 * hk, L.ptr(qkv[:, 2 * hk:]), 3 * hk, L.ptr(a), hk,
+                   L.ptr(lse1), B, nh, T, T, cf(sc), 1, L.ptr(self.lens), _ref(ds["sattn"]), L.stream())
+            x1 = ops.linear_fwd(a, self.w(p + "self_attn.fc.weight"), resid=x, drop=ds["sproj"])
             h2, m2, r2 = ops.layernorm_fwd(x1, self.p(p + "norm2.weight"), self.p(p + "norm2.bias"), 1e-5)
             q2 = ops.linear_fwd(h2, self.w(p + "enc_attn.linear_q.weight"))
             o2, n2, s2 = M._offsets[p + "enc_attn.linear_k.weight"]
@@ -233,20 +266,20 @@ class _TrainStep:
                 fq = fused.view(B, N, 3 * hk)[:, :, :hk]
                 fq[:, T:].zero_()
                 fq[:, :T] = (q2 * sc).view(B, T, hk)                              # sc = 2^-3: exact in bf16
-                ctx2, lse2 = ops.attn_fwd(fused, B, nh, hk)
+                ctx2, lse2 = ops.attn_fwd(fused, B, nh, hk, drop=ds["cattn"])
                 a2 = ctx2.view(B, N, hk)[:, :T].reshape(B * T, hk)
                 kvm, lse2 = fused, (lse2, ctx2)
             else:
                 kvm = ops.linear_fwd(mem, wkv)
                 a2 = torch.empty((B * T, hk), device=dev, dtype=BF16)
                 lse2 = torch.empty((B, nh, T), device=dev, dtype=F32)
-                L.call("dig_seq_attn_fwd", L.ptr(q2), hk, L.ptr(kvm), 2 * hk, L.ptr(kvm[:, hk:]), 2 * hk, L.ptr(a2), hk, L.ptr(lse2), B, nh, T, N,
-                       cf(sc), 0, None, L.stream())
-            x2 = ops.linear_fwd(a2, self.w(p + "enc_attn.fc.weight"), resid=x1)
+                L.call("dig_seq_attn_fwd_dropout", L.ptr(q2), hk, L.ptr(kvm), 2 * hk, L.ptr(kvm[:, hk:]), 2 * hk, L.ptr(a2), hk, L.ptr(lse2), B, nh,
+                       T, N, cf(sc), 0, None, _ref(ds["cattn"]), L.stream())
+            x2 = ops.linear_fwd(a2, self.w(p + "enc_attn.fc.weight"), resid=x1, drop=ds["cproj"])
             h3, m3, r3 = ops.layernorm_fwd(x2, self.p(p + "norm3.weight"), self.p(p + "norm3.bias"), 1e-5)
             pre = torch.empty((B * T, M.d_inner), device=dev, dtype=BF16)
-            u = ops.linear_fwd(h3, self.w(p + "mlp.w_1.weight"), bias=self.p(p + "mlp.w_1.bias"), act=1, pre=pre)
-            x3 = ops.linear_fwd(u, self.w(p + "mlp.w_2.weight"), bias=self.p(p + "mlp.w_2.bias"), resid=x2)
+            u = ops.linear_fwd(h3, self.w(p + "mlp.w_1.weight"), bias=self.p(p + "mlp.w_1.bias"), act=1, pre=pre, drop=ds["act"])
+            x3 = ops.linear_fwd(u, self.w(p + "mlp.w_2.weight"), bias=self.p(p + "mlp.w_2.bias"), resid=x2, drop=ds["out"])
             self.dec_saved.append((x, h1, m1, r1, qkv, a, lse1, x1, h2, m2, r2, q2, kvm, a2, lse2, x2, h3, m3, r3, pre, u))
             x = x3
         o, fm, fr = ops.layernorm_fwd(x, self.p("decoder.layer_norm.weight"), self.p("decoder.layer_norm.bias"), 1e-6)
@@ -286,31 +319,35 @@ class _TrainStep:
             p = f"decoder.layer_stack.{i}."
             (x0, h1, m1, r1, qkv, a, lse1, x1, h2, m2, r2, q2, kvm, a2, lse2, x2, h3, m3, r3, pre, u) = self.dec_saved[i]
             self.dec_saved[i] = None
-            # feed-forward
-            ops.linear_wgrad(dx, u, self.g(p + "mlp.w_2.weight"))
-            ops.colsum(dx, self.g(p + "mlp.w_2.bias"))
-            du, bparts = ops.linear_dgrad(dx, self.w(p + "mlp.w_2.weight"), gelu_pre=pre, colsum=True)
+            ds = self.ds_dec[i]
+            # feed-forward (every dropped branch: its gradient is the residual gradient under the same mask)
+            dz = ops.dropout_apply(dx, ds["out"])
+            ops.linear_wgrad(dz, u, self.g(p + "mlp.w_2.weight"))
+            ops.colsum(dz, self.g(p + "mlp.w_2.bias"))
+            du, bparts = ops.linear_dgrad(dz, self.w(p + "mlp.w_2.weight"), gelu_pre=pre, colsum=True, drop=ds["act"])
             ops.colsum_partials(bparts, self.g(p + "mlp.w_1.bias"))
             ops.linear_wgrad(du, h3, self.g(p + "mlp.w_1.weight"))
             dh3 = ops.linear_dgrad(du, self.w(p + "mlp.w_1.weight"))
             dx2 = ops.layernorm_bwd(dh3, x2, self.p(p + "norm3.weight"), self.p(p + "norm3.bias"), m3, r3, dx, self.g(p + "norm3.weight"),
                                     self.g(p + "norm3.bias"))
             # cross-attention over the encoder memory
-            ops.linear_wgrad(dx2, a2, self.g(p + "enc_attn.fc.weight"))
-            da2 = ops.linear_dgrad(dx2, self.w(p + "enc_attn.fc.weight"))
+            dz = ops.dropout_apply(dx2, ds["cproj"])
+            ops.linear_wgrad(dz, a2, self.g(p + "enc_attn.fc.weight"))
+            da2 = ops.linear_dgrad(dz, self.w(p + "enc_attn.fc.weight"))
             o2, n2, _ = M._offsets[p + "enc_attn.linear_k.weight"]
             if isinstance(lse2, tuple):                                           # MFMA path (see forward)
                 lse2, ctx2 = lse2                                                 # padded rows: finite outputs, zero dO -> delta = 0
                 dctx2 = torch.zeros((B * N, hk), device=dev, dtype=BF16)
                 dctx2.view(B, N, hk)[:, :T] = da2.view(B, T, hk)
-                dfused = ops.attn_bwd(kvm, ctx2, dctx2, lse2, B, nh, hk, sc)      # kvm = the fused q|k|v buffer
+                dfused = ops.attn_bwd(kvm, ctx2, dctx2, lse2, B, nh, hk, sc, drop=ds["cattn"])   # kvm = the fused q|k|v buffer
                 dq2 = dfused.view(B, N, 3 * hk)[:, :T, :hk].reshape(B * T, hk)
                 dkvm = dfused[:, hk:]                                             # [B*N, 2hk] view, row stride 3hk
             else:
                 dq2 = torch.empty_like(q2)
                 dkvm = torch.empty_like(kvm)
-                L.call("dig_seq_attn_bwd", L.ptr(q2), hk, L.ptr(kvm), 2 * hk, L.ptr(kvm[:, hk:]), 2 * hk, L.ptr(da2), hk, L.ptr(lse2), L.ptr(dq2),
-                       hk, L.ptr(dkvm), 2 * hk, L.ptr(dkvm[:, hk:]), 2 * hk, B, nh, T, N, cf(sc), 0, None, L.stream())
+                L.call("dig_seq_attn_bwd_dropout", L.ptr(q2), hk, L.ptr(kvm), 2 * hk, L.ptr(kvm[:, hk:]), 2 * hk, L.ptr(da2), hk, L.ptr(lse2),
+                       L.ptr(dq2), hk, L.ptr(dkvm), 2 * hk, L.ptr(dkvm[:, hk:]), 2 * hk, B, nh, T, N, cf(sc), 0, None, _ref(ds["cattn"]),
+                       L.stream())
             ops.linear_wgrad(dq2, h2, self.g(p + "enc_attn.linear_q.weight"))
             dh2 = ops.linear_dgrad(dq2, self.w(p + "enc_attn.linear_q.weight"))
             ops.wgrad(dkvm, mem, M.flat_grads[o2:o2 + 2 * n2].view(2 * hk, hk), 2 * hk, hk, B * N)
@@ -322,16 +359,18 @@ class _TrainStep:
             dx1 = ops.layernorm_bwd(dh2, x1, self.p(p + "norm2.weight"), self.p(p + "norm2.bias"), m2, r2, dx2, self.g(p + "norm2.weight"),
                                     self.g(p + "norm2.bias"))
             # masked self-attention
-            ops.linear_wgrad(dx1, a, self.g(p + "self_attn.fc.weight"))
-            da = ops.linear_dgrad(dx1, self.w(p + "self_attn.fc.weight"))
+            dz = ops.dropout_apply(dx1, ds["sproj"])
+            ops.linear_wgrad(dz, a, self.g(p + "self_attn.fc.weight"))
+            da = ops.linear_dgrad(dz, self.w(p + "self_attn.fc.weight"))
             dqkv = torch.empty_like(qkv)
-            L.call("dig_seq_attn_bwd", L.ptr(qkv), 3 * hk, L.ptr(qkv[:, hk:]), 3 * hk, L.ptr(qkv[:, 2 * hk:]), 3 * hk, L.ptr(da), hk, L.ptr(lse1),
-                   L.ptr(dqkv), 3 * hk, L.ptr(dqkv[:, hk:]), 3 * hk, L.ptr(dqkv[:, 2 * hk:]), 3 * hk, B, nh, T, T, cf(sc), 1, L.ptr(self.lens),
-                   L.stream())
+            L.call("dig_seq_attn_bwd_dropout", L.ptr(qkv), 3 * hk, L.ptr(qkv[:, hk:]), 3 * hk, L.ptr(qkv[:, 2 * hk:]), 3 * hk, L.ptr(da), hk,
+                   L.ptr(lse1), L.ptr(dqkv), 3 * hk, L.ptr(dqkv[:, hk:]), 3 * hk, L.ptr(dqkv[:, 2 * hk:]), 3 * hk, B, nh, T, T, cf(sc), 1,
+                   L.ptr(self.lens), _ref(ds["sattn"]), L.stream())
             ops.linear_wgrad(dqkv, h1, M._fused(M.flat_grads, p + "self_attn.linear_q.weight", 3))
             dh1 = ops.linear_dgrad(dqkv, M._fused(M._shadow, p + "self_attn.linear_q.weight", 3))
             dx = ops.layernorm_bwd(dh1, x0, self.p(p + "norm1.weight"), self.p(p + "norm1.bias"), m1, r1, dx1, self.g(p + "norm1.weight"),
                                    self.g(p + "norm1.bias"))
+        dx = ops.dropout_apply(dx, self.ds_tgt, out=dx)
         L.call("dig_seq_embed_bwd", L.ptr(self.query), L.ptr(dx), L.ptr(self.g("decoder.trg_word_emb.weight")), rows, d, C + 1, L.stream())
         # ---- linear_norm
         h, mmu, mrs, _ = self.ln_saved
@@ -349,22 +388,32 @@ class _TrainStep:
             b = f"encoder.blocks.{i}."
             x, ln1, mu1, rs1, qkv, ctx, lse, x_mid, ln2, mu2, rs2, pre, act = self.enc_saved[i]
             self.enc_saved[i] = None
-            ops.linear_wgrad(dx, act, self.g(b + "mlp.fc2.weight"))
-            dact, bparts = ops.linear_dgrad(dx, self.w(b + "mlp.fc2.weight"), gelu_pre=pre, colsum=True)
+            ds = self.ds_enc[i]
+            # a dropped branch (dropout and/or drop-path) back-propagates the residual gradient under the same mask; its bias
+            # gradient is then the column sum of the MASKED gradient, so the LayerNorm kernel's fused residual column sum is off
+            dz = ops.dropout_apply(dx, ds["mlp"])
+            if ds["mlp"] is not None:
+                ops.colsum(dz, self.g(b + "mlp.fc2.bias"))
+            ops.linear_wgrad(dz, act, self.g(b + "mlp.fc2.weight"))
+            dact, bparts = ops.linear_dgrad(dz, self.w(b + "mlp.fc2.weight"), gelu_pre=pre, colsum=True)
             ops.colsum_partials(bparts, self.g(b + "mlp.fc1.bias"))
             ops.linear_wgrad(dact, ln2, self.g(b + "mlp.fc1.weight"))
             dln2 = ops.linear_dgrad(dact, self.w(b + "mlp.fc1.weight"))
             dx_mid = ops.layernorm_bwd(dln2, x_mid, self.p(b + "norm2.weight"), self.p(b + "norm2.bias"), mu2, rs2, dx, self.g(b + "norm2.weight"),
-                                       self.g(b + "norm2.bias"), out=dln2, dres_colsum=self.g(b + "mlp.fc2.bias"))
-            ops.linear_wgrad(dx_mid, ctx, self.g(b + "attn.proj.weight"))
-            dctx = ops.linear_dgrad(dx_mid, self.w(b + "attn.proj.weight"))
-            dqkv = ops.attn_bwd(qkv, ctx, dctx, lse, self.B, H, D, scale)
+                                       self.g(b + "norm2.bias"), out=dln2, dres_colsum=self.g(b + "mlp.fc2.bias") if ds["mlp"] is None else None)
+            dz = ops.dropout_apply(dx_mid, ds["proj"])
+            if ds["proj"] is not None:
+                ops.colsum(dz, self.g(b + "attn.proj.bias"))
+            ops.linear_wgrad(dz, ctx, self.g(b + "attn.proj.weight"))
+            dctx = ops.linear_dgrad(dz, self.w(b + "attn.proj.weight"))
+            dqkv = ops.attn_bwd(qkv, ctx, dctx, lse, self.B, H, D, scale, drop=ds["attn"])
             ops.linear_wgrad(dqkv, ln1, self.g(b + "attn.qkv.weight"))
             ops.colsum(dqkv, self.g(b + "attn.q_bias"), cols=D)
             ops.colsum(dqkv[:, 2 * D:], self.g(b + "attn.v_bias"), cols=D)
             dln1 = ops.linear_dgrad(dqkv, self.w(b + "attn.qkv.weight"), out=dctx)
             dx = ops.layernorm_bwd(dln1, x, self.p(b + "norm1.weight"), self.p(b + "norm1.bias"), mu1, rs1, dx_mid, self.g(b + "norm1.weight"),
-                                   self.g(b + "norm1.bias"), out=dln1, dres_colsum=self.g(b + "attn.proj.bias"))
+                                   self.g(b + "norm1.bias"), out=dln1, dres_colsum=self.g(b + "attn.proj.bias") if ds["proj"] is None else None)
+        dx = ops.dropout_apply(dx, self.ds_pos, out=dx)
         gtok = torch.zeros(D, device=dev, dtype=F32)                          # mask_token takes no part at fine-tune: gradient discarded
         ops.patch_embed_bwd_mfma(dx, self.images, self.zmask, self.g("encoder.patch_embed.proj.weight").view(D, 48),
                                  self.g("encoder.patch_embed.proj.bias"), gtok, D, M.gh, M.gw)

@@ -28,21 +28,26 @@ def _workspace(dev, numel):
 
 
 def gemm(A, B, I, J, R, *, ta=False, tb=False, out=None, out_kind=OUT_BF16, bias=None, resid=None, pre=None, alpha=1.0,
-         alpha_cols=0, act=0, splits=1, ldc=None, a_rows=0, b_rows=0, bk=0, colsum_partials=None):
-    """C[I,J] = sum_r opA(i,r) opB(j,r); see csrc/gemm.hip for the operand conventions."""
+         alpha_cols=0, act=0, splits=1, ldc=None, a_rows=0, b_rows=0, bk=0, colsum_partials=None, drop=None):
+    """C[I,J] = sum_r opA(i,r) opB(j,r); see csrc/gemm.hip for the operand conventions.  drop: dropout.DropSpec applied to the
+    result before the residual add (dig_gemm_bf16_dropout)."""
     if out is None:
         out = torch.empty((I, J), device=A.device, dtype=BF16 if out_kind == OUT_BF16 else F32)
     if not bk:
         bk = GEMM_BK_FWD if not (ta or tb) else GEMM_BK_BWD
-    L.call("dig_gemm_bf16", L.ptr(A), L.ptr(B), L.ptr(out), I, J, R, A.stride(0), B.stride(0),
-           out.stride(0) if ldc is None else ldc, int(ta), int(tb), out_kind, L.ptr(bias), L.ptr(resid),
-           resid.stride(0) if resid is not None else 0, L.ptr(pre), pre.stride(0) if pre is not None else 0, cf(alpha),
-           alpha_cols, act, splits, a_rows, b_rows, bk, L.ptr(colsum_partials), L.stream())
+    args = (L.ptr(A), L.ptr(B), L.ptr(out), I, J, R, A.stride(0), B.stride(0),
+            out.stride(0) if ldc is None else ldc, int(ta), int(tb), out_kind, L.ptr(bias), L.ptr(resid),
+            resid.stride(0) if resid is not None else 0, L.ptr(pre), pre.stride(0) if pre is not None else 0, cf(alpha),
+            alpha_cols, act, splits, a_rows, b_rows, bk, L.ptr(colsum_partials))
+    if drop is None:
+        L.call("dig_gemm_bf16", *args, L.stream())
+    else:
+        L.call("dig_gemm_bf16_dropout", *args, ctypes.byref(drop), L.stream())
     return out
 
 
 DGRAD_GELU_BK = 32    # tile of the fc2 dgrad + GELU' + bias-sum GEMM: 128x128/BK32 beats the 256x256 tile inside the step (A/B: 25.9 vs 26.1 ms)
-def linear_fwd(x, w, *, bias=None, resid=None, act=0, pre=None, alpha=1.0, alpha_cols=0, out=None, out_kind=OUT_BF16):
+def linear_fwd(x, w, *, bias=None, resid=None, act=0, pre=None, alpha=1.0, alpha_cols=0, out=None, out_kind=OUT_BF16, drop=None):
     """y[rows,out] = x[rows,in] @ w[out,in]^T (+bias)(gelu)(+resid)."""
     K = w.shape[1]
     # tile variant per layer shape, measured on MI355X (profiles/r01_gemm_variants.txt, tools/gpu_bk_probe.py):
@@ -58,16 +63,26 @@ def linear_fwd(x, w, *, bias=None, resid=None, act=0, pre=None, alpha=1.0, alpha
     else:
         bk = 0
     return gemm(x, w, x.shape[0], w.shape[0], w.shape[1], bias=bias, resid=resid, act=act, pre=pre, alpha=alpha,
-                alpha_cols=alpha_cols, out=out, out_kind=out_kind, bk=bk)
+                alpha_cols=alpha_cols, out=out, out_kind=out_kind, bk=bk, drop=drop)
 
 
-def linear_dgrad(dy, w, out=None, gelu_pre=None, colsum=False):
+def dropout_apply(x, drop, out=None):
+    """out = dropout / drop-path (x) for a [rows, cols] bf16 tensor under `drop` (dropout.DropSpec); None -> x itself."""
+    if drop is None:
+        return x
+    out = torch.empty_like(x) if out is None else out
+    L.call("dig_dropout_apply", L.ptr(x), L.ptr(out), x.shape[0], x.shape[1], ctypes.byref(drop), L.stream())
+    return out
+
+
+def linear_dgrad(dy, w, out=None, gelu_pre=None, colsum=False, drop=None):
     """dx[rows,in] = dy[rows,out] @ w[out,in]  (* gelu'(gelu_pre) when the input of this layer was a GELU output).
     colsum=True (GELU' form only) also returns the [ceil(rows/64), in] fp32 column sums of dx per 64-row group, i.e. the
     bias gradient of the layer that produced gelu_pre, for colsum_partials()."""
     if gelu_pre is not None:
         parts = torch.empty(((dy.shape[0] + 63) // 64, w.shape[1]), device=dy.device, dtype=F32) if colsum else None
-        dx = gemm(dy, w, dy.shape[0], w.shape[1], w.shape[0], tb=True, out=out, act=2, resid=gelu_pre, bk=DGRAD_GELU_BK, colsum_partials=parts)
+        dx = gemm(dy, w, dy.shape[0], w.shape[1], w.shape[0], tb=True, out=out, act=2, resid=gelu_pre, bk=DGRAD_GELU_BK, colsum_partials=parts,
+                  drop=drop)
         return (dx, parts) if colsum else dx
     # few rows (the BN-MLP heads on pooled features): 128x64 tiles double the workgroup count (tools/gpu_head_gemm_probe.py)
     return gemm(dy, w, dy.shape[0], w.shape[1], w.shape[0], tb=True, out=out, bk=221 if dy.shape[0] <= 2048 else 0)
@@ -159,21 +174,22 @@ def layernorm_bwd(dy, x, gamma, beta, mean, rstd, dres, dgamma, dbeta, gelu=Fals
     return dx, finish, ws
 
 
-def attn_fwd(qkv, n_img, heads, D):
+def attn_fwd(qkv, n_img, heads, D, drop=None):
     ctx = torch.empty((qkv.shape[0], D), device=qkv.device, dtype=BF16)
     lse = torch.empty((n_img * heads, 256), device=qkv.device, dtype=F32)
-    L.call("dig_attn_fwd", L.ptr(qkv), L.ptr(ctx), L.ptr(lse), n_img, heads, D, L.stream())
+    L.call("dig_attn_fwd_dropout", L.ptr(qkv), L.ptr(ctx), L.ptr(lse), n_img, heads, D, ctypes.byref(drop) if drop is not None else None,
+           L.stream())
     return ctx, lse
 
 
-def attn_bwd(qkv, ctx, dctx, lse, n_img, heads, D, scale, bias_sums=False):
+def attn_bwd(qkv, ctx, dctx, lse, n_img, heads, D, scale, bias_sums=False, drop=None):
     """dqkv (dq pre-multiplied by `scale`).  bias_sums=True also returns the per-image column sums of the dq and dv parts
     ([n_img, D] fp32 each): the q_bias / v_bias gradient partials for colsum_partials()."""
     dqkv = torch.empty_like(qkv)
     qs = torch.empty((n_img, D), device=qkv.device, dtype=F32) if bias_sums else None
     vs = torch.empty((n_img, D), device=qkv.device, dtype=F32) if bias_sums else None
-    L.call("dig_attn_bwd", L.ptr(qkv), L.ptr(ctx), L.ptr(dctx), L.ptr(lse), L.ptr(dqkv), n_img, heads, D, cf(scale), L.ptr(qs), L.ptr(vs),
-           L.stream())
+    L.call("dig_attn_bwd_dropout", L.ptr(qkv), L.ptr(ctx), L.ptr(dctx), L.ptr(lse), L.ptr(dqkv), n_img, heads, D, cf(scale), L.ptr(qs), L.ptr(vs),
+           ctypes.byref(drop) if drop is not None else None, L.stream())
     return (dqkv, qs, vs) if bias_sums else dqkv
 
 

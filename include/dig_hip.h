@@ -254,6 +254,48 @@ int dig_seq_embed_bwd(const long long* tokens, const void* dx, float* demb, int 
 int dig_seq_cross_entropy_bwd(const float* logits, int ld, const long long* target, const long long* length, const float* gscalar, int B,
                               int T, int C, void* dlogits, int ldd, hipStream_t stream);
 
+
+/* ---- dropout / stochastic depth of the fine-tune step (README.md:100-118: --drop 0.1 --attn_drop_rate 0.1 --drop_path 0.1; the
+ * recognition decoder's hard-wired dropout = 0.1, models/decoder.py:141).  Replaces nn.Dropout (modeling_finetune.py:51,83-85,271;
+ * models/transformer_layer.py:236-237,394; models/decoder.py:160) and timm drop_path (modeling_finetune.py:37).
+ * No mask is stored: an element is dropped when a keyed counter hash of its coordinates is below thr = floor(p * 2^32),
+ *     x = a ^ k0;  x ^= x >> 16;  x *= 0x7feb352d;  x += k1 + b * 0x9e3779b9;  x ^= x >> 15;  x *= 0x846ca68b;  x ^= x >> 16   (uint32)
+ * with (a, b) = (row * cols + col, 0) for [rows, cols] tensors, ((query << 16) | key, sample * heads + head) for attention
+ * probabilities and (sample, 0) for drop-path; forward, backward and the CPU oracle regenerate it from the per-site key.  torch's
+ * own Philox stream cannot be reproduced bit for bit (it depends on launch geometry); the distribution and the placement of every
+ * mask are the reference's, which tests/test_finetune.py pins by feeding these masks to the unmodified reference. */
+typedef struct dig_dropout {
+  unsigned k0, k1;      /* element-dropout key of this site */
+  unsigned thr;         /* floor(p * 2^32); 0 = no element dropout */
+  float scale;          /* 1 / (1 - p) */
+  unsigned pk0, pk1;    /* drop-path key */
+  unsigned pthr;        /* floor(drop_path * 2^32); 0 = none */
+  float pscale;         /* 1 / (1 - drop_path) */
+  int rows_per_sample;  /* drop-path: sample = row / rows_per_sample */
+} dig_dropout_t;
+/* dig_gemm_bf16 with dropout and/or drop-path applied to the result after bias / activation and BEFORE the residual add
+ * (x + drop_path(dropout(linear(h)))); with act 2 the mask multiplies the GELU' product (backward of dropout(gelu(.))) and the
+ * fused column sums see the masked values.  Element index = i * J + j.  Not available for the persistent tiles (bk 132 / 164). */
+int dig_gemm_bf16_dropout(const void* A, const void* B, void* C, int I, int J, int R, int lda, int ldb, int ldc, int trans_a,
+                          int trans_b, int out_kind, const float* bias, const void* resid, int ldr, void* pre_act, int ldp, float alpha,
+                          int alpha_cols, int act, int splits, int a_rows, int b_rows, int bk, float* colsum_partials,
+                          const dig_dropout_t* drop, hipStream_t stream);
+/* out = dropout/drop-path(in) on a [rows, cols] bf16 tensor (cols % 8 == 0, in-place allowed): pos_drop / embedding dropout in the
+ * forward, and the gradient of any dropped branch in the backward (same mask, same scale). */
+int dig_dropout_apply(const void* in, void* out, long long rows, int cols, const dig_dropout_t* drop, hipStream_t stream);
+/* dig_attn_fwd / dig_attn_bwd / dig_seq_attn_fwd / dig_seq_attn_bwd with attention dropout: probabilities are normalised by the
+ * full row sum, then masked and scaled (attn_drop after softmax); drop = NULL or thr = 0 is the plain kernel. */
+int dig_attn_fwd_dropout(const void* qkv, void* ctx, float* lse, int n_img, int heads, int embed_dim, const dig_dropout_t* drop,
+                         hipStream_t stream);
+int dig_attn_bwd_dropout(const void* qkv, const void* ctx, const void* dctx, const float* lse, void* dqkv, int n_img, int heads,
+                         int embed_dim, float scale, float* q_colsum, float* v_colsum, const dig_dropout_t* drop, hipStream_t stream);
+int dig_seq_attn_fwd_dropout(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out, int ldo, float* lse, int B,
+                             int heads, int Lq, int Lk, float scale, int causal, const long long* lens, const dig_dropout_t* drop,
+                             hipStream_t stream);
+int dig_seq_attn_bwd_dropout(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* dout, int ldo,
+                             const float* lse, void* dq, int lddq, void* dk, int lddk, void* dv, int lddv, int B, int heads, int Lq, int Lk,
+                             float scale, int causal, const long long* lens, const dig_dropout_t* drop, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

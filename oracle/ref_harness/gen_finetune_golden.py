@@ -5,7 +5,13 @@ optim_factory.create_optimizer with LayerDecayValueAssigner (run_class_finetunin
 == reference (loss, logits, every gradient, parameters after one AdamW step given the same gradients), writes
 tests/golden/finetune_tiny.npz.
 
-    python oracle/ref_harness/gen_finetune_golden.py        # needs /root/reference (build container only)"""
+    python oracle/ref_harness/gen_finetune_golden.py        # needs /root/reference (build container only)
+    python oracle/ref_harness/gen_finetune_golden.py --drop # the same step with dropout / drop-path -> finetune_tiny_drop.npz
+
+--drop: the reference modules are built with drop_rate / attn_drop_rate / drop_path_rate > 0 and the decoder's default
+dropout 0.1, in train mode; every nn.Dropout / DropPath INSTANCE of the unmodified model has its forward replaced by the keyed
+mask of its site (finetune_oracle.DropOracle), looked up by module name -- the rest of the reference code (where each mask acts,
+its scale, the order of operations) runs as is.  Asserts oracle == reference and writes the fixture."""
 import os
 import sys
 import types
@@ -130,5 +136,117 @@ def main():
     print("wrote tests/golden/finetune_tiny.npz")
 
 
+def patch_dropouts(model, dr, depth, n_layers):
+    """Replace the forward of every stochastic module instance by the site's keyed mask."""
+    import modeling_finetune as MF
+    counts = {}
+
+    def elem(site, p):
+        return lambda x: dr.elem(site, x, p)
+
+    def attn(site, p):
+        return lambda x: dr.attn(site, x, p)
+
+    def twice(name, first, second):
+        def f(x):
+            n = counts.get(name, 0)
+            counts[name] = n + 1
+            return (first if n % 2 == 0 else second)(x)
+        return f
+
+    done = []
+    for name, m in model.named_modules():
+        parts = name.split(".")
+        if isinstance(m, MF.DropPath):                                      # encoder.blocks.i.drop_path: attention branch, then MLP branch
+            i = int(parts[2])
+            m.forward = twice(name, lambda x, i=i: dr.path(F.enc_site(i, 2), x, dr.dpr[i]), lambda x, i=i: dr.path(F.enc_site(i, 4), x, dr.dpr[i]))
+        elif isinstance(m, nn.Dropout):
+            if name.startswith("encoder.blocks."):
+                i = int(parts[2])
+                kind = {"attn.attn_drop": 0, "attn.proj_drop": 1, "mlp.drop": 3}[".".join(parts[3:])]
+                m.forward = (attn if kind == 0 else elem)(F.enc_site(i, kind), dr.attn_drop if kind == 0 else dr.drop)
+            elif name == "decoder.dropout":
+                m.forward = elem(F.DEC_TGT, dr.decoder_dropout)
+            elif name.startswith("decoder.layer_stack."):
+                i = int(parts[2])
+                tail = ".".join(parts[3:])
+                if tail == "mlp.dropout":                                   # used twice: after the activation, after w_2
+                    m.forward = twice(name, elem(F.dec_site(i, 4), dr.decoder_dropout), elem(F.dec_site(i, 5), dr.decoder_dropout))
+                elif tail in ("self_attn.attn_drop", "self_attn.proj_drop", "enc_attn.attn_drop", "enc_attn.proj_drop"):
+                    kind = {"self_attn.attn_drop": 0, "self_attn.proj_drop": 1, "enc_attn.attn_drop": 2, "enc_attn.proj_drop": 3}[tail]
+                    m.forward = (attn if kind in (0, 2) else elem)(F.dec_site(i, kind), dr.decoder_dropout)
+                else:
+                    continue                                                # (mlp_order2cls_attn etc.: not on the tf_decoder path)
+            else:
+                raise AssertionError("unmapped dropout module " + name)
+        else:
+            continue
+        done.append(name)
+    return done
+
+
+def main_drop():
+    refenv.setup()
+    torch.manual_seed(0)
+    from models.decoder import TFDecoder
+    import modeling_pretrain_vit as V
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_seq_ce", os.path.join(refenv.REF, "loss", "seqCrossEntropyLoss.py"))
+    ref_ce = importlib.util.module_from_spec(spec); spec.loader.exec_module(ref_ce)
+    c = D.DecoderConfig(**D.TINY)
+    ecfg = O.DiGConfig(**O.TINY)
+    rates = dict(drop=0.1, attn_drop=0.1, drop_path=0.2, decoder_dropout=0.1)
+    seed, step = 1234, 5
+    enc = V.PretrainVisionTransformerEncoder(img_size=(32, 128), patch_size=4, embed_dim=ecfg.embed_dim, depth=ecfg.depth,
+                                             num_heads=ecfg.heads, mlp_ratio=4, qkv_bias=True, norm_layer=partial(nn.LayerNorm, eps=1e-6),
+                                             num_classes=0, drop_rate=rates["drop"], attn_drop_rate=rates["attn_drop"],
+                                             drop_path_rate=rates["drop_path"])
+    dec = TFDecoder(n_layers=c.n_layers, d_embedding=c.d_model, n_head=c.n_head, d_k=c.d_k, d_v=c.d_k, d_model=c.d_model, d_inner=c.d_inner,
+                    num_classes=c.num_classes, max_seq_len=c.max_seq_len)                  # dropout: the class default (0.1), as create_decoder
+    ln = nn.Sequential(nn.Linear(ecfg.embed_dim, c.d_model), nn.LayerNorm(c.d_model))
+    model = TinyRec(enc, ln, dec).train()
+    dr = F.DropOracle(seed, step, depth=ecfg.depth, **rates)
+    patched = patch_dropouts(model, dr, ecfg.depth, c.n_layers)
+    P = {**D.det_encoder_state(ecfg, 32), **D.det_decoder_state(c, 31)}
+    sd = model.state_dict()
+    for k, v in P.items():
+        sd[k].copy_(v)
+    B = 6
+    images = O.synthetic_batch(B, ecfg, 556)[0]
+    rng = np.random.RandomState(10)
+    lens = torch.from_numpy(rng.randint(1, c.max_seq_len + 1, size=B))
+    targets = torch.from_numpy(rng.randint(0, 94, size=(B, c.max_seq_len)))
+    for b in range(B):
+        targets[b, int(lens[b]) - 1] = 94
+        targets[b, int(lens[b]):] = 95
+    outputs, _, _, _ = model((images, targets, lens))
+    loss = ref_ce.SeqCrossEntropyLoss()(outputs, targets, lens)
+    loss.backward()
+    ref_grads = {n: (p.grad.detach().clone() if p.grad is not None else None) for n, p in model.named_parameters()}
+    o_loss, o_grads, o_logits = F.loss_and_grads(P, ecfg, c, images, targets, lens, drop=dr)
+    assert abs(o_loss - loss.item()) < 1e-5 * abs(loss.item()), (o_loss, loss.item())
+    assert (o_logits - outputs.detach()).abs().max() < 2e-5
+    worst = 0.0
+    for n, g in ref_grads.items():
+        if g is None:
+            assert n == "encoder.mask_token", n
+            continue
+        e = (o_grads[n] - g).abs().max().item() / (g.abs().max().item() + 1e-12)
+        worst = max(worst, e)
+        assert e < 2e-3, (n, e)
+    # the masks matter: the deterministic forward gives a different loss
+    d_loss = F.loss_and_grads(P, ecfg, c, images, targets, lens)[0]
+    assert abs(d_loss - o_loss) > 1e-3 * abs(o_loss)
+    print(f"fine-tune step with dropout: oracle == reference under the keyed masks ({len(patched)} stochastic modules patched; loss {o_loss:.6f} "
+          f"vs {d_loss:.6f} without dropout; worst gradient rel-to-max err {worst:.2e})")
+    names = [n for n in P if ref_grads.get(n) is not None]
+    np.savez_compressed(os.path.join(GOLD, "finetune_tiny_drop.npz"), seed_enc=32, seed_dec=31, B=B, batch_seed=556, targets=targets.numpy(),
+                        lens=lens.numpy(), loss=np.float64(loss.item()), logits=outputs.detach().numpy(), drop_seed=seed, drop_step=step,
+                        rates=np.array([rates["drop"], rates["attn_drop"], rates["drop_path"], rates["decoder_dropout"]]),
+                        grad_names=np.array(names), grad_norms=np.array([ref_grads[n].double().norm().item() for n in names]),
+                        grad_samples=np.stack([np.resize(ref_grads[n].reshape(-1)[sample_index(ref_grads[n].numel())].numpy(), 8) for n in names]))
+    print("wrote tests/golden/finetune_tiny_drop.npz")
+
+
 if __name__ == "__main__":
-    main()
+    main_drop() if "--drop" in sys.argv else main()

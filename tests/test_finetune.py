@@ -1,5 +1,5 @@
-"""Row N1 (fine-tune training step, drop rates 0): the fp32 oracle against the fixture written from the unmodified reference
-(CPU), and the device step against the oracle / fixture (GPU)."""
+"""Row N1 (fine-tune training step, with and without dropout / drop-path): the fp32 oracle against the fixtures written from the
+unmodified reference (CPU), and the device step against the oracle / fixtures (GPU)."""
 import os
 
 import numpy as np
@@ -125,10 +125,11 @@ def test_seq_embedding_and_cross_entropy_kernels_vs_torch():
     assert abs(out.item() - loss.item()) < 1e-4 * abs(loss.item())
 
 
-def _device_model(c, ecfg, P):
+def _device_model(c, ecfg, P, decoder_dropout=0.0, **kw):
+    kw["decoder_dropout"] = decoder_dropout
     from dig_amd.finetune import RecModelTrain
     m = RecModelTrain(embed_dim=ecfg.embed_dim, depth=ecfg.depth, num_heads=ecfg.heads, n_layers=c.n_layers, d_model=c.d_model, n_head=c.n_head,
-                      d_k=c.d_k, d_inner=c.d_inner, nb_classes=c.num_classes, max_len=c.max_seq_len)
+                      d_k=c.d_k, d_inner=c.d_inner, nb_classes=c.num_classes, max_len=c.max_seq_len, **kw)
     m.load_state_dict(P)
     m.to("cuda:0")
     return m.train()
@@ -232,3 +233,210 @@ def test_device_finetune_engine_loop_vs_oracle():
         d_dev, d_ref = sd[n] - P[n], Pn[n] - P[n]
         cosv = torch.nn.functional.cosine_similarity(d_dev.reshape(1, -1), d_ref.reshape(1, -1)).item()
         assert cosv > 0.7 and abs(d_dev.norm().item() / d_ref.norm().item() - 1) < 0.2, (n, cosv)
+
+
+# ---------------------------------------------------------------------------------------------- dropout / drop-path
+def _drop_fixture():
+    g = np.load(os.path.join(GOLD, "finetune_tiny_drop.npz"))
+    c, ecfg = D.DecoderConfig(**D.TINY), O.DiGConfig(**O.TINY)
+    P = {**D.det_encoder_state(ecfg, int(g["seed_enc"])), **D.det_decoder_state(c, int(g["seed_dec"]))}
+    images = O.synthetic_batch(int(g["B"]), ecfg, int(g["batch_seed"]))[0]
+    r = g["rates"]
+    dr = F.DropOracle(int(g["drop_seed"]), int(g["drop_step"]), drop=float(r[0]), attn_drop=float(r[1]), drop_path=float(r[2]), depth=ecfg.depth,
+                      decoder_dropout=float(r[3]))
+    return g, c, ecfg, P, images, torch.from_numpy(g["targets"]), torch.from_numpy(g["lens"]), dr
+
+
+def test_oracle_dropout_step_matches_reference_fixture():
+    """The train-mode restatement with the keyed masks against the unmodified reference run under the same masks."""
+    g, c, ecfg, P, images, targets, lens, dr = _drop_fixture()
+    loss, grads, logits = F.loss_and_grads(P, ecfg, c, images, targets, lens, drop=dr)
+    assert abs(loss - float(g["loss"])) < 1e-5 * float(g["loss"])
+    np.testing.assert_allclose(logits.numpy(), g["logits"], atol=3e-5)
+    for i, n in enumerate(g["grad_names"].tolist()):
+        gi = grads[n]
+        assert abs(gi.double().norm().item() - g["grad_norms"][i]) <= 3e-4 * g["grad_norms"][i] + 1e-7, n
+        got = np.resize(gi.reshape(-1)[_sample_index(gi.numel())].numpy(), 8)
+        np.testing.assert_allclose(got, g["grad_samples"][i], rtol=2e-3, atol=1e-5 * (np.abs(g["grad_samples"][i]).max() + 1e-3))
+
+
+def test_dropout_keys_and_mask_statistics():
+    """Host key derivation (dig_amd.dropout) == the oracle's; the hash keeps 1-p of the elements, without visible correlation between
+    neighbours or between sites."""
+    from dig_amd import dropout as DR
+    dr = F.DropOracle(99, 7, drop=0.1, attn_drop=0.1, drop_path=0.1, depth=12)
+    plan = DR.DropPlan(99, 7)
+    for site in (DR.ENC_POS, DR.enc_site(0, 0), DR.enc_site(11, 4), DR.DEC_TGT, DR.dec_site(5, 5)):
+        assert DR.site_key(plan.step_seed, site) == dr.key(site)
+    assert (DR.enc_site(3, 2), DR.dec_site(4, 1), DR.DEC_TGT) == (F.enc_site(3, 2), F.dec_site(4, 1), F.DEC_TGT)
+    sp = plan.spec(DR.enc_site(2, 1), 0.1, DR.enc_site(2, 2), 0.05, 256)
+    assert sp.thr == F.DropOracle.thr(0.1) == 429496729 and sp.pthr == F.DropOracle.thr(0.05) and sp.rows_per_sample == 256
+    assert abs(sp.scale - 1 / 0.9) < 1e-6 and plan.spec(5, 0.0) is None
+    assert DR.DropPlan(99, 8).step_seed != plan.step_seed                     # fresh masks every step
+    k0, k1 = dr.key(DR.enc_site(1, 1))
+    n = 1 << 21
+    keep = F.keep_mask(k0, k1, np.arange(n, dtype=np.uint32), 0, sp.thr).astype(np.float64)
+    assert abs(keep.mean() - 0.9) < 1e-3
+    z = keep - keep.mean()
+    for lag in (1, 2, 8, 384):
+        assert abs((z[:-lag] * z[lag:]).mean() / z.var()) < 5e-3
+    other = F.keep_mask(*dr.key(DR.enc_site(1, 3)), np.arange(n, dtype=np.uint32), 0, sp.thr).astype(np.float64)
+    assert abs(np.corrcoef(keep, other)[0, 1]) < 5e-3
+
+
+@pytest.mark.gpu
+def test_dropout_kernels_reproduce_the_oracle_masks():
+    """dig_dropout_apply, the GEMM dropout epilogue (forward with residual + drop-path, and the GELU' backward form) and the
+    attention kernels with attention dropout: the keep/drop pattern is the oracle's, bit for bit."""
+    import ctypes
+    from dig_amd import _lib as L, ops, dropout as DR
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(4)
+    dr = F.DropOracle(77, 3, drop=0.1, attn_drop=0.1, drop_path=0.25, depth=4, decoder_dropout=0.1)
+    plan = DR.DropPlan(77, 3)
+    # elementwise + drop-path, [rows, cols] with 8 samples of 24 rows
+    rows, cols, rps = 192, 136, 24
+    x = torch.randn(rows, cols, generator=g).bfloat16()
+    sp = plan.spec(DR.enc_site(1, 1), 0.1, DR.enc_site(1, 2), dr.dpr[3], rps)
+    y = ops.dropout_apply(x.to(dev), sp).float().cpu()
+    want = dr.path(F.enc_site(1, 2), dr.elem(F.enc_site(1, 1), x.float(), 0.1).view(rows // rps, rps, cols), dr.dpr[3]).view(rows, cols)
+    assert torch.equal(y == 0, want == 0) and (y - want).abs().max() <= 2e-2 * want.abs().max()
+    assert 0.05 < (want == 0).float().mean() < 0.6
+    # GEMM epilogue: y = resid + drop_path(dropout(x W^T + b)), both tile families
+    for I, J, R, bk in ((256, 128, 64, 0), (8192, 384, 128, 244)):
+        a = torch.randn(I, R, generator=g).bfloat16(); w = torch.randn(J, R, generator=g).bfloat16()
+        bias = torch.randn(J, generator=g); res = torch.randn(I, J, generator=g).bfloat16()
+        sp = plan.spec(DR.enc_site(2, 3), 0.1, DR.enc_site(2, 4), 0.25, 64)
+        out = ops.gemm(a.to(dev), w.to(dev), I, J, R, bias=bias.to(dev), resid=res.to(dev), bk=bk, drop=sp).float().cpu()
+        lin = a.float() @ w.float().t() + bias
+        want = res.float() + dr.path(F.enc_site(2, 4), dr.elem(F.enc_site(2, 3), lin, 0.1).view(I // 64, 64, J), 0.25).view(I, J)
+        dropped = dr.path(F.enc_site(2, 4), dr.elem(F.enc_site(2, 3), torch.ones(I, J), 0.1).view(I // 64, 64, J), 0.25).view(I, J) == 0
+        assert torch.equal(out[dropped], res.float()[dropped])                  # dropped elements: the residual passes through untouched
+        assert (out - want).abs().max() <= 2e-2 * want.abs().max()
+    # dropout(gelu(.)) forward + backward form (decoder feed-forward): act 1 then mask; act 2 (x gelu') with the same mask
+    I, J, R = 320, 256, 128
+    a = torch.randn(I, R, generator=g).bfloat16(); w = (torch.randn(J, R, generator=g) / R ** 0.5).bfloat16()
+    sp = plan.spec(DR.dec_site(0, 4), 0.1)
+    pre = torch.empty(I, J, device=dev, dtype=torch.bfloat16)
+    u = ops.gemm(a.to(dev), w.to(dev), I, J, R, act=1, pre=pre, bk=32, drop=sp).float().cpu()
+    want = dr.elem(F.dec_site(0, 4), torch.nn.functional.gelu(a.float() @ w.float().t()), 0.1)
+    assert torch.equal(u == 0, want == 0) and (u - want).abs().max() <= 2e-2 * want.abs().max()
+    dy = torch.randn(I, R, generator=g).bfloat16()
+    du, parts = ops.linear_dgrad(dy.to(dev), w.t().contiguous().to(dev), gelu_pre=pre, colsum=True, drop=sp)
+    pf = pre.float().cpu()
+    dgelu = 0.5 * (1 + torch.erf(pf / 2 ** 0.5)) + pf * torch.exp(-0.5 * pf * pf) / (2 * np.pi) ** 0.5
+    want = dr.elem(F.dec_site(0, 4), (dy.float() @ w.float().t()) * dgelu, 0.1)
+    assert torch.equal(du.float().cpu() == 0, want == 0) and (du.float().cpu() - want).abs().max() <= 3e-2 * want.abs().max()
+    assert (parts.sum(0).cpu() - want.sum(0)).abs().max() <= 2e-2 * want.sum(0).abs().max() + 0.2
+
+
+def _attn_ref(q, k, v, mask, dr, site, p):
+    """softmax(q k^T) -> keyed dropout -> @ v with autograd; q pre-scaled; q,k,v [B,H,L,64] fp32 leaves."""
+    s = q @ k.transpose(-2, -1)
+    if mask is not None:
+        s = s.masked_fill(~mask, float("-inf"))
+    return dr.attn(site, s.softmax(-1), p) @ v
+
+
+@pytest.mark.gpu
+def test_attention_dropout_kernels_vs_torch_with_oracle_masks():
+    from dig_amd import _lib as L, ops, dropout as DR
+    import ctypes
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(8)
+    dr = F.DropOracle(5, 11, attn_drop=0.1, decoder_dropout=0.1)
+    plan = DR.DropPlan(5, 11)
+    cf = ctypes.c_float
+    # ---- encoder / cross-attention MFMA kernels: 256 tokens, head dim 64
+    B, H = 3, 2
+    Dm = H * 64
+    qkv = (torch.randn(B * 256, 3 * Dm, generator=g) * 0.7).bfloat16()
+    qkv[:, :Dm] *= 0.125
+    dctx = torch.randn(B * 256, Dm, generator=g).bfloat16()
+    site = DR.enc_site(0, 0)
+    sp = plan.spec(site, 0.1)
+    ctx, lse = ops.attn_fwd(qkv.to(dev), B, H, Dm, drop=sp)
+    dqkv = ops.attn_bwd(qkv.to(dev), ctx, dctx.to(dev), lse, B, H, Dm, 1.0, drop=sp).float().cpu()
+    t = qkv.float().view(B, 256, 3, H, 64).permute(2, 0, 3, 1, 4)
+    q, k, v = (t[i].clone().requires_grad_(True) for i in range(3))
+    o = _attn_ref(q, k, v, None, dr, F.enc_site(0, 0), 0.1)
+    want = o.transpose(1, 2).reshape(B * 256, Dm)
+    assert (ctx.float().cpu() - want.detach()).abs().max() < 3e-2 * want.abs().max()
+    o.backward(dctx.float().view(B, 256, H, 64).transpose(1, 2))
+    wg = torch.stack([q.grad, k.grad, v.grad]).permute(1, 3, 0, 2, 4).reshape(B * 256, 3 * Dm)
+    assert (dqkv - wg).abs().max() < 4e-2 * wg.abs().max()
+    plain_ctx, _ = ops.attn_fwd(qkv.to(dev), B, H, Dm)
+    assert (plain_ctx.float() - ctx.float()).abs().max() > 0.05 * want.abs().max()   # the mask really acts
+    # ---- decoder sequence kernels: causal + length mask (self) and plain (cross, 40 keys)
+    for Lq, Lk, causal in ((8, 8, 1), (8, 40, 0)):
+        B, H = 5, 2
+        hk = H * 64
+        qb = torch.randn(B * Lq, hk, generator=g).bfloat16(); kb = torch.randn(B * Lk, hk, generator=g).bfloat16()
+        vb = torch.randn(B * Lk, hk, generator=g).bfloat16(); do = torch.randn(B * Lq, hk, generator=g).bfloat16()
+        lens = torch.tensor([1, 3, 8, 5, 2]) if causal else None
+        site = DR.dec_site(1, 0 if causal else 2)
+        sp = plan.spec(site, 0.1)
+        out = torch.empty(B * Lq, hk, device=dev, dtype=torch.bfloat16); lse = torch.empty(B, H, Lq, device=dev)
+        qd, kd, vd, dod = qb.to(dev), kb.to(dev), vb.to(dev), do.to(dev)
+        ld = lens.to(dev) if causal else None
+        L.call("dig_seq_attn_fwd_dropout", L.ptr(qd), hk, L.ptr(kd), hk, L.ptr(vd), hk, L.ptr(out), hk, L.ptr(lse), B, H, Lq, Lk, cf(0.125),
+               causal, L.ptr(ld), ctypes.byref(sp), L.stream())
+        dq, dk, dv = (torch.empty_like(t_) for t_ in (qd, kd, vd))
+        L.call("dig_seq_attn_bwd_dropout", L.ptr(qd), hk, L.ptr(kd), hk, L.ptr(vd), hk, L.ptr(dod), hk, L.ptr(lse), L.ptr(dq), hk, L.ptr(dk), hk,
+               L.ptr(dv), hk, B, H, Lq, Lk, cf(0.125), causal, L.ptr(ld), ctypes.byref(sp), L.stream())
+        q = qb.float().view(B, Lq, H, 64).transpose(1, 2).clone().requires_grad_(True)
+        k = kb.float().view(B, Lk, H, 64).transpose(1, 2).clone().requires_grad_(True)
+        v = vb.float().view(B, Lk, H, 64).transpose(1, 2).clone().requires_grad_(True)
+        mask = None
+        if causal:
+            mask = ((torch.arange(Lk)[None, :] < lens[:, None])[:, None, :] & torch.tril(torch.ones(Lq, Lk)).bool()[None])[:, None]
+        o = _attn_ref(q * 0.125, k, v, mask, dr, F.dec_site(1, 0 if causal else 2), 0.1)
+        want = o.transpose(1, 2).reshape(B * Lq, hk)
+        assert (out.float().cpu() - want.detach()).abs().max() < 3e-2 * want.abs().max()
+        o.backward(do.float().view(B, Lq, H, 64).transpose(1, 2))
+        for got, ref in ((dq, q.grad), (dk, k.grad), (dv, v.grad)):
+            r = ref.transpose(1, 2).reshape(got.shape)
+            assert (got.float().cpu() - r).abs().max() < 4e-2 * r.abs().max() + 1e-3
+
+
+@pytest.mark.gpu
+def test_device_finetune_step_with_dropout_vs_reference_fixture():
+    """The whole training step with drop 0.1 / attn_drop 0.1 / drop_path 0.2 / decoder dropout 0.1 against the fixture produced by the
+    unmodified reference under the same keyed masks; yardstick for the gradients = the oracle under CPU bf16 autocast."""
+    from dig_amd.finetune import SeqCrossEntropyLoss
+    g, c, ecfg, P, images, targets, lens, dr = _drop_fixture()
+    r = g["rates"]
+    m = _device_model(c, ecfg, P, decoder_dropout=float(r[3]), drop_rate=float(r[0]), attn_drop_rate=float(r[1]), drop_path_rate=float(r[2]),
+                      drop_seed=int(g["drop_seed"]))
+    m.drop_step = int(g["drop_step"])
+    for p in m.parameters():
+        p.grad.zero_()
+    logits = m((images.to("cuda:0"), targets, lens))[0]
+    assert m.drop_step == int(g["drop_step"]) + 1
+    loss = SeqCrossEntropyLoss()(logits, targets, lens)
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) < 2e-2 * float(g["loss"])
+    ref_logits = torch.from_numpy(g["logits"])
+    assert ((logits.detach().cpu() - ref_logits).norm() / ref_logits.norm()).item() < 2e-2
+    det = F.train_logits(P, ecfg, c, images, targets, lens)                    # without the masks the logits are far away
+    assert ((det - ref_logits).norm() / ref_logits.norm()).item() > 0.1
+    _, ref_g, _ = F.loss_and_grads(P, ecfg, c, images, targets, lens, drop=dr)
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        _, bf_g, _ = F.loss_and_grads(P, ecfg, c, images, targets, lens, drop=dr)
+    grads = {n: p.grad.detach().float().cpu() for n, p in m.named_parameters()}
+    cos = torch.nn.functional.cosine_similarity
+    names, norms = g["grad_names"].tolist(), g["grad_norms"]
+    tot = float(np.sqrt((norms ** 2).sum()))
+    bad = []
+    for i, n in enumerate(names):
+        if norms[i] < 1e-3 * tot:
+            continue
+        rr = ref_g[n].reshape(1, -1)
+        c_hip, c_bf = cos(grads[n].reshape(1, -1), rr).item(), cos(bf_g[n].float().reshape(1, -1), rr).item()
+        q_hip, q_bf = grads[n].norm().item() / norms[i], bf_g[n].float().norm().item() / norms[i]
+        if (1 - c_hip) > 2 * (1 - c_bf) + 5e-3 or abs(q_hip - 1) > 2 * abs(q_bf - 1) + 3e-2:
+            bad.append((n, c_hip, c_bf, q_hip, q_bf))
+    assert not bad, bad
+    # a second forward draws new masks
+    logits2 = m((images.to("cuda:0"), targets, lens))[0]
+    assert (logits2 - logits).abs().max().item() > 1e-2

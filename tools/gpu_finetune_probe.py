@@ -1,14 +1,15 @@
-"""Throughput of the fine-tune training step (row N1, drop rates 0) at the README configuration: simmim_vit_small_patch4_32x128 +
-tf_decoder, 97 classes, max_len 25, batch 256, AdamW with layer decay 0.75; random weights and labels."""
+"""Throughput of the fine-tune training step (row N1) at the README configuration (README.md:92-118): simmim_vit_small_patch4_32x128 +
+tf_decoder, 97 classes, max_len 25, batch 256, --drop 0.1 --attn_drop_rate 0.1 --drop_path 0.1 (decoder dropout 0.1), AdamW with layer
+decay 0.75; random weights and labels.  `--no-drop`: every rate 0 (the deterministic step)."""
 import os, sys, time, types
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dig_amd.finetune import RecModelTrain, SeqCrossEntropyLoss, LayerDecayValueAssigner, create_optimizer
 from dig_amd.utils import NativeScalerWithGradNormCount
 dev = torch.device("cuda:0")
-args = types.SimpleNamespace(model="simmim_vit_small_patch4_32x128", decoder_name="tf_decoder", nb_classes=97, max_len=25, drop=0.0,
-                             attn_drop_rate=0.0, drop_path=0.0, opt="adamw", lr=1e-4, weight_decay=0.05, opt_eps=1e-8, opt_betas=[0.9, 0.999])
-m = RecModelTrain(args)
+args = types.SimpleNamespace(model="simmim_vit_small_patch4_32x128", decoder_name="tf_decoder", nb_classes=97, max_len=25, drop=0.0 if "--no-drop" in sys.argv else 0.1,
+                             attn_drop_rate=0.0 if "--no-drop" in sys.argv else 0.1, drop_path=0.0 if "--no-drop" in sys.argv else 0.1, opt="adamw", lr=1e-4, weight_decay=0.05, opt_eps=1e-8, opt_betas=[0.9, 0.999])
+m = RecModelTrain(args, decoder_dropout=0.0 if "--no-drop" in sys.argv else 0.1)
 g = torch.Generator().manual_seed(0)
 sd = {}
 for k, s in m.param_shapes().items():
@@ -41,4 +42,4 @@ torch.cuda.synchronize(); t = time.perf_counter(); n = 10
 for _ in range(n): loss, gn = step()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t) / n
 flops = B * (3 * 12.089e9)
-print(f"fine-tune step B={B}: {dt*1e3:.1f} ms = {B/dt:.0f} images/s  (loss {loss.item():.3f}, grad norm {gn.item():.3f}; encoder fwd+bwd alone = {flops/1e12:.1f} TFLOP -> {flops/dt/1e12:.0f} TFLOP/s)")
+print(f"fine-tune step ({'no dropout' if '--no-drop' in sys.argv else 'README drop rates'}) B={B}: {dt*1e3:.1f} ms = {B/dt:.0f} images/s  (loss {loss.item():.3f}, grad norm {gn.item():.3f}; encoder fwd+bwd alone = {flops/1e12:.1f} TFLOP -> {flops/dt/1e12:.0f} TFLOP/s)")
