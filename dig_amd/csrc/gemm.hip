@@ -111,7 +111,9 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 // NSTG-stage LDS ring: (NSTG-1) K-tiles of operand data are in flight while one is being multiplied; the hand-off is a
 // counted s_waitcnt vmcnt + raw s_barrier (a __syncthreads() would drain every LDS-DMA in flight).
-template <bool TA, bool TB, int OUT, int BK, bool RES, int NSTG>
+// DROP: the dropout / drop-path epilogue (fine-tune step only) is a separate instantiation, so that the pre-training kernels
+// carry none of its code or registers.
+template <bool TA, bool TB, int OUT, int BK, bool RES, int NSTG, bool DROP = false>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
   constexpr int TILE_BYTES = TileCfg<BK>::TILE_BYTES;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) { v[2 * e] *= dgelu_f(bf2f((bf16_t)(w[e] & 0xffff))); v[2 * e + 1] *= dgelu_f(bf2f((bf16_t)(w[e] >> 16))); }
       }
-      if (p.drop.thr | p.drop.pthr) dig_drop_apply8(v, p.drop, i, j, p.J);
+      if (DROP) dig_drop_apply8(v, p.drop, i, j, p.J);
       if (RES && p.act == 2 && live) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) csum[e] += v[e];
@@ -598,7 +600,7 @@ struct WideCfg {
 // BK = 64 / NSTG = 2: one stage in flight (wait-all hand-off).  BK = 32 / NSTG = 4: three half-depth stages in flight with a
 // counted s_waitcnt vmcnt -- a 256x256x32 step is long enough (about 0.4 us of MFMA) for that look-ahead to cover the
 // L2/HBM -> LDS latency, which a 128x128 tile's step is not.
-template <bool TA, bool TB, int OUT, int WM, int WN, int FM, int FN, bool RES, int BK, int NSTG>
+template <bool TA, bool TB, int OUT, int WM, int WN, int FM, int FN, bool RES, int BK, int NSTG, bool DROP = false>
 __global__ __launch_bounds__(64 * WM * WN, (BK == 32 && WM * WN == 8 && FM * FN == 4) ? 4 : ((BK == 32 && WM * WN == 4) ? 2 : 1)) void gemm_wide_kernel(GemmParams p) {
   using Cfg = WideCfg<WM, WN, FM, FN, BK, NSTG>;
   static_assert(FN % 2 == 0 && Cfg::NITA <= 8 && Cfg::NITB <= 8, "tile shape");
@@ -768,7 +770,7 @@ __global__ __launch_bounds__(64 * WM * WN, (BK == 32 && WM * WN == 8 && FM * FN 
 #pragma unroll
         for (int e = 0; e < 4; ++e) { v[2 * e] *= dgelu_f(bf2f((bf16_t)(w[e] & 0xffff))); v[2 * e + 1] *= dgelu_f(bf2f((bf16_t)(w[e] >> 16))); }
       }
-      if (p.drop.thr | p.drop.pthr) dig_drop_apply8(v, p.drop, i, j, p.J);
+      if (DROP) dig_drop_apply8(v, p.drop, i, j, p.J);
       if (RES && p.act == 2 && live) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) csum[e] += v[e];
@@ -809,12 +811,12 @@ __global__ __launch_bounds__(64 * WM * WN, (BK == 32 && WM * WN == 8 && FM * FN 
   }
 }
 
-template <bool TA, bool TB, int OUT, int WM, int WN, int FM, int FN, bool RES, int BK, int NSTG>
+template <bool TA, bool TB, int OUT, int WM, int WN, int FM, int FN, bool RES, int BK, int NSTG, bool DROP = false>
 int launch_wide(GemmParams p, int splits, hipStream_t stream) {
   using Cfg = WideCfg<WM, WN, FM, FN, BK, NSTG>;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wide_kernel<TA, TB, OUT, WM, WN, FM, FN, RES, BK, NSTG>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wide_kernel<TA, TB, OUT, WM, WN, FM, FN, RES, BK, NSTG, DROP>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
     attr_set = true;
   }
@@ -822,7 +824,7 @@ int launch_wide(GemmParams p, int splits, hipStream_t stream) {
   p.tiles_j = (p.J + Cfg::TBJ - 1) / Cfg::TBJ;
   p.splits_x = (splits > 1 && splits % 8 == 0) ? splits : 0;
   dim3 grid(p.tiles_i * p.tiles_j * (p.splits_x ? splits : 1), 1, p.splits_x ? 1 : splits);
-  hipLaunchKernelGGL((gemm_wide_kernel<TA, TB, OUT, WM, WN, FM, FN, RES, BK, NSTG>), grid, dim3(Cfg::NT), Cfg::LDS, stream, p);
+  hipLaunchKernelGGL((gemm_wide_kernel<TA, TB, OUT, WM, WN, FM, FN, RES, BK, NSTG, DROP>), grid, dim3(Cfg::NT), Cfg::LDS, stream, p);
   return dig_check_launch();
 }
 
@@ -839,19 +841,19 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
   }
 }
 
-template <bool TA, bool TB, int OUT, int BK, bool RES, int NSTG>
+template <bool TA, bool TB, int OUT, int BK, bool RES, int NSTG, bool DROP = false>
 int launch(const GemmParams& p, int splits, hipStream_t stream) {
   constexpr int LDS = (NSTG * 2 * BI * BK * 2) > 32768 ? (NSTG * 2 * BI * BK * 2) : 32768;   // ring; >= epilogue staging
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<TA, TB, OUT, BK, RES, NSTG>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<TA, TB, OUT, BK, RES, NSTG, DROP>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_set = true;
   }
   GemmParams q = p;
   q.splits_x = (splits > 1 && splits % 8 == 0) ? splits : 0;
   dim3 grid(p.tiles_i * p.tiles_j * (q.splits_x ? splits : 1), 1, q.splits_x ? 1 : splits);
-  hipLaunchKernelGGL((gemm_kernel<TA, TB, OUT, BK, RES, NSTG>), grid, dim3(256), LDS, stream, q);
+  hipLaunchKernelGGL((gemm_kernel<TA, TB, OUT, BK, RES, NSTG, DROP>), grid, dim3(256), LDS, stream, q);
   return dig_check_launch();
 }
 
@@ -864,8 +866,10 @@ extern "C" int dig_gemm_bf16_dropout(const void* A, const void* B, void* C, int 
                                      int b_rows, int bk, float* colsum_partials, const dig_dropout_t* drop,
                                      hipStream_t stream) {
   if (!A || !B || !C || I <= 0 || J <= 0 || R <= 0 || splits < 1) return DIG_ERR_ARG;
-  if (drop && (drop->thr || drop->pthr)) {
-    if (out_kind == 2 || (bk >= 100 && bk < 200)) return DIG_ERR_UNSUPPORTED;      // the persistent variant has no dropout epilogue
+  const bool dropping = drop && (drop->thr || drop->pthr);
+  if (dropping) {
+    // instantiated for the tiles the fine-tune step uses: 128x128 (bk 0 / 64 / 32) forward and dgrad, 256x256 (bk 244) forward
+    if (out_kind != 0 || trans_a || !(bk == 0 || bk == 32 || bk == 64 || (bk == 244 && !trans_b))) return DIG_ERR_UNSUPPORTED;
     if ((size_t)I * (size_t)J >= (1ull << 32) || (drop->pthr && drop->rows_per_sample <= 0)) return DIG_ERR_ARG;
   }
   if (bias && !aligned16(bias)) return DIG_ERR_ALIGN;
@@ -900,6 +904,15 @@ extern "C" int dig_gemm_bf16_dropout(const void* A, const void* B, void* C, int 
   p.r_per_split = ((rtiles + splits - 1) / splits) * BR;
   if ((R + p.r_per_split - 1) / p.r_per_split != splits) return DIG_ERR_ARG;   // use dig_gemm_effective_splits()
   p.tiles_i = (I + BI - 1) / BI; p.tiles_j = (J + BJ - 1) / BJ;
+  if (dropping) {
+    if (bk == 244) return resid ? launch_wide<false, false, 0, 4, 4, 2, 2, true, 64, 2, true>(p, splits, stream)
+                                : launch_wide<false, false, 0, 4, 4, 2, 2, false, 64, 2, true>(p, splits, stream);
+    if (!trans_b)
+      return bk == 32 ? (resid ? launch<false, false, 0, 32, true, 2, true>(p, splits, stream) : launch<false, false, 0, 32, false, 2, true>(p, splits, stream))
+                      : (resid ? launch<false, false, 0, 64, true, 2, true>(p, splits, stream) : launch<false, false, 0, 64, false, 2, true>(p, splits, stream));
+    return bk == 32 ? (resid ? launch<false, true, 0, 32, true, 2, true>(p, splits, stream) : launch<false, true, 0, 32, false, 2, true>(p, splits, stream))
+                    : (resid ? launch<false, true, 0, 64, true, 2, true>(p, splits, stream) : launch<false, true, 0, 64, false, 2, true>(p, splits, stream));
+  }
 #define DIG_GEMM_WCASE(ta, tb, o)                                                                                   \
   if ((trans_a != 0) == ta && (trans_b != 0) == tb && out_kind == o && bk >= 200) {                                  \
     if (bk == 422) return resid ? launch_wide<ta, tb, o, 2, 2, 4, 2, true, 32, 2>(p, splits, stream) : launch_wide<ta, tb, o, 2, 2, 4, 2, false, 32, 2>(p, splits, stream); \

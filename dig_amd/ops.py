@@ -54,11 +54,11 @@ def linear_fwd(x, w, *, bias=None, resid=None, act=0, pre=None, alpha=1.0, alpha
     #   tall layers: 256x256 tiles (16 waves) halve the L2->LDS operand traffic per FLOP;  small GELU layers: BK=32,
     #   4 workgroups/CU hide the VALU + double-store epilogue;  everything else: the default 128x128 / BK=64.
     rows = x.shape[0]
-    if rows >= 8192 and w.shape[0] >= 384 and rows * w.shape[0] >= (1 << 24):
+    if rows >= 8192 and w.shape[0] >= 384 and rows * w.shape[0] >= (1 << 24) and not (drop is not None and act):
         bk = 244
     elif act == 1:
         bk = 32
-    elif rows <= 2048 and w.shape[0] <= 512 and K >= 2048:
+    elif rows <= 2048 and w.shape[0] <= 512 and K >= 2048 and drop is None:
         bk = 212                                        # few output tiles, long K: 64x128 tiles for more workgroups
     else:
         bk = 0
