@@ -50,7 +50,15 @@ def stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_fns = {}
+
+
 def call(name, *args):
-    f = getattr(lib(), name)
-    f.restype = ctypes.c_int
-    check(f(*args), name)
+    f = _fns.get(name)
+    if f is None:
+        f = getattr(lib(), name)
+        f.restype = ctypes.c_int
+        _fns[name] = f
+    rc = f(*args)
+    if rc:
+        check(rc, name)

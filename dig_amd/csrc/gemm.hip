@@ -50,8 +50,13 @@ struct GemmParams {
   int tiles_i, tiles_j;
   float* colsum;                          // act 2 only: [ceil(I/64)][J] per-64-row column sums of the result (fp32), or null
   int splits_x;                           // >0: 1-D grid of tiles*splits blocks, every R-split pinned to one XCD
-  dig_dropout_t drop;                     // dropout / drop-path of the result before the residual add (thr = pthr = 0: off)
 };
+// dropout / drop-path of the result before the residual add: a second kernel argument of the DROP instantiations only (the plain
+// kernels take a 4-byte dummy, their GemmParams and code stay what they were)
+template <bool DROP> struct DropArg { int unused; };
+template <> struct DropArg<true> { dig_dropout_t d; };
+__device__ __forceinline__ void epilogue_drop(float (&v)[8], const DropArg<true>& a, int i, int j, int cols) { dig_drop_apply8(v, a.d, i, j, cols); }
+__device__ __forceinline__ void epilogue_drop(float (&)[8], const DropArg<false>&, int, int, int) {}
 
 constexpr int BI = 128, BJ = 128;
 constexpr int BR = 64;                   // granule of the reduction dim (R % 64 rule for direct operands, split slabs)
@@ -114,7 +119,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 // DROP: the dropout / drop-path epilogue (fine-tune step only) is a separate instantiation, so that the pre-training kernels
 // carry none of its code or registers.
 template <bool TA, bool TB, int OUT, int BK, bool RES, int NSTG, bool DROP = false>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
+__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p, DropArg<DROP> da) {
   constexpr int TILE_BYTES = TileCfg<BK>::TILE_BYTES;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -282,15 +287,18 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
               make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+        if (DROP) epilogue_drop(v, da, i, j, p.J);
       } else if (RES && p.act == 2) {                              // multiply by gelu'(pre): fused GELU backward (fc2 dgrad)
         const unsigned w[4] = {rres[ps].x, rres[ps].y, rres[ps].z, rres[ps].w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) { v[2 * e] *= dgelu_f(bf2f((bf16_t)(w[e] & 0xffff))); v[2 * e + 1] *= dgelu_f(bf2f((bf16_t)(w[e] >> 16))); }
-      }
-      if (DROP) dig_drop_apply8(v, p.drop, i, j, p.J);
-      if (RES && p.act == 2 && live) {
+        if (DROP) epilogue_drop(v, da, i, j, p.J);
+        if (live) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) csum[e] += v[e];
+          for (int e = 0; e < 8; ++e) csum[e] += v[e];
+        }
+      } else if (DROP) {
+        epilogue_drop(v, da, i, j, p.J);
       }
       if (RES && p.act != 2) {
         const unsigned w[4] = {rres[ps].x, rres[ps].y, rres[ps].z, rres[ps].w};
@@ -601,7 +609,7 @@ struct WideCfg {
 // counted s_waitcnt vmcnt -- a 256x256x32 step is long enough (about 0.4 us of MFMA) for that look-ahead to cover the
 // L2/HBM -> LDS latency, which a 128x128 tile's step is not.
 template <bool TA, bool TB, int OUT, int WM, int WN, int FM, int FN, bool RES, int BK, int NSTG, bool DROP = false>
-__global__ __launch_bounds__(64 * WM * WN, (BK == 32 && WM * WN == 8 && FM * FN == 4) ? 4 : ((BK == 32 && WM * WN == 4) ? 2 : 1)) void gemm_wide_kernel(GemmParams p) {
+__global__ __launch_bounds__(64 * WM * WN, (BK == 32 && WM * WN == 8 && FM * FN == 4) ? 4 : ((BK == 32 && WM * WN == 4) ? 2 : 1)) void gemm_wide_kernel(GemmParams p, DropArg<DROP> da) {
   using Cfg = WideCfg<WM, WN, FM, FN, BK, NSTG>;
   static_assert(FN % 2 == 0 && Cfg::NITA <= 8 && Cfg::NITB <= 8, "tile shape");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -765,15 +773,18 @@ __global__ __launch_bounds__(64 * WM * WN, (BK == 32 && WM * WN == 8 && FM * FN 
               make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+        if (DROP) epilogue_drop(v, da, i, j, p.J);
       } else if (RES && p.act == 2) {
         const unsigned w[4] = {rres[q4].x, rres[q4].y, rres[q4].z, rres[q4].w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) { v[2 * e] *= dgelu_f(bf2f((bf16_t)(w[e] & 0xffff))); v[2 * e + 1] *= dgelu_f(bf2f((bf16_t)(w[e] >> 16))); }
-      }
-      if (DROP) dig_drop_apply8(v, p.drop, i, j, p.J);
-      if (RES && p.act == 2 && live) {
+        if (DROP) epilogue_drop(v, da, i, j, p.J);
+        if (live) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) csum[e] += v[e];
+          for (int e = 0; e < 8; ++e) csum[e] += v[e];
+        }
+      } else if (DROP) {
+        epilogue_drop(v, da, i, j, p.J);
       }
       if (RES && p.act != 2) {
         const unsigned w[4] = {rres[q4].x, rres[q4].y, rres[q4].z, rres[q4].w};
@@ -812,7 +823,7 @@ __global__ __launch_bounds__(64 * WM * WN, (BK == 32 && WM * WN == 8 && FM * FN 
 }
 
 template <bool TA, bool TB, int OUT, int WM, int WN, int FM, int FN, bool RES, int BK, int NSTG, bool DROP = false>
-int launch_wide(GemmParams p, int splits, hipStream_t stream) {
+int launch_wide(GemmParams p, int splits, hipStream_t stream, DropArg<DROP> da = DropArg<DROP>{}) {
   using Cfg = WideCfg<WM, WN, FM, FN, BK, NSTG>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -824,7 +835,7 @@ int launch_wide(GemmParams p, int splits, hipStream_t stream) {
   p.tiles_j = (p.J + Cfg::TBJ - 1) / Cfg::TBJ;
   p.splits_x = (splits > 1 && splits % 8 == 0) ? splits : 0;
   dim3 grid(p.tiles_i * p.tiles_j * (p.splits_x ? splits : 1), 1, p.splits_x ? 1 : splits);
-  hipLaunchKernelGGL((gemm_wide_kernel<TA, TB, OUT, WM, WN, FM, FN, RES, BK, NSTG, DROP>), grid, dim3(Cfg::NT), Cfg::LDS, stream, p);
+  hipLaunchKernelGGL((gemm_wide_kernel<TA, TB, OUT, WM, WN, FM, FN, RES, BK, NSTG, DROP>), grid, dim3(Cfg::NT), Cfg::LDS, stream, p, da);
   return dig_check_launch();
 }
 
@@ -842,7 +853,7 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
 }
 
 template <bool TA, bool TB, int OUT, int BK, bool RES, int NSTG, bool DROP = false>
-int launch(const GemmParams& p, int splits, hipStream_t stream) {
+int launch(const GemmParams& p, int splits, hipStream_t stream, DropArg<DROP> da = DropArg<DROP>{}) {
   constexpr int LDS = (NSTG * 2 * BI * BK * 2) > 32768 ? (NSTG * 2 * BI * BK * 2) : 32768;   // ring; >= epilogue staging
   static bool attr_set = false;
   if (!attr_set) {
@@ -853,7 +864,7 @@ int launch(const GemmParams& p, int splits, hipStream_t stream) {
   GemmParams q = p;
   q.splits_x = (splits > 1 && splits % 8 == 0) ? splits : 0;
   dim3 grid(p.tiles_i * p.tiles_j * (q.splits_x ? splits : 1), 1, q.splits_x ? 1 : splits);
-  hipLaunchKernelGGL((gemm_kernel<TA, TB, OUT, BK, RES, NSTG, DROP>), grid, dim3(256), LDS, stream, q);
+  hipLaunchKernelGGL((gemm_kernel<TA, TB, OUT, BK, RES, NSTG, DROP>), grid, dim3(256), LDS, stream, q, da);
   return dig_check_launch();
 }
 
@@ -890,7 +901,6 @@ extern "C" int dig_gemm_bf16_dropout(const void* A, const void* B, void* C, int 
   GemmParams p;
   p.splits_x = 0;
   p.colsum = colsum_partials;
-  if (drop) p.drop = *drop; else { p.drop.thr = 0; p.drop.pthr = 0; }
   p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C;
   p.I = I; p.J = J; p.R = R; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
   // a_rows / b_rows (0 = default) bound the rows that really exist in memory; rows past them read as zero.
@@ -905,13 +915,14 @@ extern "C" int dig_gemm_bf16_dropout(const void* A, const void* B, void* C, int 
   if ((R + p.r_per_split - 1) / p.r_per_split != splits) return DIG_ERR_ARG;   // use dig_gemm_effective_splits()
   p.tiles_i = (I + BI - 1) / BI; p.tiles_j = (J + BJ - 1) / BJ;
   if (dropping) {
-    if (bk == 244) return resid ? launch_wide<false, false, 0, 4, 4, 2, 2, true, 64, 2, true>(p, splits, stream)
-                                : launch_wide<false, false, 0, 4, 4, 2, 2, false, 64, 2, true>(p, splits, stream);
+    const DropArg<true> da{*drop};
+    if (bk == 244) return resid ? launch_wide<false, false, 0, 4, 4, 2, 2, true, 64, 2, true>(p, splits, stream, da)
+                                : launch_wide<false, false, 0, 4, 4, 2, 2, false, 64, 2, true>(p, splits, stream, da);
     if (!trans_b)
-      return bk == 32 ? (resid ? launch<false, false, 0, 32, true, 2, true>(p, splits, stream) : launch<false, false, 0, 32, false, 2, true>(p, splits, stream))
-                      : (resid ? launch<false, false, 0, 64, true, 2, true>(p, splits, stream) : launch<false, false, 0, 64, false, 2, true>(p, splits, stream));
-    return bk == 32 ? (resid ? launch<false, true, 0, 32, true, 2, true>(p, splits, stream) : launch<false, true, 0, 32, false, 2, true>(p, splits, stream))
-                    : (resid ? launch<false, true, 0, 64, true, 2, true>(p, splits, stream) : launch<false, true, 0, 64, false, 2, true>(p, splits, stream));
+      return bk == 32 ? (resid ? launch<false, false, 0, 32, true, 2, true>(p, splits, stream, da) : launch<false, false, 0, 32, false, 2, true>(p, splits, stream, da))
+                      : (resid ? launch<false, false, 0, 64, true, 2, true>(p, splits, stream, da) : launch<false, false, 0, 64, false, 2, true>(p, splits, stream, da));
+    return bk == 32 ? (resid ? launch<false, true, 0, 32, true, 2, true>(p, splits, stream, da) : launch<false, true, 0, 32, false, 2, true>(p, splits, stream, da))
+                    : (resid ? launch<false, true, 0, 64, true, 2, true>(p, splits, stream, da) : launch<false, true, 0, 64, false, 2, true>(p, splits, stream, da));
   }
 #define DIG_GEMM_WCASE(ta, tb, o)                                                                                   \
   if ((trans_a != 0) == ta && (trans_b != 0) == tb && out_kind == o && bk >= 200) {                                  \

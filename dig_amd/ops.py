@@ -35,14 +35,16 @@ def gemm(A, B, I, J, R, *, ta=False, tb=False, out=None, out_kind=OUT_BF16, bias
         out = torch.empty((I, J), device=A.device, dtype=BF16 if out_kind == OUT_BF16 else F32)
     if not bk:
         bk = GEMM_BK_FWD if not (ta or tb) else GEMM_BK_BWD
-    args = (L.ptr(A), L.ptr(B), L.ptr(out), I, J, R, A.stride(0), B.stride(0),
-            out.stride(0) if ldc is None else ldc, int(ta), int(tb), out_kind, L.ptr(bias), L.ptr(resid),
-            resid.stride(0) if resid is not None else 0, L.ptr(pre), pre.stride(0) if pre is not None else 0, cf(alpha),
-            alpha_cols, act, splits, a_rows, b_rows, bk, L.ptr(colsum_partials))
     if drop is None:
-        L.call("dig_gemm_bf16", *args, L.stream())
+        L.call("dig_gemm_bf16", L.ptr(A), L.ptr(B), L.ptr(out), I, J, R, A.stride(0), B.stride(0),
+               out.stride(0) if ldc is None else ldc, int(ta), int(tb), out_kind, L.ptr(bias), L.ptr(resid),
+               resid.stride(0) if resid is not None else 0, L.ptr(pre), pre.stride(0) if pre is not None else 0, cf(alpha),
+               alpha_cols, act, splits, a_rows, b_rows, bk, L.ptr(colsum_partials), L.stream())
     else:
-        L.call("dig_gemm_bf16_dropout", *args, ctypes.byref(drop), L.stream())
+        L.call("dig_gemm_bf16_dropout", L.ptr(A), L.ptr(B), L.ptr(out), I, J, R, A.stride(0), B.stride(0),
+               out.stride(0) if ldc is None else ldc, int(ta), int(tb), out_kind, L.ptr(bias), L.ptr(resid),
+               resid.stride(0) if resid is not None else 0, L.ptr(pre), pre.stride(0) if pre is not None else 0, cf(alpha),
+               alpha_cols, act, splits, a_rows, b_rows, bk, L.ptr(colsum_partials), ctypes.byref(drop), L.stream())
     return out
 
 
