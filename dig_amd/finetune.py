@@ -11,7 +11,7 @@ come from a keyed counter hash instead of torch's generator, see dig_amd/dropout
 Parameters, gradients, Adam moments and the bf16 GEMM operands live in flat arenas (each tensor padded to 256 elements) whose
 layout keeps q|k|v (and k|v) projection weights adjacent, so the fused projections are views.  The whole model is ONE autograd
 node with a hand-written backward on the hot-path kernels (encoder: the pre-training kernels; decoder: `dig_seq_attn_*`,
-`dig_seq_embed_*`, `dig_gemm_bf16`, `dig_layernorm_*`).  Oracle: oracle/finetune_oracle.py, pinned to the reference."""
+`dig_seq_embed_*`, `dig_gemm_bf16`, `dig_layernorm_*`).  The CPU checker of this step lives with the tests."""
 import ctypes
 import math
 from collections import OrderedDict
