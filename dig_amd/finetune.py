@@ -161,6 +161,8 @@ class FlatGradComm:
         self.dist, self.group = dist, process_group
         self.world, self.rank = dist.get_world_size(process_group), dist.get_rank(process_group)
         dist.broadcast(model.flat_params, src=0, group=process_group)
+        # every rank draws its own dropout masks (the reference seeds each rank with args.seed + rank, run_class_finetuning.py:262-264)
+        model.drop_seed = (int(model.drop_seed) + 0x9E3779B97F4A7C15 * self.rank) & ((1 << 64) - 1)
 
     def finish_grad_sync(self, model):
         self.dist.all_reduce(model.flat_grads, group=self.group)

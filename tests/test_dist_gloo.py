@@ -198,3 +198,116 @@ def _engine_worker(rank, world, port, golden_dir, q):
 @pytest.mark.gpu
 def test_engine_two_ranks_on_one_gpu_matches_reference_ddp_fixtures(golden_dir):
     _run(_engine_worker, 2, golden_dir)
+
+
+# ---------------------------------------------------------------------------------------------- fine-tune step (row N1)
+def _ft_model(dev=None, **kw):
+    import decode_oracle as D
+    from dig_amd.finetune import RecModelTrain
+    c, ecfg = D.DecoderConfig(**D.TINY), O.DiGConfig(**O.TINY)
+    P = {**D.det_encoder_state(ecfg, 32), **D.det_decoder_state(c, 31)}
+    m = RecModelTrain(embed_dim=ecfg.embed_dim, depth=ecfg.depth, num_heads=ecfg.heads, n_layers=c.n_layers, d_model=c.d_model, n_head=c.n_head,
+                      d_k=c.d_k, d_inner=c.d_inner, nb_classes=c.num_classes, max_len=c.max_seq_len, **kw)
+    m.load_state_dict(P)
+    if dev is not None:
+        m.to(dev)
+    return m, c, ecfg
+
+
+def _ft_comm_worker(rank, world, port, q):
+    """FlatGradComm on CPU arenas: parameter broadcast, one averaged all-reduce of the flat gradient arena, per-rank mask seeds."""
+    try:
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from dig_amd.finetune import FlatGradComm
+        m, _, _ = _ft_model(drop_seed=5)
+        m.flat_params.add_(float(rank))                                        # ranks start apart
+        comm = FlatGradComm(m)
+        ref = m.flat_params.clone()
+        dist.broadcast(ref, src=0)
+        assert torch.equal(ref, m.flat_params)
+        gen = torch.Generator().manual_seed(3 + rank)
+        m.flat_grads.copy_(torch.randn(m.flat_grads.shape, generator=gen))
+        tot = m.flat_grads.clone()
+        dist.all_reduce(tot)
+        comm.finish_grad_sync(m)
+        torch.testing.assert_close(m.flat_grads, tot / world, rtol=1e-6, atol=1e-7)
+        seeds = [None] * world
+        dist.all_gather_object(seeds, m.drop_seed)
+        assert len(set(seeds)) == world and seeds[0] == 5
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_finetune_comm_world2():
+    _run(_ft_comm_worker, 2)
+
+
+def _ft_engine_worker(rank, world, port, q):
+    """The fine-tune step on `world` ranks sharing one MI355X: `world` x B samples == one process on the concatenated batch
+    (SeqCrossEntropyLoss is a per-rank mean over B; the averaged all-reduce makes it the global mean), rates 0."""
+    try:
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import types
+        from dig_amd.finetune import FlatGradComm, SeqCrossEntropyLoss, LayerDecayValueAssigner, create_optimizer
+        from dig_amd.utils import NativeScalerWithGradNormCount
+        dev = torch.device("cuda:0")
+
+        model, c, ecfg = _ft_model(dev, decoder_dropout=0.0)
+
+        def batch(r, B=4):
+            rng = np.random.RandomState(40 + r)
+            lens = torch.from_numpy(rng.randint(1, c.max_seq_len + 1, size=B))
+            tg = torch.from_numpy(rng.randint(0, 94, size=(B, c.max_seq_len)))
+            for b in range(B):
+                tg[b, int(lens[b]) - 1] = 94
+                tg[b, int(lens[b]):] = 95
+            return O.synthetic_batch(B, ecfg, 900 + r)[0], tg, lens
+
+        def one_step(model, data):
+            nl = model.get_num_layers()
+            asg = LayerDecayValueAssigner([0.75 ** (nl + 1 - i) for i in range(nl + 2)])
+            args = types.SimpleNamespace(opt="adamw", lr=1e-3, weight_decay=0.05, opt_eps=1e-8, opt_betas=None)
+            opt = create_optimizer(args, model, get_num_layer=asg.get_layer_id, get_layer_scale=asg.get_scale)
+            for grp in opt.param_groups:
+                grp["lr"] = args.lr * grp["lr_scale"]
+            opt.zero_grad()
+            im, tg, ln = data
+            loss = SeqCrossEntropyLoss()(model((im.to(dev), tg, ln))[0], tg, ln)
+            norm = NativeScalerWithGradNormCount()(loss, opt, clip_grad=None, parameters=None)
+            return loss.item(), float(norm)
+
+        model.comm = FlatGradComm(model)
+        one_step(model, batch(rank))
+        flat = model.flat_grads.detach().clone()
+        other = flat.clone()
+        dist.broadcast(other, src=0)
+        assert torch.equal(flat, other)                                         # identical averaged gradients on every rank
+        pa = model.flat_params.detach().clone()
+        pb = pa.clone()
+        dist.broadcast(pb, src=0)
+        assert torch.equal(pa, pb)                                              # and identical parameters after the step
+        solo, _, _ = _ft_model(dev, decoder_dropout=0.0)
+        parts = [batch(r) for r in range(world)]
+        one_step(solo, tuple(torch.cat([p[i] for p in parts]) for i in range(3)))
+        a, b = flat.double(), solo.flat_grads.detach().double()
+        cosv = float((a * b).sum() / (a.norm() * b.norm()))
+        assert cosv > 0.999 and abs(float(a.norm() / b.norm()) - 1) < 1e-2, (cosv, float(a.norm() / b.norm()))
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_finetune_two_ranks_on_one_gpu_data_parallel_invariance():
+    _run(_ft_engine_worker, 2)
