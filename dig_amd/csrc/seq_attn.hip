@@ -215,11 +215,14 @@ __global__ __launch_bounds__(256) void seq_embed_fwd_kernel(const long long* __r
   x[i] = f2bf(emb[(size_t)t * d + c] + pos[(size_t)(r % T) * d + c]);
 }
 
-// demb[v, :] += sum over the tokens equal to v of dx[token row, :].  One block per vocabulary row: the matching token rows are
-// first collected IN ORDER (ballot + prefix per 256-token chunk), then every thread sums its channels over that list -- a fixed
-// summation order (deterministic) without scanning the whole token list once per channel.
+// demb[v, :] += sum over the tokens equal to v of dx[token row, :].  One block per (vocabulary row, 256-channel chunk): the matching
+// token rows are first collected IN ORDER (ballot + prefix per 256-token chunk), then every thread sums its channel over that
+// list -- a fixed summation order (deterministic).  With `lens`, positions t >= lens[b] are skipped: under teacher forcing their
+// dx rows are exact zeros (no loss term, causal + length masks), and the padding token would otherwise make one block sum half
+// of all rows.
 __global__ __launch_bounds__(256) void seq_embed_bwd_kernel(const long long* __restrict__ tok, const bf16_t* __restrict__ dx,
-                                                            float* __restrict__ demb, int n_tok, int d) {
+                                                            float* __restrict__ demb, int n_tok, int d, int T,
+                                                            const long long* __restrict__ lens) {
   extern __shared__ int list[];                                         // [n_tok] matching rows, ascending
   __shared__ int wcount[4];
   __shared__ int total;
@@ -228,7 +231,8 @@ __global__ __launch_bounds__(256) void seq_embed_bwd_kernel(const long long* __r
   __syncthreads();
   for (int r0 = 0; r0 < n_tok; r0 += 256) {
     const int r = r0 + tid;
-    const bool hit = r < n_tok && tok[r] == v;
+    bool hit = r < n_tok && tok[r] == v;
+    if (hit && lens) hit = (r % T) < lens[r / T];
     const unsigned long long bal = __ballot(hit);
     if (lane == 0) wcount[wave] = __popcll(bal);
     __syncthreads();
@@ -241,11 +245,16 @@ __global__ __launch_bounds__(256) void seq_embed_bwd_kernel(const long long* __r
   }
   const int n = total;
   if (n == 0) return;
-  for (int c = tid; c < d; c += 256) {
-    float a = 0.f;
-    for (int k = 0; k < n; ++k) a += bf2f(dx[(size_t)list[k] * d + c]);
-    demb[(size_t)v * d + c] += a;
+  const int c = blockIdx.y * 256 + tid;
+  if (c >= d) return;
+  float a0 = 0.f, a1 = 0.f;                                             // two chains, fixed pairing: still one order
+  int k = 0;
+  for (; k + 1 < n; k += 2) {
+    a0 += bf2f(dx[(size_t)list[k] * d + c]);
+    a1 += bf2f(dx[(size_t)list[k + 1] * d + c]);
   }
+  if (k < n) a0 += bf2f(dx[(size_t)list[k] * d + c]);
+  demb[(size_t)v * d + c] += a0 + a1;
 }
 
 // dlogits[b,t,:] = g * (softmax(logits[b,t,:]) - onehot(target)) / B for t < length[b], else 0  (gradient of SeqCrossEntropyLoss)
@@ -325,11 +334,18 @@ extern "C" int dig_seq_embed_fwd(const long long* tokens, const float* emb, cons
   return dig_check_launch();
 }
 
-extern "C" int dig_seq_embed_bwd(const long long* tokens, const void* dx, float* demb, int n_tok, int d, int vocab, hipStream_t stream) {
+extern "C" int dig_seq_embed_bwd_lens(const long long* tokens, const void* dx, float* demb, int n_tok, int d, int vocab, int T,
+                                      const long long* lens, hipStream_t stream) {
   if (!tokens || !dx || !demb || n_tok <= 0 || d <= 0 || vocab <= 0) return DIG_ERR_ARG;
+  if (lens && (T <= 0 || n_tok % T)) return DIG_ERR_ARG;
   if ((size_t)n_tok * sizeof(int) > 60 * 1024) return DIG_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(seq_embed_bwd_kernel, dim3(vocab), dim3(256), (size_t)n_tok * sizeof(int), stream, tokens, (const bf16_t*)dx, demb, n_tok, d);
+  hipLaunchKernelGGL(seq_embed_bwd_kernel, dim3(vocab, (d + 255) / 256), dim3(256), (size_t)n_tok * sizeof(int), stream, tokens,
+                     (const bf16_t*)dx, demb, n_tok, d, T > 0 ? T : 1, lens);
   return dig_check_launch();
+}
+
+extern "C" int dig_seq_embed_bwd(const long long* tokens, const void* dx, float* demb, int n_tok, int d, int vocab, hipStream_t stream) {
+  return dig_seq_embed_bwd_lens(tokens, dx, demb, n_tok, d, vocab, 0, nullptr, stream);
 }
 
 extern "C" int dig_seq_cross_entropy_bwd(const float* logits, int ld, const long long* target, const long long* length, const float* gscalar,

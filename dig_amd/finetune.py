@@ -120,6 +120,12 @@ class RecModelTrain(RecModel):
         self._pos = _sinusoid(self.n_position, self.d).to(dev).contiguous()
         self._dev = dev
 
+    def _side_stream(self, dev):
+        st = getattr(self, "_side", None)
+        if st is None or st.device != dev:
+            st = self._side = torch.cuda.Stream(device=dev)
+        return st
+
     def refresh_shadow(self):
         ops.cast_f32_to_bf16(self.flat_params, self._shadow)
 
@@ -300,6 +306,21 @@ class _TrainStep:
         """dlogits_btc: fp32 [B, T, C] gradient w.r.t. the returned logits."""
         M = self.m
         dev = dlogits_btc.device
+        # Two HIP streams, as in the pre-training backward (engine_core.encoder_backward): the data-gradient chain (dgrad GEMMs,
+        # attention / LayerNorm backward) stays on the caller's stream; weight-gradient GEMMs and bias column sums only consume
+        # (dy, saved activation) pairs and run on a second stream, joined before the optimizer.
+        main = torch.cuda.current_stream(dev)
+        sd = M._side_stream(dev) if getattr(M, "overlap_streams", True) else main
+
+        def side(fn, *tensors):
+            if sd is main:
+                fn()
+                return
+            sd.wait_stream(main)
+            with torch.cuda.stream(sd):
+                fn()
+            for t in tensors:
+                t.record_stream(sd)
         B, T, d, nh, dk, C, N, D, H = self.B, M.max_len, M.d, M.nh, M.dk, M.nb_classes, M.N, M.D, M.H
         hk = nh * dk
         rows = B * T
@@ -307,10 +328,9 @@ class _TrainStep:
         dl[:, :C] = dlogits_btc.reshape(rows, C).to(BF16)
         x, fm, fr, o = self.fin_saved
         # classifier
-        ops.wgrad(dl, o, self.g("decoder.classifier.weight"), C, d, rows)
+        side(lambda: ops.wgrad(dl, o, self.g("decoder.classifier.weight"), C, d, rows), dl, o)
         cs = torch.zeros(CLS_PAD, device=dev, dtype=F32)
-        ops.colsum(dl, cs, cols=CLS_PAD)
-        self.g("decoder.classifier.bias").add_(cs[:C])
+        side(lambda: (ops.colsum(dl, cs, cols=CLS_PAD), self.g("decoder.classifier.bias").add_(cs[:C])), dl, cs)
         do = ops.gemm(dl, self.cls_w, rows, d, CLS_PAD, tb=True)
         dx = ops.layernorm_bwd(do, x, self.p("decoder.layer_norm.weight"), self.p("decoder.layer_norm.bias"), fm, fr, None,
                                self.g("decoder.layer_norm.weight"), self.g("decoder.layer_norm.bias"))
@@ -324,17 +344,17 @@ class _TrainStep:
             ds = self.ds_dec[i]
             # feed-forward (every dropped branch: its gradient is the residual gradient under the same mask)
             dz = ops.dropout_apply(dx, ds["out"])
-            ops.linear_wgrad(dz, u, self.g(p + "mlp.w_2.weight"))
-            ops.colsum(dz, self.g(p + "mlp.w_2.bias"))
+            side(lambda: ops.linear_wgrad(dz, u, self.g(p + "mlp.w_2.weight")), dz, u)
+            side(lambda: ops.colsum(dz, self.g(p + "mlp.w_2.bias")), dz)
             du, bparts = ops.linear_dgrad(dz, self.w(p + "mlp.w_2.weight"), gelu_pre=pre, colsum=True, drop=ds["act"])
-            ops.colsum_partials(bparts, self.g(p + "mlp.w_1.bias"))
-            ops.linear_wgrad(du, h3, self.g(p + "mlp.w_1.weight"))
+            side(lambda: ops.colsum_partials(bparts, self.g(p + "mlp.w_1.bias")), bparts)
+            side(lambda: ops.linear_wgrad(du, h3, self.g(p + "mlp.w_1.weight")), du, h3)
             dh3 = ops.linear_dgrad(du, self.w(p + "mlp.w_1.weight"))
             dx2 = ops.layernorm_bwd(dh3, x2, self.p(p + "norm3.weight"), self.p(p + "norm3.bias"), m3, r3, dx, self.g(p + "norm3.weight"),
                                     self.g(p + "norm3.bias"))
             # cross-attention over the encoder memory
             dz = ops.dropout_apply(dx2, ds["cproj"])
-            ops.linear_wgrad(dz, a2, self.g(p + "enc_attn.fc.weight"))
+            side(lambda: ops.linear_wgrad(dz, a2, self.g(p + "enc_attn.fc.weight")), dz, a2)
             da2 = ops.linear_dgrad(dz, self.w(p + "enc_attn.fc.weight"))
             o2, n2, _ = M._offsets[p + "enc_attn.linear_k.weight"]
             if isinstance(lse2, tuple):                                           # MFMA path (see forward)
@@ -350,9 +370,9 @@ class _TrainStep:
                 L.call("dig_seq_attn_bwd_dropout", L.ptr(q2), hk, L.ptr(kvm), 2 * hk, L.ptr(kvm[:, hk:]), 2 * hk, L.ptr(da2), hk, L.ptr(lse2),
                        L.ptr(dq2), hk, L.ptr(dkvm), 2 * hk, L.ptr(dkvm[:, hk:]), 2 * hk, B, nh, T, N, cf(sc), 0, None, _ref(ds["cattn"]),
                        L.stream())
-            ops.linear_wgrad(dq2, h2, self.g(p + "enc_attn.linear_q.weight"))
+            side(lambda: ops.linear_wgrad(dq2, h2, self.g(p + "enc_attn.linear_q.weight")), dq2, h2)
             dh2 = ops.linear_dgrad(dq2, self.w(p + "enc_attn.linear_q.weight"))
-            ops.wgrad(dkvm, mem, M.flat_grads[o2:o2 + 2 * n2].view(2 * hk, hk), 2 * hk, hk, B * N)
+            side(lambda: ops.wgrad(dkvm, mem, M.flat_grads[o2:o2 + 2 * n2].view(2 * hk, hk), 2 * hk, hk, B * N), dkvm, mem)
             dm = ops.gemm(dkvm, M._shadow[o2:o2 + 2 * n2].view(2 * hk, hk), B * N, hk, 2 * hk, tb=True)
             if dmem is None:
                 dmem = dm
@@ -362,25 +382,26 @@ class _TrainStep:
                                     self.g(p + "norm2.bias"))
             # masked self-attention
             dz = ops.dropout_apply(dx1, ds["sproj"])
-            ops.linear_wgrad(dz, a, self.g(p + "self_attn.fc.weight"))
+            side(lambda: ops.linear_wgrad(dz, a, self.g(p + "self_attn.fc.weight")), dz, a)
             da = ops.linear_dgrad(dz, self.w(p + "self_attn.fc.weight"))
             dqkv = torch.empty_like(qkv)
             L.call("dig_seq_attn_bwd_dropout", L.ptr(qkv), 3 * hk, L.ptr(qkv[:, hk:]), 3 * hk, L.ptr(qkv[:, 2 * hk:]), 3 * hk, L.ptr(da), hk,
                    L.ptr(lse1), L.ptr(dqkv), 3 * hk, L.ptr(dqkv[:, hk:]), 3 * hk, L.ptr(dqkv[:, 2 * hk:]), 3 * hk, B, nh, T, T, cf(sc), 1,
                    L.ptr(self.lens), _ref(ds["sattn"]), L.stream())
-            ops.linear_wgrad(dqkv, h1, M._fused(M.flat_grads, p + "self_attn.linear_q.weight", 3))
+            side(lambda: ops.linear_wgrad(dqkv, h1, M._fused(M.flat_grads, p + "self_attn.linear_q.weight", 3)), dqkv, h1)
             dh1 = ops.linear_dgrad(dqkv, M._fused(M._shadow, p + "self_attn.linear_q.weight", 3))
             dx = ops.layernorm_bwd(dh1, x0, self.p(p + "norm1.weight"), self.p(p + "norm1.bias"), m1, r1, dx1, self.g(p + "norm1.weight"),
                                    self.g(p + "norm1.bias"))
         dx = ops.dropout_apply(dx, self.ds_tgt, out=dx)
-        L.call("dig_seq_embed_bwd", L.ptr(self.query), L.ptr(dx), L.ptr(self.g("decoder.trg_word_emb.weight")), rows, d, C + 1, L.stream())
+        L.call("dig_seq_embed_bwd_lens", L.ptr(self.query), L.ptr(dx), L.ptr(self.g("decoder.trg_word_emb.weight")), rows, d, C + 1, T,
+               L.ptr(self.lens), L.stream())
         # ---- linear_norm
         h, mmu, mrs, _ = self.ln_saved
         x_last, emu, ers, enc = self.enc_last
         dh = ops.layernorm_bwd(dmem, h, self.p("linear_norm.1.weight"), self.p("linear_norm.1.bias"), mmu, mrs, None, self.g("linear_norm.1.weight"),
                                self.g("linear_norm.1.bias"))
-        ops.linear_wgrad(dh, enc, self.g("linear_norm.0.weight"))
-        ops.colsum(dh, self.g("linear_norm.0.bias"))
+        side(lambda: ops.linear_wgrad(dh, enc, self.g("linear_norm.0.weight")), dh, enc)
+        side(lambda: ops.colsum(dh, self.g("linear_norm.0.bias")), dh)
         denc = ops.linear_dgrad(dh, self.w("linear_norm.0.weight"))
         dx = ops.layernorm_bwd(denc, x_last, self.p("encoder.norm.weight"), self.p("encoder.norm.bias"), emu, ers, None, self.g("encoder.norm.weight"),
                                self.g("encoder.norm.bias"))
@@ -395,23 +416,23 @@ class _TrainStep:
             # gradient is then the column sum of the MASKED gradient, so the LayerNorm kernel's fused residual column sum is off
             dz = ops.dropout_apply(dx, ds["mlp"])
             if ds["mlp"] is not None:
-                ops.colsum(dz, self.g(b + "mlp.fc2.bias"))
-            ops.linear_wgrad(dz, act, self.g(b + "mlp.fc2.weight"))
+                side(lambda: ops.colsum(dz, self.g(b + "mlp.fc2.bias")), dz)
+            side(lambda: ops.linear_wgrad(dz, act, self.g(b + "mlp.fc2.weight")), dz, act)
             dact, bparts = ops.linear_dgrad(dz, self.w(b + "mlp.fc2.weight"), gelu_pre=pre, colsum=True)
-            ops.colsum_partials(bparts, self.g(b + "mlp.fc1.bias"))
-            ops.linear_wgrad(dact, ln2, self.g(b + "mlp.fc1.weight"))
+            side(lambda: ops.colsum_partials(bparts, self.g(b + "mlp.fc1.bias")), bparts)
+            side(lambda: ops.linear_wgrad(dact, ln2, self.g(b + "mlp.fc1.weight")), dact, ln2)
             dln2 = ops.linear_dgrad(dact, self.w(b + "mlp.fc1.weight"))
             dx_mid = ops.layernorm_bwd(dln2, x_mid, self.p(b + "norm2.weight"), self.p(b + "norm2.bias"), mu2, rs2, dx, self.g(b + "norm2.weight"),
                                        self.g(b + "norm2.bias"), out=dln2, dres_colsum=self.g(b + "mlp.fc2.bias") if ds["mlp"] is None else None)
             dz = ops.dropout_apply(dx_mid, ds["proj"])
             if ds["proj"] is not None:
-                ops.colsum(dz, self.g(b + "attn.proj.bias"))
-            ops.linear_wgrad(dz, ctx, self.g(b + "attn.proj.weight"))
+                side(lambda: ops.colsum(dz, self.g(b + "attn.proj.bias")), dz)
+            side(lambda: ops.linear_wgrad(dz, ctx, self.g(b + "attn.proj.weight")), dz, ctx)
             dctx = ops.linear_dgrad(dz, self.w(b + "attn.proj.weight"))
             dqkv = ops.attn_bwd(qkv, ctx, dctx, lse, self.B, H, D, scale, drop=ds["attn"])
-            ops.linear_wgrad(dqkv, ln1, self.g(b + "attn.qkv.weight"))
-            ops.colsum(dqkv, self.g(b + "attn.q_bias"), cols=D)
-            ops.colsum(dqkv[:, 2 * D:], self.g(b + "attn.v_bias"), cols=D)
+            side(lambda: ops.linear_wgrad(dqkv, ln1, self.g(b + "attn.qkv.weight")), dqkv, ln1)
+            side(lambda: ops.colsum(dqkv, self.g(b + "attn.q_bias"), cols=D), dqkv)
+            side(lambda: ops.colsum(dqkv[:, 2 * D:], self.g(b + "attn.v_bias"), cols=D))
             dln1 = ops.linear_dgrad(dqkv, self.w(b + "attn.qkv.weight"), out=dctx)
             dx = ops.layernorm_bwd(dln1, x, self.p(b + "norm1.weight"), self.p(b + "norm1.bias"), mu1, rs1, dx_mid, self.g(b + "norm1.weight"),
                                    self.g(b + "norm1.bias"), out=dln1, dres_colsum=self.g(b + "attn.proj.bias") if ds["proj"] is None else None)
@@ -419,6 +440,7 @@ class _TrainStep:
         gtok = torch.zeros(D, device=dev, dtype=F32)                          # mask_token takes no part at fine-tune: gradient discarded
         ops.patch_embed_bwd_mfma(dx, self.images, self.zmask, self.g("encoder.patch_embed.proj.weight").view(D, 48),
                                  self.g("encoder.patch_embed.proj.bias"), gtok, D, M.gh, M.gw)
+        main.wait_stream(sd)
 
 
 class _RecTrainFn(torch.autograd.Function):

@@ -251,6 +251,10 @@ int dig_seq_attn_bwd(const void* q, int ldq, const void* k, int ldk, const void*
 int dig_seq_embed_fwd(const long long* tokens, const float* emb, const float* pos_table, void* x, int B, int T, int d, int vocab,
                       hipStream_t stream);
 int dig_seq_embed_bwd(const long long* tokens, const void* dx, float* demb, int n_tok, int d, int vocab, hipStream_t stream);
+/* the same, skipping positions t >= lens[sample] (rows are (sample, t), T positions per sample): under teacher forcing their dx
+ * rows are exact zeros, and the padding token would otherwise dominate one vocabulary row's sum */
+int dig_seq_embed_bwd_lens(const long long* tokens, const void* dx, float* demb, int n_tok, int d, int vocab, int T, const long long* lens,
+                           hipStream_t stream);
 int dig_seq_cross_entropy_bwd(const float* logits, int ld, const long long* target, const long long* length, const float* gscalar, int B,
                               int T, int C, void* dlogits, int ldd, hipStream_t stream);
 

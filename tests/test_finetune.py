@@ -110,6 +110,15 @@ def test_seq_embedding_and_cross_entropy_kernels_vs_torch():
     L.call("dig_seq_embed_bwd", L.ptr(tok), L.ptr(dx), L.ptr(demb), B * T, d, V, L.stream())
     want = torch.zeros(V, d, device=dev).index_add_(0, tok.reshape(-1), dx.float())
     assert (demb - d0 - want).abs().max().item() < 1e-4
+    # length-aware form (d = 640: three channel chunks): positions t >= lens[b] are skipped
+    d2 = 640
+    dx2 = torch.randn(B * T, d2, device=dev).bfloat16()
+    ln = torch.tensor([25, 1, 0, 13, 7, 25, 2], device=dev)
+    valid = (torch.arange(T, device=dev)[None, :] < ln[:, None]).reshape(-1)
+    demb2 = torch.zeros(V, d2, device=dev)
+    L.call("dig_seq_embed_bwd_lens", L.ptr(tok), L.ptr(dx2), L.ptr(demb2), B * T, d2, V, T, L.ptr(ln), L.stream())
+    want2 = torch.zeros(V, d2, device=dev).index_add_(0, tok.reshape(-1)[valid], dx2.float()[valid])
+    assert (demb2 - want2).abs().max().item() < 1e-4
     logits = torch.randn(B, T, Cp, device=dev)
     tgt = torch.randint(0, C, (B, T), device=dev); lens = torch.randint(0, T + 1, (B,), device=dev)
     lf = logits[..., :C].clone().requires_grad_(True)
