@@ -69,6 +69,58 @@ class RecModelTrain(RecModel):
         self.flat_params = torch.zeros(off, dtype=F32)
         self.flat_grads = torch.zeros(off, dtype=F32)
         self._shadow = None
+        self.init_weights()
+
+    def init_weights(self):
+        """The reference's initialisation, drawn from torch's CPU generator: encoder Linear weights xavier-uniform with zero
+        biases and LayerNorm (1, 0) (`PretrainVisionTransformerEncoder._init_weights`, modeling_pretrain_vit.py:66-74); the
+        patch-embed convolution, the decoder and `linear_norm` keep PyTorch's defaults (nn.Conv2d / nn.Linear: U(-1/sqrt(fan_in),
+        1/sqrt(fan_in)) for weight and bias; nn.Embedding: N(0, 1); models/model_builder.py:78-89 adds nothing); mask_token,
+        q_bias, v_bias zero.  Fine-tuning then overwrites the encoder from the pre-training checkpoint (`load_pretrained`)."""
+        sd = OrderedDict()
+        for k, shp in self.param_shapes().items():
+            enc = k.startswith("encoder.")
+            if k.endswith("mask_token") or k.endswith("q_bias") or k.endswith("v_bias"):
+                t = torch.zeros(shp)
+            elif "norm" in k.split(".")[-2] and len(shp) == 1 or k.startswith("linear_norm.1."):
+                t = torch.ones(shp) if k.endswith("weight") else torch.zeros(shp)
+            elif k.endswith("trg_word_emb.weight"):
+                t = torch.randn(shp)
+            elif k.endswith(".weight"):
+                fan_in = 1
+                for d_ in shp[1:]:
+                    fan_in *= d_
+                if enc and len(shp) == 2:
+                    a = math.sqrt(6.0 / (shp[0] + shp[1]))                      # xavier_uniform_
+                else:
+                    a = 1.0 / math.sqrt(fan_in)                                # kaiming_uniform_(a=sqrt(5))
+                t = (torch.rand(shp) * 2 - 1) * a
+            else:                                                              # biases
+                if enc and "patch_embed" not in k:
+                    t = torch.zeros(shp)
+                else:
+                    w = self.param_shapes()[k[:-4] + "weight"]
+                    fan_in = 1
+                    for d_ in w[1:]:
+                        fan_in *= d_
+                    t = (torch.rand(shp) * 2 - 1) / math.sqrt(fan_in)
+            sd[k] = t
+        self.load_state_dict(sd)
+
+    def load_pretrained(self, checkpoint, model_key="model|module", prefix=""):
+        """run_class_finetuning.py:362-440 for the simmim_vit encoders: pick `checkpoint[model_key]`, strip a `backbone.` prefix,
+        load what matches (`encoder.*` of the pre-training model IS this model's `encoder.*`), report the rest.  Returns
+        (missing, unexpected) as the reference's `utils.load_state_dict` prints them."""
+        from .utils import load_state_dict
+        ck = None
+        for key in model_key.split("|"):
+            if key in checkpoint:
+                ck = checkpoint[key]
+                break
+        if ck is None:
+            ck = checkpoint
+        new = OrderedDict((k[9:] if k.startswith("backbone.") else k, v) for k, v in ck.items())
+        return load_state_dict(self, new, prefix=prefix)
 
     # ------------------------------------------------------------------ state
     def _view(self, flat, k, dtype_shape=True):
@@ -78,7 +130,7 @@ class RecModelTrain(RecModel):
     def load_state_dict(self, state_dict, strict=True):
         super().load_state_dict(state_dict, strict)
         for k in self._offsets:
-            if k in self._sd:
+            if k in state_dict:
                 self._view(self.flat_params, k).copy_(self._sd[k])
         self._ready = False
 

@@ -215,6 +215,35 @@ def _to_cpu(obj):
     return obj
 
 
+def load_state_dict(model, state_dict, prefix='', ignore_missing="relative_position_index"):
+    """utils/utils.py:428-480: non-strict load used for `--finetune` checkpoints.  Keys `prefix + name` that the model owns (same
+    shape) are loaded; returns (missing_keys, unexpected_keys) and prints them as the reference does.  A shape mismatch raises,
+    as `_load_from_state_dict` collects it into error_msgs."""
+    own = model.param_shapes()
+    picked, unexpected, errors = {}, [], []
+    for k, v in state_dict.items():
+        if not k.startswith(prefix):
+            unexpected.append(k)
+            continue
+        name = k[len(prefix):]
+        if name in own:
+            if tuple(v.shape) != tuple(own[name]):
+                errors.append(f"size mismatch for {name}: checkpoint {tuple(v.shape)} vs model {tuple(own[name])}")
+            else:
+                picked[name] = v
+        elif not (name.endswith("position_table") or name.startswith("patch_embed.") or name in ("pos_embed", "encoder.pos_embed")):
+            unexpected.append(k)                   # (buffers / RecModel's aliases of encoder.patch_embed, model_builder.py:92-93)
+    missing = [n for n in own if n not in picked and not any(ig in n for ig in ignore_missing.split('|'))]
+    if errors:
+        raise RuntimeError("\n".join(errors))
+    model.load_state_dict(picked, strict=False)
+    if missing:
+        print("Weights of {} not initialized from pretrained model: {}".format(model.__class__.__name__, missing))
+    if unexpected:
+        print("Weights from pretrained model not used in {}: {}".format(model.__class__.__name__, unexpected))
+    return missing, unexpected
+
+
 def save_model(args, epoch, model, model_without_ddp, optimizer, loss_scaler, model_ema=None):
     """checkpoint-{epoch}.pth with the reference's top-level keys {model, optimizer, epoch, scaler, args}."""
     if not is_main_process():

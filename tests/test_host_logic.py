@@ -208,3 +208,44 @@ def test_optimizer_state_dict_interchanges_with_reference_layout(golden_dir, tmp
     assert opt2._step == 1 and torch.equal(opt2.exp_avg[used], opt.exp_avg[used]) and torch.equal(opt2.exp_avg_sq[used], opt.exp_avg_sq[used])
     # pads of the flat moment buffers are not part of any parameter: a load leaves them zero
     assert float(opt2.exp_avg[~used].abs().max()) == 0.0
+
+
+def test_finetune_model_init_and_pretrained_encoder_handoff():
+    """RecModelTrain initialises like the reference (xavier encoder, PyTorch-default decoder) and `load_pretrained` takes the encoder
+    of a pre-training checkpoint the way run_class_finetuning.py:362-440 does: `encoder.*` loaded, momentum encoder / heads reported
+    as unused, decoder / linear_norm reported as not initialised and left at their init."""
+    import types
+    from dig_amd.finetune import RecModelTrain
+    from dig_amd.modeling_pretrain_moco_mim_ori import MoCo_ViT
+    cfg = O.DiGConfig(**O.TINY)
+    torch.manual_seed(3)
+    pre = MoCo_ViT(encoder_embed_dim=cfg.embed_dim, encoder_depth=cfg.depth, encoder_num_heads=cfg.heads, decoder_embed_dim=cfg.dec_dim,
+                   mlp_dim=cfg.moco_mlp_dim, dim=cfg.moco_dim, T=cfg.T, num_windows=4, use_pixel_target=True, patchnet_name='no_patchtrans')
+    ck = {"model": pre.state_dict(), "epoch": 3}
+    m = RecModelTrain(embed_dim=cfg.embed_dim, depth=cfg.depth, num_heads=cfg.heads, n_layers=2, d_model=128, n_head=2, d_k=64, d_inner=64,
+                      nb_classes=97, max_len=8)
+    sd0 = m.state_dict()
+    D = cfg.embed_dim
+    w = sd0["encoder.blocks.0.attn.qkv.weight"]
+    assert abs(w.abs().max().item() - (6.0 / (D + 3 * D)) ** 0.5) < 2e-3 and sd0["encoder.blocks.0.mlp.fc1.bias"].abs().max() == 0
+    assert torch.equal(sd0["decoder.layer_stack.1.norm3.weight"], torch.ones(128)) and abs(sd0["decoder.trg_word_emb.weight"].std().item() - 1) < 0.05
+    assert abs(sd0["decoder.layer_stack.0.mlp.w_1.weight"].abs().max().item() - 128 ** -0.5) < 2e-3
+    assert 0 < sd0["linear_norm.0.bias"].abs().max().item() <= D ** -0.5
+    missing, unexpected = m.load_pretrained(ck)
+    sd1 = m.state_dict()
+    for k, v in ck["model"].items():
+        if k.startswith("encoder.") and k in sd1:
+            assert torch.equal(sd1[k], v.float()), k
+    # (encoder.norm is Identity in the pre-training model, modeling_pretrain_moco_mim_ori.py:362-363: the fine-tune model's stays at init)
+    assert all(k.startswith(("decoder.", "linear_norm.", "encoder.norm.")) for k in missing) and "decoder.classifier.weight" in missing
+    assert "encoder.norm.weight" in missing
+    assert any(k.startswith("momentum_encoder.") for k in unexpected) and not any(k.startswith("encoder.blocks") for k in unexpected)
+    for k in missing:
+        assert torch.equal(sd1[k], sd0[k]), k
+    bad = dict(ck["model"])
+    bad["encoder.norm.weight"] = torch.zeros(D + 1)
+    with pytest.raises(RuntimeError):
+        m.load_pretrained({"model": bad})
+    with pytest.raises(ValueError):
+        RecModelTrain(embed_dim=cfg.embed_dim, depth=cfg.depth, num_heads=cfg.heads, n_layers=2, d_model=128, n_head=2, d_k=64, d_inner=64,
+                      drop_rate=1.0)
