@@ -80,7 +80,8 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& a, int u) {
 // comes from dig_drop_keep(key, (query << 16) | key_index, image * H + head) and is regenerated in the backward.
 template <bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
-                                                          float* __restrict__ lse, int D, int H, unsigned qkv_bytes, dig_dropout_t drop) {
+                                                          float* __restrict__ lse, int D, int H, unsigned qkv_bytes, dig_dropout_t drop,
+                                                          int nqb) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* Kt = smem;
   unsigned char* Vt = smem + TILE;
@@ -101,14 +102,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
   for (int ps = 0; ps < 2; ++ps) {
     const int q = (wave * 2 + ps) * 32 + (lane & 31);
     const bf16_t* qp = qkv + (tok0 + q) * ld + h * DH + hi * 8;
+    if (wave * 2 + ps < nqb) {                                           // nqb < 8: only the first nqb 32-query blocks exist (padded cross-attention)
 #pragma unroll
-    for (int s = 0; s < 4; ++s) qf[ps][s] = *reinterpret_cast<const bf16x8*>(qp + s * 16);
+      for (int s = 0; s < 4; ++s) qf[ps][s] = *reinterpret_cast<const bf16x8*>(qp + s * 16);
+    }
   }
   __syncthreads();
 
 #pragma unroll
   for (int ps = 0; ps < 2; ++ps) {
     const int qb = wave * 2 + ps;
+    if (qb >= nqb) continue;
     f32x16 sc[8];
 #pragma unroll
     for (int kt = 0; kt < 8; ++kt) {
@@ -221,7 +225,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(const bf16_t* __restri
                                                           const bf16_t* __restrict__ dctx, const float* __restrict__ lse,
                                                           bf16_t* __restrict__ dqkv, int D, int H, float scale,
                                                           unsigned qkv_bytes, unsigned ctx_bytes, float* __restrict__ qsum, float* __restrict__ vsum,
-                                                          dig_dropout_t drop) {
+                                                          dig_dropout_t drop, int nqb) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* Qt = smem;
   unsigned char* Kt = smem + TILE;
@@ -264,8 +268,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(const bf16_t* __restri
   __syncthreads();
   const int hi = lane >> 5;
 
-  // ---------------- phase A: dQ for query block `wave` ----------------
-  {
+  // ---------------- phase A: dQ for query block `wave` (only the first nqb blocks exist) ----------------
+  if (wave < nqb) {
     const int q0 = wave * 32;
     const int q = q0 + (lane & 31);
     const float my_lse = lse_s[q], my_del = del_s[q];
@@ -360,7 +364,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(const bf16_t* __restri
       gfr[s] = frag_direct(Gt, 0, s, lane);
     }
 #pragma unroll 2
-    for (int qt = 0; qt < 8; ++qt) {
+    for (int qt = 0; qt < nqb; ++qt) {
       f32x16 st, dp;   // rows = queries qt*32 + (e&3) + 8*(e>>2) + 4*hi, col = key
 #pragma unroll
       for (int e = 0; e < 16; ++e) { st[e] = 0.f; dp[e] = 0.f; }
@@ -440,8 +444,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(const bf16_t* __restri
 }  // namespace
 
 extern "C" int dig_attn_fwd_dropout(const void* qkv, void* ctx, float* lse, int n_img, int heads, int embed_dim,
-                                    const dig_dropout_t* drop, hipStream_t stream) {
-  if (!qkv || !ctx || !lse || n_img <= 0 || heads <= 0 || embed_dim != heads * DH) return DIG_ERR_ARG;
+                                    const dig_dropout_t* drop, int q_rows, hipStream_t stream) {
+  if (!qkv || !ctx || !lse || n_img <= 0 || heads <= 0 || embed_dim != heads * DH || q_rows < 1 || q_rows > N_TOK) return DIG_ERR_ARG;
+  const int nqb = (q_rows + 31) / 32;
   if (!aligned16(qkv) || !aligned16(ctx)) return DIG_ERR_ALIGN;
   const size_t qb = (size_t)n_img * N_TOK * 3 * embed_dim * 2;
   if (qb >= (1ull << 32)) return DIG_ERR_ARG;
@@ -453,21 +458,23 @@ extern "C" int dig_attn_fwd_dropout(const void* qkv, void* ctx, float* lse, int 
   }
   if (drop && drop->thr)
     hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3(n_img * heads), dim3(256), 2 * TILE, stream, (const bf16_t*)qkv, (bf16_t*)ctx,
-                       lse, embed_dim, heads, (unsigned)qb, *drop);
+                       lse, embed_dim, heads, (unsigned)qb, *drop, nqb);
   else
     hipLaunchKernelGGL(attn_fwd_kernel<false>, dim3(n_img * heads), dim3(256), 2 * TILE, stream, (const bf16_t*)qkv, (bf16_t*)ctx,
-                       lse, embed_dim, heads, (unsigned)qb, dig_dropout_t{});
+                       lse, embed_dim, heads, (unsigned)qb, dig_dropout_t{}, nqb);
   return dig_check_launch();
 }
 
 extern "C" int dig_attn_fwd(const void* qkv, void* ctx, float* lse, int n_img, int heads, int embed_dim, hipStream_t stream) {
-  return dig_attn_fwd_dropout(qkv, ctx, lse, n_img, heads, embed_dim, nullptr, stream);
+  return dig_attn_fwd_dropout(qkv, ctx, lse, n_img, heads, embed_dim, nullptr, N_TOK, stream);
 }
 
 extern "C" int dig_attn_bwd_dropout(const void* qkv, const void* ctx, const void* dctx, const float* lse, void* dqkv, int n_img,
                                     int heads, int embed_dim, float scale, float* q_colsum, float* v_colsum,
-                                    const dig_dropout_t* drop, hipStream_t stream) {
-  if (!qkv || !ctx || !dctx || !lse || !dqkv || n_img <= 0 || heads <= 0 || embed_dim != heads * DH) return DIG_ERR_ARG;
+                                    const dig_dropout_t* drop, int q_rows, hipStream_t stream) {
+  if (!qkv || !ctx || !dctx || !lse || !dqkv || n_img <= 0 || heads <= 0 || embed_dim != heads * DH || q_rows < 1 || q_rows > N_TOK) return DIG_ERR_ARG;
+  const int nqb = (q_rows + 31) / 32;
+  if (nqb < 8 && q_colsum) return DIG_ERR_UNSUPPORTED;                       // the fused dQ column sums assume all eight query blocks
   if ((q_colsum == nullptr) != (v_colsum == nullptr)) return DIG_ERR_ARG;
   if (!aligned16(qkv) || !aligned16(ctx) || !aligned16(dctx) || !aligned16(dqkv)) return DIG_ERR_ALIGN;
   const size_t qb = (size_t)n_img * N_TOK * 3 * embed_dim * 2;
@@ -482,15 +489,15 @@ extern "C" int dig_attn_bwd_dropout(const void* qkv, const void* ctx, const void
   if (drop && drop->thr)
     hipLaunchKernelGGL(attn_bwd_kernel<true>, dim3(n_img * heads), dim3(512), lds, stream, (const bf16_t*)qkv, (const bf16_t*)ctx,
                        (const bf16_t*)dctx, lse, (bf16_t*)dqkv, embed_dim, heads, scale, (unsigned)qb, (unsigned)(qb / 3), q_colsum,
-                       v_colsum, *drop);
+                       v_colsum, *drop, nqb);
   else
     hipLaunchKernelGGL(attn_bwd_kernel<false>, dim3(n_img * heads), dim3(512), lds, stream, (const bf16_t*)qkv, (const bf16_t*)ctx,
                        (const bf16_t*)dctx, lse, (bf16_t*)dqkv, embed_dim, heads, scale, (unsigned)qb, (unsigned)(qb / 3), q_colsum,
-                       v_colsum, dig_dropout_t{});
+                       v_colsum, dig_dropout_t{}, nqb);
   return dig_check_launch();
 }
 
 extern "C" int dig_attn_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse, void* dqkv, int n_img,
                             int heads, int embed_dim, float scale, float* q_colsum, float* v_colsum, hipStream_t stream) {
-  return dig_attn_bwd_dropout(qkv, ctx, dctx, lse, dqkv, n_img, heads, embed_dim, scale, q_colsum, v_colsum, nullptr, stream);
+  return dig_attn_bwd_dropout(qkv, ctx, dctx, lse, dqkv, n_img, heads, embed_dim, scale, q_colsum, v_colsum, nullptr, N_TOK, stream);
 }

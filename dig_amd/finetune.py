@@ -317,16 +317,16 @@ class _TrainStep:
             o2, n2, s2 = M._offsets[p + "enc_attn.linear_k.weight"]
             wkv = M._shadow[o2:o2 + 2 * n2].view(2 * hk, hk)
             if N == 256 and dk == 64:
-                # cross-attention on the MFMA kernel of the encoder (256 keys, head dim 64): the T queries of a sample are padded
-                # to 256 rows of a fused q|k|v buffer.  Zero queries cost MFMA time but no new kernel; their output rows are
-                # dropped and, with a zero output gradient, contribute nothing in backward.  Measured 4x faster than the FMA
-                # kernel at 25 x 256 (tools/gpu_seqattn_probe.py).
+                # cross-attention on the MFMA kernel of the encoder (256 keys, head dim 64): the T queries of a sample sit in rows
+                # [0, T) of a fused q|k|v buffer of 256 rows per sample, and the kernels are told to compute the first
+                # ceil(T / 32) query blocks only (rows T..31 are zero queries with a zero output gradient: no contribution).
                 fused = torch.empty((B * N, 3 * hk), device=dev, dtype=BF16)
                 ops.gemm(mem, wkv, B * N, 2 * hk, d, out=fused[:, hk:], ldc=3 * hk)
                 fq = fused.view(B, N, 3 * hk)[:, :, :hk]
-                fq[:, T:].zero_()
+                Tp = (T + 31) // 32 * 32                                          # the kernels work on whole 32-query blocks
+                fq[:, T:Tp].zero_()
                 fq[:, :T] = (q2 * sc).view(B, T, hk)                              # sc = 2^-3: exact in bf16
-                ctx2, lse2 = ops.attn_fwd(fused, B, nh, hk, drop=ds["cattn"])
+                ctx2, lse2 = ops.attn_fwd(fused, B, nh, hk, drop=ds["cattn"], q_rows=T)   # query blocks past T are not computed
                 a2 = ctx2.view(B, N, hk)[:, :T].reshape(B * T, hk)
                 kvm, lse2 = fused, (lse2, ctx2)
             else:
@@ -411,9 +411,11 @@ class _TrainStep:
             o2, n2, _ = M._offsets[p + "enc_attn.linear_k.weight"]
             if isinstance(lse2, tuple):                                           # MFMA path (see forward)
                 lse2, ctx2 = lse2                                                 # padded rows: finite outputs, zero dO -> delta = 0
-                dctx2 = torch.zeros((B * N, hk), device=dev, dtype=BF16)
-                dctx2.view(B, N, hk)[:, :T] = da2.view(B, T, hk)
-                dfused = ops.attn_bwd(kvm, ctx2, dctx2, lse2, B, nh, hk, sc, drop=ds["cattn"])   # kvm = the fused q|k|v buffer
+                dctx2 = torch.empty((B * N, hk), device=dev, dtype=BF16)
+                dv_ = dctx2.view(B, N, hk)
+                dv_[:, T:(T + 31) // 32 * 32].zero_()
+                dv_[:, :T] = da2.view(B, T, hk)
+                dfused = ops.attn_bwd(kvm, ctx2, dctx2, lse2, B, nh, hk, sc, drop=ds["cattn"], q_rows=T)   # kvm = the fused q|k|v buffer
                 dq2 = dfused.view(B, N, 3 * hk)[:, :T, :hk].reshape(B * T, hk)
                 dkvm = dfused[:, hk:]                                             # [B*N, 2hk] view, row stride 3hk
             else:

@@ -176,22 +176,23 @@ def layernorm_bwd(dy, x, gamma, beta, mean, rstd, dres, dgamma, dbeta, gelu=Fals
     return dx, finish, ws
 
 
-def attn_fwd(qkv, n_img, heads, D, drop=None):
+def attn_fwd(qkv, n_img, heads, D, drop=None, q_rows=256):
+    """q_rows < 256: only the first q_rows query rows per image are computed (the other ctx / lse rows stay uninitialised)."""
     ctx = torch.empty((qkv.shape[0], D), device=qkv.device, dtype=BF16)
     lse = torch.empty((n_img * heads, 256), device=qkv.device, dtype=F32)
     L.call("dig_attn_fwd_dropout", L.ptr(qkv), L.ptr(ctx), L.ptr(lse), n_img, heads, D, ctypes.byref(drop) if drop is not None else None,
-           L.stream())
+           q_rows, L.stream())
     return ctx, lse
 
 
-def attn_bwd(qkv, ctx, dctx, lse, n_img, heads, D, scale, bias_sums=False, drop=None):
+def attn_bwd(qkv, ctx, dctx, lse, n_img, heads, D, scale, bias_sums=False, drop=None, q_rows=256):
     """dqkv (dq pre-multiplied by `scale`).  bias_sums=True also returns the per-image column sums of the dq and dv parts
     ([n_img, D] fp32 each): the q_bias / v_bias gradient partials for colsum_partials()."""
     dqkv = torch.empty_like(qkv)
     qs = torch.empty((n_img, D), device=qkv.device, dtype=F32) if bias_sums else None
     vs = torch.empty((n_img, D), device=qkv.device, dtype=F32) if bias_sums else None
     L.call("dig_attn_bwd_dropout", L.ptr(qkv), L.ptr(ctx), L.ptr(dctx), L.ptr(lse), L.ptr(dqkv), n_img, heads, D, cf(scale), L.ptr(qs), L.ptr(vs),
-           ctypes.byref(drop) if drop is not None else None, L.stream())
+           ctypes.byref(drop) if drop is not None else None, q_rows, L.stream())
     return (dqkv, qs, vs) if bias_sums else dqkv
 
 

@@ -290,11 +290,16 @@ int dig_gemm_bf16_dropout(const void* A, const void* B, void* C, int I, int J, i
  * forward, and the gradient of any dropped branch in the backward (same mask, same scale). */
 int dig_dropout_apply(const void* in, void* out, long long rows, int cols, const dig_dropout_t* drop, hipStream_t stream);
 /* dig_attn_fwd / dig_attn_bwd / dig_seq_attn_fwd / dig_seq_attn_bwd with attention dropout: probabilities are normalised by the
- * full row sum, then masked and scaled (attn_drop after softmax); drop = NULL or thr = 0 is the plain kernel. */
+ * full row sum, then masked and scaled (attn_drop after softmax); drop = NULL or thr = 0 is the plain kernel.
+ * q_rows (1..256): only the first q_rows query rows of every image exist -- the recognition decoder's cross-attention (25 queries
+ * against the 256 encoder tokens, models/transformer_layer.py:104-108) runs on these kernels with its queries in rows [0, 25) of a
+ * fused q|k|v buffer; query blocks past ceil(q_rows / 32) are neither computed nor written (ctx / lse / dq rows there are left
+ * untouched), dK / dV sum over the existing blocks only (rows between q_rows and the block end must carry dctx = 0). */
 int dig_attn_fwd_dropout(const void* qkv, void* ctx, float* lse, int n_img, int heads, int embed_dim, const dig_dropout_t* drop,
-                         hipStream_t stream);
+                         int q_rows, hipStream_t stream);
 int dig_attn_bwd_dropout(const void* qkv, const void* ctx, const void* dctx, const float* lse, void* dqkv, int n_img, int heads,
-                         int embed_dim, float scale, float* q_colsum, float* v_colsum, const dig_dropout_t* drop, hipStream_t stream);
+                         int embed_dim, float scale, float* q_colsum, float* v_colsum, const dig_dropout_t* drop, int q_rows,
+                         hipStream_t stream);
 int dig_seq_attn_fwd_dropout(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out, int ldo, float* lse, int B,
                              int heads, int Lq, int Lk, float scale, int causal, const long long* lens, const dig_dropout_t* drop,
                              hipStream_t stream);

@@ -376,6 +376,17 @@ def test_attention_dropout_kernels_vs_torch_with_oracle_masks():
     assert (dqkv - wg).abs().max() < 4e-2 * wg.abs().max()
     plain_ctx, _ = ops.attn_fwd(qkv.to(dev), B, H, Dm)
     assert (plain_ctx.float() - ctx.float()).abs().max() > 0.05 * want.abs().max()   # the mask really acts
+    # q_rows: 40 existing queries per image (two 32-row blocks; rows 40..63 zero queries with zero dO), the rest never touched
+    Tq = 40
+    qk = qkv.clone().view(B, 256, 3 * Dm); qk[:, Tq:64, :Dm] = 0
+    dc = dctx.clone().view(B, 256, Dm); dc[:, Tq:] = 0
+    ctx_q, lse_q = ops.attn_fwd(qk.view(-1, 3 * Dm).to(dev), B, H, Dm, drop=sp, q_rows=Tq)
+    ctx_f, lse_f = ops.attn_fwd(qk.view(-1, 3 * Dm).to(dev), B, H, Dm, drop=sp)
+    assert torch.equal(ctx_q.view(B, 256, Dm)[:, :64], ctx_f.view(B, 256, Dm)[:, :64])
+    dq_q = ops.attn_bwd(qk.view(-1, 3 * Dm).to(dev), ctx_f, dc.view(-1, Dm).to(dev), lse_f, B, H, Dm, 1.0, drop=sp, q_rows=Tq).view(B, 256, 3 * Dm)
+    dq_f = ops.attn_bwd(qk.view(-1, 3 * Dm).to(dev), ctx_f, dc.view(-1, Dm).to(dev), lse_f, B, H, Dm, 1.0, drop=sp).view(B, 256, 3 * Dm)
+    assert torch.equal(dq_q[:, :64, :Dm], dq_f[:, :64, :Dm])                          # dQ of the existing blocks
+    assert (dq_q[:, :, Dm:].float() - dq_f[:, :, Dm:].float()).abs().max() <= 2e-2 * dq_f[:, :, Dm:].float().abs().max()   # dK, dV (fewer zero terms)
     # ---- decoder sequence kernels: causal + length mask (self) and plain (cross, 40 keys)
     for Lq, Lk, causal in ((8, 8, 1), (8, 40, 0)):
         B, H = 5, 2
