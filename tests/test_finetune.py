@@ -460,3 +460,35 @@ def test_device_finetune_step_with_dropout_vs_reference_fixture():
     # a second forward draws new masks
     logits2 = m((images.to("cuda:0"), targets, lens))[0]
     assert (logits2 - logits).abs().max().item() > 1e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,lens", [(1, [8]), (3, [1, 8, 2]), (5, [1, 1, 1, 1, 1])])
+def test_device_finetune_step_ragged_batches_and_length_extremes(B, lens):
+    """Batch sizes that are no multiple of any tile, sequences of length 1 and of the maximum length: loss, logits and the global
+    gradient norm against the fp32 oracle (rates 0)."""
+    from dig_amd.finetune import SeqCrossEntropyLoss
+    _, c, ecfg, P, _, _, _ = _fixture()
+    images = O.synthetic_batch(B, ecfg, 4242 + B)[0]
+    lens_t = torch.tensor(lens)
+    rng = np.random.RandomState(B)
+    targets = torch.from_numpy(rng.randint(0, 94, size=(B, c.max_seq_len)))
+    for b in range(B):
+        targets[b, lens[b] - 1] = 94
+        targets[b, lens[b]:] = 95
+    m = _device_model(c, ecfg, P)
+    for p in m.parameters():
+        p.grad.zero_()
+    logits = m((images.to("cuda:0"), targets, lens_t))[0]
+    loss = SeqCrossEntropyLoss()(logits, targets, lens_t)
+    loss.backward()
+    o_loss, o_grads, o_logits = F.loss_and_grads(P, ecfg, c, images, targets, lens_t)
+    assert abs(loss.item() - o_loss) < 2e-2 * abs(o_loss)
+    valid = (torch.arange(c.max_seq_len)[None, :] < lens_t[:, None])
+    d = (logits.detach().cpu() - o_logits)[valid]
+    assert (d.norm() / o_logits[valid].norm()).item() < 2e-2
+    tot_ref = float(torch.sqrt(sum((g.double() ** 2).sum() for n, g in o_grads.items() if n != "encoder.mask_token")))
+    tot_dev = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for _, p in m.named_parameters())))
+    assert abs(tot_dev / tot_ref - 1) < 3e-2, (tot_dev, tot_ref)
+    ge = m._view(m.flat_grads, "decoder.trg_word_emb.weight").float().cpu()
+    assert float(ge[95].abs().max()) == 0.0                                   # the padding token never receives a gradient
