@@ -635,6 +635,50 @@ class FineTuneAdamW:
                cf(g0["betas"][1]), cf(g0["eps"]), self._step, cf(grad_scale), L.stream())
 
 
+    # ---- checkpoints: torch.optim's per-parameter layout (what utils.save_model / auto_load_model exchange, utils/utils.py:546-651)
+    def _ordered_names(self):
+        return [n for g in self.param_groups for n in g["names"]]
+
+    def state_dict(self):
+        M = self.model
+        state = {}
+        if self._step > 0:
+            for i, n in enumerate(self._ordered_names()):
+                state[i] = {"step": self._step, "exp_avg": M._view(self.exp_avg, n), "exp_avg_sq": M._view(self.exp_avg_sq, n)}
+        groups, k = [], 0
+        for g in self.param_groups:
+            d = {key: v for key, v in g.items() if key not in ("params", "names")}
+            d.setdefault("amsgrad", False)
+            d["params"] = list(range(k, k + len(g["names"])))
+            k += len(g["names"])
+            groups.append(d)
+        return {"state": state, "param_groups": groups}
+
+    def load_state_dict(self, sd):
+        self._tables()
+        M = self.model
+        names = self._ordered_names()
+        if [len(g["params"]) for g in sd["param_groups"]] != [len(g["names"]) for g in self.param_groups]:
+            raise ValueError("loaded state dict has different parameter groups")
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        steps = set()
+        for i, st in sd["state"].items():
+            n = names[int(i)]
+            if tuple(st["exp_avg"].shape) != tuple(M._offsets[n][2]):
+                raise ValueError(f"optimizer state {i} ({n}): shape {tuple(st['exp_avg'].shape)} != {M._offsets[n][2]}")
+            M._view(self.exp_avg, n).copy_(st["exp_avg"])
+            M._view(self.exp_avg_sq, n).copy_(st["exp_avg_sq"])
+            steps.add(int(st["step"]))
+        if len(steps) > 1:
+            raise ValueError("per-parameter step counts differ; the fused optimizer keeps one step counter")
+        self._step = steps.pop() if steps else 0
+        for g, lg in zip(self.param_groups, sd["param_groups"]):
+            for key in ("lr", "weight_decay", "lr_scale", "betas", "eps"):
+                if key in lg:
+                    g[key] = lg[key]
+
+
 def create_optimizer(args, model, get_num_layer=None, get_layer_scale=None, filter_bias_and_bn=True, skip_list=None):
     """optim_factory.create_optimizer for `--opt adamw` on a RecModelTrain."""
     if args.opt.lower() != "adamw":

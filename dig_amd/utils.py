@@ -250,9 +250,12 @@ def save_model(args, epoch, model, model_without_ddp, optimizer, loss_scaler, mo
         return
     os.makedirs(args.output_dir, exist_ok=True)
     path = os.path.join(args.output_dir, 'checkpoint-%s.pth' % str(epoch))
-    torch.save({'model': {k: v.detach().cpu() for k, v in model_without_ddp.state_dict().items()},
-                'optimizer': _to_cpu(optimizer.state_dict()),
-                'epoch': epoch, 'scaler': loss_scaler.state_dict(), 'args': vars(args) if hasattr(args, "__dict__") else args}, path)
+    ck = {'model': {k: v.detach().cpu() for k, v in model_without_ddp.state_dict().items()},
+          'optimizer': _to_cpu(optimizer.state_dict()),
+          'epoch': epoch, 'scaler': loss_scaler.state_dict(), 'args': vars(args) if hasattr(args, "__dict__") else args}
+    if hasattr(model_without_ddp, "drop_step"):        # dropout mask keys of the fine-tune model (an extra top-level key: the
+        ck['dig_amd'] = {'drop_seed': int(model_without_ddp.drop_seed), 'drop_step': int(model_without_ddp.drop_step)}   # reference ignores it)
+    torch.save(ck, path)
 
 
 def auto_load_model(args, model, model_without_ddp, optimizer, loss_scaler, model_ema=None):
@@ -269,6 +272,8 @@ def auto_load_model(args, model, model_without_ddp, optimizer, loss_scaler, mode
     if getattr(args, "resume", ""):
         ck = torch.load(args.resume, map_location='cpu', weights_only=False)
         model_without_ddp.load_state_dict(ck['model'])
+        if 'dig_amd' in ck and hasattr(model_without_ddp, "drop_step"):
+            model_without_ddp.drop_seed, model_without_ddp.drop_step = int(ck['dig_amd']['drop_seed']), int(ck['dig_amd']['drop_step'])
         print("Resume checkpoint %s" % args.resume)
         if 'optimizer' in ck and 'epoch' in ck:
             optimizer.load_state_dict(ck['optimizer'])

@@ -492,3 +492,49 @@ def test_device_finetune_step_ragged_batches_and_length_extremes(B, lens):
     assert abs(tot_dev / tot_ref - 1) < 3e-2, (tot_dev, tot_ref)
     ge = m._view(m.flat_grads, "decoder.trg_word_emb.weight").float().cpu()
     assert float(ge[95].abs().max()) == 0.0                                   # the padding token never receives a gradient
+
+
+@pytest.mark.gpu
+def test_finetune_checkpoint_resume_is_bit_exact(tmp_path):
+    """utils.save_model / auto_load_model around the fine-tune model + FineTuneAdamW (torch per-parameter optimizer layout, dropout
+    key counter): two steps, save, third step == load into fresh objects and run the third step, bit for bit, dropout on."""
+    import types
+    from dig_amd.finetune import SeqCrossEntropyLoss, LayerDecayValueAssigner, create_optimizer
+    from dig_amd.utils import NativeScalerWithGradNormCount, save_model, auto_load_model
+    _, c, ecfg, P, images, targets, lens = _fixture()
+    dev = "cuda:0"
+
+    def make():
+        m = _device_model(c, ecfg, P, decoder_dropout=0.1, drop_rate=0.1, attn_drop_rate=0.1, drop_path_rate=0.1, drop_seed=17)
+        nl = m.get_num_layers()
+        asg = LayerDecayValueAssigner([0.75 ** (nl + 1 - i) for i in range(nl + 2)])
+        args = types.SimpleNamespace(opt="adamw", lr=1e-3, weight_decay=0.05, opt_eps=1e-8, opt_betas=None, output_dir=str(tmp_path), resume="",
+                                     auto_resume=True, start_epoch=0)
+        opt = create_optimizer(args, m, get_num_layer=asg.get_layer_id, get_layer_scale=asg.get_scale)
+        for grp in opt.param_groups:
+            grp["lr"] = args.lr * grp["lr_scale"]
+        return m, opt, args
+
+    def step(m, opt):
+        opt.zero_grad()
+        loss = SeqCrossEntropyLoss()(m((images.to(dev), targets, lens))[0], targets, lens)
+        NativeScalerWithGradNormCount()(loss, opt, clip_grad=1.0, parameters=None)
+        return loss.item()
+
+    m, opt, args = make()
+    step(m, opt); step(m, opt)
+    save_model(args, 0, m, m, opt, NativeScalerWithGradNormCount())
+    l3 = step(m, opt)
+    want = m.state_dict()
+    m2, opt2, args2 = make()
+    for _, p in m2.named_parameters():
+        p.add_(1.0)                                                            # make sure everything comes from the file
+    auto_load_model(args2, m2, m2, opt2, NativeScalerWithGradNormCount())
+    assert args2.start_epoch == 1 and m2.drop_step == 2 and opt2._step == 2
+    ck = torch.load(os.path.join(str(tmp_path), "checkpoint-0.pth"), map_location="cpu", weights_only=False)
+    assert set(ck) >= {"model", "optimizer", "epoch", "scaler", "args"} and len(ck["optimizer"]["state"]) == len(list(m.named_parameters()))
+    assert [len(g["params"]) for g in ck["optimizer"]["param_groups"]] == [len(g["names"]) for g in opt.param_groups]
+    l3b = step(m2, opt2)
+    assert l3b == l3
+    got = m2.state_dict()
+    assert all(torch.equal(got[k], want[k]) for k in want), [k for k in want if not torch.equal(got[k], want[k])][:5]
