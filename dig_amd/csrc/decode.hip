@@ -211,6 +211,78 @@ __global__ __launch_bounds__(256) void fixed_order_sum_kernel(const float* __res
   if (threadIdx.x == 0) out[0] = red[0] * scale;
 }
 
+// SeqLabelSmoothingCrossEntropyLoss.forward (loss/seqLabelSmoothingCrossEntropyLoss.py:48-70), as the reference computes it: the
+// `nll_loss` column [BT,1] and the `smooth_loss` product of a [BT] vector with the [BT,1] mask broadcast to a [BT,BT] matrix, so
+//   loss = ( confidence * BT * sum_i mask_i * nll_i  +  smoothing * (sum_i mask_i) * sum_j s_j ) / B,   s_j = -mean_c log_softmax(x_j)_c
+// with s_j taken over ALL rows j (also the padded ones).  One wave per row writes (mask_i * nll_i, s_i); a single block then adds
+// the terms in a fixed order.
+__global__ __launch_bounds__(64) void seq_ls_ce_rows_kernel(const float* __restrict__ input, const long long* __restrict__ target,
+                                                            const long long* __restrict__ length, int T, int C, float* __restrict__ rows2) {
+  const int row = blockIdx.x, b = row / T, t = row - b * T, lane = threadIdx.x, n = gridDim.x;
+  const float* x = input + (size_t)row * C;
+  float m = -INFINITY, sx = 0.f;
+  for (int c = lane; c < C; c += 64) { m = fmaxf(m, x[c]); sx += x[c]; }
+  m = wave_max(m);
+  sx = wave_sum(sx);
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s += __expf(x[c] - m);
+  s = wave_sum(s);
+  if (lane == 0) {
+    const float lse = m + __logf(s);
+    long long y = target[row];
+    y = y < 0 ? 0 : (y >= C ? C - 1 : y);
+    rows2[row] = t < length[b] ? lse - x[y] : 0.f;
+    rows2[n + row] = lse - sx / (float)C;
+  }
+}
+
+__global__ __launch_bounds__(256) void seq_ls_ce_sum_kernel(const float* __restrict__ rows2, const long long* __restrict__ length, int B, int T,
+                                                            float confidence, float smoothing, float* __restrict__ out) {
+  __shared__ float red[3][256];
+  const int n = B * T;
+  float a = 0.f, b = 0.f, cnt = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) { a += rows2[i]; b += rows2[n + i]; }
+  for (int i = threadIdx.x; i < B; i += 256) { const long long l = length[i]; cnt += (float)(l < 0 ? 0 : (l > T ? T : l)); }
+  red[0][threadIdx.x] = a; red[1][threadIdx.x] = b; red[2][threadIdx.x] = cnt;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (threadIdx.x < st)
+      for (int k = 0; k < 3; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = (confidence * (float)n * red[0][0] + smoothing * red[2][0] * red[1][0]) / (float)B;
+}
+
+// gradient: dL/dx[i,c] = g / B * ( confidence * BT * mask_i * (p_ic - [c == y_i]) + smoothing * M * (p_ic - 1/C) ),  M = sum_i mask_i
+__global__ __launch_bounds__(64) void seq_ls_ce_bwd_kernel(const float* __restrict__ logits, int ld, const long long* __restrict__ target,
+                                                           const long long* __restrict__ length, const float* __restrict__ g, int B, int T, int C,
+                                                           float confidence, float smoothing, bf16_t* __restrict__ dlogits, int ldd) {
+  const int row = blockIdx.x, b = row / T, t = row - b * T, lane = threadIdx.x;
+  float cnt = 0.f;
+  for (int i = lane; i < B; i += 64) { const long long l = length[i]; cnt += (float)(l < 0 ? 0 : (l > T ? T : l)); }
+  cnt = wave_sum(cnt);
+  const float* x = logits + (size_t)row * ld;
+  float m = -INFINITY;
+  for (int c = lane; c < C; c += 64) m = fmaxf(m, x[c]);
+  m = wave_max(m);
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s += __expf(x[c] - m);
+  s = wave_sum(s);
+  const float sc = (g ? g[0] : 1.f) / (float)B, inv = 1.f / s;
+  const float wn = t < length[b] ? confidence * (float)(B * T) : 0.f, ws = smoothing * cnt;
+  long long y = target[row];
+  y = y < 0 ? 0 : (y >= C ? C - 1 : y);
+  bf16_t* out = dlogits + (size_t)row * ldd;
+  for (int c = lane; c < ldd; c += 64) {
+    float v = 0.f;
+    if (c < C) {
+      const float p = __expf(x[c] - m) * inv;
+      v = sc * (wn * (p - (c == y ? 1.f : 0.f)) + ws * (p - 1.f / (float)C));
+    }
+    out[c] = f2bf(v);
+  }
+}
+
 // recognition_f_measure (evaluation_metric/metrics.py:83-100): per sample, the SETS of kept characters of prediction and target
 // (same cut / drop / case-fold rules as the accuracy; canon codes 1..63 -> one bit each), p = n/(|P|+1e-5), r = n/(|T|+1e-5),
 // f = 2pr/(p+r+1e-5), all in double as the reference's Python floats.
@@ -291,5 +363,21 @@ extern "C" int dig_char_fmeasure(const long long* pred, const long long* target,
                                  int B, int T, double* f_per_sample, hipStream_t stream) {
   if (!pred || !target || !canon || !f_per_sample || n_classes <= 0 || B <= 0 || T <= 0) return DIG_ERR_ARG;
   hipLaunchKernelGGL(char_fmeasure_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, pred, target, canon, n_classes, eos, B, T, f_per_sample);
+  return dig_check_launch();
+}
+
+extern "C" int dig_seq_ls_cross_entropy(const float* input, const long long* target, const long long* length, int B, int T, int C,
+                                        float smoothing, float* row_workspace, float* loss, hipStream_t stream) {
+  if (!input || !target || !length || !row_workspace || !loss || B <= 0 || T <= 0 || C <= 0 || smoothing < 0.f || smoothing > 1.f) return DIG_ERR_ARG;
+  hipLaunchKernelGGL(seq_ls_ce_rows_kernel, dim3(B * T), dim3(64), 0, stream, input, target, length, T, C, row_workspace);
+  hipLaunchKernelGGL(seq_ls_ce_sum_kernel, dim3(1), dim3(256), 0, stream, row_workspace, length, B, T, 1.f - smoothing, smoothing, loss);
+  return dig_check_launch();
+}
+
+extern "C" int dig_seq_ls_cross_entropy_bwd(const float* logits, int ld, const long long* target, const long long* length, const float* gscalar,
+                                            int B, int T, int C, float smoothing, void* dlogits, int ldd, hipStream_t stream) {
+  if (!logits || !target || !length || !dlogits || B <= 0 || T <= 0 || C <= 0 || ld < C || ldd < C || smoothing < 0.f || smoothing > 1.f) return DIG_ERR_ARG;
+  hipLaunchKernelGGL(seq_ls_ce_bwd_kernel, dim3(B * T), dim3(64), 0, stream, logits, ld, target, length, gscalar, B, T, C, 1.f - smoothing,
+                     smoothing, (bf16_t*)dlogits, ldd);
   return dig_check_launch();
 }

@@ -541,6 +541,44 @@ class _SeqCEFn(torch.autograd.Function):
         return dl[:, :C].float().reshape(B, T, C), None, None
 
 
+class SeqLabelSmoothingCrossEntropyLoss(torch.nn.Module):
+    """loss/seqLabelSmoothingCrossEntropyLoss.py (sample_normalize), the criterion `--smoothing > 0` selects
+    (run_class_finetuning.py:538-541), with the value the reference really computes: its smoothing term broadcasts to a [BT, BT]
+    matrix (include/dig_hip.h `dig_seq_ls_cross_entropy`), which this class reproduces."""
+
+    def __init__(self, smoothing=0.1):
+        super().__init__()
+        if not 0.0 <= smoothing <= 1.0:
+            raise ValueError("smoothing must be in [0, 1]")
+        self.smoothing = float(smoothing)
+
+    def forward(self, input, target, length):
+        return _SeqLSCEFn.apply(input, target.to(input.device).long().contiguous(), length.to(input.device).long().contiguous(), self.smoothing)
+
+
+class _SeqLSCEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, length, smoothing):
+        B, T, C = logits.shape
+        x = logits.detach().float().contiguous()
+        rows = torch.empty(2 * B * T, device=x.device, dtype=F32)
+        loss = torch.empty(1, device=x.device, dtype=F32)
+        L.call("dig_seq_ls_cross_entropy", L.ptr(x), L.ptr(target), L.ptr(length), B, T, C, cf(smoothing), L.ptr(rows), L.ptr(loss), L.stream())
+        ctx.save_for_backward(x, target, length)
+        ctx.smoothing = smoothing
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        x, target, length = ctx.saved_tensors
+        B, T, C = x.shape
+        Cp = (C + 7) // 8 * 8
+        dl = torch.empty((B * T, Cp), device=x.device, dtype=BF16)
+        L.call("dig_seq_ls_cross_entropy_bwd", L.ptr(x), C, L.ptr(target), L.ptr(length), L.ptr(g.reshape(1).float().contiguous()), B, T, C,
+               cf(ctx.smoothing), L.ptr(dl), Cp, L.stream())
+        return dl[:, :C].float().reshape(B, T, C), None, None, None
+
+
 # -------------------------------------------------------------------------------------------------- optimizer
 def get_num_layer_for_vit(var_name, num_max_layer):
     """optim_factory.py:33-45."""

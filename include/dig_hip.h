@@ -258,6 +258,16 @@ int dig_seq_embed_bwd_lens(const long long* tokens, const void* dx, float* demb,
 int dig_seq_cross_entropy_bwd(const float* logits, int ld, const long long* target, const long long* length, const float* gscalar, int B,
                               int T, int C, void* dlogits, int ldd, hipStream_t stream);
 
+/* SeqLabelSmoothingCrossEntropyLoss (loss/seqLabelSmoothingCrossEntropyLoss.py:48-70; `--smoothing` > 0, run_class_finetuning.py:538-541)
+ * with the arithmetic the reference really performs: its `smooth_loss = -logprobs.mean(1) * mask` multiplies a [BT] vector with the
+ * [BT,1] mask, which broadcasts to [BT,BT], so
+ *   loss = ((1 - smoothing) * BT * sum_i mask_i nll_i + smoothing * (sum_i mask_i) * sum_j s_j) / B,  s_j = -mean_c log_softmax(x_j)_c
+ * over ALL rows j.  row_workspace: 2*B*T floats.  The backward writes bf16 rows of ldd >= C columns (pad columns zero), scaled by the
+ * device scalar *gscalar (null = 1). */
+int dig_seq_ls_cross_entropy(const float* input, const long long* target, const long long* length, int B, int T, int C, float smoothing,
+                             float* row_workspace, float* loss, hipStream_t stream);
+int dig_seq_ls_cross_entropy_bwd(const float* logits, int ld, const long long* target, const long long* length, const float* gscalar, int B,
+                                 int T, int C, float smoothing, void* dlogits, int ldd, hipStream_t stream);
 
 /* ---- dropout / stochastic depth of the fine-tune step (README.md:100-118: --drop 0.1 --attn_drop_rate 0.1 --drop_path 0.1; the
  * recognition decoder's hard-wired dropout = 0.1, models/decoder.py:141).  Replaces nn.Dropout (modeling_finetune.py:51,83-85,271;

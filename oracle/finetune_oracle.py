@@ -187,6 +187,18 @@ def loss_and_grads(P, ecfg, c, images, targets, lens, drop=None):
     return loss.item(), grads, logits.detach()
 
 
+def seq_label_smoothing_cross_entropy(logits, target, length, smoothing=0.1):
+    """SeqLabelSmoothingCrossEntropyLoss.forward (loss/seqLabelSmoothingCrossEntropyLoss.py:48-70, sample_normalize), operation by
+    operation -- including `-logprobs.mean(1) * mask`, a [BT] vector times the [BT, 1] mask, which broadcasts to [BT, BT]."""
+    B, T = target.shape
+    mask = (torch.arange(T)[None, :] < length[:, None]).reshape(-1, 1)
+    logprobs = TF.log_softmax(logits.reshape(-1, logits.shape[2]), dim=1)
+    nll_loss = -logprobs.gather(1, target.reshape(-1, 1).long()) * mask
+    smooth_loss = -logprobs.mean(1) * mask
+    loss = (1.0 - smoothing) * nll_loss + smoothing * smooth_loss
+    return torch.sum(loss) / B
+
+
 def layer_id(name, num_layers):
     """optim_factory.py:33-45,71-76: `encoder.` prefix stripped first; len(values) = num_layers + 2."""
     n = name[len("encoder."):] if name.startswith("encoder") else name

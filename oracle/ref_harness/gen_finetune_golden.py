@@ -248,5 +248,30 @@ def main_drop():
     print("wrote tests/golden/finetune_tiny_drop.npz")
 
 
+def main_smoothing():
+    """The reference SeqLabelSmoothingCrossEntropyLoss (run as is) on seeded logits -> tests/golden/seq_ls_loss.npz."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_seq_ls", os.path.join(refenv.REF, "loss", "seqLabelSmoothingCrossEntropyLoss.py"))
+    ref = importlib.util.module_from_spec(spec); spec.loader.exec_module(ref)
+    out = {}
+    for case, (B, T, C, sm, lens) in enumerate([(3, 5, 7, 0.1, [5, 2, 0]), (6, 25, 97, 0.1, [25, 1, 7, 13, 25, 3]), (2, 8, 97, 0.3, [8, 4])]):
+        g = torch.Generator().manual_seed(100 + case)
+        x = (torch.randn(B, T, C, generator=g) * 2).requires_grad_(True)
+        t = torch.randint(0, C, (B, T), generator=g)
+        l = torch.tensor(lens)
+        loss = ref.SeqLabelSmoothingCrossEntropyLoss(smoothing=sm)(x, t, l)
+        loss.backward()
+        mine = F.seq_label_smoothing_cross_entropy(x.detach(), t, l, sm)
+        assert abs(mine.item() - loss.item()) <= 1e-6 * abs(loss.item()), (mine.item(), loss.item())
+        out.update({f"c{case}/shape": np.array([B, T, C]), f"c{case}/smoothing": sm, f"c{case}/lens": l.numpy(), f"c{case}/target": t.numpy(),
+                    f"c{case}/logits": x.detach().numpy(), f"c{case}/loss": np.float64(loss.item()), f"c{case}/grad": x.grad.numpy()})
+        print(f"case {case}: reference loss {loss.item():.6f} == restatement")
+    np.savez_compressed(os.path.join(GOLD, "seq_ls_loss.npz"), **out)
+    print("wrote tests/golden/seq_ls_loss.npz")
+
+
 if __name__ == "__main__":
-    main_drop() if "--drop" in sys.argv else main()
+    if "--smoothing" in sys.argv:
+        main_smoothing()
+    else:
+        main_drop() if "--drop" in sys.argv else main()

@@ -538,3 +538,41 @@ def test_finetune_checkpoint_resume_is_bit_exact(tmp_path):
     assert l3b == l3
     got = m2.state_dict()
     assert all(torch.equal(got[k], want[k]) for k in want), [k for k in want if not torch.equal(got[k], want[k])][:5]
+
+
+# ---------------------------------------------------------------------------------------------- label smoothing (--smoothing > 0)
+def _ls_cases():
+    g = np.load(os.path.join(GOLD, "seq_ls_loss.npz"))
+    for case in range(3):
+        yield (torch.from_numpy(g[f"c{case}/logits"]), torch.from_numpy(g[f"c{case}/target"]), torch.from_numpy(g[f"c{case}/lens"]),
+               float(g[f"c{case}/smoothing"]), float(g[f"c{case}/loss"]), torch.from_numpy(g[f"c{case}/grad"]))
+
+
+def test_oracle_label_smoothing_loss_matches_reference_fixture():
+    """Literal restatement (with the reference's [BT] x [BT,1] broadcast) against values and gradients of the reference class."""
+    for x, t, l, sm, loss, grad in _ls_cases():
+        xx = x.clone().requires_grad_(True)
+        got = F.seq_label_smoothing_cross_entropy(xx, t, l, sm)
+        got.backward()
+        assert abs(got.item() - loss) <= 2e-6 * abs(loss)
+        np.testing.assert_allclose(xx.grad.numpy(), grad.numpy(), rtol=1e-4, atol=1e-5 * float(grad.abs().max()))
+        # the closed form the device kernels use
+        B, T, C = x.shape
+        lp = torch.log_softmax(x.reshape(-1, C), 1)
+        mask = (torch.arange(T)[None, :] < l[:, None]).reshape(-1).float()
+        nll = -lp.gather(1, t.reshape(-1, 1)).squeeze(1) * mask
+        closed = ((1 - sm) * B * T * nll.sum() + sm * mask.sum() * (-lp.mean(1)).sum()) / B
+        assert abs(closed.item() - loss) <= 2e-5 * abs(loss)
+
+
+@pytest.mark.gpu
+def test_device_label_smoothing_loss_vs_reference_fixture():
+    from dig_amd.finetune import SeqLabelSmoothingCrossEntropyLoss
+    for x, t, l, sm, loss, grad in _ls_cases():
+        xd = x.to("cuda:0").requires_grad_(True)
+        got = SeqLabelSmoothingCrossEntropyLoss(sm)(xd, t, l)
+        (got * 0.5).backward()
+        assert abs(got.item() - loss) <= 2e-5 * abs(loss)
+        gd = xd.grad.cpu() * 2
+        assert (gd - grad).abs().max().item() <= 1e-2 * grad.abs().max().item()          # bf16 gradient rows
+        assert (gd - grad).norm().item() <= 4e-3 * grad.norm().item()
