@@ -36,7 +36,9 @@ __device__ __forceinline__ bool key_ok(const SeqAttnParams& p, int i, int j, lon
   return (!p.causal || j <= i) && (!p.lens || j < len);
 }
 
-// Work split.  Score-shaped products (S = Q K^T, dP = dO V^T, dK = dS^T Q, dV = P^T dO): a thread owns ONE key, its K / V rows
+// L8 (few keys: the 25 x 25 self-attention, where a thread per key would leave 231 of 256 threads idle): 8 lanes share one key,
+// 8 channels each (a wave load covers 8 whole 128-byte rows), 32 keys per pass, dot products finished by three lane shuffles.
+// Work split otherwise.  Score-shaped products (S = Q K^T, dP = dO V^T, dK = dS^T Q, dV = P^T dO): a thread owns ONE key, its K / V rows
 // (or dK / dV accumulators) live in registers and the query-side rows are read from LDS as broadcasts -- pure FMA streams.
 // Output-shaped products (O = P V, dQ = dS K): a thread owns one channel d and every 4th query, K / V come from LDS (bf16,
 // consecutive lanes = consecutive channels) and the probabilities are broadcast reads.
@@ -66,6 +68,20 @@ __device__ __forceinline__ float dot64(const float* __restrict__ q, const float 
     s0 += x.x * k[4 * d4]; s1 += x.y * k[4 * d4 + 1]; s2 += x.z * k[4 * d4 + 2]; s3 += x.w * k[4 * d4 + 3];
   }
   return (s0 + s1) + (s2 + s3);
+}
+
+__device__ __forceinline__ void load8(const bf16_t* __restrict__ src, float (&r)[8]) {
+  const uint4 v = *reinterpret_cast<const uint4*>(src);
+  const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { r[2 * e] = bf2f((bf16_t)(w[e] & 0xffff)); r[2 * e + 1] = bf2f((bf16_t)(w[e] >> 16)); }
+}
+
+__device__ __forceinline__ float dot8_reduce(const float* __restrict__ q8, const float (&k)[8]) {   // 8 lanes x 8 channels -> full dot in all 8
+  const float4 a = reinterpret_cast<const float4*>(q8)[0], b = reinterpret_cast<const float4*>(q8)[1];
+  float s = (a.x * k[0] + a.y * k[1]) + (a.z * k[2] + a.w * k[3]) + (b.x * k[4] + b.y * k[5]) + (b.z * k[6] + b.w * k[7]);
+  s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+  return s;
 }
 
 // stage one [Lk][64] bf16 operand of this (sample, head) into LDS, 16 bytes per thread and step
@@ -99,6 +115,7 @@ __device__ __forceinline__ void rows_times_x(const float* __restrict__ W, const 
 }
 
 // LDS: Qs [MAXQ][64] f32 | S [MAXQ][Lk] f32 | rowinv [MAXQ] f32 | Vs [Lk][64] bf16
+template <bool L8>
 __global__ __launch_bounds__(256) void seq_attn_fwd_kernel(SeqAttnParams p, bf16_t* __restrict__ out, int ldo, float* __restrict__ lse) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* Qs = reinterpret_cast<float*>(smem);
@@ -113,10 +130,27 @@ __global__ __launch_bounds__(256) void seq_attn_fwd_kernel(SeqAttnParams p, bf16
   }
   stage64(p.v, p.ldv, b, h, p.Lk, Vs);
   __syncthreads();
-  for (int j = tid; j < p.Lk; j += 256) {                                // logits of my key against every query
-    float kr[DK];
-    load_row64(p.k + ((size_t)b * p.Lk + j) * p.ldk + h * DK, kr);
-    for (int i = 0; i < p.Lq; ++i) S[i * p.Lk + j] = key_ok(p, i, j, len) ? dot64(Qs + i * DK, kr) : -INFINITY;
+  if (L8) {
+    const int ch = tid & 7;
+    for (int j0 = 0; j0 < p.Lk; j0 += 32) {
+      const int j = j0 + (tid >> 3);
+      float k8[8];
+      if (j < p.Lk) load8(p.k + ((size_t)b * p.Lk + j) * p.ldk + h * DK + ch * 8, k8);
+      else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) k8[e] = 0.f;
+      }
+      for (int i = 0; i < p.Lq; ++i) {
+        const float sc = dot8_reduce(Qs + i * DK + ch * 8, k8);
+        if (ch == 0 && j < p.Lk) S[i * p.Lk + j] = key_ok(p, i, j, len) ? sc : -INFINITY;
+      }
+    }
+  } else {
+    for (int j = tid; j < p.Lk; j += 256) {                              // logits of my key against every query
+      float kr[DK];
+      load_row64(p.k + ((size_t)b * p.Lk + j) * p.ldk + h * DK, kr);
+      for (int i = 0; i < p.Lq; ++i) S[i * p.Lk + j] = key_ok(p, i, j, len) ? dot64(Qs + i * DK, kr) : -INFINITY;
+    }
   }
   __syncthreads();
   for (int i = wave; i < p.Lq; i += 4) {                                 // one wave per query row: softmax statistics
@@ -140,6 +174,7 @@ __global__ __launch_bounds__(256) void seq_attn_fwd_kernel(SeqAttnParams p, bf16
 }
 
 // LDS: Qs, Gs [MAXQ][64] f32 | P, dS [MAXQ][Lk] f32 | Ks [Lk][64] bf16
+template <bool L8>
 __global__ __launch_bounds__(256) void seq_attn_bwd_kernel(SeqAttnParams p, const bf16_t* __restrict__ dout, int ldo, const float* __restrict__ lse,
                                                            bf16_t* __restrict__ dq, int lddq, bf16_t* __restrict__ dk, int lddk,
                                                            bf16_t* __restrict__ dv, int lddv) {
@@ -160,18 +195,42 @@ __global__ __launch_bounds__(256) void seq_attn_bwd_kernel(SeqAttnParams p, cons
   }
   stage64(p.k, p.ldk, b, h, p.Lk, Ks);
   __syncthreads();
-  for (int j = tid; j < p.Lk; j += 256) {                                // my key: P[:, j] and dP[:, j]
-    float kr[DK], vr[DK];
-    load_row64(p.k + ((size_t)b * p.Lk + j) * p.ldk + h * DK, kr);
-    load_row64(p.v + ((size_t)b * p.Lk + j) * p.ldv + h * DK, vr);
-    for (int i = 0; i < p.Lq; ++i) {
-      float pr = 0.f, dp = 0.f;
-      if (key_ok(p, i, j, len)) {
-        pr = __expf(dot64(Qs + i * DK, kr) * p.scale - lse_row[i]);
-        dp = dot64(Gs + i * DK, vr) * drop_factor(p, b * gridDim.y + h, i, j);   // dP = mask * (dO V^T) / (1 - p)
+  if (L8) {
+    const int ch = tid & 7;
+    for (int j0 = 0; j0 < p.Lk; j0 += 32) {                              // P[:, j] and dP[:, j]
+      const int j = j0 + (tid >> 3);
+      float k8[8], v8[8];
+      if (j < p.Lk) {
+        load8(p.k + ((size_t)b * p.Lk + j) * p.ldk + h * DK + ch * 8, k8);
+        load8(p.v + ((size_t)b * p.Lk + j) * p.ldv + h * DK + ch * 8, v8);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { k8[e] = 0.f; v8[e] = 0.f; }
       }
-      P[i * p.Lk + j] = pr;
-      dS[i * p.Lk + j] = dp;
+      for (int i = 0; i < p.Lq; ++i) {
+        const float sc = dot8_reduce(Qs + i * DK + ch * 8, k8) * p.scale;
+        const float dp = dot8_reduce(Gs + i * DK + ch * 8, v8);
+        if (ch == 0 && j < p.Lk) {
+          const bool ok = key_ok(p, i, j, len);
+          P[i * p.Lk + j] = ok ? __expf(sc - lse_row[i]) : 0.f;
+          dS[i * p.Lk + j] = ok ? dp * drop_factor(p, b * gridDim.y + h, i, j) : 0.f;
+        }
+      }
+    }
+  } else {
+    for (int j = tid; j < p.Lk; j += 256) {                                // my key: P[:, j] and dP[:, j]
+      float kr[DK], vr[DK];
+      load_row64(p.k + ((size_t)b * p.Lk + j) * p.ldk + h * DK, kr);
+      load_row64(p.v + ((size_t)b * p.Lk + j) * p.ldv + h * DK, vr);
+      for (int i = 0; i < p.Lq; ++i) {
+        float pr = 0.f, dp = 0.f;
+        if (key_ok(p, i, j, len)) {
+          pr = __expf(dot64(Qs + i * DK, kr) * p.scale - lse_row[i]);
+          dp = dot64(Gs + i * DK, vr) * drop_factor(p, b * gridDim.y + h, i, j);   // dP = mask * (dO V^T) / (1 - p)
+        }
+        P[i * p.Lk + j] = pr;
+        dS[i * p.Lk + j] = dp;
+      }
     }
   }
   __syncthreads();
@@ -182,23 +241,46 @@ __global__ __launch_bounds__(256) void seq_attn_bwd_kernel(SeqAttnParams p, cons
     for (int j = lane; j < p.Lk; j += 64) dS[i * p.Lk + j] = P[i * p.Lk + j] * (dS[i * p.Lk + j] - del);
   }
   __syncthreads();
-  for (int j = tid; j < p.Lk; j += 256) {                                // my key: dK[j, :] = scale * sum_i dS[i,j] Q[i,:], dV[j, :] = sum_i P[i,j] dO[i,:]
-    float ak[DK], av[DK];
+  if (L8) {
+    const int ch = tid & 7;
+    for (int j0 = 0; j0 < p.Lk; j0 += 32) {                              // dK[j, 8 ch] = scale * sum_i dS[i,j] Q[i, ch], dV[j, 8 ch] = sum_i P~[i,j] dO[i, ch]
+      const int j = j0 + (tid >> 3);
+      if (j >= p.Lk) continue;
+      float ak[8], av[8];
 #pragma unroll
-    for (int d = 0; d < DK; ++d) { ak[d] = 0.f; av[d] = 0.f; }
-    for (int i = 0; i < p.Lq; ++i) {
-      const float ds = dS[i * p.Lk + j], pr = P[i * p.Lk + j] * drop_factor(p, b * gridDim.y + h, i, j);   // dV sees the dropped P
-#pragma unroll
-      for (int d4 = 0; d4 < DK / 4; ++d4) {
-        const float4 qv = reinterpret_cast<const float4*>(Qs + i * DK)[d4];
-        const float4 gv = reinterpret_cast<const float4*>(Gs + i * DK)[d4];
-        ak[4 * d4] += ds * qv.x; ak[4 * d4 + 1] += ds * qv.y; ak[4 * d4 + 2] += ds * qv.z; ak[4 * d4 + 3] += ds * qv.w;
-        av[4 * d4] += pr * gv.x; av[4 * d4 + 1] += pr * gv.y; av[4 * d4 + 2] += pr * gv.z; av[4 * d4 + 3] += pr * gv.w;
+      for (int e = 0; e < 8; ++e) { ak[e] = 0.f; av[e] = 0.f; }
+      for (int i = 0; i < p.Lq; ++i) {
+        const float ds = dS[i * p.Lk + j], pr = P[i * p.Lk + j] * drop_factor(p, b * gridDim.y + h, i, j);
+        const float4 q0 = reinterpret_cast<const float4*>(Qs + i * DK + ch * 8)[0], q1 = reinterpret_cast<const float4*>(Qs + i * DK + ch * 8)[1];
+        const float4 g0 = reinterpret_cast<const float4*>(Gs + i * DK + ch * 8)[0], g1 = reinterpret_cast<const float4*>(Gs + i * DK + ch * 8)[1];
+        ak[0] += ds * q0.x; ak[1] += ds * q0.y; ak[2] += ds * q0.z; ak[3] += ds * q0.w; ak[4] += ds * q1.x; ak[5] += ds * q1.y; ak[6] += ds * q1.z; ak[7] += ds * q1.w;
+        av[0] += pr * g0.x; av[1] += pr * g0.y; av[2] += pr * g0.z; av[3] += pr * g0.w; av[4] += pr * g1.x; av[5] += pr * g1.y; av[6] += pr * g1.z; av[7] += pr * g1.w;
       }
+      const size_t r = (size_t)b * p.Lk + j;
+      const float sc = p.scale;
+      *reinterpret_cast<uint4*>(dk + r * lddk + h * DK + ch * 8) = make_uint4(pack_bf2(ak[0] * sc, ak[1] * sc), pack_bf2(ak[2] * sc, ak[3] * sc),
+                                                                              pack_bf2(ak[4] * sc, ak[5] * sc), pack_bf2(ak[6] * sc, ak[7] * sc));
+      *reinterpret_cast<uint4*>(dv + r * lddv + h * DK + ch * 8) = make_uint4(pack_bf2(av[0], av[1]), pack_bf2(av[2], av[3]), pack_bf2(av[4], av[5]), pack_bf2(av[6], av[7]));
     }
-    const size_t r = (size_t)b * p.Lk + j;
-    store_row64(dk + r * lddk + h * DK, ak, p.scale);
-    store_row64(dv + r * lddv + h * DK, av, 1.f);
+  } else {
+    for (int j = tid; j < p.Lk; j += 256) {                                // my key: dK[j, :] = scale * sum_i dS[i,j] Q[i,:], dV[j, :] = sum_i P[i,j] dO[i,:]
+      float ak[DK], av[DK];
+  #pragma unroll
+      for (int d = 0; d < DK; ++d) { ak[d] = 0.f; av[d] = 0.f; }
+      for (int i = 0; i < p.Lq; ++i) {
+        const float ds = dS[i * p.Lk + j], pr = P[i * p.Lk + j] * drop_factor(p, b * gridDim.y + h, i, j);   // dV sees the dropped P
+  #pragma unroll
+        for (int d4 = 0; d4 < DK / 4; ++d4) {
+          const float4 qv = reinterpret_cast<const float4*>(Qs + i * DK)[d4];
+          const float4 gv = reinterpret_cast<const float4*>(Gs + i * DK)[d4];
+          ak[4 * d4] += ds * qv.x; ak[4 * d4 + 1] += ds * qv.y; ak[4 * d4 + 2] += ds * qv.z; ak[4 * d4 + 3] += ds * qv.w;
+          av[4 * d4] += pr * gv.x; av[4 * d4 + 1] += pr * gv.y; av[4 * d4 + 2] += pr * gv.z; av[4 * d4 + 3] += pr * gv.w;
+        }
+      }
+      const size_t r = (size_t)b * p.Lk + j;
+      store_row64(dk + r * lddk + h * DK, ak, p.scale);
+      store_row64(dv + r * lddv + h * DK, av, 1.f);
+    }
   }
   rows_times_x(dS, Ks, p.Lq, p.Lk, [&](int i, int d, float a) { dq[((size_t)b * p.Lq + i) * lddq + h * DK + d] = f2bf(a * p.scale); });
 }
@@ -294,8 +376,14 @@ extern "C" int dig_seq_attn_fwd_dropout(const void* q, int ldq, const void* k, i
   SeqAttnParams p{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldq, ldk, ldv, Lq, Lk, scale, causal, lens, drop ? *drop : dig_dropout_t{}};
   const size_t lds = lds_fwd(Lk);
   static size_t attr = 0;
-  if (lds > attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(seq_attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = lds; }
-  hipLaunchKernelGGL(seq_attn_fwd_kernel, dim3(B, heads), dim3(256), lds, stream, p, (bf16_t*)out, ldo, lse);
+  static size_t attr8 = 0;
+  if (Lk <= 64) {                                                            // few keys: 8 lanes per key
+    if (lds > attr8) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(seq_attn_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr8 = lds; }
+    hipLaunchKernelGGL(seq_attn_fwd_kernel<true>, dim3(B, heads), dim3(256), lds, stream, p, (bf16_t*)out, ldo, lse);
+    return dig_check_launch();
+  }
+  if (lds > attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(seq_attn_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = lds; }
+  hipLaunchKernelGGL(seq_attn_fwd_kernel<false>, dim3(B, heads), dim3(256), lds, stream, p, (bf16_t*)out, ldo, lse);
   return dig_check_launch();
 }
 
@@ -313,8 +401,15 @@ extern "C" int dig_seq_attn_bwd_dropout(const void* q, int ldq, const void* k, i
   SeqAttnParams p{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldq, ldk, ldv, Lq, Lk, scale, causal, lens, drop ? *drop : dig_dropout_t{}};
   const size_t lds = lds_bwd(Lk);
   static size_t attr = 0;
-  if (lds > attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(seq_attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = lds; }
-  hipLaunchKernelGGL(seq_attn_bwd_kernel, dim3(B, heads), dim3(256), lds, stream, p, (const bf16_t*)dout, ldo, lse, (bf16_t*)dq, lddq, (bf16_t*)dk,
+  static size_t attr8 = 0;
+  if (Lk <= 64 && !(lddk & 7) && !(lddv & 7) && aligned16(dk) && aligned16(dv)) {   // few keys: 8 lanes per key (16-byte dK / dV stores)
+    if (lds > attr8) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(seq_attn_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr8 = lds; }
+    hipLaunchKernelGGL(seq_attn_bwd_kernel<true>, dim3(B, heads), dim3(256), lds, stream, p, (const bf16_t*)dout, ldo, lse, (bf16_t*)dq, lddq,
+                       (bf16_t*)dk, lddk, (bf16_t*)dv, lddv);
+    return dig_check_launch();
+  }
+  if (lds > attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(seq_attn_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = lds; }
+  hipLaunchKernelGGL(seq_attn_bwd_kernel<false>, dim3(B, heads), dim3(256), lds, stream, p, (const bf16_t*)dout, ldo, lse, (bf16_t*)dq, lddq, (bf16_t*)dk,
                      lddk, (bf16_t*)dv, lddv);
   return dig_check_launch();
 }
