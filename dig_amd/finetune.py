@@ -302,6 +302,24 @@ class _TrainStep:
         x = ops.dropout_apply(x, self.ds_tgt, out=x)                            # decoder.py:180
         sc = dk ** -0.5
         self.dec_saved = []
+        mfma_cross = N == 256 and dk == 64
+        kv_ready = []
+        if mfma_cross:
+            # K|V projections of the encoder memory depend on no decoder state: all layers' are issued on the second stream now and
+            # overlap the (small, latency-bound) self-attention kernels of the decoder chain; one event per layer
+            main = torch.cuda.current_stream(dev)
+            sd = M._side_stream(dev) if getattr(M, "overlap_streams", True) else main
+            sd.wait_stream(main)
+            with torch.cuda.stream(sd):
+                for i in range(M.n_layers):
+                    o2, n2, _ = M._offsets[f"decoder.layer_stack.{i}.enc_attn.linear_k.weight"]
+                    fused = torch.empty((B * N, 3 * hk), device=dev, dtype=BF16)
+                    ops.gemm(mem, M._shadow[o2:o2 + 2 * n2].view(2 * hk, hk), B * N, 2 * hk, d, out=fused[:, hk:], ldc=3 * hk)
+                    ev = torch.cuda.Event()
+                    ev.record(sd)
+                    fused.record_stream(main)
+                    kv_ready.append((fused, ev))
+            mem.record_stream(sd)
         for i in range(M.n_layers):
             p = f"decoder.layer_stack.{i}."
             ds = self.ds_dec[i]
@@ -316,12 +334,12 @@ class _TrainStep:
             q2 = ops.linear_fwd(h2, self.w(p + "enc_attn.linear_q.weight"))
             o2, n2, s2 = M._offsets[p + "enc_attn.linear_k.weight"]
             wkv = M._shadow[o2:o2 + 2 * n2].view(2 * hk, hk)
-            if N == 256 and dk == 64:
+            if mfma_cross:
                 # cross-attention on the MFMA kernel of the encoder (256 keys, head dim 64): the T queries of a sample sit in rows
                 # [0, T) of a fused q|k|v buffer of 256 rows per sample, and the kernels are told to compute the first
                 # ceil(T / 32) query blocks only (rows T..31 are zero queries with a zero output gradient: no contribution).
-                fused = torch.empty((B * N, 3 * hk), device=dev, dtype=BF16)
-                ops.gemm(mem, wkv, B * N, 2 * hk, d, out=fused[:, hk:], ldc=3 * hk)
+                fused, ev = kv_ready[i]
+                torch.cuda.current_stream(dev).wait_event(ev)
                 fq = fused.view(B, N, 3 * hk)[:, :, :hk]
                 Tp = (T + 31) // 32 * 32                                          # the kernels work on whole 32-query blocks
                 fq[:, T:Tp].zero_()
@@ -386,7 +404,7 @@ class _TrainStep:
         do = ops.gemm(dl, self.cls_w, rows, d, CLS_PAD, tb=True)
         dx = ops.layernorm_bwd(do, x, self.p("decoder.layer_norm.weight"), self.p("decoder.layer_norm.bias"), fm, fr, None,
                                self.g("decoder.layer_norm.weight"), self.g("decoder.layer_norm.bias"))
-        dmem = None
+        self._dmem = None
         sc = dk ** -0.5
         mem = self.ln_saved[3]
         for i in reversed(range(M.n_layers)):
@@ -427,11 +445,14 @@ class _TrainStep:
             side(lambda: ops.linear_wgrad(dq2, h2, self.g(p + "enc_attn.linear_q.weight")), dq2, h2)
             dh2 = ops.linear_dgrad(dq2, self.w(p + "enc_attn.linear_q.weight"))
             side(lambda: ops.wgrad(dkvm, mem, M.flat_grads[o2:o2 + 2 * n2].view(2 * hk, hk), 2 * hk, hk, B * N), dkvm, mem)
-            dm = ops.gemm(dkvm, M._shadow[o2:o2 + 2 * n2].view(2 * hk, hk), B * N, hk, 2 * hk, tb=True)
-            if dmem is None:
-                dmem = dm
-            else:
-                ops.add_bf16(dmem, dm, dmem)
+            # the gradient w.r.t. the encoder memory is needed only after the decoder loop: its GEMMs run on the second stream too
+            def mem_grad(dkvm=dkvm, o2=o2, n2=n2):
+                dm = ops.gemm(dkvm, M._shadow[o2:o2 + 2 * n2].view(2 * hk, hk), B * N, hk, 2 * hk, tb=True)
+                if self._dmem is None:
+                    self._dmem = dm
+                else:
+                    ops.add_bf16(self._dmem, dm, self._dmem)
+            side(mem_grad, dkvm)
             dx1 = ops.layernorm_bwd(dh2, x1, self.p(p + "norm2.weight"), self.p(p + "norm2.bias"), m2, r2, dx2, self.g(p + "norm2.weight"),
                                     self.g(p + "norm2.bias"))
             # masked self-attention
@@ -452,6 +473,9 @@ class _TrainStep:
         # ---- linear_norm
         h, mmu, mrs, _ = self.ln_saved
         x_last, emu, ers, enc = self.enc_last
+        main.wait_stream(sd)                                                    # the memory gradient was summed on the second stream
+        dmem, self._dmem = self._dmem, None
+        dmem.record_stream(main)
         dh = ops.layernorm_bwd(dmem, h, self.p("linear_norm.1.weight"), self.p("linear_norm.1.bias"), mmu, mrs, None, self.g("linear_norm.1.weight"),
                                self.g("linear_norm.1.bias"))
         side(lambda: ops.linear_wgrad(dh, enc, self.g("linear_norm.0.weight")), dh, enc)
