@@ -500,8 +500,10 @@ class _TrainStep:
             side(lambda: ops.colsum_partials(bparts, self.g(b + "mlp.fc1.bias")), bparts)
             side(lambda: ops.linear_wgrad(dact, ln2, self.g(b + "mlp.fc1.weight")), dact, ln2)
             dln2 = ops.linear_dgrad(dact, self.w(b + "mlp.fc1.weight"))
-            dx_mid = ops.layernorm_bwd(dln2, x_mid, self.p(b + "norm2.weight"), self.p(b + "norm2.bias"), mu2, rs2, dx, self.g(b + "norm2.weight"),
-                                       self.g(b + "norm2.bias"), out=dln2, dres_colsum=self.g(b + "mlp.fc2.bias") if ds["mlp"] is None else None)
+            dx_mid, fin2, ws2 = ops.layernorm_bwd(dln2, x_mid, self.p(b + "norm2.weight"), self.p(b + "norm2.bias"), mu2, rs2, dx,
+                                                  self.g(b + "norm2.weight"), self.g(b + "norm2.bias"), out=dln2,
+                                                  dres_colsum=self.g(b + "mlp.fc2.bias") if ds["mlp"] is None else None, defer=True)
+            side(fin2, ws2)                                                       # parameter-gradient reduction: off the chain
             dz = ops.dropout_apply(dx_mid, ds["proj"])
             if ds["proj"] is not None:
                 side(lambda: ops.colsum(dz, self.g(b + "attn.proj.bias")), dz)
@@ -512,8 +514,10 @@ class _TrainStep:
             side(lambda: ops.colsum(dqkv, self.g(b + "attn.q_bias"), cols=D), dqkv)
             side(lambda: ops.colsum(dqkv[:, 2 * D:], self.g(b + "attn.v_bias"), cols=D))
             dln1 = ops.linear_dgrad(dqkv, self.w(b + "attn.qkv.weight"), out=dctx)
-            dx = ops.layernorm_bwd(dln1, x, self.p(b + "norm1.weight"), self.p(b + "norm1.bias"), mu1, rs1, dx_mid, self.g(b + "norm1.weight"),
-                                   self.g(b + "norm1.bias"), out=dln1, dres_colsum=self.g(b + "attn.proj.bias") if ds["proj"] is None else None)
+            dx, fin1, ws1 = ops.layernorm_bwd(dln1, x, self.p(b + "norm1.weight"), self.p(b + "norm1.bias"), mu1, rs1, dx_mid,
+                                              self.g(b + "norm1.weight"), self.g(b + "norm1.bias"), out=dln1,
+                                              dres_colsum=self.g(b + "attn.proj.bias") if ds["proj"] is None else None, defer=True)
+            side(fin1, ws1)
         dx = ops.dropout_apply(dx, self.ds_pos, out=dx)
         gtok = torch.zeros(D, device=dev, dtype=F32)                          # mask_token takes no part at fine-tune: gradient discarded
         ops.patch_embed_bwd_mfma(dx, self.images, self.zmask, self.g("encoder.patch_embed.proj.weight").view(D, 48),
