@@ -576,3 +576,32 @@ def test_device_label_smoothing_loss_vs_reference_fixture():
         gd = xd.grad.cpu() * 2
         assert (gd - grad).abs().max().item() <= 1e-2 * grad.abs().max().item()          # bf16 gradient rows
         assert (gd - grad).norm().item() <= 4e-3 * grad.norm().item()
+
+
+# ---------------------------------------------------------------------------------------------- GRU attention head (--decoder_type attention)
+import attn_decoder_oracle as AD
+
+
+def _attn_fixture():
+    g = np.load(os.path.join(GOLD, "attn_decoder_tiny.npz"))
+    ecfg = O.DiGConfig(**O.TINY)
+    c = AD.AttnDecConfig(**{**AD.TINY, "in_planes": ecfg.embed_dim})
+    P = {**D.det_encoder_state(ecfg, int(g["seed_enc"])), **AD.det_state(c, int(g["seed_dec"]))}
+    images = O.synthetic_batch(int(g["B"]), ecfg, int(g["batch_seed"]))[0]
+    return g, c, ecfg, P, images, torch.from_numpy(g["targets"]), torch.from_numpy(g["lens"])
+
+
+def test_oracle_gru_attention_head_matches_reference_fixture():
+    g, c, ecfg, P, images, targets, lens = _attn_fixture()
+    loss, grads, logits = AD.loss_and_grads(P, ecfg, c, images, targets, lens)
+    assert abs(loss - float(g["loss"])) < 1e-5 * float(g["loss"])
+    np.testing.assert_allclose(logits.numpy(), g["logits"], atol=3e-5)
+    assert float(logits[:, int(lens.max()):].abs().max()) == 0.0              # steps past max(lengths) are never run: zero rows
+    norms = g["grad_norms"]
+    for i, n in enumerate(g["grad_names"].tolist()):
+        gi = grads[n]
+        assert abs(gi.double().norm().item() - norms[i]) <= 3e-4 * norms[i] + 1e-6 * norms.max(), n
+        got = np.resize(gi.reshape(-1)[_sample_index(gi.numel())].numpy(), 8)
+        np.testing.assert_allclose(got, g["grad_samples"][i], rtol=2e-3, atol=1e-5 * (np.abs(g["grad_samples"][i]).max() + 1e-3) + 1e-6 * norms.max())
+    probs = AD.head_sample(P, c, D.encoder_features(P, ecfg, images))
+    np.testing.assert_allclose(probs.numpy(), g["sample_probs"], atol=3e-5)
