@@ -38,6 +38,7 @@ def _pad256(n):
 
 class RecModelTrain(RecModel):
     """`RecModel` with trainable flat arenas.  `.train()` forward = teacher-forced logits with autograd; `.eval()` = greedy decode."""
+    _step_cls = None                                    # set below (the forward / backward of one step)
 
     def __init__(self, args=None, *, drop_rate=None, attn_drop_rate=None, drop_path_rate=None, decoder_dropout=0.1, drop_seed=None, **kw):
         """Drop rates: from `args` (--drop / --attn_drop_rate / --drop_path, run_class_finetuning.py:69-74 -> create_model,
@@ -77,35 +78,30 @@ class RecModelTrain(RecModel):
         patch-embed convolution, the decoder and `linear_norm` keep PyTorch's defaults (nn.Conv2d / nn.Linear: U(-1/sqrt(fan_in),
         1/sqrt(fan_in)) for weight and bias; nn.Embedding: N(0, 1); models/model_builder.py:78-89 adds nothing); mask_token,
         q_bias, v_bias zero.  Fine-tuning then overwrites the encoder from the pre-training checkpoint (`load_pretrained`)."""
-        sd = OrderedDict()
-        for k, shp in self.param_shapes().items():
-            enc = k.startswith("encoder.")
-            if k.endswith("mask_token") or k.endswith("q_bias") or k.endswith("v_bias"):
-                t = torch.zeros(shp)
-            elif "norm" in k.split(".")[-2] and len(shp) == 1 or k.startswith("linear_norm.1."):
-                t = torch.ones(shp) if k.endswith("weight") else torch.zeros(shp)
-            elif k.endswith("trg_word_emb.weight"):
-                t = torch.randn(shp)
-            elif k.endswith(".weight"):
-                fan_in = 1
-                for d_ in shp[1:]:
-                    fan_in *= d_
-                if enc and len(shp) == 2:
-                    a = math.sqrt(6.0 / (shp[0] + shp[1]))                      # xavier_uniform_
-                else:
-                    a = 1.0 / math.sqrt(fan_in)                                # kaiming_uniform_(a=sqrt(5))
-                t = (torch.rand(shp) * 2 - 1) * a
-            else:                                                              # biases
-                if enc and "patch_embed" not in k:
-                    t = torch.zeros(shp)
-                else:
-                    w = self.param_shapes()[k[:-4] + "weight"]
-                    fan_in = 1
-                    for d_ in w[1:]:
-                        fan_in *= d_
-                    t = (torch.rand(shp) * 2 - 1) / math.sqrt(fan_in)
-            sd[k] = t
+        sd = OrderedDict((k, self._init_tensor(k, shp)) for k, shp in self.param_shapes().items())
         self.load_state_dict(sd)
+
+    def _init_tensor(self, k, shp):
+        enc = k.startswith("encoder.")
+        if k.endswith("mask_token") or k.endswith("q_bias") or k.endswith("v_bias"):
+            return torch.zeros(shp)
+        if "norm" in k.split(".")[-2] and len(shp) == 1 or k.startswith("linear_norm.1."):
+            return torch.ones(shp) if k.endswith("weight") else torch.zeros(shp)
+        if k.endswith("trg_word_emb.weight"):
+            return torch.randn(shp)
+        if k.endswith(".weight"):
+            fan_in = 1
+            for d_ in shp[1:]:
+                fan_in *= d_
+            a = math.sqrt(6.0 / (shp[0] + shp[1])) if enc and len(shp) == 2 else 1.0 / math.sqrt(fan_in)   # xavier_uniform_ / kaiming_uniform_(a=sqrt(5))
+            return (torch.rand(shp) * 2 - 1) * a
+        if enc and "patch_embed" not in k:                                     # biases
+            return torch.zeros(shp)
+        w = self.param_shapes()[k[:-4] + "weight"]
+        fan_in = 1
+        for d_ in w[1:]:
+            fan_in *= d_
+        return (torch.rand(shp) * 2 - 1) / math.sqrt(fan_in)
 
     def load_pretrained(self, checkpoint, model_key="model|module", prefix=""):
         """run_class_finetuning.py:362-440 for the simmim_vit encoders: pick `checkpoint[model_key]`, strip a `backbone.` prefix,
@@ -242,32 +238,47 @@ class _TrainStep:
     def g(self, name):
         return self.m._view(self.m.flat_grads, name)
 
-    # ---------------------------------------------------------------- forward
-    def forward(self, images, targets, lens):
+    # ---------------------------------------------------------------- two streams (backward)
+    def begin_backward(self, dev):
+        """Two HIP streams, as in the pre-training backward (engine_core.encoder_backward): the data-gradient chain (dgrad GEMMs,
+        attention / LayerNorm backward) stays on the caller's stream; weight-gradient GEMMs and bias column sums only consume
+        (dy, saved activation) pairs and run on a second stream, joined before the optimizer."""
+        M = self.m
+        self._main = torch.cuda.current_stream(dev)
+        self._sd = M._side_stream(dev) if getattr(M, "overlap_streams", True) else self._main
+        return self._main, self._sd
+
+    def side(self, fn, *tensors):
+        if self._sd is self._main:
+            fn()
+            return
+        self._sd.wait_stream(self._main)
+        with torch.cuda.stream(self._sd):
+            fn()
+        for t in tensors:
+            t.record_stream(self._sd)
+
+    def encoder_forward(self, images):
+        """PretrainVisionTransformerEncoder.forward (modeling_pretrain_vit.py:89-112, mask=None) on the pre-training hot-path kernels;
+        returns the normalised tokens [B*N, D] (bf16) and keeps what `encoder_backward` needs."""
         M = self.m
         dev = images.device
         M.refresh_shadow()
         D, H, N = M.D, M.H, M.N
         B = images.shape[0]
-        T, d, nh, dk = M.max_len, M.d, M.nh, M.dk
-        hk = nh * dk
         self.B, self.images = B, images.contiguous().float()
         self.zmask = torch.zeros((B, N), device=dev, dtype=torch.uint8)
         # ---- encoder (PretrainVisionTransformerEncoder.forward_features, mask=None) -- the pre-training hot-path kernels
         x = ops.patch_embed_fwd(self.images, self.p("encoder.patch_embed.proj.weight").view(D, 48), self.p("encoder.patch_embed.proj.bias"),
                                 self.zmask, self.p("encoder.mask_token").view(D), M._enc_pos, D, M.gh, M.gw)
         # dropout / drop-path keys of this step (dig_amd/dropout.py); every spec is None when its rate is 0
-        plan = DR.DropPlan(M.drop_seed, M.drop_step)
+        plan = self.plan = DR.DropPlan(M.drop_seed, M.drop_step)
         M.drop_step += 1
-        pe, pa, pd = M.drop_rate, M.attn_drop_rate, M.decoder_dropout
+        pe, pa = M.drop_rate, M.attn_drop_rate
         self.ds_pos = None                              # PretrainVisionTransformerEncoder has no pos_drop (modeling_pretrain_vit.py:89-106)
         self.ds_enc = [dict(attn=plan.spec(DR.enc_site(i, 0), pa),
                             proj=plan.spec(DR.enc_site(i, 1), pe, DR.enc_site(i, 2), M.dpr[i], N),
                             mlp=plan.spec(DR.enc_site(i, 3), pe, DR.enc_site(i, 4), M.dpr[i], N)) for i in range(M.depth)]
-        self.ds_tgt = plan.spec(DR.DEC_TGT, pd)
-        self.ds_dec = [dict(sattn=plan.spec(DR.dec_site(i, 0), pd), sproj=plan.spec(DR.dec_site(i, 1), pd),
-                            cattn=plan.spec(DR.dec_site(i, 2), pd), cproj=plan.spec(DR.dec_site(i, 3), pd),
-                            act=plan.spec(DR.dec_site(i, 4), pd), out=plan.spec(DR.dec_site(i, 5), pd)) for i in range(M.n_layers)]
         x = ops.dropout_apply(x, self.ds_pos, out=x)
         scale = (D // H) ** -0.5
         self.enc_saved = []
@@ -288,6 +299,23 @@ class _TrainStep:
             x = x_out
         enc, emu, ers = ops.layernorm_fwd(x, self.p("encoder.norm.weight"), self.p("encoder.norm.bias"), 1e-6)
         self.enc_last = (x, emu, ers, enc)
+        return enc
+
+    # ---------------------------------------------------------------- forward
+    def forward(self, images, targets, lens):
+        M = self.m
+        dev = images.device
+        enc = self.encoder_forward(images)
+        D, H, N = M.D, M.H, M.N
+        B = self.B
+        T, d, nh, dk = M.max_len, M.d, M.nh, M.dk
+        hk = nh * dk
+        plan = self.plan
+        pd = M.decoder_dropout
+        self.ds_tgt = plan.spec(DR.DEC_TGT, pd)
+        self.ds_dec = [dict(sattn=plan.spec(DR.dec_site(i, 0), pd), sproj=plan.spec(DR.dec_site(i, 1), pd),
+                            cattn=plan.spec(DR.dec_site(i, 2), pd), cproj=plan.spec(DR.dec_site(i, 3), pd),
+                            act=plan.spec(DR.dec_site(i, 4), pd), out=plan.spec(DR.dec_site(i, 5), pd)) for i in range(M.n_layers)]
         # ---- linear_norm
         h = ops.linear_fwd(enc, self.w("linear_norm.0.weight"), bias=self.p("linear_norm.0.bias"))
         mem, mmu, mrs = ops.layernorm_fwd(h, self.p("linear_norm.1.weight"), self.p("linear_norm.1.bias"), 1e-5)
@@ -371,26 +399,61 @@ class _TrainStep:
         ops.gemm(o, self.cls_w, B * T, CLS_PAD, d, out=logits, out_kind=ops.OUT_F32, bias=cb)
         return logits[:, :C].reshape(B, T, C)
 
+    def encoder_backward(self, denc):
+        """denc: bf16 [B*N, D] gradient w.r.t. the tokens `encoder_forward` returned (call `begin_backward` first)."""
+        M = self.m
+        dev = denc.device
+        D, H, N = M.D, M.H, M.N
+        x_last, emu, ers, enc = self.enc_last
+        dx = ops.layernorm_bwd(denc, x_last, self.p("encoder.norm.weight"), self.p("encoder.norm.bias"), emu, ers, None, self.g("encoder.norm.weight"),
+                               self.g("encoder.norm.bias"))
+        # ---- encoder (same chain as the pre-training backward, one view, no masking)
+        scale = (D // H) ** -0.5
+        for i in reversed(range(M.depth)):
+            b = f"encoder.blocks.{i}."
+            x, ln1, mu1, rs1, qkv, ctx, lse, x_mid, ln2, mu2, rs2, pre, act = self.enc_saved[i]
+            self.enc_saved[i] = None
+            ds = self.ds_enc[i]
+            # a dropped branch (dropout and/or drop-path) back-propagates the residual gradient under the same mask; its bias
+            # gradient is then the column sum of the MASKED gradient, so the LayerNorm kernel's fused residual column sum is off
+            dz = ops.dropout_apply(dx, ds["mlp"])
+            if ds["mlp"] is not None:
+                self.side(lambda: ops.colsum(dz, self.g(b + "mlp.fc2.bias")), dz)
+            self.side(lambda: ops.linear_wgrad(dz, act, self.g(b + "mlp.fc2.weight")), dz, act)
+            dact, bparts = ops.linear_dgrad(dz, self.w(b + "mlp.fc2.weight"), gelu_pre=pre, colsum=True)
+            self.side(lambda: ops.colsum_partials(bparts, self.g(b + "mlp.fc1.bias")), bparts)
+            self.side(lambda: ops.linear_wgrad(dact, ln2, self.g(b + "mlp.fc1.weight")), dact, ln2)
+            dln2 = ops.linear_dgrad(dact, self.w(b + "mlp.fc1.weight"))
+            dx_mid, fin2, ws2 = ops.layernorm_bwd(dln2, x_mid, self.p(b + "norm2.weight"), self.p(b + "norm2.bias"), mu2, rs2, dx,
+                                                  self.g(b + "norm2.weight"), self.g(b + "norm2.bias"), out=dln2,
+                                                  dres_colsum=self.g(b + "mlp.fc2.bias") if ds["mlp"] is None else None, defer=True)
+            self.side(fin2, ws2)                                                       # parameter-gradient reduction: off the chain
+            dz = ops.dropout_apply(dx_mid, ds["proj"])
+            if ds["proj"] is not None:
+                self.side(lambda: ops.colsum(dz, self.g(b + "attn.proj.bias")), dz)
+            self.side(lambda: ops.linear_wgrad(dz, ctx, self.g(b + "attn.proj.weight")), dz, ctx)
+            dctx = ops.linear_dgrad(dz, self.w(b + "attn.proj.weight"))
+            dqkv = ops.attn_bwd(qkv, ctx, dctx, lse, self.B, H, D, scale, drop=ds["attn"])
+            self.side(lambda: ops.linear_wgrad(dqkv, ln1, self.g(b + "attn.qkv.weight")), dqkv, ln1)
+            self.side(lambda: ops.colsum(dqkv, self.g(b + "attn.q_bias"), cols=D), dqkv)
+            self.side(lambda: ops.colsum(dqkv[:, 2 * D:], self.g(b + "attn.v_bias"), cols=D))
+            dln1 = ops.linear_dgrad(dqkv, self.w(b + "attn.qkv.weight"), out=dctx)
+            dx, fin1, ws1 = ops.layernorm_bwd(dln1, x, self.p(b + "norm1.weight"), self.p(b + "norm1.bias"), mu1, rs1, dx_mid,
+                                              self.g(b + "norm1.weight"), self.g(b + "norm1.bias"), out=dln1,
+                                              dres_colsum=self.g(b + "attn.proj.bias") if ds["proj"] is None else None, defer=True)
+            self.side(fin1, ws1)
+        dx = ops.dropout_apply(dx, self.ds_pos, out=dx)
+        gtok = torch.zeros(D, device=dev, dtype=F32)                          # mask_token takes no part at fine-tune: gradient discarded
+        ops.patch_embed_bwd_mfma(dx, self.images, self.zmask, self.g("encoder.patch_embed.proj.weight").view(D, 48),
+                                 self.g("encoder.patch_embed.proj.bias"), gtok, D, M.gh, M.gw)
+
     # ---------------------------------------------------------------- backward
     def backward(self, dlogits_btc):
         """dlogits_btc: fp32 [B, T, C] gradient w.r.t. the returned logits."""
         M = self.m
         dev = dlogits_btc.device
-        # Two HIP streams, as in the pre-training backward (engine_core.encoder_backward): the data-gradient chain (dgrad GEMMs,
-        # attention / LayerNorm backward) stays on the caller's stream; weight-gradient GEMMs and bias column sums only consume
-        # (dy, saved activation) pairs and run on a second stream, joined before the optimizer.
-        main = torch.cuda.current_stream(dev)
-        sd = M._side_stream(dev) if getattr(M, "overlap_streams", True) else main
-
-        def side(fn, *tensors):
-            if sd is main:
-                fn()
-                return
-            sd.wait_stream(main)
-            with torch.cuda.stream(sd):
-                fn()
-            for t in tensors:
-                t.record_stream(sd)
+        main, sd = self.begin_backward(dev)
+        side = self.side
         B, T, d, nh, dk, C, N, D, H = self.B, M.max_len, M.d, M.nh, M.dk, M.nb_classes, M.N, M.D, M.H
         hk = nh * dk
         rows = B * T
@@ -481,54 +544,17 @@ class _TrainStep:
         side(lambda: ops.linear_wgrad(dh, enc, self.g("linear_norm.0.weight")), dh, enc)
         side(lambda: ops.colsum(dh, self.g("linear_norm.0.bias")), dh)
         denc = ops.linear_dgrad(dh, self.w("linear_norm.0.weight"))
-        dx = ops.layernorm_bwd(denc, x_last, self.p("encoder.norm.weight"), self.p("encoder.norm.bias"), emu, ers, None, self.g("encoder.norm.weight"),
-                               self.g("encoder.norm.bias"))
-        # ---- encoder (same chain as the pre-training backward, one view, no masking)
-        scale = (D // H) ** -0.5
-        for i in reversed(range(M.depth)):
-            b = f"encoder.blocks.{i}."
-            x, ln1, mu1, rs1, qkv, ctx, lse, x_mid, ln2, mu2, rs2, pre, act = self.enc_saved[i]
-            self.enc_saved[i] = None
-            ds = self.ds_enc[i]
-            # a dropped branch (dropout and/or drop-path) back-propagates the residual gradient under the same mask; its bias
-            # gradient is then the column sum of the MASKED gradient, so the LayerNorm kernel's fused residual column sum is off
-            dz = ops.dropout_apply(dx, ds["mlp"])
-            if ds["mlp"] is not None:
-                side(lambda: ops.colsum(dz, self.g(b + "mlp.fc2.bias")), dz)
-            side(lambda: ops.linear_wgrad(dz, act, self.g(b + "mlp.fc2.weight")), dz, act)
-            dact, bparts = ops.linear_dgrad(dz, self.w(b + "mlp.fc2.weight"), gelu_pre=pre, colsum=True)
-            side(lambda: ops.colsum_partials(bparts, self.g(b + "mlp.fc1.bias")), bparts)
-            side(lambda: ops.linear_wgrad(dact, ln2, self.g(b + "mlp.fc1.weight")), dact, ln2)
-            dln2 = ops.linear_dgrad(dact, self.w(b + "mlp.fc1.weight"))
-            dx_mid, fin2, ws2 = ops.layernorm_bwd(dln2, x_mid, self.p(b + "norm2.weight"), self.p(b + "norm2.bias"), mu2, rs2, dx,
-                                                  self.g(b + "norm2.weight"), self.g(b + "norm2.bias"), out=dln2,
-                                                  dres_colsum=self.g(b + "mlp.fc2.bias") if ds["mlp"] is None else None, defer=True)
-            side(fin2, ws2)                                                       # parameter-gradient reduction: off the chain
-            dz = ops.dropout_apply(dx_mid, ds["proj"])
-            if ds["proj"] is not None:
-                side(lambda: ops.colsum(dz, self.g(b + "attn.proj.bias")), dz)
-            side(lambda: ops.linear_wgrad(dz, ctx, self.g(b + "attn.proj.weight")), dz, ctx)
-            dctx = ops.linear_dgrad(dz, self.w(b + "attn.proj.weight"))
-            dqkv = ops.attn_bwd(qkv, ctx, dctx, lse, self.B, H, D, scale, drop=ds["attn"])
-            side(lambda: ops.linear_wgrad(dqkv, ln1, self.g(b + "attn.qkv.weight")), dqkv, ln1)
-            side(lambda: ops.colsum(dqkv, self.g(b + "attn.q_bias"), cols=D), dqkv)
-            side(lambda: ops.colsum(dqkv[:, 2 * D:], self.g(b + "attn.v_bias"), cols=D))
-            dln1 = ops.linear_dgrad(dqkv, self.w(b + "attn.qkv.weight"), out=dctx)
-            dx, fin1, ws1 = ops.layernorm_bwd(dln1, x, self.p(b + "norm1.weight"), self.p(b + "norm1.bias"), mu1, rs1, dx_mid,
-                                              self.g(b + "norm1.weight"), self.g(b + "norm1.bias"), out=dln1,
-                                              dres_colsum=self.g(b + "attn.proj.bias") if ds["proj"] is None else None, defer=True)
-            side(fin1, ws1)
-        dx = ops.dropout_apply(dx, self.ds_pos, out=dx)
-        gtok = torch.zeros(D, device=dev, dtype=F32)                          # mask_token takes no part at fine-tune: gradient discarded
-        ops.patch_embed_bwd_mfma(dx, self.images, self.zmask, self.g("encoder.patch_embed.proj.weight").view(D, 48),
-                                 self.g("encoder.patch_embed.proj.bias"), gtok, D, M.gh, M.gw)
+        self.encoder_backward(denc)
         main.wait_stream(sd)
+
+
+RecModelTrain._step_cls = _TrainStep
 
 
 class _RecTrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, model, images, targets, lens):
-        step = _TrainStep(model)
+        step = model._step_cls(model)
         logits = step.forward(images, targets, lens)
         ctx.step = step
         return logits

@@ -317,6 +317,34 @@ int dig_seq_attn_bwd_dropout(const void* q, int ldq, const void* k, int ldk, con
                              const float* lse, void* dq, int lddq, void* dk, int lddk, void* dv, int lddv, int B, int heads, int Lq, int Lk,
                              float scale, int causal, const long long* lens, const dig_dropout_t* drop, hipStream_t stream);
 
+
+/* ---- GRU attention recognition head (`--decoder_type attention`: models/model_builder.py:40-72 AttnRecModel,
+ * models/attn_decoder.py:11-78 AttentionRecognitionHead, :197-272 AttentionUnit / DecoderUnit).  One call per time step (the recurrence
+ * orders the steps); the Linear layers run on dig_gemm_bf16.
+ * dig_addattn_fwd: alpha[b,:] = softmax_n(w . tanh(sproj[b,:] + xproj[b,n,:])) (fp32 [B,N], kept for the backward) and
+ *   context[b,:] = sum_n alpha[b,n] x[b,n,:] written to ctx + b*ldc (bf16: ldc lets it land inside the GRU input [yProj | context]).
+ *   xproj [B,N,A], sproj [B,A], x [B,N,X] bf16; w [A] fp32 (wEmbed.weight; its bias cancels in the softmax).  N <= 512, A <= 1024.
+ * dig_addattn_bwd (one step): dctx [B,X] (bf16 rows of stride ldd) -> dv [B,N] fp32 (gradient w.r.t. the scores, kept), dsproj [B,A]
+ *   bf16, dw_acc [B,A] fp32 += per-sample partials of the wEmbed.weight gradient.
+ * dig_addattn_bwd_tokens (after the last step): dxproj [B,N,A] and dx [B,N,X] (bf16) as sums over the T steps, from the kept dv_all
+ *   [T,B,N], alpha_all [T,B,N] (fp32), sproj_all [T,B,A] and dctx_all rows (t,b) of stride ldd (bf16) -- the per-step [B,N,*] gradients
+ *   are never materialised. */
+int dig_addattn_fwd(const void* xproj, const void* sproj, const float* w, const void* x, float* alpha, void* ctx, int ldc, int B, int N, int A,
+                    int X, hipStream_t stream);
+int dig_addattn_bwd(const void* xproj, const void* sproj, const float* w, const void* x, const float* alpha, const void* dctx, int ldd, float* dv,
+                    void* dsproj, float* dw_acc, int B, int N, int A, int X, hipStream_t stream);
+int dig_addattn_bwd_tokens(const void* xproj, const void* sproj_all, const float* w, const float* dv_all, const float* alpha_all,
+                           const void* dctx_all, int ldd, void* dxproj, void* dx, int T, int B, int N, int A, int X, hipStream_t stream);
+/* torch.nn.GRU cell (gate order r | z | n): gi = W_ih [yProj|context] + b_ih, gh = W_hh s + b_hh as bf16 [B,3S] from the GEMMs;
+ * s_prev fp32 [B,S] (NULL = zeros) -> s (fp32) and its bf16 copy; gates [B,4S] fp32 = r | z | n | gh_n kept for the backward.
+ * Backward: ds = ds_a + ds_b + ds_c + ds_d (fp32, NULL terms skipped: classifier path, z-path of the later step and its two GEMM
+ * paths) -> dgi, dgh [B,3S] bf16 and ds_prev = z * ds. */
+int dig_gru_cell_fwd(const void* gi, const void* gh, const float* s_prev, float* s, void* s_bf16, float* gates, int B, int S, hipStream_t stream);
+int dig_gru_cell_bwd(const float* ds_a, const float* ds_b, const float* ds_c, const float* ds_d, const float* gates, const float* s_prev, void* dgi,
+                     void* dgh, float* ds_prev, int B, int S, hipStream_t stream);
+/* out[r, :cols] (bf16, row stride ld) = table[clamp(tokens[r]), :cols] (fp32 table): tgt_embedding lookups (attn_decoder.py:264). */
+int dig_embed_rows(const long long* tokens, const float* table, void* out, int ld, int rows, int cols, int vocab, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

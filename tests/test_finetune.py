@@ -605,3 +605,121 @@ def test_oracle_gru_attention_head_matches_reference_fixture():
         np.testing.assert_allclose(got, g["grad_samples"][i], rtol=2e-3, atol=1e-5 * (np.abs(g["grad_samples"][i]).max() + 1e-3) + 1e-6 * norms.max())
     probs = AD.head_sample(P, c, D.encoder_features(P, ecfg, images))
     np.testing.assert_allclose(probs.numpy(), g["sample_probs"], atol=3e-5)
+
+
+@pytest.mark.gpu
+def test_gru_attention_kernels_vs_torch():
+    """dig_addattn_fwd / _bwd / _bwd_tokens and dig_gru_cell_fwd / _bwd against torch autograd on the same (bf16-rounded) operands."""
+    from dig_amd import _lib as L
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(12)
+    B, N, A, X, T = 5, 256, 64, 128, 3
+    xproj = torch.randn(B, N, A, generator=g).bfloat16(); x = torch.randn(B, N, X, generator=g).bfloat16()
+    w = torch.randn(A, generator=g) * 0.3
+    sproj = [torch.randn(B, A, generator=g).bfloat16() for _ in range(T)]
+    dctx = [torch.randn(B, X, generator=g).bfloat16() for _ in range(T)]
+    xp = xproj.float().requires_grad_(True); xx = x.float().requires_grad_(True); ww = w.clone().requires_grad_(True)
+    sp = [s_.float().requires_grad_(True) for s_ in sproj]
+    alphas, ctxs = [], []
+    for t in range(T):
+        v = torch.tanh(sp[t][:, None, :] + xp) @ ww
+        al = v.softmax(1)
+        c_ = torch.bmm(al[:, None, :], xx)[:, 0]
+        alphas.append(al); ctxs.append(c_)
+        c_.backward(dctx[t].float(), retain_graph=True)
+    xd, xpd, wd = x.to(dev).view(B * N, X), xproj.to(dev).view(B * N, A), w.to(dev)
+    alpha_all = torch.empty(T, B, N, device=dev); dv_all = torch.empty(T, B, N, device=dev)
+    sproj_all = torch.stack(sproj).to(dev); dctx_all = torch.stack(dctx).to(dev)
+    dsproj_all = torch.empty(T, B, A, device=dev, dtype=torch.bfloat16); dw_acc = torch.zeros(B, A, device=dev)
+    for t in range(T):
+        ctx = torch.empty(B, X, device=dev, dtype=torch.bfloat16)
+        L.call("dig_addattn_fwd", L.ptr(xpd), L.ptr(sproj_all[t]), L.ptr(wd), L.ptr(xd), L.ptr(alpha_all[t]), L.ptr(ctx), X, B, N, A, X, L.stream())
+        assert (alpha_all[t].cpu() - alphas[t].detach()).abs().max() < 2e-4 * alphas[t].max().item() + 1e-6
+        assert (ctx.float().cpu() - ctxs[t].detach()).abs().max() < 2e-2 * ctxs[t].abs().max().item()
+        L.call("dig_addattn_bwd", L.ptr(xpd), L.ptr(sproj_all[t]), L.ptr(wd), L.ptr(xd), L.ptr(alpha_all[t]), L.ptr(dctx_all[t]), X, L.ptr(dv_all[t]),
+               L.ptr(dsproj_all[t]), L.ptr(dw_acc), B, N, A, X, L.stream())
+        assert (dsproj_all[t].float().cpu() - sp[t].grad).abs().max() < 2e-2 * sp[t].grad.abs().max().item()
+    assert (dw_acc.sum(0).cpu() - ww.grad).abs().max() < 1e-3 * ww.grad.abs().max().item()
+    dxproj = torch.empty(B * N, A, device=dev, dtype=torch.bfloat16); dx = torch.empty(B * N, X, device=dev, dtype=torch.bfloat16)
+    L.call("dig_addattn_bwd_tokens", L.ptr(xpd), L.ptr(sproj_all), L.ptr(wd), L.ptr(dv_all), L.ptr(alpha_all), L.ptr(dctx_all), X, L.ptr(dxproj), L.ptr(dx),
+           T, B, N, A, X, L.stream())
+    assert (dxproj.float().cpu().view(B, N, A) - xp.grad).abs().max() < 2e-2 * xp.grad.abs().max().item()
+    assert (dx.float().cpu().view(B, N, X) - xx.grad).abs().max() < 2e-2 * xx.grad.abs().max().item()
+    # GRU cell
+    S = 128
+    cell = torch.nn.GRUCell(7, S)
+    gi = torch.randn(B, 3 * S, generator=g).bfloat16(); gh = torch.randn(B, 3 * S, generator=g).bfloat16(); s0 = torch.randn(B, S, generator=g)
+    gif, ghf, s0f = gi.float().requires_grad_(True), gh.float().requires_grad_(True), s0.clone().requires_grad_(True)
+    r = torch.sigmoid(gif[:, :S] + ghf[:, :S]); z = torch.sigmoid(gif[:, S:2 * S] + ghf[:, S:2 * S]); n = torch.tanh(gif[:, 2 * S:] + r * ghf[:, 2 * S:])
+    s1 = (1 - z) * n + z * s0f
+    ds = torch.randn(B, S, generator=g)
+    s1.backward(ds)
+    sd_ = torch.empty(B, S, device=dev); sbf = torch.empty(B, S, device=dev, dtype=torch.bfloat16); gates = torch.empty(B, 4 * S, device=dev)
+    gid, ghd, s0d = gi.to(dev), gh.to(dev), s0.to(dev)                         # (keep the device copies alive across the launches)
+    L.call("dig_gru_cell_fwd", L.ptr(gid), L.ptr(ghd), L.ptr(s0d), L.ptr(sd_), L.ptr(sbf), L.ptr(gates), B, S, L.stream())
+    assert (sd_.cpu() - s1.detach()).abs().max() < 1e-5
+    dgi = torch.empty(B, 3 * S, device=dev, dtype=torch.bfloat16); dgh = torch.empty_like(dgi); dsp = torch.empty(B, S, device=dev)
+    half = (ds * 0.5).to(dev)
+    L.call("dig_gru_cell_bwd", L.ptr(half), L.ptr(half), None, None, L.ptr(gates), L.ptr(s0d), L.ptr(dgi), L.ptr(dgh), L.ptr(dsp), B, S, L.stream())
+    assert (dgi.float().cpu() - gif.grad).abs().max() < 1e-2 * gif.grad.abs().max().item()
+    assert (dgh.float().cpu() - ghf.grad).abs().max() < 1e-2 * ghf.grad.abs().max().item()
+    assert (dsp.cpu() - (ds * z.detach())).abs().max() < 1e-5
+
+
+def _attn_device_model(c, ecfg, P):
+    from dig_amd.attn_recognizer import AttnRecModelTrain
+    m = AttnRecModelTrain(embed_dim=ecfg.embed_dim, depth=ecfg.depth, num_heads=ecfg.heads, nb_classes=c.num_classes, max_len=c.max_len, sDim=c.sDim,
+                          attDim=c.attDim)
+    m.load_state_dict(P)
+    m.to("cuda:0")
+    return m
+
+
+@pytest.mark.gpu
+def test_device_gru_attention_model_vs_reference_fixture():
+    """AttnRecModel training step (teacher forcing, SeqCrossEntropyLoss, hand-written BPTT) and greedy sample against the fixture
+    written from the unmodified reference; gradient yardstick = the oracle under CPU bf16 autocast."""
+    from dig_amd.finetune import SeqCrossEntropyLoss
+    g, c, ecfg, P, images, targets, lens = _attn_fixture()
+    m = _attn_device_model(c, ecfg, P).train()
+    assert list(m.state_dict().keys())[-len(AD.param_shapes(c)):] == list(AD.param_shapes(c))
+    for p in m.parameters():
+        p.grad.zero_()
+    logits = m((images.to("cuda:0"), targets, lens))[0]
+    loss = SeqCrossEntropyLoss()(logits, targets, lens)
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) < 2e-2 * float(g["loss"])
+    ref_logits = torch.from_numpy(g["logits"])
+    assert ((logits.detach().cpu() - ref_logits).norm() / ref_logits.norm()).item() < 2e-2
+    assert float(logits.detach()[:, int(lens.max()):].abs().max()) == 0.0
+    _, ref_g, _ = AD.loss_and_grads(P, ecfg, c, images, targets, lens)
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        _, bf_g, _ = AD.loss_and_grads(P, ecfg, c, images, targets, lens)
+    grads = {n: p.grad.detach().float().cpu() for n, p in m.named_parameters()}
+    cos = torch.nn.functional.cosine_similarity
+    names, norms = g["grad_names"].tolist(), g["grad_norms"]
+    tot = float(np.sqrt((norms ** 2).sum()))
+    bad = []
+    for i, n in enumerate(names):
+        if norms[i] < 1e-3 * tot:
+            continue
+        rr = ref_g[n].reshape(1, -1)
+        c_hip, c_bf = cos(grads[n].reshape(1, -1), rr).item(), cos(bf_g[n].float().reshape(1, -1), rr).item()
+        q_hip, q_bf = grads[n].norm().item() / norms[i], bf_g[n].float().norm().item() / norms[i]
+        if (1 - c_hip) > 2 * (1 - c_bf) + 5e-3 or abs(q_hip - 1) > 2 * abs(q_bf - 1) + 3e-2:
+            bad.append((n, c_hip, c_bf, q_hip, q_bf))
+    assert not bad, bad
+    # greedy sample (eval)
+    m.eval()
+    probs = m((images.to("cuda:0"), None, None))[0].cpu()
+    ref = torch.from_numpy(g["sample_probs"])
+    srt = ref.sort(-1, descending=True)[0]
+    margin = srt[..., 0] - srt[..., 1]
+    same = probs.argmax(-1) == ref.argmax(-1)
+    # steps are compared while the greedy paths agree (a near-tie flips a token and the later steps legitimately differ)
+    for b in range(ref.shape[0]):
+        for t in range(ref.shape[1]):
+            if not same[b, t]:
+                assert margin[b, t] < 5e-2, (b, t, float(margin[b, t]))
+                break
+            assert (probs[b, t] - ref[b, t]).abs().max() < 3e-2
