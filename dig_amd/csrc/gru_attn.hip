@@ -42,60 +42,96 @@ __device__ __forceinline__ float token_score(const bf16_t* __restrict__ xp_row, 
 }
 
 // ---- forward: alpha (fp32, saved) and context (bf16, written at ctx + b * ldc: the caller points it into the GRU input [yProj | context])
-__global__ __launch_bounds__(256) void addattn_fwd_kernel(const bf16_t* __restrict__ xproj, const bf16_t* __restrict__ sproj,
-                                                          const float* __restrict__ w, const bf16_t* __restrict__ x, float* __restrict__ alpha,
-                                                          bf16_t* __restrict__ ctx, int ldc, int N, int A, int X) {
-  __shared__ float sp[MAXA], ws[MAXA], v[MAXN];
-  __shared__ float red[4];
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int a = tid; a < A; a += 256) { sp[a] = bf2f(sproj[(size_t)b * A + a]); ws[a] = w[a]; }
+constexpr int NT = 512, NW = NT / 64;     // one workgroup per sample and only B of them: 8 waves keep enough loads in flight per CU
+
+__device__ __forceinline__ float block_max(float v, float* red, int lane, int wave) {
+  v = wave_max(v);
+  if (lane == 0) red[wave] = v;
   __syncthreads();
-  for (int n = wave; n < N; n += 4) {
+  float m = red[0];
+#pragma unroll
+  for (int i = 1; i < NW; ++i) m = fmaxf(m, red[i]);
+  __syncthreads();
+  return m;
+}
+__device__ __forceinline__ float block_sum(float v, float* red, int lane, int wave) {
+  v = wave_sum(v);
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  float m = 0.f;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) m += red[i];
+  __syncthreads();
+  return m;
+}
+
+__global__ __launch_bounds__(NT) void addattn_fwd_kernel(const bf16_t* __restrict__ xproj, const bf16_t* __restrict__ sproj,
+                                                         const float* __restrict__ w, const bf16_t* __restrict__ x, float* __restrict__ alpha,
+                                                         bf16_t* __restrict__ ctx, int ldc, int N, int A, int X) {
+  __shared__ float sp[MAXA], ws[MAXA], v[MAXN], part[2 * MAXA];
+  __shared__ float red[NW];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int a = tid; a < A; a += NT) { sp[a] = bf2f(sproj[(size_t)b * A + a]); ws[a] = w[a]; }
+  __syncthreads();
+  for (int n = wave; n < N; n += NW) {
     const float s = token_score(xproj + ((size_t)b * N + n) * A, sp, ws, A, lane);
     if (lane == 0) v[n] = s;
   }
   __syncthreads();
   float m = -INFINITY;
-  for (int n = tid; n < N; n += 256) m = fmaxf(m, v[n]);
-  m = wave_max(m);
-  if (lane == 0) red[wave] = m;
-  __syncthreads();
-  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-  __syncthreads();
+  for (int n = tid; n < N; n += NT) m = fmaxf(m, v[n]);
+  m = block_max(m, red, lane, wave);
   float s = 0.f;
-  for (int n = tid; n < N; n += 256) { const float e = __expf(v[n] - m); v[n] = e; s += e; }
-  s = wave_sum(s);
-  if (lane == 0) red[wave] = s;
+  for (int n = tid; n < N; n += NT) { const float e = __expf(v[n] - m); v[n] = e; s += e; }
+  const float inv = 1.f / block_sum(s, red, lane, wave);
+  for (int n = tid; n < N; n += NT) { const float a = v[n] * inv; v[n] = a; alpha[(size_t)b * N + n] = a; }
   __syncthreads();
-  const float inv = 1.f / (red[0] + red[1] + red[2] + red[3]);
-  for (int n = tid; n < N; n += 256) { const float a = v[n] * inv; v[n] = a; alpha[(size_t)b * N + n] = a; }
-  __syncthreads();
-  for (int c = tid * 2; c < X; c += 512) {                               // context: two channels per thread, rows read coalesced
+  // context: a thread owns two channels (rows read coalesced); when the pairs fit in half the block, the two halves of the block
+  // take one half of the tokens each and meet in LDS
+  const int CP = X / 2;
+  if (CP <= NT / 2) {
+    const int half = tid >= NT / 2 ? 1 : 0, cp = tid - half * (NT / 2);
     float a0 = 0.f, a1 = 0.f;
-    const bf16_t* xb = x + (size_t)b * N * X + c;
-    for (int n = 0; n < N; ++n) {
-      const unsigned p = *reinterpret_cast<const unsigned*>(xb + (size_t)n * X);
-      a0 += v[n] * bf2f((bf16_t)(p & 0xffff));
-      a1 += v[n] * bf2f((bf16_t)(p >> 16));
+    if (cp < CP) {
+      const bf16_t* xb = x + (size_t)b * N * X + 2 * cp;
+      const int n_hi = half ? N : N / 2;
+      for (int n = half ? N / 2 : 0; n < n_hi; ++n) {
+        const unsigned p = *reinterpret_cast<const unsigned*>(xb + (size_t)n * X);
+        a0 += v[n] * bf2f((bf16_t)(p & 0xffff));
+        a1 += v[n] * bf2f((bf16_t)(p >> 16));
+      }
+      if (half) { part[2 * cp] = a0; part[2 * cp + 1] = a1; }
     }
-    *reinterpret_cast<unsigned*>(ctx + (size_t)b * ldc + c) = pack_bf2(a0, a1);
+    __syncthreads();
+    if (!half && cp < CP) *reinterpret_cast<unsigned*>(ctx + (size_t)b * ldc + 2 * cp) = pack_bf2(a0 + part[2 * cp], a1 + part[2 * cp + 1]);
+  } else {
+    for (int c = tid * 2; c < X; c += 2 * NT) {
+      float a0 = 0.f, a1 = 0.f;
+      const bf16_t* xb = x + (size_t)b * N * X + c;
+      for (int n = 0; n < N; ++n) {
+        const unsigned p = *reinterpret_cast<const unsigned*>(xb + (size_t)n * X);
+        a0 += v[n] * bf2f((bf16_t)(p & 0xffff));
+        a1 += v[n] * bf2f((bf16_t)(p >> 16));
+      }
+      *reinterpret_cast<unsigned*>(ctx + (size_t)b * ldc + c) = pack_bf2(a0, a1);
+    }
   }
 }
 
 // ---- backward of one step: dctx [B, X] (bf16, row stride ldd) -> dv [B, N] (fp32, kept for the final kernels), dsproj [B, A] (bf16),
 // dw_acc [B, A] (fp32, += : per-sample partials of the wEmbed gradient, summed over samples at the end)
-__global__ __launch_bounds__(256) void addattn_bwd_kernel(const bf16_t* __restrict__ xproj, const bf16_t* __restrict__ sproj,
-                                                          const float* __restrict__ w, const bf16_t* __restrict__ x, const float* __restrict__ alpha,
-                                                          const bf16_t* __restrict__ dctx, int ldd, float* __restrict__ dv_out,
-                                                          bf16_t* __restrict__ dsproj, float* __restrict__ dw_acc, int N, int A, int X) {
-  __shared__ float sp[MAXA], ws[MAXA], dv[MAXN], dc[MAXA];
-  __shared__ float red[4];
+__global__ __launch_bounds__(NT) void addattn_bwd_kernel(const bf16_t* __restrict__ xproj, const bf16_t* __restrict__ sproj,
+                                                         const float* __restrict__ w, const bf16_t* __restrict__ x, const float* __restrict__ alpha,
+                                                         const bf16_t* __restrict__ dctx, int ldd, float* __restrict__ dv_out,
+                                                         bf16_t* __restrict__ dsproj, float* __restrict__ dw_acc, int N, int A, int X) {
+  __shared__ float sp[MAXA], ws[MAXA], dv[MAXN], dc[MAXA], part[4 * (NT / 2)];
+  __shared__ float red[NW];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int a = tid; a < A; a += 256) { sp[a] = bf2f(sproj[(size_t)b * A + a]); ws[a] = w[a]; }
-  for (int c = tid; c < X; c += 256) dc[c] = bf2f(dctx[(size_t)b * ldd + c]);          // (X <= MAXA)
+  for (int a = tid; a < A; a += NT) { sp[a] = bf2f(sproj[(size_t)b * A + a]); ws[a] = w[a]; }
+  for (int c = tid; c < X; c += NT) dc[c] = bf2f(dctx[(size_t)b * ldd + c]);           // (X <= MAXA)
   __syncthreads();
   // dalpha[n] = dctx . x[n, :]: a wave per token
-  for (int n = wave; n < N; n += 4) {
+  for (int n = wave; n < N; n += NW) {
     float acc = 0.f;
     const bf16_t* xr = x + ((size_t)b * N + n) * X;
     for (int c0 = lane * 8; c0 < X; c0 += 512) {
@@ -109,31 +145,54 @@ __global__ __launch_bounds__(256) void addattn_bwd_kernel(const bf16_t* __restri
   }
   __syncthreads();
   float dot = 0.f;
-  for (int n = tid; n < N; n += 256) dot += alpha[(size_t)b * N + n] * dv[n];
-  dot = wave_sum(dot);
-  if (lane == 0) red[wave] = dot;
-  __syncthreads();
-  dot = red[0] + red[1] + red[2] + red[3];
-  for (int n = tid; n < N; n += 256) {
+  for (int n = tid; n < N; n += NT) dot += alpha[(size_t)b * N + n] * dv[n];
+  dot = block_sum(dot, red, lane, wave);
+  for (int n = tid; n < N; n += NT) {
     const float g = alpha[(size_t)b * N + n] * (dv[n] - dot);            // softmax backward
     dv[n] = g;
     dv_out[(size_t)b * N + n] = g;
   }
   __syncthreads();
-  // dsproj[a] = sum_n dv[n] * w[a] * (1 - t^2),  dw[a] += sum_n dv[n] * t,  t = tanh(sp[a] + xproj[n, a]): a thread owns channels
-  for (int a = tid * 2; a < A; a += 512) {
+  // dsproj[a] = sum_n dv[n] * w[a] * (1 - t^2),  dw[a] += sum_n dv[n] * t,  t = tanh(sp[a] + xproj[n, a]): a thread owns two channels;
+  // when the pairs fit in half the block the two halves take one half of the tokens each
+  const int AP = A / 2;
+  if (AP <= NT / 2) {
+    const int half = tid >= NT / 2 ? 1 : 0, ap = tid - half * (NT / 2), a = 2 * ap;
     float g0 = 0.f, g1 = 0.f, w0 = 0.f, w1 = 0.f;
-    const bf16_t* xb = xproj + (size_t)b * N * A + a;
-    for (int n = 0; n < N; ++n) {
-      const unsigned p = *reinterpret_cast<const unsigned*>(xb + (size_t)n * A);
-      const float t0 = tanh_fast(sp[a] + bf2f((bf16_t)(p & 0xffff))), t1 = tanh_fast(sp[a + 1] + bf2f((bf16_t)(p >> 16)));
-      const float d = dv[n];
-      g0 += d * (1.f - t0 * t0); g1 += d * (1.f - t1 * t1);
-      w0 += d * t0; w1 += d * t1;
+    if (ap < AP) {
+      const bf16_t* xb = xproj + (size_t)b * N * A + a;
+      const int n_hi = half ? N : N / 2;
+      for (int n = half ? N / 2 : 0; n < n_hi; ++n) {
+        const unsigned p = *reinterpret_cast<const unsigned*>(xb + (size_t)n * A);
+        const float t0 = tanh_fast(sp[a] + bf2f((bf16_t)(p & 0xffff))), t1 = tanh_fast(sp[a + 1] + bf2f((bf16_t)(p >> 16)));
+        const float d = dv[n];
+        g0 += d * (1.f - t0 * t0); g1 += d * (1.f - t1 * t1);
+        w0 += d * t0; w1 += d * t1;
+      }
+      if (half) { part[4 * ap] = g0; part[4 * ap + 1] = g1; part[4 * ap + 2] = w0; part[4 * ap + 3] = w1; }
     }
-    *reinterpret_cast<unsigned*>(dsproj + (size_t)b * A + a) = pack_bf2(g0 * ws[a], g1 * ws[a + 1]);
-    dw_acc[(size_t)b * A + a] += w0;
-    dw_acc[(size_t)b * A + a + 1] += w1;
+    __syncthreads();
+    if (!half && ap < AP) {
+      g0 += part[4 * ap]; g1 += part[4 * ap + 1]; w0 += part[4 * ap + 2]; w1 += part[4 * ap + 3];
+      *reinterpret_cast<unsigned*>(dsproj + (size_t)b * A + a) = pack_bf2(g0 * ws[a], g1 * ws[a + 1]);
+      dw_acc[(size_t)b * A + a] += w0;
+      dw_acc[(size_t)b * A + a + 1] += w1;
+    }
+  } else {
+    for (int a = tid * 2; a < A; a += 2 * NT) {
+      float g0 = 0.f, g1 = 0.f, w0 = 0.f, w1 = 0.f;
+      const bf16_t* xb = xproj + (size_t)b * N * A + a;
+      for (int n = 0; n < N; ++n) {
+        const unsigned p = *reinterpret_cast<const unsigned*>(xb + (size_t)n * A);
+        const float t0 = tanh_fast(sp[a] + bf2f((bf16_t)(p & 0xffff))), t1 = tanh_fast(sp[a + 1] + bf2f((bf16_t)(p >> 16)));
+        const float d = dv[n];
+        g0 += d * (1.f - t0 * t0); g1 += d * (1.f - t1 * t1);
+        w0 += d * t0; w1 += d * t1;
+      }
+      *reinterpret_cast<unsigned*>(dsproj + (size_t)b * A + a) = pack_bf2(g0 * ws[a], g1 * ws[a + 1]);
+      dw_acc[(size_t)b * A + a] += w0;
+      dw_acc[(size_t)b * A + a + 1] += w1;
+    }
   }
 }
 
@@ -247,7 +306,7 @@ extern "C" int dig_addattn_fwd(const void* xproj, const void* sproj, const float
   if (!xproj || !sproj || !w || !x || !alpha || !ctx || B <= 0 || N <= 0 || N > MAXN || A <= 0 || A > MAXA || (A & 7) || X <= 0 || (X & 1) || (ldc & 1))
     return DIG_ERR_ARG;
   if (!aligned16(xproj)) return DIG_ERR_ALIGN;
-  hipLaunchKernelGGL(addattn_fwd_kernel, dim3(B), dim3(256), 0, stream, (const bf16_t*)xproj, (const bf16_t*)sproj, w, (const bf16_t*)x, alpha,
+  hipLaunchKernelGGL(addattn_fwd_kernel, dim3(B), dim3(NT), 0, stream, (const bf16_t*)xproj, (const bf16_t*)sproj, w, (const bf16_t*)x, alpha,
                      (bf16_t*)ctx, ldc, N, A, X);
   return dig_check_launch();
 }
@@ -258,7 +317,7 @@ extern "C" int dig_addattn_bwd(const void* xproj, const void* sproj, const float
       X <= 0 || X > MAXA || (X & 7))
     return DIG_ERR_ARG;
   if (!aligned16(xproj) || !aligned16(x)) return DIG_ERR_ALIGN;
-  hipLaunchKernelGGL(addattn_bwd_kernel, dim3(B), dim3(256), 0, stream, (const bf16_t*)xproj, (const bf16_t*)sproj, w, (const bf16_t*)x, alpha,
+  hipLaunchKernelGGL(addattn_bwd_kernel, dim3(B), dim3(NT), 0, stream, (const bf16_t*)xproj, (const bf16_t*)sproj, w, (const bf16_t*)x, alpha,
                      (const bf16_t*)dctx, ldd, dv, (bf16_t*)dsproj, dw_acc, N, A, X);
   return dig_check_launch();
 }
