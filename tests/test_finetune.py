@@ -723,3 +723,31 @@ def test_device_gru_attention_model_vs_reference_fixture():
                 assert margin[b, t] < 5e-2, (b, t, float(margin[b, t]))
                 break
             assert (probs[b, t] - ref[b, t]).abs().max() < 3e-2
+
+
+@pytest.mark.gpu
+def test_gru_attention_model_through_the_engine_loops():
+    """AttnRecModel through dig_amd.engine_for_finetuning: train_one_epoch (2 micro-batches, update_freq 1) lowers nothing it should
+    not -- first-step loss equals the oracle's, parameters move -- and evaluate() runs the greedy sample with the reference's meters."""
+    import types
+    from dig_amd.finetune import SeqCrossEntropyLoss, LayerDecayValueAssigner, create_optimizer
+    from dig_amd.engine_for_finetuning import train_one_epoch, evaluate
+    from dig_amd.utils import NativeScalerWithGradNormCount
+    g, c, ecfg, P, images, targets, lens = _attn_fixture()
+    m = _attn_device_model(c, ecfg, P)
+    nl, lr, wd = m.get_num_layers(), 1e-3, 0.05
+    asg = LayerDecayValueAssigner([0.75 ** (nl + 1 - i) for i in range(nl + 2)])
+    args = types.SimpleNamespace(opt="adamw", lr=lr, weight_decay=wd, opt_eps=1e-8, opt_betas=None, eval_freq=1000, beam_width=0)
+    opt = create_optimizer(args, m, get_num_layer=asg.get_layer_id, get_layer_scale=asg.get_scale)
+    voc = D.vocabulary()
+    loader = type("Ldr", (list,), {})([(images, targets, lens), (images.flip(0), targets.flip(0), lens.flip(0))])
+    loader.dataset = types.SimpleNamespace(idx_to_class={i: ch for i, ch in enumerate(voc)})
+    before = m.flat_params.detach().clone()
+    stats = train_one_epoch(m, SeqCrossEntropyLoss(), loader, opt, torch.device("cuda:0"), 0, NativeScalerWithGradNormCount(), None, None, None,
+                            None, start_steps=0, lr_schedule_values=np.array([lr, lr]), wd_schedule_values=np.array([wd, wd]),
+                            num_training_steps_per_epoch=2, update_freq=1, args=args)
+    assert np.isfinite(stats["loss"]) and not torch.equal(before, m.flat_params)
+    o_loss = AD.loss_and_grads(P, ecfg, c, images, targets, lens)[0]
+    assert stats["loss"] < 1.05 * o_loss                                       # mean of step 1 (= oracle loss) and step 2 (after one update)
+    ev = evaluate(loader, m, torch.device("cuda:0"), args=args)
+    assert set(ev) >= {"loss", "acc", "recognition_fmeasure"} and np.isfinite(ev["loss"]) and 0.0 <= ev["acc"] <= 100.0
