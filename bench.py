@@ -216,12 +216,15 @@ def main():
         mim_only = {"workload": WORKLOAD_TEXT["mim_only" if a.workload == "mim_moco" else "mim_moco"],
                     "value": a.steps * B * world / dt1, "unit": "images/sec", "ms_per_step": dt1 / a.steps * 1e3, "steps": a.steps}
     # ---- roofline of the dominant kernel: one extra, instrumented step (outside the timed region)
+    # (EVERY rank runs these two steps -- they contain the step's collectives; only rank 0 instruments its launches)
     roof = None
+    import contextlib
+    model.overlap_streams = False                     # kernels one at a time, so event brackets time single launches
+    probe = GemmProbe() if rank == 0 else contextlib.nullcontext()
+    with probe:
+        run(2, a.warmup + a.steps)
+    model.overlap_streams = True
     if rank == 0:
-        model.overlap_streams = False                 # kernels one at a time, so event brackets time single launches
-        with GemmProbe() as probe:
-            run(2, a.warmup + a.steps)
-        model.overlap_streams = True
         summ = probe.summary()
         dom = max(summ, key=lambda k: summ[k]["seconds"])
         d = summ[dom]

@@ -61,6 +61,8 @@ def init_distributed_mode(args):
         args.rank = int(os.environ["RANK"])
         args.world_size = int(os.environ['WORLD_SIZE'])
         args.gpu = int(os.environ.get('LOCAL_RANK', 0))
+        if os.environ.get("DIG_SHARE_GPU") == "1":           # harness test only: every rank on device 0 (with DIG_DIST_BACKEND=gloo)
+            args.gpu = 0
     else:
         print('Not using distributed mode')
         args.distributed = False
@@ -68,10 +70,11 @@ def init_distributed_mode(args):
         return
     args.distributed = True
     torch.cuda.set_device(args.gpu)
-    args.dist_backend = 'nccl'
+    args.dist_backend = os.environ.get("DIG_DIST_BACKEND", "nccl")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    extra = {"device_id": torch.device("cuda", args.gpu)} if args.dist_backend == "nccl" else {}
     dist.init_process_group(backend=args.dist_backend, init_method=getattr(args, "dist_url", "env://"),
-                            world_size=args.world_size, rank=args.rank, device_id=torch.device("cuda", args.gpu))
+                            world_size=args.world_size, rank=args.rank, **extra)
     dist.barrier()
 
 

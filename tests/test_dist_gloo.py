@@ -311,3 +311,22 @@ def _ft_engine_worker(rank, world, port, q):
 @pytest.mark.gpu
 def test_finetune_two_ranks_on_one_gpu_data_parallel_invariance():
     _run(_ft_engine_worker, 2)
+
+
+@pytest.mark.gpu
+def test_bench_harness_two_ranks_on_one_gpu():
+    """bench.py end to end with WORLD_SIZE = 2 (gloo, both ranks on device 0): every rank must take part in every step that holds
+    collectives (the roofline probe steps included) and rank 0 prints one JSON line for n_gpus = 2."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DIG_DIST_BACKEND="gloo", DIG_SHARE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+           str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "8", "--no-mim-only",
+           "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 1 and line["value"] > 0 and line["scaling"] == "weak"
+    assert line["roofline"]["achieved"] > 0 and line["config"]["global_batch"] == 16
