@@ -58,10 +58,6 @@ def linear_fwd(x, w, *, bias=None, resid=None, act=0, pre=None, alpha=1.0, alpha
     rows = x.shape[0]
     if rows >= 8192 and w.shape[0] >= 384 and rows * w.shape[0] >= (1 << 24) and not (drop is not None and act):
         bk = 244
-        if w.shape[0] % 256 == 128 and w.shape[0] < 512 and drop is None:
-            # 384 outputs = 1.5 tiles of 256: a quarter of the 256x256 tile's columns would be padding.  256x128 (K <= 512) and
-            # 128x128/BK64 (long K) tile it exactly: 41.9 -> 36.7 us and 108.4 -> 103.3 us alone, -0.08 ms per step in the A/B
-            bk = 242 if K <= 512 else 0
     elif act == 1:
         bk = 32
     elif rows <= 2048 and w.shape[0] <= 512 and K >= 2048 and drop is None:
