@@ -751,3 +751,128 @@ def test_gru_attention_model_through_the_engine_loops():
     assert stats["loss"] < 1.05 * o_loss                                       # mean of step 1 (= oracle loss) and step 2 (after one update)
     ev = evaluate(loader, m, torch.device("cuda:0"), args=args)
     assert set(ev) >= {"loss", "acc", "recognition_fmeasure"} and np.isfinite(ev["loss"]) and 0.0 <= ev["acc"] <= 100.0
+
+
+# ---------------------------------------------------------------------------------------------- full-size models (README shapes)
+def _bucket_check(grads, ref_g, cos_min=0.985, enc_cos_min=0.99):
+    cos = torch.nn.functional.cosine_similarity
+    buckets = {}
+    for n, r in ref_g.items():
+        if n == "encoder.mask_token" or n.endswith("wEmbed.bias"):
+            continue
+        key = ".".join(n.split(".")[:3]) if n.startswith(("encoder.blocks.", "decoder.layer_stack.")) else ".".join(n.split(".")[:2])
+        a, b = buckets.setdefault(key, ([], []))
+        a.append(grads[n].reshape(-1)); b.append(r.reshape(-1))
+    bad = []
+    for key, (a, b) in buckets.items():
+        a, b = torch.cat(a), torch.cat(b)
+        c, q = cos(a[None], b[None]).item(), (a.norm() / b.norm()).item()
+        if c < (enc_cos_min if key.startswith("encoder.") else cos_min) or abs(q - 1) > 4e-2:
+            bad.append((key, round(c, 4), round(q, 4)))
+    return bad
+
+
+def _full_batch(B, T, seed):
+    rng = np.random.RandomState(seed)
+    lens = torch.from_numpy(rng.randint(2, T + 1, size=B))
+    tg = torch.from_numpy(rng.randint(0, 94, size=(B, T)))
+    for b in range(B):
+        tg[b, int(lens[b]) - 1] = 94
+        tg[b, int(lens[b]):] = 95
+    return tg, lens
+
+
+@pytest.mark.gpu
+def test_full_size_finetune_step_vs_oracle():
+    """simmim_vit_small_patch4_32x128 + tf_decoder (6 layers, d 512, 8 heads) at B = 32 (8192 token rows: the tall-layer tiles of
+    the encoder, the 25 x 256 cross-attention on the MFMA kernels), rates 0: loss, logits and the gradient of every block against the
+    fp32 oracle on the same inputs."""
+    import types
+    from dig_amd.finetune import RecModelTrain, SeqCrossEntropyLoss
+    ecfg = O.make_config("pretrain_simmim_moco_ori_vit_small_patch4_32x128")
+    c = D.DecoderConfig()
+    P = {**D.det_encoder_state(ecfg, 52), **D.det_decoder_state(c, 53)}
+    B = 32
+    images = O.synthetic_batch(B, ecfg, 5252)[0]
+    tg, lens = _full_batch(B, c.max_seq_len, 7)
+    args = types.SimpleNamespace(model="simmim_vit_small_patch4_32x128", decoder_name="tf_decoder", nb_classes=97, max_len=25, drop=0.0,
+                                 attn_drop_rate=0.0, drop_path=0.0)
+    m = RecModelTrain(args, decoder_dropout=0.0)
+    m.load_state_dict(P); m.to("cuda:0"); m.train()
+    for p in m.parameters():
+        p.grad.zero_()
+    logits = m((images.to("cuda:0"), tg, lens))[0]
+    loss = SeqCrossEntropyLoss()(logits, tg, lens)
+    loss.backward()
+    torch.set_num_threads(max(8, min(64, os.cpu_count() or 8)))
+    o_loss, o_grads, o_logits = F.loss_and_grads(P, ecfg, c, images, tg, lens)
+    assert abs(loss.item() - o_loss) < 2e-2 * abs(o_loss)
+    valid = torch.arange(c.max_seq_len)[None, :] < lens[:, None]
+    assert ((logits.detach().cpu() - o_logits)[valid].norm() / o_logits[valid].norm()).item() < 3e-2
+    grads = {n: p.grad.detach().float().cpu() for n, p in m.named_parameters()}
+    bad = _bucket_check(grads, o_grads)
+    assert not bad, bad
+
+
+@pytest.mark.gpu
+def test_full_size_gru_attention_step_vs_oracle():
+    """simmim_vit_small_patch4_32x128 + AttentionRecognitionHead (sDim = attDim = 512) at B = 32: loss, logits, gradients per block."""
+    import types
+    from dig_amd.attn_recognizer import AttnRecModelTrain
+    from dig_amd.finetune import SeqCrossEntropyLoss
+    ecfg = O.make_config("pretrain_simmim_moco_ori_vit_small_patch4_32x128")
+    c = AD.AttnDecConfig()
+    P = {**D.det_encoder_state(ecfg, 62), **AD.det_state(c, 63)}
+    B = 32
+    images = O.synthetic_batch(B, ecfg, 6262)[0]
+    tg, lens = _full_batch(B, c.max_len, 8)
+    args = types.SimpleNamespace(model="simmim_vit_small_patch4_32x128", nb_classes=97, max_len=25, drop=0.0, attn_drop_rate=0.0, drop_path=0.0)
+    m = AttnRecModelTrain(args)
+    m.load_state_dict(P); m.to("cuda:0"); m.train()
+    for p in m.parameters():
+        p.grad.zero_()
+    logits = m((images.to("cuda:0"), tg, lens))[0]
+    loss = SeqCrossEntropyLoss()(logits, tg, lens)
+    loss.backward()
+    torch.set_num_threads(max(8, min(64, os.cpu_count() or 8)))
+    o_loss, o_grads, o_logits = AD.loss_and_grads(P, ecfg, c, images, tg, lens)
+    assert abs(loss.item() - o_loss) < 2e-2 * abs(o_loss)
+    valid = torch.arange(c.max_len)[None, :] < lens[:, None]
+    assert ((logits.detach().cpu() - o_logits)[valid].norm() / o_logits[valid].norm()).item() < 3e-2
+    grads = {n: p.grad.detach().float().cpu() for n, p in m.named_parameters()}
+    bad = _bucket_check(grads, o_grads)
+    assert not bad, bad
+
+
+@pytest.mark.gpu
+def test_full_size_finetune_step_with_readme_drop_rates_vs_oracle():
+    """The README recipe's regularisers at full size (--drop 0.1 --attn_drop_rate 0.1 --drop_path 0.1, decoder dropout 0.1), B = 16:
+    the device step against the fp32 oracle under the same keyed masks (12 encoder layers of 256 x 256 attention masks, drop-path
+    rates from 0 to 0.1)."""
+    import types
+    from dig_amd.finetune import RecModelTrain, SeqCrossEntropyLoss
+    ecfg = O.make_config("pretrain_simmim_moco_ori_vit_small_patch4_32x128")
+    c = D.DecoderConfig()
+    P = {**D.det_encoder_state(ecfg, 72), **D.det_decoder_state(c, 73)}
+    B = 16
+    images = O.synthetic_batch(B, ecfg, 7272)[0]
+    tg, lens = _full_batch(B, c.max_seq_len, 9)
+    args = types.SimpleNamespace(model="simmim_vit_small_patch4_32x128", decoder_name="tf_decoder", nb_classes=97, max_len=25, drop=0.1,
+                                 attn_drop_rate=0.1, drop_path=0.1)
+    m = RecModelTrain(args, drop_seed=4711)
+    m.load_state_dict(P); m.to("cuda:0"); m.train()
+    m.drop_step = 3
+    for p in m.parameters():
+        p.grad.zero_()
+    logits = m((images.to("cuda:0"), tg, lens))[0]
+    loss = SeqCrossEntropyLoss()(logits, tg, lens)
+    loss.backward()
+    torch.set_num_threads(max(8, min(64, os.cpu_count() or 8)))
+    dr = F.DropOracle(4711, 3, drop=0.1, attn_drop=0.1, drop_path=0.1, depth=ecfg.depth, decoder_dropout=0.1)
+    o_loss, o_grads, o_logits = F.loss_and_grads(P, ecfg, c, images, tg, lens, drop=dr)
+    assert abs(loss.item() - o_loss) < 2e-2 * abs(o_loss)
+    valid = torch.arange(c.max_seq_len)[None, :] < lens[:, None]
+    assert ((logits.detach().cpu() - o_logits)[valid].norm() / o_logits[valid].norm()).item() < 3e-2
+    grads = {n: p.grad.detach().float().cpu() for n, p in m.named_parameters()}
+    bad = _bucket_check(grads, o_grads, cos_min=0.98, enc_cos_min=0.985)
+    assert not bad, bad
