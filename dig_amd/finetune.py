@@ -667,7 +667,13 @@ class FineTuneAdamW:
         self.model = model
         groups = OrderedDict()
         self._name_group = {}
-        for name, p in model.named_parameters():
+        # every registered parameter in registration order -- `encoder.mask_token` included: the reference's optimizer lists it
+        # (requires_grad) although the fine-tune forward never gives it a gradient, so it holds an index but no state
+        self._stateless = set()
+        for name in model._offsets:
+            p = model._view(model.flat_params, name)
+            if name == "encoder.mask_token":
+                self._stateless.add(name)
             if p.ndim == 1 or name.endswith(".bias") or name in skip_list:
                 gname, wd = "no_decay", 0.0
             else:
@@ -700,10 +706,13 @@ class FineTuneAdamW:
         idx = torch.full((M.n_flat // 256,), 255, dtype=torch.uint8)          # 255 = no gradient (mask_token, padding)
         for gi, g in enumerate(self.param_groups):
             for n in g["names"]:
+                if n in self._stateless:
+                    continue                                                    # no gradient: the update leaves it alone (index 255)
                 o, cnt, _ = M._offsets[n]
                 idx[o // 256:(o + _pad256(cnt)) // 256] = gi
         self._idx = idx.to(dev)
-        self._host_ring = [torch.empty(2, 256, dtype=F32).pin_memory() for _ in range(8)]   # the host may run steps ahead
+        pin = (lambda t: t.pin_memory()) if dev.type == "cuda" else (lambda t: t)
+        self._host_ring = [pin(torch.empty(2, 256, dtype=F32)) for _ in range(8)]   # the host may run steps ahead
         self._dev_tab = torch.empty(2, 256, device=dev, dtype=F32)
         self.exp_avg = torch.zeros(M.n_flat, device=dev, dtype=F32)
         self.exp_avg_sq = torch.zeros(M.n_flat, device=dev, dtype=F32)
@@ -736,7 +745,8 @@ class FineTuneAdamW:
         state = {}
         if self._step > 0:
             for i, n in enumerate(self._ordered_names()):
-                state[i] = {"step": self._step, "exp_avg": M._view(self.exp_avg, n), "exp_avg_sq": M._view(self.exp_avg_sq, n)}
+                if n not in self._stateless:
+                    state[i] = {"step": self._step, "exp_avg": M._view(self.exp_avg, n), "exp_avg_sq": M._view(self.exp_avg_sq, n)}
         groups, k = [], 0
         for g in self.param_groups:
             d = {key: v for key, v in g.items() if key not in ("params", "names")}

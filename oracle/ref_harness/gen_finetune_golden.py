@@ -125,8 +125,18 @@ def main():
     for n in Pn:
         assert (Pn[n] - sd2[n]).abs().max() < 1e-6, n
     print(f"fine-tune step: oracle == reference (loss {o_loss:.6f}, worst gradient rel-to-max err {worst:.2e}); AdamW + layer decay restatement exact")
+    # optimizer checkpoint layout (torch per-parameter indices in group order): which parameter name sits at which state index
+    id2name = {id(p): n for n, p in model.named_parameters()}
+    osd = opt.state_dict()
+    index_names = [id2name[id(p)] for g_ in opt.param_groups for p in g_["params"]]
+    stateless = [index_names[i] for i in range(len(index_names)) if i not in osd["state"]]
+    assert stateless == ["encoder.mask_token"], stateless                        # in the list (requires_grad) but never given a gradient
+    group_sizes = [len(g_["params"]) for g_ in osd["param_groups"]]
+    group_lr_scale = [float(g_["lr_scale"]) for g_ in osd["param_groups"]]
+    group_wd_list = [float(g_["weight_decay"]) for g_ in osd["param_groups"]]
     names = [n for n in P if ref_grads.get(n) is not None]
-    np.savez_compressed(os.path.join(GOLD, "finetune_tiny.npz"), seed_enc=32, seed_dec=31, B=B, batch_seed=555, targets=targets.numpy(),
+    np.savez_compressed(os.path.join(GOLD, "finetune_tiny.npz"), opt_index_names=np.array(index_names), opt_group_sizes=np.array(group_sizes),
+                        opt_group_lr_scale=np.array(group_lr_scale), opt_group_wd=np.array(group_wd_list), seed_enc=32, seed_dec=31, B=B, batch_seed=555, targets=targets.numpy(),
                         lens=lens.numpy(), loss=np.float64(loss.item()), logits=outputs.detach().numpy(), lr=args.lr, weight_decay=args.weight_decay,
                         layer_decay=layer_decay, grad_names=np.array(names),
                         grad_norms=np.array([ref_grads[n].double().norm().item() for n in names]),

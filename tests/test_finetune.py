@@ -533,6 +533,7 @@ def test_finetune_checkpoint_resume_is_bit_exact(tmp_path):
     assert args2.start_epoch == 1 and m2.drop_step == 2 and opt2._step == 2
     ck = torch.load(os.path.join(str(tmp_path), "checkpoint-0.pth"), map_location="cpu", weights_only=False)
     assert set(ck) >= {"model", "optimizer", "epoch", "scaler", "args"} and len(ck["optimizer"]["state"]) == len(list(m.named_parameters()))
+    assert sum(len(g_["params"]) for g_ in ck["optimizer"]["param_groups"]) == len(ck["optimizer"]["state"]) + 1      # + mask_token: listed, stateless
     assert [len(g["params"]) for g in ck["optimizer"]["param_groups"]] == [len(g["names"]) for g in opt.param_groups]
     l3b = step(m2, opt2)
     assert l3b == l3
@@ -876,3 +877,30 @@ def test_full_size_finetune_step_with_readme_drop_rates_vs_oracle():
     grads = {n: p.grad.detach().float().cpu() for n, p in m.named_parameters()}
     bad = _bucket_check(grads, o_grads, cos_min=0.98, enc_cos_min=0.985)
     assert not bad, bad
+
+
+def test_finetune_optimizer_checkpoint_layout_matches_reference():
+    """FineTuneAdamW.state_dict(): torch's per-parameter indices in the order of the REFERENCE optimizer (optim_factory.create_optimizer with
+    the layer-decay assigner; the fixture holds which parameter sits at which index, the group sizes, lr_scale and weight_decay)."""
+    import types
+    from dig_amd.finetune import RecModelTrain, LayerDecayValueAssigner, create_optimizer
+    g, c, ecfg, P, _, _, _ = _fixture()
+    m = RecModelTrain(embed_dim=ecfg.embed_dim, depth=ecfg.depth, num_heads=ecfg.heads, n_layers=c.n_layers, d_model=c.d_model, n_head=c.n_head,
+                      d_k=c.d_k, d_inner=c.d_inner, nb_classes=c.num_classes, max_len=c.max_seq_len, decoder_dropout=0.0)
+    m.load_state_dict(P)
+    nl, ld = m.get_num_layers(), float(g["layer_decay"])
+    asg = LayerDecayValueAssigner([ld ** (nl + 1 - i) for i in range(nl + 2)])
+    args = types.SimpleNamespace(opt="adamw", lr=float(g["lr"]), weight_decay=float(g["weight_decay"]), opt_eps=1e-8, opt_betas=None)
+    opt = create_optimizer(args, m, get_num_layer=asg.get_layer_id, get_layer_scale=asg.get_scale)
+    assert opt._ordered_names() == g["opt_index_names"].tolist()
+    sd = opt.state_dict()
+    assert [len(gr["params"]) for gr in sd["param_groups"]] == g["opt_group_sizes"].tolist()
+    np.testing.assert_allclose([gr["lr_scale"] for gr in sd["param_groups"]], g["opt_group_lr_scale"], rtol=1e-12)
+    np.testing.assert_allclose([gr["weight_decay"] for gr in sd["param_groups"]], g["opt_group_wd"], rtol=1e-12)
+    # a reference-shaped state (one tensor per index) loads and round-trips
+    opt._tables()
+    state = {i: {"step": 4, "exp_avg": torch.full(m._offsets[n][2], float(i)), "exp_avg_sq": torch.full(m._offsets[n][2], 0.5 * i)}
+             for i, n in enumerate(opt._ordered_names()) if n != "encoder.mask_token"}       # (listed, but stateless in the reference)
+    opt.load_state_dict({"state": state, "param_groups": sd["param_groups"]})
+    back = opt.state_dict()
+    assert opt._step == 4 and set(back["state"]) == set(state) and all(torch.equal(back["state"][i]["exp_avg"], state[i]["exp_avg"]) for i in state)
