@@ -107,6 +107,9 @@ def cpu_baseline(model_name, budget_s=20.0):
     tr = O.OracleTrainer(cfg, seed=0)
     im, au, mk = O.synthetic_batch(Bc, cfg, 1234)
     hp = O.StepHyper(lr=1.5e-4 * Bc / 256)
+    # thread count: the best of 8 / 16 / 32 / 64 / 128 on the MI355X host (2 x EPYC 9575F, 256 hardware threads) is 16 --
+    # 6.5 / 8.5 / 7.4 / 3.2 / 1.6 samples/s (tools/cpu_baseline_threads.py): torch's default of 128 threads spends its time in fork/join
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 8)))
     tr.step(im, au, mk, hp)                                     # warm-up
     n, t0 = 0, time.perf_counter()
     while True:
