@@ -601,7 +601,9 @@ struct WideCfg {
   static constexpr int TBI = 32 * FM * WM, TBJ = 32 * FN * WN;
   static constexpr int A_BYTES = TBI * BK * 2, B_BYTES = TBJ * BK * 2;
   static constexpr int STAGE = A_BYTES + B_BYTES;
-  static constexpr int NITA = A_BYTES / 16 / NT, NITB = B_BYTES / 16 / NT;
+  static constexpr int PA = A_BYTES / 16, PB = B_BYTES / 16;                  // 16-byte pieces of the two operand tiles
+  static constexpr int NITA = (PA + NT - 1) / NT, NITB = (PB + NT - 1) / NT;   // passes of the whole workgroup (the last one may be partial:
+  static constexpr bool RAGGED = (PA % NT) || (PB % NT);                       //  whole waves skip it -- 12-wave tiles; NSTG must be 2 then)
   static constexpr int LDS = (NSTG * STAGE > (NT / 64) * 8192) ? NSTG * STAGE : (NT / 64) * 8192;
 };
 
@@ -612,6 +614,7 @@ template <bool TA, bool TB, int OUT, int WM, int WN, int FM, int FN, bool RES, i
 __global__ __launch_bounds__(64 * WM * WN, (BK == 32 && WM * WN == 8 && FM * FN == 4) ? 4 : ((BK == 32 && WM * WN == 4) ? 2 : 1)) void gemm_wide_kernel(GemmParams p, DropArg<DROP> da) {
   using Cfg = WideCfg<WM, WN, FM, FN, BK, NSTG>;
   static_assert(FN % 2 == 0 && Cfg::NITA <= 8 && Cfg::NITB <= 8, "tile shape");
+  static_assert(!Cfg::RAGGED || NSTG == 2, "a partial staging pass changes the per-wave load count: only the wait-all hand-off is safe");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -649,12 +652,14 @@ __global__ __launch_bounds__(64 * WM * WN, (BK == 32 && WM * WN == 8 && FM * FN 
     unsigned char* b = a + Cfg::A_BYTES;
 #pragma unroll
     for (int it = 0; it < Cfg::NITA; ++it) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, LDS_PTR(a + it * Cfg::NT * 16), 16, offA[it], 0, 0, 0);
+      if (!Cfg::RAGGED || it * Cfg::NT + wave * 64 < Cfg::PA)                 // (wave-uniform: piece counts are multiples of 64)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, LDS_PTR(a + it * Cfg::NT * 16), 16, offA[it], 0, 0, 0);
       offA[it] += stepA;
     }
 #pragma unroll
     for (int it = 0; it < Cfg::NITB; ++it) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_, LDS_PTR(b + it * Cfg::NT * 16), 16, offB[it], 0, 0, 0);
+      if (!Cfg::RAGGED || it * Cfg::NT + wave * 64 < Cfg::PB)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_, LDS_PTR(b + it * Cfg::NT * 16), 16, offB[it], 0, 0, 0);
       offB[it] += stepB;
     }
   };
@@ -884,7 +889,7 @@ extern "C" int dig_gemm_bf16_dropout(const void* A, const void* B, void* C, int 
     if ((size_t)I * (size_t)J >= (1ull << 32) || (drop->pthr && drop->rows_per_sample <= 0)) return DIG_ERR_ARG;
   }
   if (bias && !aligned16(bias)) return DIG_ERR_ALIGN;
-  if (out_kind < 0 || out_kind > 2 || act < 0 || act > 2 || (bk != 0 && bk != 32 && bk != 33 && bk != 34 && bk != 64 && bk != 132 && bk != 164 && bk != 244 && bk != 242 && bk != 224 && bk != 344 && bk != 343 && bk != 448 && bk != 484 && bk != 444 && bk != 432 && bk != 232 && bk != 332 && bk != 223 && bk != 212 && bk != 221 && bk != 422 && bk != 424 && bk != 423)) return DIG_ERR_ARG;
+  if (out_kind < 0 || out_kind > 2 || act < 0 || act > 2 || (bk != 0 && bk != 32 && bk != 33 && bk != 34 && bk != 64 && bk != 132 && bk != 164 && bk != 244 && bk != 242 && bk != 264 && bk != 224 && bk != 344 && bk != 343 && bk != 448 && bk != 484 && bk != 444 && bk != 432 && bk != 232 && bk != 332 && bk != 223 && bk != 212 && bk != 221 && bk != 422 && bk != 424 && bk != 423)) return DIG_ERR_ARG;
   if (act == 2 && !resid) return DIG_ERR_ARG;                   // act 2: resid carries the saved pre-activation
   if (bk >= 100 && bk < 200 && resid && pre_act) return DIG_ERR_UNSUPPORTED;
   if (bk == 0) bk = 64;
@@ -942,6 +947,7 @@ extern "C" int dig_gemm_bf16_dropout(const void* A, const void* B, void* C, int 
     if (bk == 344) return resid ? launch_wide<ta, tb, o, 4, 4, 2, 2, true, 32, 4>(p, splits, stream) : launch_wide<ta, tb, o, 4, 4, 2, 2, false, 32, 4>(p, splits, stream); \
     if (bk == 343) return resid ? launch_wide<ta, tb, o, 4, 4, 2, 2, true, 32, 3>(p, splits, stream) : launch_wide<ta, tb, o, 4, 4, 2, 2, false, 32, 3>(p, splits, stream); \
     if (bk == 242) return resid ? launch_wide<ta, tb, o, 4, 2, 2, 2, true, 64, 2>(p, splits, stream) : launch_wide<ta, tb, o, 4, 2, 2, 2, false, 64, 2>(p, splits, stream); \
+    if (bk == 264) return resid ? launch_wide<ta, tb, o, 4, 3, 2, 2, true, 64, 2>(p, splits, stream) : launch_wide<ta, tb, o, 4, 3, 2, 2, false, 64, 2>(p, splits, stream); \
     return resid ? launch_wide<ta, tb, o, 2, 4, 2, 2, true, 64, 2>(p, splits, stream) : launch_wide<ta, tb, o, 2, 4, 2, 2, false, 64, 2>(p, splits, stream);               \
   }
   DIG_GEMM_WCASE(false, false, 0)

@@ -41,7 +41,8 @@ typedef struct ihipStream_t* hipStream_t;
  *   requirements: J % 8 == 0; lda, ldb, ldc, ldr, ldp % 8 == 0; 16-byte aligned pointers; R % 64 == 0 for a non-transposed
  *   operand; a_rows / b_rows (0 = default) = rows of A / B that exist in memory (rows beyond read as zero).
  *   bk selects the tile variant (csrc/gemm.hip): 0/32/64 = 128x128 tile with that K step (33/34: 3-/4-stage ring; 132/164:
- *   persistent); 2xx/3xx/4xx = multi-wave tiles of gemm_wide_kernel (244 = 256x256, 16 waves, the default for tall layers).
+ *   persistent); 2xx/3xx/4xx = multi-wave tiles of gemm_wide_kernel (244 = 256x256, 16 waves, the default for tall layers;
+ *   264 = 256x192, 12 waves: the widths of this model -- 384, 1152, 1536 -- are multiples of 192, not all of 256).
  *   colsum_partials (act 2 only): [ceil(I/64)][J] fp32 column sums of the result per 64-row group, or null.
  */
 int dig_gemm_bf16(const void* A, const void* B, void* C, int I, int J, int R, int lda, int ldb, int ldc, int trans_a,

@@ -9,12 +9,14 @@ def bench(f, n=30):
     torch.cuda.synchronize(); t = time.perf_counter()
     for _ in range(n): f()
     torch.cuda.synchronize(); return (time.perf_counter() - t) / n * 1e6
-for name, J, R, resid in (("proj", 384, 384, True), ("fc2", 384, 1536, True), ("qkv", 1152, 384, False)):
+for name, J, R, resid in (("proj", 384, 384, True), ("fc2", 384, 1536, True), ("qkv", 1152, 384, False), ("fc1", 1536, 384, False)):
     x = torch.randn(I, R, device=dev).bfloat16(); w = (torch.randn(J, R, device=dev) * 0.05).bfloat16(); bias = torch.randn(J, device=dev)
     res = torch.randn(I, J, device=dev).bfloat16() if resid else None
     out = torch.empty(I, J, device=dev, dtype=torch.bfloat16)
-    line = []
-    for bk in (244, 242, 224, 0, 32, 232, 332, 344):
+    ref = ops.gemm(x, w, I, J, R, bias=bias, resid=res, bk=0).float()
+    chk = ops.gemm(x, w, I, J, R, bias=bias, resid=res, bk=264).float()
+    line = [f"264 vs 128x128 max|d| {(chk - ref).abs().max().item():.3g}"]
+    for bk in (244, 264, 242, 0, 332):
         try:
             t = bench(lambda: ops.gemm(x, w, I, J, R, bias=bias, resid=res, out=out, bk=bk))
             line.append(f"{bk}: {t:6.1f} us ({2*I*J*R/t/1e6:4.0f} TF)")
