@@ -91,7 +91,9 @@ def linear_dgrad(dy, w, out=None, gelu_pre=None, colsum=False, drop=None):
         dx = gemm(dy, w, dy.shape[0], w.shape[1], w.shape[0], tb=True, out=out, act=2, resid=gelu_pre, bk=DGRAD_GELU_BK, colsum_partials=parts,
                   drop=drop)
         return (dx, parts) if colsum else dx
-    # few rows (the BN-MLP heads on pooled features): 128x64 tiles double the workgroup count (tools/gpu_head_gemm_probe.py)
+    # few rows (the BN-MLP heads on pooled features): 128x64 tiles double the workgroup count (tools/gpu_head_gemm_probe.py).
+    # (The 256x192 tile is 8-20 % faster for the tall 384-wide dgrads alone -- tools/experiments/gpu_dgrad_tile_probe.py -- but not in
+    #  the step: 25.69 vs 25.77 ms over three A/B pairs; the small 128x128 workgroups share the CUs better with the weight-gradient stream.)
     return gemm(dy, w, dy.shape[0], w.shape[1], w.shape[0], tb=True, out=out, bk=221 if dy.shape[0] <= 2048 else 0)
 
 
