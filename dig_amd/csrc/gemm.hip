@@ -884,8 +884,8 @@ extern "C" int dig_gemm_bf16_dropout(const void* A, const void* B, void* C, int 
   if (!A || !B || !C || I <= 0 || J <= 0 || R <= 0 || splits < 1) return DIG_ERR_ARG;
   const bool dropping = drop && (drop->thr || drop->pthr);
   if (dropping) {
-    // instantiated for the tiles the fine-tune step uses: 128x128 (bk 0 / 64 / 32) forward and dgrad, 256x256 (bk 244) forward
-    if (out_kind != 0 || trans_a || !(bk == 0 || bk == 32 || bk == 64 || (bk == 244 && !trans_b))) return DIG_ERR_UNSUPPORTED;
+    // instantiated for the tiles the fine-tune step uses: 128x128 (bk 0 / 64 / 32) forward and dgrad, 256x256 / 256x192 (bk 244 / 264) forward
+    if (out_kind != 0 || trans_a || !(bk == 0 || bk == 32 || bk == 64 || ((bk == 244 || bk == 264) && !trans_b))) return DIG_ERR_UNSUPPORTED;
     if ((size_t)I * (size_t)J >= (1ull << 32) || (drop->pthr && drop->rows_per_sample <= 0)) return DIG_ERR_ARG;
   }
   if (bias && !aligned16(bias)) return DIG_ERR_ALIGN;
@@ -923,6 +923,8 @@ extern "C" int dig_gemm_bf16_dropout(const void* A, const void* B, void* C, int 
     const DropArg<true> da{*drop};
     if (bk == 244) return resid ? launch_wide<false, false, 0, 4, 4, 2, 2, true, 64, 2, true>(p, splits, stream, da)
                                 : launch_wide<false, false, 0, 4, 4, 2, 2, false, 64, 2, true>(p, splits, stream, da);
+    if (bk == 264) return resid ? launch_wide<false, false, 0, 4, 3, 2, 2, true, 64, 2, true>(p, splits, stream, da)
+                                : launch_wide<false, false, 0, 4, 3, 2, 2, false, 64, 2, true>(p, splits, stream, da);
     if (!trans_b)
       return bk == 32 ? (resid ? launch<false, false, 0, 32, true, 2, true>(p, splits, stream, da) : launch<false, false, 0, 32, false, 2, true>(p, splits, stream, da))
                       : (resid ? launch<false, false, 0, 64, true, 2, true>(p, splits, stream, da) : launch<false, false, 0, 64, false, 2, true>(p, splits, stream, da));

@@ -58,7 +58,7 @@ def linear_fwd(x, w, *, bias=None, resid=None, act=0, pre=None, alpha=1.0, alpha
     rows = x.shape[0]
     if rows >= 8192 and w.shape[0] >= 384 and rows * w.shape[0] >= (1 << 24) and not (drop is not None and act):
         bk = 244
-        if w.shape[0] % 256 == 128 and w.shape[0] < 512 and drop is None:
+        if w.shape[0] % 256 == 128 and w.shape[0] < 512:
             # 384 outputs = 1.5 tiles of 256: a quarter of the 256x256 tile's columns would be padding.  The 256x192 tile (12 waves) covers
             # them in two exact tiles and keeps the two-fold reuse of the activation rows: proj 39.4 -> 34.5 us, fc2 114.8 -> 99.2 us alone;
             # in the step 25.98 -> 25.57 ms and the forward family 9.76 -> 9.43 ms (three A/B pairs on one box)

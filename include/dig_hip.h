@@ -291,7 +291,7 @@ typedef struct dig_dropout {
 /* dig_gemm_bf16 with dropout and/or drop-path applied to the result after bias / activation and BEFORE the residual add
  * (x + drop_path(dropout(linear(h)))); with act 2 the mask multiplies the GELU' product (backward of dropout(gelu(.))) and the
  * fused column sums see the masked values.  Element index = i * J + j.  Separate kernel instantiations (the plain GEMMs carry
- * none of this code), built for out_kind 0 forward / dgrad on the 128x128 tiles (bk 0 / 64 / 32) and forward on bk 244; any
+ * none of this code), built for out_kind 0 forward / dgrad on the 128x128 tiles (bk 0 / 64 / 32) and forward on bk 244 / 264; any
  * other combination returns -4. */
 int dig_gemm_bf16_dropout(const void* A, const void* B, void* C, int I, int J, int R, int lda, int ldb, int ldc, int trans_a,
                           int trans_b, int out_kind, const float* bias, const void* resid, int ldr, void* pre_act, int ldp, float alpha,

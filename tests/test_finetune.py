@@ -312,7 +312,7 @@ def test_dropout_kernels_reproduce_the_oracle_masks():
     assert torch.equal(y == 0, want == 0) and (y - want).abs().max() <= 2e-2 * want.abs().max()
     assert 0.05 < (want == 0).float().mean() < 0.6
     # GEMM epilogue: y = resid + drop_path(dropout(x W^T + b)), both tile families
-    for I, J, R, bk in ((256, 128, 64, 0), (8192, 384, 128, 244)):
+    for I, J, R, bk in ((256, 128, 64, 0), (8192, 384, 128, 244), (8192, 384, 128, 264)):
         a = torch.randn(I, R, generator=g).bfloat16(); w = torch.randn(J, R, generator=g).bfloat16()
         bias = torch.randn(J, generator=g); res = torch.randn(I, J, generator=g).bfloat16()
         sp = plan.spec(DR.enc_site(2, 3), 0.1, DR.enc_site(2, 4), 0.25, 64)
