@@ -615,6 +615,7 @@ __global__ __launch_bounds__(64 * WM * WN, (BK == 32 && WM * WN == 8 && FM * FN 
   using Cfg = WideCfg<WM, WN, FM, FN, BK, NSTG>;
   static_assert(FN % 2 == 0 && Cfg::NITA <= 8 && Cfg::NITB <= 8, "tile shape");
   static_assert(!Cfg::RAGGED || NSTG == 2, "a partial staging pass changes the per-wave load count: only the wait-all hand-off is safe");
+  static_assert(Cfg::PA % 64 == 0 && Cfg::PB % 64 == 0, "whole waves take part in a staging pass or skip it");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
