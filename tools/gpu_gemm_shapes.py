@@ -30,7 +30,7 @@ def dgrad(name, J, R, gelu=False, bks=(32, 64, 244, 422, 424, 423)):
     ts = {bk: bench(lambda: ops.gemm(dy, w, I, J, R, bk=bk, **args)) for bk in bks}
     b = min(ts, key=ts.get)
     print(f"dgrad {name:22s}", " ".join(f"{bk}:{t:6.1f}" for bk, t in ts.items()), f"| best {b} {2*I*J*R/ts[b]/1e6:.0f} TF", flush=True)
-def wgrad(name, I, J, bks=(32, 64, 244, 242, 224, 448, 484), splits=(8, 16, 24, 32, 40)):
+def wgrad(name, I, J, bks=(32, 64, 244, 264, 242), splits=(8, 16, 24, 32, 40, 48)):
     R = ROWS
     dy = torch.randn(R, I, device=dev).bfloat16(); x = torch.randn(R, J, device=dev).bfloat16()
     dw = torch.zeros(I, J, device=dev)
