@@ -56,6 +56,8 @@ class RecModelTrain(RecModel):
         self.dpr = [x.item() for x in torch.linspace(0, self.drop_path_rate, self.depth)]
         self.drop_seed = torch.initial_seed() if drop_seed is None else int(drop_seed)
         self.drop_step = 0                              # training forwards so far: every step draws fresh keys
+        self.frozen = set()                             # names with requires_grad = False (`fix_encoder_layers`)
+        self.frozen_blocks = 0                          # encoder blocks 0 .. frozen_blocks-1 (and patch_embed) take no gradient
         self.comm = None
         self._dev = None
         self._offsets = OrderedDict()
@@ -132,6 +134,21 @@ class RecModelTrain(RecModel):
 
     def state_dict(self, *a, **k):
         return OrderedDict((n, self._view(self.flat_params, n).detach().cpu().clone()) for n in self._offsets)
+
+    def fix_encoder_layers(self, fixed_encoder_layers):
+        """`--fixed_encoder_layers k` (run_class_finetuning.py:500-518): k >= 1 freezes `encoder.patch_embed`, k > 1 also the encoder
+        blocks with index < k - 1 (k capped at depth + 1).  Call BEFORE `create_optimizer` (frozen parameters are not listed there, as
+        `get_parameter_groups` skips `requires_grad = False`).  The backward stops above the last frozen block: nothing below it is
+        computed.  Returns the frozen names (what the reference prints)."""
+        k = int(fixed_encoder_layers)
+        self.frozen, self.frozen_blocks = set(), 0
+        if k >= 1:
+            self.frozen |= {n for n in self._offsets if "encoder.patch_embed" in n}
+        if k > 1:
+            k = min(k, self.depth + 1)
+            self.frozen_blocks = k - 1
+            self.frozen |= {n for n in self._offsets if n.startswith("encoder.blocks.") and int(n.split(".")[2]) < k - 1}
+        return [n for n in self._offsets if n in self.frozen]
 
     def named_parameters(self, *a, **k):
         for n in self._offsets:
@@ -292,10 +309,11 @@ class _TrainStep:
             # x + drop_path(proj_drop(proj(.))) / x + drop_path(drop(fc2(.))) (modeling_finetune.py:120,59,156-158): GEMM epilogue
             x_mid = ops.linear_fwd(ctx, self.w(b + "attn.proj.weight"), bias=self.p(b + "attn.proj.bias"), resid=x, drop=ds["proj"])
             ln2, mu2, rs2 = ops.layernorm_fwd(x_mid, self.p(b + "norm2.weight"), self.p(b + "norm2.bias"), 1e-6)
-            pre = torch.empty((B * N, M.F), device=dev, dtype=BF16)
+            frozen = i < M.frozen_blocks                                        # no gradient flows into a frozen block: nothing is kept
+            pre = None if frozen else torch.empty((B * N, M.F), device=dev, dtype=BF16)
             act = ops.linear_fwd(ln2, self.w(b + "mlp.fc1.weight"), bias=self.p(b + "mlp.fc1.bias"), act=1, pre=pre)
             x_out = ops.linear_fwd(act, self.w(b + "mlp.fc2.weight"), bias=self.p(b + "mlp.fc2.bias"), resid=x_mid, drop=ds["mlp"])
-            self.enc_saved.append((x, ln1, mu1, rs1, qkv, ctx, lse, x_mid, ln2, mu2, rs2, pre, act))
+            self.enc_saved.append(None if frozen else (x, ln1, mu1, rs1, qkv, ctx, lse, x_mid, ln2, mu2, rs2, pre, act))
             x = x_out
         enc, emu, ers = ops.layernorm_fwd(x, self.p("encoder.norm.weight"), self.p("encoder.norm.bias"), 1e-6)
         self.enc_last = (x, emu, ers, enc)
@@ -409,7 +427,7 @@ class _TrainStep:
                                self.g("encoder.norm.bias"))
         # ---- encoder (same chain as the pre-training backward, one view, no masking)
         scale = (D // H) ** -0.5
-        for i in reversed(range(M.depth)):
+        for i in reversed(range(M.frozen_blocks, M.depth)):                   # (frozen blocks are a prefix: the chain stops above them)
             b = f"encoder.blocks.{i}."
             x, ln1, mu1, rs1, qkv, ctx, lse, x_mid, ln2, mu2, rs2, pre, act = self.enc_saved[i]
             self.enc_saved[i] = None
@@ -442,6 +460,8 @@ class _TrainStep:
                                               self.g(b + "norm1.weight"), self.g(b + "norm1.bias"), out=dln1,
                                               dres_colsum=self.g(b + "attn.proj.bias") if ds["proj"] is None else None, defer=True)
             self.side(fin1, ws1)
+        if "encoder.patch_embed.proj.weight" in M.frozen:
+            return
         dx = ops.dropout_apply(dx, self.ds_pos, out=dx)
         gtok = torch.zeros(D, device=dev, dtype=F32)                          # mask_token takes no part at fine-tune: gradient discarded
         ops.patch_embed_bwd_mfma(dx, self.images, self.zmask, self.g("encoder.patch_embed.proj.weight").view(D, 48),
@@ -671,6 +691,8 @@ class FineTuneAdamW:
         # (requires_grad) although the fine-tune forward never gives it a gradient, so it holds an index but no state
         self._stateless = set()
         for name in model._offsets:
+            if name in getattr(model, "frozen", ()):
+                continue                                                    # requires_grad = False: not listed (optim_factory.py:66-67)
             p = model._view(model.flat_params, name)
             if name == "encoder.mask_token":
                 self._stateless.add(name)

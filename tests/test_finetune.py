@@ -904,3 +904,39 @@ def test_finetune_optimizer_checkpoint_layout_matches_reference():
     opt.load_state_dict({"state": state, "param_groups": sd["param_groups"]})
     back = opt.state_dict()
     assert opt._step == 4 and set(back["state"]) == set(state) and all(torch.equal(back["state"][i]["exp_avg"], state[i]["exp_avg"]) for i in state)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [1, 2, 3])
+def test_fixed_encoder_layers_match_oracle_with_frozen_parameters(k):
+    """`--fixed_encoder_layers k` (run_class_finetuning.py:500-518): frozen parameters get no gradient, keep their values and are absent
+    from the optimizer; every other gradient equals the oracle's (freezing a prefix does not change the gradients above it)."""
+    import types
+    from dig_amd.finetune import SeqCrossEntropyLoss, LayerDecayValueAssigner, create_optimizer
+    from dig_amd.utils import NativeScalerWithGradNormCount
+    g, c, ecfg, P, images, targets, lens = _fixture()
+    m = _device_model(c, ecfg, P)
+    frozen = m.fix_encoder_layers(k)
+    want = [n for n in P if "encoder.patch_embed" in n] + ([n for n in P if n.startswith("encoder.blocks.") and int(n.split(".")[2]) < min(k, ecfg.depth + 1) - 1] if k > 1 else [])
+    assert sorted(frozen) == sorted(want) and len(frozen) > 0
+    nl = m.get_num_layers()
+    asg = LayerDecayValueAssigner([0.75 ** (nl + 1 - i) for i in range(nl + 2)])
+    args = types.SimpleNamespace(opt="adamw", lr=1e-3, weight_decay=0.05, opt_eps=1e-8, opt_betas=None)
+    opt = create_optimizer(args, m, get_num_layer=asg.get_layer_id, get_layer_scale=asg.get_scale)
+    assert not (set(opt._ordered_names()) & set(frozen))
+    for grp in opt.param_groups:
+        grp["lr"] = args.lr * grp["lr_scale"]
+    opt.zero_grad()
+    loss = SeqCrossEntropyLoss()(m((images.to("cuda:0"), targets, lens))[0], targets, lens)
+    NativeScalerWithGradNormCount()(loss, opt, clip_grad=None, parameters=None)
+    assert abs(loss.item() - float(g["loss"])) < 2e-2 * float(g["loss"])
+    _, ref_g, _ = F.loss_and_grads(P, ecfg, c, images, targets, lens)
+    sd = m.state_dict()
+    for n, p in m.named_parameters():
+        gr = p.grad.detach().float().cpu()
+        if n in frozen:
+            assert float(gr.abs().max()) == 0.0 and torch.equal(sd[n], P[n]), n
+        elif ref_g[n].norm() > 1e-3 * max(v.norm() for v in ref_g.values()):
+            cosv = torch.nn.functional.cosine_similarity(gr.reshape(1, -1), ref_g[n].reshape(1, -1)).item()
+            assert cosv > 0.98, (n, cosv)
+            assert not torch.equal(sd[n], P[n]), n
