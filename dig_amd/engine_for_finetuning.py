@@ -31,8 +31,8 @@ def train_one_epoch(model: torch.nn.Module, criterion: torch.nn.Module, data_loa
                     data_loader_val=None, max_accuracy=0., criterion_aux=None, teacher_model=None):
     if loss_scaler is None:
         raise NotImplementedError("the deepspeed branch (loss_scaler=None) is not built")
-    if mixup_fn is not None or model_ema is not None or teacher_model is not None or getattr(args, "w2v_path", None) is not None:
-        raise NotImplementedError("mixup / model EMA / distillation teacher / w2v targets are not built")
+    if mixup_fn is not None or teacher_model is not None or getattr(args, "w2v_path", None) is not None:
+        raise NotImplementedError("mixup / distillation teacher / w2v targets are not built")
     update_freq = update_freq or 1
     model.train(True)
     core = model.module if hasattr(model, "module") else model
@@ -94,6 +94,8 @@ def train_one_epoch(model: torch.nn.Module, criterion: torch.nn.Module, data_loa
                                 update_grad=(data_iter_step + 1) % update_freq == 0)
         if (data_iter_step + 1) % update_freq == 0:
             optimizer.zero_grad()
+            if model_ema is not None:
+                model_ema.update(core)                                          # engine_for_finetuning.py:136-139
         loss_scale_value = loss_scaler.state_dict()["scale"]
         acc = accuracy(output.detach().argmax(-1), targets, voc) if voc is not None else None
         dev_vals = torch.stack([loss_report.reshape(()).float(), acc.float() if acc is not None else torch.zeros((), device=loss_report.device),

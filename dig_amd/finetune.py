@@ -222,6 +222,39 @@ class RecModelTrain(RecModel):
         return logits, None, None, None
 
 
+class ModelEma:
+    """timm.utils.ModelEma as run_class_finetuning.py:456-462 / engine_for_finetuning.py:136-139 use it (`--model_ema`): an exponential
+    moving average of every state-dict tensor, `ema = decay * ema + (1 - decay) * model` after each optimizer step -- one `dig_ema_update`
+    launch over the flat parameter arena.  `.ema` is a model object of the same class whose parameters are the averaged ones (for
+    `evaluate(data_loader, model_ema.ema, ...)` and for the `model_ema` entry of checkpoints)."""
+
+    def __init__(self, model, decay=0.9999, device='', resume=''):
+        import copy
+        if resume:
+            raise NotImplementedError("ModelEma(resume=...) is not built: load the checkpoint's 'model_ema' into .ema.load_state_dict")
+        self.decay = float(decay)
+        self.ema = copy.copy(model)                                            # shares configuration, owns its arenas
+        self.ema.flat_params = model.flat_params.detach().clone()
+        self.ema.flat_grads = torch.zeros_like(model.flat_grads)
+        self.ema._shadow = None
+        self.ema._side = None
+        self.ema.comm = None
+        self.ema._ready = False
+        self.ema._graphs = {}                                                  # (its own HIP-graph cache: the copy above is shallow)
+        self.ema._sd = OrderedDict((k, v.clone()) for k, v in model._sd.items())
+        self.ema.train(False)
+
+    def update(self, model):
+        e = self.ema
+        if e.flat_params.device != model.flat_params.device:
+            e.flat_params = e.flat_params.to(model.flat_params.device)
+        if e.flat_params.is_cuda:
+            ops.ema_update(e.flat_params, model.flat_params, None, e.flat_params.numel(), self.decay)
+        else:
+            e.flat_params.mul_(self.decay).add_(model.flat_params, alpha=1.0 - self.decay)
+        e._ready = False
+
+
 class FlatGradComm:
     """Data parallelism for the fine-tune step: one all-reduce of the flat gradient arena after the backward (the hook
     `NativeScalerWithGradNormCount` calls), parameters broadcast from rank 0 at construction -- what DistributedDataParallel does

@@ -940,3 +940,36 @@ def test_fixed_encoder_layers_match_oracle_with_frozen_parameters(k):
             cosv = torch.nn.functional.cosine_similarity(gr.reshape(1, -1), ref_g[n].reshape(1, -1)).item()
             assert cosv > 0.98, (n, cosv)
             assert not torch.equal(sd[n], P[n]), n
+
+
+@pytest.mark.gpu
+def test_model_ema_tracks_the_parameters():
+    """`--model_ema`: after every optimizer step ema = decay * ema + (1 - decay) * model for every tensor; the averaged model evaluates."""
+    import types
+    from dig_amd.finetune import SeqCrossEntropyLoss, LayerDecayValueAssigner, create_optimizer, ModelEma
+    from dig_amd.engine_for_finetuning import train_one_epoch
+    from dig_amd.utils import NativeScalerWithGradNormCount
+    g, c, ecfg, P, images, targets, lens = _fixture()
+    m = _device_model(c, ecfg, P)
+    ema = ModelEma(m, decay=0.9)
+    nl, lr, wd = m.get_num_layers(), 1e-2, 0.05
+    asg = LayerDecayValueAssigner([0.75 ** (nl + 1 - i) for i in range(nl + 2)])
+    args = types.SimpleNamespace(opt="adamw", lr=lr, weight_decay=wd, opt_eps=1e-8, opt_betas=None, eval_freq=1000)
+    opt = create_optimizer(args, m, get_num_layer=asg.get_layer_id, get_layer_scale=asg.get_scale)
+    loader = type("Ldr", (list,), {})([(images, targets, lens)] * 3)
+    loader.dataset = types.SimpleNamespace(idx_to_class={i: ch for i, ch in enumerate(D.vocabulary())})
+    p0 = m.flat_params.detach().clone()
+    snaps = []
+    orig_update = ema.update
+    ema.update = lambda mm: (orig_update(mm), snaps.append(mm.flat_params.detach().clone()))[0]
+    train_one_epoch(m, SeqCrossEntropyLoss(), loader, opt, torch.device("cuda:0"), 0, NativeScalerWithGradNormCount(), None, ema, None, None,
+                    start_steps=0, lr_schedule_values=np.full(3, lr), wd_schedule_values=np.full(3, wd), num_training_steps_per_epoch=3,
+                    update_freq=1, args=args)
+    assert len(snaps) == 3
+    want = p0.clone()
+    for s_ in snaps:
+        want = 0.9 * want + 0.1 * s_
+    torch.testing.assert_close(ema.ema.flat_params, want, rtol=1e-5, atol=1e-7)
+    assert not torch.equal(ema.ema.flat_params, m.flat_params)
+    probs = ema.ema((images.to("cuda:0"), None, None))[0]                      # the averaged model decodes (eval mode)
+    assert probs.shape[0] == images.shape[0] and torch.isfinite(probs).all()
