@@ -134,7 +134,7 @@ class _AttnTrainStep(_TrainStep):
         side(lambda: ops.colsum(dgh2, g(PRE + "gru.bias_hh_l0")), dgh2)
         side(lambda: ops.linear_wgrad(dsp2, sprev, g(PRE + "attention_unit.sEmbed.weight")), dsp2, sprev)
         side(lambda: ops.colsum(dsp2, g(PRE + "attention_unit.sEmbed.bias")), dsp2)
-        side(lambda: g(PRE + "attention_unit.wEmbed.weight").view(A).add_(dw_acc.sum(0)), dw_acc)   # (wEmbed.bias: softmax-invariant, gradient 0)
+        side(lambda: ops.colsum_partials(dw_acc, g(PRE + "attention_unit.wEmbed.weight").view(A)), dw_acc)   # (wEmbed.bias: softmax-invariant, gradient 0)
         dyp = dinp_all.view(rows, E + X)[:, :E].contiguous()
         side(lambda: L.call("dig_seq_embed_bwd", L.ptr(yprev), L.ptr(dyp), L.ptr(g(PRE + "tgt_embedding.weight")), rows, E, C + 1, L.stream()), dyp)
         # ---- token gradients: sums over the steps, then the xEmbed Linear
