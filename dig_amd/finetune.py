@@ -62,12 +62,23 @@ class RecModelTrain(RecModel):
         self._dev = None
         self._offsets = OrderedDict()
         off = 0
-        for k, s in self.param_shapes().items():
+        shapes = self.param_shapes()
+        for k, s in shapes.items():
             n = 1
             for d_ in s:
                 n *= d_
+            if k.endswith("attn.q_bias") and k[:-6] + "v_bias" in shapes:
+                # q_bias | zeros (K has no bias, modeling_finetune.py:91) | v_bias laid out as ONE [3D] vector: the fused qkv GEMM takes it as
+                # its bias without a per-step concatenation (the gap belongs to no optimizer granule and stays zero)
+                self._offsets[k] = (off, n, tuple(s))
+                self._offsets[k[:-6] + "v_bias"] = (off + 2 * n, n, tuple(s))
+                off += _pad256(3 * n)
+                continue
+            if k in self._offsets:
+                continue                                                    # (v_bias: placed with its q_bias)
             self._offsets[k] = (off, n, tuple(s))
             off += _pad256(n)
+        self._offsets = OrderedDict((k, self._offsets[k]) for k in shapes)      # registration order (state_dict / optimizer indices)
         self.n_flat = off
         self.flat_params = torch.zeros(off, dtype=F32)
         self.flat_grads = torch.zeros(off, dtype=F32)
@@ -335,7 +346,8 @@ class _TrainStep:
         for i in range(M.depth):
             b = f"encoder.blocks.{i}."
             ds = self.ds_enc[i]
-            qkv_bias = torch.cat([self.p(b + "attn.q_bias"), torch.zeros(D, device=dev), self.p(b + "attn.v_bias")])
+            qo = M._offsets[b + "attn.q_bias"][0]
+            qkv_bias = M.flat_params[qo:qo + 3 * D]                             # q_bias | 0 | v_bias (arena layout)
             ln1, mu1, rs1 = ops.layernorm_fwd(x, self.p(b + "norm1.weight"), self.p(b + "norm1.bias"), 1e-6)
             qkv = ops.linear_fwd(ln1, self.w(b + "attn.qkv.weight"), bias=qkv_bias, alpha=scale, alpha_cols=D)
             ctx, lse = ops.attn_fwd(qkv, B, H, D, drop=ds["attn"])
@@ -764,7 +776,7 @@ class FineTuneAdamW:
                 if n in self._stateless:
                     continue                                                    # no gradient: the update leaves it alone (index 255)
                 o, cnt, _ = M._offsets[n]
-                idx[o // 256:(o + _pad256(cnt)) // 256] = gi
+                idx[o // 256:(o + cnt + 255) // 256] = gi                      # (a v_bias may start inside a granule: see the arena layout)
         self._idx = idx.to(dev)
         pin = (lambda t: t.pin_memory()) if dev.type == "cuda" else (lambda t: t)
         self._host_ring = [pin(torch.empty(2, 256, dtype=F32)) for _ in range(8)]   # the host may run steps ahead
