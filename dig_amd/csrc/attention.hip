@@ -19,6 +19,11 @@
 // the transpose read).
 #include "common.h"
 
+// phase time stamps for tools/experiments/attn_bwd_lab.hip (empty in the product build)
+#ifndef DIG_ATTN_TS
+#define DIG_ATTN_TS(i)
+#endif
+
 namespace {
 
 constexpr int N_TOK = 256;
@@ -60,6 +65,40 @@ __device__ __forceinline__ bf16x8 frag_tr(const unsigned char* tile, int r0, int
   const int rb = ra + 8;
   bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(tile + u_addr(ra, col)));
   bf16x4 h4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(tile + u_addr(rb, col)));
+  bf16x8 r;
+  r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+  r[4] = h4[0]; r[5] = h4[1]; r[6] = h4[2]; r[7] = h4[3];
+  return r;
+}
+
+// Loop forms of the two fragment reads.  Inside a loop over 32-row tiles the XOR swizzle of layout U depends only on the low
+// row bits, i.e. on the lane: the byte offsets below are computed once per kernel and a tile is `base + tile * 4096` plus
+// instruction immediates (the generic helpers recomputed ~40 VALU address instructions per tile).
+struct FragOff {
+  int d[4];        // frag_direct: 16-B chunk (2s + hi) of row (lane & 31), s = 0..3
+  int t[2][2];     // frag_tr: [dt][row half a / b] for r0 = 0, coloff = 32 * dt
+};
+__device__ __forceinline__ FragOff frag_offsets(int lane) {
+  FragOff o;
+  const int row = lane & 31, hi = lane >> 5;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) o.d[s] = row * 128 + (((2 * s + hi) ^ swz(row)) << 4);
+  const int i = lane & 15;
+  const int ra = 4 * hi + (i >> 2);
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt) {
+    const int col = dt * 32 + ((lane >> 4) & 1) * 16 + (i & 3) * 4;
+    o.t[dt][0] = u_addr(ra, col);
+    o.t[dt][1] = u_addr(ra + 8, col);
+  }
+  return o;
+}
+__device__ __forceinline__ bf16x8 frag_direct_o(const unsigned char* tile32, const FragOff& o, int s) {      // tile32 = tile + 32-row block * 4096
+  return *reinterpret_cast<const bf16x8*>(tile32 + o.d[s]);
+}
+__device__ __forceinline__ bf16x8 frag_tr_o(const unsigned char* tile16, const FragOff& o, int dt) {         // tile16 = tile + 16-row block * 2048
+  bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(tile16 + o.t[dt][0]));
+  bf16x4 h4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(tile16 + o.t[dt][1]));
   bf16x8 r;
   r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
   r[4] = h4[0]; r[5] = h4[1]; r[6] = h4[2]; r[7] = h4[3];
@@ -441,6 +480,305 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(const bf16_t* __restri
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// backward, two workgroups per CU: 4 waves per (image, head), 64 KiB of LDS time-shared between the two phases.
+// Phase B (dK, dV) needs all of Q, dO in LDS and one key block's K / V rows in registers; phase A (dQ) needs all of K, V in
+// LDS and one query block's Q / dO rows in registers.  So: stage Q, dO -> delta from the LDS copy of dO and a coalesced read
+// of O -> phase B with K / V fragments fetched straight from global memory (each wave reads only its own 2 x 32 rows) ->
+// restage the same 64 KiB with K, V (the Q / dO fragments of the first query block are lifted out of LDS first) -> phase A.
+// Two such workgroups fit one CU (2 x 66 KiB), so the staging bursts, LDS fragment reads and row stores of one
+// (image, head) overlap the MFMA phases of another -- the 8-wave / 128 KiB form ran one workgroup per CU with nothing to
+// overlap its serial phases (tools/experiments/attn_bwd_lab.hip: phase timeline and ablations).
+// ------------------------------------------------------------------------------------------------
+template <bool DROP>
+__global__ __launch_bounds__(256, 2) void attn_bwd2_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ ctx,
+                                                           const bf16_t* __restrict__ dctx, const float* __restrict__ lse,
+                                                           bf16_t* __restrict__ dqkv, int D, int H, float scale,
+                                                           unsigned qkv_bytes, unsigned ctx_bytes, float* __restrict__ qsum, float* __restrict__ vsum,
+                                                           dig_dropout_t drop, int nqb, int stagger) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* T0 = smem;                                              // Q, then K
+  unsigned char* T1 = smem + TILE;                                       // dO, then V
+  float* lse_s = reinterpret_cast<float*>(smem + 2 * TILE);              // [256]  -lse
+  float* del_s = lse_s + N_TOK;                                          // [256]  -delta
+  float* csum_s = del_s + N_TOK;                                         // [8 blocks][2][64]: column sums of dQ and dV (qsum only)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int img = blockIdx.x / H, h = blockIdx.x - img * H;
+  const int ld = 3 * D;
+  const size_t tok0 = (size_t)img * N_TOK;
+  const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)qkv, 0, qkv_bytes, 0x00020000);
+  const auto rg = __builtin_amdgcn_make_buffer_rsrc((void*)dctx, 0, ctx_bytes, 0x00020000);
+  const unsigned base = (unsigned)((tok0 * ld + h * DH) * 2);
+  const int hi = lane >> 5;
+  const FragOff fo = frag_offsets(lane);
+  // De-phase the two workgroups of a CU (speed only; no assumption is needed for correctness): all first-round workgroups
+  // start together and would run their HBM bursts (staging, restaging, stores) and their MFMA phases in lock step across
+  // the chip.  The second workgroup of each CU (blocks 256..511 in the observed dispatch order) starts `stagger` sleeps late.
+  if (stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 512)
+    for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(127);
+  DIG_ATTN_TS(0)
+  // O rows for delta: 8 lanes cover one 128-byte row, 32 rows per pass (coalesced; a thread-per-row read of O and dO cost
+  // a quarter of the kernel: every load instruction touched 64 different lines)
+  bf16x8 orow[8];
+#pragma unroll
+  for (int ps = 0; ps < 8; ++ps)
+    orow[ps] = *reinterpret_cast<const bf16x8*>(ctx + (tok0 + ps * 32 + (tid >> 3)) * D + h * DH + (tid & 7) * 8);
+  stage_tile<256>(T0, rs, base, ld, tid, wave);                                         // Q
+  stage_tile<256>(T1, rg, (unsigned)((tok0 * D + h * DH) * 2), D, tid, wave);           // dO
+  // K / V fragments of a key block, straight from global
+  bf16x8 kf[4], vf[4];
+  auto load_kv = [&](int kb) {
+    const int key = kb * 32 + (lane & 31);
+    const bf16_t* kp = qkv + (tok0 + key) * ld + D + h * DH + hi * 8;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      kf[s] = *reinterpret_cast<const bf16x8*>(kp + s * 16);
+      vf[s] = *reinterpret_cast<const bf16x8*>(kp + D + s * 16);
+    }
+  };
+  load_kv(wave * 2);
+  lse_s[tid] = -lse[(size_t)blockIdx.x * N_TOK + tid];              // negated: they seed the S / dP accumulators
+  DIG_ATTN_TS(1)
+  __syncthreads();
+  DIG_ATTN_TS(2)
+  // delta[q] = sum_d dO[q,d] * O[q,d]
+#pragma unroll
+  for (int ps = 0; ps < 8; ++ps) {
+    const int row = ps * 32 + (tid >> 3), c = tid & 7;
+    const bf16x8 gv = *reinterpret_cast<const bf16x8*>(T1 + row * 128 + ((c ^ swz(row)) << 4));
+    float acc = 0.f;
+    const uint4 ow = __builtin_bit_cast(uint4, orow[ps]), gw = __builtin_bit_cast(uint4, gv);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(dig_bf16x2, ow.x), __builtin_bit_cast(dig_bf16x2, gw.x), acc, false);   // v_dot2c_f32_bf16
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(dig_bf16x2, ow.y), __builtin_bit_cast(dig_bf16x2, gw.y), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(dig_bf16x2, ow.z), __builtin_bit_cast(dig_bf16x2, gw.z), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(dig_bf16x2, ow.w), __builtin_bit_cast(dig_bf16x2, gw.w), acc, false);
+    // sum over the 8 lanes of the row with DPP moves (quad xor 1, quad xor 2, row_shl 4): __shfl_xor lowers to ds_bpermute,
+    // an LDS round trip per step
+    acc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc), 0xB1, 0xF, 0xF, true));
+    acc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc), 0x4E, 0xF, 0xF, true));
+    acc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc), 0x104, 0xF, 0xF, true));
+    if (c == 0) del_s[row] = -acc;
+  }
+  __syncthreads();
+  DIG_ATTN_TS(3)
+
+  // ---------------- phase B: dK, dV for key blocks 2*wave, 2*wave+1 ----------------
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps) {
+    const int kb = wave * 2 + ps;
+    const int k0 = kb * 32;
+    const int key = k0 + (lane & 31);
+    f32x16 dk[2], dv[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { dk[dt][e] = 0.f; dv[dt][e] = 0.f; }
+    bf16x8 qfr[4], gfr[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      qfr[s] = frag_direct_o(T0, fo, s);
+      gfr[s] = frag_direct_o(T1, fo, s);
+    }
+    // The accumulators of S^T and dP^T are seeded with -lse[q] and -delta[q] (rows = queries), so the MFMAs deliver
+    // S - lse and dP - delta directly: 3 VALU ops per element (mul, exp, mul) instead of 5 and no [16] + [16] row constants
+    // held in registers across the softmax arithmetic (the compiler had sunk half of them into the arithmetic as four
+    // just-in-time LDS reads with a full lgkmcnt(0) stall each).  Dropout needs dP * mask - delta: seeded with 0 there.
+    f32x16 st, dp;
+    auto seed = [&](int qt) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int qr = qt * 32 + 8 * g + 4 * hi;
+        const float4 l4 = *reinterpret_cast<const float4*>(lse_s + qr);
+        st[g * 4] = l4.x; st[g * 4 + 1] = l4.y; st[g * 4 + 2] = l4.z; st[g * 4 + 3] = l4.w;
+        if (!DROP) {
+          const float4 d4 = *reinterpret_cast<const float4*>(del_s + qr);
+          dp[g * 4] = d4.x; dp[g * 4 + 1] = d4.y; dp[g * 4 + 2] = d4.z; dp[g * 4 + 3] = d4.w;
+        } else {
+          dp[g * 4] = 0.f; dp[g * 4 + 1] = 0.f; dp[g * 4 + 2] = 0.f; dp[g * 4 + 3] = 0.f;
+        }
+      }
+    };
+    seed(0);
+    for (int qt = 0; qt < nqb; ++qt) {
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr[s], kf[s], st, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gfr[s], vf[s], dp, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      bf16x8 gtr[2][2], qtr[2][2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          gtr[u][dt] = frag_tr_o(T1 + qt * 4096 + u * 2048, fo, dt);
+          qtr[u][dt] = frag_tr_o(T0 + qt * 4096 + u * 2048, fo, dt);
+        }
+      const int qtn = (qt + 1) & 7;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        qfr[s] = frag_direct_o(T0 + qtn * 4096, fo, s);
+        gfr[s] = frag_direct_o(T1 + qtn * 4096, fo, s);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      bf16x8 pf[2], ds[2];
+      if (!DROP) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float p = __expf(st[e]);
+          st[e] = p;
+          dp[e] = p * dp[e];
+        }
+      } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 d4 = *reinterpret_cast<const float4*>(del_s + qt * 32 + 8 * g + 4 * hi);
+          const float dl[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float p = __expf(st[g * 4 + e]);
+            const unsigned qi = qt * 32 + 8 * g + 4 * hi + e;
+            const float m = dig_drop_keep(drop.k0, drop.k1, (qi << 16) | (unsigned)key, blockIdx.x, drop.thr) ? drop.scale : 0.f;
+            st[g * 4 + e] = p * m;                                          // dropped probabilities (for dV)
+            dp[g * 4 + e] = p * (dp[g * 4 + e] * m + dl[e]);
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) { pf[u] = pack8(st, u); ds[u] = pack8(dp, u); }
+      __builtin_amdgcn_sched_barrier(0);
+      seed(qtn);                                                           // next tile's seeds land while the output MFMAs run
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gtr[u][dt], pf[u], dv[dt], 0, 0, 0);
+          dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtr[u][dt], ds[u], dk[dt], 0, 0, 0);
+        }
+    }
+    if (ps == 0) { DIG_ATTN_TS(7) }
+    if (ps == 0) load_kv(kb + 1);                                         // the next block's rows fly while this block's result is stored
+    bf16_t* okp = dqkv + (tok0 + key) * ld + D + h * DH;
+    store_rows(okp, dk, hi);
+    store_rows(okp + D, dv, hi);
+    if (vsum) wave_colsum(dv, csum_s + kb * 128 + 64, lane);
+  }
+  DIG_ATTN_TS(4)
+
+  // ---------------- restage: K -> T0, V -> T1 (every wave is done with Q, dO) ----------------
+  // Q / dO fragments of this wave's first query block are lifted out of LDS before it is overwritten; the second block's come
+  // from global memory (L2-warm) while the first block's result is stored
+  bf16x8 qf[4], gf[4];
+  if (wave * 2 < nqb) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      qf[s] = frag_direct_o(T0 + wave * 8192, fo, s);
+      gf[s] = frag_direct_o(T1 + wave * 8192, fo, s);
+    }
+  }
+  auto load_qg = [&](int qb) {
+    const int q = qb * 32 + (lane & 31);
+    const bf16_t* qp = qkv + (tok0 + q) * ld + h * DH + hi * 8;
+    const bf16_t* gp = dctx + (tok0 + q) * D + h * DH + hi * 8;
+    if (qb < nqb) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        qf[s] = *reinterpret_cast<const bf16x8*>(qp + s * 16);
+        gf[s] = *reinterpret_cast<const bf16x8*>(gp + s * 16);
+      }
+    }
+  };
+  __syncthreads();
+  stage_tile<256>(T0, rs, base + (unsigned)(D * 2), ld, tid, wave);      // K
+  stage_tile<256>(T1, rs, base + (unsigned)(2 * D * 2), ld, tid, wave);  // V
+  __syncthreads();
+  DIG_ATTN_TS(5)
+
+  // ---------------- phase A: dQ for query blocks 2*wave, 2*wave+1 ----------------
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps) {
+    const int qb = wave * 2 + ps;
+    if (qb >= nqb) continue;
+    const int q0 = qb * 32;
+    const int q = q0 + (lane & 31);
+    const float my_lse = lse_s[q], my_del = del_s[q];
+    f32x16 dq[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) dq[dt][e] = 0.f;
+    // Software pipeline over the 8 key tiles: operand fragments of tile kt+1 are requested from LDS right after the
+    // S / dP MFMAs of tile kt have issued, and the transposed K fragments of tile kt while its softmax arithmetic runs
+    bf16x8 kfr[4], vfr[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      kfr[s] = frag_direct_o(T0, fo, s);
+      vfr[s] = frag_direct_o(T1, fo, s);
+    }
+#pragma unroll 2
+    for (int kt = 0; kt < 8; ++kt) {
+      f32x16 st, dp;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { st[e] = 0.f; dp[e] = 0.f; }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[s], qf[s], st, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[s], gf[s], dp, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      bf16x8 ktr[2][2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) ktr[u][dt] = frag_tr_o(T0 + kt * 4096 + u * 2048, fo, dt);
+      const int ktn = (kt + 1) & 7;                                        // (the wrap-around load of the last tile is unused)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        kfr[s] = frag_direct_o(T0 + ktn * 4096, fo, s);
+        vfr[s] = frag_direct_o(T1 + ktn * 4096, fo, s);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        float g = dp[e];
+        if (DROP) {                                                        // dP = mask * (dO V^T) / (1 - p)
+          const unsigned key = kt * 32 + 8 * (e >> 2) + 4 * hi + (e & 3);
+          g = dig_drop_keep(drop.k0, drop.k1, ((unsigned)q << 16) | key, blockIdx.x, drop.thr) ? g * drop.scale : 0.f;
+        }
+        st[e] = __expf(st[e] + my_lse) * (g + my_del);                     // dS^T (my_lse = -lse, my_del = -delta)
+      }
+      const bf16x8 ds0 = pack8(st, 0), ds1 = pack8(st, 1);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktr[0][dt], ds0, dq[dt], 0, 0, 0);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktr[1][dt], ds1, dq[dt], 0, 0, 0);
+    }
+    if (ps == 0) load_qg(qb + 1);                                         // next block's rows fly while this block's result is stored
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) dq[dt][e] *= scale;
+    store_rows(dqkv + (tok0 + q) * ld + h * DH, dq, hi);
+    if (qsum) wave_colsum(dq, csum_s + qb * 128, lane);
+  }
+  DIG_ATTN_TS(6)
+  // fused q_bias / v_bias gradients: this (image, head)'s column sums of dQ and dV, one partial row per image
+  if (qsum) {
+    __syncthreads();
+    if (tid < 128) {
+      float a = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) a += csum_s[w * 128 + tid];
+      float* dst = tid < 64 ? qsum : vsum;
+      dst[(size_t)img * D + h * DH + (tid & 63)] = a;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int dig_attn_fwd_dropout(const void* qkv, void* ctx, float* lse, int n_img, int heads, int embed_dim,
@@ -480,11 +818,29 @@ extern "C" int dig_attn_bwd_dropout(const void* qkv, const void* ctx, const void
   const size_t qb = (size_t)n_img * N_TOK * 3 * embed_dim * 2;
   if (qb >= (1ull << 32)) return DIG_ERR_ARG;
   const int lds = 4 * TILE + 2 * N_TOK * 4 + 8 * 128 * 4;
+  const int lds2 = 2 * TILE + 2 * N_TOK * 4 + (q_colsum ? 8 * 128 * 4 : 0);
   static bool attr = false;
+  static int variant = 2, stagger_opt = 0;
   if (!attr) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd2_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TILE + 2 * N_TOK * 4 + 8 * 128 * 4);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TILE + 2 * N_TOK * 4 + 8 * 128 * 4);
+    if (const char* e = getenv("DIG_ATTN_BWD")) variant = atoi(e);
+    if (const char* e = getenv("DIG_ATTN_STAGGER")) stagger_opt = atoi(e);
     attr = true;
+  }
+  if (variant == 2) {
+    const int stagger = n_img * heads >= 1024 ? stagger_opt : 0;
+    if (drop && drop->thr)
+      hipLaunchKernelGGL(attn_bwd2_kernel<true>, dim3(n_img * heads), dim3(256), lds2, stream, (const bf16_t*)qkv, (const bf16_t*)ctx,
+                         (const bf16_t*)dctx, lse, (bf16_t*)dqkv, embed_dim, heads, scale, (unsigned)qb, (unsigned)(qb / 3), q_colsum,
+                         v_colsum, *drop, nqb, stagger);
+    else
+      hipLaunchKernelGGL(attn_bwd2_kernel<false>, dim3(n_img * heads), dim3(256), lds2, stream, (const bf16_t*)qkv, (const bf16_t*)ctx,
+                         (const bf16_t*)dctx, lse, (bf16_t*)dqkv, embed_dim, heads, scale, (unsigned)qb, (unsigned)(qb / 3), q_colsum,
+                         v_colsum, dig_dropout_t{}, nqb, stagger);
+    return dig_check_launch();
   }
   if (drop && drop->thr)
     hipLaunchKernelGGL(attn_bwd_kernel<true>, dim3(n_img * heads), dim3(512), lds, stream, (const bf16_t*)qkv, (const bf16_t*)ctx,
