@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward: dqkv = d/d(qkv) given d(ctx); 8 waves, phase A (dQ, wave = query block), phase B (dK,dV, wave = key block)
+// backward: dqkv = d/d(qkv) given d(ctx); phase A (dQ, a wave owns query blocks), phase B (dK, dV, a wave owns key blocks)
 // ------------------------------------------------------------------------------------------------
 // Store one lane-row of a 32 x 64 result held as two 32x32 MFMA accumulators (lane = row, registers = 4-column groups
 // interleaved between the two lane halves).  v_permlane32_swap trades column groups between lane l and l+32 so that each
@@ -246,240 +246,26 @@ __device__ __forceinline__ void store_rows(bf16_t* row, const f32x16 (&acc)[2], 
 }
 
 // Column sums of a 32 x 64 block held as two 32x32 accumulators (lane & 31 = row; registers = columns): reduce over the 32
-// rows of each lane half, then lanes 0 and 32 write their 2 x 16 columns into out[64].
+// rows of each lane half with DPP adds (quad xor 1, quad xor 2, half-row mirror, row mirror, row_bcast15 -- no LDS traffic;
+// __shfl_xor lowers to ds_bpermute, 160 LDS round trips per block), then lanes 16 and 48 write their 2 x 16 columns into out[64].
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_fold(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
 __device__ __forceinline__ void wave_colsum(const f32x16 (&acc)[2], float* out, int lane) {
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       float v = acc[dt][e];
-      v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
-      v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64);
-      if ((lane & 31) == 0) out[dt * 32 + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3)] = v;
+      v = dpp_fold<0xB1, 0xF>(v);        // quad_perm [1,0,3,2]
+      v = dpp_fold<0x4E, 0xF>(v);        // quad_perm [2,3,0,1]
+      v = dpp_fold<0x141, 0xF>(v);       // row_half_mirror
+      v = dpp_fold<0x140, 0xF>(v);       // row_mirror: every lane of a 16-lane row holds the row's sum
+      v = dpp_fold<0x142, 0xA>(v);       // row_bcast15 into rows 1 and 3: lanes 16..31 / 48..63 hold their half's 32-row sum
+      if ((lane & 31) == 16) out[dt * 32 + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3)] = v;
     }
 }
-
-template <bool DROP>
-__global__ __launch_bounds__(512, 2) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ ctx,
-                                                          const bf16_t* __restrict__ dctx, const float* __restrict__ lse,
-                                                          bf16_t* __restrict__ dqkv, int D, int H, float scale,
-                                                          unsigned qkv_bytes, unsigned ctx_bytes, float* __restrict__ qsum, float* __restrict__ vsum,
-                                                          dig_dropout_t drop, int nqb) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* Qt = smem;
-  unsigned char* Kt = smem + TILE;
-  unsigned char* Vt = smem + 2 * TILE;
-  unsigned char* Gt = smem + 3 * TILE;                                   // dO
-  float* lse_s = reinterpret_cast<float*>(smem + 4 * TILE);              // [256]
-  float* del_s = lse_s + N_TOK;                                          // [256]
-  float* csum_s = del_s + N_TOK;                                         // [8 waves][2][64]: column sums of dQ and dV
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int img = blockIdx.x / H, h = blockIdx.x - img * H;
-  const int ld = 3 * D;
-  const size_t tok0 = (size_t)img * N_TOK;
-  const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)qkv, 0, qkv_bytes, 0x00020000);
-  const auto rg = __builtin_amdgcn_make_buffer_rsrc((void*)dctx, 0, ctx_bytes, 0x00020000);
-  const unsigned base = (unsigned)((tok0 * ld + h * DH) * 2);
-  stage_tile<512>(Qt, rs, base, ld, tid, wave);
-  stage_tile<512>(Kt, rs, base + (unsigned)(D * 2), ld, tid, wave);
-  stage_tile<512>(Vt, rs, base + (unsigned)(2 * D * 2), ld, tid, wave);
-  stage_tile<512>(Gt, rg, (unsigned)((tok0 * D + h * DH) * 2), D, tid, wave);
-  // delta[q] = sum_d dO[q,d] * O[q,d]; two threads per query (32 d each)
-  {
-    const int q = tid >> 1, half = tid & 1;
-    const bf16_t* o = ctx + (tok0 + q) * D + h * DH + half * 32;
-    const bf16_t* g = dctx + (tok0 + q) * D + h * DH + half * 32;
-    float acc = 0.f;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const bf16x8 ov = *reinterpret_cast<const bf16x8*>(o + c * 8);
-      const bf16x8 gv = *reinterpret_cast<const bf16x8*>(g + c * 8);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) acc += bf2f((bf16_t)ov[e]) * bf2f((bf16_t)gv[e]);
-    }
-    acc += __shfl_xor(acc, 1, 64);
-    if (half == 0) {
-      del_s[q] = acc;
-      lse_s[q] = lse[(size_t)blockIdx.x * N_TOK + q];
-    }
-  }
-  __syncthreads();
-  const int hi = lane >> 5;
-
-  // ---------------- phase A: dQ for query block `wave` (only the first nqb blocks exist) ----------------
-  if (wave < nqb) {
-    const int q0 = wave * 32;
-    const int q = q0 + (lane & 31);
-    const float my_lse = lse_s[q], my_del = del_s[q];
-    bf16x8 qf[4], gf[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      qf[s] = frag_direct(Qt, q0, s, lane);
-      gf[s] = frag_direct(Gt, q0, s, lane);
-    }
-    f32x16 dq[2];
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) dq[dt][e] = 0.f;
-    // Software pipeline over the 8 key tiles: operand fragments of tile kt+1 are requested from LDS right after the
-    // S / dP MFMAs of tile kt have issued, and the transposed K fragments of tile kt while its softmax arithmetic runs, so
-    // no MFMA waits on an LDS round trip (the compiler's own schedule put every ds_read directly in front of its MFMA).
-    bf16x8 kfr[4], vfr[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      kfr[s] = frag_direct(Kt, 0, s, lane);
-      vfr[s] = frag_direct(Vt, 0, s, lane);
-    }
-#pragma unroll 2
-    for (int kt = 0; kt < 8; ++kt) {
-      f32x16 st, dp;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) { st[e] = 0.f; dp[e] = 0.f; }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[s], qf[s], st, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[s], gf[s], dp, 0, 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      bf16x8 ktr[2][2];
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) ktr[u][dt] = frag_tr(Kt, kt * 32 + u * 16, dt * 32, lane);
-      const int ktn = (kt + 1) & 7;                                        // (the wrap-around load of the last tile is unused)
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        kfr[s] = frag_direct(Kt, ktn * 32, s, lane);
-        vfr[s] = frag_direct(Vt, ktn * 32, s, lane);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        float g = dp[e];
-        if (DROP) {                                                        // dP = mask * (dO V^T) / (1 - p)
-          const unsigned key = kt * 32 + 8 * (e >> 2) + 4 * hi + (e & 3);
-          g = dig_drop_keep(drop.k0, drop.k1, ((unsigned)q << 16) | key, blockIdx.x, drop.thr) ? g * drop.scale : 0.f;
-        }
-        st[e] = __expf(st[e] - my_lse) * (g - my_del);                     // dS^T
-      }
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const bf16x8 ds = pack8(st, u);
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-          dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktr[u][dt], ds, dq[dt], 0, 0, 0);
-      }
-    }
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) dq[dt][e] *= scale;
-    store_rows(dqkv + (tok0 + q) * ld + h * DH, dq, hi);
-    if (qsum) wave_colsum(dq, csum_s + wave * 128, lane);
-  }
-
-  // ---------------- phase B: dK, dV for key block `wave` ----------------
-  {
-    const int k0 = wave * 32;
-    const int key = k0 + (lane & 31);
-    bf16x8 kf[4], vf[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      kf[s] = frag_direct(Kt, k0, s, lane);
-      vf[s] = frag_direct(Vt, k0, s, lane);
-    }
-    f32x16 dk[2], dv[2];
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) { dk[dt][e] = 0.f; dv[dt][e] = 0.f; }
-    bf16x8 qfr[4], gfr[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      qfr[s] = frag_direct(Qt, 0, s, lane);
-      gfr[s] = frag_direct(Gt, 0, s, lane);
-    }
-#pragma unroll 2
-    for (int qt = 0; qt < nqb; ++qt) {
-      f32x16 st, dp;   // rows = queries qt*32 + (e&3) + 8*(e>>2) + 4*hi, col = key
-#pragma unroll
-      for (int e = 0; e < 16; ++e) { st[e] = 0.f; dp[e] = 0.f; }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr[s], kf[s], st, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gfr[s], vf[s], dp, 0, 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      bf16x8 gtr[2][2], qtr[2][2];
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-          gtr[u][dt] = frag_tr(Gt, qt * 32 + u * 16, dt * 32, lane);
-          qtr[u][dt] = frag_tr(Qt, qt * 32 + u * 16, dt * 32, lane);
-        }
-      float ls[4][4], dl[4][4];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int qr = qt * 32 + 8 * g + 4 * hi;
-        const float4 l4 = *reinterpret_cast<const float4*>(lse_s + qr);
-        const float4 d4 = *reinterpret_cast<const float4*>(del_s + qr);
-        ls[g][0] = l4.x; ls[g][1] = l4.y; ls[g][2] = l4.z; ls[g][3] = l4.w;
-        dl[g][0] = d4.x; dl[g][1] = d4.y; dl[g][2] = d4.z; dl[g][3] = d4.w;
-      }
-      const int qtn = (qt + 1) & 7;
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        qfr[s] = frag_direct(Qt, qtn * 32, s, lane);
-        gfr[s] = frag_direct(Gt, qtn * 32, s, lane);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float p = __expf(st[g * 4 + e] - ls[g][e]);
-          float m = 1.f;
-          if (DROP) {
-            const unsigned qi = qt * 32 + 8 * g + 4 * hi + e;
-            m = dig_drop_keep(drop.k0, drop.k1, (qi << 16) | (unsigned)key, blockIdx.x, drop.thr) ? drop.scale : 0.f;
-          }
-          st[g * 4 + e] = p * m;                                          // dropped probabilities (for dV)
-          dp[g * 4 + e] = p * (dp[g * 4 + e] * m - dl[g][e]);
-        }
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const bf16x8 pf = pack8(st, u);
-        const bf16x8 ds = pack8(dp, u);
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-          dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gtr[u][dt], pf, dv[dt], 0, 0, 0);
-          dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtr[u][dt], ds, dk[dt], 0, 0, 0);
-        }
-      }
-    }
-    bf16_t* okp = dqkv + (tok0 + key) * ld + D + h * DH;
-    store_rows(okp, dk, hi);
-    store_rows(okp + D, dv, hi);
-    if (vsum) wave_colsum(dv, csum_s + wave * 128 + 64, lane);
-  }
-  // fused q_bias / v_bias gradients: this (image, head)'s column sums of dQ and dV, one partial row per image
-  if (qsum) {
-    __syncthreads();
-    if (tid < 128) {
-      float a = 0.f;
-#pragma unroll
-      for (int w = 0; w < 8; ++w) a += csum_s[w * 128 + tid];
-      float* dst = tid < 64 ? qsum : vsum;
-      dst[(size_t)img * D + h * DH + (tid & 63)] = a;
-    }
-  }
-}
-
 
 // ------------------------------------------------------------------------------------------------
 // backward, two workgroups per CU: 4 waves per (image, head), 64 KiB of LDS time-shared between the two phases.
@@ -492,11 +278,11 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(const bf16_t* __restri
 // overlap its serial phases (tools/experiments/attn_bwd_lab.hip: phase timeline and ablations).
 // ------------------------------------------------------------------------------------------------
 template <bool DROP>
-__global__ __launch_bounds__(256, 2) void attn_bwd2_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ ctx,
+__global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ ctx,
                                                            const bf16_t* __restrict__ dctx, const float* __restrict__ lse,
                                                            bf16_t* __restrict__ dqkv, int D, int H, float scale,
                                                            unsigned qkv_bytes, unsigned ctx_bytes, float* __restrict__ qsum, float* __restrict__ vsum,
-                                                           dig_dropout_t drop, int nqb, int stagger) {
+                                                           dig_dropout_t drop, int nqb) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* T0 = smem;                                              // Q, then K
   unsigned char* T1 = smem + TILE;                                       // dO, then V
@@ -513,11 +299,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd2_kernel(const bf16_t* __restr
   const unsigned base = (unsigned)((tok0 * ld + h * DH) * 2);
   const int hi = lane >> 5;
   const FragOff fo = frag_offsets(lane);
-  // De-phase the two workgroups of a CU (speed only; no assumption is needed for correctness): all first-round workgroups
-  // start together and would run their HBM bursts (staging, restaging, stores) and their MFMA phases in lock step across
-  // the chip.  The second workgroup of each CU (blocks 256..511 in the observed dispatch order) starts `stagger` sleeps late.
-  if (stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 512)
-    for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(127);
   DIG_ATTN_TS(0)
   // O rows for delta: 8 lanes cover one 128-byte row, 32 rows per pass (coalesced; a thread-per-row read of O and dO cost
   // a quarter of the kernel: every load instruction touched 64 different lines)
@@ -817,37 +598,19 @@ extern "C" int dig_attn_bwd_dropout(const void* qkv, const void* ctx, const void
   if (!aligned16(qkv) || !aligned16(ctx) || !aligned16(dctx) || !aligned16(dqkv)) return DIG_ERR_ALIGN;
   const size_t qb = (size_t)n_img * N_TOK * 3 * embed_dim * 2;
   if (qb >= (1ull << 32)) return DIG_ERR_ARG;
-  const int lds = 4 * TILE + 2 * N_TOK * 4 + 8 * 128 * 4;
-  const int lds2 = 2 * TILE + 2 * N_TOK * 4 + (q_colsum ? 8 * 128 * 4 : 0);
+  const int lds = 2 * TILE + 2 * N_TOK * 4 + (q_colsum ? 8 * 128 * 4 : 0);
   static bool attr = false;
-  static int variant = 2, stagger_opt = 0;
   if (!attr) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd2_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TILE + 2 * N_TOK * 4 + 8 * 128 * 4);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TILE + 2 * N_TOK * 4 + 8 * 128 * 4);
-    if (const char* e = getenv("DIG_ATTN_BWD")) variant = atoi(e);
-    if (const char* e = getenv("DIG_ATTN_STAGGER")) stagger_opt = atoi(e);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TILE + 2 * N_TOK * 4 + 8 * 128 * 4);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TILE + 2 * N_TOK * 4 + 8 * 128 * 4);
     attr = true;
   }
-  if (variant == 2) {
-    const int stagger = n_img * heads >= 1024 ? stagger_opt : 0;
-    if (drop && drop->thr)
-      hipLaunchKernelGGL(attn_bwd2_kernel<true>, dim3(n_img * heads), dim3(256), lds2, stream, (const bf16_t*)qkv, (const bf16_t*)ctx,
-                         (const bf16_t*)dctx, lse, (bf16_t*)dqkv, embed_dim, heads, scale, (unsigned)qb, (unsigned)(qb / 3), q_colsum,
-                         v_colsum, *drop, nqb, stagger);
-    else
-      hipLaunchKernelGGL(attn_bwd2_kernel<false>, dim3(n_img * heads), dim3(256), lds2, stream, (const bf16_t*)qkv, (const bf16_t*)ctx,
-                         (const bf16_t*)dctx, lse, (bf16_t*)dqkv, embed_dim, heads, scale, (unsigned)qb, (unsigned)(qb / 3), q_colsum,
-                         v_colsum, dig_dropout_t{}, nqb, stagger);
-    return dig_check_launch();
-  }
   if (drop && drop->thr)
-    hipLaunchKernelGGL(attn_bwd_kernel<true>, dim3(n_img * heads), dim3(512), lds, stream, (const bf16_t*)qkv, (const bf16_t*)ctx,
+    hipLaunchKernelGGL(attn_bwd_kernel<true>, dim3(n_img * heads), dim3(256), lds, stream, (const bf16_t*)qkv, (const bf16_t*)ctx,
                        (const bf16_t*)dctx, lse, (bf16_t*)dqkv, embed_dim, heads, scale, (unsigned)qb, (unsigned)(qb / 3), q_colsum,
                        v_colsum, *drop, nqb);
   else
-    hipLaunchKernelGGL(attn_bwd_kernel<false>, dim3(n_img * heads), dim3(512), lds, stream, (const bf16_t*)qkv, (const bf16_t*)ctx,
+    hipLaunchKernelGGL(attn_bwd_kernel<false>, dim3(n_img * heads), dim3(256), lds, stream, (const bf16_t*)qkv, (const bf16_t*)ctx,
                        (const bf16_t*)dctx, lse, (bf16_t*)dqkv, embed_dim, heads, scale, (unsigned)qb, (unsigned)(qb / 3), q_colsum,
                        v_colsum, dig_dropout_t{}, nqb);
   return dig_check_launch();

@@ -21,13 +21,19 @@
 // modeling_finetune.py:97), exact-erf GELU with optional pre-activation store, + residual, and either
 // bf16 / fp32 store, or (split-R wgrad) an fp32 partial slab per R-slice that dig_reduce_partials then sums into
 // the gradient arena -- device-scope fp32 atomics go to the memory side on a multi-XCD part and measured ~8x slower.
-// Variants kept for measurement (selected by the `bk` argument; the default path is bk 64 forward / 32 otherwise):
-//   bk 33 / 34: BK=32 with a 3- / 4-stage ring (counted vmcnt);  bk 164 / 132: persistent workgroups with the next
-//   tile's first stage prefetched across the epilogue.  On MI355X neither beats the 2-stage non-persistent kernel on the
-//   K=384 layers (profiles/r01_gemm_variants.txt); the persistent form wins at large K (8192^3: 1028 vs 868 TFLOP/s).
+// Tile variants (the `bk` argument, include/dig_hip.h DIG_GEMM_TILE_*): 128x128 with K step 64 (forward default) or 32 (default
+// when an operand is read transposed), 256x256 / 256x192 (16 / 12 waves: tall layers), 64x128 / 128x64 (layers with few rows).
+// Everything else that was measured -- 3-/4-stage rings, persistent workgroups for both tile families, 4x2 / 2x4 / 4x4 MFMA
+// blocks per wave, a 256x128 two-workgroups-per-CU form -- lost or tied on the shapes of this model and is not built any more
+// (numbers: profiles/r01_gemm_variants.txt, profiles/r02_gemm_lab.txt).
 // Workgroup -> tile mapping is XCD-aware (block b runs on XCD b%8): each XCD walks a contiguous range of
 // tiles with j fastest, so an A row-panel is re-read from that XCD's L2, not from HBM.
 #include "common.h"
+
+// phase time stamps for tools/experiments/gemm_lab.hip (empty in the product build)
+#ifndef DIG_GEMM_TS
+#define DIG_GEMM_TS(i)
+#endif
 
 namespace {
 
@@ -337,221 +343,6 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p, DropArg<DROP
 }
 
 // ----------------------------------------------------------------------------------------------------------------
-// Persistent variant: a workgroup walks a list of (split, tile) work items; the K-tile stream is flattened across items
-// so the first operand stage of the NEXT tile is already in flight (LDS-DMA) while the current tile runs its epilogue.
-// Ring = 2 stages, counted s_waitcnt vmcnt (the previous tile's stores may stay in flight) + raw s_barrier; the C-shuffle
-// staging is a separate 16 KiB (16 rows per wave at a time), so it never collides with DMA writes.
-template <bool TA, bool TB, int OUT, int BK, bool RES, bool PRE>
-__global__ __launch_bounds__(256, 2) void gemm_persist_kernel(GemmParams p, int n_items) {
-  constexpr int TILE_BYTES = TileCfg<BK>::TILE_BYTES;
-  constexpr int NITP = TileCfg<BK>::NIT;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wi = wave >> 1, wj = wave & 1;
-  float* stg = reinterpret_cast<float*>(smem + 4 * TILE_BYTES) + wave * 1024;     // 16 rows x 64 fp32 per wave
-  const auto ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
-  const auto rb_ = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.b_bytes, 0x00020000);
-  const int ntiles = p.tiles_i * p.tiles_j;
-  const unsigned stepA = TA ? (unsigned)(BK * p.lda * 2) : (unsigned)(BK * 2);
-  const unsigned stepB = TB ? (unsigned)(BK * p.ldb * 2) : (unsigned)(BK * 2);
-  constexpr int NST = (OUT == 0 ? 8 : 16) * (PRE ? 2 : 1);         // global stores per thread per (fully live) tile
-
-  auto item_coords = [&](int item, int& i0, int& j0, int& rbeg, int& nt, int& z) {
-    z = item / ntiles;
-    const int logical = item - z * ntiles;
-    const int ti = logical / p.tiles_j, tj = logical - ti * p.tiles_j;
-    i0 = ti * BI; j0 = tj * BJ;
-    rbeg = z * p.r_per_split;
-    const int rend = min(p.R, rbeg + p.r_per_split);
-    nt = (rend - rbeg + BK - 1) / BK;
-  };
-
-  // ---- issue cursor
-  unsigned offA[4], offB[4];
-  int is_item = blockIdx.x, is_t = 0, is_nt = 0;
-  auto issue_setup = [&]() {
-    int i0, j0, rbeg, z;
-    item_coords(is_item, i0, j0, rbeg, is_nt, z);
-#pragma unroll
-    for (int it = 0; it < NITP; ++it) {
-      const int piece = it * 256 + tid;
-      offA[it] = stage_offset<TA, BK>(piece, i0, rbeg, p.lda);
-      offB[it] = stage_offset<TB, BK>(piece, j0, rbeg, p.ldb);
-    }
-    is_t = 0;
-  };
-  auto issue_stage = [&](int slot) {
-    unsigned char* a = smem + slot * 2 * TILE_BYTES + wave * 1024;
-    unsigned char* b = a + TILE_BYTES;
-#pragma unroll
-    for (int it = 0; it < NITP; ++it) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, LDS_PTR(a + it * 4096), 16, offA[it], 0, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_, LDS_PTR(b + it * 4096), 16, offB[it], 0, 0, 0);
-      offA[it] += stepA;
-      offB[it] += stepB;
-    }
-    ++is_t;
-  };
-  if (is_item >= n_items) return;
-  issue_setup();
-  issue_stage(0);
-
-  const int hi = lane >> 5, cg = lane & 7;
-  int slot = 0;
-  int after_epi = 0;
-  f32x16 acc[2][2];
-  float bias8[8];
-  uint4 rres[RES ? 8 : 1];
-  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
-    int i0, j0, rbeg, nt, z;
-    item_coords(item, i0, j0, rbeg, nt, z);
-    const int j = j0 + wj * 64 + cg * 8;
-    const bool jok = j < p.J;
-    const int jc = jok ? j : 0;
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
-    for (int t = 0; t < nt; ++t) {
-      if (after_epi == 1) wait_vmcnt<NST>(); else wait_vmcnt<0>();
-      after_epi = 0;
-      __builtin_amdgcn_s_barrier();
-      if (t == nt - 1) {
-        // epilogue operands are requested BEFORE the next tile's DMA so that waiting for them does not wait for it
-        if (OUT != 2 && p.bias) {
-          const float4 b0 = *reinterpret_cast<const float4*>(p.bias + jc);
-          const float4 b1 = *reinterpret_cast<const float4*>(p.bias + jc + 4);
-          bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w;
-          bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
-        } else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
-        }
-        if (RES) {
-#pragma unroll
-          for (int q = 0; q < 8; ++q) {
-            const int i = min(i0 + wi * 64 + q * 8 + (lane >> 3), p.I - 1);
-            rres[q] = *reinterpret_cast<const uint4*>(p.resid + (size_t)i * p.ldr + jc);
-          }
-        }
-      }
-      // next stage of the flattened stream -> the other slot (last read one step ago; every wave is past the barrier)
-      if (is_t >= is_nt) {
-        is_item += gridDim.x;
-        if (is_item < n_items) issue_setup();
-      }
-      if (is_item < n_items) issue_stage(slot ^ 1);
-      const unsigned char* at = smem + slot * 2 * TILE_BYTES;
-      const unsigned char* bt = at + TILE_BYTES;
-#pragma unroll
-      for (int s = 0; s < BK / 16; ++s) {
-        bf16x8 af[2], bfr[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          af[u] = load_frag<TA, BK>(at, wi * 64 + u * 32, s, lane);
-          bfr[u] = load_frag<TB, BK>(bt, wj * 64 + u * 32, s, lane);
-        }
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-          for (int b = 0; b < 2; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[b], af[a], acc[a][b], 0, 0, 0);
-      }
-      slot ^= 1;
-    }
-    // ---------------- epilogue of this item ----------------
-    const float al = (j < p.alpha_cols) ? p.alpha : 1.0f;
-    float* cpart = reinterpret_cast<float*>(p.C);
-    if (OUT == 2) cpart += (size_t)z * p.I * p.ldc;
-#pragma unroll
-    for (int qt = 0; qt < 4; ++qt) {
-      const int a = qt >> 1;
-      if (((lane >> 4) & 1) == (qt & 1)) {
-        const int row = lane & 15;
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int chunk = (b * 32 + 8 * g + 4 * hi) >> 2;
-            *reinterpret_cast<float4*>(stg + row * 64 + ((chunk ^ row) << 2)) =
-                make_float4(acc[a][b][g * 4], acc[a][b][g * 4 + 1], acc[a][b][g * 4 + 2], acc[a][b][g * 4 + 3]);
-          }
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int row = h * 8 + (lane >> 3);
-        const int q = qt * 2 + h;
-        const int i = i0 + wi * 64 + qt * 16 + row;
-        const float4 x0 = *reinterpret_cast<const float4*>(stg + row * 64 + (((2 * cg) ^ row) << 2));
-        const float4 x1 = *reinterpret_cast<const float4*>(stg + row * 64 + (((2 * cg + 1) ^ row) << 2));
-        const bool live = (i < p.I) && jok;
-        float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-        if (OUT == 2) {
-          if (live) {
-            float* c = cpart + (size_t)i * p.ldc + j;
-            *reinterpret_cast<float4*>(c) = x0;
-            *reinterpret_cast<float4*>(c + 4) = x1;
-          }
-          continue;
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (v[e] + bias8[e]) * al;
-        if (p.act == 1) {
-          if (PRE && live)
-            *reinterpret_cast<uint4*>(p.pre + (size_t)i * p.ldp + j) =
-                make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
-        } else if (RES && p.act == 2) {
-          const unsigned w[4] = {rres[q].x, rres[q].y, rres[q].z, rres[q].w};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { v[2 * e] *= dgelu_f(bf2f((bf16_t)(w[e] & 0xffff))); v[2 * e + 1] *= dgelu_f(bf2f((bf16_t)(w[e] >> 16))); }
-        }
-        if (RES && p.act != 2) {
-          const unsigned w[4] = {rres[q].x, rres[q].y, rres[q].z, rres[q].w};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { v[2 * e] += bf2f((bf16_t)(w[e] & 0xffff)); v[2 * e + 1] += bf2f((bf16_t)(w[e] >> 16)); }
-        }
-        if (live) {
-          if (OUT == 0) {
-            *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)i * p.ldc + j) =
-                make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
-          } else {
-            float* c = reinterpret_cast<float*>(p.C) + (size_t)i * p.ldc + j;
-            *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
-            *reinterpret_cast<float4*>(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
-          }
-        }
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_wave_barrier();
-    }
-    after_epi = (i0 + BI <= p.I && j0 + BJ <= p.J) ? 1 : 2;
-  }
-}
-
-template <bool TA, bool TB, int OUT, int BK, bool RES, bool PRE>
-int launch_persist(const GemmParams& p, int splits, hipStream_t stream) {
-  constexpr int LDS = 4 * BI * BK * 2 + 16384;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_persist_kernel<TA, TB, OUT, BK, RES, PRE>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_set = true;
-  }
-  const int n_items = p.tiles_i * p.tiles_j * splits;
-  const int per_cu = LDS > 65536 ? 2 : 3;
-  const int grid = std::min(n_items, 256 * per_cu);
-  hipLaunchKernelGGL((gemm_persist_kernel<TA, TB, OUT, BK, RES, PRE>), dim3(grid), dim3(256), LDS, stream, p, n_items);
-  return dig_check_launch();
-}
-
-// ----------------------------------------------------------------------------------------------------------------
 // Wide-tile variant: WM x WN waves of 64x64 each (256x256, 256x128 or 128x256 outputs per workgroup, BK = 64, 2 stages).
 // Per-wave code is the same as gemm_kernel; what changes is the operand traffic: a 256x256 tile moves half the L2->LDS
 // bytes per FLOP of a 128x128 tile, and that traffic (measured ~55 GB/s per CU) is what bounds the K-loop on MI355X.
@@ -621,6 +412,7 @@ __global__ __launch_bounds__(64 * WM * WN, (BK == 32 && WM * WN == 8 && FM * FN 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wi = wave / WN, wj = wave % WN;
 
+  DIG_GEMM_TS(0)
   const int nblk = p.tiles_i * p.tiles_j;
   const int bid = blockIdx.x;
   int logical, split;
@@ -681,6 +473,7 @@ __global__ __launch_bounds__(64 * WM * WN, (BK == 32 && WM * WN == 8 && FM * FN 
   for (int t = 0; t < nt; ++t) {
     if (t + LA - 1 < nt) wait_vmcnt<(LA - 1) * LPS>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
+    if (t == 0) { DIG_GEMM_TS(1) }
     if (t + LA < nt) stage((t + LA) % NSTG);
     const unsigned char* at = smem + (t % NSTG) * Cfg::STAGE;
     const unsigned char* bt = at + Cfg::A_BYTES;
@@ -706,7 +499,9 @@ __global__ __launch_bounds__(64 * WM * WN, (BK == 32 && WM * WN == 8 && FM * FN 
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[s & 1][b], af[s & 1][a], acc[a][b], 0, 0, 0);
     }
   }
+  DIG_GEMM_TS(2)
   __syncthreads();
+  DIG_GEMM_TS(3)
 
   // ---- epilogue (C-shuffle per wave in 32-row x 64-column pieces; same contract as gemm_kernel)
   const int cg = lane & 7;
@@ -826,6 +621,7 @@ __global__ __launch_bounds__(64 * WM * WN, (BK == 32 && WM * WN == 8 && FM * FN 
     }
   }
   }
+  DIG_GEMM_TS(4)
 }
 
 template <bool TA, bool TB, int OUT, int WM, int WN, int FM, int FN, bool RES, int BK, int NSTG, bool DROP = false>
@@ -890,9 +686,8 @@ extern "C" int dig_gemm_bf16_dropout(const void* A, const void* B, void* C, int 
     if ((size_t)I * (size_t)J >= (1ull << 32) || (drop->pthr && drop->rows_per_sample <= 0)) return DIG_ERR_ARG;
   }
   if (bias && !aligned16(bias)) return DIG_ERR_ALIGN;
-  if (out_kind < 0 || out_kind > 2 || act < 0 || act > 2 || (bk != 0 && bk != 32 && bk != 33 && bk != 34 && bk != 64 && bk != 132 && bk != 164 && bk != 244 && bk != 242 && bk != 264 && bk != 224 && bk != 344 && bk != 343 && bk != 448 && bk != 484 && bk != 444 && bk != 432 && bk != 232 && bk != 332 && bk != 223 && bk != 212 && bk != 221 && bk != 422 && bk != 424 && bk != 423)) return DIG_ERR_ARG;
+  if (out_kind < 0 || out_kind > 2 || act < 0 || act > 2 || (bk != 0 && bk != 32 && bk != 64 && bk != 244 && bk != 264 && bk != 212 && bk != 221)) return DIG_ERR_ARG;
   if (act == 2 && !resid) return DIG_ERR_ARG;                   // act 2: resid carries the saved pre-activation
-  if (bk >= 100 && bk < 200 && resid && pre_act) return DIG_ERR_UNSUPPORTED;
   if (bk == 0) bk = 64;
   if (!aligned16(A) || !aligned16(B) || !aligned16(C) || (lda & 7) || (ldb & 7)) return DIG_ERR_ALIGN;
   if ((J & 7) || (ldc & 7) || (resid && ((ldr & 7) || !aligned16(resid))) || (pre_act && ((ldp & 7) || !aligned16(pre_act)))) return DIG_ERR_ALIGN;
@@ -901,7 +696,7 @@ extern "C" int dig_gemm_bf16_dropout(const void* A, const void* B, void* C, int 
   if (out_kind == 2 && (bias || resid || act)) return DIG_ERR_ARG;
   if (out_kind != 2 && splits != 1) return DIG_ERR_ARG;
   if (out_kind == 2 && ldc != J) return DIG_ERR_ARG;            // partial slabs are dense [splits][I][J]
-  if (colsum_partials && !(act == 2 && out_kind == 0 && trans_b && !trans_a && (bk < 100 || bk == 244 || bk == 242 || bk == 224 || bk == 344 || bk == 343)))
+  if (colsum_partials && !(act == 2 && out_kind == 0 && trans_b && !trans_a && (bk < 100 || bk == 244)))
     return DIG_ERR_UNSUPPORTED;                                  // 128x128 kernel and the 64x64-per-wave wide tiles
   if (colsum_partials && !aligned16(colsum_partials)) return DIG_ERR_ALIGN;
   GemmParams p;
@@ -934,52 +729,20 @@ extern "C" int dig_gemm_bf16_dropout(const void* A, const void* B, void* C, int 
   }
 #define DIG_GEMM_WCASE(ta, tb, o)                                                                                   \
   if ((trans_a != 0) == ta && (trans_b != 0) == tb && out_kind == o && bk >= 200) {                                  \
-    if (bk == 422) return resid ? launch_wide<ta, tb, o, 2, 2, 4, 2, true, 32, 2>(p, splits, stream) : launch_wide<ta, tb, o, 2, 2, 4, 2, false, 32, 2>(p, splits, stream); \
-    if (bk == 424) return resid ? launch_wide<ta, tb, o, 2, 2, 2, 4, true, 32, 2>(p, splits, stream) : launch_wide<ta, tb, o, 2, 2, 2, 4, false, 32, 2>(p, splits, stream); \
-    if (bk == 423) return resid ? launch_wide<ta, tb, o, 2, 2, 4, 2, true, 32, 3>(p, splits, stream) : launch_wide<ta, tb, o, 2, 2, 4, 2, false, 32, 3>(p, splits, stream); \
     if (bk == 212) return resid ? launch_wide<ta, tb, o, 1, 2, 2, 2, true, 64, 2>(p, splits, stream) : launch_wide<ta, tb, o, 1, 2, 2, 2, false, 64, 2>(p, splits, stream); \
     if (bk == 221) return resid ? launch_wide<ta, tb, o, 2, 1, 2, 2, true, 64, 2>(p, splits, stream) : launch_wide<ta, tb, o, 2, 1, 2, 2, false, 64, 2>(p, splits, stream); \
-    if (bk == 232) return resid ? launch_wide<ta, tb, o, 4, 2, 2, 2, true, 32, 2>(p, splits, stream) : launch_wide<ta, tb, o, 4, 2, 2, 2, false, 32, 2>(p, splits, stream); \
-    if (bk == 332) return resid ? launch_wide<ta, tb, o, 4, 2, 2, 2, true, 32, 3>(p, splits, stream) : launch_wide<ta, tb, o, 4, 2, 2, 2, false, 32, 3>(p, splits, stream); \
-    if (bk == 223) return resid ? launch_wide<ta, tb, o, 2, 4, 2, 2, true, 32, 2>(p, splits, stream) : launch_wide<ta, tb, o, 2, 4, 2, 2, false, 32, 2>(p, splits, stream); \
-    if (bk == 448) return resid ? launch_wide<ta, tb, o, 2, 4, 4, 2, true, 64, 2>(p, splits, stream) : launch_wide<ta, tb, o, 2, 4, 4, 2, false, 64, 2>(p, splits, stream); \
-    if (bk == 484) return resid ? launch_wide<ta, tb, o, 4, 2, 2, 4, true, 64, 2>(p, splits, stream) : launch_wide<ta, tb, o, 4, 2, 2, 4, false, 64, 2>(p, splits, stream); \
-    if (bk == 444) return resid ? launch_wide<ta, tb, o, 2, 2, 4, 4, true, 64, 2>(p, splits, stream) : launch_wide<ta, tb, o, 2, 2, 4, 4, false, 64, 2>(p, splits, stream); \
-    if (bk == 432) return resid ? launch_wide<ta, tb, o, 2, 2, 4, 4, true, 32, 2>(p, splits, stream) : launch_wide<ta, tb, o, 2, 2, 4, 4, false, 32, 2>(p, splits, stream); \
-    if (bk == 244) return resid ? launch_wide<ta, tb, o, 4, 4, 2, 2, true, 64, 2>(p, splits, stream) : launch_wide<ta, tb, o, 4, 4, 2, 2, false, 64, 2>(p, splits, stream); \
-    if (bk == 344) return resid ? launch_wide<ta, tb, o, 4, 4, 2, 2, true, 32, 4>(p, splits, stream) : launch_wide<ta, tb, o, 4, 4, 2, 2, false, 32, 4>(p, splits, stream); \
-    if (bk == 343) return resid ? launch_wide<ta, tb, o, 4, 4, 2, 2, true, 32, 3>(p, splits, stream) : launch_wide<ta, tb, o, 4, 4, 2, 2, false, 32, 3>(p, splits, stream); \
-    if (bk == 242) return resid ? launch_wide<ta, tb, o, 4, 2, 2, 2, true, 64, 2>(p, splits, stream) : launch_wide<ta, tb, o, 4, 2, 2, 2, false, 64, 2>(p, splits, stream); \
     if (bk == 264) return resid ? launch_wide<ta, tb, o, 4, 3, 2, 2, true, 64, 2>(p, splits, stream) : launch_wide<ta, tb, o, 4, 3, 2, 2, false, 64, 2>(p, splits, stream); \
-    return resid ? launch_wide<ta, tb, o, 2, 4, 2, 2, true, 64, 2>(p, splits, stream) : launch_wide<ta, tb, o, 2, 4, 2, 2, false, 64, 2>(p, splits, stream);               \
+    return resid ? launch_wide<ta, tb, o, 4, 4, 2, 2, true, 64, 2>(p, splits, stream) : launch_wide<ta, tb, o, 4, 4, 2, 2, false, 64, 2>(p, splits, stream);               \
   }
   DIG_GEMM_WCASE(false, false, 0)
   DIG_GEMM_WCASE(false, false, 1)
   DIG_GEMM_WCASE(false, true, 0)
   DIG_GEMM_WCASE(true, true, 2)
 #undef DIG_GEMM_WCASE
-#define DIG_GEMM_PCASE(ta, tb, o)                                                                                   \
-  if ((trans_a != 0) == ta && (trans_b != 0) == tb && out_kind == o && bk >= 100) {                                  \
-    const bool pre_ = pre_act != nullptr;                                                                            \
-    if (bk == 164)                                                                                                   \
-      return resid ? launch_persist<ta, tb, o, 64, true, false>(p, splits, stream)                                   \
-                   : (pre_ ? launch_persist<ta, tb, o, 64, false, true>(p, splits, stream)                           \
-                           : launch_persist<ta, tb, o, 64, false, false>(p, splits, stream));                        \
-    return resid ? launch_persist<ta, tb, o, 32, true, false>(p, splits, stream)                                     \
-                 : (pre_ ? launch_persist<ta, tb, o, 32, false, true>(p, splits, stream)                             \
-                         : launch_persist<ta, tb, o, 32, false, false>(p, splits, stream));                          \
-  }
-  DIG_GEMM_PCASE(false, false, 0)
-  DIG_GEMM_PCASE(false, false, 1)
-  DIG_GEMM_PCASE(false, true, 0)
-  DIG_GEMM_PCASE(true, true, 2)
-#undef DIG_GEMM_PCASE
 #define DIG_GEMM_CASE(ta, tb, o)                                                \
   if ((trans_a != 0) == ta && (trans_b != 0) == tb && out_kind == o)           \
     return bk == 64 ? (resid ? launch<ta, tb, o, 64, true, 2>(p, splits, stream) : launch<ta, tb, o, 64, false, 2>(p, splits, stream)) \
-         : bk == 32 ? (resid ? launch<ta, tb, o, 32, true, 2>(p, splits, stream) : launch<ta, tb, o, 32, false, 2>(p, splits, stream)) \
-         : bk == 33 ? (resid ? launch<ta, tb, o, 32, true, 3>(p, splits, stream) : launch<ta, tb, o, 32, false, 3>(p, splits, stream)) \
-                    : (resid ? launch<ta, tb, o, 32, true, 4>(p, splits, stream) : launch<ta, tb, o, 32, false, 4>(p, splits, stream));
+                    : (resid ? launch<ta, tb, o, 32, true, 2>(p, splits, stream) : launch<ta, tb, o, 32, false, 2>(p, splits, stream));
   DIG_GEMM_CASE(false, false, 0)
   DIG_GEMM_CASE(false, false, 1)
   DIG_GEMM_CASE(false, true, 0)

@@ -7,11 +7,14 @@ backward is the explicit reverse sequence below, activations in bf16, gradients 
 fp32 gradient arena, per-stage callbacks so the data-parallel wrapper can start the RCCL all-reduce of a finished
 parameter range while earlier layers are still in backward.
 """
+import os
+
 import torch
 
 from . import ops
 
 BF16, F32 = torch.bfloat16, torch.float32
+FUSED_QV_BIAS_SUMS = os.environ.get("DIG_FUSED_QV_BIAS", "1") != "0"
 
 
 class LocalComm:
@@ -164,14 +167,18 @@ class _Step:
             # x_mid = x + proj(attn(ln1))
             on_side(lambda: ops.linear_wgrad(dx_mid, ctx, g["attn.proj.weight"]), dx_mid, ctx)
             dctx = ops.linear_dgrad(dx_mid, blk["attn.proj.weight"])
-            dqkv = ops.attn_bwd(qkv, ctx, dctx, lse, views * B, H, D, scale)
             gb = g["qkv_bias"]
-            # (attn_bwd can also emit these column sums itself -- ops.attn_bwd(bias_sums=True) -- but that lengthens the
-            #  kernel on the critical chain; two small column-sum launches on the side stream measured 0.4 ms/step faster)
-            on_side(lambda: (ops.linear_wgrad(dqkv, ln1, g["attn.qkv.weight"]),
-                             ops.colsum(dqkv, gb[:D], cols=D),                 # q_bias (dq already carries the q scale)
-                             ops.colsum(dqkv[:, 2 * D:], gb[2 * D:], cols=D)),  # v_bias; K has no bias
-                    dqkv, ln1)
+            if FUSED_QV_BIAS_SUMS:
+                # q_bias / v_bias gradients: per-image column sums of dQ (already carrying the q scale) and dV leave the attention
+                # kernel as [2B, D] fp32 partials (DPP row reductions of the accumulators, no extra pass over the 150 MB dqkv);
+                # K has no bias
+                dqkv, qs, vs = ops.attn_bwd(qkv, ctx, dctx, lse, views * B, H, D, scale, bias_sums=True)
+                on_side(lambda: (ops.linear_wgrad(dqkv, ln1, g["attn.qkv.weight"]),
+                                 ops.colsum_partials(qs, gb[:D]), ops.colsum_partials(vs, gb[2 * D:])), dqkv, ln1, qs, vs)
+            else:
+                dqkv = ops.attn_bwd(qkv, ctx, dctx, lse, views * B, H, D, scale)
+                on_side(lambda: (ops.linear_wgrad(dqkv, ln1, g["attn.qkv.weight"]),
+                                 ops.colsum(dqkv, gb[:D], cols=D), ops.colsum(dqkv[:, 2 * D:], gb[2 * D:], cols=D)), dqkv, ln1)
             dln1 = ops.linear_dgrad(dqkv, blk["attn.qkv.weight"], out=dctx)
             dx, fin1, ws1 = ops.layernorm_bwd(dln1, x, blk["norm1.weight"], blk["norm1.bias"], mu1, rs1, dx_mid, g["norm1.weight"],
                                               g["norm1.bias"], out=dln1, dres_colsum=g["attn.proj.bias"], defer=True)

@@ -40,11 +40,17 @@ typedef struct ihipStream_t* hipStream_t;
  *               resid (bf16, act != 2): v += resid[i,j]
  *   requirements: J % 8 == 0; lda, ldb, ldc, ldr, ldp % 8 == 0; 16-byte aligned pointers; R % 64 == 0 for a non-transposed
  *   operand; a_rows / b_rows (0 = default) = rows of A / B that exist in memory (rows beyond read as zero).
- *   bk selects the tile variant (csrc/gemm.hip): 0/32/64 = 128x128 tile with that K step (33/34: 3-/4-stage ring; 132/164:
- *   persistent); 2xx/3xx/4xx = multi-wave tiles of gemm_wide_kernel (244 = 256x256, 16 waves, the default for tall layers;
- *   264 = 256x192, 12 waves: the widths of this model -- 384, 1152, 1536 -- are multiples of 192, not all of 256).
+ *   bk = tile variant, one of DIG_GEMM_TILE_* below (0 = default: 128x128 with K step 64 when both operands are read along
+ *   their contiguous axis, 32 otherwise).
  *   colsum_partials (act 2 only): [ceil(I/64)][J] fp32 column sums of the result per 64-row group, or null.
  */
+#define DIG_GEMM_TILE_DEFAULT 0
+#define DIG_GEMM_TILE_128x128_K32 32   /* 4 waves; transposed-operand layers (dgrad / wgrad) */
+#define DIG_GEMM_TILE_128x128_K64 64   /* 4 waves; forward layers */
+#define DIG_GEMM_TILE_256x256 244      /* 16 waves, 128 KiB LDS: tall forward layers (half the operand traffic per FLOP) */
+#define DIG_GEMM_TILE_256x192 264      /* 12 waves: tall layers whose width is 384 (a multiple of 192, not of 256) */
+#define DIG_GEMM_TILE_64x128 212       /* 2 waves: few rows, long K (projection-head layers) */
+#define DIG_GEMM_TILE_128x64 221       /* 2 waves: few rows (projection-head dgrads) */
 int dig_gemm_bf16(const void* A, const void* B, void* C, int I, int J, int R, int lda, int ldb, int ldc, int trans_a,
                   int trans_b, int out_kind, const float* bias, const void* resid, int ldr, void* pre_act, int ldp, float alpha,
                   int alpha_cols, int act, int splits, int a_rows, int b_rows, int bk, float* colsum_partials,

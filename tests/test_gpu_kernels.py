@@ -69,7 +69,7 @@ def test_gemm_fwd_dgrad_wgrad(dev, I, J, R, bk):
 
 
 @pytest.mark.parametrize("I,J,R", [(2048, 1152, 384), (716, 200, 192), (8192, 1536, 384), (300, 520, 64), (8192, 384, 1536)])
-@pytest.mark.parametrize("bk", [244, 264, 242, 224, 344, 343, 448, 484, 444, 432, 232, 212, 221, 422, 424, 423])
+@pytest.mark.parametrize("bk", [244, 264, 212, 221])
 def test_gemm_wide_tile_variants(dev, I, J, R, bk):
     """Every multi-wave tile shape of gemm_wide_kernel (WM x WN waves of FM x FN MFMA blocks) on full and ragged tiles:
     forward epilogues, transposed-B (dgrad) and split-R partial slabs (wgrad)."""
