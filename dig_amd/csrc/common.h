@@ -12,6 +12,7 @@ typedef __attribute__((ext_vector_type(2))) short bf16x2;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef unsigned dig_u32x4 __attribute__((ext_vector_type(4)));
 
 #define DIG_OK 0
 #define DIG_ERR_ARG (-1)

@@ -29,10 +29,14 @@
 // Workgroup -> tile mapping is XCD-aware (block b runs on XCD b%8): each XCD walks a contiguous range of
 // tiles with j fastest, so an A row-panel is re-read from that XCD's L2, not from HBM.
 #include "common.h"
+#include <type_traits>
 
 // phase time stamps for tools/experiments/gemm_lab.hip (empty in the product build)
 #ifndef DIG_GEMM_TS
 #define DIG_GEMM_TS(i)
+#define DIG_GEMM_PW_BEGIN()
+#define DIG_GEMM_PW_ACC(k)
+#define DIG_GEMM_PW_END()
 #endif
 
 namespace {
@@ -44,6 +48,7 @@ struct GemmParams {
   int I, J, R;
   int lda, ldb, ldc;
   unsigned a_bytes, b_bytes;
+  unsigned c_bytes;                       // persistent forward tiles: bytes of C (= of pre_act / resid: same leading dimension required)
   const float* bias;
   const bf16_t* resid;
   int ldr;
@@ -641,6 +646,237 @@ int launch_wide(GemmParams p, int splits, hipStream_t stream, DropArg<DROP> da =
   return dig_check_launch();
 }
 
+// 16-byte LDS accesses the compiler does not see (see gemm_pwide_kernel); the caller orders them with explicit lgkmcnt waits
+__device__ __forceinline__ void lds_write16(float* p, f32x4 v) {
+  asm volatile("ds_write_b128 %0, %1" ::"v"((unsigned)(uintptr_t)LDS_PTR(p)), "v"(v) : "memory");
+}
+__device__ __forceinline__ void lds_read16x2(const float* p0, const float* p1, f32x4& a, f32x4& b) {
+  asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+               : "=&v"(a), "=&v"(b)
+               : "v"((unsigned)(uintptr_t)LDS_PTR(p0)), "v"((unsigned)(uintptr_t)LDS_PTR(p1))
+               : "memory");
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// Persistent form of the 256x256 / 256x192 forward tiles (bf16 output, 64x64 per wave, BK = 64, two LDS slots).  One workgroup
+// per CU walks tiles vb = blockIdx.x, blockIdx.x + gridDim.x, ... (same tile <-> XCD assignment as gemm_wide_kernel) and the
+// K-stage stream is flattened across tiles: while the last K-stage of a tile is multiplied, the FIRST stage of the next tile is
+// already on its way into the other slot, and the epilogue runs out of the slot that was consumed last (16-row C-shuffle pieces,
+// 4 KiB per wave).  Removes, per tile, the ~3.4 k cycles from workgroup entry to the first operand stage and the dispatch gap
+// between two workgroups of a CU (tools/experiments/gemm_lab.hip: with one 128 KiB workgroup per CU and six K-stages per tile
+// the sum of the wave lifetimes was only 80 % of the launch).
+// Register discipline (16 waves = 128 VGPRs): everything derived from the lane id is re-derived per tile from a laundered copy,
+// otherwise the compiler keeps K-loop and epilogue address sets alive across each other and spills ~30 registers -- and scratch
+// accesses are VMEM operations, i.e. they would sit in the same in-order queue as the LDS-DMA and the result stores.
+template <int WN, bool RES, bool PRE>
+__global__ __launch_bounds__(256 * WN, 1) void gemm_pwide_kernel(GemmParams p, int n_items) {
+  constexpr int WM = 4, FM = 2, FN = 2, BK = 64;
+  using Cfg = WideCfg<WM, WN, FM, FN, BK, 2>;
+  static_assert(Cfg::PA % 64 == 0 && Cfg::PB % 64 == 0, "whole waves take part in a staging pass or skip it");
+  static_assert(Cfg::STAGE >= (Cfg::NT / 64) * 4096, "a slot holds the C-shuffle staging of every wave");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wi = wave / WN, wj = wave % WN;
+  const int nblk = p.tiles_i * p.tiles_j;
+  const int nt = p.R / BK;                                              // host-checked: R % 64 == 0
+  const auto ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
+  const auto rb_ = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.b_bytes, 0x00020000);
+  // outputs / residual through buffer descriptors too: 32-bit offsets instead of 64-bit per-lane pointers (registers), and rows
+  // beyond I are dropped by the bounds check, so every lane issues the same stores (the counted hand-off below needs that)
+  const auto rc_ = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, p.c_bytes, 0x00020000);
+  const auto rp_ = __builtin_amdgcn_make_buffer_rsrc((void*)p.pre, 0, PRE ? p.c_bytes : 0, 0x00020000);
+  const auto rr_ = __builtin_amdgcn_make_buffer_rsrc((void*)p.resid, 0, RES ? p.c_bytes : 0, 0x00020000);
+  const auto rbias_ = __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, p.bias ? p.J * 4 : 0, 0x00020000);   // no bias: reads as zeros
+  const int q8 = nblk >> 3, rm8 = nblk & 7;
+  auto tile_of = [&](int vb, int& ti, int& tj) {                        // virtual block -> tile: each XCD walks a contiguous tile range
+    const int xcd = vb & 7;
+    const int logical = (xcd < rm8 ? xcd * (q8 + 1) : rm8 * (q8 + 1) + (xcd - rm8) * q8) + (vb >> 3);
+    ti = logical / p.tiles_j; tj = logical - ti * p.tiles_j;
+  };
+  // ---- issue cursor (runs one K-stage ahead of the compute cursor, across tile boundaries)
+  unsigned offA[8], offB[8];   // (a dependent bound here makes hipcc 7.2 drop the host-side kernel stub)
+  int is_vb = blockIdx.x, is_t = 0;
+  auto issue_setup = [&]() {
+    int ti, tj;
+    tile_of(is_vb, ti, tj);
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+#pragma unroll
+    for (int it = 0; it < Cfg::NITA; ++it) offA[it] = wstage_offset<false, Cfg::TBI, BK>(it * Cfg::NT + tid, ti * Cfg::TBI, 0, p.lda);
+#pragma unroll
+    for (int it = 0; it < Cfg::NITB; ++it) offB[it] = wstage_offset<false, Cfg::TBJ, BK>(it * Cfg::NT + tid, tj * Cfg::TBJ, 0, p.ldb);
+    is_t = 0;
+  };
+  auto issue_stage = [&](int slot) {
+    unsigned char* a = smem + slot * Cfg::STAGE + wave * 1024;
+    unsigned char* b = a + Cfg::A_BYTES;
+#pragma unroll
+    for (int it = 0; it < Cfg::NITA; ++it) {
+      if (!Cfg::RAGGED || it * Cfg::NT + wave * 64 < Cfg::PA)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, LDS_PTR(a + it * Cfg::NT * 16), 16, offA[it], 0, 0, 0);
+      offA[it] += (unsigned)(BK * 2);
+    }
+#pragma unroll
+    for (int it = 0; it < Cfg::NITB; ++it) {
+      if (!Cfg::RAGGED || it * Cfg::NT + wave * 64 < Cfg::PB)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_, LDS_PTR(b + it * Cfg::NT * 16), 16, offB[it], 0, 0, 0);
+      offB[it] += (unsigned)(BK * 2);
+    }
+    ++is_t;
+  };
+  if (is_vb >= n_items) return;
+  DIG_GEMM_PW_BEGIN()
+  issue_setup();
+  issue_stage(0);
+  int slot = 0;
+  bool counted = false;                                                 // the last thing this wave issued: exactly NST stores behind the DMA
+  constexpr int NST = 8 * (PRE ? 2 : 1);                                // 16-byte stores per thread per full tile
+  for (int vb = blockIdx.x; vb < n_items; vb += gridDim.x) {
+    int ti, tj;
+    tile_of(vb, ti, tj);
+    const int i0 = ti * Cfg::TBI, j0 = tj * Cfg::TBJ;
+    f32x16 acc[FM][FN];
+#pragma unroll
+    for (int a = 0; a < FM; ++a)
+#pragma unroll
+      for (int b = 0; b < FN; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+    float4 bias_lo = make_float4(0.f, 0.f, 0.f, 0.f), bias_hi = bias_lo;
+    uint4 rres[RES ? 8 : 1];
+    {
+      int lane = threadIdx.x & 63;
+      asm volatile("" : "+v"(lane));                                     // K-loop addresses are rebuilt per tile (see the header)
+      auto kstep = [&](auto last_tag, auto first_tag) {
+        constexpr bool LAST = decltype(last_tag)::value;                   // the tile's last K-stage also requests the epilogue operands
+        constexpr bool FIRST = decltype(first_tag)::value;
+        if (counted) wait_vmcnt<NST>(); else wait_vmcnt<0>();
+        counted = false;
+        __builtin_amdgcn_s_barrier();                                    // this stage has landed for every wave; the other slot is free
+        if (FIRST) { DIG_GEMM_PW_ACC(0) }
+        if (is_t >= nt) {
+          is_vb += gridDim.x;
+          if (is_vb < n_items) issue_setup();
+        }
+        if (LAST) {
+          // bias: requested BEFORE the next tile's DMA, so that using it in the epilogue does not wait for that DMA (VMEM results
+          // return in issue order)
+          const int jb = min(j0 + wj * 64 + (lane & 7) * 8, p.J - 8);
+          bias_lo = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rbias_, jb * 4, 0, 0));
+          bias_hi = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rbias_, jb * 4 + 16, 0, 0));
+        }
+        if (is_vb < n_items) issue_stage(slot ^ 1);
+        if (RES && LAST) {
+          // residual rows: requested right behind the DMA (32 registers for one K-stage); their first use comes a whole K-stage
+          // later, when the DMA in front of them has landed anyway
+          const int jr = min(j0 + wj * 64 + (lane & 7) * 8, p.J - 8);
+#pragma unroll
+          for (int ps = 0; ps < 8; ++ps) {
+            const int i = i0 + wi * 64 + ps * 8 + (lane >> 3);                                   // rows beyond I read as zero
+            rres[ps] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rr_, (i * p.ldr + jr) * 2, 0, 0));
+          }
+        }
+        const unsigned char* at = smem + slot * Cfg::STAGE;
+        const unsigned char* bt = at + Cfg::A_BYTES;
+#pragma unroll
+        for (int s = 0; s < BK / 16; ++s) {
+          bf16x8 af[FM], bfr[FN];
+#pragma unroll
+          for (int u = 0; u < FM; ++u) af[u] = wload_frag<false, Cfg::TBI, BK>(at, wi * (32 * FM) + u * 32, s, lane);
+#pragma unroll
+          for (int u = 0; u < FN; ++u) bfr[u] = wload_frag<false, Cfg::TBJ, BK>(bt, wj * (32 * FN) + u * 32, s, lane);
+#pragma unroll
+          for (int a = 0; a < FM; ++a)
+#pragma unroll
+            for (int b = 0; b < FN; ++b)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[b], af[a], acc[a][b], 0, 0, 0);
+        }
+        slot ^= 1;
+      };
+      if (nt > 1) kstep(std::false_type{}, std::true_type{});
+      for (int t = 1; t + 1 < nt; ++t) kstep(std::false_type{}, std::false_type{});
+      kstep(std::true_type{}, std::false_type{});            // (nt == 1: the 'first stage' stamp of the lab build is skipped)
+    }
+    // ---------------- epilogue of this tile: staging = the slot consumed last (slot ^ 1 after the toggle) ----------------
+    DIG_GEMM_PW_ACC(1)
+    __builtin_amdgcn_s_barrier();                                        // every wave is done reading that slot
+    DIG_GEMM_PW_ACC(2)
+    int lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane));
+    const int cg = lane & 7, hi = lane >> 5;
+    float* stg = reinterpret_cast<float*>(smem + (slot ^ 1) * Cfg::STAGE + wave * 4096);     // 16 rows x 64 fp32
+    const int j = j0 + wj * 64 + cg * 8;
+    const bool jok = j < p.J;
+    const float bias8[8] = {bias_lo.x, bias_lo.y, bias_lo.z, bias_lo.w, bias_hi.x, bias_hi.y, bias_hi.z, bias_hi.w};
+    const float al = (j < p.alpha_cols) ? p.alpha : 1.0f;
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {                                     // 16-row pieces: rows qt*16 .. qt*16+15 of the wave's 64
+      const int a = qt >> 1;
+      if (((lane >> 4) & 1) == (qt & 1)) {
+        const int row = lane & 15;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int chunk = (b * 32 + 8 * g + 4 * hi) >> 2;
+            const f32x4 q4 = {acc[a][b][g * 4], acc[a][b][g * 4 + 1], acc[a][b][g * 4 + 2], acc[a][b][g * 4 + 3]};
+            lds_write16(stg + row * 64 + ((chunk ^ row) << 2), q4);
+          }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int row = hh * 8 + (lane >> 3);
+        const int ps = qt * 2 + hh;
+        const int i = i0 + wi * 64 + qt * 16 + row;
+        f32x4 x0, x1;
+        lds_read16x2(stg + row * 64 + (((2 * cg) ^ row) << 2), stg + row * 64 + (((2 * cg + 1) ^ row) << 2), x0, x1);
+        const int ooff = jok ? (i * p.ldc + j) * 2 : -1;                  // byte offset of this lane's 8 outputs (-1: out of range, dropped)
+        float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (v[e] + bias8[e]) * al;
+        if (p.act == 1) {
+          if (PRE)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(dig_u32x4, make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]))),
+                                                   rp_, ooff, 0, 0);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+        }
+        if (RES) {
+          const unsigned w[4] = {rres[ps].x, rres[ps].y, rres[ps].z, rres[ps].w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[2 * e] += bf2f((bf16_t)(w[e] & 0xffff)); v[2 * e + 1] += bf2f((bf16_t)(w[e] >> 16)); }
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(dig_u32x4, make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]))),
+                                               rc_, ooff, 0, 0);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+    }
+    DIG_GEMM_PW_ACC(3)
+    counted = !PRE || p.act == 1;                                        // every wave has issued exactly NST stores behind the DMA
+  }
+  DIG_GEMM_PW_END()
+}
+
+template <int WN, bool RES, bool PRE>
+int launch_pwide(GemmParams p, hipStream_t stream) {
+  using Cfg = WideCfg<4, WN, 2, 2, 64, 2>;
+  constexpr int LDS = 2 * Cfg::STAGE;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pwide_kernel<WN, RES, PRE>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_set = true;
+  }
+  p.tiles_i = (p.I + Cfg::TBI - 1) / Cfg::TBI;
+  p.tiles_j = (p.J + Cfg::TBJ - 1) / Cfg::TBJ;
+  const int n_items = p.tiles_i * p.tiles_j;
+  const int grid = std::min(n_items, 256);                               // one 16- / 12-wave workgroup per CU
+  hipLaunchKernelGGL((gemm_pwide_kernel<WN, RES, PRE>), dim3(grid), dim3(Cfg::NT), LDS, stream, p, n_items);
+  return dig_check_launch();
+}
+
 // out[e] (+)= sum_s part[s][e]   (deterministic split-R combine; also the "+=" into the gradient arena)
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int splits, long long n4,
                                                               float* __restrict__ out, int accumulate) {
@@ -686,7 +922,7 @@ extern "C" int dig_gemm_bf16_dropout(const void* A, const void* B, void* C, int 
     if ((size_t)I * (size_t)J >= (1ull << 32) || (drop->pthr && drop->rows_per_sample <= 0)) return DIG_ERR_ARG;
   }
   if (bias && !aligned16(bias)) return DIG_ERR_ALIGN;
-  if (out_kind < 0 || out_kind > 2 || act < 0 || act > 2 || (bk != 0 && bk != 32 && bk != 64 && bk != 244 && bk != 264 && bk != 212 && bk != 221)) return DIG_ERR_ARG;
+  if (out_kind < 0 || out_kind > 2 || act < 0 || act > 2 || (bk != 0 && bk != 32 && bk != 64 && bk != 244 && bk != 264 && bk != 212 && bk != 221 && bk != 544 && bk != 564)) return DIG_ERR_ARG;
   if (act == 2 && !resid) return DIG_ERR_ARG;                   // act 2: resid carries the saved pre-activation
   if (bk == 0) bk = 64;
   if (!aligned16(A) || !aligned16(B) || !aligned16(C) || (lda & 7) || (ldb & 7)) return DIG_ERR_ALIGN;
@@ -702,6 +938,7 @@ extern "C" int dig_gemm_bf16_dropout(const void* A, const void* B, void* C, int 
   GemmParams p;
   p.splits_x = 0;
   p.colsum = colsum_partials;
+  p.c_bytes = 0;
   p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C;
   p.I = I; p.J = J; p.R = R; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
   // a_rows / b_rows (0 = default) bound the rows that really exist in memory; rows past them read as zero.
@@ -726,6 +963,15 @@ extern "C" int dig_gemm_bf16_dropout(const void* A, const void* B, void* C, int 
                       : (resid ? launch<false, false, 0, 64, true, 2, true>(p, splits, stream, da) : launch<false, false, 0, 64, false, 2, true>(p, splits, stream, da));
     return bk == 32 ? (resid ? launch<false, true, 0, 32, true, 2, true>(p, splits, stream, da) : launch<false, true, 0, 32, false, 2, true>(p, splits, stream, da))
                     : (resid ? launch<false, true, 0, 64, true, 2, true>(p, splits, stream, da) : launch<false, true, 0, 64, false, 2, true>(p, splits, stream, da));
+  }
+  if ((bk == 544 || bk == 564) && !trans_a && !trans_b && out_kind == 0 && act != 2 && !colsum_partials) {   // persistent forward tiles
+    const bool pre_ = pre_act != nullptr && act == 1;
+    if (pre_ && resid) return DIG_ERR_UNSUPPORTED;
+    if ((size_t)I * ldc * 2 >= (1ull << 31) || (resid && ldr != ldc) || (pre_ && ldp != ldc)) return DIG_ERR_UNSUPPORTED;
+    p.c_bytes = (unsigned)((size_t)I * ldc * 2);
+    if (bk == 544 && resid) return DIG_ERR_UNSUPPORTED;               // (16 waves + a resident residual tile: over the 128-VGPR budget)
+    if (bk == 544) return (pre_ ? launch_pwide<4, false, true>(p, stream) : launch_pwide<4, false, false>(p, stream));
+    return resid ? launch_pwide<3, true, false>(p, stream) : (pre_ ? launch_pwide<3, false, true>(p, stream) : launch_pwide<3, false, false>(p, stream));
   }
 #define DIG_GEMM_WCASE(ta, tb, o)                                                                                   \
   if ((trans_a != 0) == ta && (trans_b != 0) == tb && out_kind == o && bk >= 200) {                                  \

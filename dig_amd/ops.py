@@ -1,6 +1,7 @@
 """Thin tensor-level wrappers over the C-ABI (include/dig_hip.h).  Every function launches hand-written HIP
 kernels on the caller's current stream; nothing here computes on the host or falls back to ATen."""
 import ctypes
+import os
 
 import torch
 
@@ -48,6 +49,7 @@ def gemm(A, B, I, J, R, *, ta=False, tb=False, out=None, out_kind=OUT_BF16, bias
     return out
 
 
+PERSISTENT_FWD = os.environ.get("DIG_PERSISTENT_FWD", "1") != "0"
 DGRAD_GELU_BK = 32    # tile of the fc2 dgrad + GELU' + bias-sum GEMM: 128x128/BK32 beats the 256x256 tile inside the step (A/B: 25.9 vs 26.1 ms)
 def linear_fwd(x, w, *, bias=None, resid=None, act=0, pre=None, alpha=1.0, alpha_cols=0, out=None, out_kind=OUT_BF16, drop=None):
     """y[rows,out] = x[rows,in] @ w[out,in]^T (+bias)(gelu)(+resid)."""
@@ -69,6 +71,8 @@ def linear_fwd(x, w, *, bias=None, resid=None, act=0, pre=None, alpha=1.0, alpha
         bk = 212                                        # few output tiles, long K: 64x128 tiles for more workgroups
     else:
         bk = 0
+    if PERSISTENT_FWD and drop is None and out_kind == OUT_BF16 and ((bk == 244 and resid is None) or bk == 264):
+        bk += 300                                       # 544 / 564: the persistent form of the same tile (bit-identical results)
     return gemm(x, w, x.shape[0], w.shape[0], w.shape[1], bias=bias, resid=resid, act=act, pre=pre, alpha=alpha,
                 alpha_cols=alpha_cols, out=out, out_kind=out_kind, bk=bk, drop=drop)
 

@@ -12,6 +12,10 @@ __device__ long long* g_rt;
 #define NTS 8
 #define MAXW 16
 #define DIG_GEMM_TS(i) if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096) { g_ts[((size_t)blockIdx.x * MAXW + (threadIdx.x >> 6)) * NTS + (i)] = (long long)__builtin_amdgcn_s_memtime(); if ((i) == 0 || (i) == 4) g_rt[((size_t)blockIdx.x * MAXW + (threadIdx.x >> 6)) * 2 + ((i) ? 1 : 0)] = (long long)__builtin_amdgcn_s_memrealtime(); }
+// persistent kernel: per-wave sums over its tiles of (wait for the tile's first stage | K loop | barrier | epilogue), in slots 0..3, tile count in 5
+#define DIG_GEMM_PW_BEGIN() long long pw_last = (long long)__builtin_amdgcn_s_memtime(), pw_acc[4] = {0, 0, 0, 0}; int pw_n = 0; const long long pw_rt0 = (long long)__builtin_amdgcn_s_memrealtime();
+#define DIG_GEMM_PW_ACC(k) { const long long pw_now = (long long)__builtin_amdgcn_s_memtime(); pw_acc[k] += pw_now - pw_last; pw_last = pw_now; if ((k) == 3) ++pw_n; }
+#define DIG_GEMM_PW_END() if ((threadIdx.x & 63) == 0) { long long* q = g_ts + ((size_t)blockIdx.x * MAXW + (threadIdx.x >> 6)) * NTS; q[0] = 1; q[1] = 1 + pw_acc[0] / pw_n; q[2] = q[1] + pw_acc[1] / pw_n; q[3] = q[2] + pw_acc[2] / pw_n; q[4] = q[3] + pw_acc[3] / pw_n; long long* r = g_rt + ((size_t)blockIdx.x * MAXW + (threadIdx.x >> 6)) * 2; r[0] = pw_rt0; r[1] = (long long)__builtin_amdgcn_s_memrealtime(); }
 #include "../../dig_amd/csrc/gemm.hip"
 
 static long long *ts, *rt;
@@ -65,6 +69,12 @@ int main() {
       {"fc1 384->1536 gelu      256x256 (244)", 1536, 384, 1, false, false, 244},
       {"fc1 384->1536 gelu+pre  256x256 (244)", 1536, 384, 1, true, false, 244},
       {"fc1 384->1536 plain     256x256 (244)", 1536, 384, 0, false, false, 244},
+      {"fc1 384->1536 gelu      persistent 256x256 (544)", 1536, 384, 1, false, false, 544},
+      {"fc1 384->1536 gelu+pre  persistent 256x256 (544)", 1536, 384, 1, true, false, 544},
+      {"fc1 384->1536 plain     persistent 256x256 (544)", 1536, 384, 0, false, false, 544},
+      {"qkv 384->1152 bias      persistent 256x256 (544)", 1152, 384, 0, false, false, 544},
+      {"proj 384->384 +res      persistent 256x192 (564)", 384, 384, 0, false, true, 564},
+      {"fc2 1536->384 +res      persistent 256x192 (564)", 384, 1536, 0, false, true, 564},
       {"qkv 384->1152 bias      256x256 (244)", 1152, 384, 0, false, false, 244},
       {"proj 384->384 +res      256x192 (264)", 384, 384, 0, false, true, 264},
       {"fc2 1536->384 +res      256x192 (264)", 384, 1536, 0, false, true, 264},
@@ -78,6 +88,18 @@ int main() {
       dig_gemm_bf16(x, w, y, I, c.J, c.R, c.R, c.R, c.J, 0, 0, 0, bias, c.res ? res : nullptr, c.J, c.pre ? pre : nullptr, c.J, 1.0f, 0, c.act, 1, 0, 0, c.bk,
                     nullptr, 0);
     });
+  }
+  // 8-wave forms of the 256x256 tile (not in the library): 2x4 waves of 128x64 and 4x2 waves of 64x128
+  {
+    GemmParams q{};
+    q.A = x384; q.B = w; q.C = y; q.I = I; q.J = 1536; q.R = 384; q.lda = 384; q.ldb = 384; q.ldc = 1536;
+    q.a_bytes = (unsigned)((size_t)I * 384 * 2); q.b_bytes = 1536u * 384 * 2; q.bias = bias; q.resid = nullptr; q.ldr = 0; q.pre = nullptr; q.ldp = 0;
+    q.alpha = 1.f; q.alpha_cols = 0; q.act = 0; q.r_per_split = 384; q.colsum = nullptr; q.splits_x = 0;
+    const double fl = 2.0 * I * 1536 * 384, by = 2.0 * I * 384 + 2.0 * 1536 * 384 + 2.0 * I * 1536;
+    timeline("fc1 plain 256x256, 8 waves 2x4 of 128x64", fl, by, [&] { launch_wide<false, false, 0, 2, 4, 4, 2, false, 64, 2>(q, 1, 0); });
+    timeline("fc1 plain 256x256, 8 waves 4x2 of 64x128", fl, by, [&] { launch_wide<false, false, 0, 4, 2, 2, 4, false, 64, 2>(q, 1, 0); });
+    q.act = 1;
+    timeline("fc1 gelu  256x256, 8 waves 2x4 of 128x64", fl, by, [&] { launch_wide<false, false, 0, 2, 4, 4, 2, false, 64, 2>(q, 1, 0); });
   }
   return 0;
 }
