@@ -101,5 +101,47 @@ int main() {
     q.act = 1;
     timeline("fc1 gelu  256x256, 8 waves 2x4 of 128x64", fl, by, [&] { launch_wide<false, false, 0, 2, 4, 4, 2, false, 64, 2>(q, 1, 0); });
   }
+  // ---- backward shapes: ring depth of the 128x128 tile (bytes in flight per CU) for HBM-streamed operands
+  {
+    unsigned short* dact = x1536;                                        // [I, 1536]
+    float* slabs; hipMalloc(&slabs, (size_t)24 * 1536 * 384 * 4);
+    auto dgrad_params = [&](int J, int R) {
+      GemmParams q{};
+      q.A = dact; q.B = w; q.C = y; q.I = I; q.J = J; q.R = R; q.lda = R; q.ldb = J; q.ldc = J;
+      q.a_bytes = (unsigned)((size_t)I * R * 2); q.b_bytes = (unsigned)((size_t)R * J * 2); q.bias = nullptr; q.resid = nullptr; q.pre = nullptr;
+      q.alpha = 1.f; q.alpha_cols = 0; q.act = 0; q.r_per_split = R; q.colsum = nullptr; q.splits_x = 0;
+      q.tiles_i = (I + 127) / 128; q.tiles_j = (J + 127) / 128;
+      return q;
+    };
+    {
+      GemmParams q = dgrad_params(384, 1536);
+      const double fl = 2.0 * I * 384 * 1536, by = 2.0 * I * 1536 + 2.0 * I * 384;
+      timeline("dgrad fc1 (K 1536 -> 384) 128x128 BK32 2-stage", fl, by, [&] { launch<false, true, 0, 32, false, 2>(q, 1, 0); });
+      timeline("dgrad fc1 (K 1536 -> 384) 128x128 BK32 3-stage", fl, by, [&] { launch<false, true, 0, 32, false, 3>(q, 1, 0); });
+      timeline("dgrad fc1 (K 1536 -> 384) 128x128 BK32 4-stage", fl, by, [&] { launch<false, true, 0, 32, false, 4>(q, 1, 0); });
+      timeline("dgrad fc1 (K 1536 -> 384) 128x128 BK64 2-stage", fl, by, [&] { launch<false, true, 0, 64, false, 2>(q, 1, 0); });
+      timeline("dgrad fc1 (K 1536 -> 384) 256x192 BK64 2-stage", fl, by, [&] { launch_wide<false, true, 0, 4, 3, 2, 2, false, 64, 2>(q, 1, 0); });
+    }
+    {
+      GemmParams q = dgrad_params(384, 1152);
+      const double fl = 2.0 * I * 384 * 1152, by = 2.0 * I * 1152 + 2.0 * I * 384;
+      timeline("dgrad qkv (K 1152 -> 384) 128x128 BK32 2-stage", fl, by, [&] { launch<false, true, 0, 32, false, 2>(q, 1, 0); });
+      timeline("dgrad qkv (K 1152 -> 384) 128x128 BK32 4-stage", fl, by, [&] { launch<false, true, 0, 32, false, 4>(q, 1, 0); });
+    }
+    {
+      // wgrad fc1: dW[1536, 384] = dact^T [1536, R] x ln2 [R, 384], 24 R-splits into fp32 slabs
+      GemmParams q{};
+      q.A = dact; q.B = x384; q.C = slabs; q.I = 1536; q.J = 384; q.R = I; q.lda = 1536; q.ldb = 384; q.ldc = 384;
+      q.a_bytes = (unsigned)((size_t)I * 1536 * 2); q.b_bytes = (unsigned)((size_t)I * 384 * 2); q.bias = nullptr; q.resid = nullptr; q.pre = nullptr;
+      q.alpha = 1.f; q.alpha_cols = 0; q.act = 0; q.colsum = nullptr; q.splits_x = 0;
+      q.tiles_i = 12; q.tiles_j = 3;
+      const int splits = dig_gemm_effective_splits(I, 24);
+      q.r_per_split = ((I / 64 + splits - 1) / splits) * 64;
+      const double fl = 2.0 * I * 384 * 1536, by = 2.0 * I * 1536 + 2.0 * I * 384;
+      timeline("wgrad fc1 (1536 x 384, R 65536) 128x128 BK32 2-stage", fl, by, [&] { launch<true, true, 2, 32, false, 2>(q, splits, 0); });
+      timeline("wgrad fc1 (1536 x 384, R 65536) 128x128 BK32 3-stage", fl, by, [&] { launch<true, true, 2, 32, false, 3>(q, splits, 0); });
+      timeline("wgrad fc1 (1536 x 384, R 65536) 128x128 BK32 4-stage", fl, by, [&] { launch<true, true, 2, 32, false, 4>(q, splits, 0); });
+    }
+  }
   return 0;
 }
