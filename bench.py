@@ -34,6 +34,22 @@ PEAK_BF16 = 2.5e15
 PEAK_HBM = 8.0e12                                                      # /opt/skills/guides/MI355X_MICROARCH.md
 
 
+class FreshMaskLoader:
+    """`n` steps over a small set of resident image batches; every step gets a FRESH mask from the device
+    generator of dig_amd.datasets (Philox4x32-10, exactly 179 of 256 per view -- the engine zeroes view 1's mask as the reference does)."""
+
+    def __init__(self, batches, n, gen):
+        self.batches, self.n, self.gen = batches, n, gen
+
+    def __len__(self):
+        return self.n
+
+    def __iter__(self):
+        for i in range(self.n):
+            (im, au, _), a, b = self.batches[i % len(self.batches)]
+            yield ([im, au, self.gen(im.shape[0]).to(torch.float64)], a, b)
+
+
 def synth_batches(n, B, device, seed):
     """U(-1,1) crops from Generator(seed), RandomMaskingGenerator((8,32), 0.7, num_view=2) masks."""
     g = torch.Generator().manual_seed(seed)
@@ -70,14 +86,15 @@ class GemmProbe:
             out = self._orig(A, B, I, J, R, **kw)
             e1.record()
             variant = ("wgrad" if kw.get("ta") else ("dgrad" if kw.get("tb") else "fwd"))
-            # algorithmic HBM bytes of the launch: both operands once, every output / residual / saved pre-activation once
-            # (weight gradients: fp32 read-modify-write of dW; the split-R slabs are implementation traffic, not counted)
+            # algorithmic HBM bytes of the launch: both operands once, the output and the residual once (weight gradients: fp32
+            # read-modify-write of dW).  NOT counted: the saved pre-activation of fc1 (an implementation choice of the backward),
+            # the split-R slabs
             byt = 2.0 * I * R + 2.0 * J * R
             if kw.get("ta"):
                 byt += 8.0 * I * J
             else:
                 byt += I * J * (4.0 if kw.get("out_kind") == ops.OUT_F32 else 2.0)
-                byt += 2.0 * I * J * ((kw.get("pre") is not None) + (kw.get("resid") is not None))
+                byt += 2.0 * I * J * (kw.get("resid") is not None)
             self.rec.append((variant, 2.0 * I * J * R, byt, e0, e1))
             return out
         ops.gemm = timed
@@ -118,7 +135,15 @@ def cpu_baseline(model_name, budget_s=20.0):
         dt = time.perf_counter() - t0
         if dt > budget_s or n >= 8:
             break
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_model = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "unknown")
+    except OSError:
+        pass
     return {"value": n * Bc / dt, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "host_cpu": cpu_model, "host_logical_cpus": os.cpu_count(),
+            "threads_note": "16 torch threads: the best of 8/16/32/64/128 on this host class (tools/cpu_baseline_threads.py; more threads are slower)",
             "sample": f"{n} oracle steps (fp32 torch CPU restatement of the reference step) at batch {Bc}, same model/recipe"}
 
 
@@ -175,8 +200,11 @@ def main():
     lr_s, wd_s = np.full(total + 8, args.lr), np.full(total + 8, 0.1)
     batches = synth_batches(4, B, dev, 1234 + rank)
 
+    from dig_amd.datasets import RandomMaskingGenerator
+    mask_gen = RandomMaskingGenerator((8, 32), 0.7, num_view=2, seed=1234 + rank, device=dev)
+
     def run(n, start):
-        loader = [batches[i % len(batches)] for i in range(n)]
+        loader = FreshMaskLoader(batches, n, mask_gen)
         return train_one_epoch(run_model, None, None, loader, None, opt, dev, 0, scaler, None, patch_size=4, normlize_target=False,
                                start_steps=start, lr_schedule_values=lr_s, wd_schedule_values=wd_s, args=args)
 
@@ -233,19 +261,30 @@ def main():
         d = summ[dom]
         tf = d["flops"] / d["seconds"] / 1e12
         gbs = d["bytes"] / d["seconds"] / 1e9
-        traffic = None
-        try:                                   # HBM bytes per launch from the committed PMC profile of this same command
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-                traffic = json.load(f)["kernels"][dom]["hbm_bytes_per_launch"]
+        # HBM bytes per launch: rocprofv3 --pmc passes (FETCH_SIZE x2 per the gfx950 correction, WRITE_SIZE) over this same command,
+        # collected with tools/collect_pmc.sh and committed with the hash of the library they were measured on; reported only while
+        # that hash still matches the library this run loaded
+        traffic, traffic_src = None, None
+        try:
+            import hashlib
+            from dig_amd import _lib
+            with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
+                tj = json.load(f)
+            with open(_lib.LIB_PATH, "rb") as f:
+                lib_hash = hashlib.sha256(f.read()).hexdigest()[:16]
+            if tj.get("lib_sha256_16") == lib_hash:
+                traffic = tj["kernels"][dom]["hbm_bytes_per_launch"]
+                traffic_src = f"profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE, library {lib_hash})"
+            else:
+                traffic_src = f"profiles/r02_pmc_traffic.json was collected on library {tj.get('lib_sha256_16')}, this run loaded {lib_hash}: not reported"
         except Exception:
             pass
-        # which roof binds this kernel family: the larger of (FLOPs / MFMA peak) and (algorithmic bytes / HBM peak)
-        hbm_bound = d["bytes"] / PEAK_HBM > d["flops"] / PEAK_BF16
+        # the bounding roofline of this path is bf16 MFMA; the HBM view of the same launches is kept beside it
         mfma_view = {"achieved": tf, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": tf / (PEAK_BF16 / 1e12)}
         hbm_view = {"achieved": gbs, "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": gbs / (PEAK_HBM / 1e9)}
-        roof = {"bound": "hbm" if hbm_bound else "mfma", **(hbm_view if hbm_bound else mfma_view), "traffic": traffic,
-                "kernel": f"dig_gemm_bf16[{dom}] (gemm_kernel / gemm_wide_kernel, v_mfma_f32_32x32x16_bf16, fused bias/GELU/residual epilogues)",
-                "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 gfx950 correction)" if traffic else None,
+        roof = {"bound": "mfma", **mfma_view, "traffic": traffic,
+                "kernel": f"dig_gemm_bf16[{dom}] (gemm_kernel / gemm_wide_kernel / gemm_pwide_kernel, v_mfma_f32_32x32x16_bf16, fused bias/GELU/residual epilogues)",
+                "traffic_source": traffic_src,
                 "mfma": mfma_view, "hbm": hbm_view,
                 "flops_per_launch": d["flops"] / d["launches"], "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
                 "avg_launch_us": d["seconds"] / d["launches"] * 1e6, "launches_per_step": d["launches"] // 2,

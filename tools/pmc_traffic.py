@@ -7,6 +7,8 @@ import csv, json, re, sys, collections
 
 
 def family(name):
+    if "gemm_pwide_kernel" in name:
+        return "fwd"
     m = re.search(r"gemm(?:_wide|_persist)?_kernel<(true|false), (true|false)", name)
     if m:
         return {"falsefalse": "fwd", "falsetrue": "dgrad", "truetrue": "wgrad"}.get(m.group(1) + m.group(2), "gemm_other")
