@@ -51,6 +51,40 @@ def stream():
 
 
 _fns = {}
+_protos = None
+_HEADER = os.path.join(os.path.dirname(_HERE), "include", "dig_hip.h")
+_SCALARS = {"int": ctypes.c_int, "unsigned": ctypes.c_uint, "unsigned int": ctypes.c_uint, "float": ctypes.c_float,
+            "long long": ctypes.c_longlong, "unsigned long long": ctypes.c_ulonglong, "hipStream_t": ctypes.c_void_p}
+
+
+def _prototypes():
+    """{function name: [ctypes argument types]} parsed from include/dig_hip.h -- the header IS the contract, so the binding takes its
+    argument types from it: every `long long` parameter is passed as 64 bits whatever the call site wrapped it in, floats are converted,
+    a wrong argument count fails in Python instead of reading garbage off the stack."""
+    global _protos
+    if _protos is None:
+        import re
+        _protos = {}
+        try:
+            with open(_HEADER) as f:
+                text = re.sub(r"/\*.*?\*/", " ", f.read(), flags=re.S)
+        except OSError:
+            return _protos                                    # header not shipped next to the package: untyped calls, as before
+        for m in re.finditer(r"\b(?:int|long long)\s+(dig_\w+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+            types = []
+            for prm in m.group(2).split(","):
+                prm = " ".join(prm.split())
+                if "*" in prm:
+                    types.append(ctypes.c_void_p)
+                    continue
+                ty = " ".join(w for w in prm.split()[:-1] if w != "const")
+                if ty not in _SCALARS:
+                    types = None
+                    break
+                types.append(_SCALARS[ty])
+            if types is not None:
+                _protos[m.group(1)] = types
+    return _protos
 
 
 def call(name, *args):
@@ -58,6 +92,9 @@ def call(name, *args):
     if f is None:
         f = getattr(lib(), name)
         f.restype = ctypes.c_int
+        at = _prototypes().get(name)
+        if at is not None:
+            f.argtypes = at
         _fns[name] = f
     rc = f(*args)
     if rc:

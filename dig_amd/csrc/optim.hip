@@ -17,7 +17,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
                                                     float* __restrict__ v, bf16_t* __restrict__ shadow, long long n4,
                                                     const unsigned char* __restrict__ group, float lr0, float wd0, float lr1,
                                                     float wd1, float beta1, float beta2, float eps, float inv_bc1,
-                                                    float inv_sqrt_bc2, float grad_scale) {
+                                                    float inv_sqrt_bc2, float grad_scale, const float* __restrict__ finite_gate) {
+  if (finite_gate && !isfinite(finite_gate[0])) return;                 // non-finite gradients: the whole update is a no-op (GradScaler's inf-skip)
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
     const int grp = group[i >> 6];
     const float lr = grp ? lr1 : lr0, wd = grp ? wd1 : wd0;
@@ -50,7 +51,8 @@ __global__ __launch_bounds__(256) void adamw_groups_kernel(float* __restrict__ p
                                                            float* __restrict__ v, bf16_t* __restrict__ shadow, long long n4,
                                                            const unsigned char* __restrict__ group_idx, const float* __restrict__ lr_tab,
                                                            const float* __restrict__ wd_tab, float beta1, float beta2, float eps, float inv_bc1,
-                                                           float inv_sqrt_bc2, float grad_scale) {
+                                                           float inv_sqrt_bc2, float grad_scale, const float* __restrict__ finite_gate) {
+  if (finite_gate && !isfinite(finite_gate[0])) return;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
     const int grp = group_idx[i >> 6];
     float4 pp = reinterpret_cast<float4*>(p)[i];
@@ -165,25 +167,25 @@ inline int flat_grid(long long n4) { return (int)std::min<long long>(4096, (n4 +
 
 extern "C" int dig_adamw_step(float* p, const float* g, float* m, float* v, void* bf16_shadow, long long n,
                               const unsigned char* group_flags, float lr0, float wd0, float lr1, float wd1, float beta1,
-                              float beta2, float eps, int step, float grad_scale, hipStream_t stream) {
+                              float beta2, float eps, int step, float grad_scale, const float* finite_gate, hipStream_t stream) {
   if (!p || !g || !m || !v || !group_flags || n <= 0 || (n & 255) || step < 1) return DIG_ERR_ARG;
   if (!aligned16(p) || !aligned16(g) || !aligned16(m) || !aligned16(v) || (bf16_shadow && (((uintptr_t)bf16_shadow) & 7))) return DIG_ERR_ALIGN;
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
   hipLaunchKernelGGL(adamw_kernel, dim3(flat_grid(n / 4)), dim3(256), 0, stream, p, g, m, v, (bf16_t*)bf16_shadow, n / 4,
-                     group_flags, lr0, wd0, lr1, wd1, beta1, beta2, eps, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)), grad_scale);
+                     group_flags, lr0, wd0, lr1, wd1, beta1, beta2, eps, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)), grad_scale, finite_gate);
   return dig_check_launch();
 }
 
 extern "C" int dig_adamw_step_groups(float* p, const float* g, float* m, float* v, void* bf16_shadow, long long n,
                                      const unsigned char* group_idx, const float* lr_tab, const float* wd_tab, float beta1, float beta2,
-                                     float eps, int step, float grad_scale, hipStream_t stream) {
+                                     float eps, int step, float grad_scale, const float* finite_gate, hipStream_t stream) {
   if (!p || !g || !m || !v || !group_idx || !lr_tab || !wd_tab || n <= 0 || (n & 255) || step < 1) return DIG_ERR_ARG;
   if (!aligned16(p) || !aligned16(g) || !aligned16(m) || !aligned16(v) || (bf16_shadow && (((uintptr_t)bf16_shadow) & 7))) return DIG_ERR_ALIGN;
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
   hipLaunchKernelGGL(adamw_groups_kernel, dim3(flat_grid(n / 4)), dim3(256), 0, stream, p, g, m, v, (bf16_t*)bf16_shadow, n / 4, group_idx,
-                     lr_tab, wd_tab, beta1, beta2, eps, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)), grad_scale);
+                     lr_tab, wd_tab, beta1, beta2, eps, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)), grad_scale, finite_gate);
   return dig_check_launch();
 }
 

@@ -73,7 +73,8 @@ class _StepReadback:
                 loss_value = float('nan')
             if host[7] != host[8] or int(host[7]) != self.core._per_sample_mask:
                 raise RuntimeError("masks must select the same number of tokens in every sample "
-                                   f"(got {int(host[7])}..{int(host[8])}, expected {self.core._per_sample_mask})")
+                                   f"(got {int(host[7])}..{int(host[8])}, expected {self.core._per_sample_mask}; after a deliberate change "
+                                   "of the mask ratio call model.reset_mask_count())")
             if not math.isfinite(loss_value):
                 print("Loss is {}, stopping training".format(loss_value))
                 sys.exit(1)

@@ -142,6 +142,7 @@ class RecModelTrain(RecModel):
             if k in state_dict:
                 self._view(self.flat_params, k).copy_(self._sd[k])
         self._ready = False
+        self.weights_changed()
 
     def state_dict(self, *a, **k):
         return OrderedDict((n, self._view(self.flat_params, n).detach().cpu().clone()) for n in self._offsets)
@@ -185,6 +186,7 @@ class RecModelTrain(RecModel):
             self.flat_params = self.flat_params.to(dev)
             self.flat_grads = self.flat_grads.to(dev)
             self._ready = False
+            self.weights_changed()
         return self
 
     def _prepare_train(self, dev):
@@ -210,11 +212,22 @@ class RecModelTrain(RecModel):
         o, n, s = self._offsets[first]
         return flat[o:o + count * n].view(count * s[0], s[1])
 
-    def sync_eval_weights(self):
-        """Copy the arena back into the inference path's tensors (used by `.eval()` forward / checkpoints)."""
+    def weights_changed(self):
+        """Whoever writes the flat parameter arena (FineTuneAdamW.step, load_state_dict, ModelEma.update, .to) bumps this counter;
+        the eval forward re-syncs its tensors, re-packs the bf16 operands and re-captures the decode HIP graph only when it moved."""
+        self._weights_version = getattr(self, "_weights_version", 0) + 1
+
+    def sync_eval_weights(self, force=False):
+        """Copy the arena back into the inference path's tensors (used by `.eval()` forward / checkpoints) -- once per weight
+        version: `evaluate()` calls the eval forward for every batch, and a sync per call meant a full weight copy, a repack and a
+        HIP-graph capture per batch."""
+        ver = getattr(self, "_weights_version", 0)
+        if not force and getattr(self, "_synced_version", None) == ver:
+            return
         for k in self._offsets:
             self._sd[k] = self._view(self.flat_params, k).detach().clone()
         self._ready = False
+        self._synced_version = ver
 
     # ------------------------------------------------------------------ forward
     def forward(self, x):
@@ -253,6 +266,7 @@ class ModelEma:
         self.ema._ready = False
         self.ema._graphs = {}                                                  # (its own HIP-graph cache: the copy above is shallow)
         self.ema._sd = OrderedDict((k, v.clone()) for k, v in model._sd.items())
+        self.ema._weights_version, self.ema._synced_version = 0, None
         self.ema.train(False)
 
     def update(self, model):
@@ -263,7 +277,7 @@ class ModelEma:
             ops.ema_update(e.flat_params, model.flat_params, None, e.flat_params.numel(), self.decay)
         else:
             e.flat_params.mul_(self.decay).add_(model.flat_params, alpha=1.0 - self.decay)
-        e._ready = False
+        e.weights_changed()
 
 
 class FlatGradComm:
@@ -786,7 +800,7 @@ class FineTuneAdamW:
         self._tab_dev = dev
 
     @torch.no_grad()
-    def step(self, closure=None, grad_scale: float = 1.0):
+    def step(self, closure=None, grad_scale: float = 1.0, finite_gate=None):
         self._tables()
         M = self.model
         ng = len(self.param_groups)
@@ -800,7 +814,8 @@ class FineTuneAdamW:
         self._step += 1
         L.call("dig_adamw_step_groups", L.ptr(M.flat_params), L.ptr(M.flat_grads), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq), None,
                ctypes.c_longlong(M.n_flat), L.ptr(self._idx), L.ptr(self._dev_tab[0]), L.ptr(self._dev_tab[1]), cf(g0["betas"][0]),
-               cf(g0["betas"][1]), cf(g0["eps"]), self._step, cf(grad_scale), L.stream())
+               cf(g0["betas"][1]), cf(g0["eps"]), self._step, cf(grad_scale), L.ptr(finite_gate), L.stream())
+        M.weights_changed()
 
 
     # ---- checkpoints: torch.optim's per-parameter layout (what utils.save_model / auto_load_model exchange, utils/utils.py:546-651)

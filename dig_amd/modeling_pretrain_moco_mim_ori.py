@@ -103,6 +103,11 @@ class MoCo_ViT(nn.Module):
         self.N = self.gh * self.gw
         self.T = T
         self.num_windows = num_windows
+        if (img_size[1] // patch_size) % num_windows:
+            # the reference pools with adaptive_avg_pool2d, which also takes uneven windows (its argparse default of 5 on a 32-column grid);
+            # the pooling kernel here covers the README recipe (num_windows 4): equal windows only -- say so at construction
+            raise NotImplementedError(f"num_windows={num_windows} does not divide the {img_size[1] // patch_size}-column token grid: "
+                                      "dig_window_pool_fwd / _bwd pool equal windows (README: --num_windows 4)")
         self.dec_dim, self.dec_classes = decoder_embed_dim, decoder_num_classes
         self.moco_dim, self.moco_mlp_dim = dim, mlp_dim
         self.ln_eps, self.bn_eps, self.bn_momentum = 1e-6, 1e-5, 0.1
@@ -394,9 +399,15 @@ class MoCo_ViT(nn.Module):
         """Masked tokens per sample of view 0 (the reference reshapes to [B, -1, C], so it is constant over the
         batch).  Read back once and cached: per-step validation happens where the engine synchronises anyway."""
         c = getattr(self, "_per_sample_mask", None)
-        if c is None:
+        if c is None or getattr(self, "_per_sample_mask_n", None) != mask_u8.shape[1]:
             c = self._per_sample_mask = int(mask_u8[0].sum().item())
+            self._per_sample_mask_n = mask_u8.shape[1]
         return c
+
+    def reset_mask_count(self):
+        """Forget the cached number of masked tokens per sample: call when the masking ratio of the data pipeline changes (the next
+        forward reads it back once).  Without it a changed ratio is caught by the engine's read-back, one step late, as an error."""
+        self._per_sample_mask = None
 
     # ------------------------------------------------------------------ forward
     def forward(self, image, aug_image, vis_mask_pos, m, only_mim_on_ori_img=True):
@@ -414,7 +425,7 @@ def _factory(embed_dim, heads, **kwargs):
     model.default_cfg = {'url': '', 'num_classes': 1000, 'input_size': (3, 32, 128), 'pool_size': None, 'crop_pct': 1.0,
                          'interpolation': 'bicubic', 'mean': (0.5, 0.5, 0.5), 'std': (0.5, 0.5, 0.5)}
     if init_ckpt:
-        model.load_state_dict(torch.load(init_ckpt, map_location="cpu")["model"])
+        model.load_state_dict(torch.load(init_ckpt, map_location="cpu", weights_only=False)["model"])   # reference checkpoints carry an argparse.Namespace
     return model
 
 

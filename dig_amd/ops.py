@@ -378,6 +378,6 @@ def sumsq(x, workspace, out):
     L.call("dig_sumsq", L.ptr(x), cll(x.numel()), L.ptr(workspace), L.ptr(out), L.stream())
 
 
-def adamw_step(p, g, m, v, shadow, group_flags, lr0, wd0, lr1, wd1, beta1, beta2, eps, step, grad_scale=1.0):
+def adamw_step(p, g, m, v, shadow, group_flags, lr0, wd0, lr1, wd1, beta1, beta2, eps, step, grad_scale=1.0, finite_gate=None):
     L.call("dig_adamw_step", L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), L.ptr(shadow), cll(p.numel()), L.ptr(group_flags), cf(lr0),
-           cf(wd0), cf(lr1), cf(wd1), cf(beta1), cf(beta2), cf(eps), int(step), cf(grad_scale), L.stream())
+           cf(wd0), cf(lr1), cf(wd1), cf(beta1), cf(beta2), cf(eps), int(step), cf(grad_scale), L.ptr(finite_gate), L.stream())

@@ -61,14 +61,15 @@ class FusedAdamW(torch.optim.Optimizer):
             g.zero_()
 
     @torch.no_grad()
-    def step(self, closure=None, grad_scale: float = 1.0):
+    def step(self, closure=None, grad_scale: float = 1.0, finite_gate=None):
+        """finite_gate: device float (the squared gradient norm); a non-finite value turns the launch into a no-op."""
         self._bind()
         g0, g1 = self.param_groups
         b1, b2 = g0["betas"]
         self._step += 1
         M = self.model
         ops.adamw_step(M.flat_params, M.flat_grads, self.exp_avg, self.exp_avg_sq, None, M.flat_groups,
-                       g0["lr"], g0["weight_decay"], g1["lr"], g1["weight_decay"], b1, b2, g0["eps"], self._step, grad_scale)
+                       g0["lr"], g0["weight_decay"], g1["lr"], g1["weight_decay"], b1, b2, g0["eps"], self._step, grad_scale, finite_gate)
 
     # ---- checkpoint format: the reference's torch-Optimizer layout (custom_optim/optimizer.py state_dict):
     #   {'state': {i: {'step', 'exp_avg', 'exp_avg_sq'}}, 'param_groups': [{..., 'params': [i, ...]}, ...]}

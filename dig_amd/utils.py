@@ -107,7 +107,9 @@ class NativeScalerWithGradNormCount:
         if clip_grad is not None and clip_grad > 0:
             # clip_grad_norm_ semantics: scale by min(1, max_norm / (norm + 1e-6)); one host read, as in torch
             scale = min(1.0, float(clip_grad) / (float(norm) + 1e-6))
-        optimizer.step(grad_scale=scale)
+        # the squared norm doubles as the update's gate: after a non-finite loss the optimizer launch changes nothing (GradScaler's
+        # inf-skip, utils/utils.py:498-504), so the weights a caller sees after the late `sys.exit(1)` of the engine are the last good ones
+        optimizer.step(grad_scale=scale, finite_gate=model._norm_ws[1024:])
         return norm
 
     def state_dict(self):

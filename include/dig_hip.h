@@ -169,19 +169,21 @@ int dig_ce_rows(float* logits, int n, int m, int label_offset, float gscale, flo
  * modeling_pretrain_moco_mim_ori.py:428-442; grad norm utils/utils.py:507-519).
  *   dig_adamw_step: group_flags[i / 256] in {0,1} selects (lr0, wd0) or (lr1, wd1) for element i (parameters are padded
  *                   to 256 elements); step >= 1 is the Adam step count; grad_scale multiplies g (clipping / averaging);
- *                   bf16_shadow (optional) receives the updated parameters in bf16.
+ *                   bf16_shadow (optional) receives the updated parameters in bf16;  finite_gate (optional): a device float --
+ *                   when it is not finite (the squared gradient norm of dig_sumsq after a NaN / Inf loss) the launch changes
+ *                   nothing, as torch's GradScaler skips optimizer.step() on inf / nan gradients (utils/utils.py:498-504).
  *   dig_ema_update: pm = pm*m + p*(1-m); bf16_shadow (optional) receives pm in bf16.
  *   dig_sumsq:      out[0] = sum x^2 (two-stage, deterministic); workspace: dig_sumsq_workspace_bytes.
  */
 int dig_adamw_step(float* p, const float* g, float* m, float* v, void* bf16_shadow, long long n, const unsigned char* group_flags,
                    float lr0, float wd0, float lr1, float wd1, float beta1, float beta2, float eps, int step, float grad_scale,
-                   hipStream_t stream);
+                   const float* finite_gate, hipStream_t stream);
 /* Same update with any number of parameter groups (layer-wise lr decay: optim_factory.py:33-100, run_class_finetuning.py:471-520):
  * group_idx holds one uint8 per 256-element granule indexing the device tables lr_tab / wd_tab; index 255 = granule without a
  * gradient, left untouched (the reference's AdamW skips p.grad is None). */
 int dig_adamw_step_groups(float* p, const float* g, float* m, float* v, void* bf16_shadow, long long n, const unsigned char* group_idx,
                           const float* lr_tab, const float* wd_tab, float beta1, float beta2, float eps, int step, float grad_scale,
-                          hipStream_t stream);
+                          const float* finite_gate, hipStream_t stream);
 int dig_ema_update(float* pm, const float* p, void* bf16_shadow, long long n, float m, hipStream_t stream);
 long long dig_sumsq_workspace_bytes(long long n);
 int dig_sumsq(const float* x, long long n, float* workspace, float* out, hipStream_t stream);

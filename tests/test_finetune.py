@@ -816,6 +816,58 @@ def test_full_size_finetune_step_vs_oracle():
 
 
 @pytest.mark.gpu
+def test_full_size_b256_finetune_properties():
+    """BASELINE.json configs[4] at its full per-GPU size (simmim_vit_small_patch4_32x128 + tf_decoder, 97 classes, 25 positions,
+    B = 256 = 65 536 encoder token rows), README drop rates: size-independent properties of the training step -- finite loss and
+    gradients for every parameter, the step is reproducible from (seed, step) (keyed dropout masks, deterministic reductions), the
+    loss of a repeated batch goes down, and greedy decoding of that batch in eval mode returns [B, 25] tokens."""
+    import types
+    from dig_amd.finetune import RecModelTrain, SeqCrossEntropyLoss, create_optimizer
+    ecfg = O.make_config("pretrain_simmim_moco_ori_vit_small_patch4_32x128")
+    c = D.DecoderConfig()
+    P = {**D.det_encoder_state(ecfg, 82), **D.det_decoder_state(c, 83)}
+    B = 256
+    images = O.synthetic_batch(B, ecfg, 8282)[0].to("cuda:0")
+    tg, lens = _full_batch(B, c.max_seq_len, 11)
+    args = types.SimpleNamespace(model="simmim_vit_small_patch4_32x128", decoder_name="tf_decoder", nb_classes=97, max_len=25, drop=0.1,
+                                 attn_drop_rate=0.1, drop_path=0.1, opt="adamw", lr=1e-4, weight_decay=0.05, opt_eps=1e-8, opt_betas=None,
+                                 layer_decay=0.75)
+    crit = SeqCrossEntropyLoss()
+
+    def one_model():
+        m = RecModelTrain(args, decoder_dropout=0.1)
+        m.load_state_dict(P); m.to("cuda:0"); m.train()
+        return m
+
+    def step_loss(m):
+        for p in m.parameters():
+            p.grad.zero_()
+        loss = crit(m((images, tg, lens))[0], tg, lens)
+        loss.backward()
+        return loss
+
+    m1, m2 = one_model(), one_model()
+    l1, l2 = step_loss(m1), step_loss(m2)
+    assert torch.isfinite(l1) and float(l1) == float(l2)
+    for (n, p), (_, q) in zip(m1.named_parameters(), m2.named_parameters()):
+        assert torch.isfinite(p.grad).all(), n
+        assert torch.equal(p.grad, q.grad), n
+    del m2
+    opt = create_optimizer(args, m1)
+    losses = []
+    for _ in range(4):
+        loss = step_loss(m1)
+        opt.step()
+        losses.append(float(loss))
+    assert losses[-1] < losses[0], losses
+    m1.eval()
+    with torch.no_grad():
+        out = m1((images, tg, lens))
+    pred = out[0] if isinstance(out, (tuple, list)) else out
+    assert pred.shape[0] == B and pred.shape[1] == c.max_seq_len
+
+
+@pytest.mark.gpu
 def test_full_size_gru_attention_step_vs_oracle():
     """simmim_vit_small_patch4_32x128 + AttentionRecognitionHead (sDim = attDim = 512) at B = 32: loss, logits, gradients per block."""
     import types

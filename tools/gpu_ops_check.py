@@ -190,7 +190,7 @@ p = torch.randn(n, device=dev); g = torch.randn(n, device=dev) * 1e-2; m = torch
 p0, m0, v0 = p.clone(), m.clone(), v.clone()
 sh = torch.empty(n, device=dev, dtype=torch.bfloat16)
 segb = (ctypes.c_longlong * 2)(0, n // 2); sege = (ctypes.c_longlong * 2)(n // 2, n); segw = (ctypes.c_float * 2)(0.1, 0.0)
-L.call("dig_adamw_step", L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), L.ptr(sh), ctypes.c_longlong(n), 2, segb, sege, segw, cf(1e-3), cf(0.9), cf(0.999), cf(1e-8), 3, cf(1.0), L.stream())
+L.call("dig_adamw_step", L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), L.ptr(sh), ctypes.c_longlong(n), 2, segb, sege, segw, cf(1e-3), cf(0.9), cf(0.999), cf(1e-8), 3, cf(1.0), None, L.stream())
 import math
 rp = p0.clone(); rp[: n // 2] *= (1 - 1e-3 * 0.1)
 rm = m0 * 0.9 + g * 0.1; rv = v0 * 0.999 + g * g * 0.001
