@@ -291,13 +291,18 @@ def main():
                 "by_variant": {k: {"TFLOP/s": v["flops"] / v["seconds"] / 1e12, "GB/s": v["bytes"] / v["seconds"] / 1e9,
                                    "ms_per_step": v["seconds"] / 2 * 1e3, "launches_per_step": v["launches"] // 2}
                                for k, v in summ.items()}}
-    sys.stdout.flush()
-    sys.stderr.flush()
-    os.dup2(saved_fd1, 1)
-    sys.stdout = stdout
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+    sys.stdout.flush()
+    sys.stderr.flush()
+    try:                                   # RCCL prints its banner through C stdio: its buffer must drain while fd 1 still points at stderr,
+        import ctypes                      # or the banner lands on the real stdout behind the JSON line at exit
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    os.dup2(saved_fd1, 1)
+    sys.stdout = stdout
     if rank != 0:
         return
     value = a.steps * B * world / dt

@@ -294,8 +294,8 @@ class FlatGradComm:
         model.drop_seed = (int(model.drop_seed) + 0x9E3779B97F4A7C15 * self.rank) & ((1 << 64) - 1)
 
     def finish_grad_sync(self, model):
+        # (the mean: the scaler seeds every backward with loss / world, see parallel.DistComm.finish_grad_sync)
         self.dist.all_reduce(model.flat_grads, group=self.group)
-        ops.scale_f32(model.flat_grads, 1.0 / self.world) if model.flat_grads.is_cuda else model.flat_grads.mul_(1.0 / self.world)
 
 
 class _TrainStep:

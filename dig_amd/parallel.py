@@ -9,6 +9,7 @@ Replaces the reference's SyncBatchNorm.convert + DistributedDataParallel pair (r
     kernels (SyncBN semantics: statistics over the global batch);
   * MoCo keys are all-gathered once per step as a single [2, 4B, dim] message (the reference gathers k1 and k2
     separately, modeling_pretrain_moco_mim_ori.py:551-552,580-591);
+  * the mean over ranks is taken by seeding the backward with loss / world (utils.NativeScalerWithGradNormCount): no scaling pass;
   * parameters / buffers are broadcast from rank 0 at construction (what DDP's constructor does).
 """
 import torch
@@ -41,18 +42,12 @@ class DistComm:
         self._pending.append((dist.all_reduce(g, group=self.group, async_op=True), g))
 
     def finish_grad_sync(self, model):
-        """Wait for the outstanding bucket all-reduces; the 1/world averaging is folded into the optimizer's
-        grad_scale-free path by scaling here once (flat kernel)."""
-        from . import ops
-        if not self._pending:
-            return
+        """Wait for the outstanding bucket all-reduces.  The 1/world averaging costs nothing: NativeScalerWithGradNormCount seeds the
+        backward with loss / world, so every rank's gradients arrive pre-divided and the SUM all-reduce is the mean (a power-of-two
+        scale commutes with every rounding on the way: bit-identical to scaling the 174 MB arena afterwards, minus that pass)."""
         for work, _ in self._pending:
             work.wait()
         self._pending = []
-        if model.flat_grads.is_cuda:
-            ops.scale_f32(model.flat_grads, 1.0 / self.world)
-        else:
-            model.flat_grads.mul_(1.0 / self.world)
 
 
 class DistributedDataParallel(torch.nn.Module):

@@ -95,11 +95,13 @@ class NativeScalerWithGradNormCount:
     state_dict_key = "amp_scaler"
 
     def __call__(self, loss, optimizer, clip_grad=None, parameters=None, create_graph=False, update_grad=True):
-        loss.backward(create_graph=create_graph)
-        if not update_grad:
-            return None
         model = optimizer.model
         comm = getattr(model, "comm", None)
+        world = getattr(comm, "world", 1) if comm is not None else 1
+        # data parallel: the backward is seeded with loss / world, so the SUM all-reduce of the gradient arena is DDP's mean
+        (loss * (1.0 / world) if world > 1 else loss).backward(create_graph=create_graph)
+        if not update_grad:
+            return None
         if comm is not None:
             comm.finish_grad_sync(model)
         norm = get_grad_norm_(model=model)

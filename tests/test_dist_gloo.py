@@ -82,7 +82,8 @@ def _comm_worker(rank, world, port, q):
         assert torch.equal(ref, m.flat_params)
         if rank != 0:
             assert not torch.equal(before, m.flat_params)
-        # bucketed gradient all-reduce in backward order + averaging == mean over ranks of the whole arena
+        # bucketed gradient all-reduce in backward order == SUM over ranks of the whole arena (the mean comes from seeding the backward
+        # with loss / world in NativeScalerWithGradNormCount: the engine tests below check the averaged result against DDP fixtures)
         gen = torch.Generator().manual_seed(7 + rank)
         m.flat_grads.copy_(torch.randn(m.flat_grads.shape, generator=gen))
         mine = m.flat_grads.clone()
@@ -91,7 +92,7 @@ def _comm_worker(rank, world, port, q):
         m.comm.finish_grad_sync(m)
         tot = mine.clone()
         dist.all_reduce(tot)
-        torch.testing.assert_close(m.flat_grads, tot / world, rtol=1e-6, atol=1e-7)
+        torch.testing.assert_close(m.flat_grads, tot, rtol=1e-6, atol=1e-7)
         # key all-gather: rank order, one message for (k1, k2)
         k = torch.full((1, 2, 3, 4), float(rank))
         k[0, 1] += 0.5
@@ -231,7 +232,7 @@ def _ft_comm_worker(rank, world, port, q):
         tot = m.flat_grads.clone()
         dist.all_reduce(tot)
         comm.finish_grad_sync(m)
-        torch.testing.assert_close(m.flat_grads, tot / world, rtol=1e-6, atol=1e-7)
+        torch.testing.assert_close(m.flat_grads, tot, rtol=1e-6, atol=1e-7)
         seeds = [None] * world
         dist.all_gather_object(seeds, m.drop_seed)
         assert len(set(seeds)) == world and seeds[0] == 5
