@@ -55,7 +55,7 @@ __global__ __launch_bounds__(64) void self_attn_kernel(const bf16_t* __restrict_
 // thread its own row and ran at 1.8 TB/s).  Scores: partial dot over the lane's 8 channels + 3 shuffles.  Values: each lane
 // accumulates its 8 channels over its key slot's keys, then shuffles / LDS combine the 32 slots.
 __global__ __launch_bounds__(256) void cross_attn_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kv, bf16_t* __restrict__ out,
-                                                         float* __restrict__ weights, int Nm, int hk, float scale) {
+                                                         float* __restrict__ weights, int Nm, int hk, float scale, int slots_per_mem) {
   extern __shared__ float sm[];                                        // [Nm] scores / probabilities, then [4][64] partial outputs
   __shared__ float red[8];
   const int b = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, H = gridDim.y;
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void cross_attn_kernel(const bf16_t* __restric
 #pragma unroll
     for (int e = 0; e < 4; ++e) { qv[2 * e] = bf2f((bf16_t)(w[e] & 0xffff)) * scale; qv[2 * e + 1] = bf2f((bf16_t)(w[e] >> 16)) * scale; }
   }
-  const bf16_t* kb = kv + (size_t)b * Nm * 2 * hk + h * DK + chunk * 8;
+  const bf16_t* kb = kv + (size_t)(b / slots_per_mem) * Nm * 2 * hk + h * DK + chunk * 8;   // beam search: `slots_per_mem` queries share a memory
   float lmax = -INFINITY;
   for (int j = slot; j < Nm; j += 32) {
     const uint4 v = *reinterpret_cast<const uint4*>(kb + (size_t)j * 2 * hk);
@@ -141,6 +141,64 @@ __global__ __launch_bounds__(64) void softmax_argmax_kernel(const float* __restr
   const float inv = 1.f / s;
   for (int c = lane; c < C; c += 64) probs[(size_t)b * C + c] = __expf(row[c] - m) * inv;
   if (lane == 0) token[b] = am;
+}
+
+// One step of TFDecoder.beam_search (decoder.py:283-307) for one sample: log-softmax of its `bw` slots' logits, + the slots' running
+// scores, top-`bw` of the bw*C candidates (ties: the lower candidate index, i.e. torch.topk's result wherever it is defined), then the
+// bookkeeping of that step: symbol = candidate % C, predecessor = candidate / C + b*bw, stored score, and the running score that
+// the next step starts from (-inf once a slot has emitted EOS, :299-301).  One 256-thread workgroup per sample; bw <= 16.
+__global__ __launch_bounds__(256) void beam_step_kernel(const float* __restrict__ logits, int ld, float* __restrict__ seq_scores, int bw, int C,
+                                                        int eos, long long* __restrict__ symbols, long long* __restrict__ preds,
+                                                        float* __restrict__ stored) {
+  extern __shared__ float cand[];                                       // [bw * C]
+  __shared__ float lse[16];
+  __shared__ float rv[4];
+  __shared__ int ri[4];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int k = wave; k < bw; k += 4) {                                   // a wave per slot: log-sum-exp of the row
+    const float* row = logits + (size_t)(b * bw + k) * ld;
+    float m = -INFINITY;
+    for (int c = lane; c < C; c += 64) m = fmaxf(m, row[c]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += __expf(row[c] - m);
+    s = wave_sum(s);
+    if (lane == 0) lse[k] = m + __logf(s);
+  }
+  __syncthreads();
+  const int n = bw * C;
+  for (int i = tid; i < n; i += 256) {
+    const int k = i / C, c = i - k * C;
+    cand[i] = seq_scores[b * bw + k] + (logits[(size_t)(b * bw + k) * ld + c] - lse[k]);
+  }
+  __syncthreads();
+  for (int r = 0; r < bw; ++r) {
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = tid; i < n; i += 256) {
+      const float v = cand[i];
+      if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) { rv[wave] = bv; ri[wave] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+      for (int w = 1; w < 4; ++w)
+        if (rv[w] > bv || (rv[w] == bv && ri[w] < bi)) { bv = rv[w]; bi = ri[w]; }
+      if (bi == 0x7fffffff) bi = r;                                      // every candidate is NaN / -inf and already taken: keep indices valid
+      const int sym = bi % C;
+      symbols[b * bw + r] = sym;
+      preds[b * bw + r] = bi / C + b * bw;
+      stored[b * bw + r] = bv;
+      seq_scores[b * bw + r] = sym == eos ? -INFINITY : bv;
+      cand[bi] = -INFINITY;                                              // taken (a -inf candidate can be taken again: the reference's
+    }                                                                    //  order among -inf ties is unspecified as well)
+    __syncthreads();
+  }
 }
 
 // Accuracy (evaluation_metric/metrics.py:19-81): both label rows are cut at EOS, UNKNOWN and every class that is not a digit
@@ -328,19 +386,28 @@ extern "C" int dig_decode_self_attn(const void* qkv_cache, void* out, int B, int
 }
 
 extern "C" int dig_decode_cross_attn(const void* q, const void* kv_mem, void* out, float* weights, int B, int n_mem, int heads,
-                                     int head_dim, float scale, hipStream_t stream) {
-  if (!q || !kv_mem || !out || B <= 0 || n_mem <= 0 || heads <= 0) return DIG_ERR_ARG;
+                                     int head_dim, float scale, int slots_per_mem, hipStream_t stream) {
+  if (!q || !kv_mem || !out || B <= 0 || n_mem <= 0 || heads <= 0 || slots_per_mem < 1 || B % slots_per_mem) return DIG_ERR_ARG;
   if (head_dim != DK || n_mem > 8192) return DIG_ERR_UNSUPPORTED;
   if (!aligned16(kv_mem)) return DIG_ERR_ALIGN;
   const size_t lds = (size_t)std::max(n_mem, 4 * DK) * sizeof(float);
   hipLaunchKernelGGL(cross_attn_kernel, dim3(B, heads), dim3(256), lds, stream, (const bf16_t*)q, (const bf16_t*)kv_mem, (bf16_t*)out, weights,
-                     n_mem, heads * DK, scale);
+                     n_mem, heads * DK, scale, slots_per_mem);
   return dig_check_launch();
 }
 
 extern "C" int dig_softmax_argmax(const float* logits, int ld, float* probs, long long* tokens, int B, int C, hipStream_t stream) {
   if (!logits || !probs || !tokens || B <= 0 || C <= 0 || ld < C) return DIG_ERR_ARG;
   hipLaunchKernelGGL(softmax_argmax_kernel, dim3(B), dim3(64), 0, stream, logits, ld, probs, tokens, C);
+  return dig_check_launch();
+}
+
+extern "C" int dig_beam_step(const float* logits, int ld, float* seq_scores, int B, int beam_width, int C, int eos, long long* symbols,
+                             long long* predecessors, float* stored_scores, hipStream_t stream) {
+  if (!logits || !seq_scores || !symbols || !predecessors || !stored_scores || B <= 0 || C <= 0 || ld < C) return DIG_ERR_ARG;
+  if (beam_width < 1 || beam_width > 16 || (size_t)beam_width * C * sizeof(float) > 60000) return DIG_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(beam_step_kernel, dim3(B), dim3(256), (size_t)beam_width * C * sizeof(float), stream, logits, ld, seq_scores, beam_width, C,
+                     eos, symbols, predecessors, stored_scores);
   return dig_check_launch();
 }
 

@@ -141,9 +141,8 @@ def _vocabulary(dataset):
 
 @torch.no_grad()
 def evaluate(data_loader, model, device, args=None):
-    if getattr(args, "beam_width", 0):
-        raise NotImplementedError("beam search is not built (greedy decode only)")
-    criterion = SeqCrossEntropyLoss()
+    beam = int(getattr(args, "beam_width", 0) or 0)                                  # engine_for_finetuning.py:246-256: with beam search the model
+    criterion = SeqCrossEntropyLoss()                                               # returns token ids, the loss meter reads 0
     metric_logger = utils.MetricLogger(delimiter="  ")
     header = 'Test:'
     model.eval()
@@ -153,8 +152,13 @@ def evaluate(data_loader, model, device, args=None):
         images = images.to(device, non_blocking=True)
         target = target.to(device, non_blocking=True)
         output, _, _, _ = model((images, target, lens))
-        loss = criterion(output, target, lens)                                   # (on probabilities, as the reference does: :249)
-        pred_ids = output.argmax(-1)
+        if beam > 0:
+            if getattr(model, "beam_width", 0) != beam:
+                raise RuntimeError(f"args.beam_width={beam} but the model was built with beam_width={getattr(model, 'beam_width', 0)}")
+            loss, pred_ids = torch.zeros((), device=output.device), output
+        else:
+            loss = criterion(output, target, lens)                               # (on probabilities, as the reference does: :249)
+            pred_ids = output.argmax(-1)
         vals = torch.stack([loss.double(), accuracy(pred_ids, target, voc).double(), recognition_f_measure(pred_ids, target, voc)]).tolist()
         batch_size = images.shape[0]
         metric_logger.update(loss=vals[0])

@@ -14,6 +14,8 @@ import ctypes
 from collections import OrderedDict
 
 import numpy as np
+import types
+
 import torch
 
 from . import _lib as L
@@ -53,8 +55,8 @@ class RecModel(torch.nn.Module):
             dk = DECODERS[args.decoder_name]
             n_layers, d_model, n_head, d_k, d_inner = dk["n_layers"], dk["d_model"], dk["n_head"], dk["d_k"], dk["d_inner"]
             nb_classes, max_len = args.nb_classes, args.max_len
-            if getattr(args, "beam_width", 0) or getattr(args, "use_1d_attdec", False) or getattr(args, "text_cond_vis", False):
-                raise NotImplementedError("beam search / 1-D attention decoder / text-conditional attention are not built (greedy tf_decoder only)")
+            if getattr(args, "use_1d_attdec", False) or getattr(args, "text_cond_vis", False):
+                raise NotImplementedError("1-D attention decoder / text-conditional attention are not built (tf_decoder, greedy or beam search)")
         if d_k != 64 or embed_dim // num_heads != 64:
             raise NotImplementedError("head dimension 64 only")
         self.D, self.H, self.depth, self.F = embed_dim, num_heads, depth, 4 * embed_dim
@@ -66,6 +68,8 @@ class RecModel(torch.nn.Module):
         self._ready = False
         self._graphs = {}
         self.use_hip_graph = True
+        self.beam_width = int(getattr(args, "beam_width", 0) or 0) if args is not None else 0      # model_builder.py:110
+        self.eos = 94                                                       # TFDecoder.beam_search's default (decoder.py:254)
 
     # ------------------------------------------------------------------ state
     def param_shapes(self):
@@ -185,54 +189,108 @@ class RecModel(torch.nn.Module):
         m, _, _ = ops.layernorm_fwd(h, w["ln_nw"], w["ln_nb"], 1e-5)
         return m
 
+    def _decode_state(self, mem, n_mem, slots_per_mem=1):
+        """Buffers of a K/V-cached decode over S = B * slots_per_mem sequences (greedy: 1 slot per sample; beam search: beam_width
+        slots that share their sample's projected memory)."""
+        w, d, nh, dk, T = self._w, self.d, self.nh, self.dk, self.max_len
+        hk = nh * dk
+        dev = mem.device
+        S = (mem.shape[0] // n_mem) * slots_per_mem
+        st = types.SimpleNamespace(S=S, n_mem=n_mem, spm=slots_per_mem)
+        st.kv_mem = [ops.linear_fwd(mem, w[f"decoder.layer_stack.{i}."]["kv2"]) for i in range(self.n_layers)]      # [B*n_mem, 2hk]
+        st.cache = [torch.zeros((S, T, 3 * hk), device=dev, dtype=BF16) for _ in range(self.n_layers)]
+        st.x = torch.empty((S, d), device=dev, dtype=BF16)
+        st.a = torch.empty((S, hk), device=dev, dtype=BF16)
+        st.wts = torch.empty((S, nh, n_mem), device=dev, dtype=F32)
+        st.logits = torch.empty((S, w["Cp"]), device=dev, dtype=F32)
+        return st
+
+    def _decode_step(self, st, t, tok):
+        """Feed token `tok` [S] at position t through the decoder stack; leaves the classifier logits in st.logits [S, Cp] and the
+        last layer's cross-attention weights in st.wts."""
+        w, d, nh, dk, T, C = self._w, self.d, self.nh, self.dk, self.max_len, self.nb_classes
+        hk = nh * dk
+        S = st.S
+        scale = dk ** -0.5
+        s_ = L.stream()
+        x = st.x
+        L.call("dig_decode_embed", L.ptr(tok), L.ptr(w["emb"]), L.ptr(w["pos"][t]), L.ptr(x), S, d, C + 1, s_)
+        for i in range(self.n_layers):
+            p = w[f"decoder.layer_stack.{i}."]
+            last = i == self.n_layers - 1
+            h, _, _ = ops.layernorm_fwd(x, p["n1w"], p["n1b"], 1e-5)
+            row = st.cache[i][:, t]                                                # [S, 3hk] view, row stride T*3hk
+            ops.gemm(h, p["qkv"], S, 3 * hk, d, out=row, ldc=T * 3 * hk)
+            L.call("dig_decode_self_attn", L.ptr(st.cache[i]), L.ptr(st.a), S, T, nh, dk, t, cf(scale), s_)
+            x = ops.linear_fwd(st.a, p["fc"], resid=x)
+            h, _, _ = ops.layernorm_fwd(x, p["n2w"], p["n2b"], 1e-5)
+            q2 = ops.linear_fwd(h, p["q2"])
+            L.call("dig_decode_cross_attn", L.ptr(q2), L.ptr(st.kv_mem[i]), L.ptr(st.a), L.ptr(st.wts) if last else None, S, st.n_mem, nh, dk,
+                   cf(scale), st.spm, s_)
+            x = ops.linear_fwd(st.a, p["fc2"], resid=x)
+            h, _, _ = ops.layernorm_fwd(x, p["n3w"], p["n3b"], 1e-5)
+            u = ops.linear_fwd(h, p["w1"], bias=p["b1"], act=1)
+            x = ops.linear_fwd(u, p["w2"], bias=p["b2"], resid=x)
+        o, _, _ = ops.layernorm_fwd(x, w["fnw"], w["fnb"], 1e-6)
+        ops.gemm(o, w["cls_w"], S, w["Cp"], d, out=st.logits, out_kind=ops.OUT_F32, bias=w["cls_b"])
+
     def greedy_decode(self, mem, n_mem, force_tokens=None):
         """TFDecoder.forward_test with a K/V cache.  mem: bf16 [B*n_mem, d].  force_tokens ([B, max_len] int64, optional) feeds
         the given tokens instead of the arg-max (teacher forcing, for parity tests).  Returns (probs [B,T,C] fp32,
         attn_maps [B,T,n_mem] fp32, tokens [B,T] int64)."""
-        w, d, nh, dk, T, C = self._w, self.d, self.nh, self.dk, self.max_len, self.nb_classes
-        hk = nh * dk
+        w, T, C = self._w, self.max_len, self.nb_classes
         dev = mem.device
-        B = mem.shape[0] // n_mem
-        scale = dk ** -0.5
-        st = L.stream()
-        kv_mem = [ops.linear_fwd(mem, w[f"decoder.layer_stack.{i}."]["kv2"]) for i in range(self.n_layers)]      # [B*n_mem, 2hk]
-        cache = [torch.zeros((B, T, 3 * hk), device=dev, dtype=BF16) for _ in range(self.n_layers)]
+        st = self._decode_state(mem, n_mem)
+        B = st.S
         tok = torch.full((B,), self.start_idx, device=dev, dtype=torch.int64)
         probs = torch.empty((B, T, C), device=dev, dtype=F32)
         maps = torch.empty((B, T, n_mem), device=dev, dtype=F32)
         toks = torch.empty((B, T), device=dev, dtype=torch.int64)
-        x = torch.empty((B, d), device=dev, dtype=BF16)
-        a = torch.empty((B, hk), device=dev, dtype=BF16)
-        wts = torch.empty((B, nh, n_mem), device=dev, dtype=F32)
-        logits = torch.empty((B, w["Cp"]), device=dev, dtype=F32)
         step_probs = torch.empty((B, C), device=dev, dtype=F32)
         for t in range(T):
-            L.call("dig_decode_embed", L.ptr(tok), L.ptr(w["emb"]), L.ptr(w["pos"][t]), L.ptr(x), B, d, C + 1, st)
-            for i in range(self.n_layers):
-                p = w[f"decoder.layer_stack.{i}."]
-                last = i == self.n_layers - 1
-                h, _, _ = ops.layernorm_fwd(x, p["n1w"], p["n1b"], 1e-5)
-                row = cache[i][:, t]                                                  # [B, 3hk] view, row stride T*3hk
-                ops.gemm(h, p["qkv"], B, 3 * hk, d, out=row, ldc=T * 3 * hk)
-                L.call("dig_decode_self_attn", L.ptr(cache[i]), L.ptr(a), B, T, nh, dk, t, cf(scale), st)
-                x = ops.linear_fwd(a, p["fc"], resid=x)
-                h, _, _ = ops.layernorm_fwd(x, p["n2w"], p["n2b"], 1e-5)
-                q2 = ops.linear_fwd(h, p["q2"])
-                L.call("dig_decode_cross_attn", L.ptr(q2), L.ptr(kv_mem[i]), L.ptr(a), L.ptr(wts) if last else None, B, n_mem, nh, dk,
-                       cf(scale), st)
-                x = ops.linear_fwd(a, p["fc2"], resid=x)
-                h, _, _ = ops.layernorm_fwd(x, p["n3w"], p["n3b"], 1e-5)
-                u = ops.linear_fwd(h, p["w1"], bias=p["b1"], act=1)
-                x = ops.linear_fwd(u, p["w2"], bias=p["b2"], resid=x)
-            o, _, _ = ops.layernorm_fwd(x, w["fnw"], w["fnb"], 1e-6)
-            ops.gemm(o, w["cls_w"], B, w["Cp"], d, out=logits, out_kind=ops.OUT_F32, bias=w["cls_b"])
-            L.call("dig_softmax_argmax", L.ptr(logits), w["Cp"], L.ptr(step_probs), L.ptr(tok), B, C, st)
+            self._decode_step(st, t, tok)
+            L.call("dig_softmax_argmax", L.ptr(st.logits), w["Cp"], L.ptr(step_probs), L.ptr(tok), B, C, L.stream())
             probs[:, t] = step_probs
-            maps[:, t] = wts.mean(1)
+            maps[:, t] = st.wts.mean(1)
             toks[:, t] = tok
             if force_tokens is not None:
                 tok = force_tokens[:, t].contiguous()
         return probs, maps, toks
+
+    def beam_search(self, mem, n_mem, beam_width, eos=None, force_logits=None, return_logits=False):
+        """TFDecoder.beam_search (models/decoder.py:254-370) on the K/V-cached decode kernels.  As in the reference the token history
+        of beam slot k is what slot k emitted (decoder.py:307 never re-orders it by predecessor), so the per-slot K/V cache is
+        exactly the reference's recomputation; only scores and back-pointers are re-ranked (`dig_beam_step`, one launch per step),
+        and the final back-tracking runs on the host over the [T, B*beam_width] decisions (one device -> host copy).
+        Returns token ids [B, max_len] int64 (the best hypothesis per sample, decoder.py:369).  force_logits ([T, S, C] fp32,
+        optional): use these classifier outputs instead of the decoder's (parity tests of the bookkeeping); return_logits: also
+        return the decoder's classifier outputs [T, S, C] of every step."""
+        w, T, C = self._w, self.max_len, self.nb_classes
+        eos = self.eos if eos is None else eos
+        dev = mem.device
+        bw = int(beam_width)
+        st = self._decode_state(mem, n_mem, slots_per_mem=bw)
+        S = st.S
+        B = S // bw
+        tok = torch.full((S,), self.start_idx, device=dev, dtype=torch.int64)
+        seq_scores = torch.full((S,), float("-inf"), device=dev, dtype=F32)
+        seq_scores[::bw] = 0.0                                              # only slot 0 of a sample is live at step 0 (:272-274)
+        syms = torch.empty((T, S), device=dev, dtype=torch.int64)
+        preds = torch.empty((T, S), device=dev, dtype=torch.int64)
+        scores = torch.empty((T, S), device=dev, dtype=F32)
+        kept = []
+        for t in range(T):
+            if force_logits is None:
+                self._decode_step(st, t, tok)
+                lg, ld = st.logits, w["Cp"]
+                if return_logits:
+                    kept.append(st.logits[:, :C].clone())
+            else:
+                lg, ld = force_logits[t].contiguous(), force_logits.shape[-1]
+            L.call("dig_beam_step", L.ptr(lg), ld, L.ptr(seq_scores), B, bw, C, eos, L.ptr(syms[t]), L.ptr(preds[t]), L.ptr(scores[t]), L.stream())
+            tok = syms[t]
+        ids = beam_backtrack(scores.cpu().numpy(), preds.cpu().numpy(), syms.cpu().numpy(), B, bw, eos).to(dev)
+        return (ids, torch.stack(kept)) if return_logits else ids
 
     def forward(self, x):
         if self.training:
@@ -245,6 +303,11 @@ class RecModel(torch.nn.Module):
         if not self._ready or self._dev != images.device:
             self._prepare(images.device)
         with torch.no_grad():
+            if self.beam_width > 0:
+                # RecModel.forward -> TFDecoder.forward(..., beam_width) (model_builder.py:151-158, decoder.py:101-102): token ids
+                # [B, max_len] and an all-ones tensor in place of (probabilities, attention maps)
+                ids = self.beam_search(self.memory(self.encoder_features(images)), self.N, self.beam_width)
+                return ids, None, None, torch.ones_like(ids)
             if not self.use_hip_graph:
                 probs, maps, _ = self._recognize(images)
                 return probs, None, None, maps
@@ -272,6 +335,36 @@ class RecModel(torch.nn.Module):
         enc = self.encoder_features(images)
         mem = self.memory(enc)
         return self.greedy_decode(mem, self.N)
+
+
+def beam_backtrack(scores, preds, syms, B, bw, eos):
+    """The back-tracking that ends TFDecoder.beam_search (models/decoder.py:311-369): numpy [T, B*bw] decisions -> int64 [B, T].
+    Walk the back-pointers from the best final beams; a hypothesis that emitted EOS at step t takes over a slot of its sample from
+    the back (worst live beam first) with the score it had when it ended; finally re-sort by score and keep beam 0."""
+    import numpy as np
+    T = syms.shape[0]
+    base = (np.arange(B) * bw)[:, None]
+    last = scores[-1].reshape(B, bw)
+    order = np.argsort(-last, axis=1, kind="stable")
+    s = np.take_along_axis(last, order, 1).copy()
+    t_pred = (order + base).reshape(-1)
+    found = [0] * B
+    rows = []
+    for t in range(T - 1, -1, -1):
+        cur = syms[t][t_pred].copy()
+        t_pred = preds[t][t_pred].copy()
+        ended = np.nonzero(syms[t] == eos)[0]
+        for idx in ended[::-1]:
+            b = int(idx) // bw
+            k = bw - (found[b] % bw) - 1
+            found[b] += 1
+            t_pred[b * bw + k] = preds[t][idx]
+            cur[b * bw + k] = syms[t][idx]
+            s[b, k] = scores[t][idx]
+        rows.append(cur)
+    best = np.argsort(-s, axis=1, kind="stable")[:, 0] + base[:, 0]
+    out = np.stack([r[best] for r in reversed(rows)], axis=1)
+    return torch.from_numpy(out.astype(np.int64))
 
 
 def class_canon(voc):

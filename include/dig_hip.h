@@ -229,7 +229,14 @@ int dig_decode_embed(const long long* tokens, const float* emb, const float* pe_
 int dig_decode_self_attn(const void* qkv_cache, void* out, int B, int T, int heads, int head_dim, int t, float scale,
                          hipStream_t stream);
 int dig_decode_cross_attn(const void* q, const void* kv_mem, void* out, float* weights, int B, int n_mem, int heads, int head_dim,
-                          float scale, hipStream_t stream);
+                          float scale, int slots_per_mem /* query b reads memory b / slots_per_mem: the beam slots of one sample share
+                          its projected memory (1 for greedy decoding) */, hipStream_t stream);
+/* One step of TFDecoder.beam_search (models/decoder.py:283-307) over B samples x beam_width slots: log-softmax of the slots' logits,
+ * + the running scores seq_scores [B*beam_width] (in / out: -inf for a slot that has just emitted `eos`), top-beam_width of the
+ * beam_width*C candidates per sample -> symbols = candidate % C, predecessors = candidate / C + sample*beam_width (both int64
+ * [B*beam_width]) and stored_scores (the un-masked top-k scores, what the final back-tracking reads). */
+int dig_beam_step(const float* logits, int ld, float* seq_scores, int B, int beam_width, int C, int eos, long long* symbols,
+                  long long* predecessors, float* stored_scores, hipStream_t stream);
 int dig_softmax_argmax(const float* logits, int ld, float* probs, long long* tokens, int B, int C, hipStream_t stream);
 /* Accuracy of evaluation_metric/metrics.py:19-81 on the device: rows of pred / target ([B][T] int64 class ids) are cut at `eos`;
  * canon[c] (uint8, n_classes entries) is the canonical code of class c -- 0 for classes the metric drops (UNKNOWN, anything that

@@ -179,6 +179,66 @@ def greedy_decode_cached(P, c: DecoderConfig, memory):
     return torch.stack(outs, 1), torch.stack(maps, 1), torch.stack(toks, 1)
 
 
+def beam_search(P, c: DecoderConfig, memory, beam_width, eos=94):
+    """TFDecoder.beam_search (decoder.py:254-370), literally.  Note what the reference does and this restatement keeps: the decoder
+    input of beam slot k at step t+1 is the symbol slot k EMITTED at every earlier step (`init_target_seq[:, step + 1] =
+    step_max_index`, decoder.py:307) -- the token history of a slot is never re-ordered by its predecessor, only the scores and the
+    back-pointers used by the final back-tracking are.  Returns the best hypothesis per sample [B, max_seq_len] (decoder.py:369)."""
+    B, N, C = memory.shape
+    bw, T, nc = beam_width, c.max_seq_len, c.num_classes
+    mem = memory.unsqueeze(1).repeat(1, bw, 1, 1).reshape(-1, N, C)                     # AABBCC order (decoder.py:262)
+    seq = torch.zeros((B * bw, T + 1), dtype=torch.long)
+    seq[:, 0] = c.start_idx
+    pos_index = (torch.arange(B) * bw).view(-1, 1)
+    seq_scores = torch.full((B * bw, 1), -float("inf"))
+    seq_scores[torch.arange(B) * bw] = 0.0
+    stored_scores, stored_pred, stored_sym = [], [], []
+    for step in range(T):
+        o, _ = decoder_attention(P, c, seq, torch.full((B * bw,), step + 1, dtype=torch.long), mem)
+        logp = F.log_softmax(o[:, step] @ P["decoder.classifier.weight"].t() + P["decoder.classifier.bias"], dim=-1)
+        cand_scores = seq_scores.repeat(1, nc) + logp
+        scores, candidates = cand_scores.view(B, -1).topk(bw, dim=1)
+        sym = (candidates % nc).view(B * bw)
+        seq_scores = scores.view(B * bw, 1)
+        pred = (candidates // nc + pos_index.expand_as(candidates)).view(B * bw, 1)
+        stored_scores.append(seq_scores.clone())
+        seq_scores = seq_scores.masked_fill(sym.view(-1, 1).eq(eos), -float("inf"))
+        stored_pred.append(pred)
+        stored_sym.append(sym)
+        seq[:, step + 1] = sym
+    return backtrack(torch.stack(stored_scores).squeeze(-1), torch.stack(stored_pred).squeeze(-1), torch.stack(stored_sym), B, bw, eos)
+
+
+def backtrack(stored_scores, stored_pred, stored_sym, B, bw, eos):
+    """The back-tracking of decoder.py:311-369 (IBM seq2seq TopKDecoder): [T, B*bw] scores / predecessors / symbols -> best
+    hypothesis [B, T].  Ended hypotheses (EOS at step t) replace the worst live ones from the back, then everything is re-sorted."""
+    T = stored_sym.shape[0]
+    pos_index = (torch.arange(B) * bw).view(-1, 1)
+    sorted_score, sorted_idx = stored_scores[-1].view(B, bw).topk(bw)
+    s = sorted_score.clone()
+    found = [0] * B
+    t_pred = (sorted_idx + pos_index.expand_as(sorted_idx)).view(B * bw)
+    p = []
+    for t in range(T - 1, -1, -1):
+        cur = stored_sym[t].index_select(0, t_pred)
+        t_pred = stored_pred[t].index_select(0, t_pred).clone()
+        eos_idx = stored_sym[t].eq(eos).nonzero()
+        for i in range(eos_idx.size(0) - 1, -1, -1):
+            idx = int(eos_idx[i][0])
+            b = idx // bw
+            res_k = bw - (found[b] % bw) - 1
+            found[b] += 1
+            res = b * bw + res_k
+            t_pred[res] = stored_pred[t][idx]
+            cur[res] = stored_sym[t][idx]
+            s[b, res_k] = stored_scores[t][idx]
+        p.append(cur)
+    s, re_sorted = s.topk(bw)
+    re_sorted = (re_sorted + pos_index.expand_as(re_sorted)).view(B * bw)
+    out = torch.cat([step.index_select(0, re_sorted).view(B, bw, -1) for step in reversed(p)], -1)
+    return out[:, 0, :]
+
+
 # ---------------------------------------------------------------------------------------------- encoder + linear_norm
 def finetune_encoder_shapes(cfg: O.DiGConfig) -> "OrderedDict[str, tuple]":
     """`encoder.*` keys of RecModel: the fine-tune factory `simmim_vit_small_patch4_32x128` is the pre-training encoder class

@@ -1,7 +1,8 @@
 """Golden vectors for the recognition forward + greedy decode (row N4) from the UNMODIFIED reference classes:
 models/decoder.py TFDecoder.forward_test, modeling_pretrain_vit.py PretrainVisionTransformerEncoder, and the real RecModel
 (models/model_builder.py) for the state_dict key order.  Asserts oracle/decode_oracle.py == reference, writes
-tests/golden/decode_tiny.npz (decoder alone) and tests/golden/recognize_tiny.npz (encoder + linear_norm + decoder).
+tests/golden/decode_tiny.npz (decoder alone), tests/golden/decode_beam_tiny.npz (TFDecoder.beam_search, width 5) and
+tests/golden/recognize_tiny.npz (encoder + linear_norm + decoder).
 
     python oracle/ref_harness/gen_decode_golden.py        # needs /root/reference (build container only)"""
 import os
@@ -50,6 +51,26 @@ def main():
     np.savez_compressed(os.path.join(GOLD, "decode_tiny.npz"), seed=21, B=B, Nm=Nm, probs=ref_out.numpy(), maps=ref_maps.numpy(),
                         tokens=toks.numpy(), cfg_keys=np.array(list(D.TINY.keys())), cfg_vals=np.array(list(D.TINY.values())))
     print("decoder: oracle == reference forward_test; tokens", toks[0].tolist())
+
+    # ---- beam search (decoder.py:254-370) from the unmodified TFDecoder, beam width 5: (a) the random-weight decoder (EOS is rare),
+    # (b) the same decoder with the classifier bias of EOS (94) raised, so that hypotheses end early and the back-tracking's
+    # replacement of live beams by ended ones (decoder.py:333-353) is exercised
+    beam = {}
+    for tag, boost in (("plain", 0.0), ("eos", 3.0)):
+        Pb = {k: v.clone() for k, v in P.items()}
+        Pb["decoder.classifier.bias"][94] += boost
+        sd["classifier.bias"].copy_(Pb["decoder.classifier.bias"])
+        with torch.no_grad():
+            ref_ids, ref_ones = dec.beam_search(None, mem, None, None, None, 5, eos=94)
+            mine = D.beam_search(Pb, c, mem, 5, eos=94)
+        assert torch.equal(ref_ids, mine), (tag, ref_ids, mine)
+        assert torch.equal(ref_ones, torch.ones_like(ref_ids))
+        beam[tag] = ref_ids.numpy()
+        print(f"beam search ({tag}): oracle == reference; sample 0", ref_ids[0].tolist(), " EOS positions:", int((ref_ids == 94).sum()))
+    sd["classifier.bias"].copy_(P["decoder.classifier.bias"])
+    np.savez_compressed(os.path.join(GOLD, "decode_beam_tiny.npz"), seed=21, B=B, Nm=Nm, beam_width=5, eos=94, eos_bias_boost=3.0,
+                        tokens_plain=beam["plain"], tokens_eos=beam["eos"], cfg_keys=np.array(list(D.TINY.keys())),
+                        cfg_vals=np.array(list(D.TINY.values())))
 
     # ---- encoder + linear_norm + decoder, tiny widths, reference classes wired as RecModel.forward does in eval mode
     ecfg = O.DiGConfig(**O.TINY)                                                     # embed 128, depth 2, heads 2

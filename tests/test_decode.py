@@ -29,6 +29,41 @@ def test_oracle_decode_matches_reference_fixture():
         np.testing.assert_allclose(maps.numpy(), g["maps"], atol=3e-6)
 
 
+def _beam_fixture():
+    g = np.load(os.path.join(GOLD, "decode_beam_tiny.npz"))
+    c = D.DecoderConfig(**{k: int(v) for k, v in zip(g["cfg_keys"].tolist(), g["cfg_vals"].tolist())})
+    return g, c
+
+
+def test_oracle_beam_search_matches_reference_fixture():
+    """TFDecoder.beam_search of the unmodified reference (oracle/ref_harness/gen_decode_golden.py), beam width 5: the random-weight
+    decoder and the one whose EOS bias is raised so that hypotheses end early (back-tracking with replacement)."""
+    g, c = _beam_fixture()
+    mem = O.det_tensor("memory", (int(g["B"]), int(g["Nm"]), c.d_model), 4, 1.0)
+    for tag, boost in (("plain", 0.0), ("eos", float(g["eos_bias_boost"]))):
+        P = D.det_decoder_state(c, int(g["seed"]))
+        P["decoder.classifier.bias"][int(g["eos"])] += boost
+        ids = D.beam_search(P, c, mem, int(g["beam_width"]), eos=int(g["eos"]))
+        assert np.array_equal(ids.numpy(), g["tokens_" + tag]), tag
+    assert (g["tokens_eos"] == int(g["eos"])).sum() > 0
+
+
+def test_host_backtracking_matches_oracle():
+    """dig_amd.recognizer.beam_backtrack (numpy, the product's host side of beam search) against the oracle's literal restatement of
+    decoder.py:311-369 on random decision tables with many EOS events (distinct scores: ties are unspecified in the reference too)."""
+    from dig_amd.recognizer import beam_backtrack
+    rng = np.random.RandomState(0)
+    for B, bw, T, eos in ((3, 5, 8, 94), (1, 2, 25, 7), (6, 4, 12, 3)):
+        S = B * bw
+        scores = -rng.rand(T, S).astype(np.float32).cumsum(0) - 1e-3 * rng.rand(T, S).astype(np.float32)
+        syms = rng.randint(0, 10 if eos < 10 else 97, size=(T, S)).astype(np.int64)
+        syms[rng.rand(T, S) < 0.15] = eos
+        preds = (rng.randint(0, bw, size=(T, S)) + (np.arange(S) // bw * bw)[None, :]).astype(np.int64)
+        want = D.backtrack(torch.from_numpy(scores), torch.from_numpy(preds), torch.from_numpy(syms), B, bw, eos)
+        got = beam_backtrack(scores, preds, syms, B, bw, eos)
+        assert torch.equal(got, want), (B, bw, T)
+
+
 def test_oracle_recognizer_matches_reference_fixture():
     g = np.load(os.path.join(GOLD, "recognize_tiny.npz"))
     _, c = _tiny()
@@ -125,7 +160,7 @@ def test_decode_attention_kernels_vs_torch():
     q = torch.randn(B, hk, device=dev).to(torch.bfloat16)
     kv = torch.randn(B, Nm, 2 * hk, device=dev).to(torch.bfloat16)
     w = torch.empty(B, H, Nm, device=dev)
-    L.call("dig_decode_cross_attn", L.ptr(q), L.ptr(kv), L.ptr(out), L.ptr(w), B, Nm, H, 64, ctypes.c_float(0.125), L.stream())
+    L.call("dig_decode_cross_attn", L.ptr(q), L.ptr(kv), L.ptr(out), L.ptr(w), B, Nm, H, 64, ctypes.c_float(0.125), 1, L.stream())
     qf = q.float().view(B, H, 1, 64)
     kf = kv[:, :, :hk].float().view(B, Nm, H, 64).permute(0, 2, 1, 3)
     vf = kv[:, :, hk:].float().view(B, Nm, H, 64).permute(0, 2, 1, 3)
@@ -135,6 +170,101 @@ def test_decode_attention_kernels_vs_torch():
     probs = torch.empty(B, 97, device=dev); tok = torch.empty(B, dtype=torch.int64, device=dev)
     L.call("dig_softmax_argmax", L.ptr(logits), 104, L.ptr(probs), L.ptr(tok), B, 97, L.stream())
     assert (probs - logits[:, :97].softmax(-1)).abs().max().item() < 1e-6 and torch.equal(tok, logits[:, :97].argmax(-1)) and int(tok[2]) == 5
+
+
+@pytest.mark.gpu
+def test_beam_step_kernel_vs_torch():
+    """dig_beam_step against the reference's own expressions (log_softmax + topk over [B, bw*C], decoder.py:291-301) on random logits,
+    with -inf running scores (dead slots) and EOS masking."""
+    from dig_amd import _lib as L
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1)
+    for B, bw, C, ld, eos in ((7, 5, 97, 104, 94), (3, 1, 97, 97, 94), (4, 8, 20, 24, 3)):
+        S = B * bw
+        logits = torch.randn(S, ld, device=dev) * 3
+        seq = (-torch.rand(S, device=dev) * 5)
+        seq[torch.rand(S, device=dev) < 0.3] = float("-inf")
+        seq[::bw] = 0.0                                                    # at least one live slot per sample
+        seq_in = seq.clone()
+        sym = torch.empty(S, dtype=torch.int64, device=dev); pred = torch.empty_like(sym); st = torch.empty(S, device=dev)
+        L.call("dig_beam_step", L.ptr(logits), ld, L.ptr(seq), B, bw, C, eos, L.ptr(sym), L.ptr(pred), L.ptr(st), L.stream())
+        cand = seq_in[:, None] + logits[:, :C].log_softmax(-1)
+        sc, ci = cand.view(B, -1).topk(bw, dim=1)
+        live = torch.isfinite(sc)                                          # (the order among -inf candidates is unspecified)
+        assert torch.equal(sym.view(B, bw)[live], (ci % C)[live])
+        assert torch.equal(pred.view(B, bw)[live], (ci // C + (torch.arange(B, device=dev) * bw)[:, None])[live])
+        assert (st.view(B, bw)[live] - sc[live]).abs().max().item() < 1e-5
+        want_next = sc.masked_fill((ci % C) == eos, float("-inf"))
+        assert torch.equal(torch.isfinite(seq.view(B, bw))[live], torch.isfinite(want_next)[live])
+
+
+@pytest.mark.gpu
+def test_device_beam_search_vs_oracle():
+    """RecModel.beam_search (K/V-cached decode kernels + dig_beam_step + host back-tracking), beam width 5:
+    (1) the search fed the oracle's own fp32 classifier outputs: token-equal with the REFERENCE fixture in both cases;
+    (2) end to end on the decoder's own bf16 logits (see below)."""
+    g, c = _beam_fixture()
+    ecfg = O.DiGConfig(**O.TINY)
+    B, Nm, bw, eos = int(g["B"]), int(g["Nm"]), int(g["beam_width"]), int(g["eos"])
+    mem32 = O.det_tensor("memory", (B, Nm, c.d_model), 4, 1.0)
+    mem = mem32.to("cuda:0").to(torch.bfloat16).reshape(B * Nm, c.d_model).contiguous()
+    for tag, boost in (("plain", 0.0), ("eos", float(g["eos_bias_boost"]))):
+        P = {**D.det_encoder_state(ecfg, 22), **D.det_decoder_state(c, int(g["seed"]))}
+        P["decoder.classifier.bias"][eos] += boost
+        # the reference's per-step logits, replayed: run the oracle loop once and record what the classifier produced per slot
+        logits = _oracle_beam_logits(P, c, mem32, bw, eos)
+        m = _tiny_model(c, ecfg, P)
+        m._prepare(torch.device("cuda:0"))
+        ids = m.beam_search(mem, Nm, bw, eos=eos, force_logits=logits.to("cuda:0"))
+        assert np.array_equal(ids.cpu().numpy(), g["tokens_" + tag]), tag
+    # end to end: the decoder's own bf16 logits drive the search.  (a) step 0 (all slots still hold <BOS>) agrees with the fp32
+    # oracle's logits; (b) the reference's bookkeeping (log_softmax + topk + back-tracking, fp32 torch) replayed on the DEVICE's
+    # per-step logits yields the same hypotheses token for token -- tokens fed back, slot order, EOS masking and back-pointers are
+    # wired as in decoder.py:283-369 (a random-weight decoder has too many near ties for a token comparison across precisions)
+    P = {**D.det_encoder_state(ecfg, 22), **D.det_decoder_state(c, int(g["seed"]))}
+    P["decoder.classifier.bias"][eos] += float(g["eos_bias_boost"])
+    m = _tiny_model(c, ecfg, P)
+    ids, dev_logits = m.beam_search(mem, Nm, bw, eos=eos, return_logits=True)
+    ref_logits = _oracle_beam_logits(P, c, mem32.to(torch.bfloat16).float(), bw, eos)
+    assert (dev_logits[0].cpu() - ref_logits[0]).abs().max().item() < 5e-2 * ref_logits[0].abs().max().item()
+    nc, T, S = c.num_classes, c.max_seq_len, B * bw
+    seq_scores = torch.full((S, 1), -float("inf")); seq_scores[torch.arange(B) * bw] = 0.0
+    st_s, st_p, st_y = [], [], []
+    for t in range(T):
+        cand = seq_scores.repeat(1, nc) + dev_logits[t].cpu().log_softmax(-1)
+        sc, ci = cand.view(B, -1).topk(bw, dim=1)
+        sym = (ci % nc).view(S)
+        st_s.append(sc.view(S)); st_p.append((ci // nc + (torch.arange(B) * bw)[:, None]).view(S)); st_y.append(sym)
+        seq_scores = sc.view(S, 1).masked_fill(sym.view(-1, 1).eq(eos), -float("inf"))
+    want = D.backtrack(torch.stack(st_s), torch.stack(st_p), torch.stack(st_y), B, bw, eos)
+    assert torch.equal(ids.cpu(), want), (ids.cpu(), want)
+    assert (ids == eos).any()
+    m.beam_width = bw                                                      # the RecModel.forward surface with --beam_width
+    m.eos = eos
+    images = O.synthetic_batch(2, ecfg, 5)[0].to("cuda:0")
+    out = m((images, None, None))
+    assert out[0].shape == (2, c.max_seq_len) and out[0].dtype == torch.int64 and torch.equal(out[3], torch.ones_like(out[0]))
+
+
+def _oracle_beam_logits(P, c, memory, bw, eos):
+    """Classifier outputs [T, B*bw, C] of the oracle's beam-search loop (decoder.py:283-290) on `memory`."""
+    import torch.nn.functional as F
+    B, N, Cm = memory.shape
+    nc, T = c.num_classes, c.max_seq_len
+    mem = memory.unsqueeze(1).repeat(1, bw, 1, 1).reshape(-1, N, Cm)
+    seq = torch.zeros((B * bw, T + 1), dtype=torch.long); seq[:, 0] = c.start_idx
+    seq_scores = torch.full((B * bw, 1), -float("inf")); seq_scores[torch.arange(B) * bw] = 0.0
+    out = []
+    for step in range(T):
+        o, _ = D.decoder_attention(P, c, seq, torch.full((B * bw,), step + 1, dtype=torch.long), mem)
+        lg = o[:, step] @ P["decoder.classifier.weight"].t() + P["decoder.classifier.bias"]
+        out.append(lg)
+        cand = seq_scores.repeat(1, nc) + F.log_softmax(lg, dim=-1)
+        scores, candidates = cand.view(B, -1).topk(bw, dim=1)
+        sym = (candidates % nc).view(B * bw)
+        seq_scores = scores.view(B * bw, 1).masked_fill(sym.view(-1, 1).eq(eos), -float("inf"))
+        seq[:, step + 1] = sym
+    return torch.stack(out)
 
 
 def test_oracle_string_accuracy_rules():
