@@ -161,7 +161,11 @@ class AttnRecModelTrain(RecModelTrain):
             embed_dim, num_heads = ENCODERS[args.model]
             nb_classes, max_len = args.nb_classes, args.max_len
             if getattr(args, "beam_width", 0):
-                raise NotImplementedError("beam search is not built (greedy sample only)")
+                # the reference never reaches AttentionRecognitionHead.beam_search: AttnRecModel.forward (model_builder.py:66-72) calls
+                # the head's __call__ (forward_train / sample) whatever args.beam_width says, and the method itself indexes with the float
+                # result of `candidates / num_classes` (attn_decoder.py:126-127).  Refused here rather than silently decoded greedily.
+                raise NotImplementedError("--beam_width with --decoder_type attention: the reference's AttnRecModel ignores it (greedy sample()); "
+                                          "beam search is built for tf_decoder")
             drop_rate = float(getattr(args, "drop", 0.0)) if drop_rate is None else drop_rate
             attn_drop_rate = float(getattr(args, "attn_drop_rate", 0.0)) if attn_drop_rate is None else attn_drop_rate
             drop_path_rate = float(getattr(args, "drop_path", 0.0)) if drop_path_rate is None else drop_path_rate

@@ -194,8 +194,10 @@ __global__ void scatter_rows_add_kernel(const bf16_t* __restrict__ src, const in
 }
 
 // target[m, (p1*4+p2)*3 + c] = img[b, c, ph*4+p1, pw*4+p2] * 0.5 + 0.5  for token idx[m] = b*N + n
+// normalize != 0 (`normlize_target`, engine_for_pretraining_moco.py:88-93): per patch and channel, (x - mean) / (sqrt(unbiased var) + 1e-6)
+// over the patch's 16 pixels of the un-normalised image
 __global__ void mim_target_kernel(const float* __restrict__ img, const int* __restrict__ idx, float* __restrict__ target, int M,
-                                  int gh, int gw, int Himg, int Wimg) {
+                                  int gh, int gw, int Himg, int Wimg, int normalize) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= M * 48) return;
   const int m = e / 48, k = e - m * 48;
@@ -204,7 +206,17 @@ __global__ void mim_target_kernel(const float* __restrict__ img, const int* __re
   const int b = t / ntok, n = t - b * ntok;
   const int ph = n / gw, pw = n - ph * gw;
   const int c = k % 3, p = k / 3, p1 = p >> 2, p2 = p & 3;
-  target[e] = img[(((size_t)b * 3 + c) * Himg + ph * 4 + p1) * Wimg + pw * 4 + p2] * 0.5f + 0.5f;
+  const float* base = img + (((size_t)b * 3 + c) * Himg + ph * 4) * Wimg + pw * 4;
+  const float x = base[p1 * Wimg + p2] * 0.5f + 0.5f;
+  if (!normalize) { target[e] = x; return; }
+  float v[16], mean = 0.f;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) { v[q] = base[(q >> 2) * Wimg + (q & 3)] * 0.5f + 0.5f; mean += v[q]; }
+  mean *= (1.0f / 16.0f);
+  float var = 0.f;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) var += (v[q] - mean) * (v[q] - mean);
+  target[e] = (x - mean) / (sqrtf(var * (1.0f / 15.0f)) + 1e-6f);
 }
 
 // loss += sum (pred - target)^2 * inv_count ;  dpred = gscale * 2 * (pred - target) * inv_count (bf16, ld_d, pad cols zeroed)
@@ -455,10 +467,10 @@ extern "C" int dig_scatter_rows_add(const void* src, const int* idx, void* dst, 
   return dig_check_launch();
 }
 
-extern "C" int dig_mim_target(const float* img, const int* idx, float* target, int M, int gh, int gw, hipStream_t stream) {
+extern "C" int dig_mim_target(const float* img, const int* idx, float* target, int M, int gh, int gw, int normalize, hipStream_t stream) {
   if (!img || !idx || !target || M <= 0) return DIG_ERR_ARG;
   hipLaunchKernelGGL(mim_target_kernel, dim3((M * 48 + 255) / 256), dim3(256), 0, stream, img, idx, target, M, gh, gw, gh * 4,
-                     gw * 4);
+                     gw * 4, normalize);
   return dig_check_launch();
 }
 

@@ -20,10 +20,10 @@ class _MimMSE(torch.autograd.Function):
     (un-normalise + '(p1 p2 c)' patchify + boolean select, engine_for_pretraining_moco.py:85-111,141)."""
 
     @staticmethod
-    def forward(ctx, vis_out, images, idx):
+    def forward(ctx, vis_out, images, idx, normalize=False):
         B, per, C = vis_out.shape
         M = B * per
-        target = ops.mim_target(images, idx, M, 8, 32)
+        target = ops.mim_target(images, idx, M, 8, 32, normalize)
         loss = torch.zeros(1, device=vis_out.device, dtype=torch.float32)
         dpred = torch.empty((M, C), device=vis_out.device, dtype=torch.bfloat16)
         if vis_out.stride(2) != 1 or vis_out.stride(0) != per * vis_out.stride(1):
@@ -38,11 +38,11 @@ class _MimMSE(torch.autograd.Function):
         d = torch.empty(ctx.shape, device=g.device, dtype=torch.float32)
         ops.cast_bf16_to_f32(ctx.dpred, d)
         ops.scale_by_device_scalar(d, g.reshape(1).float())
-        return d, None, None
+        return d, None, None, None
 
 
-def mim_mse_loss(vis_out, images, idx):
-    return _MimMSE.apply(vis_out, images, idx)
+def mim_mse_loss(vis_out, images, idx, normalize=False):
+    return _MimMSE.apply(vis_out, images, idx, normalize)
 
 
 class _StepReadback:
@@ -103,8 +103,6 @@ def train_one_epoch(model: torch.nn.Module, teacher_model, teacher_model_without
                     loss_scaler, max_norm: float = 0, patch_size: int = 16, normlize_target: bool = True, log_writer=None,
                     lr_scheduler=None, start_steps=None, lr_schedule_values=None, wd_schedule_values=None,
                     momentum_schedule=None, args=None):
-    if normlize_target:
-        raise NotImplementedError("normlize_target=True is not part of the pre-training recipe (run_mae_pretraining_moco.py:90)")
     if args.num_view != 2 or not args.only_mim_on_ori_img:
         raise NotImplementedError("the hot path is the 2-view, only_mim_on_ori_img recipe (README.md:53-78)")
     model.train()
@@ -157,7 +155,7 @@ def train_one_epoch(model: torch.nn.Module, teacher_model, teacher_model_without
         # through the whole contrastive branch; leaving the term out lets the engine skip those launches (engine_core.backward).
         # A non-finite contra_loss would have poisoned the reference's loss (0 * inf = nan): the readback keeps that exit.
         vis_out = out_dict['vis_out']
-        loss_pixel = mim_mse_loss(vis_out[0], core._last_images, core._last_idx)
+        loss_pixel = mim_mse_loss(vis_out[0], core._last_images, core._last_idx, bool(normlize_target))
         loss = loss + loss_pixel * args.loss_weight_pixel
 
         optimizer.zero_grad()

@@ -258,9 +258,9 @@ def scatter_rows_add(src, idx, dst, M):
     L.call("dig_scatter_rows_add", L.ptr(src), L.ptr(idx), L.ptr(dst), M, src.shape[1], L.stream())
 
 
-def mim_target(img, idx, M, gh, gw):
+def mim_target(img, idx, M, gh, gw, normalize=False):
     tgt = torch.empty((M, 48), device=img.device, dtype=F32)
-    L.call("dig_mim_target", L.ptr(img), L.ptr(idx), L.ptr(tgt), M, gh, gw, L.stream())
+    L.call("dig_mim_target", L.ptr(img), L.ptr(idx), L.ptr(tgt), M, gh, gw, int(normalize), L.stream())
     return tgt
 
 

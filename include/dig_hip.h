@@ -148,7 +148,8 @@ int dig_window_pool_bwd(const void* dpool, void* dx, int n_img, int gh, int gw, 
 int dig_mask_to_index(const unsigned char* mask, int* idx, int* count, int B, int N, int max_per_sample, hipStream_t stream);
 int dig_gather_rows(const void* src, const int* idx, void* dst, int M, int M_pad, int D, hipStream_t stream);
 int dig_scatter_rows_add(const void* src, const int* idx, void* dst, int M, int D, hipStream_t stream);
-int dig_mim_target(const float* img, const int* idx, float* target, int M, int gh, int gw, hipStream_t stream);
+int dig_mim_target(const float* img, const int* idx, float* target, int M, int gh, int gw, int normalize /* normlize_target,
+                   engine_for_pretraining_moco.py:88-93: per-patch, per-channel (x - mean) / (sqrt(unbiased var) + 1e-6) */, hipStream_t stream);
 int dig_mse_fwd_bwd(const float* pred, int ld_pred, const float* target, int M, int C, float gscale, float* loss, void* dpred,
                     int ld_dpred, hipStream_t stream);
 

@@ -459,14 +459,19 @@ def model_forward(P, S, images, aug_images, mask, m: float, cfg: DiGConfig, comm
     return out
 
 
-def mim_targets(images, mask_f, cfg: DiGConfig, num_view: int = 2, only_mim_on_ori_img: bool = True):
-    """engine_for_pretraining_moco.py:80-111 with normlize_target=False (the pretrain default, run_mae…:90).
+def mim_targets(images, mask_f, cfg: DiGConfig, num_view: int = 2, only_mim_on_ori_img: bool = True, normlize_target: bool = False):
+    """engine_for_pretraining_moco.py:80-111 (normlize_target=False is the pretrain default, run_mae…:90; True: :88-93, every patch is
+    standardised per channel over its p1*p2 pixels with the unbiased variance).
     mask_f: the loader's [B, num_view, N] float64 0/1 array.  Returns (bool mask [B,num_view,N], [labels])."""
     B = images.shape[0]
     mask = mask_f.flatten(1).to(torch.bool).view(B, num_view, -1).clone()
     if only_mim_on_ori_img:
         mask[:, 1:, :] = False
     patches = patchify_ppc(images * 0.5 + 0.5, cfg.patch)
+    if normlize_target:
+        sq = patches.reshape(B, patches.shape[1], cfg.patch * cfg.patch, -1)              # 'b n (p1 p2) c'
+        sq = (sq - sq.mean(dim=-2, keepdim=True)) / (sq.var(dim=-2, unbiased=True, keepdim=True).sqrt() + 1e-6)
+        patches = sq.reshape(B, patches.shape[1], -1)
     C = patches.shape[-1]
     labels = [patches[mask[:, v]].reshape(B, -1, C) for v in range(num_view)]
     return mask, labels

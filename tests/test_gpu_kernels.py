@@ -220,6 +220,10 @@ def test_mask_index_gather_target_are_bit_exact(dev):
     assert torch.equal(idx.cpu(), ref_idx) and bool((cnt.cpu() == 179).all())
     tgt = ops.mim_target(im.to(dev), idx, B * 179, 8, 32)
     assert torch.equal(tgt.cpu().reshape(B, 179, 48), labels[0])                          # bit-exact floats too (x*0.5+0.5)
+    # normlize_target=True (engine_for_pretraining_moco.py:88-93): per-patch, per-channel standardisation with the unbiased variance
+    _, nlabels = O.mim_targets(im, mk, cfg, normlize_target=True)
+    ntgt = ops.mim_target(im.to(dev), idx, B * 179, 8, 32, normalize=True)
+    assert (ntgt.cpu().reshape(B, 179, 48) - nlabels[0]).abs().max().item() < 2e-5 * nlabels[0].abs().max().item()
     src = torch.randn(B * 256, 384, device=dev).bfloat16()
     M = B * 179
     Mp = (M + 63) // 64 * 64

@@ -249,3 +249,38 @@ def test_finetune_model_init_and_pretrained_encoder_handoff():
     with pytest.raises(ValueError):
         RecModelTrain(embed_dim=cfg.embed_dim, depth=cfg.depth, num_heads=cfg.heads, n_layers=2, d_model=128, n_head=2, d_k=64, d_inner=64,
                       drop_rate=1.0)
+
+
+def test_pretrain_driver_parses_the_readme_command_and_shards_image_folders(tmp_path):
+    """run_mae_pretraining_moco.py (repo root): the reference's README flag set (README.md:53-78) parses as is; the image-folder source
+    shards a directory tree over ranks like DistributedSampler(shuffle=True, drop_last=True) -- disjoint per rank, reshuffled per epoch."""
+    import importlib.util
+    from PIL import Image
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("dig_driver", os.path.join(root, "run_mae_pretraining_moco.py"))
+    drv = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(drv)
+    readme = ("--image_alone_path DATA --mask_ratio 0.7 --batch_size 128 --opt adamw --output_dir OUT --epochs 10 --warmup_steps 5000 --max_len 25 "
+              "--num_view 2 --moco_dim 256 --moco_mlp_dim 4096 --moco_m 0.99 --moco_m_cos --moco_t 0.2 --num_windows 4 --contrast_warmup_steps 0 "
+              "--contrast_start_epoch 0 --loss_weight_pixel 1. --loss_weight_contrast 0.1 --only_mim_on_ori_img --weight_decay 0.1 "
+              "--opt_betas 0.9 0.999 --model pretrain_simmim_moco_ori_vit_small_patch4_32x128 --patchnet_name no_patchtrans --encoder_type vit")
+    a = drv.get_args(readme.split())
+    assert a.batch_size == 128 and a.num_view == 2 and a.moco_t == 0.2 and a.only_mim_on_ori_img and a.opt_betas == [0.9, 0.999]
+    assert a.use_moco_m_cos == 1 and a.normlize_target is False and a.image_alone_path == ["DATA"] and a.warmup_epochs == 40
+    rng = np.random.RandomState(0)
+    for i in range(23):
+        d = tmp_path / f"d{i % 3}"
+        d.mkdir(exist_ok=True)
+        Image.fromarray(rng.randint(0, 255, size=(20 + i, 50 + 2 * i, 3), dtype=np.uint8)).save(d / f"im{i}.png")
+    seen = []
+    tf = lambda crops, aug: (len(crops), [c.shape for c in crops], None)
+    for rank in range(2):
+        ld = drv.ImageFolderCrops([str(tmp_path)], 4, rank, 2, tf, None, 2)
+        assert len(ld) == 23 // 4 // 2
+        ld.set_epoch(0)
+        e0 = [b[0][1] for b in ld]
+        ld.set_epoch(1)
+        e1 = [b[0][1] for b in ld]
+        assert all(len(b) == 4 for b in e0) and e0 != e1
+        seen.append({sh for b in e0 for sh in b})
+    assert not (seen[0] & seen[1])                                          # every crop has a distinct shape here: shards are disjoint
