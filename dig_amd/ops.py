@@ -109,9 +109,11 @@ def colsum_partials(parts, out):
 def wgrad_splits(rows, tiles):
     """(R-splits, BK) of a weight-gradient GEMM.  Splits come in multiples of 8 so that every split is pinned to one XCD
     (csrc/gemm.hip: its tiles then share the operand rows through that XCD's L2 instead of re-fetching them from HBM);
-    measured on MI355X with tools/gpu_gemm_shapes.py wgrad: 36 tiles -> 24 splits / BK 32, 9 tiles -> 40 / BK 64."""
+    measured on MI355X: 36 tiles -> 16 splits / BK 32 (in the step), 9 tiles -> 40 / BK 64 (tools/experiments/gpu_gemm_shapes.py)."""
     if tiles >= 24:
-        want, bk = 24, 32
+        # 16 splits x 36 tiles = 576 workgroups: ONE round at three workgroups per CU (24 splits = 864 left a 96-workgroup second round);
+        # in the step, same box: 25.22 -> 24.98 ms (tools/experiments/sweep_wgrad_splits.py; 8 / 12 / 32 / 40 splits are slower)
+        want, bk = 16, 32
     else:
         want, bk = min(40, 8 * max(1, round(360 / tiles / 8))), 64
     cap = max(1, rows // 512)
