@@ -201,7 +201,7 @@ class RecModelTrain(RecModel):
     def _side_stream(self, dev):
         st = getattr(self, "_side", None)
         if st is None or st.device != dev:
-            st = self._side = torch.cuda.Stream(device=dev)
+            st = self._side = torch.cuda.Stream(device=dev, priority=-1)   # (as the pre-training side stream)
         return st
 
     def refresh_shadow(self):
