@@ -973,6 +973,7 @@ extern "C" int dig_gemm_bf16_dropout(const void* A, const void* B, void* C, int 
     if (bk == 544) return (pre_ ? launch_pwide<4, false, true>(p, stream) : launch_pwide<4, false, false>(p, stream));
     return resid ? launch_pwide<3, true, false>(p, stream) : (pre_ ? launch_pwide<3, false, true>(p, stream) : launch_pwide<3, false, false>(p, stream));
   }
+  if (bk == 544 || bk == 564) bk -= 300;                               // other operand forms: the one-tile-per-workgroup kernel of that shape
 #define DIG_GEMM_WCASE(ta, tb, o)                                                                                   \
   if ((trans_a != 0) == ta && (trans_b != 0) == tb && out_kind == o && bk >= 200) {                                  \
     if (bk == 212) return resid ? launch_wide<ta, tb, o, 1, 2, 2, 2, true, 64, 2>(p, splits, stream) : launch_wide<ta, tb, o, 1, 2, 2, 2, false, 64, 2>(p, splits, stream); \

@@ -51,6 +51,13 @@ typedef struct ihipStream_t* hipStream_t;
 #define DIG_GEMM_TILE_256x192 264      /* 12 waves: tall layers whose width is 384 (a multiple of 192, not of 256) */
 #define DIG_GEMM_TILE_64x128 212       /* 2 waves: few rows, long K (projection-head layers) */
 #define DIG_GEMM_TILE_128x64 221       /* 2 waves: few rows (projection-head dgrads) */
+/* Persistent forms of the two tall tiles: one workgroup per CU walks a contiguous range of tiles and keeps the next tile's first
+ * operand stage in flight during the epilogue; same arithmetic order, bit-identical results.  Forward only (trans_a = trans_b = 0),
+ * out_kind 0, act 0 / 1, no colsum_partials; ldr == ldc, ldp == ldc, I * ldc < 2^30, no residual together with pre_act, and no
+ * residual at all for the 256x256 form -- a forward call outside those limits returns DIG_ERR_UNSUPPORTED.  Transposed operands
+ * or fp32 / partial outputs with these codes run the one-tile-per-workgroup kernel of the same shape (244 / 264). */
+#define DIG_GEMM_TILE_256x256_PERSISTENT 544
+#define DIG_GEMM_TILE_256x192_PERSISTENT 564
 int dig_gemm_bf16(const void* A, const void* B, void* C, int I, int J, int R, int lda, int ldb, int ldc, int trans_a,
                   int trans_b, int out_kind, const float* bias, const void* resid, int ldr, void* pre_act, int ldp, float alpha,
                   int alpha_cols, int act, int splits, int a_rows, int b_rows, int bk, float* colsum_partials,
