@@ -17,8 +17,13 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
                                                     float* __restrict__ v, bf16_t* __restrict__ shadow, long long n4,
                                                     const unsigned char* __restrict__ group, float lr0, float wd0, float lr1,
                                                     float wd1, float beta1, float beta2, float eps, float inv_bc1,
-                                                    float inv_sqrt_bc2, float grad_scale, const float* __restrict__ finite_gate) {
+                                                    float inv_sqrt_bc2, float grad_scale, const float* __restrict__ finite_gate,
+                                                    const float* __restrict__ dev_scalars) {
   if (finite_gate && !isfinite(finite_gate[0])) return;                 // non-finite gradients: the whole update is a no-op (GradScaler's inf-skip)
+  if (dev_scalars) {                                                    // per-step scalars from memory: a captured graph replays with new values
+    lr0 = dev_scalars[0]; wd0 = dev_scalars[1]; lr1 = dev_scalars[2]; wd1 = dev_scalars[3];
+    inv_bc1 = dev_scalars[4]; inv_sqrt_bc2 = dev_scalars[5];
+  }
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
     const int grp = group[i >> 6];
     const float lr = grp ? lr1 : lr0, wd = grp ? wd1 : wd0;
@@ -82,7 +87,8 @@ __global__ __launch_bounds__(256) void adamw_groups_kernel(float* __restrict__ p
 }
 
 __global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ pm, const float* __restrict__ p, bf16_t* __restrict__ shadow,
-                                                  long long n4, float m, float one_minus_m) {
+                                                  long long n4, float m, float one_minus_m, const float* __restrict__ dev_m) {
+  if (dev_m) { m = dev_m[0]; one_minus_m = dev_m[1]; }
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
     float4 a = reinterpret_cast<float4*>(pm)[i];
     const float4 b = reinterpret_cast<const float4*>(p)[i];
@@ -173,7 +179,25 @@ extern "C" int dig_adamw_step(float* p, const float* g, float* m, float* v, void
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
   hipLaunchKernelGGL(adamw_kernel, dim3(flat_grid(n / 4)), dim3(256), 0, stream, p, g, m, v, (bf16_t*)bf16_shadow, n / 4,
-                     group_flags, lr0, wd0, lr1, wd1, beta1, beta2, eps, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)), grad_scale, finite_gate);
+                     group_flags, lr0, wd0, lr1, wd1, beta1, beta2, eps, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)), grad_scale, finite_gate,
+                     (const float*)nullptr);
+  return dig_check_launch();
+}
+
+extern "C" int dig_adamw_bias_corrections(float beta1, float beta2, int step, float* out2) {
+  if (!out2 || step < 1) return DIG_ERR_ARG;
+  out2[0] = (float)(1.0 / (1.0 - pow((double)beta1, (double)step)));
+  out2[1] = (float)(1.0 / sqrt(1.0 - pow((double)beta2, (double)step)));
+  return DIG_OK;
+}
+
+extern "C" int dig_adamw_step_dev(float* p, const float* g, float* m, float* v, void* bf16_shadow, long long n,
+                                  const unsigned char* group_flags, const float* scalars6, float beta1, float beta2, float eps,
+                                  float grad_scale, const float* finite_gate, hipStream_t stream) {
+  if (!p || !g || !m || !v || !group_flags || !scalars6 || n <= 0 || (n & 255)) return DIG_ERR_ARG;
+  if (!aligned16(p) || !aligned16(g) || !aligned16(m) || !aligned16(v) || (bf16_shadow && (((uintptr_t)bf16_shadow) & 7))) return DIG_ERR_ALIGN;
+  hipLaunchKernelGGL(adamw_kernel, dim3(flat_grid(n / 4)), dim3(256), 0, stream, p, g, m, v, (bf16_t*)bf16_shadow, n / 4,
+                     group_flags, 0.f, 0.f, 0.f, 0.f, beta1, beta2, eps, 1.f, 1.f, grad_scale, finite_gate, scalars6);
   return dig_check_launch();
 }
 
@@ -193,7 +217,16 @@ extern "C" int dig_ema_update(float* pm, const float* p, void* bf16_shadow, long
   if (!pm || !p || n <= 0 || (n & 3)) return DIG_ERR_ARG;
   if (!aligned16(pm) || !aligned16(p) || (bf16_shadow && (((uintptr_t)bf16_shadow) & 7))) return DIG_ERR_ALIGN;
   hipLaunchKernelGGL(ema_kernel, dim3(flat_grid(n / 4)), dim3(256), 0, stream, pm, p, (bf16_t*)bf16_shadow, n / 4, m,
-                     (float)(1.0 - (double)m));
+                     (float)(1.0 - (double)m), (const float*)nullptr);
+  return dig_check_launch();
+}
+
+extern "C" int dig_ema_update_dev(float* pm, const float* p, void* bf16_shadow, long long n, const float* m_and_one_minus_m,
+                                  hipStream_t stream) {
+  if (!pm || !p || !m_and_one_minus_m || n <= 0 || (n & 3)) return DIG_ERR_ARG;
+  if (!aligned16(pm) || !aligned16(p) || (bf16_shadow && (((uintptr_t)bf16_shadow) & 7))) return DIG_ERR_ALIGN;
+  hipLaunchKernelGGL(ema_kernel, dim3(flat_grid(n / 4)), dim3(256), 0, stream, pm, p, (bf16_t*)bf16_shadow, n / 4, 0.f, 0.f,
+                     m_and_one_minus_m);
   return dig_check_launch();
 }
 

@@ -472,12 +472,13 @@ def dig_forward(model, image, aug_image, vis_mask_pos, m, only_mim_on_ori_img=Tr
     mask = vis_mask_pos
     if mask.dim() == 2:
         mask = mask.view(image.shape[0], -1, model.N)
+    m = m if isinstance(m, torch.Tensor) else float(m)          # a device [m, 1-m] pair under graph capture (step_graph.py)
     anchor = getattr(model, "_anchor", None)
     if anchor is None or anchor.device != image.device:
         anchor = model._anchor = torch.zeros(1, device=image.device, requires_grad=True)
     if torch.is_grad_enabled():
-        contra, accs, vis_out = _DigFn.apply(anchor, model, image, aug_image, mask, float(m))
+        contra, accs, vis_out = _DigFn.apply(anchor, model, image, aug_image, mask, m)
     else:
-        contra, accs, vis_out = _Step(model).forward(image, aug_image, mask, float(m))
+        contra, accs, vis_out = _Step(model).forward(image, aug_image, mask, m)
     return {"contra_loss": contra, "q1_acc1": accs[0:1], "q1_acc5": accs[1:2], "q2_acc1": accs[2:3], "q2_acc5": accs[3:4],
             "vis_out": [vis_out]}

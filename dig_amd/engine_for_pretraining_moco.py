@@ -6,12 +6,14 @@ build (:83-111) as one gather kernel with bit-exact index order, model forward (
 combine (:119-144), backward + global grad norm + fused AdamW through the loss_scaler object (:152-157), metrics."""
 import math
 import sys
+import time
 from typing import Iterable
 
 import numpy as np
 import torch
 
 from . import ops
+from . import step_graph
 from . import utils
 
 
@@ -98,6 +100,47 @@ class _StepReadback:
                 lw.set_step()
 
 
+def _step_body(model, core, optimizer, loss_scaler, max_norm, args, normlize_target, images, aug_images, bool_vis_masked_pos, moco_m,
+               w_contrast, contrast_on, adamw_dev_scalars=None):
+    """One iteration's device work (engine_for_pretraining_moco.py:76-157): forward, both losses, zero_grad, backward, grad norm,
+    AdamW.  Nothing here reads back, so the same code runs eagerly (moco_m / w_contrast Python floats) or under HIP-graph capture
+    (moco_m = device [m, 1-m], w_contrast = device scalar, AdamW scalars from device memory).  Returns the ten logged values as one
+    device vector and whether a gradient norm is among them."""
+    B = images.shape[0]
+    bool_vis_masked_pos = bool_vis_masked_pos.flatten(1).to(torch.bool).view(B, args.num_view, -1)
+    bool_vis_masked_pos[:, 1, :].fill_(0)                               # only the original view is masked (:103-104)
+
+    out_dict = model(images, aug_images, bool_vis_masked_pos, moco_m, args.only_mim_on_ori_img)
+    loss = 0.
+    contra_loss = out_dict['contra_loss']
+    if contrast_on:
+        loss = loss + contra_loss * w_contrast
+    # else: the reference adds 0 * contra_loss (:137), which leaves the value unchanged and back-propagates exact zeros
+    # through the whole contrastive branch; leaving the term out lets the engine skip those launches (engine_core.backward).
+    # A non-finite contra_loss would have poisoned the reference's loss (0 * inf = nan): the readback keeps that exit.
+    vis_out = out_dict['vis_out']
+    loss_pixel = mim_mse_loss(vis_out[0], core._last_images, core._last_idx, bool(normlize_target))
+    loss = loss + loss_pixel * args.loss_weight_pixel
+
+    optimizer.zero_grad()
+    if adamw_dev_scalars is None:
+        grad_norm = loss_scaler(loss, optimizer, clip_grad=max_norm, parameters=model.parameters(), create_graph=False)
+    else:
+        grad_norm = loss_scaler(loss, optimizer, clip_grad=max_norm, parameters=None, create_graph=False, adamw_dev_scalars=adamw_dev_scalars)
+
+    # Everything the reference reads back with .item() (loss :146, accuracies :130-135, grad_norm :183) goes to the
+    # host as ONE asynchronous copy, resolved while the next step is already queued: the reference's blocking reads
+    # and its per-step torch.cuda.synchronize() (:159) drain the HIP queues twice per step and leave the GPU waiting
+    # on kernel launches (measured: 1.1 ms of a 28.7 ms step).  The non-finite-loss exit (:148-150) and the
+    # ragged-mask check therefore fire one step late -- before anything is logged or saved for that step.
+    dev_vals = torch.stack([loss.detach().reshape(()), contra_loss.detach().reshape(()), loss_pixel.detach().reshape(()),
+                            out_dict['q1_acc1'][0], out_dict['q1_acc5'][0], out_dict['q2_acc1'][0], out_dict['q2_acc5'][0],
+                            core._last_mask_counts.min().float(), core._last_mask_counts.max().float(),
+                            grad_norm.detach().reshape(()).float() if isinstance(grad_norm, torch.Tensor)
+                            else torch.full((), float('nan') if grad_norm is None else float(grad_norm), device=loss.device)])
+    return dev_vals, grad_norm is not None
+
+
 def train_one_epoch(model: torch.nn.Module, teacher_model, teacher_model_without_ddp, data_loader: Iterable,
                     word_data_loader: Iterable, optimizer: torch.optim.Optimizer, device: torch.device, epoch: int,
                     loss_scaler, max_norm: float = 0, patch_size: int = 16, normlize_target: bool = True, log_writer=None,
@@ -126,6 +169,7 @@ def train_one_epoch(model: torch.nn.Module, teacher_model, teacher_model_without
         contrast_loss_weights = np.zeros(iters_per_epoch)
 
     readback = _StepReadback(metric_logger, log_writer, core)
+    graph_ok = step_graph.usable(core, model, optimizer, loss_scaler, max_norm)
     for step, (batch, text, text_lens) in enumerate(metric_logger.log_every(data_loader, print_freq, header)):
         it = start_steps + step
         if lr_schedule_values is not None or wd_schedule_values is not None:
@@ -137,41 +181,28 @@ def train_one_epoch(model: torch.nn.Module, teacher_model, teacher_model_without
         moco_m = utils.adjust_moco_momentum(epoch + 1.0 * step / iters_per_epoch, args) if args.use_moco_m_cos else args.moco_m
         metric_logger.update(moco_m=moco_m)
 
+        t_host = time.perf_counter()
         images, aug_images, bool_vis_masked_pos = batch
         images = images.to(device, non_blocking=True)
         aug_images = aug_images.to(device, non_blocking=True)
-        bool_vis_masked_pos = bool_vis_masked_pos.to(device, non_blocking=True).flatten(1).to(torch.bool)
-        B = images.shape[0]
-        bool_vis_masked_pos = bool_vis_masked_pos.view(B, args.num_view, -1)
-        bool_vis_masked_pos[:, 1, :].fill_(0)                               # only the original view is masked (:103-104)
-
-        out_dict = model(images, aug_images, bool_vis_masked_pos, moco_m, args.only_mim_on_ori_img)
-        loss = 0.
-        contra_loss = out_dict['contra_loss']
+        bool_vis_masked_pos = bool_vis_masked_pos.to(device, non_blocking=True)
         w_contrast = float(contrast_loss_weights[step])
-        if w_contrast != 0.0:
-            loss = loss + contra_loss * w_contrast
-        # else: the reference adds 0 * contra_loss (:137), which leaves the value unchanged and back-propagates exact zeros
-        # through the whole contrastive branch; leaving the term out lets the engine skip those launches (engine_core.backward).
-        # A non-finite contra_loss would have poisoned the reference's loss (0 * inf = nan): the readback keeps that exit.
-        vis_out = out_dict['vis_out']
-        loss_pixel = mim_mse_loss(vis_out[0], core._last_images, core._last_idx, bool(normlize_target))
-        loss = loss + loss_pixel * args.loss_weight_pixel
-
-        optimizer.zero_grad()
-        grad_norm = loss_scaler(loss, optimizer, clip_grad=max_norm, parameters=model.parameters(), create_graph=False)
         loss_scale_value = loss_scaler.state_dict()["scale"]
-
-        # Everything the reference reads back with .item() (loss :146, accuracies :130-135, grad_norm :183) goes to the
-        # host as ONE asynchronous copy, resolved while the next step is already queued: the reference's blocking reads
-        # and its per-step torch.cuda.synchronize() (:159) drain the HIP queues twice per step and leave the GPU waiting
-        # on kernel launches (measured: 1.1 ms of a 28.7 ms step).  The non-finite-loss exit (:148-150) and the
-        # ragged-mask check therefore fire one step late -- before anything is logged or saved for that step.
-        dev_vals = torch.stack([loss.detach().reshape(()), contra_loss.detach().reshape(()), loss_pixel.detach().reshape(()),
-                                out_dict['q1_acc1'][0], out_dict['q1_acc5'][0], out_dict['q2_acc1'][0], out_dict['q2_acc5'][0],
-                                core._last_mask_counts.min().float(), core._last_mask_counts.max().float(),
-                                grad_norm.detach().reshape(()).float() if isinstance(grad_norm, torch.Tensor)
-                                else torch.full((), float('nan') if grad_norm is None else float(grad_norm), device=loss.device)])
+        if graph_ok and getattr(core, "_per_sample_mask", None) is not None:
+            # the captured form of this launch sequence (dig_amd/step_graph.py): scalars and inputs go to static device buffers,
+            # then one graph launch; the first steps of every sequence run the same body eagerly
+            sg = step_graph.get(core, images.device)
+            m32 = float(np.float32(moco_m))                            # dig_ema_update's own arithmetic: (float)(1 - (double)(float)m)
+            sg.set_scalars(step_graph.adamw_scalars(optimizer) + [m32, 1.0 - m32, w_contrast])
+            sig, (s_img, s_aug, s_mask) = sg.set_inputs(images, aug_images, bool_vis_masked_pos)
+            key = (sig, w_contrast != 0.0, bool(normlize_target), core._per_sample_mask, float(args.loss_weight_pixel))
+            dev_vals = sg.run(key, lambda: _step_body(model, core, optimizer, loss_scaler, max_norm, args, normlize_target, s_img, s_aug, s_mask,
+                                                      sg.scalars[6:8], sg.scalars[8], w_contrast != 0.0, sg.scalars[0:6])[0])
+            optimizer._step += 1
+            has_grad_norm = True
+        else:
+            dev_vals, has_grad_norm = _step_body(model, core, optimizer, loss_scaler, max_norm, args, normlize_target, images, aug_images,
+                                                 bool_vis_masked_pos, moco_m, w_contrast, w_contrast != 0.0)
         min_lr, max_lr = 10., 0.
         for group in optimizer.param_groups:
             min_lr, max_lr = min(min_lr, group["lr"]), max(max_lr, group["lr"])
@@ -180,7 +211,9 @@ def train_one_epoch(model: torch.nn.Module, teacher_model, teacher_model_without
             if group["weight_decay"] > 0:
                 weight_decay_value = group["weight_decay"]
         readback.push(dev_vals, dict(loss_scale=loss_scale_value, lr=max_lr, min_lr=min_lr, weight_decay=weight_decay_value,
-                                     has_grad_norm=grad_norm is not None, w_contrast=w_contrast))
+                                     has_grad_norm=has_grad_norm, w_contrast=w_contrast))
+        # host seconds spent queueing this step (diagnostic: bench.py reports it as host_ms_per_step)
+        core._host_launch = (getattr(core, "_host_launch", (0.0, 0))[0] + time.perf_counter() - t_host, getattr(core, "_host_launch", (0.0, 0))[1] + 1)
         readback.resolve(keep=1)
         if lr_scheduler is not None:
             lr_scheduler.step_update(start_steps + step)

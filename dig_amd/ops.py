@@ -373,7 +373,11 @@ def axpy_f32(y, x, a=1.0):
 
 
 def ema_update(pm, p, shadow, n, m):
-    L.call("dig_ema_update", L.ptr(pm), L.ptr(p), L.ptr(shadow), cll(n), cf(m), L.stream())
+    """pm = pm*m + p*(1-m).  m: a Python float, or a device fp32 tensor [m, 1-m] (captured-graph form: the value is read at run time)."""
+    if isinstance(m, torch.Tensor):
+        L.call("dig_ema_update_dev", L.ptr(pm), L.ptr(p), L.ptr(shadow), cll(n), L.ptr(m), L.stream())
+    else:
+        L.call("dig_ema_update", L.ptr(pm), L.ptr(p), L.ptr(shadow), cll(n), cf(m), L.stream())
 
 
 def sumsq(x, workspace, out):
@@ -383,3 +387,17 @@ def sumsq(x, workspace, out):
 def adamw_step(p, g, m, v, shadow, group_flags, lr0, wd0, lr1, wd1, beta1, beta2, eps, step, grad_scale=1.0, finite_gate=None):
     L.call("dig_adamw_step", L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), L.ptr(shadow), cll(p.numel()), L.ptr(group_flags), cf(lr0),
            cf(wd0), cf(lr1), cf(wd1), cf(beta1), cf(beta2), cf(eps), int(step), cf(grad_scale), L.ptr(finite_gate), L.stream())
+
+
+def adamw_step_dev(p, g, m, v, shadow, group_flags, scalars6, beta1, beta2, eps, grad_scale=1.0, finite_gate=None):
+    """dig_adamw_step with (lr0, wd0, lr1, wd1, 1/bc1, 1/sqrt(bc2)) read from the device tensor scalars6 at run time."""
+    L.call("dig_adamw_step_dev", L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), L.ptr(shadow), cll(p.numel()), L.ptr(group_flags),
+           L.ptr(scalars6), cf(beta1), cf(beta2), cf(eps), cf(grad_scale), L.ptr(finite_gate), L.stream())
+
+
+def adamw_bias_corrections(beta1, beta2, step):
+    """(1/(1-beta1^t), 1/sqrt(1-beta2^t)) as fp32, computed by the library exactly as dig_adamw_step does."""
+    import ctypes
+    out = (ctypes.c_float * 2)()
+    L.call("dig_adamw_bias_corrections", cf(beta1), cf(beta2), int(step), ctypes.cast(out, ctypes.c_void_p))
+    return float(out[0]), float(out[1])

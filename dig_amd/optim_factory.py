@@ -61,13 +61,19 @@ class FusedAdamW(torch.optim.Optimizer):
             g.zero_()
 
     @torch.no_grad()
-    def step(self, closure=None, grad_scale: float = 1.0, finite_gate=None):
-        """finite_gate: device float (the squared gradient norm); a non-finite value turns the launch into a no-op."""
+    def step(self, closure=None, grad_scale: float = 1.0, finite_gate=None, dev_scalars=None):
+        """finite_gate: device float (the squared gradient norm); a non-finite value turns the launch into a no-op.
+        dev_scalars: device fp32 [lr0, wd0, lr1, wd1, 1/bc1, 1/sqrt(bc2)] of THIS step (step_graph.adamw_scalars): the launch reads
+        them at run time and the caller advances `_step` (a captured launch is replayed, this method is not)."""
         self._bind()
         g0, g1 = self.param_groups
         b1, b2 = g0["betas"]
-        self._step += 1
         M = self.model
+        if dev_scalars is not None:
+            ops.adamw_step_dev(M.flat_params, M.flat_grads, self.exp_avg, self.exp_avg_sq, None, M.flat_groups, dev_scalars, b1, b2,
+                               g0["eps"], grad_scale, finite_gate)
+            return
+        self._step += 1
         ops.adamw_step(M.flat_params, M.flat_grads, self.exp_avg, self.exp_avg_sq, None, M.flat_groups,
                        g0["lr"], g0["weight_decay"], g1["lr"], g1["weight_decay"], b1, b2, g0["eps"], self._step, grad_scale, finite_gate)
 

@@ -94,7 +94,7 @@ def get_grad_norm_(parameters=None, norm_type: float = 2.0, model=None):
 class NativeScalerWithGradNormCount:
     state_dict_key = "amp_scaler"
 
-    def __call__(self, loss, optimizer, clip_grad=None, parameters=None, create_graph=False, update_grad=True):
+    def __call__(self, loss, optimizer, clip_grad=None, parameters=None, create_graph=False, update_grad=True, adamw_dev_scalars=None):
         model = optimizer.model
         comm = getattr(model, "comm", None)
         world = getattr(comm, "world", 1) if comm is not None else 1
@@ -111,7 +111,10 @@ class NativeScalerWithGradNormCount:
             scale = min(1.0, float(clip_grad) / (float(norm) + 1e-6))
         # the squared norm doubles as the update's gate: after a non-finite loss the optimizer launch changes nothing (GradScaler's
         # inf-skip, utils/utils.py:498-504), so the weights a caller sees after the late `sys.exit(1)` of the engine are the last good ones
-        optimizer.step(grad_scale=scale, finite_gate=model._norm_ws[1024:])
+        if adamw_dev_scalars is not None:           # captured step (dig_amd/step_graph.py): schedule values come from device memory
+            optimizer.step(grad_scale=scale, finite_gate=model._norm_ws[1024:], dev_scalars=adamw_dev_scalars)
+        else:
+            optimizer.step(grad_scale=scale, finite_gate=model._norm_ws[1024:])
         return norm
 
     def state_dict(self):

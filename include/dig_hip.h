@@ -193,6 +193,15 @@ int dig_adamw_step_groups(float* p, const float* g, float* m, float* v, void* bf
                           const float* lr_tab, const float* wd_tab, float beta1, float beta2, float eps, int step, float grad_scale,
                           const float* finite_gate, hipStream_t stream);
 int dig_ema_update(float* pm, const float* p, void* bf16_shadow, long long n, float m, hipStream_t stream);
+/* The same two launches with their per-step scalars read from device memory, so that a captured HIP graph of the training step
+ * (dig_amd/step_graph.py) replays with the current schedule values: scalars6 = {lr0, wd0, lr1, wd1, 1/(1-beta1^t), 1/sqrt(1-beta2^t)}
+ * (the last two exactly as dig_adamw_step derives them from `step`: dig_adamw_bias_corrections, a host function);
+ * m_and_one_minus_m = {m, (float)(1 - (double)m)}.  Bit-identical to the by-value forms for equal scalars. */
+int dig_adamw_bias_corrections(float beta1, float beta2, int step, float* out2_host);
+int dig_adamw_step_dev(float* p, const float* g, float* m, float* v, void* bf16_shadow, long long n, const unsigned char* group_flags,
+                       const float* scalars6, float beta1, float beta2, float eps, float grad_scale, const float* finite_gate,
+                       hipStream_t stream);
+int dig_ema_update_dev(float* pm, const float* p, void* bf16_shadow, long long n, const float* m_and_one_minus_m, hipStream_t stream);
 long long dig_sumsq_workspace_bytes(long long n);
 int dig_sumsq(const float* x, long long n, float* workspace, float* out, hipStream_t stream);
 

@@ -234,6 +234,49 @@ def test_checkpoint_resume_is_bit_exact(tmp_path):
         assert torch.equal(sd_ref[k], sd_b[k]), k
 
 
+def _run_epoch(model, batches, hp, lr_values, w_contrast=None):
+    from dig_amd.optim_factory import create_optimizer
+    from dig_amd.engine_for_pretraining_moco import train_one_epoch
+    from dig_amd.utils import NativeScalerWithGradNormCount
+    from gpu_util import engine_args
+    args = engine_args(hp)
+    if w_contrast is not None:
+        args.loss_weight_contrast = w_contrast
+    opt = create_optimizer(args, model)
+    loader = [([im, au, mk], torch.ones(1), torch.ones(1)) for im, au, mk in batches]
+    stats = train_one_epoch(model, None, None, loader, None, opt, torch.device("cuda:0"), 0, NativeScalerWithGradNormCount(), None,
+                            patch_size=4, normlize_target=False, start_steps=0, lr_schedule_values=lr_values,
+                            wd_schedule_values=np.linspace(0.05, 0.1, len(batches)), args=args)
+    return stats, opt
+
+
+@pytest.mark.parametrize("w_contrast", [0.1, 0.0])
+def test_graphed_step_equals_eager(w_contrast):
+    """dig_amd/step_graph.py: nine steps with a moving lr / weight-decay / EMA-momentum schedule and fresh inputs every step, once with
+    every step launched eagerly and once with steps 5..9 replayed from the captured HIP graph (step 1 eager, 2-4 the eager warm-up of
+    the captured body): weights, momentum weights, BN buffers, both Adam moments and the logged meters are bit-identical."""
+    cfg = O.DiGConfig(**O.TINY)
+    hp = O.StepHyper(lr=1e-3)
+    n = 9
+    batches = [O.synthetic_batch(4, cfg, 4200 + s) for s in range(n)]
+    lr_values = np.linspace(2e-4, 1e-3, n)
+    a = build_model(cfg, *O.det_state(cfg, 5))
+    a.step_graph = False
+    st_a, opt_a = _run_epoch(a, batches, hp, lr_values, w_contrast)
+    assert getattr(a, "_step_graph", None) is None
+    b = build_model(cfg, *O.det_state(cfg, 5))
+    st_b, opt_b = _run_epoch(b, batches, hp, lr_values, w_contrast)
+    assert b._step_graph.replays == n - 4 and len(b._step_graph.graphs) == 1
+    assert opt_a._step == opt_b._step == n
+    sa, sb = a.state_dict(), b.state_dict()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    assert torch.equal(opt_a.exp_avg, opt_b.exp_avg) and torch.equal(opt_a.exp_avg_sq, opt_b.exp_avg_sq)
+    assert torch.equal(a.flat_grads, b.flat_grads)
+    for k in st_a:
+        assert st_a[k] == st_b[k] or (st_a[k] != st_a[k] and st_b[k] != st_b[k]), (k, st_a[k], st_b[k])
+
+
 def test_vit_small_b32_step_vs_oracle():
     """The BASELINE model (ViT-S, dim 256 / mlp 4096 heads) at a quarter of the per-GPU batch, one full step against the fp32
     oracle on the same inputs: losses, grad-norm, and the gradient direction of every parameter bucket."""
