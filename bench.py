@@ -160,6 +160,7 @@ def main():
                     help="headline workload: mim_moco = BASELINE configs[2]'s step (SimMIM + MoCo-v3, the default at every N so that the "
                          "N=1/2/4/8 series is one workload); mim_only = configs[1] (loss_weight_contrast=0).  The other one is reported "
                          "in the same JSON line under `mim_only` / `mim_moco`.")
+    ap.add_argument("--no-step-graph", action="store_true", help="skip the extra measurement of the HIP-graph replay of the step")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     a = ap.parse_args()
 
@@ -196,7 +197,7 @@ def main():
                                  lr=1.5e-4 * B * world / 256, weight_decay=0.1, opt_eps=1e-8, opt_betas=[0.9, 0.999])
     opt = create_optimizer(args, model)
     scaler = U.NativeScalerWithGradNormCount()
-    total = a.warmup + 2 * a.steps + 8
+    total = a.warmup + 3 * a.steps + 24
     lr_s, wd_s = np.full(total + 8, args.lr), np.full(total + 8, 0.1)
     batches = synth_batches(4, B, dev, 1234 + rank)
 
@@ -215,9 +216,11 @@ def main():
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
+    model._host_launch = (0.0, 0)
     t0 = time.perf_counter()
     stats = run(a.steps, a.warmup)
     torch.cuda.synchronize()
+    host_ms = model._host_launch[0] / max(model._host_launch[1], 1) * 1e3      # host time spent queueing a step (outside the GPU's critical path)
     if world > 1:
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
@@ -246,11 +249,29 @@ def main():
         args.loss_weight_contrast = W_MAIN
         mim_only = {"workload": WORKLOAD_TEXT["mim_only" if a.workload == "mim_moco" else "mim_moco"],
                     "value": a.steps * B * world / dt1, "unit": "images/sec", "ms_per_step": dt1 / a.steps * 1e3, "steps": a.steps}
+    # ---- the same workload replayed from the captured HIP graph (dig_amd/step_graph.py; single process only): reported beside the headline
+    graphed = None
+    if world == 1 and not force_dist and not a.no_step_graph:
+        pos = a.warmup + a.steps + (0 if a.no_mim_only else a.steps + 2)
+        model.step_graph = True
+        run(6, pos)                                       # eager warm-up of the captured body + capture
+        torch.cuda.synchronize()
+        model._host_launch = (0.0, 0)
+        t2 = time.perf_counter()
+        run(a.steps, pos + 6)
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t2
+        graphed = {"ms_per_step": dt2 / a.steps * 1e3, "value": a.steps * B / dt2, "unit": "images/sec",
+                   "host_ms_per_step": model._host_launch[0] / max(model._host_launch[1], 1) * 1e3,
+                   "replays": model._step_graph.replays, "note": "opt-in (DIG_STEP_GRAPH=1): same launches, bit-identical results, one "
+                   "hipGraphLaunch per step; ROCm's graph executor runs the two-branch graph slower than the two eager streams"}
+        model.step_graph = False
     # ---- roofline of the dominant kernel: one extra, instrumented step (outside the timed region)
     # (EVERY rank runs these two steps -- they contain the step's collectives; only rank 0 instruments its launches)
     roof = None
     import contextlib
     model.overlap_streams = False                     # kernels one at a time, so event brackets time single launches
+    model.step_graph = False                          # (and launched eagerly: a replayed graph has no per-launch brackets)
     probe = GemmProbe() if rank == 0 else contextlib.nullcontext()
     with probe:
         run(2, a.warmup + a.steps)
@@ -313,7 +334,7 @@ def main():
             "config": {"workload": f"{model_name}: full train_one_epoch step, {WORKLOAD_TEXT[a.workload]}; dim 256, mlp 4096, m 0.99 cos, "
                                    f"T 0.2, 4 windows, mask 0.7, 2 views, AdamW wd 0.1, {B} samples/GPU, random-init weights",
                        "global_batch": B * world, "parallelism": f"dp{world}", "loss": float(stats.get("loss", float('nan')))},
-            "step_mfma_frac": (value / world * fl / PEAK_BF16) if fl else None,
+            "step_mfma_frac": (value / world * fl / PEAK_BF16) if fl else None, "host_ms_per_step": host_ms, "step_graph": graphed,
             "roofline": roof, ("mim_only" if a.workload == "mim_moco" else "mim_moco"): mim_only}
     if not a.no_cpu_baseline and world == 1:
         line["cpu_baseline"] = cpu_baseline(model_name, a.cpu_budget)

@@ -195,7 +195,8 @@ def train_one_epoch(model: torch.nn.Module, teacher_model, teacher_model_without
             m32 = float(np.float32(moco_m))                            # dig_ema_update's own arithmetic: (float)(1 - (double)(float)m)
             sg.set_scalars(step_graph.adamw_scalars(optimizer) + [m32, 1.0 - m32, w_contrast])
             sig, (s_img, s_aug, s_mask) = sg.set_inputs(images, aug_images, bool_vis_masked_pos)
-            key = (sig, w_contrast != 0.0, bool(normlize_target), core._per_sample_mask, float(args.loss_weight_pixel))
+            key = (sig, w_contrast != 0.0, bool(normlize_target), core._per_sample_mask, float(args.loss_weight_pixel),
+                   bool(getattr(core, "overlap_streams", True)))
             dev_vals = sg.run(key, lambda: _step_body(model, core, optimizer, loss_scaler, max_norm, args, normlize_target, s_img, s_aug, s_mask,
                                                       sg.scalars[6:8], sg.scalars[8], w_contrast != 0.0, sg.scalars[0:6])[0])
             optimizer._step += 1

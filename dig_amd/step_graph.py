@@ -12,6 +12,17 @@ once and replayed, the same launches cost the host one hipGraphLaunch.  What mak
   pool, the second stream forks from and joins the capturing stream through events (torch's wait_stream), which HIP records as graph
   dependencies.
 
+Measured on one MI355X (tools/gpu_step_graph_probe.py, ViT-S, B = 128, A/B in one process): eager 25.0 ms per step with 10.3 ms of
+host work to queue it; replayed 26.3 ms with 1.9 ms of host work.  The replay is SLOWER on the GPU: ROCm's graph executor spreads
+the nodes of a forked graph over DEBUG_HIP_FORCE_GRAPH_QUEUES internal queues (4 by default: 35.1 ms; 8: 42.0 ms; 3: 36.9 ms; 2:
+26.3 ms; 1: 28.6 ms) without regard to which capture stream a node came from, so the long data-gradient chain hops between queues
+at every fork and pays a cross-queue barrier each time; stream priorities are lost as well.  A graph captured from ONE stream
+replays exactly as fast as the eager launches (27.77 vs 27.80 ms, 0.34 ms of host work), but one stream costs 2.8 ms per step
+against two (`model.overlap_streams = False` selects that form).  dig_amd/__init__.py therefore sets the queue count to 2, and the captured step is OPT-IN (`DIG_STEP_GRAPH=1` or
+`model.step_graph = True`): it is the mode for a host that cannot keep 10 ms per step free (a busy data-loading process, a slow
+core), not a throughput gain.  bench.py reports both modes (`step_graph` in the JSON line).  Grouping the weight-gradient launches
+into one or two forks per encoder block did not help either mode (eager 25.0 -> 25.5 ms, replay unchanged).
+
 Not captured: data-parallel runs (RCCL calls stay eager), gradient clipping (torch's clip_grad_norm_ semantics need one host read),
 and anything that changes the launch sequence -- each distinct sequence (contrastive branch on / off, batch size, masked tokens per
 sample, normalised targets) gets its own graph, after `WARMUP` eager steps of that sequence (module loading, hipFuncSetAttribute,
@@ -23,7 +34,7 @@ import torch
 
 from . import ops
 
-ENABLED = os.environ.get("DIG_STEP_GRAPH", "1") != "0"
+ENABLED = os.environ.get("DIG_STEP_GRAPH", "0") == "1"
 WARMUP = 3
 
 
@@ -80,14 +91,12 @@ def usable(core, model, optimizer, loss_scaler, max_norm):
     """The captured form covers the single-process recipe; everything else takes the eager path."""
     from .optim_factory import FusedAdamW
     from .utils import NativeScalerWithGradNormCount
-    if not ENABLED or not getattr(core, "step_graph", True) or model is not core:
+    if not getattr(core, "step_graph", ENABLED) or model is not core:
         return False
     comm = getattr(core, "comm", None)
     if comm is not None and (comm.world > 1 or getattr(comm, "world_override", False)):
         return False
     if max_norm is not None and max_norm > 0:
-        return False
-    if not getattr(core, "overlap_streams", True):
         return False
     return type(optimizer) is FusedAdamW and type(loss_scaler) is NativeScalerWithGradNormCount and optimizer.model is core
 

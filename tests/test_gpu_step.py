@@ -265,6 +265,7 @@ def test_graphed_step_equals_eager(w_contrast):
     st_a, opt_a = _run_epoch(a, batches, hp, lr_values, w_contrast)
     assert getattr(a, "_step_graph", None) is None
     b = build_model(cfg, *O.det_state(cfg, 5))
+    b.step_graph = True
     st_b, opt_b = _run_epoch(b, batches, hp, lr_values, w_contrast)
     assert b._step_graph.replays == n - 4 and len(b._step_graph.graphs) == 1
     assert opt_a._step == opt_b._step == n
@@ -273,8 +274,8 @@ def test_graphed_step_equals_eager(w_contrast):
         assert torch.equal(sa[k], sb[k]), k
     assert torch.equal(opt_a.exp_avg, opt_b.exp_avg) and torch.equal(opt_a.exp_avg_sq, opt_b.exp_avg_sq)
     assert torch.equal(a.flat_grads, b.flat_grads)
-    for k in st_a:
-        assert st_a[k] == st_b[k] or (st_a[k] != st_a[k] and st_b[k] != st_b[k]), (k, st_a[k], st_b[k])
+    for k in st_a:            # (the REPORTED loss / accuracy sums are accumulated with atomics -- DESIGN.md "Determinism" -- hence not torch.equal)
+        assert abs(st_a[k] - st_b[k]) <= 1e-6 * abs(st_a[k]), (k, st_a[k], st_b[k])
 
 
 def test_vit_small_b32_step_vs_oracle():

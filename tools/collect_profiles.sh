@@ -2,7 +2,7 @@
 # Collects the round's measurement files on the GPU box (run through gpurun from the repo root):
 #   bash tools/collect_profiles.sh r02
 # -> gpurun_out/<tag>_final_bench.json            python bench.py (the driver's command, default flags)
-#    gpurun_out/<tag>_final_kernel_stats.csv      rocprofv3 --kernel-trace --stats of bench.py --steps 30 --warmup 8 --no-cpu-baseline --no-mim-only
+#    gpurun_out/<tag>_final_kernel_stats.csv      rocprofv3 --kernel-trace --stats of bench.py --steps 30 --warmup 8 --no-cpu-baseline --no-mim-only --no-step-graph
 #    gpurun_out/<tag>_final_bench_under_rocprof.json
 #    gpurun_out/<tag>_pmc_traffic.json            FETCH_SIZE / WRITE_SIZE passes (separate), tagged with the library hash
 #    gpurun_out/<tag>_pmc_kernel_counters.txt     MFMA / LDS utilisation, occupancy, instruction mix passes
@@ -15,12 +15,12 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python $ROOT/bench.py > $OUT/${TAG}_final_bench.json 2> $OUT/${TAG}_final_bench.err
 rm -rf $OUT/prof_stats
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -- python $ROOT/bench.py --steps 30 --warmup 8 --no-cpu-baseline --no-mim-only > $OUT/${TAG}_final_bench_under_rocprof.json 2> /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -- python $ROOT/bench.py --steps 30 --warmup 8 --no-cpu-baseline --no-mim-only --no-step-graph > $OUT/${TAG}_final_bench_under_rocprof.json 2> /dev/null
 cp $(ls $OUT/prof_stats/*/*kernel_stats.csv | head -1) $OUT/${TAG}_final_kernel_stats.csv
 f=$(ls $OUT/prof_stats/*/*kernel_trace.csv | head -1)
 python $ROOT/tools/trace_by_queue.py $f 10 10 60 > $OUT/${TAG}_final_by_queue.txt
 rm -rf $OUT/prof_stats
-SHORT="python $ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-mim-only"
+SHORT="python $ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-mim-only --no-step-graph"
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf $OUT/prof_$c
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/prof_$c -- $SHORT > /dev/null 2>&1

@@ -34,9 +34,13 @@ def run(n):
     return dt / n * 1e3, model._host_launch[0] / n * 1e3
 out = sys.stdout
 sys.stdout = sys.stderr
+import os
+from dig_amd import step_graph
+if os.environ.get("PROBE_SERIAL") == "1":            # one stream: is the replay of a linear graph as fast as the eager launches?
+    model.overlap_streams = False
 model.step_graph = True
 run(8)                                   # eager first step, warm-up, capture
-for rep in range(3):
+for rep in range(int(os.environ.get('PROBE_REPS', '3'))):
     for mode in (False, True):
         model.step_graph = mode
         run(3)

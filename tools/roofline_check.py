@@ -14,7 +14,7 @@ for r in rows:
         ta, tb = m.group(1) == "true", m.group(2) == "true"
     k = "wgrad" if ta else ("dgrad" if tb else "fwd")
     fam[k][0] += int(r["Calls"]); fam[k][1] += float(r["TotalDurationNs"])
-out = [f"rocprofv3 --kernel-trace --stats of `python bench.py --steps 30 --warmup 8 --no-cpu-baseline --no-mim-only` ({sys.argv[1].split(chr(47))[-1]}):",
+out = [f"rocprofv3 --kernel-trace --stats of `python bench.py --steps 30 --warmup 8 --no-cpu-baseline --no-mim-only --no-step-graph` ({sys.argv[1].split(chr(47))[-1]}):",
        "dig_gemm_bf16 launches grouped by family (template arguments TA, TB of gemm_kernel / gemm_wide_kernel), against the HIP-event figures",
        "bench.py prints in the same process (..._bench_under_rocprof.json) and in the unprofiled default run (..._final_bench.json).",
        "In the timed steps two HIP streams overlap, so a kernel's rocprof duration includes the slowdown from its neighbour on the other",
