@@ -276,7 +276,9 @@ class _Step:
         return dy
 
     # ------------------------------------------------------------------ full forward
-    def forward(self, images, aug, mask_b2n, m):
+    def forward(self, images, aug, mask_b2n, m, mim_views=1):
+        """mim_views: 1 = only_mim_on_ori_img (the README recipe: the decoder runs on view 0's masked rows), 2 = both views' masked rows
+        (modeling_pretrain_moco_mim_ori.py:572-577)."""
         M = self.m
         dev = images.device
         B, D, N, nw = images.shape[0], M.D, M.N, M.num_windows
@@ -366,11 +368,14 @@ class _Step:
         accs = stats[:, 1:].reshape(4) * (100.0 / n)                        # q1_acc1, q1_acc5, q2_acc1, q2_acc5
         # ---- SimMIM decoder on the masked tokens of view 0 only (:560-570; the reference decodes all rows then selects)
         per = M._mask_count(mask_u8, B)
-        Mrows = B * per
+        Mrows = mim_views * B * per
         Mp = (Mrows + 63) // 64 * 64
-        idx, cnt = ops.mask_to_index(mask_u8[:B], per)
-        M._last_mask_counts, M._last_idx, M._last_images = cnt, idx, images
-        self.idx, self.Mrows, self.Mp, self.per = idx, Mrows, Mp, per
+        idx, cnt = ops.mask_to_index(mask_u8[:mim_views * B], per)           # token rows b*N + n of enc, views stacked as the encoder stacks them
+        M._last_mask_counts, M._last_idx, M._last_images = cnt, idx[:B], images
+        # view 1's MIM target is cut from the ORIGINAL images with view 1's mask (engine_for_pretraining_moco.py:106-108 indexes
+        # `images_patch`, built from `images`, for every view), so its target indices are relative to `images`
+        M._last_idx_views = [idx[:B]] + ([idx[B:] - B * N] if mim_views == 2 else [])
+        self.idx, self.Mrows, self.Mp, self.per, self.mim_views = idx, Mrows, Mp, per, mim_views
         w16, f32 = M._w("online"), M._f32
         gath = ops.gather_rows(enc, idx, Mrows, Mp)
         h0 = ops.linear_fwd(gath, w16["pix_decoder.0.weight"])
@@ -380,7 +385,7 @@ class _Step:
         C = M.dec_classes
         ops.gemm(h2, w16["pix_decoder.4.weight"], Mp, C, M.dec_dim, out=pred, out_kind=ops.OUT_F32, bias=f32["pix_decoder.4.bias"], ldc=64)
         self.saved_dec = (gath, h0, h1, h2, mu, rs)
-        vis_out = pred[:Mrows, :C].reshape(B, per, C)
+        vis_out = pred[:Mrows, :C].reshape(mim_views * B, per, C)
         return contra, accs, vis_out
 
     # ------------------------------------------------------------------ full backward
@@ -393,10 +398,11 @@ class _Step:
         # contrast_start_epoch, BASELINE config 2): every gradient of that branch -- predictor, projector, pix_projector and
         # the whole augmented view -- is exactly zero in the reference, so nothing is launched for it and the encoder
         # backward runs on view 0's rows only (the gradient arena was zero-filled by optimizer.zero_grad()).
-        views = 2 if g_contra is not None else 1
-        d_enc = torch.empty_like(self.enc) if views == 2 else torch.zeros((B * N, D), device=dev, dtype=BF16)
+        contrast = g_contra is not None
+        views = 2 if (contrast or (g_vis is not None and self.mim_views == 2)) else 1      # encoder rows that carry a gradient
+        d_enc = torch.empty_like(self.enc) if contrast else torch.zeros((views * B * N, D), device=dev, dtype=BF16)
         n = B * nw
-        if views == 2:
+        if contrast:
             dqn = self.dqn
             ops.scale_by_device_scalar(dqn, g_contra.reshape(1).float())
             dq = ops.l2norm_bwd(dqn, self.qn, self.q_inv)
@@ -447,9 +453,9 @@ class _Step:
 
 class _DigFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, anchor, model, images, aug, mask, m):
+    def forward(ctx, anchor, model, images, aug, mask, m, mim_views):
         step = _Step(model)
-        contra, accs, vis_out = step.forward(images, aug, mask, m)
+        contra, accs, vis_out = step.forward(images, aug, mask, m, mim_views)
         ctx.step = step
         ctx.set_materialize_grads(False)          # an unused output arrives as None, not as a zero tensor (host-visible)
         ctx.mark_non_differentiable(accs)
@@ -459,7 +465,7 @@ class _DigFn(torch.autograd.Function):
     def backward(ctx, g_contra, g_accs, g_vis):
         step, ctx.step = ctx.step, None
         step.backward(g_contra, g_vis)
-        return None, None, None, None, None, None
+        return None, None, None, None, None, None, None
 
 
 def dig_forward(model, image, aug_image, vis_mask_pos, m, only_mim_on_ori_img=True):
@@ -467,8 +473,7 @@ def dig_forward(model, image, aug_image, vis_mask_pos, m, only_mim_on_ori_img=Tr
         raise RuntimeError("dig_amd.MoCo_ViT runs on an MI355X (cuda device) only; there is no CPU fallback")
     if model._flat["online"].device != image.device:
         raise RuntimeError("model and inputs are on different devices (call model.to(device))")
-    if not only_mim_on_ori_img:
-        raise NotImplementedError("only_mim_on_ori_img=False is not implemented (README configuration uses True)")
+    mim_views = 1 if only_mim_on_ori_img else 2
     mask = vis_mask_pos
     if mask.dim() == 2:
         mask = mask.view(image.shape[0], -1, model.N)
@@ -477,8 +482,9 @@ def dig_forward(model, image, aug_image, vis_mask_pos, m, only_mim_on_ori_img=Tr
     if anchor is None or anchor.device != image.device:
         anchor = model._anchor = torch.zeros(1, device=image.device, requires_grad=True)
     if torch.is_grad_enabled():
-        contra, accs, vis_out = _DigFn.apply(anchor, model, image, aug_image, mask, m)
+        contra, accs, vis_out = _DigFn.apply(anchor, model, image, aug_image, mask, m, mim_views)
     else:
-        contra, accs, vis_out = _Step(model).forward(image, aug_image, mask, m)
+        contra, accs, vis_out = _Step(model).forward(image, aug_image, mask, m, mim_views)
+    B = image.shape[0]
     return {"contra_loss": contra, "q1_acc1": accs[0:1], "q1_acc5": accs[1:2], "q2_acc1": accs[2:3], "q2_acc5": accs[3:4],
-            "vis_out": [vis_out]}
+            "vis_out": [vis_out] if mim_views == 1 else [vis_out[:B], vis_out[B:]]}

@@ -108,7 +108,8 @@ def _step_body(model, core, optimizer, loss_scaler, max_norm, args, normlize_tar
     device vector and whether a gradient norm is among them."""
     B = images.shape[0]
     bool_vis_masked_pos = bool_vis_masked_pos.flatten(1).to(torch.bool).view(B, args.num_view, -1)
-    bool_vis_masked_pos[:, 1, :].fill_(0)                               # only the original view is masked (:103-104)
+    if args.only_mim_on_ori_img:
+        bool_vis_masked_pos[:, 1, :].fill_(0)                           # only the original view is masked (:103-104)
 
     out_dict = model(images, aug_images, bool_vis_masked_pos, moco_m, args.only_mim_on_ori_img)
     loss = 0.
@@ -119,7 +120,14 @@ def _step_body(model, core, optimizer, loss_scaler, max_norm, args, normlize_tar
     # through the whole contrastive branch; leaving the term out lets the engine skip those launches (engine_core.backward).
     # A non-finite contra_loss would have poisoned the reference's loss (0 * inf = nan): the readback keeps that exit.
     vis_out = out_dict['vis_out']
-    loss_pixel = mim_mse_loss(vis_out[0], core._last_images, core._last_idx, bool(normlize_target))
+    if args.only_mim_on_ori_img:
+        loss_pixel = mim_mse_loss(vis_out[0], core._last_images, core._last_idx, bool(normlize_target))
+    else:
+        # both views carry a masked-pixel loss (:138-141); every view's target comes from the ORIGINAL crops (:106-108)
+        loss_pixel = 0.
+        for i in range(args.num_view):
+            loss_pixel = loss_pixel + (1. / args.num_view) * mim_mse_loss(vis_out[i], core._last_images, core._last_idx_views[i],
+                                                                         bool(normlize_target))
     loss = loss + loss_pixel * args.loss_weight_pixel
 
     optimizer.zero_grad()
@@ -146,8 +154,10 @@ def train_one_epoch(model: torch.nn.Module, teacher_model, teacher_model_without
                     loss_scaler, max_norm: float = 0, patch_size: int = 16, normlize_target: bool = True, log_writer=None,
                     lr_scheduler=None, start_steps=None, lr_schedule_values=None, wd_schedule_values=None,
                     momentum_schedule=None, args=None):
-    if args.num_view != 2 or not args.only_mim_on_ori_img:
-        raise NotImplementedError("the hot path is the 2-view, only_mim_on_ori_img recipe (README.md:53-78)")
+    if args.num_view != 2:
+        # the reference model itself is 2-view only: it stacks [image, aug_image] = 2B rows and chunks every result in two
+        # (modeling_pretrain_moco_mim_ori.py:491,501,521,548), so a [B, num_view, N] mask with num_view != 2 fails in its encoder
+        raise NotImplementedError("num_view must be 2: the model stacks exactly two views (modeling_pretrain_moco_mim_ori.py:491-523)")
     model.train()
     core = model.module if hasattr(model, "module") else model
     metric_logger = utils.MetricLogger(delimiter="  ")
@@ -195,7 +205,7 @@ def train_one_epoch(model: torch.nn.Module, teacher_model, teacher_model_without
             m32 = float(np.float32(moco_m))                            # dig_ema_update's own arithmetic: (float)(1 - (double)(float)m)
             sg.set_scalars(step_graph.adamw_scalars(optimizer) + [m32, 1.0 - m32, w_contrast])
             sig, (s_img, s_aug, s_mask) = sg.set_inputs(images, aug_images, bool_vis_masked_pos)
-            key = (sig, w_contrast != 0.0, bool(normlize_target), core._per_sample_mask, float(args.loss_weight_pixel),
+            key = (sig, w_contrast != 0.0, bool(normlize_target), core._per_sample_mask, float(args.loss_weight_pixel), bool(args.only_mim_on_ori_img),
                    bool(getattr(core, "overlap_streams", True)))
             dev_vals = sg.run(key, lambda: _step_body(model, core, optimizer, loss_scaler, max_norm, args, normlize_target, s_img, s_aug, s_mask,
                                                       sg.scalars[6:8], sg.scalars[8], w_contrast != 0.0, sg.scalars[0:6])[0])

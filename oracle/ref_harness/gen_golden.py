@@ -55,7 +55,7 @@ def ref_args(hp: O.StepHyper, epochs=10):
     a.contrast_warmup_steps = 0
     a.loss_weight_contrast = hp.w_contrast
     a.loss_weight_pixel = hp.w_pixel
-    a.only_mim_on_ori_img = True
+    a.only_mim_on_ori_img = bool(hp.only_mim_on_ori_img)
     a.eval_freq = 500
     a.opt = 'adamw'
     a.lr = hp.lr
@@ -106,6 +106,8 @@ def run_reference_steps(cfg, seed, B, n_steps, hp, world=1, rank=0, sync_bn=Fals
     def wrapped(*a, **k):
         out = fwd(*a, **k)
         caps["vis_out"] = out["vis_out"][0].detach().clone()
+        if len(out["vis_out"]) > 1:                     # only_mim_on_ori_img=False: the second view's masked predictions
+            caps["vis_out1"] = out["vis_out"][1].detach().clone()
         return out
     model.forward = wrapped
     run_model = model
@@ -177,7 +179,8 @@ def run_oracle_steps(cfg, seed, B, n_steps, hp, comm=None, rank=0, teacher=None)
                           params={k: v.detach().clone() for k, v in tr.P.items()},
                           bufs={k: v.clone() for k, v in tr.S.items()},
                           caps=dict(enc=taps["enc"].detach(), qs=torch.cat([taps["q1"], taps["q2"]]).detach(),
-                                    ks=torch.cat([taps["k1"], taps["k2"]]).detach(), vis_out=out["vis_out"][0].detach())))
+                                    ks=torch.cat([taps["k1"], taps["k2"]]).detach(), vis_out=out["vis_out"][0].detach(),
+                                    **({"vis_out1": out["vis_out"][1].detach()} if len(out["vis_out"]) > 1 else {}))))
     return steps
 
 
@@ -246,6 +249,8 @@ def pack(ref_steps, cfg, seed, B, hp, extra=None):
             d[f"s{s}/cap/{k}/norm"] = np.float64(v.double().norm().item())
             d[f"s{s}/cap/{k}/samples"] = v.reshape(-1)[sample_index(v.numel(), 64)].numpy()
         d[f"s{s}/cap/vis_out/full"] = r["caps"]["vis_out"].numpy().astype(np.float32)
+        if "vis_out1" in r["caps"]:
+            d[f"s{s}/cap/vis_out1/full"] = r["caps"]["vis_out1"].numpy().astype(np.float32)
     if extra:
         d.update(extra)
     return d
@@ -372,3 +377,5 @@ if __name__ == "__main__":
             gen_single("vit_base_b2_w1", base, 11, 2, 1, O.StepHyper(lr=1.5e-4 * 2 / 256))
         if a.only in ("", "c0"):                    # BASELINE configs[1]'s loss: loss_weight_contrast = 0 (MIM-only gradients)
             gen_single("tiny_w1_c0", tiny, 5, 4, 1, O.StepHyper(lr=1e-3, w_contrast=0.0))
+        if a.only in ("", "mim2"):                  # only_mim_on_ori_img=False: both views masked, MIM loss on both (engine :100-111,138-141)
+            gen_single("tiny_w1_mim2", tiny, 9, 4, 1, O.StepHyper(lr=1e-3, only_mim_on_ori_img=False))

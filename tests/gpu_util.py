@@ -14,7 +14,7 @@ def rel(a, b):
 def engine_args(hp, epochs=10):
     return types.SimpleNamespace(num_view=2, moco_m=hp.moco_m, use_moco_m_cos=1, epochs=epochs, contrast_start_epoch=0,
                                  contrast_warmup_steps=0, loss_weight_contrast=hp.w_contrast, loss_weight_pixel=hp.w_pixel,
-                                 only_mim_on_ori_img=True, eval_freq=500, opt='adamw', lr=hp.lr, weight_decay=hp.weight_decay,
+                                 only_mim_on_ori_img=bool(getattr(hp, "only_mim_on_ori_img", True)), eval_freq=500, opt='adamw', lr=hp.lr, weight_decay=hp.weight_decay,
                                  opt_eps=hp.eps, opt_betas=None)
 
 

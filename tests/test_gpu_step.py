@@ -89,6 +89,36 @@ def test_zero_contrast_weight_skips_branch_but_matches_oracle():
     assert n_zero >= 10, n_zero                                           # predictor + projector + pix_projector weights
 
 
+@pytest.mark.parametrize("w_contrast", [0.1, 0.0])
+def test_both_views_mim_vs_oracle(w_contrast):
+    """only_mim_on_ori_img=False (engine_for_pretraining_moco.py:100-111,138-141; modeling_pretrain_moco_mim_ori.py:572-577): view 1
+    keeps its mask in both encoders, the decoder runs on both views' masked rows, loss_pixel is the mean of the two MSEs (view 1
+    against patches of the ORIGINAL crops).  With a zero contrastive weight the encoder backward still covers both views."""
+    cfg = O.DiGConfig(**O.TINY)
+    seed, B = 9, 4
+    hp = O.StepHyper(lr=1e-3, w_contrast=w_contrast, only_mim_on_ori_img=False)
+    im, au, mk = O.synthetic_batch(B, cfg, seed * 1000 + 3)
+    model = build_model(cfg, *O.det_state(cfg, seed))
+    (stats,), _ = run_engine_steps(model, [(im, au, mk)], hp)
+    grads = {n: p.grad.detach().float().cpu().clone() for n, p in model.named_parameters() if p.requires_grad}
+    hp0 = dataclasses.replace(hp, moco_m=O.adjust_moco_momentum(0.0, 10, hp.moco_m))
+    ref_m, ref_g, _, _ = O.OracleTrainer(cfg, *O.det_state(cfg, seed)).loss_and_grads(im, au, mk, hp0)
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        _, bf_g, _, _ = O.OracleTrainer(cfg, *O.det_state(cfg, seed)).loss_and_grads(im, au, mk, hp0)
+    for k in ("loss", "loss_pixel", "loss_contrast", "grad_norm"):
+        assert close(stats[k], ref_m[k]), (k, stats[k], ref_m[k])
+    cos = torch.nn.functional.cosine_similarity
+    for n, g in grads.items():
+        r = ref_g[n].reshape(1, -1)
+        if r.abs().max() == 0:
+            assert g.abs().max().item() == 0.0, n
+            continue
+        c_hip, c_bf = cos(g.reshape(1, -1), r).item(), cos(bf_g[n].float().reshape(1, -1), r).item()
+        q_hip, q_bf = (g.norm() / r.norm()).item(), (bf_g[n].float().norm() / r.norm()).item()
+        assert (1 - c_hip) <= 2 * (1 - c_bf) + 5e-3 and abs(q_hip - 1) <= 2 * abs(q_bf - 1) + 3e-2, (n, c_hip, c_bf, q_hip, q_bf)
+    assert model._last_idx_views[1].min().item() >= 0 and model._last_idx_views[1].max().item() < B * 256
+
+
 def _fixture_step0(name):
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
     kw = {k: v for k, v in zip(g["cfg_keys"].tolist(), g["cfg_vals"].tolist())}
@@ -96,21 +126,24 @@ def _fixture_step0(name):
             "moco_mlp_dim", "pix_mlp_dim", "num_windows"}
     cfg = O.DiGConfig(**{k: (int(v) if k in ints else v) for k, v in kw.items()})
     hpk = {k: v for k, v in zip(g["hp_keys"].tolist(), g["hp_vals"].tolist())}
-    hpk["only_mim_on_ori_img"] = True
+    hpk["only_mim_on_ori_img"] = bool(hpk.get("only_mim_on_ori_img", 1.0))
     return g, cfg, O.StepHyper(**hpk), int(g["seed"]), int(g["B"])
 
 
-@pytest.mark.parametrize("name", ["tiny_w1", "vit_small_b4_w1", "vit_base_b2_w1", "tiny_w1_c0"])
+@pytest.mark.parametrize("name", ["tiny_w1", "vit_small_b4_w1", "vit_base_b2_w1", "tiny_w1_c0", "tiny_w1_mim2"])
 def test_step_vs_reference_golden_fixture(name):
     """Fixtures come from the UNMODIFIED reference engine (tests/golden, oracle/ref_harness/gen_golden.py).
     vit_small_b4_w1 is BASELINE.json configs[0] (the reference's own CPU-runnable case), vit_base_b2_w1 the model of
-    configs[3], tiny_w1_c0 the loss of configs[1] (loss_weight_contrast = 0: the engine skips the contrastive backward)."""
+    configs[3], tiny_w1_c0 the loss of configs[1] (loss_weight_contrast = 0: the engine skips the contrastive backward), tiny_w1_mim2 the
+    only_mim_on_ori_img=False variant (both views masked, a masked-pixel loss on each, view 1's target cut from the original crops)."""
     g, cfg, hp, seed, B = _fixture_step0(name)
     im, au, mk = O.synthetic_batch(B, cfg, seed * 1000)
     model = build_model(cfg, *O.det_state(cfg, seed))
     cap = {}
     def grab(mod, inp, out):                                              # (a forward hook must return None, or it replaces the output)
         cap.setdefault("vis_out", out["vis_out"][0].detach().float().cpu().clone())
+        if len(out["vis_out"]) > 1:
+            cap.setdefault("vis_out1", out["vis_out"][1].detach().float().cpu().clone())
     hook = model.register_forward_hook(grab)
     (stats,), _ = run_engine_steps(model, [(im, au, mk)], hp)
     hook.remove()
@@ -130,6 +163,10 @@ def test_step_vs_reference_golden_fixture(name):
     assert cap["vis_out"].shape == vis_ref.shape
     assert ((cap["vis_out"] - vis_ref).norm() / vis_ref.norm()).item() < 2e-2
     assert (cap["vis_out"] - vis_ref).abs().max().item() < 3e-2 * max(1.0, vis_ref.abs().max().item())
+    if not hp.only_mim_on_ori_img:
+        vis_ref1 = torch.from_numpy(g["s0/cap/vis_out1/full"]).float()
+        assert cap["vis_out1"].shape == vis_ref1.shape
+        assert ((cap["vis_out1"] - vis_ref1).norm() / vis_ref1.norm()).item() < 2e-2
     bn, bnorm = g["s0/buf_names"].tolist(), g["s0/buf_norms"]
     sd = model.state_dict()
     for i, n in enumerate(bn):

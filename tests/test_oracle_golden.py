@@ -54,6 +54,8 @@ def check_step0(g, rtol=3e-4):
         got = np.resize(gi.reshape(-1)[sample_index(gi.numel())].numpy(), 8)
         np.testing.assert_allclose(got, samples[i], rtol=rtol, atol=1e-5 * max(1e-3, float(np.abs(samples[i]).max()) + norms[i] / np.sqrt(gi.numel())))
     np.testing.assert_allclose(out["vis_out"][0].detach().numpy(), g["s0/cap/vis_out/full"], rtol=1e-4, atol=2e-5)
+    if "s0/cap/vis_out1/full" in g:
+        np.testing.assert_allclose(out["vis_out"][1].detach().numpy(), g["s0/cap/vis_out1/full"], rtol=1e-4, atol=2e-5)
     enc = taps["enc"].detach()
     np.testing.assert_allclose(enc.reshape(-1)[sample_index(enc.numel(), 64)].numpy(), g["s0/cap/enc/samples"], rtol=1e-4, atol=1e-4)
     ks = torch.cat([taps["k1"], taps["k2"]]).detach()
@@ -94,6 +96,14 @@ def test_zero_contrast_weight_step_matches_reference(golden_dir):
     zero = [n for n, v in zip(names, norms) if v == 0.0]
     assert any(n.startswith("predictor.") for n in zero) and any(n.startswith("pix_projector.") for n in zero)
     assert float(g["s0/stat/loss"]) == pytest.approx(float(g["s0/stat/loss_pixel"]), rel=1e-6) and float(g["s0/stat/loss_contrast"]) > 0
+
+
+def test_both_views_mim_step_matches_reference(golden_dir):
+    """only_mim_on_ori_img=False: both views masked in both encoders, one masked-pixel loss per view (the second against patches of the
+    ORIGINAL crops, engine_for_pretraining_moco.py:106-108), loss_pixel their mean."""
+    g = load(golden_dir, "tiny_w1_mim2")
+    assert not hp_from(g).only_mim_on_ori_img and "s0/cap/vis_out1/full" in g
+    check_step0(g)
 
 
 def test_param_inventory_matches_reference_counts():
