@@ -1,0 +1,971 @@
+// libdig_cpu.so -- a plain-C++ build of the hot-path part of the C ABI in include/dig_hip.h (last bullet).
+//
+// What this is: the same entry points (names, argument lists, error codes, in-place / accumulate conventions, bf16 storage with
+// round-to-nearest-even) as libdig_hip.so for the operators of the PRE-TRAINING step, written as
+// straightforward loops over host memory; `stream` is ignored and every call is synchronous.  It exists so that the operator-level
+// parity tests (tests/test_gpu_kernels.py) and the host logic of dig_amd/ops.py above the ABI run in a container without a GPU.
+//
+// What this is NOT: it is not the oracle (tests compare it, like the HIP library, against fp32 torch references and oracle/), and
+// it is not a fallback -- nothing under dig_amd/ loads it; the product raises without libdig_hip.so (dig_amd/_lib.py).  Entry
+// points outside the pre-training step (recognition decode, fine-tune sequence attention, GRU head, input transform) are not built
+// here; tests/test_cpu_abi.py lists the exported subset.
+//
+// Build: make -C cpu_abi   (g++ -O2 -fopenmp -shared -fPIC; __graft_entry__.build() runs it)
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+typedef void* hipStream_t;
+enum { DIG_OK = 0, DIG_ERR_ARG = -1, DIG_ERR_ALIGN = -2, DIG_ERR_LAUNCH = -3, DIG_ERR_UNSUPPORTED = -4 };
+typedef uint16_t bf16_t;
+
+struct dig_dropout_t {
+  unsigned k0, k1, thr;
+  float scale;
+  unsigned pk0, pk1, pthr;
+  float pscale;
+  int rows_per_sample;
+};
+
+namespace {
+
+inline float bf2f(bf16_t h) {
+  const uint32_t u = (uint32_t)h << 16;
+  float f;
+  std::memcpy(&f, &u, 4);
+  return f;
+}
+inline bf16_t f2bf(float f) {                       // round to nearest even, as v_cvt_pk_bf16_f32
+  uint32_t u;
+  std::memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+inline float gelu_f(float x) { return 0.5f * x * (1.0f + std::erf(x * 0.70710678118654752f)); }
+inline float dgelu_f(float x) {
+  const float cdf = 0.5f * (1.0f + std::erf(x * 0.70710678118654752f));
+  return cdf + x * 0.39894228040143268f * std::exp(-0.5f * x * x);
+}
+inline unsigned drop_hash(unsigned k0, unsigned k1, unsigned a, unsigned b) {
+  unsigned x = a ^ k0;
+  x ^= x >> 16; x *= 0x7feb352du;
+  x += k1 + b * 0x9e3779b9u;
+  x ^= x >> 15; x *= 0x846ca68bu;
+  x ^= x >> 16;
+  return x;
+}
+inline bool drop_keep(unsigned k0, unsigned k1, unsigned a, unsigned b, unsigned thr) { return drop_hash(k0, k1, a, b) >= thr; }
+// factor of element (i, j) of a [rows, cols] tensor under element dropout + drop-path (common.h dig_drop_apply8)
+inline float drop_factor(const dig_dropout_t& d, long long i, int j, int cols) {
+  float s = 1.f;
+  if (d.pthr) s = drop_keep(d.pk0, d.pk1, (unsigned)(i / d.rows_per_sample), 0u, d.pthr) ? d.pscale : 0.f;
+  if (d.thr) {
+    s *= d.scale;
+    if (!drop_keep(d.k0, d.k1, (unsigned)i * (unsigned)cols + (unsigned)j, 0u, d.thr)) s = 0.f;
+  }
+  return s;
+}
+
+constexpr int BR = 64, N_TOK = 256, DH = 64;
+
+}  // namespace
+
+extern "C" {
+
+// ------------------------------------------------------------------------------------------------------------------ GEMM
+int dig_gemm_effective_splits(int R, int splits) {
+  if (R <= 0 || splits < 1) return 0;
+  const int rtiles = (R + BR - 1) / BR;
+  const int per = ((rtiles + splits - 1) / splits) * BR;
+  return (R + per - 1) / per;
+}
+
+int dig_gemm_bf16_dropout(const void* A_, const void* B_, void* C_, int I, int J, int R, int lda, int ldb, int ldc, int trans_a,
+                          int trans_b, int out_kind, const float* bias, const void* resid_, int ldr, void* pre_, int ldp, float alpha,
+                          int alpha_cols, int act, int splits, int a_rows, int b_rows, int bk, float* colsum_partials,
+                          const dig_dropout_t* drop, hipStream_t) {
+  if (!A_ || !B_ || !C_ || I <= 0 || J <= 0 || R <= 0 || splits < 1) return DIG_ERR_ARG;
+  const bool dropping = drop && (drop->thr || drop->pthr);
+  if (dropping) {
+    if (out_kind != 0 || trans_a || !(bk == 0 || bk == 32 || bk == 64 || ((bk == 244 || bk == 264) && !trans_b))) return DIG_ERR_UNSUPPORTED;
+    if ((size_t)I * (size_t)J >= (1ull << 32) || (drop->pthr && drop->rows_per_sample <= 0)) return DIG_ERR_ARG;
+  }
+  if (bias && !aligned16(bias)) return DIG_ERR_ALIGN;
+  if (out_kind < 0 || out_kind > 2 || act < 0 || act > 2 ||
+      (bk != 0 && bk != 32 && bk != 64 && bk != 244 && bk != 264 && bk != 212 && bk != 221 && bk != 544 && bk != 564))
+    return DIG_ERR_ARG;
+  if (act == 2 && !resid_) return DIG_ERR_ARG;
+  if (!aligned16(A_) || !aligned16(B_) || !aligned16(C_) || (lda & 7) || (ldb & 7)) return DIG_ERR_ALIGN;
+  if ((J & 7) || (ldc & 7) || (resid_ && ((ldr & 7) || !aligned16(resid_))) || (pre_ && ((ldp & 7) || !aligned16(pre_)))) return DIG_ERR_ALIGN;
+  if (!trans_a && (R % BR)) return DIG_ERR_ARG;
+  if (!trans_b && (R % BR)) return DIG_ERR_ARG;
+  if (out_kind == 2 && (bias || resid_ || act)) return DIG_ERR_ARG;
+  if (out_kind != 2 && splits != 1) return DIG_ERR_ARG;
+  if (out_kind == 2 && ldc != J) return DIG_ERR_ARG;
+  if (colsum_partials && !(act == 2 && out_kind == 0 && trans_b && !trans_a)) return DIG_ERR_UNSUPPORTED;
+  const int rtiles = (R + BR - 1) / BR;
+  const int per = ((rtiles + splits - 1) / splits) * BR;
+  if ((R + per - 1) / per != splits) return DIG_ERR_ARG;
+  const bf16_t* A = (const bf16_t*)A_;
+  const bf16_t* B = (const bf16_t*)B_;
+  const bf16_t* resid = (const bf16_t*)resid_;
+  bf16_t* pre = (bf16_t*)pre_;
+  const int arows = a_rows > 0 ? a_rows : (trans_a ? R : I);
+  const int brows = b_rows > 0 ? b_rows : (trans_b ? R : J);
+  // operands as dense fp32 [I][R] / [J][R] (rows past a_rows / b_rows read as zero)
+  std::vector<float> a((size_t)I * R), b((size_t)J * R);
+#pragma omp parallel for
+  for (int i = 0; i < I; ++i)
+    for (int r = 0; r < R; ++r) {
+      const int row = trans_a ? r : i;
+      a[(size_t)i * R + r] = row < arows ? bf2f(trans_a ? A[(size_t)r * lda + i] : A[(size_t)i * lda + r]) : 0.f;
+    }
+#pragma omp parallel for
+  for (int j = 0; j < J; ++j)
+    for (int r = 0; r < R; ++r) {
+      const int row = trans_b ? r : j;
+      b[(size_t)j * R + r] = row < brows ? bf2f(trans_b ? B[(size_t)r * ldb + j] : B[(size_t)j * ldb + r]) : 0.f;
+    }
+  if (out_kind == 2) {
+    float* C = (float*)C_;
+#pragma omp parallel for collapse(2)
+    for (int s = 0; s < splits; ++s)
+      for (int i = 0; i < I; ++i) {
+        const int r0 = s * per, r1 = std::min(R, r0 + per);
+        for (int j = 0; j < J; ++j) {
+          float acc = 0.f;
+          for (int r = r0; r < r1; ++r) acc += a[(size_t)i * R + r] * b[(size_t)j * R + r];
+          C[((size_t)s * I + i) * J + j] = acc;
+        }
+      }
+    return DIG_OK;
+  }
+  const int groups = (I + 63) / 64;
+  std::vector<float> csum(colsum_partials ? (size_t)groups * J : 0, 0.f);
+#pragma omp parallel for
+  for (int g = 0; g < groups; ++g)
+    for (int i = g * 64; i < std::min(I, g * 64 + 64); ++i)
+      for (int j = 0; j < J; ++j) {
+        float acc = 0.f;
+        for (int r = 0; r < R; ++r) acc += a[(size_t)i * R + r] * b[(size_t)j * R + r];
+        float v = (acc + (bias ? bias[j] : 0.f)) * (j < alpha_cols ? alpha : 1.0f);
+        if (act == 1) {
+          if (pre) pre[(size_t)i * ldp + j] = f2bf(v);
+          v = gelu_f(v);
+          if (dropping) v *= drop_factor(*drop, i, j, J);
+        } else if (act == 2) {
+          v *= dgelu_f(bf2f(resid[(size_t)i * ldr + j]));
+          if (dropping) v *= drop_factor(*drop, i, j, J);
+          if (colsum_partials) csum[(size_t)g * J + j] += v;
+        } else if (dropping) {
+          v *= drop_factor(*drop, i, j, J);
+        }
+        if (resid && act != 2) v += bf2f(resid[(size_t)i * ldr + j]);
+        if (out_kind == 0) ((bf16_t*)C_)[(size_t)i * ldc + j] = f2bf(v);
+        else ((float*)C_)[(size_t)i * ldc + j] = v;
+      }
+  if (colsum_partials) std::memcpy(colsum_partials, csum.data(), csum.size() * sizeof(float));
+  return DIG_OK;
+}
+
+int dig_gemm_bf16(const void* A, const void* B, void* C, int I, int J, int R, int lda, int ldb, int ldc, int trans_a, int trans_b,
+                  int out_kind, const float* bias, const void* resid, int ldr, void* pre_act, int ldp, float alpha, int alpha_cols,
+                  int act, int splits, int a_rows, int b_rows, int bk, float* colsum_partials, hipStream_t stream) {
+  return dig_gemm_bf16_dropout(A, B, C, I, J, R, lda, ldb, ldc, trans_a, trans_b, out_kind, bias, resid, ldr, pre_act, ldp, alpha, alpha_cols,
+                               act, splits, a_rows, b_rows, bk, colsum_partials, nullptr, stream);
+}
+
+int dig_reduce_partials(const float* partials, int splits, long long n, float* out, int accumulate, hipStream_t) {
+  if (!partials || !out || splits < 1 || n <= 0 || (n & 3)) return DIG_ERR_ARG;
+  if (!aligned16(partials) || !aligned16(out)) return DIG_ERR_ALIGN;
+#pragma omp parallel for
+  for (long long e = 0; e < n; ++e) {
+    float acc = accumulate ? out[e] : 0.f;
+    for (int s = 0; s < splits; ++s) acc += partials[(long long)s * n + e];
+    out[e] = acc;
+  }
+  return DIG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------ attention
+int dig_attn_fwd_dropout(const void* qkv_, void* ctx_, float* lse, int n_img, int heads, int embed_dim, const dig_dropout_t* drop,
+                         int q_rows, hipStream_t) {
+  if (!qkv_ || !ctx_ || !lse || n_img <= 0 || heads <= 0 || embed_dim != heads * DH || q_rows < 1 || q_rows > N_TOK) return DIG_ERR_ARG;
+  if (!aligned16(qkv_) || !aligned16(ctx_)) return DIG_ERR_ALIGN;
+  const bf16_t* qkv = (const bf16_t*)qkv_;
+  bf16_t* ctx = (bf16_t*)ctx_;
+  const int D = embed_dim, ld = 3 * D, nq = (q_rows + 31) / 32 * 32;
+  const bool dropping = drop && drop->thr;
+#pragma omp parallel for collapse(2)
+  for (int b = 0; b < n_img; ++b)
+    for (int h = 0; h < heads; ++h) {
+      std::vector<float> s(N_TOK);
+      for (int i = 0; i < nq; ++i) {
+        const bf16_t* q = qkv + ((size_t)b * N_TOK + i) * ld + h * DH;
+        float mx = -3.0e38f;
+        for (int j = 0; j < N_TOK; ++j) {
+          const bf16_t* k = qkv + ((size_t)b * N_TOK + j) * ld + D + h * DH;
+          float acc = 0.f;
+          for (int c = 0; c < DH; ++c) acc += bf2f(q[c]) * bf2f(k[c]);
+          s[j] = acc;
+          mx = std::max(mx, acc);
+        }
+        float sum = 0.f;
+        for (int j = 0; j < N_TOK; ++j) { s[j] = std::exp(s[j] - mx); sum += s[j]; }
+        lse[((size_t)b * heads + h) * N_TOK + i] = mx + std::log(sum);
+        const float inv = 1.0f / sum;
+        float o[DH];
+        for (int c = 0; c < DH; ++c) o[c] = 0.f;
+        for (int j = 0; j < N_TOK; ++j) {
+          float p = s[j] * inv;
+          if (dropping) p = drop_keep(drop->k0, drop->k1, ((unsigned)i << 16) | (unsigned)j, (unsigned)(b * heads + h), drop->thr) ? p * drop->scale : 0.f;
+          const bf16_t* v = qkv + ((size_t)b * N_TOK + j) * ld + 2 * D + h * DH;
+          for (int c = 0; c < DH; ++c) o[c] += p * bf2f(v[c]);
+        }
+        for (int c = 0; c < DH; ++c) ctx[((size_t)b * N_TOK + i) * D + h * DH + c] = f2bf(o[c]);
+      }
+    }
+  return DIG_OK;
+}
+
+int dig_attn_fwd(const void* qkv, void* ctx, float* lse, int n_img, int heads, int embed_dim, hipStream_t stream) {
+  return dig_attn_fwd_dropout(qkv, ctx, lse, n_img, heads, embed_dim, nullptr, N_TOK, stream);
+}
+
+int dig_attn_bwd_dropout(const void* qkv_, const void* ctx_, const void* dctx_, const float* lse, void* dqkv_, int n_img, int heads,
+                         int embed_dim, float scale, float* q_colsum, float* v_colsum, const dig_dropout_t* drop, int q_rows, hipStream_t) {
+  if (!qkv_ || !ctx_ || !dctx_ || !lse || !dqkv_ || n_img <= 0 || heads <= 0 || embed_dim != heads * DH || q_rows < 1 || q_rows > N_TOK) return DIG_ERR_ARG;
+  const int nqb = (q_rows + 31) / 32;
+  if (nqb < 8 && q_colsum) return DIG_ERR_UNSUPPORTED;
+  if ((q_colsum == nullptr) != (v_colsum == nullptr)) return DIG_ERR_ARG;
+  if (!aligned16(qkv_) || !aligned16(ctx_) || !aligned16(dctx_) || !aligned16(dqkv_)) return DIG_ERR_ALIGN;
+  const bf16_t* qkv = (const bf16_t*)qkv_;
+  const bf16_t* ctx = (const bf16_t*)ctx_;
+  const bf16_t* dctx = (const bf16_t*)dctx_;
+  bf16_t* dqkv = (bf16_t*)dqkv_;
+  const int D = embed_dim, ld = 3 * D, nq = nqb * 32;
+  const bool dropping = drop && drop->thr;
+#pragma omp parallel for
+  for (int b = 0; b < n_img; ++b) {
+    std::vector<float> qs(q_colsum ? D : 0, 0.f), vs(q_colsum ? D : 0, 0.f);
+    for (int h = 0; h < heads; ++h) {
+      std::vector<float> dk((size_t)N_TOK * DH, 0.f), dv((size_t)N_TOK * DH, 0.f), p(N_TOK), dp(N_TOK);
+      for (int i = 0; i < nq; ++i) {
+        const size_t row = (size_t)b * N_TOK + i;
+        const bf16_t* q = qkv + row * ld + h * DH;
+        const bf16_t* o = ctx + row * D + h * DH;
+        const bf16_t* go = dctx + row * D + h * DH;
+        const float l = lse[((size_t)b * heads + h) * N_TOK + i];
+        float delta = 0.f;
+        for (int c = 0; c < DH; ++c) delta += bf2f(go[c]) * bf2f(o[c]);
+        for (int j = 0; j < N_TOK; ++j) {
+          const bf16_t* k = qkv + ((size_t)b * N_TOK + j) * ld + D + h * DH;
+          const bf16_t* v = qkv + ((size_t)b * N_TOK + j) * ld + 2 * D + h * DH;
+          float s = 0.f, d = 0.f;
+          for (int c = 0; c < DH; ++c) { s += bf2f(q[c]) * bf2f(k[c]); d += bf2f(go[c]) * bf2f(v[c]); }
+          p[j] = std::exp(s - l);
+          dp[j] = d;
+        }
+        float dq[DH];
+        for (int c = 0; c < DH; ++c) dq[c] = 0.f;
+        for (int j = 0; j < N_TOK; ++j) {
+          float keep = 1.f;
+          if (dropping) keep = drop_keep(drop->k0, drop->k1, ((unsigned)i << 16) | (unsigned)j, (unsigned)(b * heads + h), drop->thr) ? drop->scale : 0.f;
+          const float pd = p[j] * keep;                   // the probability that multiplied V in the forward
+          const float ds = p[j] * (dp[j] * keep - delta); // d(score): softmax backward through the (dropped) probabilities
+          const bf16_t* k = qkv + ((size_t)b * N_TOK + j) * ld + D + h * DH;
+          for (int c = 0; c < DH; ++c) {
+            dq[c] += ds * bf2f(k[c]);
+            dk[(size_t)j * DH + c] += ds * bf2f(q[c]);
+            dv[(size_t)j * DH + c] += pd * bf2f(go[c]);
+          }
+        }
+        for (int c = 0; c < DH; ++c) {
+          dqkv[row * ld + h * DH + c] = f2bf(dq[c] * scale);
+          if (q_colsum) qs[h * DH + c] += dq[c] * scale;
+        }
+      }
+      for (int j = 0; j < N_TOK; ++j)
+        for (int c = 0; c < DH; ++c) {
+          dqkv[((size_t)b * N_TOK + j) * ld + D + h * DH + c] = f2bf(dk[(size_t)j * DH + c]);
+          dqkv[((size_t)b * N_TOK + j) * ld + 2 * D + h * DH + c] = f2bf(dv[(size_t)j * DH + c]);
+          if (q_colsum) vs[h * DH + c] += dv[(size_t)j * DH + c];
+        }
+    }
+    if (q_colsum) {
+      std::memcpy(q_colsum + (size_t)b * D, qs.data(), D * sizeof(float));
+      std::memcpy(v_colsum + (size_t)b * D, vs.data(), D * sizeof(float));
+    }
+  }
+  return DIG_OK;
+}
+
+int dig_attn_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse, void* dqkv, int n_img, int heads, int embed_dim,
+                 float scale, float* q_colsum, float* v_colsum, hipStream_t stream) {
+  return dig_attn_bwd_dropout(qkv, ctx, dctx, lse, dqkv, n_img, heads, embed_dim, scale, q_colsum, v_colsum, nullptr, N_TOK, stream);
+}
+
+// ------------------------------------------------------------------------------------------------------------------ LayerNorm
+static bool ln_dim_ok(int D) { return D == 64 || D == 128 || D == 192 || D == 256 || D == 384 || D == 512; }
+
+int dig_layernorm_fwd(const void* x_, const float* gamma, const float* beta, void* y_, float* mean, float* rstd, int rows, int D, float eps,
+                      int fuse_gelu, hipStream_t) {
+  if (!x_ || !gamma || !beta || !y_ || !mean || !rstd || rows <= 0) return DIG_ERR_ARG;
+  if (!aligned16(x_) || !aligned16(y_)) return DIG_ERR_ALIGN;
+  if (!ln_dim_ok(D)) return DIG_ERR_UNSUPPORTED;
+  const bf16_t* x = (const bf16_t*)x_;
+  bf16_t* y = (bf16_t*)y_;
+#pragma omp parallel for
+  for (int r = 0; r < rows; ++r) {
+    float s = 0.f;
+    for (int c = 0; c < D; ++c) s += bf2f(x[(size_t)r * D + c]);
+    const float mu = s / D;
+    float q = 0.f;
+    for (int c = 0; c < D; ++c) { const float d = bf2f(x[(size_t)r * D + c]) - mu; q += d * d; }
+    const float rs = 1.0f / std::sqrt(q / D + eps);
+    for (int c = 0; c < D; ++c) {
+      float v = (bf2f(x[(size_t)r * D + c]) - mu) * rs * gamma[c] + beta[c];
+      if (fuse_gelu) v = gelu_f(v);
+      y[(size_t)r * D + c] = f2bf(v);
+    }
+    mean[r] = mu;
+    rstd[r] = rs;
+  }
+  return DIG_OK;
+}
+
+int dig_layernorm_bwd_parts(int rows) { return std::max(1, std::min(1024, (rows + 15) / 16)); }
+long long dig_layernorm_bwd_workspace_bytes(int rows, int D) { return (long long)dig_layernorm_bwd_parts(rows) * 3 * D * sizeof(float); }
+
+// the partial rows are the sums over the row slices part p owns (rows p, p + parts, ...); their total is what finalize adds
+int dig_layernorm_bwd_partials(const void* dy_, const void* x_, const float* gamma, const float* beta, const float* mean, const float* rstd,
+                               const void* dres_, void* dx_, float* workspace, int rows, int D, int fuse_gelu, hipStream_t) {
+  if (!dy_ || !x_ || !gamma || !mean || !rstd || !dx_ || !workspace || rows <= 0) return DIG_ERR_ARG;
+  if (fuse_gelu && !beta) return DIG_ERR_ARG;
+  if (!aligned16(x_) || !aligned16(dy_) || !aligned16(dx_) || (dres_ && !aligned16(dres_))) return DIG_ERR_ALIGN;
+  if (!ln_dim_ok(D)) return DIG_ERR_UNSUPPORTED;
+  const bf16_t* dy = (const bf16_t*)dy_;
+  const bf16_t* x = (const bf16_t*)x_;
+  const bf16_t* dres = (const bf16_t*)dres_;
+  bf16_t* dx = (bf16_t*)dx_;
+  const int parts = dig_layernorm_bwd_parts(rows);
+  std::memset(workspace, 0, (size_t)parts * 3 * D * sizeof(float));
+#pragma omp parallel for
+  for (int p = 0; p < parts; ++p) {
+    float* w = workspace + (size_t)p * 3 * D;
+    std::vector<float> xh(D), d(D);
+    for (int r = p; r < rows; r += parts) {
+      float c1 = 0.f, c2 = 0.f;
+      for (int c = 0; c < D; ++c) {
+        xh[c] = (bf2f(x[(size_t)r * D + c]) - mean[r]) * rstd[r];
+        float g = bf2f(dy[(size_t)r * D + c]);
+        if (fuse_gelu) g *= dgelu_f(xh[c] * gamma[c] + beta[c]);
+        w[c] += g * xh[c];
+        w[D + c] += g;
+        d[c] = g * gamma[c];
+        c1 += d[c];
+        c2 += d[c] * xh[c];
+      }
+      c1 /= D;
+      c2 /= D;
+      for (int c = 0; c < D; ++c) {
+        float o = rstd[r] * (d[c] - c1 - xh[c] * c2);
+        if (dres) { const float e = bf2f(dres[(size_t)r * D + c]); o += e; w[2 * D + c] += e; }
+        dx[(size_t)r * D + c] = f2bf(o);
+      }
+    }
+  }
+  return DIG_OK;
+}
+
+int dig_layernorm_bwd_finalize(const float* workspace, int rows, int D, float* dgamma, float* dbeta, float* dcolsum, hipStream_t) {
+  if (!workspace || !dgamma || !dbeta || rows <= 0 || D <= 0 || (D & 15)) return DIG_ERR_ARG;
+  const int parts = dig_layernorm_bwd_parts(rows);
+  for (int c = 0; c < D; ++c) {
+    float a = 0.f, b = 0.f, e = 0.f;
+    for (int p = 0; p < parts; ++p) {
+      a += workspace[(size_t)p * 3 * D + c];
+      b += workspace[(size_t)p * 3 * D + D + c];
+      e += workspace[(size_t)p * 3 * D + 2 * D + c];
+    }
+    dgamma[c] += a;
+    dbeta[c] += b;
+    if (dcolsum) dcolsum[c] += e;
+  }
+  return DIG_OK;
+}
+
+int dig_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean, const float* rstd,
+                      const void* dres, void* dx, float* dgamma, float* dbeta, float* dcolsum, float* workspace, int rows, int D,
+                      int fuse_gelu, hipStream_t stream) {
+  if (!dgamma || !dbeta || (dcolsum && !dres)) return DIG_ERR_ARG;
+  const int rc = dig_layernorm_bwd_partials(dy, x, gamma, beta, mean, rstd, dres, dx, workspace, rows, D, fuse_gelu, stream);
+  if (rc != DIG_OK) return rc;
+  return dig_layernorm_bwd_finalize(workspace, rows, D, dgamma, dbeta, dcolsum, stream);
+}
+
+// ------------------------------------------------------------------------------------------------------------------ BatchNorm
+long long dig_bn_stats_workspace_bytes(int rows, int C) { return (long long)((rows + 63) / 64) * 2 * C * sizeof(float); }
+
+int dig_bn_stats(const void* x_, float* sums, float* workspace, int rows, int C, hipStream_t) {
+  if (!x_ || !sums || !workspace || rows <= 0 || C <= 0 || (C & 7)) return DIG_ERR_ARG;
+  const bf16_t* x = (const bf16_t*)x_;
+#pragma omp parallel for
+  for (int c = 0; c < C; ++c) {
+    float a = 0.f, b = 0.f;
+    for (int r = 0; r < rows; ++r) { const float v = bf2f(x[(size_t)r * C + c]); a += v; b += v * v; }
+    sums[c] = a;
+    sums[C + c] = b;
+  }
+  return DIG_OK;
+}
+
+int dig_bn_fwd_apply(const void* x_, const float* sums, float n_total, float eps, const float* gamma, const float* beta, int relu, void* y_,
+                     float* mean_out, float* rstd_out, int rows, int C, hipStream_t) {
+  if (!x_ || !sums || !y_ || !mean_out || !rstd_out || rows <= 0 || C <= 0 || (C & 7) || n_total <= 0.f) return DIG_ERR_ARG;
+  if ((gamma == nullptr) != (beta == nullptr)) return DIG_ERR_ARG;
+  const bf16_t* x = (const bf16_t*)x_;
+  bf16_t* y = (bf16_t*)y_;
+  const float inv_n = 1.0f / n_total;
+#pragma omp parallel for
+  for (int c = 0; c < C; ++c) {
+    const float mu = sums[c] * inv_n;
+    const float var = std::max(sums[C + c] * inv_n - mu * mu, 0.f);
+    const float rs = 1.0f / std::sqrt(var + eps);
+    mean_out[c] = mu;
+    rstd_out[c] = rs;
+    for (int r = 0; r < rows; ++r) {
+      float o = (bf2f(x[(size_t)r * C + c]) - mu) * rs;
+      if (gamma) o = o * gamma[c] + beta[c];
+      if (relu) o = std::max(o, 0.f);
+      y[(size_t)r * C + c] = f2bf(o);
+    }
+  }
+  return DIG_OK;
+}
+
+int dig_bn_update_running(const float* sums, float n_total, float momentum, float* running_mean, float* running_var, int C, hipStream_t) {
+  if (!sums || !running_mean || !running_var || C <= 0 || n_total <= 1.f) return DIG_ERR_ARG;
+  for (int c = 0; c < C; ++c) {
+    const float mu = sums[c] / n_total;
+    const float var = std::max(sums[C + c] / n_total - mu * mu, 0.f);
+    running_mean[c] = running_mean[c] * (1.f - momentum) + mu * momentum;
+    running_var[c] = running_var[c] * (1.f - momentum) + var * (n_total / (n_total - 1.f)) * momentum;
+  }
+  return DIG_OK;
+}
+
+int dig_bn_bwd_stats(const void* dy_, const void* x_, const float* mean, const float* rstd, const float* gamma, const float* beta, int relu,
+                     float* sums, float* workspace, int rows, int C, hipStream_t) {
+  if (!dy_ || !x_ || !mean || !rstd || !sums || !workspace || rows <= 0 || C <= 0 || (C & 7)) return DIG_ERR_ARG;
+  const bf16_t* dy = (const bf16_t*)dy_;
+  const bf16_t* x = (const bf16_t*)x_;
+#pragma omp parallel for
+  for (int c = 0; c < C; ++c) {
+    const float g0 = gamma ? gamma[c] : 1.f, b0 = gamma ? beta[c] : 0.f;
+    float a = 0.f, b = 0.f;
+    for (int r = 0; r < rows; ++r) {
+      const float xh = (bf2f(x[(size_t)r * C + c]) - mean[c]) * rstd[c];
+      float d = bf2f(dy[(size_t)r * C + c]);
+      if (relu && !(g0 * xh + b0 > 0.f)) d = 0.f;
+      a += d;
+      b += d * xh;
+    }
+    sums[c] = a;
+    sums[C + c] = b;
+  }
+  return DIG_OK;
+}
+
+int dig_bn_bwd_apply(const void* dy_, const void* x_, const float* mean, const float* rstd, const float* gamma, const float* beta, int relu,
+                     const float* sums, float n_total, void* dx_, int rows, int C, hipStream_t) {
+  if (!dy_ || !x_ || !mean || !rstd || !sums || !dx_ || rows <= 0 || C <= 0 || (C & 7) || n_total <= 0.f) return DIG_ERR_ARG;
+  const bf16_t* dy = (const bf16_t*)dy_;
+  const bf16_t* x = (const bf16_t*)x_;
+  bf16_t* dx = (bf16_t*)dx_;
+  const float inv_n = 1.0f / n_total;
+#pragma omp parallel for
+  for (int c = 0; c < C; ++c) {
+    const float g0 = gamma ? gamma[c] : 1.f, b0 = gamma ? beta[c] : 0.f;
+    const float s1 = sums[c] * inv_n, s2 = sums[C + c] * inv_n;
+    for (int r = 0; r < rows; ++r) {
+      const float xh = (bf2f(x[(size_t)r * C + c]) - mean[c]) * rstd[c];
+      float g = bf2f(dy[(size_t)r * C + c]);
+      if (relu && !(g0 * xh + b0 > 0.f)) g = 0.f;
+      dx[(size_t)r * C + c] = f2bf(g0 * rstd[c] * (g - s1 - xh * s2));
+    }
+  }
+  return DIG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------ patch embedding
+int dig_patch_embed_fwd(const float* img, const float* W, const float* bias, const unsigned char* mask, const float* mask_token,
+                        const float* pos, void* out_, int n_img, int gh, int gw, int D, hipStream_t) {
+  if (!img || !W || !bias || !mask_token || !pos || !out_ || n_img <= 0 || D <= 0 || D > 1024 || (D & 63)) return DIG_ERR_ARG;
+  bf16_t* out = (bf16_t*)out_;
+  const int ntok = gh * gw, Himg = gh * 4, Wimg = gw * 4;
+#pragma omp parallel for
+  for (int t = 0; t < n_img * ntok; ++t) {
+    const int b = t / ntok, n = t % ntok, ph = n / gw, pw = n % gw;
+    float patch[48];
+    for (int k = 0; k < 48; ++k) {
+      const int c = k >> 4, p1 = (k >> 2) & 3, p2 = k & 3;
+      patch[k] = img[(((size_t)b * 3 + c) * Himg + ph * 4 + p1) * Wimg + pw * 4 + p2];
+    }
+    const bool m = mask && mask[t];
+    for (int d = 0; d < D; ++d) {
+      float acc = bias[d];
+      for (int k = 0; k < 48; ++k) acc += patch[k] * W[d * 48 + k];
+      out[(size_t)t * D + d] = f2bf((m ? mask_token[d] : acc) + pos[(size_t)n * D + d]);
+    }
+  }
+  return DIG_OK;
+}
+
+int dig_patch_embed_bwd(const void* dy_, const float* img, const unsigned char* mask, float* dW, float* dbias, float* dmask_token, int n_img,
+                        int gh, int gw, int D, hipStream_t) {
+  if (!dy_ || !img || !dW || !dbias || !dmask_token || n_img <= 0 || D <= 0 || D > 1024 || (D & 63)) return DIG_ERR_ARG;
+  const bf16_t* dy = (const bf16_t*)dy_;
+  const int ntok = gh * gw, Himg = gh * 4, Wimg = gw * 4;
+#pragma omp parallel for
+  for (int d = 0; d < D; ++d) {
+    float acc[48], ab = 0.f, am = 0.f;
+    for (int k = 0; k < 48; ++k) acc[k] = 0.f;
+    for (int t = 0; t < n_img * ntok; ++t) {
+      const float g = bf2f(dy[(size_t)t * D + d]);
+      if (mask && mask[t]) { am += g; continue; }
+      ab += g;
+      const int b = t / ntok, n = t % ntok, ph = n / gw, pw = n % gw;
+      for (int k = 0; k < 48; ++k) {
+        const int c = k >> 4, p1 = (k >> 2) & 3, p2 = k & 3;
+        acc[k] += g * img[(((size_t)b * 3 + c) * Himg + ph * 4 + p1) * Wimg + pw * 4 + p2];
+      }
+    }
+    for (int k = 0; k < 48; ++k) dW[d * 48 + k] += acc[k];
+    dbias[d] += ab;
+    dmask_token[d] += am;
+  }
+  return DIG_OK;
+}
+
+int dig_patchify_bf16(const float* img, const unsigned char* mask, void* out_, int n_img, int gh, int gw, hipStream_t) {
+  if (!img || !out_ || n_img <= 0) return DIG_ERR_ARG;
+  if (!aligned16(img) || !aligned16(out_)) return DIG_ERR_ALIGN;
+  bf16_t* out = (bf16_t*)out_;
+  const int ntok = gh * gw, Himg = gh * 4, Wimg = gw * 4;
+#pragma omp parallel for
+  for (int t = 0; t < n_img * ntok; ++t) {
+    const int b = t / ntok, n = t % ntok, ph = n / gw, pw = n % gw;
+    const bool m = mask && mask[t];
+    for (int k = 0; k < 64; ++k) {
+      float v = 0.f;
+      if (k < 48 && !m) {
+        const int c = k >> 4, p1 = (k >> 2) & 3, p2 = k & 3;
+        v = img[(((size_t)b * 3 + c) * Himg + ph * 4 + p1) * Wimg + pw * 4 + p2];
+      }
+      out[(size_t)t * 64 + k] = f2bf(v);
+    }
+  }
+  return DIG_OK;
+}
+
+long long dig_colsum_workspace_bytes(int rows, int C) { return (long long)((rows + 63) / 64) * C * sizeof(float); }
+
+int dig_colsum_masked(const void* x_, const unsigned char* mask, float* out_unmasked, float* out_masked, float* workspace, int rows, int C,
+                      hipStream_t) {
+  if (!x_ || !mask || !out_unmasked || !out_masked || !workspace || rows <= 0 || C <= 0 || (C & 7)) return DIG_ERR_ARG;
+  if (!aligned16(x_)) return DIG_ERR_ALIGN;
+  const bf16_t* x = (const bf16_t*)x_;
+#pragma omp parallel for
+  for (int c = 0; c < C; ++c) {
+    float a = 0.f, b = 0.f;
+    for (int r = 0; r < rows; ++r) (mask[r] ? b : a) += bf2f(x[(size_t)r * C + c]);
+    out_unmasked[c] += a;
+    out_masked[c] += b;
+  }
+  return DIG_OK;
+}
+
+int dig_window_pool_fwd(const void* x_, void* out, int out_is_f32, int n_img, int gh, int gw, int nwin, int D, hipStream_t) {
+  if (!x_ || !out || n_img <= 0 || nwin <= 0 || gw % nwin || (D & 1)) return DIG_ERR_ARG;
+  const bf16_t* x = (const bf16_t*)x_;
+  const int wlen = gw / nwin;
+  const float inv = 1.0f / (gh * wlen);
+#pragma omp parallel for
+  for (int idx = 0; idx < n_img * nwin; ++idx) {
+    const int img = idx / nwin, win = idx % nwin;
+    for (int d = 0; d < D; ++d) {
+      float a = 0.f;
+      for (int r = 0; r < gh; ++r)
+        for (int c = 0; c < wlen; ++c) a += bf2f(x[((size_t)img * gh * gw + r * gw + win * wlen + c) * D + d]);
+      if (out_is_f32) ((float*)out)[(size_t)idx * D + d] = a * inv;
+      else ((bf16_t*)out)[(size_t)idx * D + d] = f2bf(a * inv);
+    }
+  }
+  return DIG_OK;
+}
+
+int dig_window_pool_bwd(const void* dpool_, void* dx_, int n_img, int gh, int gw, int nwin, int D, int accumulate, hipStream_t) {
+  if (!dpool_ || !dx_ || n_img <= 0 || nwin <= 0 || gw % nwin || (D & 1)) return DIG_ERR_ARG;
+  const bf16_t* dpool = (const bf16_t*)dpool_;
+  bf16_t* dx = (bf16_t*)dx_;
+  const int ntok = gh * gw;
+  const float inv = 1.0f / (gh * (gw / nwin));
+#pragma omp parallel for
+  for (int t = 0; t < n_img * ntok; ++t) {
+    const int img = t / ntok, n = t % ntok, win = (n % gw) / (gw / nwin);
+    for (int d = 0; d < D; ++d) {
+      float a = bf2f(dpool[((size_t)img * nwin + win) * D + d]) * inv;
+      if (accumulate) a += bf2f(dx[(size_t)t * D + d]);
+      dx[(size_t)t * D + d] = f2bf(a);
+    }
+  }
+  return DIG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------ SimMIM plumbing
+int dig_mask_to_index(const unsigned char* mask, int* idx, int* count, int B, int N, int max_per_sample, hipStream_t) {
+  if (!mask || !idx || !count || B <= 0 || N <= 0 || max_per_sample <= 0) return DIG_ERR_ARG;
+  for (int b = 0; b < B; ++b) {
+    int k = 0;
+    for (int n = 0; n < N; ++n)
+      if (mask[(size_t)b * N + n]) {
+        if (k < max_per_sample) idx[(size_t)b * max_per_sample + k] = b * N + n;
+        ++k;
+      }
+    count[b] = k;
+  }
+  return DIG_OK;
+}
+
+int dig_gather_rows(const void* src_, const int* idx, void* dst_, int M, int M_pad, int D, hipStream_t) {
+  if (!src_ || !idx || !dst_ || M <= 0 || M_pad < M || (D & 7)) return DIG_ERR_ARG;
+  if (!aligned16(src_) || !aligned16(dst_)) return DIG_ERR_ALIGN;
+  const bf16_t* src = (const bf16_t*)src_;
+  bf16_t* dst = (bf16_t*)dst_;
+  for (int m = 0; m < M_pad; ++m) {
+    if (m < M) std::memcpy(dst + (size_t)m * D, src + (size_t)idx[m] * D, D * 2);
+    else std::memset(dst + (size_t)m * D, 0, D * 2);
+  }
+  return DIG_OK;
+}
+
+int dig_scatter_rows_add(const void* src_, const int* idx, void* dst_, int M, int D, hipStream_t) {
+  if (!src_ || !idx || !dst_ || M <= 0 || (D & 7)) return DIG_ERR_ARG;
+  if (!aligned16(src_) || !aligned16(dst_)) return DIG_ERR_ALIGN;
+  const bf16_t* src = (const bf16_t*)src_;
+  bf16_t* dst = (bf16_t*)dst_;
+  for (int m = 0; m < M; ++m)
+    for (int c = 0; c < D; ++c) dst[(size_t)idx[m] * D + c] = f2bf(bf2f(dst[(size_t)idx[m] * D + c]) + bf2f(src[(size_t)m * D + c]));
+  return DIG_OK;
+}
+
+int dig_mim_target(const float* img, const int* idx, float* target, int M, int gh, int gw, int normalize, hipStream_t) {
+  if (!img || !idx || !target || M <= 0) return DIG_ERR_ARG;
+  const int ntok = gh * gw, Himg = gh * 4, Wimg = gw * 4;
+  for (int m = 0; m < M; ++m) {
+    const int t = idx[m], b = t / ntok, n = t % ntok, ph = n / gw, pw = n % gw;
+    for (int c = 0; c < 3; ++c) {
+      const float* base = img + (((size_t)b * 3 + c) * Himg + ph * 4) * Wimg + pw * 4;
+      float v[16], mean = 0.f;
+      for (int q = 0; q < 16; ++q) { v[q] = base[(q >> 2) * Wimg + (q & 3)] * 0.5f + 0.5f; mean += v[q]; }
+      mean *= (1.0f / 16.0f);
+      float var = 0.f;
+      for (int q = 0; q < 16; ++q) var += (v[q] - mean) * (v[q] - mean);
+      const float sd = std::sqrt(var * (1.0f / 15.0f)) + 1e-6f;
+      for (int q = 0; q < 16; ++q) target[(size_t)m * 48 + q * 3 + c] = normalize ? (v[q] - mean) / sd : v[q];
+    }
+  }
+  return DIG_OK;
+}
+
+int dig_mse_fwd_bwd(const float* pred, int ld_pred, const float* target, int M, int C, float gscale, float* loss, void* dpred_, int ld_dpred,
+                    hipStream_t) {
+  if (!pred || !target || M <= 0 || C <= 0 || ld_pred < C || (dpred_ && ld_dpred < C)) return DIG_ERR_ARG;
+  bf16_t* dpred = (bf16_t*)dpred_;
+  const float inv = 1.0f / ((float)M * (float)C);
+  double acc = 0.0;
+  for (int m = 0; m < M; ++m)
+    for (int c = 0; c < (dpred ? ld_dpred : C); ++c) {
+      float g = 0.f;
+      if (c < C) {
+        const float df = pred[(size_t)m * ld_pred + c] - target[(size_t)m * C + c];
+        acc += (double)df * df;
+        g = 2.f * df * inv * gscale;
+      }
+      if (dpred) dpred[(size_t)m * ld_dpred + c] = f2bf(g);
+    }
+  if (loss) loss[0] += (float)(acc * inv);
+  return DIG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------ InfoNCE
+int dig_l2norm_fwd(const float* x, float* y, float* inv_norm, int n, int C, float eps, hipStream_t) {
+  if (!x || !y || !inv_norm || n <= 0 || C <= 0) return DIG_ERR_ARG;
+  for (int r = 0; r < n; ++r) {
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += x[(size_t)r * C + c] * x[(size_t)r * C + c];
+    const float inv = 1.0f / std::max(std::sqrt(s), eps);
+    for (int c = 0; c < C; ++c) y[(size_t)r * C + c] = x[(size_t)r * C + c] * inv;
+    inv_norm[r] = inv;
+  }
+  return DIG_OK;
+}
+
+int dig_l2norm_bwd(const float* dy, const float* y, const float* inv_norm, float* dx, int n, int C, hipStream_t) {
+  if (!dy || !y || !inv_norm || !dx || n <= 0 || C <= 0) return DIG_ERR_ARG;
+  for (int r = 0; r < n; ++r) {
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += y[(size_t)r * C + c] * dy[(size_t)r * C + c];
+    for (int c = 0; c < C; ++c) dx[(size_t)r * C + c] = (dy[(size_t)r * C + c] - y[(size_t)r * C + c] * s) * inv_norm[r];
+  }
+  return DIG_OK;
+}
+
+int dig_sgemm(const float* A, const float* B, float* C, int I, int J, int R, int lda, int ldb, int ldc, int trans_b, float alpha,
+              int r_splits, hipStream_t) {
+  if (!A || !B || !C || I <= 0 || J <= 0 || R <= 0 || r_splits < 1) return DIG_ERR_ARG;
+  const int per = ((R + r_splits - 1) / r_splits + 63) / 64 * 64;
+  if ((R + per - 1) / per != r_splits) return DIG_ERR_ARG;
+#pragma omp parallel for collapse(2)
+  for (int s = 0; s < r_splits; ++s)
+    for (int i = 0; i < I; ++i)
+      for (int j = 0; j < J; ++j) {
+        float acc = 0.f;
+        for (int r = s * per; r < std::min(R, (s + 1) * per); ++r) acc += A[(size_t)i * lda + r] * (trans_b ? B[(size_t)r * ldb + j] : B[(size_t)j * ldb + r]);
+        C[((size_t)s * I + i) * ldc + j] = alpha * acc;
+      }
+  return DIG_OK;
+}
+
+int dig_ce_rows(float* logits, int n, int m, int label_offset, float gscale, float* out3, hipStream_t) {
+  if (!logits || !out3 || n <= 0 || m <= 0 || label_offset < 0 || label_offset + n > m) return DIG_ERR_ARG;
+  for (int i = 0; i < n; ++i) {
+    float* row = logits + (size_t)i * m;
+    const int label = i + label_offset;
+    float mx = -3.0e38f;
+    for (int j = 0; j < m; ++j) mx = std::max(mx, row[j]);
+    const float zl = row[label];
+    float s = 0.f;
+    int gt = 0;
+    for (int j = 0; j < m; ++j) { s += std::exp(row[j] - mx); gt += row[j] > zl; }
+    const float lse = mx + std::log(s);
+    for (int j = 0; j < m; ++j) row[j] = gscale * (std::exp(row[j] - mx) / s - (j == label ? 1.f : 0.f));
+    out3[0] += lse - zl;
+    if (gt < 1) out3[1] += 1.f;
+    if (gt < 5) out3[2] += 1.f;
+  }
+  return DIG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------ optimizer
+static int adamw_core(float* p, const float* g, float* m, float* v, bf16_t* shadow, long long n, const unsigned char* group, float lr0,
+                      float wd0, float lr1, float wd1, float beta1, float beta2, float eps, float inv_bc1, float inv_sqrt_bc2,
+                      float grad_scale, const float* finite_gate) {
+  if (finite_gate && !std::isfinite(finite_gate[0])) return DIG_OK;
+#pragma omp parallel for
+  for (long long i = 0; i < n; ++i) {
+    const int grp = group[i >> 8];
+    const float lr = grp ? lr1 : lr0, wd = grp ? wd1 : wd0;
+    const float gk = g[i] * grad_scale;
+    float P = p[i] * (1.0f - lr * wd);
+    const float M = m[i] * beta1 + gk * (1.0f - beta1);
+    const float V = v[i] * beta2 + gk * gk * (1.0f - beta2);
+    P -= (lr * inv_bc1) * (M / (std::sqrt(V) * inv_sqrt_bc2 + eps));
+    p[i] = P; m[i] = M; v[i] = V;
+    if (shadow) shadow[i] = f2bf(P);
+  }
+  return DIG_OK;
+}
+
+int dig_adamw_bias_corrections(float beta1, float beta2, int step, float* out2) {
+  if (!out2 || step < 1) return DIG_ERR_ARG;
+  out2[0] = (float)(1.0 / (1.0 - std::pow((double)beta1, (double)step)));
+  out2[1] = (float)(1.0 / std::sqrt(1.0 - std::pow((double)beta2, (double)step)));
+  return DIG_OK;
+}
+
+int dig_adamw_step(float* p, const float* g, float* m, float* v, void* bf16_shadow, long long n, const unsigned char* group_flags, float lr0,
+                   float wd0, float lr1, float wd1, float beta1, float beta2, float eps, int step, float grad_scale, const float* finite_gate,
+                   hipStream_t) {
+  if (!p || !g || !m || !v || !group_flags || n <= 0 || (n & 255) || step < 1) return DIG_ERR_ARG;
+  if (!aligned16(p) || !aligned16(g) || !aligned16(m) || !aligned16(v)) return DIG_ERR_ALIGN;
+  float bc[2];
+  dig_adamw_bias_corrections(beta1, beta2, step, bc);
+  return adamw_core(p, g, m, v, (bf16_t*)bf16_shadow, n, group_flags, lr0, wd0, lr1, wd1, beta1, beta2, eps, bc[0], bc[1], grad_scale, finite_gate);
+}
+
+int dig_adamw_step_dev(float* p, const float* g, float* m, float* v, void* bf16_shadow, long long n, const unsigned char* group_flags,
+                       const float* s6, float beta1, float beta2, float eps, float grad_scale, const float* finite_gate, hipStream_t) {
+  if (!p || !g || !m || !v || !group_flags || !s6 || n <= 0 || (n & 255)) return DIG_ERR_ARG;
+  if (!aligned16(p) || !aligned16(g) || !aligned16(m) || !aligned16(v)) return DIG_ERR_ALIGN;
+  return adamw_core(p, g, m, v, (bf16_t*)bf16_shadow, n, group_flags, s6[0], s6[1], s6[2], s6[3], beta1, beta2, eps, s6[4], s6[5], grad_scale, finite_gate);
+}
+
+// any number of parameter groups (layer-wise lr decay): group_idx per 256-element granule indexes lr_tab / wd_tab; 255 = no gradient
+int dig_adamw_step_groups(float* p, const float* g, float* m, float* v, void* bf16_shadow, long long n, const unsigned char* group_idx,
+                          const float* lr_tab, const float* wd_tab, float beta1, float beta2, float eps, int step, float grad_scale,
+                          const float* finite_gate, hipStream_t) {
+  if (!p || !g || !m || !v || !group_idx || !lr_tab || !wd_tab || n <= 0 || (n & 255) || step < 1) return DIG_ERR_ARG;
+  if (!aligned16(p) || !aligned16(g) || !aligned16(m) || !aligned16(v)) return DIG_ERR_ALIGN;
+  if (finite_gate && !std::isfinite(finite_gate[0])) return DIG_OK;
+  float bc[2];
+  dig_adamw_bias_corrections(beta1, beta2, step, bc);
+  bf16_t* shadow = (bf16_t*)bf16_shadow;
+#pragma omp parallel for
+  for (long long i = 0; i < n; ++i) {
+    const int grp = group_idx[i >> 8];
+    if (grp != 255) {
+      const float lr = lr_tab[grp], wd = wd_tab[grp], gk = g[i] * grad_scale;
+      float P = p[i] * (1.0f - lr * wd);
+      const float M = m[i] * beta1 + gk * (1.0f - beta1);
+      const float V = v[i] * beta2 + gk * gk * (1.0f - beta2);
+      P -= (lr * bc[0]) * (M / (std::sqrt(V) * bc[1] + eps));
+      p[i] = P; m[i] = M; v[i] = V;
+    }
+    if (shadow) shadow[i] = f2bf(p[i]);
+  }
+  return DIG_OK;
+}
+
+static int ema_core(float* pm, const float* p, bf16_t* shadow, long long n, float m, float om) {
+#pragma omp parallel for
+  for (long long i = 0; i < n; ++i) {
+    pm[i] = pm[i] * m + p[i] * om;
+    if (shadow) shadow[i] = f2bf(pm[i]);
+  }
+  return DIG_OK;
+}
+int dig_ema_update(float* pm, const float* p, void* bf16_shadow, long long n, float m, hipStream_t) {
+  if (!pm || !p || n <= 0 || (n & 3)) return DIG_ERR_ARG;
+  if (!aligned16(pm) || !aligned16(p)) return DIG_ERR_ALIGN;
+  return ema_core(pm, p, (bf16_t*)bf16_shadow, n, m, (float)(1.0 - (double)m));
+}
+int dig_ema_update_dev(float* pm, const float* p, void* bf16_shadow, long long n, const float* mm, hipStream_t) {
+  if (!pm || !p || !mm || n <= 0 || (n & 3)) return DIG_ERR_ARG;
+  if (!aligned16(pm) || !aligned16(p)) return DIG_ERR_ALIGN;
+  return ema_core(pm, p, (bf16_t*)bf16_shadow, n, mm[0], mm[1]);
+}
+
+long long dig_sumsq_workspace_bytes(long long) { return 1024 * sizeof(float); }
+int dig_sumsq(const float* x, long long n, float* workspace, float* out, hipStream_t) {
+  if (!x || !workspace || !out || n <= 0 || (n & 3)) return DIG_ERR_ARG;
+  if (!aligned16(x)) return DIG_ERR_ALIGN;
+  double acc = 0.0;
+  for (long long i = 0; i < n; ++i) acc += (double)x[i] * x[i];
+  out[0] = (float)acc;
+  return DIG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------ helpers
+int dig_colsum(const void* x_, float* out, float* workspace, int rows, int C, int ld, hipStream_t) {
+  if (!x_ || !out || !workspace || rows <= 0 || C <= 0 || (C & 7) || (ld & 7)) return DIG_ERR_ARG;
+  if (!aligned16(x_)) return DIG_ERR_ALIGN;
+  const bf16_t* x = (const bf16_t*)x_;
+#pragma omp parallel for
+  for (int c = 0; c < C; ++c) {
+    float a = 0.f;
+    for (int r = 0; r < rows; ++r) a += bf2f(x[(size_t)r * ld + c]);
+    out[c] += a;
+  }
+  return DIG_OK;
+}
+
+int dig_colsum_partials(const float* partials, int n_parts, int C, float* out, hipStream_t) {
+  if (!partials || !out || n_parts <= 0 || C <= 0 || (C & 7)) return DIG_ERR_ARG;
+  if (!aligned16(partials)) return DIG_ERR_ALIGN;
+  for (int c = 0; c < C; ++c) {
+    float a = 0.f;
+    for (int b = 0; b < n_parts; ++b) a += partials[(size_t)b * C + c];
+    out[c] += a;
+  }
+  return DIG_OK;
+}
+
+int dig_gelu_bwd(const void* dact_, const void* pre_, void* dpre_, long long n, hipStream_t) {
+  if (!dact_ || !pre_ || !dpre_ || n <= 0 || (n & 7)) return DIG_ERR_ARG;
+  if (!aligned16(dact_) || !aligned16(pre_) || !aligned16(dpre_)) return DIG_ERR_ALIGN;
+  const bf16_t* dact = (const bf16_t*)dact_;
+  const bf16_t* pre = (const bf16_t*)pre_;
+  bf16_t* dpre = (bf16_t*)dpre_;
+#pragma omp parallel for
+  for (long long i = 0; i < n; ++i) dpre[i] = f2bf(bf2f(dact[i]) * dgelu_f(bf2f(pre[i])));
+  return DIG_OK;
+}
+
+int dig_add_bf16(const void* a_, const void* b_, void* out_, long long n, hipStream_t) {
+  if (!a_ || !b_ || !out_ || n <= 0 || (n & 7)) return DIG_ERR_ARG;
+  if (!aligned16(a_) || !aligned16(b_) || !aligned16(out_)) return DIG_ERR_ALIGN;
+  const bf16_t* a = (const bf16_t*)a_;
+  const bf16_t* b = (const bf16_t*)b_;
+  bf16_t* o = (bf16_t*)out_;
+  for (long long i = 0; i < n; ++i) o[i] = f2bf(bf2f(a[i]) + bf2f(b[i]));
+  return DIG_OK;
+}
+
+int dig_cast_f32_to_bf16(const float* x, void* y, long long n, hipStream_t) {
+  if (!x || !y || n <= 0 || (n & 3)) return DIG_ERR_ARG;
+  if (!aligned16(x) || (((uintptr_t)y) & 7)) return DIG_ERR_ALIGN;
+  for (long long i = 0; i < n; ++i) ((bf16_t*)y)[i] = f2bf(x[i]);
+  return DIG_OK;
+}
+
+int dig_cast_bf16_to_f32(const void* x, float* y, long long n, hipStream_t) {
+  if (!x || !y || n <= 0 || (n & 3)) return DIG_ERR_ARG;
+  if (!aligned16(y) || (((uintptr_t)x) & 7)) return DIG_ERR_ALIGN;
+  for (long long i = 0; i < n; ++i) y[i] = bf2f(((const bf16_t*)x)[i]);
+  return DIG_OK;
+}
+
+int dig_pad_cast_rows(const float* src, void* dst_, int M, int C, int M_pad, int ld, hipStream_t) {
+  if (!src || !dst_ || M <= 0 || C <= 0 || M_pad < M || ld < C) return DIG_ERR_ARG;
+  bf16_t* dst = (bf16_t*)dst_;
+  for (int r = 0; r < M_pad; ++r)
+    for (int c = 0; c < ld; ++c) dst[(size_t)r * ld + c] = (r < M && c < C) ? f2bf(src[(size_t)r * C + c]) : (bf16_t)0;
+  return DIG_OK;
+}
+
+int dig_fill_f32(float* x, long long n, float value, hipStream_t) {
+  if (!x || n <= 0 || (n & 3)) return DIG_ERR_ARG;
+  if (!aligned16(x)) return DIG_ERR_ALIGN;
+  std::fill(x, x + n, value);
+  return DIG_OK;
+}
+
+int dig_scale_f32(float* x, long long n, float s, hipStream_t) {
+  if (!x || n <= 0 || (n & 3)) return DIG_ERR_ARG;
+  if (!aligned16(x)) return DIG_ERR_ALIGN;
+  for (long long i = 0; i < n; ++i) x[i] *= s;
+  return DIG_OK;
+}
+
+int dig_scale_by_device_scalar(float* x, long long n, const float* scalar, float extra, hipStream_t) {
+  if (!x || !scalar || n <= 0) return DIG_ERR_ARG;
+  const float s = scalar[0] * extra;
+  for (long long i = 0; i < n; ++i) x[i] *= s;
+  return DIG_OK;
+}
+
+int dig_axpy_f32(float* y, const float* x, long long n, float a, hipStream_t) {
+  if (!y || !x || n <= 0) return DIG_ERR_ARG;
+  for (long long i = 0; i < n; ++i) y[i] += a * x[i];
+  return DIG_OK;
+}
+
+int dig_dropout_apply(const void* in_, void* out_, long long rows, int cols, const dig_dropout_t* drop, hipStream_t) {
+  if (!in_ || !out_ || !drop || rows <= 0 || cols <= 0 || (cols & 7) || rows * cols >= (1ll << 32)) return DIG_ERR_ARG;
+  if (drop->pthr && drop->rows_per_sample <= 0) return DIG_ERR_ARG;
+  if (!aligned16(in_) || !aligned16(out_)) return DIG_ERR_ALIGN;
+  const bf16_t* in = (const bf16_t*)in_;
+  bf16_t* out = (bf16_t*)out_;
+#pragma omp parallel for
+  for (long long i = 0; i < rows; ++i)
+    for (int j = 0; j < cols; ++j) out[i * cols + j] = f2bf(bf2f(in[i * cols + j]) * drop_factor(*drop, i, j, cols));
+  return DIG_OK;
+}
+
+}  // extern "C"

@@ -1,5 +1,7 @@
-"""Kernel-level parity on the MI355X: every C-ABI op against a plain PyTorch fp32 reference of the same op
-(bf16 I/O => tolerance 1e-2 relative Frobenius; fp32 / integer paths tight or exact)."""
+"""Operator-level parity: every C-ABI op of the pre-training step against a plain PyTorch fp32 reference of the same op
+(bf16 I/O => tolerance 1e-2 relative Frobenius; fp32 / integer paths tight or exact).  Every test runs twice: on the MI355X
+through libdig_hip.so (`hip`, marked gpu) and in the GPU-less container through cpu_abi/libdig_cpu.so, the plain-C++ build of the
+same entry points (`cpu_abi`; same dig_amd/ops.py host code, large shapes skipped: the loops are not meant to be fast)."""
 import ctypes
 import math
 
@@ -10,17 +12,27 @@ import torch.nn.functional as F
 
 from gpu_util import rel
 
-pytestmark = pytest.mark.gpu
 cf = ctypes.c_float
 
 
-@pytest.fixture(scope="module")
-def dev():
-    assert torch.cuda.is_available(), "GPU tests need an MI355X"
-    from dig_amd import _lib
-    _lib.lib()
+@pytest.fixture(scope="module", params=[pytest.param("hip", marks=pytest.mark.gpu), "cpu_abi"])
+def dev(request):
     torch.manual_seed(0)
-    return torch.device("cuda:0")
+    if request.param == "hip":
+        assert torch.cuda.is_available(), "GPU tests need an MI355X"
+        from dig_amd import _lib
+        _lib.lib()
+        yield torch.device("cuda:0")
+    else:
+        from cpu_abi_util import cpu_abi_backend
+        with cpu_abi_backend() as d:
+            yield d
+
+
+def cpu_limit(dev, work, limit=6e9):
+    """The plain-loop build covers the small and ragged shapes; the big ones stay on the GPU."""
+    if dev.type == "cpu" and work > limit:
+        pytest.skip("cpu_abi: large shape, covered by the hip run")
 
 
 @pytest.mark.parametrize("I,J,R", [(256, 256, 128), (2048, 1152, 384), (716, 48, 192), (8192, 1536, 384), (1024, 4096, 4096),
@@ -28,6 +40,7 @@ def dev():
 @pytest.mark.parametrize("bk", [32, 64])
 def test_gemm_fwd_dgrad_wgrad(dev, I, J, R, bk):
     from dig_amd import ops
+    cpu_limit(dev, I * J * R * (1 if bk == 64 else 1e9))            # (the tile code means nothing to the CPU build: one pass)
     ops.GEMM_BK_FWD = ops.GEMM_BK_BWD = bk
     try:
         x = torch.randn(I, R, device=dev).bfloat16()
@@ -74,6 +87,7 @@ def test_gemm_wide_tile_variants(dev, I, J, R, bk):
     """Every multi-wave tile shape of gemm_wide_kernel (WM x WN waves of FM x FN MFMA blocks) on full and ragged tiles:
     forward epilogues, transposed-B (dgrad) and split-R partial slabs (wgrad)."""
     from dig_amd import ops
+    cpu_limit(dev, I * J * R * (1 if bk == 244 else 1e9))
     x = torch.randn(I, R, device=dev).bfloat16()
     w = (torch.randn(J, R, device=dev) * 0.05).bfloat16()
     bias = torch.randn(J, device=dev)
