@@ -59,15 +59,15 @@ inline unsigned drop_hash(unsigned k0, unsigned k1, unsigned a, unsigned b) {
   return x;
 }
 inline bool drop_keep(unsigned k0, unsigned k1, unsigned a, unsigned b, unsigned thr) { return drop_hash(k0, k1, a, b) >= thr; }
-// factor of element (i, j) of a [rows, cols] tensor under element dropout + drop-path (common.h dig_drop_apply8)
-inline float drop_factor(const dig_dropout_t& d, long long i, int j, int cols) {
+// element (i, j) of a [rows, cols] tensor under element dropout + drop-path (common.h dig_drop_apply8; a dropped element is +0)
+inline float drop_apply(float v, const dig_dropout_t& d, long long i, int j, int cols) {
   float s = 1.f;
   if (d.pthr) s = drop_keep(d.pk0, d.pk1, (unsigned)(i / d.rows_per_sample), 0u, d.pthr) ? d.pscale : 0.f;
   if (d.thr) {
     s *= d.scale;
-    if (!drop_keep(d.k0, d.k1, (unsigned)i * (unsigned)cols + (unsigned)j, 0u, d.thr)) s = 0.f;
+    return drop_keep(d.k0, d.k1, (unsigned)i * (unsigned)cols + (unsigned)j, 0u, d.thr) ? v * s : 0.f;
   }
-  return s;
+  return v * s;
 }
 
 constexpr int BR = 64, N_TOK = 256, DH = 64;
@@ -156,13 +156,13 @@ int dig_gemm_bf16_dropout(const void* A_, const void* B_, void* C_, int I, int J
         if (act == 1) {
           if (pre) pre[(size_t)i * ldp + j] = f2bf(v);
           v = gelu_f(v);
-          if (dropping) v *= drop_factor(*drop, i, j, J);
+          if (dropping) v = drop_apply(v, *drop, i, j, J);
         } else if (act == 2) {
           v *= dgelu_f(bf2f(resid[(size_t)i * ldr + j]));
-          if (dropping) v *= drop_factor(*drop, i, j, J);
+          if (dropping) v = drop_apply(v, *drop, i, j, J);
           if (colsum_partials) csum[(size_t)g * J + j] += v;
         } else if (dropping) {
-          v *= drop_factor(*drop, i, j, J);
+          v = drop_apply(v, *drop, i, j, J);
         }
         if (resid && act != 2) v += bf2f(resid[(size_t)i * ldr + j]);
         if (out_kind == 0) ((bf16_t*)C_)[(size_t)i * ldc + j] = f2bf(v);
@@ -964,7 +964,7 @@ int dig_dropout_apply(const void* in_, void* out_, long long rows, int cols, con
   bf16_t* out = (bf16_t*)out_;
 #pragma omp parallel for
   for (long long i = 0; i < rows; ++i)
-    for (int j = 0; j < cols; ++j) out[i * cols + j] = f2bf(bf2f(in[i * cols + j]) * drop_factor(*drop, i, j, cols));
+    for (int j = 0; j < cols; ++j) out[i * cols + j] = f2bf(drop_apply(bf2f(in[i * cols + j]), *drop, i, j, cols));
   return DIG_OK;
 }
 
