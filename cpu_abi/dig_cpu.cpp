@@ -191,6 +191,33 @@ int dig_reduce_partials(const float* partials, int splits, long long n, float* o
   return DIG_OK;
 }
 
+struct dig_reduce_seg_t { const float* partials; float* out; long long n; int splits; int reserved; };
+struct dig_colsum_seg_t { const float* partials; float* out; long long stride; int n_parts; int C; };
+
+int dig_reduce_partials_multi(const dig_reduce_seg_t* segs, int n_segs, hipStream_t stream) {
+  if (!segs || n_segs < 1 || n_segs > 8) return DIG_ERR_ARG;
+  for (int k = 0; k < n_segs; ++k) {
+    const int rc = dig_reduce_partials(segs[k].partials, segs[k].splits, segs[k].n, segs[k].out, 1, stream);
+    if (rc) return rc;
+  }
+  return DIG_OK;
+}
+
+int dig_colsum_partials_multi(const dig_colsum_seg_t* segs, int n_segs, hipStream_t) {
+  if (!segs || n_segs < 1 || n_segs > 12) return DIG_ERR_ARG;
+  for (int k = 0; k < n_segs; ++k) {
+    const dig_colsum_seg_t& g = segs[k];
+    if (!g.partials || !g.out || g.n_parts <= 0 || g.C <= 0 || (g.C & 7) || g.stride < g.C || (g.stride & 3)) return DIG_ERR_ARG;
+    if (!aligned16(g.partials)) return DIG_ERR_ALIGN;
+    for (int c = 0; c < g.C; ++c) {
+      float a = 0.f;
+      for (int b = 0; b < g.n_parts; ++b) a += g.partials[(size_t)b * g.stride + c];
+      g.out[c] += a;
+    }
+  }
+  return DIG_OK;
+}
+
 // ------------------------------------------------------------------------------------------------------------------ attention
 int dig_attn_fwd_dropout(const void* qkv_, void* ctx_, float* lse, int n_img, int heads, int embed_dim, const dig_dropout_t* drop,
                          int q_rows, hipStream_t) {

@@ -86,6 +86,12 @@ __device__ __forceinline__ float dgelu_f(float x) {
 // backward (and the CPU oracle, oracle/finetune_oracle.py `keep_mask`) regenerate the same mask from (key, coordinates)
 // and no mask tensor is ever stored.  ~9 integer ops per element; coordinates: elementwise tensors a = row * cols + col,
 // b = 0; attention probabilities a = (query << 16) | key, b = sample * heads + head; drop-path a = sample, b = 0.
+// multi-segment reduction descriptors (include/dig_hip.h: dig_reduce_seg_t, dig_colsum_seg_t)
+#define DIG_REDUCE_MAX_SEGS 8
+#define DIG_COLSUM_MAX_SEGS 12
+struct dig_reduce_seg_t { const float* partials; float* out; long long n; int splits; int reserved; };
+struct dig_colsum_seg_t { const float* partials; float* out; long long stride; int n_parts; int C; };
+
 struct dig_dropout_t {
   unsigned k0, k1;        // site key
   unsigned thr;           // 0: no element dropout

@@ -333,6 +333,48 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __res
   }
 }
 
+// the same for up to DIG_COLSUM_MAX_SEGS partial sets in ONE launch (an encoder block's LayerNorm and bias gradients): partial rows of
+// segment k are `stride` floats apart (a LayerNorm workspace interleaves its three vectors), blocks [first[k], first[k+1]) own 8 columns each
+struct ColsumSegs {
+  const float* part[DIG_COLSUM_MAX_SEGS];
+  float* out[DIG_COLSUM_MAX_SEGS];
+  long long stride[DIG_COLSUM_MAX_SEGS];
+  int n_parts[DIG_COLSUM_MAX_SEGS];
+  int first[DIG_COLSUM_MAX_SEGS + 1];
+  int n_segs;
+};
+__global__ __launch_bounds__(256) void colsum_finalize_multi_kernel(ColsumSegs a) {
+  __shared__ float4 red[128][2];
+  int k = 0;
+  while (k + 1 < a.n_segs && (int)blockIdx.x >= a.first[k + 1]) ++k;
+  const float* __restrict__ partial = a.part[k];
+  const long long stride = a.stride[k];
+  const int nb = a.n_parts[k];
+  const int cx = threadIdx.x & 1, ry = threadIdx.x >> 1;
+  const int c = ((int)blockIdx.x - a.first[k]) * 8 + cx * 4;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int b = ry; b < nb; b += 128) {
+    const float4 v = *reinterpret_cast<const float4*>(partial + (size_t)b * stride + c);
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  red[ry][cx] = acc;
+  __syncthreads();
+  for (int st = 64; st > 0; st >>= 1) {
+    if (ry < st) {
+      const float4 o = red[ry + st][cx];
+      float4 m = red[ry][cx];
+      m.x += o.x; m.y += o.y; m.z += o.z; m.w += o.w;
+      red[ry][cx] = m;
+    }
+    __syncthreads();
+  }
+  if (ry == 0) {
+    float* out = a.out[k];
+    const float4 m = red[0][cx];
+    out[c] += m.x; out[c + 1] += m.y; out[c + 2] += m.z; out[c + 3] += m.w;
+  }
+}
+
 // P[t, k] (bf16, ld 64) = masked ? 0 : img patch element k (conv order c,p1,p2), k < 48; pad columns 48..63 = 0.
 // Lets the patch-embed weight gradient run as an MFMA wgrad GEMM (dW[D,48] = dy^T P) instead of a VALU loop.
 __global__ __launch_bounds__(256) void patchify_bf16_kernel(const float* __restrict__ img, const unsigned char* __restrict__ mask,
@@ -530,6 +572,24 @@ extern "C" int dig_colsum_partials(const float* partials, int n_parts, int C, fl
   if (!partials || !out || n_parts <= 0 || C <= 0 || (C & 7)) return DIG_ERR_ARG;
   if (!aligned16(partials)) return DIG_ERR_ALIGN;
   hipLaunchKernelGGL(colsum_finalize_kernel, dim3(C / 8), dim3(256), 0, stream, partials, n_parts, C, out);
+  return dig_check_launch();
+}
+
+extern "C" int dig_colsum_partials_multi(const dig_colsum_seg_t* segs, int n_segs, hipStream_t stream) {
+  if (!segs || n_segs < 1 || n_segs > DIG_COLSUM_MAX_SEGS) return DIG_ERR_ARG;
+  ColsumSegs a;
+  a.n_segs = n_segs;
+  int blocks = 0;
+  for (int k = 0; k < n_segs; ++k) {
+    const dig_colsum_seg_t& g = segs[k];
+    if (!g.partials || !g.out || g.n_parts <= 0 || g.C <= 0 || (g.C & 7) || g.stride < g.C || (g.stride & 3)) return DIG_ERR_ARG;
+    if (!aligned16(g.partials)) return DIG_ERR_ALIGN;
+    a.part[k] = g.partials; a.out[k] = g.out; a.stride[k] = g.stride; a.n_parts[k] = g.n_parts;
+    a.first[k] = blocks;
+    blocks += g.C / 8;
+  }
+  a.first[n_segs] = blocks;
+  hipLaunchKernelGGL(colsum_finalize_multi_kernel, dim3(blocks), dim3(256), 0, stream, a);
   return dig_check_launch();
 }
 

@@ -890,6 +890,33 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
   }
 }
 
+// the same for up to DIG_REDUCE_MAX_SEGS slab sets in ONE launch (the four weight gradients of an encoder block): blocks
+// [first[k], first[k+1]) walk segment k
+struct ReduceSegs {
+  const float* part[DIG_REDUCE_MAX_SEGS];
+  float* out[DIG_REDUCE_MAX_SEGS];
+  long long n4[DIG_REDUCE_MAX_SEGS];
+  int splits[DIG_REDUCE_MAX_SEGS];
+  int first[DIG_REDUCE_MAX_SEGS + 1];
+  int n_segs;
+};
+__global__ __launch_bounds__(256) void reduce_partials_multi_kernel(ReduceSegs a) {
+  int k = 0;
+  while (k + 1 < a.n_segs && (int)blockIdx.x >= a.first[k + 1]) ++k;
+  const float* __restrict__ part = a.part[k];
+  float* __restrict__ out = a.out[k];
+  const long long n4 = a.n4[k];
+  const int splits = a.splits[k], nblk = a.first[k + 1] - a.first[k];
+  for (long long i = (long long)((int)blockIdx.x - a.first[k]) * blockDim.x + threadIdx.x; i < n4; i += (long long)nblk * blockDim.x) {
+    float4 acc = reinterpret_cast<const float4*>(out)[i];
+    for (int s = 0; s < splits; ++s) {
+      const float4 b = reinterpret_cast<const float4*>(part)[(long long)s * n4 + i];
+      acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;
+    }
+    reinterpret_cast<float4*>(out)[i] = acc;
+  }
+}
+
 template <bool TA, bool TB, int OUT, int BK, bool RES, int NSTG, bool DROP = false>
 int launch(const GemmParams& p, int splits, hipStream_t stream, DropArg<DROP> da = DropArg<DROP>{}) {
   constexpr int LDS = (NSTG * 2 * BI * BK * 2) > 32768 ? (NSTG * 2 * BI * BK * 2) : 32768;   // ring; >= epilogue staging
@@ -1013,6 +1040,24 @@ extern "C" int dig_gemm_effective_splits(int R, int splits) {
   const int rtiles = (R + BR - 1) / BR;
   const int per = ((rtiles + splits - 1) / splits) * BR;
   return (R + per - 1) / per;
+}
+
+extern "C" int dig_reduce_partials_multi(const dig_reduce_seg_t* segs, int n_segs, hipStream_t stream) {
+  if (!segs || n_segs < 1 || n_segs > DIG_REDUCE_MAX_SEGS) return DIG_ERR_ARG;
+  ReduceSegs a;
+  a.n_segs = n_segs;
+  int blocks = 0;
+  for (int k = 0; k < n_segs; ++k) {
+    const dig_reduce_seg_t& g = segs[k];
+    if (!g.partials || !g.out || g.splits < 1 || g.n <= 0 || (g.n & 3)) return DIG_ERR_ARG;
+    if (!aligned16(g.partials) || !aligned16(g.out)) return DIG_ERR_ALIGN;
+    a.part[k] = g.partials; a.out[k] = g.out; a.n4[k] = g.n / 4; a.splits[k] = g.splits;
+    a.first[k] = blocks;
+    blocks += (int)std::min<long long>(1024, (g.n / 4 + 255) / 256);
+  }
+  a.first[n_segs] = blocks;
+  hipLaunchKernelGGL(reduce_partials_multi_kernel, dim3(blocks), dim3(256), 0, stream, a);
+  return dig_check_launch();
 }
 
 extern "C" int dig_reduce_partials(const float* partials, int splits, long long n, float* out, int accumulate,

@@ -14,6 +14,7 @@ import torch
 from . import ops
 
 BF16, F32 = torch.bfloat16, torch.float32
+BATCH_REDUCE = os.environ.get("DIG_BATCH_REDUCE", "1") != "0"       # an encoder block's eleven reduction launches as two
 FUSED_QV_BIAS_SUMS = os.environ.get("DIG_FUSED_QV_BIAS", "1") != "0"
 
 
@@ -156,16 +157,24 @@ class _Step:
                 x, ln1, mu1, rs1, qkv, ctx, x_mid, ln2, mu2, rs2, pre, act = (t[:Rh] for t in (x, ln1, mu1, rs1, qkv, ctx, x_mid, ln2, mu2, rs2, pre, act))
                 lse = lse[:B * H]
             # x_out = x_mid + fc2(gelu(fc1(ln2)))
-            on_side(lambda: ops.linear_wgrad(dx, act, g["mlp.fc2.weight"]), dx, act)
+            # The reductions this block leaves behind (four split-R slab sums, five bias / LayerNorm-parameter column sums) are
+            # collected in `red` and issued as two launches after the block's last weight-gradient GEMM (ops.GradReduceBatch).
+            red = ops.GradReduceBatch() if BATCH_REDUCE else None
+            wg = red.wgrad if red else ops.linear_wgrad
+            csum = red.colsum_partials if red else ops.colsum_partials
+            on_side(lambda: wg(dx, act, g["mlp.fc2.weight"]), dx, act)
             dact, bparts = ops.linear_dgrad(dx, blk["mlp.fc2.weight"], gelu_pre=pre, colsum=True)   # d(pre-activation): GELU' and
-            on_side(lambda: (ops.linear_wgrad(dact, ln2, g["mlp.fc1.weight"]),                       # the fc1 bias sums fused
-                             ops.colsum_partials(bparts, g["mlp.fc1.bias"])), dact, ln2, bparts)      # (0.3 ms/step vs a 201 MB pass)
+            on_side(lambda: (wg(dact, ln2, g["mlp.fc1.weight"]),                                     # the fc1 bias sums fused
+                             csum(bparts, g["mlp.fc1.bias"])), dact, ln2, bparts)                    # (0.3 ms/step vs a 201 MB pass)
             dln2 = ops.linear_dgrad(dact, blk["mlp.fc1.weight"])
             dx_mid, fin2, ws2 = ops.layernorm_bwd(dln2, x_mid, blk["norm2.weight"], blk["norm2.bias"], mu2, rs2, dx, g["norm2.weight"],
                                                   g["norm2.bias"], out=dln2, dres_colsum=g["mlp.fc2.bias"], defer=True)
-            on_side(fin2, ws2)                                                # norm2 grads + colsum(dx) = fc2 bias grad: off the chain
+            if red:                                                           # norm2 grads + colsum(dx) = fc2 bias grad: off the chain
+                red.layernorm_finalize(ws2, x_mid.shape[0], D, g["norm2.weight"], g["norm2.bias"], g["mlp.fc2.bias"])
+            else:
+                on_side(fin2, ws2)
             # x_mid = x + proj(attn(ln1))
-            on_side(lambda: ops.linear_wgrad(dx_mid, ctx, g["attn.proj.weight"]), dx_mid, ctx)
+            on_side(lambda: wg(dx_mid, ctx, g["attn.proj.weight"]), dx_mid, ctx)
             dctx = ops.linear_dgrad(dx_mid, blk["attn.proj.weight"])
             gb = g["qkv_bias"]
             if FUSED_QV_BIAS_SUMS:
@@ -173,16 +182,20 @@ class _Step:
                 # kernel as [2B, D] fp32 partials (DPP row reductions of the accumulators, no extra pass over the 150 MB dqkv);
                 # K has no bias
                 dqkv, qs, vs = ops.attn_bwd(qkv, ctx, dctx, lse, views * B, H, D, scale, bias_sums=True)
-                on_side(lambda: (ops.linear_wgrad(dqkv, ln1, g["attn.qkv.weight"]),
-                                 ops.colsum_partials(qs, gb[:D]), ops.colsum_partials(vs, gb[2 * D:])), dqkv, ln1, qs, vs)
+                on_side(lambda: (wg(dqkv, ln1, g["attn.qkv.weight"]),
+                                 csum(qs, gb[:D]), csum(vs, gb[2 * D:])), dqkv, ln1, qs, vs)
             else:
                 dqkv = ops.attn_bwd(qkv, ctx, dctx, lse, views * B, H, D, scale)
-                on_side(lambda: (ops.linear_wgrad(dqkv, ln1, g["attn.qkv.weight"]),
+                on_side(lambda: (wg(dqkv, ln1, g["attn.qkv.weight"]),
                                  ops.colsum(dqkv, gb[:D], cols=D), ops.colsum(dqkv[:, 2 * D:], gb[2 * D:], cols=D)), dqkv, ln1)
             dln1 = ops.linear_dgrad(dqkv, blk["attn.qkv.weight"], out=dctx)
             dx, fin1, ws1 = ops.layernorm_bwd(dln1, x, blk["norm1.weight"], blk["norm1.bias"], mu1, rs1, dx_mid, g["norm1.weight"],
                                               g["norm1.bias"], out=dln1, dres_colsum=g["attn.proj.bias"], defer=True)
-            on_side(fin1, ws1)                                                # norm1 grads + colsum(dx_mid) = proj bias grad
+            if red:                                                           # norm1 grads + colsum(dx_mid) = proj bias grad
+                red.layernorm_finalize(ws1, x.shape[0], D, g["norm1.weight"], g["norm1.bias"], g["attn.proj.bias"])
+                on_side(red.flush, *red.tensors())
+            else:
+                on_side(fin1, ws1)
             del dact, pre, act, dln2, dqkv, dctx
             # this block's gradients are final once BOTH streams pass this point: the bucket's all-reduce is issued from the
             # side stream after it has waited for the main chain, so the main chain itself never stalls on the collective

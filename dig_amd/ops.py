@@ -132,6 +132,86 @@ def wgrad(dy, x, dw, I, J, rows):
     L.call("dig_reduce_partials", L.ptr(ws), sp, cll(I * J), L.ptr(dw), 1, L.stream())
 
 
+_ws3 = {}
+
+
+def _batch_workspace(dev, numel):
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0)
+    w = _ws3.get(key)
+    if w is None or w.numel() < numel:
+        w = _ws3[key] = torch.empty(numel, device=dev, dtype=F32)
+    return w
+
+
+class _ReduceSeg(ctypes.Structure):
+    """include/dig_hip.h `dig_reduce_seg_t`."""
+    _fields_ = [("partials", ctypes.c_void_p), ("out", ctypes.c_void_p), ("n", ctypes.c_longlong), ("splits", ctypes.c_int), ("reserved", ctypes.c_int)]
+
+
+class _ColsumSeg(ctypes.Structure):
+    """include/dig_hip.h `dig_colsum_seg_t`."""
+    _fields_ = [("partials", ctypes.c_void_p), ("out", ctypes.c_void_p), ("stride", ctypes.c_longlong), ("n_parts", ctypes.c_int), ("C", ctypes.c_int)]
+
+
+class GradReduceBatch:
+    """The reductions an encoder block's backward leaves behind -- split-R slabs of its four weight gradients, the fc1 / q / v bias
+    column sums, the parameter-gradient partials of its two LayerNorms -- collected and issued as TWO launches at flush()
+    (dig_reduce_partials_multi, dig_colsum_partials_multi) instead of eleven; same per-element summation order as the single forms."""
+    SLAB_FLOATS = 1 << 25                                       # 128 MiB: the four ViT-S weight gradients at 16 splits need 113 MiB
+
+    def __init__(self):
+        self.slabs, self.vecs, self.keep, self.off = [], [], [], 0
+
+    def wgrad(self, dy, x, dw, rows=None):
+        """dw[I,J] += dy[rows,:I]^T x[rows,:J]: the split-R GEMM now, the slab sum at flush()."""
+        I, J = dw.shape
+        rows = dy.shape[0] if rows is None else rows
+        sp, bk = wgrad_splits(rows, ((I + 127) // 128) * ((J + 127) // 128))
+        need = sp * I * J
+        if need > self.SLAB_FLOATS or len(self.slabs) == 8:
+            wgrad(dy, x, dw, I, J, rows)
+            return
+        if self.off + need > self.SLAB_FLOATS:
+            self.flush()
+        ws = _batch_workspace(dy.device, self.SLAB_FLOATS)[self.off:self.off + need]      # its own scratch: slabs stay pending until flush()
+        self.off += need
+        gemm(dy, x, I, J, rows, ta=True, tb=True, out=ws, out_kind=OUT_F32_PARTIAL, splits=sp, ldc=J, bk=bk)
+        self.slabs.append((ws, dw, I * J, sp))
+
+    def colsum_partials(self, parts, out):
+        """out[c] += sum_b parts[b, c] at flush()."""
+        self._vec(parts, out, parts.shape[1], parts.shape[0], parts.shape[1])
+
+    def layernorm_finalize(self, ws, rows, D, dgamma, dbeta, dcolsum):
+        """dig_layernorm_bwd_finalize of a deferred layernorm_bwd(..., defer=True) workspace at flush()."""
+        n = L.lib().dig_layernorm_bwd_parts(rows)
+        for k, out in enumerate((dgamma, dbeta, dcolsum)):
+            if out is not None:
+                self._vec(ws[k * D:], out, 3 * D, n, D)
+
+    def _vec(self, parts, out, stride, n_parts, C):
+        if len(self.vecs) == 12:
+            self._flush_vecs()
+        self.vecs.append((parts, out, stride, n_parts, C))
+
+    def tensors(self):
+        """Everything flush() reads that another stream may have produced (for record_stream)."""
+        return [v[0] for v in self.vecs]
+
+    def _flush_vecs(self):
+        if self.vecs:
+            segs = (_ColsumSeg * len(self.vecs))(*[_ColsumSeg(p.data_ptr(), o.data_ptr(), st, n, C) for p, o, st, n, C in self.vecs])
+            L.call("dig_colsum_partials_multi", segs, len(self.vecs), L.stream())
+            self.vecs = []
+
+    def flush(self):
+        if self.slabs:
+            segs = (_ReduceSeg * len(self.slabs))(*[_ReduceSeg(w.data_ptr(), d.data_ptr(), n, sp, 0) for w, d, n, sp in self.slabs])
+            L.call("dig_reduce_partials_multi", segs, len(self.slabs), L.stream())
+            self.slabs, self.off = [], 0
+        self._flush_vecs()
+
+
 def linear_wgrad(dy, x, dw, rows=None):
     """dw[out,in] += dy[rows,out]^T @ x[rows,in]."""
     rows = dy.shape[0] if rows is None else rows

@@ -65,6 +65,11 @@ int dig_gemm_bf16(const void* A, const void* B, void* C, int I, int J, int R, in
 int dig_gemm_effective_splits(int R, int splits);
 /* out[e] (+)= sum_s partials[s][e], e < n  (deterministic split-R combine; accumulate=1 adds into the gradient arena) */
 int dig_reduce_partials(const float* partials, int splits, long long n, float* out, int accumulate, hipStream_t stream);
+/* out += sum_s partials[s] for up to DIG_REDUCE_MAX_SEGS slab sets in one launch (the weight gradients of one encoder block:
+ * 4 reduce launches -> 1; same fixed summation order per element as dig_reduce_partials with accumulate = 1).  `segs` is host memory. */
+#define DIG_REDUCE_MAX_SEGS 8
+typedef struct dig_reduce_seg { const float* partials; float* out; long long n; int splits; int reserved; } dig_reduce_seg_t;
+int dig_reduce_partials_multi(const dig_reduce_seg_t* segs, int n_segs, hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Fused self-attention, 256 tokens x head_dim 64 (Attention.forward, modeling_finetune.py:97-118, and its gradient).
@@ -213,6 +218,13 @@ int dig_colsum(const void* x, float* out, float* workspace, int rows, int C, int
 /* out[c] += sum_b partials[b][c]: finishes the [ceil(I/64)][J] column sums that dig_gemm_bf16(act 2, colsum_partials) leaves
  * (the fc1 bias gradient fused into the fc2 data-gradient GEMM; reference: autograd of nn.Linear bias, modeling_pretrain_vit.py:60-76) */
 int dig_colsum_partials(const float* partials, int n_parts, int C, float* out, hipStream_t stream);
+/* out[c] += sum_b partials[b * stride + c], c < C, for up to DIG_COLSUM_MAX_SEGS partial sets in one launch: the bias and LayerNorm
+ * parameter gradients an encoder block's backward leaves as partials (fc1 bias from the fc2 dgrad, q / v bias from dig_attn_bwd, and the
+ * three interleaved vectors of each dig_layernorm_bwd_partials workspace: stride 3*D, bases workspace + {0, D, 2D}) -- 5 finalize
+ * launches -> 1, same summation order per column as dig_colsum_partials.  C % 8 == 0, stride % 4 == 0; `segs` is host memory. */
+#define DIG_COLSUM_MAX_SEGS 12
+typedef struct dig_colsum_seg { const float* partials; float* out; long long stride; int n_parts; int C; } dig_colsum_seg_t;
+int dig_colsum_partials_multi(const dig_colsum_seg_t* segs, int n_segs, hipStream_t stream);
 int dig_gelu_bwd(const void* dact, const void* pre, void* dpre, long long n, hipStream_t stream);
 int dig_add_bf16(const void* a, const void* b, void* out, long long n, hipStream_t stream);
 int dig_cast_f32_to_bf16(const float* x, void* y, long long n, hipStream_t stream);

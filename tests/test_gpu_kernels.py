@@ -315,3 +315,45 @@ def test_adamw_ema_sumsq_colsum(dev):
     xx = torch.randn(3000, 48, device=dev).bfloat16(); cs = torch.ones(48, device=dev)
     ops.colsum(xx, cs)
     assert rel(cs, 1 + xx.float().sum(0)) < 1e-5
+
+
+def test_grad_reduce_batch_equals_single_launches(dev):
+    """ops.GradReduceBatch (dig_reduce_partials_multi + dig_colsum_partials_multi: an encoder block's eleven reduction launches as two)
+    against the single-launch forms on the same inputs."""
+    from dig_amd import ops
+    rows, D, F4 = 4096, 128, 512
+    dy1, x1 = torch.randn(rows, F4, device=dev).bfloat16(), torch.randn(rows, D, device=dev).bfloat16()
+    dy2, x2 = torch.randn(rows, D, device=dev).bfloat16(), torch.randn(rows, F4, device=dev).bfloat16()
+    parts = torch.randn(rows // 64, F4, device=dev)
+    qs = torch.randn(16, D, device=dev)
+    xx, gy, dres = (torch.randn(rows, D, device=dev).bfloat16() for _ in range(3))
+    gam, bet = torch.randn(D, device=dev), torch.randn(D, device=dev)
+    _, mean, rstd = ops.layernorm_fwd(xx, gam, bet, 1e-6)
+
+    def run(batched):
+        dw1, dw2 = torch.randn(F4, D, device=dev), torch.randn(D, F4, device=dev)
+        torch.manual_seed(5)
+        b1, bq, dg, db, dc = (torch.randn(n, device="cpu").to(dev) for n in (F4, D, D, D, D))
+        dx, fin, ws = ops.layernorm_bwd(gy, xx, gam, bet, mean, rstd, dres, dg, db, dres_colsum=dc, defer=True)
+        if batched:
+            red = ops.GradReduceBatch()
+            red.wgrad(dy1, x1, dw1); red.wgrad(dy2, x2, dw2)
+            red.colsum_partials(parts, b1); red.colsum_partials(qs, bq)
+            red.layernorm_finalize(ws, rows, D, dg, db, dc)
+            assert len(red.slabs) == 2 and len(red.vecs) == 5
+            red.flush()
+            assert not red.slabs and not red.vecs
+        else:
+            ops.linear_wgrad(dy1, x1, dw1); ops.linear_wgrad(dy2, x2, dw2)
+            ops.colsum_partials(parts, b1); ops.colsum_partials(qs, bq)
+            fin()
+        return dw1, dw2, b1, bq, dg, db, dc
+    torch.manual_seed(9)
+    a = run(False)
+    torch.manual_seed(9)
+    b = run(True)
+    for i, (u, v) in enumerate(zip(a, b)):
+        if i < 4:                                   # slab sums and column sums: the same order per element -> the same bits
+            assert torch.equal(u, v), i
+        else:                                       # LayerNorm vectors: 128 x 2 instead of 64 x 4 row groups in the tree (both fixed orders)
+            assert rel(u, v) < 1e-6, i
