@@ -383,8 +383,13 @@ class _TrainStep:
         M = self.m
         dev = images.device
         enc = self.encoder_forward(images)
-        D, H, N = M.D, M.H, M.N
+        D, H, N = M.D, M.H, M.n_mem                                           # N: memory tokens per sample the decoder attends over
         B = self.B
+        if M.use_1d_attdec:                                                   # model_builder.py:145-148: column means of the 8 x 32 grid
+            cols = torch.empty((B * M.gw, D), device=dev, dtype=BF16)
+            ops.window_pool_fwd(enc, cols, B, M.gh, M.gw, M.gw, D)
+            enc = cols
+        self.mem_in = enc
         T, d, nh, dk = M.max_len, M.d, M.nh, M.dk
         hk = nh * dk
         plan = self.plan
@@ -533,7 +538,7 @@ class _TrainStep:
         dev = dlogits_btc.device
         main, sd = self.begin_backward(dev)
         side = self.side
-        B, T, d, nh, dk, C, N, D, H = self.B, M.max_len, M.d, M.nh, M.dk, M.nb_classes, M.N, M.D, M.H
+        B, T, d, nh, dk, C, N, D, H = self.B, M.max_len, M.d, M.nh, M.dk, M.nb_classes, M.n_mem, M.D, M.H
         hk = nh * dk
         rows = B * T
         dl = torch.zeros((rows, CLS_PAD), device=dev, dtype=BF16)
@@ -614,7 +619,7 @@ class _TrainStep:
                L.ptr(self.lens), L.stream())
         # ---- linear_norm
         h, mmu, mrs, _ = self.ln_saved
-        x_last, emu, ers, enc = self.enc_last
+        enc = self.mem_in
         main.wait_stream(sd)                                                    # the memory gradient was summed on the second stream
         dmem, self._dmem = self._dmem, None
         dmem.record_stream(main)
@@ -623,6 +628,10 @@ class _TrainStep:
         side(lambda: ops.linear_wgrad(dh, enc, self.g("linear_norm.0.weight")), dh, enc)
         side(lambda: ops.colsum(dh, self.g("linear_norm.0.bias")), dh)
         denc = ops.linear_dgrad(dh, self.w("linear_norm.0.weight"))
+        if M.use_1d_attdec:                                                     # every token of a column gets 1/gh of the column's gradient
+            dfull = torch.empty((B * M.N, D), device=dev, dtype=BF16)
+            ops.window_pool_bwd(denc, dfull, B, M.gh, M.gw, M.gw, D, False)
+            denc = dfull
         self.encoder_backward(denc)
         main.wait_stream(sd)
 

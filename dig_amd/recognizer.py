@@ -48,19 +48,25 @@ def _encoder_pos(n_pos, d):
 
 class RecModel(torch.nn.Module):
     def __init__(self, args=None, *, embed_dim=None, depth=12, num_heads=None, n_layers=None, d_model=None, n_head=None, d_k=64,
-                 d_inner=None, nb_classes=97, max_len=25, n_position=200):
+                 d_inner=None, nb_classes=97, max_len=25, n_position=200, use_1d_attdec=False):
         super().__init__()
         if args is not None:
             embed_dim, num_heads = ENCODERS[args.model]
             dk = DECODERS[args.decoder_name]
             n_layers, d_model, n_head, d_k, d_inner = dk["n_layers"], dk["d_model"], dk["n_head"], dk["d_k"], dk["d_inner"]
             nb_classes, max_len = args.nb_classes, args.max_len
-            if getattr(args, "use_1d_attdec", False) or getattr(args, "text_cond_vis", False):
-                raise NotImplementedError("1-D attention decoder / text-conditional attention are not built (tf_decoder, greedy or beam search)")
+            use_1d_attdec = bool(getattr(args, "use_1d_attdec", False))
+            if getattr(args, "text_cond_vis", False) or getattr(args, "insert_sem", False):
+                raise NotImplementedError("text-conditional attention / semantic insertion are not built (tf_decoder on 2-D or 1-D features, "
+                                          "greedy or beam search)")
         if d_k != 64 or embed_dim // num_heads != 64:
             raise NotImplementedError("head dimension 64 only")
         self.D, self.H, self.depth, self.F = embed_dim, num_heads, depth, 4 * embed_dim
         self.gh, self.gw, self.N = 8, 32, 256
+        # --use_1d_attdec (run_class_finetuning.py:89, model_builder.py:145-148): the decoder attends over the gw column means of the
+        # token grid instead of all gh*gw tokens
+        self.use_1d_attdec = bool(use_1d_attdec)
+        self.n_mem = self.gw if self.use_1d_attdec else self.N
         self.n_layers, self.d, self.nh, self.dk, self.d_inner = n_layers, d_model, n_head, d_k, d_inner
         self.nb_classes, self.max_len, self.n_position = nb_classes, max_len, n_position
         self.start_idx = nb_classes                                         # decoder.py:149
@@ -185,6 +191,11 @@ class RecModel(torch.nn.Module):
     def memory(self, enc):
         """linear_norm (model_builder.py:86-89): Linear + LayerNorm(eps 1e-5) on the feature map."""
         w = self._w
+        if self.use_1d_attdec:                                          # enc_x.view(B, gh, gw, C).mean(1): [B*gw, D]
+            B = enc.shape[0] // self.N
+            cols = torch.empty((B * self.gw, self.D), device=enc.device, dtype=enc.dtype)
+            ops.window_pool_fwd(enc, cols, B, self.gh, self.gw, self.gw, self.D)
+            enc = cols
         h = ops.linear_fwd(enc, w["ln_w"], bias=w["ln_b"])
         m, _, _ = ops.layernorm_fwd(h, w["ln_nw"], w["ln_nb"], 1e-5)
         return m
@@ -306,7 +317,7 @@ class RecModel(torch.nn.Module):
             if self.beam_width > 0:
                 # RecModel.forward -> TFDecoder.forward(..., beam_width) (model_builder.py:151-158, decoder.py:101-102): token ids
                 # [B, max_len] and an all-ones tensor in place of (probabilities, attention maps)
-                ids = self.beam_search(self.memory(self.encoder_features(images)), self.N, self.beam_width)
+                ids = self.beam_search(self.memory(self.encoder_features(images)), self.n_mem, self.beam_width)
                 return ids, None, None, torch.ones_like(ids)
             if not self.use_hip_graph:
                 probs, maps, _ = self._recognize(images)
@@ -334,7 +345,7 @@ class RecModel(torch.nn.Module):
     def _recognize(self, images):
         enc = self.encoder_features(images)
         mem = self.memory(enc)
-        return self.greedy_decode(mem, self.N)
+        return self.greedy_decode(mem, self.n_mem)
 
 
 def beam_backtrack(scores, preds, syms, B, bw, eos):

@@ -266,9 +266,18 @@ def encoder_features(P, cfg: O.DiGConfig, images):
     return F.layer_norm(x, (cfg.embed_dim,), P["encoder.norm.weight"], P["encoder.norm.bias"], 1e-6)
 
 
-def recognize(P, cfg: O.DiGConfig, c: DecoderConfig, images, cached=True):
+def columns_1d(enc, cfg: O.DiGConfig):
+    """`enc_x.view(B, *patch_shape, C).mean(1)` (model_builder.py:146-148, --use_1d_attdec): [B, gh*gw, C] -> [B, gw, C]."""
+    B, N, C = enc.shape
+    gh, gw = cfg.img_h // cfg.patch, cfg.img_w // cfg.patch
+    return enc.view(B, gh, gw, C).mean(1)
+
+
+def recognize(P, cfg: O.DiGConfig, c: DecoderConfig, images, cached=True, use_1d_attdec=False):
     """RecModel.forward in eval mode (model_builder.py:124-160): (probabilities [B,T,C], cross-attention maps, tokens)."""
     enc = encoder_features(P, cfg, images)
+    if use_1d_attdec:
+        enc = columns_1d(enc, cfg)
     mem = F.layer_norm(enc @ P["linear_norm.0.weight"].t() + P["linear_norm.0.bias"], (c.d_model,), P["linear_norm.1.weight"],
                        P["linear_norm.1.bias"], 1e-5)
     return (greedy_decode_cached if cached else greedy_decode)(P, c, mem)

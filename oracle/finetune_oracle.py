@@ -166,9 +166,12 @@ def _decoder_train(P, c, trg_seq, tgt_lens, memory, dr):
     return TF.layer_norm(x, (c.d_model,), P["decoder.layer_norm.weight"], P["decoder.layer_norm.bias"], 1e-6)
 
 
-def train_logits(P, ecfg, c, images, targets, lens, drop=None):
-    """RecModel.forward (train) up to the classifier: [B, T, num_classes].  drop: DropOracle (None = every rate 0)."""
+def train_logits(P, ecfg, c, images, targets, lens, drop=None, use_1d_attdec=False):
+    """RecModel.forward (train) up to the classifier: [B, T, num_classes].  drop: DropOracle (None = every rate 0).
+    use_1d_attdec (model_builder.py:145-148): the decoder attends over the 32 column means of the 8 x 32 token grid."""
     enc = D.encoder_features(P, ecfg, images) if drop is None else _encoder_train(P, ecfg, images, drop)
+    if use_1d_attdec:
+        enc = D.columns_1d(enc, ecfg)
     mem = torch.nn.functional.layer_norm(enc @ P["linear_norm.0.weight"].t() + P["linear_norm.0.bias"], (c.d_model,),
                                          P["linear_norm.1.weight"], P["linear_norm.1.bias"], 1e-5)
     B = images.shape[0]
@@ -178,9 +181,9 @@ def train_logits(P, ecfg, c, images, targets, lens, drop=None):
     return out @ P["decoder.classifier.weight"].t() + P["decoder.classifier.bias"]
 
 
-def loss_and_grads(P, ecfg, c, images, targets, lens, drop=None):
+def loss_and_grads(P, ecfg, c, images, targets, lens, drop=None, use_1d_attdec=False):
     Q = OrderedDict((k, v.detach().clone().requires_grad_(k != "encoder.mask_token")) for k, v in P.items())
-    logits = train_logits(Q, ecfg, c, images, targets, lens, drop)
+    logits = train_logits(Q, ecfg, c, images, targets, lens, drop, use_1d_attdec)
     loss = D.seq_cross_entropy(logits, targets, lens)
     loss.backward()
     grads = OrderedDict((k, (v.grad if v.grad is not None else torch.zeros_like(v))) for k, v in Q.items())

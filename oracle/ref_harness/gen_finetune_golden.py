@@ -42,13 +42,20 @@ def sample_index(numel, k=8):
 class TinyRec(nn.Module):
     """RecModel (models/model_builder.py:74-160) with the reference's own sub-modules at test widths."""
 
-    def __init__(self, enc, ln, dec):
+    def __init__(self, enc, ln, dec, use_1d_attdec=False):
         super().__init__()
         self.encoder, self.decoder, self.linear_norm = enc, dec, ln
+        self.use_1d_attdec = use_1d_attdec
 
     def forward(self, x):
         x, tgt, tgt_lens = x
-        dec_in = self.linear_norm(self.encoder(x))
+        enc_x = self.encoder(x)
+        if not self.training:
+            tgt = tgt_lens = None                                               # model_builder.py:138-140
+        if self.use_1d_attdec:                                                  # model_builder.py:145-148
+            B, N, C = enc_x.shape
+            enc_x = enc_x.view(B, *self.encoder.patch_embed.patch_shape, C).mean(1)
+        dec_in = self.linear_norm(enc_x)
         out, maps = self.decoder(dec_in, dec_in, targets=tgt, tgt_lens=tgt_lens, train_mode=self.training, cls_query_attn_maps=None,
                                  trg_word_emb=None, beam_width=0)
         return out, None, None, maps
@@ -144,6 +151,60 @@ def main():
                         param_norms=np.array([sd2[n].double().norm().item() for n in names]),
                         group_scale=np.array([groups[n][0] for n in names]), group_wd=np.array([groups[n][1] for n in names]))
     print("wrote tests/golden/finetune_tiny.npz")
+
+
+def main_1d():
+    """--use_1d_attdec (run_class_finetuning.py:89, model_builder.py:145-148): train step and greedy evaluation with the decoder on the
+    32 column means of the token grid."""
+    refenv.setup()
+    torch.manual_seed(0)
+    from models.decoder import TFDecoder
+    import modeling_pretrain_vit as V
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_seq_ce", os.path.join(refenv.REF, "loss", "seqCrossEntropyLoss.py"))
+    ref_ce = importlib.util.module_from_spec(spec); spec.loader.exec_module(ref_ce)
+    c = D.DecoderConfig(**D.TINY)
+    ecfg = O.DiGConfig(**O.TINY)
+    enc = V.PretrainVisionTransformerEncoder(img_size=(32, 128), patch_size=4, embed_dim=ecfg.embed_dim, depth=ecfg.depth,
+                                             num_heads=ecfg.heads, mlp_ratio=4, qkv_bias=True, norm_layer=partial(nn.LayerNorm, eps=1e-6),
+                                             num_classes=0, drop_rate=0.0, attn_drop_rate=0.0, drop_path_rate=0.0)
+    dec = TFDecoder(n_layers=c.n_layers, d_embedding=c.d_model, n_head=c.n_head, d_k=c.d_k, d_v=c.d_k, d_model=c.d_model, d_inner=c.d_inner,
+                    num_classes=c.num_classes, max_seq_len=c.max_seq_len, dropout=0.0)
+    ln = nn.Sequential(nn.Linear(ecfg.embed_dim, c.d_model), nn.LayerNorm(c.d_model))
+    model = TinyRec(enc, ln, dec, use_1d_attdec=True).train()
+    P = {**D.det_encoder_state(ecfg, 42), **D.det_decoder_state(c, 41)}
+    sd = model.state_dict()
+    for k, v in P.items():
+        sd[k].copy_(v)
+    B = 5
+    images = O.synthetic_batch(B, ecfg, 565)[0]
+    rng = np.random.RandomState(19)
+    lens = torch.from_numpy(rng.randint(1, c.max_seq_len + 1, size=B))
+    targets = torch.from_numpy(rng.randint(0, 94, size=(B, c.max_seq_len)))
+    for b in range(B):
+        targets[b, int(lens[b]) - 1] = 94
+        targets[b, int(lens[b]):] = 95
+    outputs, _, _, _ = model((images, targets, lens))
+    loss = ref_ce.SeqCrossEntropyLoss()(outputs, targets, lens)
+    loss.backward()
+    ref_grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+    o_loss, o_grads, o_logits = F.loss_and_grads(P, ecfg, c, images, targets, lens, use_1d_attdec=True)
+    assert abs(o_loss - loss.item()) < 1e-5 * abs(loss.item()), (o_loss, loss.item())
+    assert (o_logits - outputs.detach()).abs().max() < 2e-5
+    worst = max((o_grads[n] - g).abs().max().item() / (g.abs().max().item() + 1e-12) for n, g in ref_grads.items())
+    assert worst < 2e-3, worst
+    model.eval()
+    with torch.no_grad():
+        probs, _, _, maps = model((images, None, None))
+    o_probs, o_maps, o_tok = D.recognize(P, ecfg, c, images, cached=True, use_1d_attdec=True)
+    assert (o_probs - probs).abs().max() < 2e-5 and torch.equal(o_tok, probs.argmax(-1))
+    print(f"1-D decoder: oracle == reference (train loss {o_loss:.6f}, worst gradient rel-to-max err {worst:.2e}; greedy eval probabilities equal)")
+    names = sorted(ref_grads)
+    np.savez_compressed(os.path.join(GOLD, "finetune_tiny_1d.npz"), seed_enc=42, seed_dec=41, B=B, batch_seed=565, targets=targets.numpy(),
+                        lens=lens.numpy(), loss=np.float64(loss.item()), logits=outputs.detach().numpy(), grad_names=np.array(names),
+                        grad_norms=np.array([ref_grads[n].double().norm().item() for n in names]),
+                        eval_probs=probs.numpy(), eval_tokens=probs.argmax(-1).numpy())
+    print("wrote tests/golden/finetune_tiny_1d.npz")
 
 
 def patch_dropouts(model, dr, depth, n_layers):
@@ -283,5 +344,7 @@ def main_smoothing():
 if __name__ == "__main__":
     if "--smoothing" in sys.argv:
         main_smoothing()
+    elif "--1d" in sys.argv:
+        main_1d()
     else:
         main_drop() if "--drop" in sys.argv else main()

@@ -194,6 +194,71 @@ def test_device_finetune_step_vs_reference_fixture():
     assert torch.equal(sd["encoder.mask_token"], P["encoder.mask_token"])        # no gradient: untouched, as in the reference
 
 
+def _fixture_1d():
+    g = np.load(os.path.join(GOLD, "finetune_tiny_1d.npz"))
+    c, ecfg = D.DecoderConfig(**D.TINY), O.DiGConfig(**O.TINY)
+    P = {**D.det_encoder_state(ecfg, int(g["seed_enc"])), **D.det_decoder_state(c, int(g["seed_dec"]))}
+    images = O.synthetic_batch(int(g["B"]), ecfg, int(g["batch_seed"]))[0]
+    return g, c, ecfg, P, images, torch.from_numpy(g["targets"]), torch.from_numpy(g["lens"])
+
+
+def test_oracle_1d_decoder_matches_reference_fixture():
+    """--use_1d_attdec (model_builder.py:145-148): the decoder attends over the 32 column means of the token grid; train step and
+    greedy evaluation of the oracle against the fixture written from the reference modules."""
+    g, c, ecfg, P, images, targets, lens = _fixture_1d()
+    loss, grads, logits = F.loss_and_grads(P, ecfg, c, images, targets, lens, use_1d_attdec=True)
+    assert abs(loss - float(g["loss"])) < 1e-5 * float(g["loss"])
+    np.testing.assert_allclose(logits.numpy(), g["logits"], atol=3e-5)
+    for i, n in enumerate(g["grad_names"].tolist()):
+        assert abs(grads[n].double().norm().item() - g["grad_norms"][i]) <= 3e-4 * g["grad_norms"][i] + 1e-7, n
+    probs, maps, tok = D.recognize(P, ecfg, c, images, cached=True, use_1d_attdec=True)
+    np.testing.assert_allclose(probs.numpy(), g["eval_probs"], atol=3e-5)
+    assert maps.shape[-1] == 32 and np.array_equal(tok.numpy(), g["eval_tokens"])
+
+
+@pytest.mark.gpu
+def test_device_1d_decoder_train_step_and_eval_vs_fixture():
+    """The same on the device: column means by dig_window_pool_fwd / _bwd (nwin = 32), cross-attention over 32 memory tokens on the
+    generic sequence-attention kernels (training) and dig_decode_cross_attn (greedy evaluation)."""
+    from dig_amd.finetune import SeqCrossEntropyLoss
+    g, c, ecfg, P, images, targets, lens = _fixture_1d()
+    m = _device_model(c, ecfg, P, use_1d_attdec=True)
+    assert m.n_mem == 32
+    logits = m((images.to("cuda:0"), targets, lens))[0]
+    loss = SeqCrossEntropyLoss()(logits, targets, lens)
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) < 2e-2 * float(g["loss"])
+    ref_logits = torch.from_numpy(g["logits"])
+    assert ((logits.detach().cpu() - ref_logits).norm() / ref_logits.norm()).item() < 2e-2
+    _, ref_g, _ = F.loss_and_grads(P, ecfg, c, images, targets, lens, use_1d_attdec=True)
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        _, bf_g, _ = F.loss_and_grads(P, ecfg, c, images, targets, lens, use_1d_attdec=True)
+    grads = {n: p.grad.detach().float().cpu() for n, p in m.named_parameters()}
+    cos = torch.nn.functional.cosine_similarity
+    names, norms = g["grad_names"].tolist(), g["grad_norms"]
+    tot = float(np.sqrt((norms ** 2).sum()))
+    bad = []
+    for i, n in enumerate(names):
+        if norms[i] < 1e-3 * tot:
+            continue
+        r = ref_g[n].reshape(1, -1)
+        c_hip, c_bf = cos(grads[n].reshape(1, -1), r).item(), cos(bf_g[n].float().reshape(1, -1), r).item()
+        q_hip, q_bf = grads[n].norm().item() / norms[i], bf_g[n].float().norm().item() / norms[i]
+        if (1 - c_hip) > 2 * (1 - c_bf) + 5e-3 or abs(q_hip - 1) > 2 * abs(q_bf - 1) + 3e-2:
+            bad.append((n, c_hip, c_bf, q_hip, q_bf))
+    assert not bad, bad
+    m.eval()
+    probs, _, _, maps = m((images.to("cuda:0"), None, None))
+    ref_p = torch.from_numpy(g["eval_probs"])
+    assert maps.shape[-1] == 32 and (probs.float().cpu() - ref_p).abs().max().item() < 3e-2
+    top2 = ref_p.topk(2, -1)[0]
+    sure = (top2[..., 0] - top2[..., 1]) > 6e-2                                # tokens wherever the reference's margin exceeds the bf16 noise
+    first_eos = torch.from_numpy(g["eval_tokens"]).eq(94).int().argmax(1)
+    alive = torch.arange(ref_p.shape[1])[None, :] <= first_eos[:, None]
+    same = probs.argmax(-1).cpu().eq(torch.from_numpy(g["eval_tokens"]))
+    assert bool(same[sure & alive].all())
+
+
 @pytest.mark.gpu
 def test_device_finetune_engine_loop_vs_oracle():
     """dig_amd.engine_for_finetuning.train_one_epoch (schedules x lr_scale, gradient accumulation, class accuracy, lagged meters)
