@@ -1,16 +1,25 @@
-import sys, time, torch
+"""LayerNorm forward / backward alone at the step's shape (65 536 x 384 bf16): microseconds and achieved HBM rate."""
+import sys, torch
 sys.path.insert(0, ".")
 from dig_amd import ops
 dev = torch.device("cuda:0")
-def bench(fn, n=50):
-    for _ in range(5): fn()
-    torch.cuda.synchronize(); t = time.perf_counter()
-    for _ in range(n): fn()
-    torch.cuda.synchronize(); return (time.perf_counter() - t) / n * 1e6
-rows, D = 65536, 384
-x = torch.randn(rows, D, device=dev).bfloat16(); dy = torch.randn_like(x); dres = torch.randn_like(x)
-g = torch.ones(D, device=dev); b = torch.zeros(D, device=dev)
+R, D = 65536, 384
+x = torch.randn(R, D, device=dev).bfloat16(); dy = torch.randn(R, D, device=dev).bfloat16(); dres = torch.randn(R, D, device=dev).bfloat16()
+g, b = torch.randn(D, device=dev), torch.randn(D, device=dev)
+dg, db, dc = torch.zeros(D, device=dev), torch.zeros(D, device=dev), torch.zeros(D, device=dev)
 y, mean, rstd = ops.layernorm_fwd(x, g, b, 1e-6)
-dg = torch.zeros(D, device=dev); db = torch.zeros(D, device=dev); dc = torch.zeros(D, device=dev); dx = torch.empty_like(x)
-print("ln fwd %.1f us" % bench(lambda: ops.layernorm_fwd(x, g, b, 1e-6)))
-print("ln bwd %.1f us" % bench(lambda: ops.layernorm_bwd(dy, x, g, b, mean, rstd, dres, dg, db, out=dx, dres_colsum=dc)))
+def bench(f, n=200):
+    for _ in range(20): f()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): f()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+out = torch.empty_like(x)
+t = bench(lambda: ops.layernorm_fwd(x, g, b, 1e-6))
+print(f"ln_fwd            {t:6.1f} us  {2 * R * D * 2 / t / 1e6:5.2f} TB/s (read x, write y)")
+t = bench(lambda: ops.layernorm_bwd(dy, x, g, b, mean, rstd, dres, dg, db, out=out, dres_colsum=dc, defer=True))
+print(f"ln_bwd partials   {t:6.1f} us  {4 * R * D * 2 / t / 1e6:5.2f} TB/s (read dy, x, dres; write dx)")
+t = bench(lambda: ops.layernorm_bwd(dy, x, g, b, mean, rstd, None, dg, db, out=out, defer=True))
+print(f"ln_bwd no dres    {t:6.1f} us  {3 * R * D * 2 / t / 1e6:5.2f} TB/s")
