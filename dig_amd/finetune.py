@@ -14,6 +14,7 @@ node with a hand-written backward on the hot-path kernels (encoder: the pre-trai
 `dig_seq_embed_*`, `dig_gemm_bf16`, `dig_layernorm_*`).  The CPU checker of this step lives with the tests."""
 import ctypes
 import math
+import os
 from collections import OrderedDict
 
 import torch
@@ -25,6 +26,8 @@ from .recognizer import RecModel, _encoder_pos, _sinusoid
 
 BF16, F32 = torch.bfloat16, torch.float32
 cf = ctypes.c_float
+FT_FUSED_QV = os.environ.get("DIG_FT_FUSED_QV", "1") != "0"
+FT_BATCH_REDUCE = os.environ.get("DIG_FT_BATCH_REDUCE", "0") == "1"      # opt-in: fewer launches, ~0.3 ms slower per step
 CLS_PAD = 128                     # classifier rows padded to a multiple of 64 (it is a non-transposed GEMM operand in backward)
 
 
@@ -498,32 +501,52 @@ class _TrainStep:
             ds = self.ds_enc[i]
             # a dropped branch (dropout and/or drop-path) back-propagates the residual gradient under the same mask; its bias
             # gradient is then the column sum of the MASKED gradient, so the LayerNorm kernel's fused residual column sum is off
+            # the block's reductions (slab sums of its four weight gradients, bias / LayerNorm-parameter column sums) go out as two
+            # launches after its last weight-gradient GEMM (ops.GradReduceBatch), as in the pre-training backward
+            red = ops.GradReduceBatch() if FT_BATCH_REDUCE else None
+            wg = red.wgrad if red else ops.linear_wgrad
+            csum = red.colsum_partials if red else ops.colsum_partials
             dz = ops.dropout_apply(dx, ds["mlp"])
             if ds["mlp"] is not None:
                 self.side(lambda: ops.colsum(dz, self.g(b + "mlp.fc2.bias")), dz)
-            self.side(lambda: ops.linear_wgrad(dz, act, self.g(b + "mlp.fc2.weight")), dz, act)
+            self.side(lambda: wg(dz, act, self.g(b + "mlp.fc2.weight")), dz, act)
             dact, bparts = ops.linear_dgrad(dz, self.w(b + "mlp.fc2.weight"), gelu_pre=pre, colsum=True)
-            self.side(lambda: ops.colsum_partials(bparts, self.g(b + "mlp.fc1.bias")), bparts)
-            self.side(lambda: ops.linear_wgrad(dact, ln2, self.g(b + "mlp.fc1.weight")), dact, ln2)
+            self.side(lambda: csum(bparts, self.g(b + "mlp.fc1.bias")), bparts)
+            self.side(lambda: wg(dact, ln2, self.g(b + "mlp.fc1.weight")), dact, ln2)
             dln2 = ops.linear_dgrad(dact, self.w(b + "mlp.fc1.weight"))
             dx_mid, fin2, ws2 = ops.layernorm_bwd(dln2, x_mid, self.p(b + "norm2.weight"), self.p(b + "norm2.bias"), mu2, rs2, dx,
                                                   self.g(b + "norm2.weight"), self.g(b + "norm2.bias"), out=dln2,
                                                   dres_colsum=self.g(b + "mlp.fc2.bias") if ds["mlp"] is None else None, defer=True)
-            self.side(fin2, ws2)                                                       # parameter-gradient reduction: off the chain
+            if red:                                                                    # parameter-gradient reduction: off the chain
+                red.layernorm_finalize(ws2, x_mid.shape[0], D, self.g(b + "norm2.weight"), self.g(b + "norm2.bias"),
+                                       self.g(b + "mlp.fc2.bias") if ds["mlp"] is None else None)
+            else:
+                self.side(fin2, ws2)
             dz = ops.dropout_apply(dx_mid, ds["proj"])
             if ds["proj"] is not None:
                 self.side(lambda: ops.colsum(dz, self.g(b + "attn.proj.bias")), dz)
-            self.side(lambda: ops.linear_wgrad(dz, ctx, self.g(b + "attn.proj.weight")), dz, ctx)
+            self.side(lambda: wg(dz, ctx, self.g(b + "attn.proj.weight")), dz, ctx)
             dctx = ops.linear_dgrad(dz, self.w(b + "attn.proj.weight"))
-            dqkv = ops.attn_bwd(qkv, ctx, dctx, lse, self.B, H, D, scale, drop=ds["attn"])
-            self.side(lambda: ops.linear_wgrad(dqkv, ln1, self.g(b + "attn.qkv.weight")), dqkv, ln1)
-            self.side(lambda: ops.colsum(dqkv, self.g(b + "attn.q_bias"), cols=D), dqkv)
-            self.side(lambda: ops.colsum(dqkv[:, 2 * D:], self.g(b + "attn.v_bias"), cols=D))
+            # q_bias / v_bias gradients leave the attention kernel as per-image partial sums (no pass over the 150 MB dqkv)
+            if FT_FUSED_QV:
+                dqkv, qs, vs = ops.attn_bwd(qkv, ctx, dctx, lse, self.B, H, D, scale, drop=ds["attn"], bias_sums=True)
+                self.side(lambda: (wg(dqkv, ln1, self.g(b + "attn.qkv.weight")), csum(qs, self.g(b + "attn.q_bias")),
+                                   csum(vs, self.g(b + "attn.v_bias"))), dqkv, ln1, qs, vs)
+            else:
+                dqkv = ops.attn_bwd(qkv, ctx, dctx, lse, self.B, H, D, scale, drop=ds["attn"])
+                self.side(lambda: wg(dqkv, ln1, self.g(b + "attn.qkv.weight")), dqkv, ln1)
+                self.side(lambda: ops.colsum(dqkv, self.g(b + "attn.q_bias"), cols=D), dqkv)
+                self.side(lambda: ops.colsum(dqkv[:, 2 * D:], self.g(b + "attn.v_bias"), cols=D))
             dln1 = ops.linear_dgrad(dqkv, self.w(b + "attn.qkv.weight"), out=dctx)
             dx, fin1, ws1 = ops.layernorm_bwd(dln1, x, self.p(b + "norm1.weight"), self.p(b + "norm1.bias"), mu1, rs1, dx_mid,
                                               self.g(b + "norm1.weight"), self.g(b + "norm1.bias"), out=dln1,
                                               dres_colsum=self.g(b + "attn.proj.bias") if ds["proj"] is None else None, defer=True)
-            self.side(fin1, ws1)
+            if red:
+                red.layernorm_finalize(ws1, x.shape[0], D, self.g(b + "norm1.weight"), self.g(b + "norm1.bias"),
+                                       self.g(b + "attn.proj.bias") if ds["proj"] is None else None)
+                self.side(red.flush, *red.tensors())
+            else:
+                self.side(fin1, ws1)
         if "encoder.patch_embed.proj.weight" in M.frozen:
             return
         dx = ops.dropout_apply(dx, self.ds_pos, out=dx)

@@ -132,6 +132,7 @@ def wgrad(dy, x, dw, I, J, rows):
     L.call("dig_reduce_partials", L.ptr(ws), sp, cll(I * J), L.ptr(dw), 1, L.stream())
 
 
+BATCH_SLABS = os.environ.get("DIG_BATCH_SLABS", "1") != "0"
 _ws3 = {}
 
 
@@ -166,6 +167,9 @@ class GradReduceBatch:
         """dw[I,J] += dy[rows,:I]^T x[rows,:J]: the split-R GEMM now, the slab sum at flush()."""
         I, J = dw.shape
         rows = dy.shape[0] if rows is None else rows
+        if not BATCH_SLABS:
+            wgrad(dy, x, dw, I, J, rows)
+            return
         sp, bk = wgrad_splits(rows, ((I + 127) // 128) * ((J + 127) // 128))
         need = sp * I * J
         if need > self.SLAB_FLOATS or len(self.slabs) == 8:
