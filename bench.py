@@ -150,8 +150,8 @@ def cpu_baseline(model_name, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)      # >= 100 timed steps after >= 20 warm-up steps
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=128, help="samples per GPU")
     ap.add_argument("--model", default="small", choices=["tiny", "small", "base"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
