@@ -154,9 +154,16 @@ def test_step_vs_reference_golden_fixture(name):
     grads = {n: p.grad.detach().float().cpu() for n, p in model.named_parameters() if p.requires_grad}
     names, norms = g["s0/grad_names"].tolist(), g["s0/grad_norms"]
     tot = float(np.sqrt((norms ** 2).sum()))
+    # per-tensor gradient norms against the REFERENCE's; yardstick = the oracle of the same step under CPU bf16 autocast (the device may
+    # be at most twice as far from the reference as that run is, + 3 %; the round-1 form of this check was a flat 8 %)
+    hp0 = dataclasses.replace(hp, moco_m=float(g["s0/stat/moco_m"]))
+    torch.set_num_threads(max(8, min(32, os.cpu_count() or 8)))
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        _, bf_g, _, _ = O.OracleTrainer(cfg, *O.det_state(cfg, seed)).loss_and_grads(im, au, mk, hp0)
     for i, n in enumerate(names):
         if norms[i] > 1e-3 * tot:                                        # tensors that carry the gradient
-            assert abs(grads[n].norm().item() / norms[i] - 1) < 8e-2, (n, grads[n].norm().item(), norms[i])
+            q_hip, q_bf = grads[n].norm().item() / norms[i], bf_g[n].float().norm().item() / norms[i]
+            assert abs(q_hip - 1) <= 2 * abs(q_bf - 1) + 3e-2, (n, q_hip, q_bf)
     # mask gather order is bit-exact => vis_out rows line up with the reference's: compare the full [B, 179, 48] tensor, captured
     # from the step's own forward (before the optimizer touched the weights)
     vis_ref = torch.from_numpy(g["s0/cap/vis_out/full"]).float()
@@ -188,13 +195,22 @@ def test_two_steps_carry_state():
         for k in ("loss", "loss_pixel", "loss_contrast"):
             assert close(stats[s][k], ref[k], rtol=3e-2, atol=3e-3), (s, k, stats[s][k], ref[k])
     assert opt._step == 2 and int(model.state_dict()["pix_projector.1.num_batches_tracked"]) == 2
-    # parameters moved, in the same direction as the oracle's (sign-like Adam steps: compare the update vectors)
+    # parameters moved, in the same direction as the oracle's.  Two sign-like Adam steps turn small gradient noise into large
+    # update noise, so the yardstick is the same oracle run under CPU bf16 autocast: the device may be at most twice as far from
+    # the fp32 updates as that run is (the round-1 form of this check was a bare cosine > 0.7)
     P0, _ = O.det_state(cfg, seed)
-    for n in ("encoder.blocks.0.mlp.fc1.weight", "pix_decoder.0.weight", "encoder_projection_layer.3.weight"):
+    tb = O.OracleTrainer(cfg, *O.det_state(cfg, seed))
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        for s in range(2):
+            tb.step(*batches[s], dataclasses.replace(hp, moco_m=O.adjust_moco_momentum(float(s), 10, hp.moco_m)))
+    cos = torch.nn.functional.cosine_similarity
+    for n in ("encoder.blocks.0.mlp.fc1.weight", "pix_decoder.0.weight", "encoder_projection_layer.3.weight", "encoder.blocks.1.attn.qkv.weight",
+              "predictor.0.weight", "encoder.patch_embed.proj.weight"):
         d_hip = dict(model.named_parameters())[n].detach().cpu() - P0[n]
         d_ref = tr.P[n] - P0[n]
-        c = torch.nn.functional.cosine_similarity(d_hip.reshape(1, -1), d_ref.reshape(1, -1)).item()
-        assert c > 0.7, (n, c)
+        d_bf = tb.P[n].float() - P0[n]
+        c_hip, c_bf = cos(d_hip.reshape(1, -1), d_ref.reshape(1, -1)).item(), cos(d_bf.reshape(1, -1), d_ref.reshape(1, -1)).item()
+        assert (1 - c_hip) <= 2 * (1 - c_bf) + 2e-2, (n, c_hip, c_bf)
 
 
 @pytest.mark.parametrize("B", [1, 3, 5])
