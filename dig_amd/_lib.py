@@ -6,7 +6,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("DIG_HIP_LIB") or os.path.join(_HERE, "lib", "libdig_hip.so")      # DIG_HIP_LIB: another BUILD of the same library (A/B runs)
+LIB_PATH = os.path.join(_HERE, "lib", "libdig_hip.so")
 
 _lib = None
 
