@@ -285,7 +285,7 @@ def main():
         # HBM bytes per launch: rocprofv3 --pmc passes (FETCH_SIZE x2 per the gfx950 correction, WRITE_SIZE) over this same command,
         # collected with tools/collect_pmc.sh and committed with the hash of the library they were measured on; reported only while
         # that hash still matches the library this run loaded
-        traffic, traffic_src = None, None
+        traffic, traffic_src, step_bytes = None, None, None
         try:
             import hashlib
             from dig_amd import _lib
@@ -295,6 +295,8 @@ def main():
                 lib_hash = hashlib.sha256(f.read()).hexdigest()[:16]
             if tj.get("lib_sha256_16") == lib_hash:
                 traffic = tj["kernels"][dom]["hbm_bytes_per_launch"]
+                if tj.get("steps_in_run"):                      # all kernel families of the step: measured HBM bytes per step
+                    step_bytes = sum(v["launches"] * v["hbm_bytes_per_launch"] for v in tj["kernels"].values()) / tj["steps_in_run"]
                 traffic_src = f"profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE, library {lib_hash})"
             else:
                 traffic_src = f"profiles/r02_pmc_traffic.json was collected on library {tj.get('lib_sha256_16')}, this run loaded {lib_hash}: not reported"
@@ -306,7 +308,7 @@ def main():
         roof = {"bound": "mfma", **mfma_view, "traffic": traffic,
                 "kernel": f"dig_gemm_bf16[{dom}] (gemm_kernel / gemm_wide_kernel / gemm_pwide_kernel, v_mfma_f32_32x32x16_bf16, fused bias/GELU/residual epilogues)",
                 "traffic_source": traffic_src,
-                "mfma": mfma_view, "hbm": hbm_view,
+                "mfma": mfma_view, "hbm": hbm_view, "step_hbm_bytes": step_bytes,
                 "flops_per_launch": d["flops"] / d["launches"], "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
                 "avg_launch_us": d["seconds"] / d["launches"] * 1e6, "launches_per_step": d["launches"] // 2,
                 "by_variant": {k: {"TFLOP/s": v["flops"] / v["seconds"] / 1e12, "GB/s": v["bytes"] / v["seconds"] / 1e9,
@@ -334,7 +336,11 @@ def main():
             "config": {"workload": f"{model_name}: full train_one_epoch step, {WORKLOAD_TEXT[a.workload]}; dim 256, mlp 4096, m 0.99 cos, "
                                    f"T 0.2, 4 windows, mask 0.7, 2 views, AdamW wd 0.1, {B} samples/GPU, random-init weights",
                        "global_batch": B * world, "parallelism": f"dp{world}", "loss": float(stats.get("loss", float('nan')))},
-            "step_mfma_frac": (value / world * fl / PEAK_BF16) if fl else None, "host_ms_per_step": host_ms, "step_graph": graphed,
+            "step_mfma_frac": (value / world * fl / PEAK_BF16) if fl else None,
+            # the whole step against the HBM roof: PMC-measured bytes of every kernel family per step (profiles/r02_pmc_traffic.json,
+            # same library hash) / step time / 8 TB/s -- the roof that actually prices this model width
+            "step_hbm_frac": (roof["step_hbm_bytes"] / (dt / a.steps) / PEAK_HBM) if roof and roof.get("step_hbm_bytes") and B == 128 and a.model == "small" and a.workload == "mim_moco" else None,
+            "host_ms_per_step": host_ms, "step_graph": graphed,
             "roofline": roof, ("mim_only" if a.workload == "mim_moco" else "mim_moco"): mim_only}
     if not a.no_cpu_baseline and world == 1:
         line["cpu_baseline"] = cpu_baseline(model_name, a.cpu_budget)

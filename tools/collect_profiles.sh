@@ -30,6 +30,7 @@ python - <<PY
 import hashlib, json
 p = "$OUT/${TAG}_pmc_traffic.json"
 d = json.load(open(p))
+d["steps_in_run"] = 7          # --steps 3 --warmup 2 + the two instrumented steps of the roofline probe
 d["lib_sha256_16"] = hashlib.sha256(open("$ROOT/dig_amd/lib/libdig_hip.so", "rb").read()).hexdigest()[:16]
 json.dump(d, open(p, "w"), indent=1)
 PY
