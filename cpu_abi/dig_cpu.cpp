@@ -913,6 +913,102 @@ int dig_colsum_partials(const float* partials, int n_parts, int C, float* out, h
   return DIG_OK;
 }
 
+// ---- fused MLP chain (include/dig_hip.h; csrc/mlp_chain.hip): the same arithmetic as plain loops -- fp32 accumulation, the hidden
+// values rounded to bf16 between the two layers, bias and residual added in fp32 before the final rounding
+int dig_mlp_chain_supported(int D, int F) { return D == 384 && F >= 128 && F % 128 == 0 && F <= 6144; }
+int dig_mlp_chain_colsum_rows(int R) { return ((R + 127) / 128) * 4; }
+
+int dig_mlp_chain_fwd(const void* x_, const void* w1_, const float* b1, const void* w2_, const float* b2, const void* resid_, void* out_,
+                      void* pre_out_, void* act_out_, int R, int D, int F, hipStream_t) {
+  if (!x_ || !w1_ || !w2_ || !out_ || R <= 0) return DIG_ERR_ARG;
+  if (!dig_mlp_chain_supported(D, F)) return DIG_ERR_UNSUPPORTED;
+  if ((pre_out_ == nullptr) != (act_out_ == nullptr)) return DIG_ERR_ARG;
+  if (!aligned16(x_) || !aligned16(w1_) || !aligned16(w2_) || !aligned16(out_)) return DIG_ERR_ALIGN;
+  const bf16_t* x = (const bf16_t*)x_; const bf16_t* w1 = (const bf16_t*)w1_; const bf16_t* w2 = (const bf16_t*)w2_;
+  const bf16_t* resid = (const bf16_t*)resid_;
+  bf16_t* out = (bf16_t*)out_; bf16_t* pre_out = (bf16_t*)pre_out_; bf16_t* act_out = (bf16_t*)act_out_;
+  std::vector<float> W1((size_t)F * D), W2((size_t)D * F);
+  for (size_t i = 0; i < W1.size(); ++i) { W1[i] = bf2f(w1[i]); W2[i] = bf2f(w2[i]); }
+#pragma omp parallel
+  {
+    std::vector<float> xr(D), h(F);
+#pragma omp for
+    for (int r = 0; r < R; ++r) {
+      for (int k = 0; k < D; ++k) xr[k] = bf2f(x[(size_t)r * D + k]);
+      for (int f = 0; f < F; ++f) {
+        float a = b1 ? b1[f] : 0.f;
+        const float* w = &W1[(size_t)f * D];
+        for (int k = 0; k < D; ++k) a += w[k] * xr[k];
+        if (pre_out) pre_out[(size_t)r * F + f] = f2bf(a);
+        const bf16_t g = f2bf(gelu_f(a));
+        if (act_out) act_out[(size_t)r * F + f] = g;
+        h[f] = bf2f(g);
+      }
+      for (int j = 0; j < D; ++j) {
+        float a = (b2 ? b2[j] : 0.f) + (resid ? bf2f(resid[(size_t)r * D + j]) : 0.f);
+        const float* w = &W2[(size_t)j * F];
+        for (int f = 0; f < F; ++f) a += w[f] * h[f];
+        out[(size_t)r * D + j] = f2bf(a);
+      }
+    }
+  }
+  return DIG_OK;
+}
+
+int dig_mlp_chain_bwd(const void* dy_, const void* w2t_, const void* pre_, const void* w1t_, void* dpre_out_, void* dx_out_,
+                      float* colsum_partials, int R, int D, int F, hipStream_t) {
+  if (!dy_ || !w2t_ || !pre_ || !w1t_ || !dpre_out_ || !dx_out_ || R <= 0) return DIG_ERR_ARG;
+  if (!dig_mlp_chain_supported(D, F)) return DIG_ERR_UNSUPPORTED;
+  if (!aligned16(dy_) || !aligned16(w2t_) || !aligned16(pre_) || !aligned16(w1t_) || !aligned16(dpre_out_) || !aligned16(dx_out_)) return DIG_ERR_ALIGN;
+  const bf16_t* dy = (const bf16_t*)dy_; const bf16_t* w2t = (const bf16_t*)w2t_; const bf16_t* w1t = (const bf16_t*)w1t_;
+  const bf16_t* pre = (const bf16_t*)pre_;
+  bf16_t* dpre = (bf16_t*)dpre_out_; bf16_t* dx = (bf16_t*)dx_out_;
+  std::vector<float> W2T((size_t)F * D), W1T((size_t)D * F);
+  for (size_t i = 0; i < W2T.size(); ++i) { W2T[i] = bf2f(w2t[i]); W1T[i] = bf2f(w1t[i]); }
+#pragma omp parallel
+  {
+    std::vector<float> yr(D), h(F);
+#pragma omp for
+    for (int r = 0; r < R; ++r) {
+      for (int k = 0; k < D; ++k) yr[k] = bf2f(dy[(size_t)r * D + k]);
+      for (int f = 0; f < F; ++f) {
+        float a = 0.f;
+        const float* w = &W2T[(size_t)f * D];
+        for (int k = 0; k < D; ++k) a += w[k] * yr[k];
+        const bf16_t g = f2bf(a * dgelu_f(bf2f(pre[(size_t)r * F + f])));
+        dpre[(size_t)r * F + f] = g;
+        h[f] = bf2f(g);
+      }
+      for (int j = 0; j < D; ++j) {
+        float a = 0.f;
+        const float* w = &W1T[(size_t)j * F];
+        for (int f = 0; f < F; ++f) a += w[f] * h[f];
+        dx[(size_t)r * D + j] = f2bf(a);
+      }
+    }
+  }
+  if (colsum_partials) {                                  // partial row p = 32-row block p (the rounded values, as the device sums them)
+    const int np = dig_mlp_chain_colsum_rows(R);
+#pragma omp parallel for
+    for (int pr = 0; pr < np; ++pr)
+      for (int f = 0; f < F; ++f) {
+        float a = 0.f;
+        for (int r = pr * 32; r < std::min(R, pr * 32 + 32); ++r) a += bf2f(dpre[(size_t)r * F + f]);
+        colsum_partials[(size_t)pr * F + f] = a;
+      }
+  }
+  return DIG_OK;
+}
+
+int dig_transpose_bf16(const void* src_, void* dst_, int rows, int cols, hipStream_t) {
+  if (!src_ || !dst_ || rows <= 0 || cols <= 0) return DIG_ERR_ARG;
+  const bf16_t* src = (const bf16_t*)src_; bf16_t* dst = (bf16_t*)dst_;
+#pragma omp parallel for
+  for (int r = 0; r < rows; ++r)
+    for (int c = 0; c < cols; ++c) dst[(size_t)c * rows + r] = src[(size_t)r * cols + c];
+  return DIG_OK;
+}
+
 int dig_gelu_bwd(const void* dact_, const void* pre_, void* dpre_, long long n, hipStream_t) {
   if (!dact_ || !pre_ || !dpre_ || n <= 0 || (n & 7)) return DIG_ERR_ARG;
   if (!aligned16(dact_) || !aligned16(pre_) || !aligned16(dpre_)) return DIG_ERR_ALIGN;

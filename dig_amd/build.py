@@ -10,6 +10,9 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libdig_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-ffp-contract=fast",
          "-Wno-unused-result"]
+# per-file extras.  mlp_chain.hip: the SLP vectoriser packs the GELU polynomial into v_pk_fma_f32 pairs, which cost s_nop hazard
+# padding in a VALU stream that is placed between MFMAs by hand (205 -> 44 s_nop in the S-wave loop without it)
+EXTRA_FLAGS = {"mlp_chain.hip": ["-fno-slp-vectorize"]}
 
 
 def sources():
@@ -40,7 +43,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     def cc(job):
         src, obj = job
-        cmd = [hipcc] + FLAGS + ["-I", os.path.join(os.path.dirname(HERE), "include"), "-c", src, "-o", obj]
+        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-I", os.path.join(os.path.dirname(HERE), "include"), "-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")

@@ -1,0 +1,512 @@
+// Fused two-layer MLP ("chain") kernels for gfx950: the hidden tensor of a transformer FFN never goes through HBM as a GEMM operand.
+//
+// Reference math: Mlp.forward, modeling_finetune.py:53-60 -- x + fc2(gelu(fc1(LN2(x)))) inside Block.forward :150-158 -- and its
+// autograd.  One launch replaces the fc1 GEMM (+ bias + exact-erf GELU) and the fc2 GEMM (+ bias + residual) of a block
+// (forward), or the fc2 data gradient (x GELU') and the fc1 data gradient (backward):
+//     forward :  out[R,D] = resid + b2 + gelu(X[R,D] W1[F,D]^T + b1) W2[D,F]^T
+//     backward:  dX[R,D]  = ((dY[R,D] W2[D,F]) * gelu'(pre[R,F])) W1[F,D]          (given W2^T [F,D] and W1^T [D,F] copies)
+// Both are the same chain   out = epi( ew( X B1^T ) B2^T )   with B1 [F,D] and B2 [D,F] read along their contiguous axis.
+//
+// Design (CDNA4).  A workgroup owns 128 token rows and walks the hidden dimension F in chunks of 64; 8 waves = 4 pairs, a pair
+// owns 32 tokens, the two waves of a pair sit on the same SIMD and have different ROLES:
+//   * the S-wave keeps its 32 x D slice of X in registers (MFMA B fragments, 96 VGPRs) and computes S^T[64 f, 32 tokens] =
+//     B1chunk X^T (swapped operands: a lane owns a token, its registers run over f), applies the elementwise op (bias + GELU, or
+//     x GELU'(pre)) in fp32 and parks the bf16 result P[32 tokens][64 f] in LDS (4 KiB per pair);
+//   * the O-wave keeps the 32 x D output accumulators in registers (192 VGPRs, initialised with bias + residual, so the epilogue
+//     is a convert-and-store) and computes out^T[D, 32 tokens] += B2chunk P^T for the chunk the S-wave finished a period earlier;
+//     it also drains the side outputs (pre-activation / GELU output for the online forward, d(pre-activation) for the backward)
+//     from LDS to HBM with row-contiguous 16-byte stores.
+// The matrix pipe of a SIMD is shared by the pair, and the S-wave's VALU work (14 ops per hidden element) runs in the shadow of
+// the O-wave's MFMAs -- the hardware's own wave arbitration does the overlap that a single 16-wave lock-step GEMM cannot
+// (its GELU epilogue is as long as its K loop).
+// Weights stream HBM/L2 -> LDS by buffer_load ... lds into two 3-slot rings of 16 KiB (B1: [64 f][128 k], B2: [128 j][64 f],
+// XOR swizzle on the source side); a "tick" = one slot of each ring = 16 MFMAs per wave, one workgroup barrier per tick, the
+// DMA for tick n+2 is issued right behind the barrier of tick n (counted s_waitcnt vmcnt, raw s_barrier).  Three ticks = one chunk,
+// so the ring slot of a tick is its position in the chunk (compile-time).
+// LDS: rings 96 KiB + P 16 KiB + (forward) b1 [F] fp32 + (online forward) pre tile 16 KiB / (backward) pre tiles 2 x 16 KiB.
+// The per-chunk pipeline is  S-wave: MFMA(c) | elementwise(c-1)   O-wave: MFMA(c-2)   => two chunk periods of fill/drain in 26.
+//
+// Backward extras: the fc1 bias gradient = column sums of d(pre-activation) over tokens.  In the S-wave's layout tokens run
+// across lanes; instead of 160 DPP adds per chunk the packed bf16 block is multiplied by a constant selection matrix on the
+// matrix core (D[m, n] = P[m, n]: an MFMA used as a transposer, 4 MFMAs per chunk), after which tokens run over a lane's
+// registers: 15 in-lane adds + one cross-half add per 32 columns.  Partials go to colsum[ceil(R/32)][F] (fp32), summed by
+// dig_colsum_partials.
+#include "common.h"
+#include <type_traits>
+
+// hooks of tools/experiments/chain_lab.hip (empty in the product build): per-wave time accounting of the tick protocol and
+// compile-time ablations (bit 0: no elementwise work, 1: no ring DMA, 2: no O-wave MFMAs, 3: no S-wave MFMAs)
+#ifndef DIG_CHAIN_T
+#define DIG_CHAIN_T(k)
+#define DIG_CHAIN_T_BEGIN()
+#define DIG_CHAIN_T_END()
+#endif
+#ifndef DIG_CHAIN_ABL
+#define DIG_CHAIN_ABL 0
+#endif
+
+namespace {
+
+constexpr int KD = 384;                 // model width: reduction dim of stage 1, output width of stage 2
+constexpr int FC = 64;                  // hidden units per chunk
+constexpr int BM = 128;                 // token rows per workgroup
+constexpr int NJB = KD / 32;            // 12 output column blocks per token block
+constexpr int SLOT = 16384;
+constexpr int W1_RING = 0;
+constexpr int W2_RING = 3 * SLOT;
+constexpr int P_OFF = 6 * SLOT;         // 4 pairs x [32 tokens][64 f] bf16
+constexpr int X_OFF = P_OFF + SLOT;     // MODE 1: pre-activation tile (output staging); MODE 2: two pre tiles (DMA input); MODE 0: b1
+constexpr int KS_PER_TICK = 8;          // 128 k per B1 slot
+constexpr int JB_PER_TICK = 4;          // 128 output columns per B2 slot
+
+struct ChainParams {
+  const bf16_t* X;        // [R, KD]
+  const bf16_t* B1;       // [F, KD]
+  const bf16_t* B2;       // [KD, F]
+  const float* bias1;     // [F] (forward) or null
+  const float* bias2;     // [KD] or null
+  const bf16_t* resid;    // [R, KD] or null
+  bf16_t* out;            // [R, KD]
+  bf16_t* side0;          // MODE 1: gelu output [R, F];  MODE 2: d(pre-activation) [R, F];  may be null in MODE 1
+  bf16_t* side1;          // MODE 1: pre-activation out [R, F];  MODE 2: pre-activation in [R, F]
+  float* colsum;          // MODE 2: [ceil(R/32)][F] or null
+  int R, F;
+  unsigned x_bytes, w_bytes, side_bytes;
+};
+
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void lds_write8(unsigned addr, uint2 v) {
+  // an LDS store the compiler does not see: a visible one would be ordered behind the LDS-DMA in flight with s_waitcnt vmcnt(0)
+  asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(uintptr_t)LDS_PTR(p); }
+
+// NOTE on LDS reads: hipcc (ROCm 7.2) puts s_waitcnt vmcnt(0) in front of an LDS load that carries no alias information while an
+// LDS-DMA is in flight; loads through ext_vector types (bf16x8, bf16x4, f32x4, dig_u32x4) carry TBAA tags and are left alone --
+// every LDS read below is of that kind (checked in the ISA: no vmcnt(0) inside the tick loops).  LDS writes are inline asm.
+// MODE 0: forward, no side outputs (momentum branch / evaluation);  1: forward + pre-activation and GELU output (online branch:
+// what the backward reads);  2: backward (data gradient through both layers + d(pre-activation) + fc1 bias-gradient partials)
+template <int MODE>
+__global__ __launch_bounds__(512) void mlp_chain_kernel(ChainParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int B1S_OFF = X_OFF + (MODE == 1 ? SLOT : 0);          // forward: b1 [F] fp32 in LDS
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int pair = wave & 3, role = wave >> 2;
+  const int hi = lane >> 5, rr = lane & 31;
+  const int m0 = blockIdx.x * BM;
+  const int F = p.F;
+  const int NC = F / FC;
+  DIG_CHAIN_T_BEGIN()
+
+  const auto rB1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.B1, 0, p.w_bytes, 0x00020000);
+  const auto rB2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.B2, 0, p.w_bytes, 0x00020000);
+  const auto rX = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, p.x_bytes, 0x00020000);
+  const auto rSide1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.side1, 0, p.side1 ? p.side_bytes : 0, 0x00020000);
+
+  if (MODE != 2) {                                                   // b1 -> LDS, before any LDS-DMA is in flight
+    float* b1s = reinterpret_cast<float*>(smem + B1S_OFF);
+    for (int i = tid; i < F; i += 512) b1s[i] = p.bias1 ? p.bias1[i] : 0.f;
+    __syncthreads();
+  }
+
+  // ---- weight rings: per-thread source offsets (the swizzle lives on the source side: LDS-DMA destinations are lane-linear)
+  unsigned v1[2], v2[2], vp[2];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int pc = it * 512 + tid;
+    const int r1 = pc >> 4, c1 = (pc & 15) ^ (r1 & 15);              // B1 slot: [64 f][128 k], 16 chunks of 16 B per row
+    v1[it] = (unsigned)((r1 * KD + 8 * c1) * 2);
+    const int r2 = pc >> 3, c2 = (pc & 7) ^ ((r2 >> 1) & 7);         // B2 slot: [128 j][64 f], 8 chunks per row
+    v2[it] = (unsigned)((r2 * F + 8 * c2) * 2);
+    vp[it] = (unsigned)(((size_t)(m0 + r2) * F + 8 * c2) * 2);       // MODE 2 pre tile: [128 tokens][64 f], same image as P
+  }
+  auto issue_ring = [&](int slot, unsigned s1, unsigned s2) {
+    unsigned char* d1 = smem + W1_RING + slot * SLOT + wave * 1024;
+    unsigned char* d2 = smem + W2_RING + slot * SLOT + wave * 1024;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) __builtin_amdgcn_raw_ptr_buffer_load_lds(rB1, LDS_PTR(d1 + it * 8192), 16, v1[it], s1, 0, 0);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) __builtin_amdgcn_raw_ptr_buffer_load_lds(rB2, LDS_PTR(d2 + it * 8192), 16, v2[it], s2, 0, 0);
+  };
+  // Barrier of tick (c, TAU): this wave's DMA pieces of the tick have landed (NW = VMEM operations it has issued behind them), its
+  // own LDS traffic is complete; then the DMA for the tick after next goes out (ring slot = position of that tick in its chunk).
+  auto tick_sync = [&](auto tau_tag, auto nw_tag, int c) {
+    constexpr int TAU = decltype(tau_tag)::value;
+    DIG_CHAIN_T(3)
+    wait_vm<decltype(nw_tag)::value>();
+    DIG_CHAIN_T(0)
+    wait_lgkm0();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    DIG_CHAIN_T(1)
+    constexpr int tn = (TAU + 2) % 3;
+    const int cn = TAU == 0 ? c : c + 1;
+    const int d1 = cn < NC ? cn : 0;                                  // past the end: re-read a valid piece into the free slot
+    const int d2 = (cn >= 2 && cn < NC + 2) ? cn - 2 : 0;
+    if (!(DIG_CHAIN_ABL & 2)) issue_ring(tn, (unsigned)((d1 * FC * KD + tn * 128) * 2), (unsigned)((tn * 128 * F + d2 * FC) * 2));
+    if (MODE == 2 && TAU == 0) {                                      // pre-activation tile of chunk c (used in period c + 1)
+      const int dc = c < NC ? c : NC - 1;
+      unsigned char* dp = smem + X_OFF + (c & 1) * SLOT + wave * 1024;
+#pragma unroll
+      for (int it = 0; it < 2; ++it) __builtin_amdgcn_raw_ptr_buffer_load_lds(rSide1, LDS_PTR(dp + it * 8192), 16, vp[it], (unsigned)(dc * FC * 2), 0, 0);
+    }
+    DIG_CHAIN_T(2)
+  };
+  constexpr int E_ALL = MODE == 2 ? 2 : 0;                            // VMEM operations every wave issues behind the ring DMA of a tick 0
+  using T0 = std::integral_constant<int, 0>;
+  using T1 = std::integral_constant<int, 1>;
+  using T2 = std::integral_constant<int, 2>;
+  using TRUE_ = std::true_type;
+  using FALSE_ = std::false_type;
+
+  issue_ring(0, 0u, 0u);                                              // ticks (0,0) and (0,1)
+  issue_ring(1, (unsigned)(128 * 2), (unsigned)((128 * F) * 2));
+
+  const int psw = (rr >> 1) & 7;
+  if (role == 0) {
+    // =========================================================== S-wave =====================================================
+    bf16x8 xf[KD / 16];
+    {
+      const unsigned xo = (unsigned)(((size_t)(m0 + pair * 32 + rr) * KD + hi * 8) * 2);       // rows beyond R read as zero
+#pragma unroll
+      for (int s = 0; s < KD / 16; ++s)
+        xf[s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rX, xo + s * 32, 0, 0));
+    }
+    int a1off[KS_PER_TICK];
+#pragma unroll
+    for (int s = 0; s < KS_PER_TICK; ++s) a1off[s] = rr * 256 + (((2 * s + hi) ^ (rr & 15)) << 4);
+    const unsigned pw_base = lds_addr(smem + P_OFF + pair * 4096 + rr * 128 + hi * 8);
+    // selection matrices of the column-sum transposer (MODE 2): E_u[(hi', i)][n] = 1 iff n == 16 u + 8 (i >> 2) + 4 hi' + (i & 3)
+    bf16x8 esel[2];
+    if (MODE == 2) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) esel[u][i] = (rr == 16 * u + 8 * (i >> 2) + 4 * hi + (i & 3)) ? (short)0x3F80 : (short)0;
+    }
+    f32x16 Sa[2], Sb[2];
+
+    // One chunk period of the S-wave.  The instruction order below IS the schedule: every MFMA is followed by one "gap" of
+    // elementwise work for chunk c - 1 (one hidden element = ~14 VALU ops, which issue in the shadow of that MFMA and of the
+    // O-wave's) and a sched_barrier, so the compiler neither clusters the VALU work nor serialises LDS read -> MFMA pairs; the
+    // B1 fragments of k-step s + 1 are requested before the MFMAs of k-step s.
+    auto s_period = [&](auto m1_tag, auto g_tag, f32x16 (&Sc)[2], f32x16 (&Sp)[2], int c) {
+      constexpr bool M1 = decltype(m1_tag)::value, G = decltype(g_tag)::value;
+      uint2 pk[8];                                                    // packed results of chunk c - 1: quad q = (block q >> 2, g = q & 3)
+      uint2 pkpre[3];
+      bf16x4 prq[3];                                                  // MODE 2: pre-activation quads of the current tick
+      float ga[4];
+      auto quad_addr = [&](int q) { return pw_base + (unsigned)((q ^ psw) << 4); };          // 16-byte chunk 4 b + g = q of the token's row
+      auto colsum_block = [&](int b) {                                // MODE 2: column sums over this wave's 32 tokens of block b of chunk c - 1
+        if (!(G && MODE == 2)) return;
+        if (!p.colsum) return;
+        f32x16 z;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) z[e] = 0.f;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const uint4 a4 = make_uint4(pk[4 * b + 2 * u].x, pk[4 * b + 2 * u].y, pk[4 * b + 2 * u + 1].x, pk[4 * b + 2 * u + 1].y);
+          z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a4), esel[u], z, 0, 0, 0);
+        }
+        float sm = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sm += z[e];
+        sm += __shfl_xor(sm, 32, 64);
+        if (hi == 0) p.colsum[(size_t)(blockIdx.x * 4 + pair) * F + (c - 1) * FC + b * 32 + rr] = sm;
+      };
+      // gap i (0..15) of tick TAU: element e = i & 3 of quad q = 3 TAU + (i >> 2); ticks 0 / 1 carry 12 elements, tick 2 carries 8
+      auto gap = [&](auto tau_tag, auto i_tag) {
+        constexpr int TAU = decltype(tau_tag)::value, I = decltype(i_tag)::value;
+        if (G && !(DIG_CHAIN_ABL & 1)) {
+          constexpr int NEL = TAU < 2 ? 12 : 8;
+          if (TAU == 1 && I < 3) {                                    // the three quads tick 0 computed (the P tile was not free yet)
+            lds_write8(quad_addr(I), pk[I]);
+            if (MODE == 1) lds_write8(quad_addr(I) + (unsigned)(X_OFF - P_OFF), pkpre[I]);
+          }
+          if (I < NEL) {
+            constexpr int q = 3 * TAU + (I >> 2), e = I & 3, b = q >> 2, g = q & 3;
+            float v = Sp[b][4 * g + e];
+            if (MODE == 2) {
+              v *= dgelu_f(bf2f((bf16_t)prq[I >> 2][e]));
+              ga[e] = v;
+            } else {
+              if (MODE == 1) {
+                if (e == 1) { const unsigned w = pack_bf2(Sp[b][4 * g], Sp[b][4 * g + 1]); if (TAU == 0) pkpre[q].x = w; else pkpre[0].x = w; }
+                if (e == 3) { const unsigned w = pack_bf2(Sp[b][4 * g + 2], Sp[b][4 * g + 3]); if (TAU == 0) pkpre[q].y = w; else pkpre[0].y = w; }
+              }
+              ga[e] = gelu_f(v);
+            }
+            if (e == 1) pk[q].x = pack_bf2(ga[0], ga[1]);
+            if (e == 3) {
+              pk[q].y = pack_bf2(ga[2], ga[3]);
+              if (TAU > 0) {
+                lds_write8(quad_addr(q), pk[q]);
+                if (MODE == 1) lds_write8(quad_addr(q) + (unsigned)(X_OFF - P_OFF), pkpre[0]);
+              }
+            }
+          }
+          if (MODE == 2 && TAU == 1 && I == 12) colsum_block(0);
+          if (MODE == 2 && TAU == 2 && I == 8) colsum_block(1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      auto tick = [&](auto tau_tag) {
+        constexpr int TAU = decltype(tau_tag)::value;
+        if (G && MODE == 2) {                                         // pre-activation quads of this tick (DMA'd two periods ago)
+          constexpr int NQ = TAU < 2 ? 3 : 2;
+#pragma unroll
+          for (int k = 0; k < NQ; ++k)
+            prq[k] = *reinterpret_cast<const bf16x4*>(smem + X_OFF + ((c - 1) & 1) * SLOT + pair * 4096 + rr * 128 + hi * 8 + (((3 * TAU + k) ^ psw) << 4));
+        }
+        const unsigned char* w = smem + W1_RING + TAU * SLOT;
+        bf16x8 wa[2], wb[2];
+        if (M1) { wa[0] = *reinterpret_cast<const bf16x8*>(w + a1off[0]); wa[1] = *reinterpret_cast<const bf16x8*>(w + 8192 + a1off[0]); }
+        __builtin_amdgcn_sched_barrier(0);
+        auto kstep = [&](auto s_tag, bf16x8 (&cur)[2], bf16x8 (&nxt)[2]) {
+          constexpr int S = decltype(s_tag)::value;
+          if (M1 && S < KS_PER_TICK - 1) {
+            nxt[0] = *reinterpret_cast<const bf16x8*>(w + a1off[S + 1]);
+            nxt[1] = *reinterpret_cast<const bf16x8*>(w + 8192 + a1off[S + 1]);
+          }
+          if (M1 && !(DIG_CHAIN_ABL & 8)) Sc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[0], xf[TAU * KS_PER_TICK + S], Sc[0], 0, 0, 0);
+          gap(tau_tag, std::integral_constant<int, 2 * S>{});
+          if (M1 && !(DIG_CHAIN_ABL & 8)) Sc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[1], xf[TAU * KS_PER_TICK + S], Sc[1], 0, 0, 0);
+          gap(tau_tag, std::integral_constant<int, 2 * S + 1>{});
+        };
+        kstep(std::integral_constant<int, 0>{}, wa, wb); kstep(std::integral_constant<int, 1>{}, wb, wa);
+        kstep(std::integral_constant<int, 2>{}, wa, wb); kstep(std::integral_constant<int, 3>{}, wb, wa);
+        kstep(std::integral_constant<int, 4>{}, wa, wb); kstep(std::integral_constant<int, 5>{}, wb, wa);
+        kstep(std::integral_constant<int, 6>{}, wa, wb); kstep(std::integral_constant<int, 7>{}, wb, wa);
+      };
+      // ---- tick 0
+      tick_sync(T0{}, std::integral_constant<int, 4>{}, c);
+      if (M1) {
+        if (MODE != 2) {
+          const float* b1s = reinterpret_cast<const float*>(smem + B1S_OFF) + c * FC + 4 * hi;
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const f32x4 bv = *reinterpret_cast<const f32x4*>(b1s + b * 32 + g * 8);
+              Sc[b][4 * g] = bv[0]; Sc[b][4 * g + 1] = bv[1]; Sc[b][4 * g + 2] = bv[2]; Sc[b][4 * g + 3] = bv[3];
+            }
+        } else {
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) Sc[b][e] = 0.f;
+        }
+      }
+      tick(T0{});
+      // ---- tick 1: the O-wave took chunk c - 2 out of the P tile during tick 0; chunk c - 1 may go in now
+      tick_sync(T1{}, std::integral_constant<int, 4 + E_ALL>{}, c);
+      tick(T1{});
+      // ---- tick 2
+      tick_sync(T2{}, std::integral_constant<int, 4 + E_ALL>{}, c);
+      tick(T2{});
+    };
+
+    s_period(TRUE_{}, FALSE_{}, Sa, Sb, 0);
+    int c = 1;
+    for (; c + 1 < NC; c += 2) {
+      s_period(TRUE_{}, TRUE_{}, Sb, Sa, c);
+      s_period(TRUE_{}, TRUE_{}, Sa, Sb, c + 1);
+    }
+    // NC is even (host-checked): c == NC - 1 here, its accumulators are Sb
+    s_period(TRUE_{}, TRUE_{}, Sb, Sa, c);
+    s_period(FALSE_{}, TRUE_{}, Sa, Sb, c + 1);
+    s_period(FALSE_{}, FALSE_{}, Sa, Sb, c + 2);
+    if (DIG_CHAIN_ABL & 1) asm volatile("" ::"v"(Sa[0]), "v"(Sa[1]), "v"(Sb[0]), "v"(Sb[1]));
+    DIG_CHAIN_T(3)
+    DIG_CHAIN_T_END()
+  } else {
+    // =========================================================== O-wave =====================================================
+    f32x16 D2[NJB];
+    {
+      // bias and residual through buffer descriptors: a null pointer reads as zeros (no branches), rows beyond R read as zeros
+      const auto rRes = __builtin_amdgcn_make_buffer_rsrc((void*)p.resid, 0, p.resid ? p.x_bytes : 0, 0x00020000);
+      const auto rBias = __builtin_amdgcn_make_buffer_rsrc((void*)p.bias2, 0, p.bias2 ? KD * 4 : 0, 0x00020000);
+      const unsigned ro = (unsigned)(((size_t)(m0 + pair * 32 + rr) * KD + 4 * hi) * 2);
+#pragma unroll
+      for (int jb = 0; jb < NJB; ++jb) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const auto bv = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rBias, (jb * 32 + g * 8 + 4 * hi) * 4, 0, 0));
+          const auto w = __builtin_amdgcn_raw_buffer_load_b64(rRes, ro + (jb * 32 + g * 8) * 2, 0, 0);
+          D2[jb][4 * g] = bv.x + bf2f((bf16_t)(w[0] & 0xffff));
+          D2[jb][4 * g + 1] = bv.y + bf2f((bf16_t)(w[0] >> 16));
+          D2[jb][4 * g + 2] = bv.z + bf2f((bf16_t)(w[1] & 0xffff));
+          D2[jb][4 * g + 3] = bv.w + bf2f((bf16_t)(w[1] >> 16));
+        }
+        __builtin_amdgcn_sched_barrier(0);                            // one column block at a time: 24 registers of loads in flight, not 288
+      }
+    }
+    int a2off[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) a2off[s] = rr * 128 + (((2 * s + hi) ^ psw) << 4);
+    const auto rS0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.side0, 0, p.side0 ? p.side_bytes : 0, 0x00020000);
+    constexpr int N_SIDE = MODE == 0 ? 0 : (MODE == 1 ? 8 : 4);        // side-output stores of an active period (issued in its tick 0)
+
+    auto o_period = [&](auto on_tag, int c) {
+      constexpr bool ON = decltype(on_tag)::value;
+      constexpr int EX = E_ALL + (ON ? N_SIDE : 0);
+      bf16x8 pf[4];
+      auto jtick = [&](auto tau_tag) {
+        constexpr int TAU = decltype(tau_tag)::value;
+        if (!ON) return;
+        const unsigned char* w = smem + W2_RING + TAU * SLOT;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          bf16x8 wf[JB_PER_TICK];
+#pragma unroll
+          for (int jb = 0; jb < JB_PER_TICK; ++jb) wf[jb] = *reinterpret_cast<const bf16x8*>(w + jb * 4096 + a2off[s]);
+#pragma unroll
+          for (int jb = 0; jb < JB_PER_TICK; ++jb)
+            if (!(DIG_CHAIN_ABL & 4)) D2[TAU * JB_PER_TICK + jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[jb], pf[s], D2[TAU * JB_PER_TICK + jb], 0, 0, 0);
+            else asm volatile("" ::"v"(wf[jb]));
+        }
+      };
+      // ---- tick 0: chunk c - 2 leaves the P tile (operand fragments into registers, side outputs to HBM)
+      tick_sync(T0{}, std::integral_constant<int, 4>{}, c);
+      if (ON) {
+        const unsigned char* pt = smem + P_OFF + pair * 4096;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) pf[s] = *reinterpret_cast<const bf16x8*>(pt + a2off[s]);
+        if (MODE != 0) {
+          const int r8 = lane >> 3, cp = lane & 7;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int row = 8 * q + r8;
+            const int ch = cp ^ ((row >> 1) & 7);
+            const unsigned go = (unsigned)(((size_t)(m0 + pair * 32 + row) * F + (c - 2) * FC + 8 * ch) * 2);   // rows beyond R: dropped
+            const dig_u32x4 a = *reinterpret_cast<const dig_u32x4*>(pt + row * 128 + cp * 16);
+            __builtin_amdgcn_raw_buffer_store_b128(a, rS0, go, 0, 0);
+            if (MODE == 1) {
+              const dig_u32x4 b = *reinterpret_cast<const dig_u32x4*>(pt + (X_OFF - P_OFF) + row * 128 + cp * 16);
+              __builtin_amdgcn_raw_buffer_store_b128(b, rSide1, go, 0, 0);
+            }
+          }
+        }
+      }
+      jtick(T0{});
+      tick_sync(T1{}, std::integral_constant<int, 4 + EX>{}, c);
+      jtick(T1{});
+      tick_sync(T2{}, std::integral_constant<int, 4 + EX>{}, c);
+      jtick(T2{});
+    };
+    o_period(FALSE_{}, 0);
+    o_period(FALSE_{}, 1);
+    for (int c = 2; c < NC + 2; ++c) o_period(TRUE_{}, c);
+    DIG_CHAIN_T(3)
+    DIG_CHAIN_T_END()
+
+    // ---- epilogue: bias and residual are already in the accumulators.  v_permlane32_swap trades column groups between lane l and
+    // l + 32 so that each lane owns 16 contiguous columns per 32-column block: 16-byte stores.
+    const int row = m0 + pair * 32 + rr;
+    if (row < p.R) {
+      bf16_t* orow = p.out + (size_t)row * KD + hi * 16;
+#pragma unroll
+      for (int jb = 0; jb < NJB; ++jb) {
+        unsigned Pk[4][2];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          Pk[g][0] = pack_bf2(D2[jb][g * 4], D2[jb][g * 4 + 1]);
+          Pk[g][1] = pack_bf2(D2[jb][g * 4 + 2], D2[jb][g * 4 + 3]);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const auto r0 = __builtin_amdgcn_permlane32_swap(Pk[0][k], Pk[2][k], false, false);
+          Pk[0][k] = r0[0]; Pk[2][k] = r0[1];
+          const auto r1 = __builtin_amdgcn_permlane32_swap(Pk[1][k], Pk[3][k], false, false);
+          Pk[1][k] = r1[0]; Pk[3][k] = r1[1];
+        }
+        *reinterpret_cast<uint4*>(orow + jb * 32) = make_uint4(Pk[0][0], Pk[0][1], Pk[2][0], Pk[2][1]);
+        *reinterpret_cast<uint4*>(orow + jb * 32 + 8) = make_uint4(Pk[1][0], Pk[1][1], Pk[3][0], Pk[3][1]);
+      }
+    }
+  }
+}
+
+template <int MODE>
+int launch_chain(const ChainParams& p, hipStream_t stream) {
+  const int lds = X_OFF + (MODE == 0 ? p.F * 4 : (MODE == 1 ? SLOT + p.F * 4 : 2 * SLOT));
+  if (lds > 160 * 1024) return DIG_ERR_UNSUPPORTED;
+  static int attr_lds = 0;
+  if (lds > attr_lds) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_chain_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return DIG_ERR_LAUNCH;
+    attr_lds = lds;
+  }
+  hipLaunchKernelGGL((mlp_chain_kernel<MODE>), dim3((p.R + BM - 1) / BM), dim3(512), lds, stream, p);
+  return dig_check_launch();
+}
+
+int check_common(const void* x, const void* b1, const void* b2, const void* out, int R, int D, int F) {
+  if (!x || !b1 || !b2 || !out || R <= 0) return DIG_ERR_ARG;
+  if (D != KD || F < 2 * FC || (F % (2 * FC))) return DIG_ERR_UNSUPPORTED;       // an even number of 64-wide chunks
+  if (!aligned16(x) || !aligned16(b1) || !aligned16(b2) || !aligned16(out)) return DIG_ERR_ALIGN;
+  if ((size_t)R * F * 2 >= (1ull << 32) || (size_t)F * D * 2 >= (1ull << 31)) return DIG_ERR_UNSUPPORTED;
+  return DIG_OK;
+}
+
+}  // namespace
+
+// C-ABI: see include/dig_hip.h
+extern "C" int dig_mlp_chain_supported(int D, int F) { return D == KD && F >= 2 * FC && F % (2 * FC) == 0 && F <= 6144; }
+
+extern "C" int dig_mlp_chain_fwd(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, const void* resid,
+                                 void* out, void* pre_out, void* act_out, int R, int D, int F, hipStream_t stream) {
+  const int rc = check_common(x, w1, w2, out, R, D, F);
+  if (rc != DIG_OK) return rc;
+  if ((b1 && !aligned16(b1)) || (b2 && !aligned16(b2)) || (resid && !aligned16(resid)) || (pre_out && !aligned16(pre_out)) ||
+      (act_out && !aligned16(act_out)))
+    return DIG_ERR_ALIGN;
+  if ((pre_out == nullptr) != (act_out == nullptr)) return DIG_ERR_ARG;             // both side outputs or none
+  ChainParams p;
+  p.X = (const bf16_t*)x; p.B1 = (const bf16_t*)w1; p.B2 = (const bf16_t*)w2; p.bias1 = b1; p.bias2 = b2;
+  p.resid = (const bf16_t*)resid; p.out = (bf16_t*)out; p.side0 = (bf16_t*)act_out; p.side1 = (bf16_t*)pre_out; p.colsum = nullptr;
+  p.R = R; p.F = F;
+  p.x_bytes = (unsigned)((size_t)R * D * 2); p.w_bytes = (unsigned)((size_t)F * D * 2); p.side_bytes = (unsigned)((size_t)R * F * 2);
+  return pre_out ? launch_chain<1>(p, stream) : launch_chain<0>(p, stream);
+}
+
+extern "C" int dig_mlp_chain_bwd(const void* dy, const void* w2t, const void* pre, const void* w1t, void* dpre_out, void* dx_out,
+                                 float* colsum_partials, int R, int D, int F, hipStream_t stream) {
+  const int rc = check_common(dy, w2t, w1t, dx_out, R, D, F);
+  if (rc != DIG_OK) return rc;
+  if (!pre || !dpre_out) return DIG_ERR_ARG;
+  if (!aligned16(pre) || !aligned16(dpre_out) || (colsum_partials && !aligned16(colsum_partials))) return DIG_ERR_ALIGN;
+  ChainParams p;
+  p.X = (const bf16_t*)dy; p.B1 = (const bf16_t*)w2t; p.B2 = (const bf16_t*)w1t; p.bias1 = nullptr; p.bias2 = nullptr;
+  p.resid = nullptr; p.out = (bf16_t*)dx_out; p.side0 = (bf16_t*)dpre_out; p.side1 = (bf16_t*)pre; p.colsum = colsum_partials;
+  p.R = R; p.F = F;
+  p.x_bytes = (unsigned)((size_t)R * D * 2); p.w_bytes = (unsigned)((size_t)F * D * 2); p.side_bytes = (unsigned)((size_t)R * F * 2);
+  return launch_chain<2>(p, stream);
+}
+
+// number of partial rows dig_mlp_chain_bwd writes into colsum_partials ([rows][F] fp32)
+extern "C" int dig_mlp_chain_colsum_rows(int R) { return ((R + BM - 1) / BM) * 4; }
+
+// dst[cols, rows] = src[rows, cols]^T (bf16): the K-contiguous copies of W2 / W1 the backward chain reads (1.2 MB each, once per step)
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int rows, int cols) {
+  __shared__ bf16_t tile[64][66];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    tile[r][c] = (r0 + r < rows && c0 + c < cols) ? src[(size_t)(r0 + r) * cols + c0 + c] : (bf16_t)0;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int c = i >> 6, r = i & 63;
+    if (c0 + c < cols && r0 + r < rows) dst[(size_t)(c0 + c) * rows + r0 + r] = tile[r][c];
+  }
+}
+extern "C" int dig_transpose_bf16(const void* src, void* dst, int rows, int cols, hipStream_t stream) {
+  if (!src || !dst || rows <= 0 || cols <= 0) return DIG_ERR_ARG;
+  hipLaunchKernelGGL(transpose_bf16_kernel, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, stream, (const bf16_t*)src,
+                     (bf16_t*)dst, rows, cols);
+  return dig_check_launch();
+}

@@ -77,6 +77,45 @@ def linear_fwd(x, w, *, bias=None, resid=None, act=0, pre=None, alpha=1.0, alpha
                 alpha_cols=alpha_cols, out=out, out_kind=out_kind, bk=bk, drop=drop)
 
 
+MLP_CHAIN = os.environ.get("DIG_MLP_CHAIN", "1") != "0"      # fused fc1 -> GELU -> fc2 (csrc/mlp_chain.hip) where the widths allow it
+
+
+def mlp_chain_supported(D, F):
+    return MLP_CHAIN and bool(L.lib().dig_mlp_chain_supported(int(D), int(F)))
+
+
+def mlp_chain_fwd(x, w1, b1, w2, b2, resid, save=False):
+    """out = resid + b2 + gelu(x w1^T + b1) w2^T in one launch (Mlp.forward + the block's residual add).  save=True also returns the
+    pre-activation and the GELU output ([rows, F] bf16) for the backward: (out, pre, act)."""
+    rows, D = x.shape
+    Fh = w1.shape[0]
+    out = torch.empty((rows, D), device=x.device, dtype=BF16)
+    pre = torch.empty((rows, Fh), device=x.device, dtype=BF16) if save else None
+    act = torch.empty((rows, Fh), device=x.device, dtype=BF16) if save else None
+    L.call("dig_mlp_chain_fwd", L.ptr(x), L.ptr(w1), L.ptr(b1), L.ptr(w2), L.ptr(b2), L.ptr(resid), L.ptr(out), L.ptr(pre), L.ptr(act),
+           rows, D, Fh, L.stream())
+    return (out, pre, act) if save else out
+
+
+def mlp_chain_bwd(dy, w2t, pre, w1t, colsum=True, out=None):
+    """dpre = (dy w2) * gelu'(pre), dx = dpre w1 in one launch (w2t = w2^T [F, D], w1t = w1^T [D, F]: transpose_bf16).
+    Returns (dx, dpre, parts): parts = [n, F] fp32 partial column sums of dpre (the fc1 bias gradient, for colsum_partials) or None."""
+    rows, D = dy.shape
+    Fh = w2t.shape[0]
+    dx = torch.empty((rows, D), device=dy.device, dtype=BF16) if out is None else out
+    dpre = torch.empty((rows, Fh), device=dy.device, dtype=BF16)
+    parts = torch.empty((L.lib().dig_mlp_chain_colsum_rows(rows), Fh), device=dy.device, dtype=F32) if colsum else None
+    L.call("dig_mlp_chain_bwd", L.ptr(dy), L.ptr(w2t), L.ptr(pre), L.ptr(w1t), L.ptr(dpre), L.ptr(dx), L.ptr(parts), rows, D, Fh, L.stream())
+    return dx, dpre, parts
+
+
+def transpose_bf16(src, out=None):
+    rows, cols = src.shape
+    out = torch.empty((cols, rows), device=src.device, dtype=BF16) if out is None else out
+    L.call("dig_transpose_bf16", L.ptr(src), L.ptr(out), rows, cols, L.stream())
+    return out
+
+
 def dropout_apply(x, drop, out=None):
     """out = dropout / drop-path (x) for a [rows, cols] bf16 tensor under `drop` (dropout.DropSpec); None -> x itself."""
     if drop is None:

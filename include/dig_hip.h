@@ -72,6 +72,30 @@ typedef struct dig_reduce_seg { const float* partials; float* out; long long n; 
 int dig_reduce_partials_multi(const dig_reduce_seg_t* segs, int n_segs, hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * Fused two-layer MLP ("chain"): Mlp.forward of a transformer block and its data gradient (modeling_finetune.py:53-60 inside
+ * Block.forward :150-158) in ONE launch each -- the [R, F] hidden tensor is never a GEMM operand in HBM.
+ *   dig_mlp_chain_fwd:  out[R,D] = resid + b2 + gelu_erf(x[R,D] w1[F,D]^T + b1) w2[D,F]^T      (bf16 I/O, fp32 accumulation,
+ *       the hidden values rounded to bf16 between the layers exactly as the two-GEMM path rounds them).
+ *       pre_out / act_out ([R,F] bf16, both or neither): the pre-activation x w1^T + b1 and its GELU, saved for the backward
+ *       (online branch); without them nothing of size [R,F] touches HBM (momentum branch, evaluation).
+ *   dig_mlp_chain_bwd:  dpre_out[R,F] = (dy[R,D] w2) * gelu'(pre[R,F]);  dx_out[R,D] = dpre_out w1.  The weights are passed as
+ *       K-contiguous copies w2t = w2^T [F,D] and w1t = w1^T [D,F] (dig_transpose_bf16, 1.2 MB each, once per step).
+ *       colsum_partials (optional): [dig_mlp_chain_colsum_rows(R)][F] fp32 column sums of dpre_out over blocks of 32 rows -- the
+ *       fc1 bias gradient after dig_colsum_partials.
+ *   Supported widths: dig_mlp_chain_supported(D, F) (D == 384, F a multiple of 128, F <= 6144); R is arbitrary (rows beyond R read as
+ *   zero and are not written).  All pointers 16-byte aligned, dense row-major tensors.  Anything else: DIG_ERR_UNSUPPORTED (the
+ *   caller runs the two dig_gemm_bf16 launches instead).
+ */
+int dig_mlp_chain_supported(int D, int F);
+int dig_mlp_chain_fwd(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, const void* resid, void* out,
+                      void* pre_out, void* act_out, int R, int D, int F, hipStream_t stream);
+int dig_mlp_chain_bwd(const void* dy, const void* w2t, const void* pre, const void* w1t, void* dpre_out, void* dx_out,
+                      float* colsum_partials, int R, int D, int F, hipStream_t stream);
+int dig_mlp_chain_colsum_rows(int R);
+/* dst[cols, rows] = src[rows, cols]^T, bf16 */
+int dig_transpose_bf16(const void* src, void* dst, int rows, int cols, hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * Fused self-attention, 256 tokens x head_dim 64 (Attention.forward, modeling_finetune.py:97-118, and its gradient).
  * qkv: bf16 [n_img*256, 3*embed_dim] laid out (q | k | v) x (head, 64) with q already scaled by head_dim^-0.5.
  * ctx: bf16 [n_img*256, embed_dim];  lse: fp32 [n_img*heads, 256] (log-sum-exp of every score row, saved for backward).

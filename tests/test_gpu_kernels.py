@@ -357,3 +357,49 @@ def test_grad_reduce_batch_equals_single_launches(dev):
             assert torch.equal(u, v), i
         else:                                       # LayerNorm vectors: 128 x 2 instead of 64 x 4 row groups in the tree (both fixed orders)
             assert rel(u, v) < 1e-6, i
+
+
+@pytest.mark.parametrize("R,Fh", [(128, 128), (256, 1536), (4096, 1536), (333, 256), (65536, 1536), (1000, 2048)])
+def test_mlp_chain_fwd_bwd(dev, R, Fh):
+    """dig_mlp_chain_fwd / _bwd (fc1 -> GELU -> fc2 and its data gradient in one launch each) against fp32 torch and against the
+    two-GEMM path they replace; ragged row counts, both forward forms (with and without the saved pre-activation / GELU output)."""
+    from dig_amd import ops
+    D = 384
+    cpu_limit(dev, 4.0 * R * D * Fh, limit=3e9)
+    assert ops.mlp_chain_supported(D, Fh) and not ops.mlp_chain_supported(512, 2048) and not ops.mlp_chain_supported(D, 192)
+    g = torch.Generator(device="cpu").manual_seed(R + Fh)
+    rn = lambda *s: torch.randn(*s, generator=g).to(dev)
+    x = rn(R, D).bfloat16()
+    w1 = (rn(Fh, D) * 0.06).bfloat16(); b1 = rn(Fh) * 0.5
+    w2 = (rn(D, Fh) * 0.04).bfloat16(); b2 = rn(D) * 0.5
+    res = rn(R, D).bfloat16()
+    pre_ref = x.float() @ w1.float().t() + b1
+    act_ref = F.gelu(pre_ref)
+    out_ref = act_ref.bfloat16().float() @ w2.float().t() + b2 + res.float()
+    out = ops.mlp_chain_fwd(x, w1, b1, w2, b2, res)
+    assert rel(out, out_ref) < 1e-2
+    out2, pre, act = ops.mlp_chain_fwd(x, w1, b1, w2, b2, res, save=True)
+    assert torch.equal(out, out2)                                     # the side outputs do not change the arithmetic
+    assert rel(pre, pre_ref) < 1e-2 and rel(act, act_ref) < 1e-2
+    assert rel(ops.mlp_chain_fwd(x, w1, None, w2, None, None), F.gelu(x.float() @ w1.float().t()).bfloat16().float() @ w2.float().t()) < 1e-2
+    # against the two launches it replaces: same operand rounding, same fp32 accumulation -> agreement far inside the bf16 yardstick
+    pre2 = torch.empty_like(pre)
+    act2 = ops.linear_fwd(x, w1, bias=b1, act=1, pre=pre2)
+    out3 = ops.linear_fwd(act2, w2, bias=b2, resid=res)
+    assert rel(pre, pre2) < 2e-3 and rel(act, act2) < 2e-3 and rel(out, out3) < 4e-3
+    # ---- backward: dpre = (dy w2) * gelu'(pre), dx = dpre w1, fc1 bias gradient = column sums of dpre
+    dy = rn(R, D).bfloat16()
+    w2t, w1t = ops.transpose_bf16(w2), ops.transpose_bf16(w1)
+    assert torch.equal(w2t, w2.t().contiguous()) and torch.equal(w1t, w1.t().contiguous())
+    dx, dpre, parts = ops.mlp_chain_bwd(dy, w2t, pre, w1t)
+    pp = pre.float().requires_grad_(True)
+    F.gelu(pp).backward(dy.float() @ w2.float())
+    assert rel(dpre, pp.grad) < 1e-2
+    assert rel(dx, dpre.float() @ w1.float()) < 1e-2 and rel(dx, pp.grad @ w1.float()) < 1.5e-2
+    db = torch.randn(Fh, generator=g).to(dev); db0 = db.clone()
+    ops.colsum_partials(parts, db)
+    assert rel(db - db0, dpre.float().sum(0)) < 1e-4 and rel(db - db0, pp.grad.sum(0)) < 3e-3
+    dact, bparts = ops.linear_dgrad(dy, w2, gelu_pre=pre, colsum=True)
+    assert rel(dpre, dact) < 2e-3 and rel(dx, ops.linear_dgrad(dact, w1)) < 4e-3
+    dx2, dpre2, parts2 = ops.mlp_chain_bwd(dy, w2t, pre, w1t)
+    assert torch.equal(dx, dx2) and torch.equal(dpre, dpre2) and torch.equal(parts, parts2)     # bit-reproducible
