@@ -261,8 +261,8 @@ __global__ void gelu_bwd_kernel(const bf16_t* __restrict__ dact, const bf16_t* _
     unsigned r[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-      r[k] = pack_bf2(bf2f((bf16_t)(xx[k] & 0xffff)) * dgelu_f(bf2f((bf16_t)(yy[k] & 0xffff))),
-                      bf2f((bf16_t)(xx[k] >> 16)) * dgelu_f(bf2f((bf16_t)(yy[k] >> 16))));
+      r[k] = pack_bf2(bf2f((bf16_t)(xx[k] & 0xffff)) * dgelu_acc_f(bf2f((bf16_t)(yy[k] & 0xffff))),
+                      bf2f((bf16_t)(xx[k] >> 16)) * dgelu_acc_f(bf2f((bf16_t)(yy[k] >> 16))));
     reinterpret_cast<uint4*>(dpre)[i] = make_uint4(r[0], r[1], r[2], r[3]);
   }
 }

@@ -44,6 +44,9 @@
 #ifndef DIG_CHAIN_ABL
 #define DIG_CHAIN_ABL 0
 #endif
+#ifndef DIG_CHAIN_PRIO
+#define DIG_CHAIN_PRIO 0                  // 1: S-waves at s_setprio 1, 2: O-waves (static, for the whole kernel)
+#endif
 
 namespace {
 
@@ -106,11 +109,6 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainParams p) {
   const auto rX = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, p.x_bytes, 0x00020000);
   const auto rSide1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.side1, 0, p.side1 ? p.side_bytes : 0, 0x00020000);
 
-  if (MODE != 2) {                                                   // b1 -> LDS, before any LDS-DMA is in flight
-    float* b1s = reinterpret_cast<float*>(smem + B1S_OFF);
-    for (int i = tid; i < F; i += 512) b1s[i] = p.bias1 ? p.bias1[i] : 0.f;
-    __syncthreads();
-  }
 
   // ---- weight rings: per-thread source offsets (the swizzle lives on the source side: LDS-DMA destinations are lane-linear)
   unsigned v1[2], v2[2], vp[2];
@@ -132,7 +130,10 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainParams p) {
     for (int it = 0; it < 2; ++it) __builtin_amdgcn_raw_ptr_buffer_load_lds(rB2, LDS_PTR(d2 + it * 8192), 16, v2[it], s2, 0, 0);
   };
   // Barrier of tick (c, TAU): this wave's DMA pieces of the tick have landed (NW = VMEM operations it has issued behind them), its
-  // own LDS traffic is complete; then the DMA for the tick after next goes out (ring slot = position of that tick in its chunk).
+  // own LDS traffic is complete.  The DMA for the tick after next (ring slot = position of that tick in its chunk) is then issued
+  // piece by piece BETWEEN the tick's MFMA groups (dma_piece: an LDS-DMA costs its wave 40-70 issue cycles, tools/experiments/
+  // chain_lab.hip), behind the tick's other VMEM operations (side-output stores, the backward's pre-activation tile).
+  unsigned dma_s1 = 0, dma_s2 = 0;
   auto tick_sync = [&](auto tau_tag, auto nw_tag, int c) {
     constexpr int TAU = decltype(tau_tag)::value;
     DIG_CHAIN_T(3)
@@ -146,7 +147,8 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainParams p) {
     const int cn = TAU == 0 ? c : c + 1;
     const int d1 = cn < NC ? cn : 0;                                  // past the end: re-read a valid piece into the free slot
     const int d2 = (cn >= 2 && cn < NC + 2) ? cn - 2 : 0;
-    if (!(DIG_CHAIN_ABL & 2)) issue_ring(tn, (unsigned)((d1 * FC * KD + tn * 128) * 2), (unsigned)((tn * 128 * F + d2 * FC) * 2));
+    dma_s1 = (unsigned)((d1 * FC * KD + tn * 128) * 2);
+    dma_s2 = (unsigned)((tn * 128 * F + d2 * FC) * 2);
     if (MODE == 2 && TAU == 0) {                                      // pre-activation tile of chunk c (used in period c + 1)
       const int dc = c < NC ? c : NC - 1;
       unsigned char* dp = smem + X_OFF + (c & 1) * SLOT + wave * 1024;
@@ -155,6 +157,13 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainParams p) {
     }
     DIG_CHAIN_T(2)
   };
+  auto dma_piece = [&](auto tau_tag, auto k_tag) {                    // piece k (0..3) of the DMA issued during tick TAU
+    constexpr int TAU = decltype(tau_tag)::value, K = decltype(k_tag)::value;
+    constexpr int tn = (TAU + 2) % 3;
+    if (DIG_CHAIN_ABL & 2) return;
+    if (K < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rB1, LDS_PTR(smem + W1_RING + tn * SLOT + wave * 1024 + K * 8192), 16, v1[K], dma_s1, 0, 0);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rB2, LDS_PTR(smem + W2_RING + tn * SLOT + wave * 1024 + (K - 2) * 8192), 16, v2[K - 2], dma_s2, 0, 0);
+  };
   constexpr int E_ALL = MODE == 2 ? 2 : 0;                            // VMEM operations every wave issues behind the ring DMA of a tick 0
   using T0 = std::integral_constant<int, 0>;
   using T1 = std::integral_constant<int, 1>;
@@ -162,10 +171,29 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainParams p) {
   using TRUE_ = std::true_type;
   using FALSE_ = std::false_type;
 
-  issue_ring(0, 0u, 0u);                                              // ticks (0,0) and (0,1)
+  // Start-up order: the ring DMA of ticks (0,0) and (0,1) first, then the bias vectors b1 [F] and b2 [KD] -> LDS (stores in inline asm: a
+  // visible LDS store would drain the DMA just issued; the barrier of tick (0,0) publishes them), then the S-waves' X rows.
+  issue_ring(0, 0u, 0u);
   issue_ring(1, (unsigned)(128 * 2), (unsigned)((128 * F) * 2));
+  if (MODE != 2) {
+    const auto rb1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.bias1, 0, p.bias1 ? F * 4 : 0, 0x00020000);     // null: zeros
+    const auto rb2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.bias2, 0, p.bias2 ? KD * 4 : 0, 0x00020000);
+    const unsigned base = lds_addr(smem + B1S_OFF);
+    for (int i0 = 0; i0 < F; i0 += 2048) {
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb1, (unsigned)((i0 + u * 512 + tid) * 4), 0, 0));
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (i0 + u * 512 + tid < F) asm volatile("ds_write_b32 %0, %1" ::"v"(base + (unsigned)((i0 + u * 512 + tid) * 4)), "v"(v[u]) : "memory");
+    }
+    const float v2 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb2, (unsigned)(tid * 4), 0, 0));
+    if (tid < KD) asm volatile("ds_write_b32 %0, %1" ::"v"(base + (unsigned)((F + tid) * 4)), "v"(v2) : "memory");
+  }
 
   const int psw = (rr >> 1) & 7;
+  if (DIG_CHAIN_PRIO == 1 && role == 0) __builtin_amdgcn_s_setprio(1);
+  if (DIG_CHAIN_PRIO == 2 && role == 1) __builtin_amdgcn_s_setprio(1);
   if (role == 0) {
     // =========================================================== S-wave =====================================================
     bf16x8 xf[KD / 16];
@@ -196,7 +224,7 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainParams p) {
     auto s_period = [&](auto m1_tag, auto g_tag, f32x16 (&Sc)[2], f32x16 (&Sp)[2], int c) {
       constexpr bool M1 = decltype(m1_tag)::value, G = decltype(g_tag)::value;
       uint2 pk[8];                                                    // packed results of chunk c - 1: quad q = (block q >> 2, g = q & 3)
-      uint2 pkpre[3];
+      uint2 pkpre[3], pkpre_t;                                        // MODE 1: pre-activation quads held over tick 0 / of the quad in progress
       bf16x4 prq[3];                                                  // MODE 2: pre-activation quads of the current tick
       float ga[4];
       auto quad_addr = [&](int q) { return pw_base + (unsigned)((q ^ psw) << 4); };          // 16-byte chunk 4 b + g = q of the token's row
@@ -217,49 +245,42 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainParams p) {
         sm += __shfl_xor(sm, 32, 64);
         if (hi == 0) p.colsum[(size_t)(blockIdx.x * 4 + pair) * F + (c - 1) * FC + b * 32 + rr] = sm;
       };
-      // gap i (0..15) of tick TAU: element e = i & 3 of quad q = 3 TAU + (i >> 2); ticks 0 / 1 carry 12 elements, tick 2 carries 8
-      auto gap = [&](auto tau_tag, auto i_tag) {
-        constexpr int TAU = decltype(tau_tag)::value, I = decltype(i_tag)::value;
-        if (G && !(DIG_CHAIN_ABL & 1)) {
-          constexpr int NEL = TAU < 2 ? 12 : 8;
-          if (TAU == 1 && I < 3) {                                    // the three quads tick 0 computed (the P tile was not free yet)
-            lds_write8(quad_addr(I), pk[I]);
-            if (MODE == 1) lds_write8(quad_addr(I) + (unsigned)(X_OFF - P_OFF), pkpre[I]);
+      // Elementwise work of a chunk: 32 hidden elements per lane = 16 PAIRS (two independent dependency chains: a lone polynomial
+      // chain issues at ~6.6 cycles per op, two interleaved ones at ~4), 6 / 5 / 5 per tick, placed behind the first MFMA of a
+      // k-step.  Global pair P = elements (2 (P & 1), 2 (P & 1) + 1) of quad P >> 1.  The P tile is free from tick 1 on (the O-wave
+      // takes chunk c - 2 out of it during tick 0): quads finished in tick 0 (0, 1 and half of 2) are held in registers.
+      auto pairwork = [&](auto tau_tag, auto j_tag) {
+        constexpr int TAU = decltype(tau_tag)::value, J = decltype(j_tag)::value;
+        constexpr int NP = TAU == 0 ? 6 : 5, P0 = TAU == 0 ? 0 : (TAU == 1 ? 6 : 11);
+        if (!(G && !(DIG_CHAIN_ABL & 1)) || J >= NP) return;
+        constexpr int PG = P0 + J, q = PG >> 1, e0 = 2 * (PG & 1), b = q >> 2, g = q & 3;
+        float v0 = Sp[b][4 * g + e0], v1 = Sp[b][4 * g + e0 + 1];
+        if (MODE == 2) {
+          dgelu2(bf2f((bf16_t)prq[q - (TAU == 0 ? 0 : (TAU == 1 ? 3 : 5))][e0]), bf2f((bf16_t)prq[q - (TAU == 0 ? 0 : (TAU == 1 ? 3 : 5))][e0 + 1]), v0, v1);
+        } else {
+          if (MODE == 1) {
+            const unsigned w = pack_bf2(v0, v1);
+            if (q < 3) { if (e0 == 0) pkpre[q].x = w; else pkpre[q].y = w; }
+            else { if (e0 == 0) pkpre_t.x = w; else pkpre_t.y = w; }
           }
-          if (I < NEL) {
-            constexpr int q = 3 * TAU + (I >> 2), e = I & 3, b = q >> 2, g = q & 3;
-            float v = Sp[b][4 * g + e];
-            if (MODE == 2) {
-              v *= dgelu_f(bf2f((bf16_t)prq[I >> 2][e]));
-              ga[e] = v;
-            } else {
-              if (MODE == 1) {
-                if (e == 1) { const unsigned w = pack_bf2(Sp[b][4 * g], Sp[b][4 * g + 1]); if (TAU == 0) pkpre[q].x = w; else pkpre[0].x = w; }
-                if (e == 3) { const unsigned w = pack_bf2(Sp[b][4 * g + 2], Sp[b][4 * g + 3]); if (TAU == 0) pkpre[q].y = w; else pkpre[0].y = w; }
-              }
-              ga[e] = gelu_f(v);
-            }
-            if (e == 1) pk[q].x = pack_bf2(ga[0], ga[1]);
-            if (e == 3) {
-              pk[q].y = pack_bf2(ga[2], ga[3]);
-              if (TAU > 0) {
-                lds_write8(quad_addr(q), pk[q]);
-                if (MODE == 1) lds_write8(quad_addr(q) + (unsigned)(X_OFF - P_OFF), pkpre[0]);
-              }
-            }
-          }
-          if (MODE == 2 && TAU == 1 && I == 12) colsum_block(0);
-          if (MODE == 2 && TAU == 2 && I == 8) colsum_block(1);
+          gelu_fast2(v0, v1);
         }
-        __builtin_amdgcn_sched_barrier(0);
+        if (e0 == 0) pk[q].x = pack_bf2(v0, v1);
+        else {
+          pk[q].y = pack_bf2(v0, v1);
+          if (q >= 3) {                                                 // quads 0..2 are written by the hold path of tick 1
+            lds_write8(quad_addr(q), pk[q]);
+            if (MODE == 1) lds_write8(quad_addr(q) + (unsigned)(X_OFF - P_OFF), pkpre_t);
+          }
+        }
       };
       auto tick = [&](auto tau_tag) {
         constexpr int TAU = decltype(tau_tag)::value;
-        if (G && MODE == 2) {                                         // pre-activation quads of this tick (DMA'd two periods ago)
-          constexpr int NQ = TAU < 2 ? 3 : 2;
+        if (G && MODE == 2) {                                         // pre-activation quads of this tick's pairs (DMA'd two periods ago)
+          constexpr int Q0 = TAU == 0 ? 0 : (TAU == 1 ? 3 : 5);
 #pragma unroll
-          for (int k = 0; k < NQ; ++k)
-            prq[k] = *reinterpret_cast<const bf16x4*>(smem + X_OFF + ((c - 1) & 1) * SLOT + pair * 4096 + rr * 128 + hi * 8 + (((3 * TAU + k) ^ psw) << 4));
+          for (int k = 0; k < 3; ++k)
+            prq[k] = *reinterpret_cast<const bf16x4*>(smem + X_OFF + ((c - 1) & 1) * SLOT + pair * 4096 + rr * 128 + hi * 8 + (((Q0 + k) ^ psw) << 4));
         }
         const unsigned char* w = smem + W1_RING + TAU * SLOT;
         bf16x8 wa[2], wb[2];
@@ -272,9 +293,17 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainParams p) {
             nxt[1] = *reinterpret_cast<const bf16x8*>(w + 8192 + a1off[S + 1]);
           }
           if (M1 && !(DIG_CHAIN_ABL & 8)) Sc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[0], xf[TAU * KS_PER_TICK + S], Sc[0], 0, 0, 0);
-          gap(tau_tag, std::integral_constant<int, 2 * S>{});
+          pairwork(tau_tag, s_tag);
+          __builtin_amdgcn_sched_barrier(0);
           if (M1 && !(DIG_CHAIN_ABL & 8)) Sc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[1], xf[TAU * KS_PER_TICK + S], Sc[1], 0, 0, 0);
-          gap(tau_tag, std::integral_constant<int, 2 * S + 1>{});
+          if (G && !(DIG_CHAIN_ABL & 1) && TAU == 1 && S < 3) {        // the three quads tick 0 computed (the P tile was not free yet)
+            lds_write8(quad_addr(S), pk[S]);
+            if (MODE == 1) lds_write8(quad_addr(S) + (unsigned)(X_OFF - P_OFF), pkpre[S]);
+          }
+          if (S & 1) dma_piece(tau_tag, std::integral_constant<int, (S >> 1)>{});
+          if (G && !(DIG_CHAIN_ABL & 1) && MODE == 2 && TAU == 1 && S == 6) colsum_block(0);
+          if (G && !(DIG_CHAIN_ABL & 1) && MODE == 2 && TAU == 2 && S == 4) colsum_block(1);
+          __builtin_amdgcn_sched_barrier(0);
         };
         kstep(std::integral_constant<int, 0>{}, wa, wb); kstep(std::integral_constant<int, 1>{}, wb, wa);
         kstep(std::integral_constant<int, 2>{}, wa, wb); kstep(std::integral_constant<int, 3>{}, wb, wa);
@@ -305,7 +334,7 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainParams p) {
       tick_sync(T1{}, std::integral_constant<int, 4 + E_ALL>{}, c);
       tick(T1{});
       // ---- tick 2
-      tick_sync(T2{}, std::integral_constant<int, 4 + E_ALL>{}, c);
+      tick_sync(T2{}, std::integral_constant<int, 4>{}, c);
       tick(T2{});
     };
 
@@ -324,50 +353,94 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainParams p) {
     DIG_CHAIN_T_END()
   } else {
     // =========================================================== O-wave =====================================================
+    // Output accumulators start as bias + residual (the epilogue is then a convert-and-store).  The O-wave has nothing to multiply
+    // during the first two chunk periods (the S-wave is two chunks ahead), so the residual rows are fetched and unpacked THERE, half
+    // of the column blocks per tick (48 registers of loads in flight), instead of in front of the pipeline.
     f32x16 D2[NJB];
-    {
-      // bias and residual through buffer descriptors: a null pointer reads as zeros (no branches), rows beyond R read as zeros
-      const auto rRes = __builtin_amdgcn_make_buffer_rsrc((void*)p.resid, 0, p.resid ? p.x_bytes : 0, 0x00020000);
-      const auto rBias = __builtin_amdgcn_make_buffer_rsrc((void*)p.bias2, 0, p.bias2 ? KD * 4 : 0, 0x00020000);
-      const unsigned ro = (unsigned)(((size_t)(m0 + pair * 32 + rr) * KD + 4 * hi) * 2);
+    const auto rRes = __builtin_amdgcn_make_buffer_rsrc((void*)p.resid, 0, p.resid ? p.x_bytes : 0, 0x00020000);   // null: zeros; rows beyond R: zeros
+    const unsigned ro = (unsigned)(((size_t)(m0 + pair * 32 + rr) * KD + 4 * hi) * 2);
+    dig_u32x4 rq[4];                                                   // residual quads of one group (2 column blocks) in flight
+    // group k (0..5) = column blocks 2k, 2k + 1: requested in idle tick k, unpacked in tick k + 1 (one tick of latency cover)
+    auto init_load = [&](auto k_tag) {
+      constexpr int K = decltype(k_tag)::value;
 #pragma unroll
-      for (int jb = 0; jb < NJB; ++jb) {
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {
+          constexpr int jb0 = 2 * K;
+          const auto w0 = __builtin_amdgcn_raw_buffer_load_b64(rRes, ro + ((jb0 + j) * 32 + (2 * gp) * 8) * 2, 0, 0);
+          const auto w1 = __builtin_amdgcn_raw_buffer_load_b64(rRes, ro + ((jb0 + j) * 32 + (2 * gp + 1) * 8) * 2, 0, 0);
+          rq[2 * j + gp] = dig_u32x4{w0[0], w0[1], w1[0], w1[1]};
+        }
+    };
+    auto init_finish = [&](auto k_tag) {
+      constexpr int K = decltype(k_tag)::value;
+      const float* b2s = reinterpret_cast<const float*>(smem + B1S_OFF) + F + 4 * hi;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const auto bv = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rBias, (jb * 32 + g * 8 + 4 * hi) * 4, 0, 0));
-          const auto w = __builtin_amdgcn_raw_buffer_load_b64(rRes, ro + (jb * 32 + g * 8) * 2, 0, 0);
-          D2[jb][4 * g] = bv.x + bf2f((bf16_t)(w[0] & 0xffff));
-          D2[jb][4 * g + 1] = bv.y + bf2f((bf16_t)(w[0] >> 16));
-          D2[jb][4 * g + 2] = bv.z + bf2f((bf16_t)(w[1] & 0xffff));
-          D2[jb][4 * g + 3] = bv.w + bf2f((bf16_t)(w[1] >> 16));
+          constexpr int jb0 = 2 * K;
+          f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+          if (MODE != 2) bv = *reinterpret_cast<const f32x4*>(b2s + (jb0 + j) * 32 + g * 8);
+          const unsigned wx = rq[2 * j + (g >> 1)][2 * (g & 1)], wy = rq[2 * j + (g >> 1)][2 * (g & 1) + 1];
+          D2[jb0 + j][4 * g] = bv[0] + bf2f((bf16_t)(wx & 0xffff));
+          D2[jb0 + j][4 * g + 1] = bv[1] + bf2f((bf16_t)(wx >> 16));
+          D2[jb0 + j][4 * g + 2] = bv[2] + bf2f((bf16_t)(wy & 0xffff));
+          D2[jb0 + j][4 * g + 3] = bv[3] + bf2f((bf16_t)(wy >> 16));
         }
-        __builtin_amdgcn_sched_barrier(0);                            // one column block at a time: 24 registers of loads in flight, not 288
-      }
-    }
+    };
+    // idle tick KT (0..5): unpack the group requested a tick ago, request the next one; the last tick also waits for its own group
+    auto init_step = [&](auto kt_tag) {
+      constexpr int KT = decltype(kt_tag)::value;
+      if (KT >= 1 && KT <= 5) init_finish(std::integral_constant<int, (KT >= 1 && KT <= 5) ? KT - 1 : 0>{});
+      if (KT >= 0 && KT <= 5) init_load(std::integral_constant<int, (KT >= 0 && KT <= 5) ? KT : 0>{});
+      if (KT == 5) init_finish(std::integral_constant<int, 5>{});
+      __builtin_amdgcn_sched_barrier(0);
+    };
     int a2off[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) a2off[s] = rr * 128 + (((2 * s + hi) ^ psw) << 4);
     const auto rS0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.side0, 0, p.side0 ? p.side_bytes : 0, 0x00020000);
     constexpr int N_SIDE = MODE == 0 ? 0 : (MODE == 1 ? 8 : 4);        // side-output stores of an active period (issued in its tick 0)
 
-    auto o_period = [&](auto on_tag, int c) {
+    auto o_period = [&](auto on_tag, auto init_tag, int c) {
       constexpr bool ON = decltype(on_tag)::value;
+      constexpr int KT0 = decltype(init_tag)::value;                  // first init tick of this period (0, 3) or -9: none
       constexpr int EX = E_ALL + (ON ? N_SIDE : 0);
       bf16x8 pf[4];
       auto jtick = [&](auto tau_tag) {
         constexpr int TAU = decltype(tau_tag)::value;
-        if (!ON) return;
         const unsigned char* w = smem + W2_RING + TAU * SLOT;
+        bf16x8 wfa[JB_PER_TICK], wfb[JB_PER_TICK];
+        if (ON) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          bf16x8 wf[JB_PER_TICK];
-#pragma unroll
-          for (int jb = 0; jb < JB_PER_TICK; ++jb) wf[jb] = *reinterpret_cast<const bf16x8*>(w + jb * 4096 + a2off[s]);
-#pragma unroll
-          for (int jb = 0; jb < JB_PER_TICK; ++jb)
-            if (!(DIG_CHAIN_ABL & 4)) D2[TAU * JB_PER_TICK + jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[jb], pf[s], D2[TAU * JB_PER_TICK + jb], 0, 0, 0);
-            else asm volatile("" ::"v"(wf[jb]));
+          for (int jb = 0; jb < JB_PER_TICK; ++jb) wfa[jb] = *reinterpret_cast<const bf16x8*>(w + jb * 4096 + a2off[0]);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        // B2 fragments of k-step S + 1 are requested while the MFMAs of k-step S issue, in two halves so that the second half
+        // can take over the registers the first two MFMAs have just released (24 fragment registers live instead of 32)
+        auto kstep = [&](auto s_tag, bf16x8 (&cur)[JB_PER_TICK], bf16x8 (&nxt)[JB_PER_TICK]) {
+          constexpr int S = decltype(s_tag)::value;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            if (ON && S < 3) {
+              nxt[2 * h] = *reinterpret_cast<const bf16x8*>(w + (2 * h) * 4096 + a2off[S + 1]);
+              nxt[2 * h + 1] = *reinterpret_cast<const bf16x8*>(w + (2 * h + 1) * 4096 + a2off[S + 1]);
+            }
+            if (ON) {
+#pragma unroll
+              for (int jb = 2 * h; jb < 2 * h + 2; ++jb)
+                if (!(DIG_CHAIN_ABL & 4)) D2[TAU * JB_PER_TICK + jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[jb], pf[S], D2[TAU * JB_PER_TICK + jb], 0, 0, 0);
+                else asm volatile("" ::"v"(cur[jb]));
+            }
+            if (h == 0) __builtin_amdgcn_sched_barrier(0);
+          }
+          dma_piece(tau_tag, s_tag);
+          __builtin_amdgcn_sched_barrier(0);
+        };
+        kstep(std::integral_constant<int, 0>{}, wfa, wfb); kstep(std::integral_constant<int, 1>{}, wfb, wfa);
+        kstep(std::integral_constant<int, 2>{}, wfa, wfb); kstep(std::integral_constant<int, 3>{}, wfb, wfa);
       };
       // ---- tick 0: chunk c - 2 leaves the P tile (operand fragments into registers, side outputs to HBM)
       tick_sync(T0{}, std::integral_constant<int, 4>{}, c);
@@ -391,23 +464,29 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainParams p) {
           }
         }
       }
+      init_step(std::integral_constant<int, KT0>{});
+      __builtin_amdgcn_sched_barrier(0);                              // the side-output stores stay in front of the tick's ring DMA
       jtick(T0{});
       tick_sync(T1{}, std::integral_constant<int, 4 + EX>{}, c);
+      init_step(std::integral_constant<int, KT0 + 1>{});
       jtick(T1{});
-      tick_sync(T2{}, std::integral_constant<int, 4 + EX>{}, c);
+      tick_sync(T2{}, std::integral_constant<int, 4>{}, c);
+      init_step(std::integral_constant<int, KT0 + 2>{});
       jtick(T2{});
     };
-    o_period(FALSE_{}, 0);
-    o_period(FALSE_{}, 1);
-    for (int c = 2; c < NC + 2; ++c) o_period(TRUE_{}, c);
+    o_period(FALSE_{}, std::integral_constant<int, 0>{}, 0);
+    o_period(FALSE_{}, std::integral_constant<int, 3>{}, 1);
+    for (int c = 2; c < NC + 2; ++c) o_period(TRUE_{}, std::integral_constant<int, -9>{}, c);
     DIG_CHAIN_T(3)
     DIG_CHAIN_T_END()
 
     // ---- epilogue: bias and residual are already in the accumulators.  v_permlane32_swap trades column groups between lane l and
     // l + 32 so that each lane owns 16 contiguous columns per 32-column block: 16-byte stores.
-    const int row = m0 + pair * 32 + rr;
+    int tid2 = threadIdx.x;
+    asm volatile("" : "+v"(tid2));                                    // re-derive the lane's row here: kept live across the loop it would be spilled
+    const int row = m0 + pair * 32 + (tid2 & 31), hi2 = (tid2 >> 5) & 1;
     if (row < p.R) {
-      bf16_t* orow = p.out + (size_t)row * KD + hi * 16;
+      bf16_t* orow = p.out + (size_t)row * KD + hi2 * 16;
 #pragma unroll
       for (int jb = 0; jb < NJB; ++jb) {
         unsigned Pk[4][2];
@@ -432,15 +511,20 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainParams p) {
 
 template <int MODE>
 int launch_chain(const ChainParams& p, hipStream_t stream) {
-  const int lds = X_OFF + (MODE == 0 ? p.F * 4 : (MODE == 1 ? SLOT + p.F * 4 : 2 * SLOT));
+  const int lds = X_OFF + (MODE == 0 ? (p.F + KD) * 4 : (MODE == 1 ? SLOT + (p.F + KD) * 4 : 2 * SLOT));
+#ifdef DIG_CHAIN_LDS_ALL
+  const int lds_launch = 160 * 1024;                                   // (lab build: stamps live in the spare LDS)
+#else
+  const int lds_launch = lds;
+#endif
   if (lds > 160 * 1024) return DIG_ERR_UNSUPPORTED;
   static int attr_lds = 0;
-  if (lds > attr_lds) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_chain_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+  if (lds_launch > attr_lds) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_chain_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_launch) != hipSuccess)
       return DIG_ERR_LAUNCH;
-    attr_lds = lds;
+    attr_lds = lds_launch;
   }
-  hipLaunchKernelGGL((mlp_chain_kernel<MODE>), dim3((p.R + BM - 1) / BM), dim3(512), lds, stream, p);
+  hipLaunchKernelGGL((mlp_chain_kernel<MODE>), dim3((p.R + BM - 1) / BM), dim3(512), lds_launch, stream, p);
   return dig_check_launch();
 }
 

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
 #pragma unroll
       for (int k = 0; k < EPL; ++k) {
         v[u][k] = (v[u][k] - mu[u]) * rs[u];                     // xhat
-        if (GELU) d[u][k] *= dgelu_f(v[u][k] * g[k] + bt[k]);
+        if (GELU) d[u][k] *= dgelu_acc_f(v[u][k] * g[k] + bt[k]);
         dg[k] += d[u][k] * v[u][k];
         db[k] += d[u][k];
         d[u][k] *= g[k];

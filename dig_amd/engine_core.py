@@ -90,19 +90,35 @@ class _Step:
                        ops.L.ptr(x[half * B * N:(half + 1) * B * N]), B, M.gh, M.gw, D, ops.L.stream())
         saved = []
         scale = (D // H) ** -0.5
+        chain = ops.mlp_chain_supported(D, M.F) and bool(ops.MLP_CHAIN_MASK & (2 if save else 1))
         for blk in ew.blocks:
             ln1, mu1, rs1 = ops.layernorm_fwd(x, blk["norm1.weight"], blk["norm1.bias"], M.ln_eps)
             qkv = ops.linear_fwd(ln1, blk["attn.qkv.weight"], bias=blk["qkv_bias"], alpha=scale, alpha_cols=D)
             ctx, lse = ops.attn_fwd(qkv, 2 * B, H, D)
             x_mid = ops.linear_fwd(ctx, blk["attn.proj.weight"], bias=blk["attn.proj.bias"], resid=x)
             ln2, mu2, rs2 = ops.layernorm_fwd(x_mid, blk["norm2.weight"], blk["norm2.bias"], M.ln_eps)
-            pre = torch.empty((R, M.F), device=x.device, dtype=BF16) if save else None
-            act = ops.linear_fwd(ln2, blk["mlp.fc1.weight"], bias=blk["mlp.fc1.bias"], act=1, pre=pre)
-            x_out = ops.linear_fwd(act, blk["mlp.fc2.weight"], bias=blk["mlp.fc2.bias"], resid=x_mid)
+            if chain:
+                # fc1 -> GELU -> fc2 (+ residual) in one launch: the [R, F] hidden tensor is never a GEMM operand in HBM; the online
+                # branch still writes the pre-activation and the GELU output (the backward's inputs), the momentum branch nothing
+                if save:
+                    x_out, pre, act = ops.mlp_chain_fwd(ln2, blk["mlp.fc1.weight"], blk["mlp.fc1.bias"], blk["mlp.fc2.weight"],
+                                                        blk["mlp.fc2.bias"], x_mid, save=True)
+                else:
+                    pre = act = None
+                    x_out = ops.mlp_chain_fwd(ln2, blk["mlp.fc1.weight"], blk["mlp.fc1.bias"], blk["mlp.fc2.weight"], blk["mlp.fc2.bias"], x_mid)
+            else:
+                pre = torch.empty((R, M.F), device=x.device, dtype=BF16) if save else None
+                act = ops.linear_fwd(ln2, blk["mlp.fc1.weight"], bias=blk["mlp.fc1.bias"], act=1, pre=pre)
+                x_out = ops.linear_fwd(act, blk["mlp.fc2.weight"], bias=blk["mlp.fc2.bias"], resid=x_mid)
             if save:
                 saved.append((x, ln1, mu1, rs1, qkv, ctx, lse, x_mid, ln2, mu2, rs2, pre, act))
             x = x_out
         return x, saved
+
+    def mlp_weight_transposes(self, ew):
+        """K-contiguous copies of the MLP weights for the fused backward (W2^T [F, D], W1^T [D, F]; 1.2 MB each, 24 small launches):
+        they depend on nothing but this step's bf16 weight shadow, so forward() queues them on the side stream behind the momentum branch."""
+        return [(ops.transpose_bf16(b["mlp.fc2.weight"]), ops.transpose_bf16(b["mlp.fc1.weight"])) for b in ew.blocks]
 
     # ------------------------------------------------------------------ two-stream helpers (backward)
     def _streams(self, dev):
@@ -149,6 +165,14 @@ class _Step:
         def on_side(fn, *tensors):
             self._on_side(dev, fn, *tensors)
 
+        chain = ops.mlp_chain_supported(D, M.F) and bool(ops.MLP_CHAIN_MASK & 4)
+        wT = getattr(self, "wT", None)
+        if chain and wT is None:
+            wT = self.mlp_weight_transposes(ew)
+        elif chain:
+            for pair_ in wT:                                            # made on the side stream in forward(), read here on the main one
+                for t in pair_:
+                    t.record_stream(main)
         for i in reversed(range(M.depth)):
             blk, g = ew.blocks[i], ew.blocks[i]["g"]
             x, ln1, mu1, rs1, qkv, ctx, lse, x_mid, ln2, mu2, rs2, pre, act = saved[i]
@@ -164,10 +188,17 @@ class _Step:
             wg = red.wgrad if red else ops.linear_wgrad
             csum = red.colsum_partials if red else ops.colsum_partials
             on_side(lambda: wg(dx, act, g["mlp.fc2.weight"]), dx, act)
-            dact, bparts = ops.linear_dgrad(dx, blk["mlp.fc2.weight"], gelu_pre=pre, colsum=True)   # d(pre-activation): GELU' and
-            on_side(lambda: (wg(dact, ln2, g["mlp.fc1.weight"]),                                     # the fc1 bias sums fused
-                             csum(bparts, g["mlp.fc1.bias"])), dact, ln2, bparts)                    # (0.3 ms/step vs a 201 MB pass)
-            dln2 = ops.linear_dgrad(dact, blk["mlp.fc1.weight"])
+            if chain:
+                # data gradient through fc2, GELU' and fc1 in one launch (d(pre-activation) leaves it as a side output for the fc1
+                # weight gradient, with its column sums = the fc1 bias gradient)
+                w2t, w1t = wT[i]
+                dln2, dact, bparts = ops.mlp_chain_bwd(dx, w2t, pre, w1t)
+                on_side(lambda: (wg(dact, ln2, g["mlp.fc1.weight"]), csum(bparts, g["mlp.fc1.bias"])), dact, ln2, bparts)
+            else:
+                dact, bparts = ops.linear_dgrad(dx, blk["mlp.fc2.weight"], gelu_pre=pre, colsum=True)   # d(pre-activation): GELU' and
+                on_side(lambda: (wg(dact, ln2, g["mlp.fc1.weight"]),                                     # the fc1 bias sums fused
+                                 csum(bparts, g["mlp.fc1.bias"])), dact, ln2, bparts)                    # (0.3 ms/step vs a 201 MB pass)
+                dln2 = ops.linear_dgrad(dact, blk["mlp.fc1.weight"])
             dx_mid, fin2, ws2 = ops.layernorm_bwd(dln2, x_mid, blk["norm2.weight"], blk["norm2.bias"], mu2, rs2, dx, g["norm2.weight"],
                                                   g["norm2.bias"], out=dln2, dres_colsum=g["mlp.fc2.bias"], defer=True)
             if red:                                                           # norm2 grads + colsum(dx) = fc2 bias grad: off the chain
@@ -322,6 +353,9 @@ class _Step:
                 ops.window_pool_fwd(enc_m[B * N:], pooled_m[B * nw:], B, M.gh, M.gw, nw, D)
                 ks, _ = self.mlp_forward(pooled_m, "momentum_projection_layer", "momentum", False)
                 del enc_m, masked_m, pooled_m
+            self.wT = None
+            if torch.is_grad_enabled() and ops.mlp_chain_supported(D, M.F) and (ops.MLP_CHAIN_MASK & 4):
+                self.wT = self.mlp_weight_transposes(ew_on)             # (both modes join the side stream before the backward can start)
         # ---- online branch
         enc, self.saved_enc = self.encoder_forward(ew_on, images, aug, mask_u8, True)
         self.enc = enc
@@ -462,7 +496,7 @@ class _Step:
         main, side = self._streams(dev)
         if side is not main:
             main.wait_stream(side)                  # every gradient is final on the caller's stream (grad norm / AdamW follow)
-        self.saved_enc = self.saved_pix = self.saved_proj = self.saved_pred = self.saved_dec = None
+        self.saved_enc = self.saved_pix = self.saved_proj = self.saved_pred = self.saved_dec = self.wT = None
 
 
 class _DigFn(torch.autograd.Function):

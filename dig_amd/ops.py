@@ -78,6 +78,11 @@ def linear_fwd(x, w, *, bias=None, resid=None, act=0, pre=None, alpha=1.0, alpha
 
 
 MLP_CHAIN = os.environ.get("DIG_MLP_CHAIN", "1") != "0"      # fused fc1 -> GELU -> fc2 (csrc/mlp_chain.hip) where the widths allow it
+# Where the fused kernels are used: bit 0 momentum forward, bit 1 online forward, bit 2 backward.  A chain workgroup owns its CU (8 waves x
+# 256 VGPRs, up to 144 KiB of LDS), so nothing of the other HIP stream runs beside it: in the forward that is a net win (24.89 -> 24.03
+# ms per step with both branches fused), in the backward the weight-gradient stream loses more than the fused data gradient gains
+# (25.73 ms with bit 2 alone, 24.87 with all three; one box, 40 timed steps each) -- default 3.
+MLP_CHAIN_MASK = int(os.environ.get("DIG_MLP_CHAIN_MASK", "3"))
 
 
 def mlp_chain_supported(D, F):

@@ -7,11 +7,18 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
-__device__ long long* g_ts;
-#define NTS 8
-#define DIG_CHAIN_T_BEGIN() long long ct_last = (long long)__builtin_amdgcn_s_memtime(), ct_acc[4] = {0, 0, 0, 0}; const long long ct_t0 = ct_last;
-#define DIG_CHAIN_T(k) { const long long ct_now = (long long)__builtin_amdgcn_s_memtime(); ct_acc[k] += ct_now - ct_last; ct_last = ct_now; }
-#define DIG_CHAIN_T_END() if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024) { long long* q = g_ts + ((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * NTS; for (int k = 0; k < 4; ++k) q[k] = ct_acc[k]; q[4] = ct_last - ct_t0; q[5] = ct_t0; }
+// Stamps go to a spare LDS region (12 KiB at the top of the 160 KiB; the product kernel uses at most 144 KiB) with one ds_write_b32 each
+// -- accumulators or global stores would cost registers (the kernel sits at 245-256 VGPRs; an earlier version of this lab spilled 768
+// bytes per lane and measured its own scratch traffic) -- and workgroup TL_BLOCK copies them out at its end.
+__device__ unsigned* g_tl;                   // [8 waves][80 ticks][4 stamps]: 3 = arrive (end of the previous tick's work), 0 = DMA landed, 1 = barrier released, 2 = tick set up
+#define TL_BLOCK 300
+#define TL_OFF (160 * 1024 - 12 * 1024)
+#define DIG_CHAIN_LDS_ALL 1
+#define DIG_CHAIN_T_BEGIN() int ct_n = 0;
+#define DIG_CHAIN_T(k) { if (ct_n < 80) { const unsigned ct_now = (unsigned)__builtin_amdgcn_s_memtime(); const unsigned ct_a = TL_OFF + (((threadIdx.x >> 6) * 80 + ct_n) * 4 + (k)) * 4; \
+  asm volatile("ds_write_b32 %0, %1" ::"v"(ct_a), "v"(ct_now) : "memory"); } if ((k) == 2) ++ct_n; }
+#define DIG_CHAIN_T_END() if (blockIdx.x == TL_BLOCK) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const int ct_w = threadIdx.x >> 6, ct_l = threadIdx.x & 63; \
+  for (int i = ct_l; i < 320; i += 64) g_tl[ct_w * 320 + i] = *reinterpret_cast<const unsigned*>(smem + TL_OFF + (ct_w * 320 + i) * 4); }
 #include "../../dig_amd/csrc/mlp_chain.hip"
 
 static void fill_bf16(unsigned short* d, size_t n, unsigned seed, float scale) {
@@ -33,8 +40,8 @@ int main(int argc, char** argv) {
   fill_bf16(x, (size_t)R * D, 1, 1.f); fill_bf16(res, (size_t)R * D, 2, 1.f);
   fill_bf16(w1, (size_t)F * D, 3, 0.1f); fill_bf16(w2, (size_t)F * D, 4, 0.07f);
   fill_bf16(pre, (size_t)R * F, 5, 2.f);
-  long long* ts; hipMalloc(&ts, (size_t)1024 * 8 * NTS * 8);
-  hipMemcpyToSymbol(HIP_SYMBOL(g_ts), &ts, sizeof(ts));
+  unsigned* tl; hipMalloc(&tl, 8 * 320 * 4); hipMemset(tl, 0, 8 * 320 * 4);
+  hipMemcpyToSymbol(HIP_SYMBOL(g_tl), &tl, sizeof(tl));
   for (int mode = 0; mode < 3; ++mode) {
     auto fn = [&]() {
       if (mode == 0) dig_mlp_chain_fwd(x, w1, b1, w2, b2, res, out, nullptr, nullptr, R, D, F, 0);
@@ -43,28 +50,40 @@ int main(int argc, char** argv) {
     };
     for (int it = 0; it < 200; ++it) fn();
     hipDeviceSynchronize();
-    hipMemset(ts, 0, (size_t)1024 * 8 * NTS * 8);
+    hipMemset(tl, 0, 8 * 320 * 4);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0, 0);
     const int n = 30;
     for (int it = 0; it < n; ++it) fn();
     hipEventRecord(e1, 0); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    std::vector<long long> t((size_t)1024 * 8 * NTS);
-    hipMemcpy(t.data(), ts, t.size() * 8, hipMemcpyDeviceToHost);
     const double us = ms / n * 1e3;
     printf("ABL %d mode %d: %7.1f us  %6.0f TFLOP/s\n", DIG_CHAIN_ABL, mode, us, 4.0 * R * D * F / us / 1e6);
+    std::vector<unsigned> L(8 * 320);
+    hipMemcpy(L.data(), tl, L.size() * 4, hipMemcpyDeviceToHost);
+    // aggregates of workgroup TL_BLOCK (last launch): per role, mean over its 4 waves of the 78 protocol ticks
+    unsigned t0 = L[3];
+    for (int w = 0; w < 8; ++w) if ((int)(L[w * 320 + 3] - t0) < 0) t0 = L[w * 320 + 3];
     for (int role = 0; role < 2; ++role) {
-      double acc[5] = {0}; long cnt = 0;
-      for (int b = 0; b < 512; ++b)
-        for (int w = role * 4; w < role * 4 + 4; ++w) {
-          const long long* q = &t[((size_t)b * 8 + w) * NTS];
-          if (!q[4]) continue;
-          for (int k = 0; k < 5; ++k) acc[k] += (double)q[k];
-          ++cnt;
+      double dw = 0, bw = 0, su = 0, wk = 0, life = 0;
+      for (int w = role * 4; w < role * 4 + 4; ++w) {
+        for (int k = 0; k < 78; ++k) {
+          const unsigned* q = &L[(w * 80 + k) * 4];
+          dw += (int)(q[0] - q[3]); bw += (int)(q[1] - q[0]); su += (int)(q[2] - q[1]);
+          wk += (int)(L[(w * 80 + k + 1) * 4 + 3] - q[2]);
         }
-      if (cnt) printf("   %s-wave: wave life %8.0f ticks = dma wait %7.0f + barrier %7.0f + dma issue %6.0f + work %7.0f   (78 protocol ticks: %5.0f per tick)\n",
-                      role ? "O" : "S", acc[4] / cnt, acc[0] / cnt, acc[1] / cnt, acc[2] / cnt, acc[3] / cnt, acc[4] / cnt / 78.0);
+        life += (int)(L[(w * 80 + 78) * 4 + 3] - L[w * 320 + 3]);
+      }
+      printf("   %s-wave (workgroup %d): 78 ticks = %7.0f cycles = dma wait %6.0f + barrier %6.0f + set-up %5.0f + work %7.0f   (%5.0f per tick)\n",
+             role ? "O" : "S", TL_BLOCK, life / 4, dw / 4, bw / 4, su / 4, wk / 4, life / 4 / 78.0);
+    }
+    if (getenv("CHAIN_TL")) {
+      printf("   timeline (per wave and tick: arrival, +dma wait, +barrier wait), cycles since the workgroup's first stamp\n");
+      for (int k = 0; k < 79; ++k) {
+        printf("   t%02d", k);
+        for (int w = 0; w < 8; ++w) { const unsigned* q = &L[(w * 80 + k) * 4]; printf(" | %c%d %6d %5d %5d", w < 4 ? 'S' : 'O', w & 3, (int)(q[3] - t0), (int)(q[0] - q[3]), (int)(q[1] - q[0])); }
+        printf("\n");
+      }
     }
   }
   return 0;
