@@ -32,6 +32,8 @@ WORKLOAD_TEXT = {
 }
 PEAK_BF16 = 2.5e15
 PEAK_HBM = 8.0e12                                                      # /opt/skills/guides/MI355X_MICROARCH.md
+PMC_FILE = "r03_pmc_traffic.json"                                      # rocprofv3 --pmc passes of this command (tools/collect_profiles.sh), stamped
+#                                                                        with the hash of the kernel SOURCES they were measured on
 
 
 class FreshMaskLoader:
@@ -69,7 +71,7 @@ def synth_batches(n, B, device, seed):
 
 
 class GemmProbe:
-    """Times every dig_gemm_bf16 launch of one step with HIP events on the launch stream (torch's current stream)."""
+    """Times every dig_gemm_bf16 and dig_mlp_chain_fwd launch of one step with HIP events on the launch stream (torch's current stream)."""
 
     def __init__(self):
         from dig_amd import ops
@@ -98,10 +100,26 @@ class GemmProbe:
             self.rec.append((variant, 2.0 * I * J * R, byt, e0, e1))
             return out
         ops.gemm = timed
+        orig_chain = self._orig_chain = ops.mlp_chain_fwd
+
+        def timed_chain(x, w1, b1, w2, b2, resid, save=False):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = orig_chain(x, w1, b1, w2, b2, resid, save=save)
+            e1.record()
+            R, D = x.shape
+            Fh = w1.shape[0]
+            # algorithmic HBM bytes of the fused fc1 -> GELU -> fc2 launch: x, residual and output rows once, both weight matrices once;
+            # the online form also writes what the reference's autograd keeps for the backward (pre-activation and GELU output)
+            byt = 2.0 * R * D * 3 + 2.0 * 2 * D * Fh + (2.0 * 2 * R * Fh if save else 0.0)
+            self.rec.append(("mlp_chain", 4.0 * R * D * Fh, byt, e0, e1))
+            return out
+        ops.mlp_chain_fwd = timed_chain
         return self
 
     def __exit__(self, *a):
         self.ops.gemm = self._orig
+        self.ops.mlp_chain_fwd = self._orig_chain
 
     def summary(self):
         torch.cuda.synchronize()
@@ -116,35 +134,43 @@ class GemmProbe:
 
 
 def cpu_baseline(model_name, budget_s=20.0):
-    """The fp32 CPU oracle (oracle/dig_oracle.py, pinned to the reference by tests/golden) on this host's cores."""
+    """The fp32 CPU oracle (oracle/dig_oracle.py, pinned to the reference by tests/golden) on this host's cores, at the two batch sizes
+    SURVEY.md 8(d) names: B = 4 (BASELINE configs[0], the reference's own CPU-runnable case) and B = 128 (the per-GPU batch of the
+    metric; one timed step -- about 15 s -- so that the default run stays within minutes)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import dig_oracle as O
     cfg = O.make_config(model_name)
-    Bc = 8
-    tr = O.OracleTrainer(cfg, seed=0)
-    im, au, mk = O.synthetic_batch(Bc, cfg, 1234)
-    hp = O.StepHyper(lr=1.5e-4 * Bc / 256)
     # thread count: the best of 8 / 16 / 32 / 64 / 128 on the MI355X host (2 x EPYC 9575F, 256 hardware threads) is 16 --
     # 6.5 / 8.5 / 7.4 / 3.2 / 1.6 samples/s (tools/cpu_baseline_threads.py): torch's default of 128 threads spends its time in fork/join
     torch.set_num_threads(max(1, min(16, os.cpu_count() or 8)))
-    tr.step(im, au, mk, hp)                                     # warm-up
-    n, t0 = 0, time.perf_counter()
-    while True:
-        tr.step(im, au, mk, hp)
-        n += 1
-        dt = time.perf_counter() - t0
-        if dt > budget_s or n >= 8:
-            break
+    tr = O.OracleTrainer(cfg, seed=0)
+
+    def timed(Bc, max_steps, budget):
+        im, au, mk = O.synthetic_batch(Bc, cfg, 1234)
+        hp = O.StepHyper(lr=1.5e-4 * Bc / 256)
+        n, t0 = 0, time.perf_counter()
+        while True:
+            tr.step(im, au, mk, hp)
+            n += 1
+            dt = time.perf_counter() - t0
+            if dt > budget or n >= max_steps:
+                return n * Bc / dt, n, dt
+    timed(4, 1, 0.0)                                                     # warm-up (thread pool, allocator)
+    v4, n4, t4 = timed(4, 6, budget_s * 0.25)
+    v128, n128, t128 = timed(128, 1, 0.0) if budget_s >= 10 else (None, 0, 0.0)
     cpu_model = "unknown"
     try:
         with open("/proc/cpuinfo") as f:
             cpu_model = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "unknown")
     except OSError:
         pass
-    return {"value": n * Bc / dt, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+    return {"value": v128 if v128 is not None else v4, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
             "host_cpu": cpu_model, "host_logical_cpus": os.cpu_count(),
-            "threads_note": "16 torch threads: the best of 8/16/32/64/128 on this host class (tools/cpu_baseline_threads.py; more threads are slower)",
-            "sample": f"{n} oracle steps (fp32 torch CPU restatement of the reference step) at batch {Bc}, same model/recipe"}
+            "batch_128": {"value": v128, "steps": n128, "seconds": t128}, "batch_4": {"value": v4, "steps": n4, "seconds": t4},
+            "threads_note": "16 torch threads: the best of 8/16/32/64/128 on this host class (tools/cpu_baseline_threads.py: 6.5 / 8.5 / 7.4 / "
+                            "3.2 / 1.6 samples/s; all 256 logical CPUs are slower, torch's fork/join dominates)",
+            "sample": f"fp32 torch CPU restatement of the reference step (oracle/dig_oracle.py), same model/recipe: {n128} step at batch 128 "
+                      f"(`value`), {n4} steps at batch 4 (BASELINE configs[0]), 1 warm-up step"}
 
 
 def main():
@@ -287,26 +313,29 @@ def main():
         # that hash still matches the library this run loaded
         traffic, traffic_src, step_bytes = None, None, None
         try:
-            import hashlib
-            from dig_amd import _lib
-            with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
+            from dig_amd import build as dig_build
+            src_hash = dig_build.source_hash()
+            with open(os.path.join(ROOT, "profiles", PMC_FILE)) as f:
                 tj = json.load(f)
-            with open(_lib.LIB_PATH, "rb") as f:
-                lib_hash = hashlib.sha256(f.read()).hexdigest()[:16]
-            if tj.get("lib_sha256_16") == lib_hash:
+            if tj.get("src_sha256_16") == src_hash:
                 traffic = tj["kernels"][dom]["hbm_bytes_per_launch"]
                 if tj.get("steps_in_run"):                      # all kernel families of the step: measured HBM bytes per step
                     step_bytes = sum(v["launches"] * v["hbm_bytes_per_launch"] for v in tj["kernels"].values()) / tj["steps_in_run"]
-                traffic_src = f"profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE, library {lib_hash})"
+                traffic_src = f"profiles/{PMC_FILE} (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE, kernel sources {src_hash})"
             else:
-                traffic_src = f"profiles/r02_pmc_traffic.json was collected on library {tj.get('lib_sha256_16')}, this run loaded {lib_hash}: not reported"
-        except Exception:
-            pass
+                traffic_src = f"profiles/{PMC_FILE} was collected on kernel sources {tj.get('src_sha256_16')}, this tree has {src_hash}: not reported"
+        except Exception as e:  # noqa: BLE001
+            traffic_src = f"profiles/{PMC_FILE}: {type(e).__name__}"
         # the bounding roofline of this path is bf16 MFMA; the HBM view of the same launches is kept beside it
         mfma_view = {"achieved": tf, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": tf / (PEAK_BF16 / 1e12)}
         hbm_view = {"achieved": gbs, "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": gbs / (PEAK_HBM / 1e9)}
-        roof = {"bound": "mfma", **mfma_view, "traffic": traffic,
-                "kernel": f"dig_gemm_bf16[{dom}] (gemm_kernel / gemm_wide_kernel / gemm_pwide_kernel, v_mfma_f32_32x32x16_bf16, fused bias/GELU/residual epilogues)",
+        # which roof bounds the dominant family: the larger of its MFMA time at 2.5 PFLOP/s and its HBM time at 8 TB/s on algorithmic work
+        bound = "mfma" if d["flops"] / PEAK_BF16 >= d["bytes"] / PEAK_HBM else "hbm"
+        kname = ("dig_mlp_chain_fwd (mlp_chain_kernel: fc1 -> GELU -> fc2 + residual in one launch, S-wave / O-wave role split, v_mfma_f32_32x32x16_bf16)"
+                 if dom == "mlp_chain" else
+                 f"dig_gemm_bf16[{dom}] (gemm_kernel / gemm_wide_kernel / gemm_pwide_kernel, v_mfma_f32_32x32x16_bf16, fused bias/GELU/residual epilogues)")
+        roof = {"bound": bound, **(mfma_view if bound == "mfma" else hbm_view), "traffic": traffic,
+                "kernel": kname,
                 "traffic_source": traffic_src,
                 "mfma": mfma_view, "hbm": hbm_view, "step_hbm_bytes": step_bytes,
                 "flops_per_launch": d["flops"] / d["launches"], "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
@@ -337,8 +366,8 @@ def main():
                                    f"T 0.2, 4 windows, mask 0.7, 2 views, AdamW wd 0.1, {B} samples/GPU, random-init weights",
                        "global_batch": B * world, "parallelism": f"dp{world}", "loss": float(stats.get("loss", float('nan')))},
             "step_mfma_frac": (value / world * fl / PEAK_BF16) if fl else None,
-            # the whole step against the HBM roof: PMC-measured bytes of every kernel family per step (profiles/r02_pmc_traffic.json,
-            # same library hash) / step time / 8 TB/s -- the roof that actually prices this model width
+            # the whole step against the HBM roof: PMC-measured bytes of every kernel family per step (profiles/r03_pmc_traffic.json,
+            # same kernel sources) / step time / 8 TB/s -- the roof that actually prices this model width
             "step_hbm_frac": (roof["step_hbm_bytes"] / (dt / a.steps) / PEAK_HBM) if roof and roof.get("step_hbm_bytes") and B == 128 and a.model == "small" and a.workload == "mim_moco" else None,
             "host_ms_per_step": host_ms, "step_graph": graphed,
             "roofline": roof, ("mim_only" if a.workload == "mim_moco" else "mim_moco"): mim_only}

@@ -19,6 +19,21 @@ def sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
+def source_hash() -> str:
+    """sha256 (16 hex digits) over the kernel sources (csrc/*.hip, csrc/*.h, include/dig_hip.h, this file's flags): what a measurement
+    file can be stamped with and re-checked against -- the bytes of the built .so differ from build to build of identical sources."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
+    files.append(os.path.join(os.path.dirname(HERE), "include", "dig_hip.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    h.update(repr((FLAGS, sorted(EXTRA_FLAGS.items()))).encode())
+    return h.hexdigest()[:16]
+
+
 def _stale(out, deps):
     if not os.path.exists(out):
         return True

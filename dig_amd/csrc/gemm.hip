@@ -872,7 +872,13 @@ int launch_pwide(GemmParams p, hipStream_t stream) {
   p.tiles_i = (p.I + Cfg::TBI - 1) / Cfg::TBI;
   p.tiles_j = (p.J + Cfg::TBJ - 1) / Cfg::TBJ;
   const int n_items = p.tiles_i * p.tiles_j;
-  const int grid = std::min(n_items, 256);                               // one 16- / 12-wave workgroup per CU
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+  }
+  const int grid = std::min(n_items, n_cu);                              // one 16- / 12-wave workgroup per CU
   hipLaunchKernelGGL((gemm_pwide_kernel<WN, RES, PRE>), dim3(grid), dim3(Cfg::NT), LDS, stream, p, n_items);
   return dig_check_launch();
 }
@@ -993,12 +999,16 @@ extern "C" int dig_gemm_bf16_dropout(const void* A, const void* B, void* C, int 
   }
   if ((bk == 544 || bk == 564) && !trans_a && !trans_b && out_kind == 0 && act != 2 && !colsum_partials) {   // persistent forward tiles
     const bool pre_ = pre_act != nullptr && act == 1;
-    if (pre_ && resid) return DIG_ERR_UNSUPPORTED;
-    if ((size_t)I * ldc * 2 >= (1ull << 31) || (resid && ldr != ldc) || (pre_ && ldp != ldc)) return DIG_ERR_UNSUPPORTED;
-    p.c_bytes = (unsigned)((size_t)I * ldc * 2);
-    if (bk == 544 && resid) return DIG_ERR_UNSUPPORTED;               // (16 waves + a resident residual tile: over the 128-VGPR budget)
-    if (bk == 544) return (pre_ ? launch_pwide<4, false, true>(p, stream) : launch_pwide<4, false, false>(p, stream));
-    return resid ? launch_pwide<3, true, false>(p, stream) : (pre_ ? launch_pwide<3, false, true>(p, stream) : launch_pwide<3, false, false>(p, stream));
+    // Outside the persistent kernel's limits (32-bit byte offsets of C, one leading dimension for C / residual / pre-activation, no
+    // residual on the 16-wave tile or together with a saved pre-activation) the call runs on the one-tile-per-workgroup kernel of the
+    // same shape below -- same results, no row-count cliff for a very large per-GPU batch.
+    const bool fits = (size_t)I * ldc * 2 < (1ull << 31) && !(resid && ldr != ldc) && !(pre_ && ldp != ldc) && !(pre_ && resid) &&
+                      !(bk == 544 && resid);
+    if (fits) {
+      p.c_bytes = (unsigned)((size_t)I * ldc * 2);
+      if (bk == 544) return (pre_ ? launch_pwide<4, false, true>(p, stream) : launch_pwide<4, false, false>(p, stream));
+      return resid ? launch_pwide<3, true, false>(p, stream) : (pre_ ? launch_pwide<3, false, true>(p, stream) : launch_pwide<3, false, false>(p, stream));
+    }
   }
   if (bk == 544 || bk == 564) bk -= 300;                               // other operand forms: the one-tile-per-workgroup kernel of that shape
 #define DIG_GEMM_WCASE(ta, tb, o)                                                                                   \

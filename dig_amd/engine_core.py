@@ -422,7 +422,9 @@ class _Step:
         M._last_mask_counts, M._last_idx, M._last_images = cnt, idx[:B], images
         # view 1's MIM target is cut from the ORIGINAL images with view 1's mask (engine_for_pretraining_moco.py:106-108 indexes
         # `images_patch`, built from `images`, for every view), so its target indices are relative to `images`
-        M._last_idx_views = [idx[:B]] + ([idx[B:] - B * N] if mim_views == 2 else [])
+        # (mask_to_index zero-fills the slots of a sample with fewer masked tokens than `per`; relative to `images` those would be -B*N:
+        #  clamp, so that the target gather of a ragged mask -- reported one step late -- stays inside the image buffer)
+        M._last_idx_views = [idx[:B]] + ([(idx[B:] - B * N).clamp_min_(0)] if mim_views == 2 else [])
         self.idx, self.Mrows, self.Mp, self.per, self.mim_views = idx, Mrows, Mp, per, mim_views
         w16, f32 = M._w("online"), M._f32
         gath = ops.gather_rows(enc, idx, Mrows, Mp)

@@ -224,7 +224,9 @@ class RecModelTrain(RecModel):
         """Copy the arena back into the inference path's tensors (used by `.eval()` forward / checkpoints) -- once per weight
         version: `evaluate()` calls the eval forward for every batch, and a sync per call meant a full weight copy, a repack and a
         HIP-graph capture per batch."""
-        ver = getattr(self, "_weights_version", 0)
+        # writers that go through the parameter views (an in-place op on model.parameters()) do not call weights_changed(): torch's own
+        # version counter of the arena catches those
+        ver = (getattr(self, "_weights_version", 0), self.flat_params._version)
         if not force and getattr(self, "_synced_version", None) == ver:
             return
         for k in self._offsets:
@@ -293,6 +295,7 @@ class FlatGradComm:
         self.dist, self.group = dist, process_group
         self.world, self.rank = dist.get_world_size(process_group), dist.get_rank(process_group)
         dist.broadcast(model.flat_params, src=0, group=process_group)
+        model.weights_changed()              # the arena was just overwritten: an eval forward must re-sync (and re-capture its HIP graph)
         # every rank draws its own dropout masks (the reference seeds each rank with args.seed + rank, run_class_finetuning.py:262-264)
         model.drop_seed = (int(model.drop_seed) + 0x9E3779B97F4A7C15 * self.rank) & ((1 << 64) - 1)
 

@@ -22,13 +22,21 @@ class DistComm:
         self.world = dist.get_world_size(process_group)
         self.rank = dist.get_rank(process_group)
         self._pending = []
+        self.log = None                      # a list: every collective issued is recorded as (op, numel) -- the order on the communicator
+        #                                       must be the same on every rank or the first multi-GPU step dead-locks (tests/golden/collective_order_tiny.json)
+
+    def _note(self, op, t):
+        if self.log is not None:
+            self.log.append((op, int(t.numel())))
 
     def all_reduce_(self, t):
+        self._note("all_reduce", t)
         dist.all_reduce(t, group=self.group)
         return t
 
     def all_gather_cat(self, t):
         out = torch.empty((self.world,) + tuple(t.shape[1:]), device=t.device, dtype=t.dtype)
+        self._note("all_gather", t)
         if dist.get_backend(self.group) == "gloo":           # (test backend: no all_gather_into_tensor for device tensors)
             dist.all_gather(list(out.unsqueeze(1).unbind(0)), t.contiguous(), group=self.group)
         else:
@@ -39,6 +47,7 @@ class DistComm:
         """Called by the backward as soon as every gradient in bucket `key` is final."""
         lo, hi = model.bucket_range(key)
         g = model.flat_grads[lo:hi]
+        self._note("all_reduce_async:" + key, g)
         self._pending.append((dist.all_reduce(g, group=self.group, async_op=True), g))
 
     def finish_grad_sync(self, model):

@@ -54,8 +54,8 @@ typedef struct ihipStream_t* hipStream_t;
 /* Persistent forms of the two tall tiles: one workgroup per CU walks a contiguous range of tiles and keeps the next tile's first
  * operand stage in flight during the epilogue; same arithmetic order, bit-identical results.  Forward only (trans_a = trans_b = 0),
  * out_kind 0, act 0 / 1, no colsum_partials; ldr == ldc, ldp == ldc, I * ldc < 2^30, no residual together with pre_act, and no
- * residual at all for the 256x256 form -- a forward call outside those limits returns DIG_ERR_UNSUPPORTED.  Transposed operands
- * or fp32 / partial outputs with these codes run the one-tile-per-workgroup kernel of the same shape (244 / 264). */
+ * residual at all for the 256x256 form.  A call outside those limits -- as well as transposed operands or fp32 / partial outputs with
+ * these codes -- runs the one-tile-per-workgroup kernel of the same shape (244 / 264): same results, no error. */
 #define DIG_GEMM_TILE_256x256_PERSISTENT 544
 #define DIG_GEMM_TILE_256x192_PERSISTENT 564
 int dig_gemm_bf16(const void* A, const void* B, void* C, int I, int J, int R, int lda, int ldb, int ldc, int trans_a,

@@ -140,7 +140,7 @@ def run_reference_steps(cfg, seed, B, n_steps, hp, world=1, rank=0, sync_bn=Fals
     for s in range(n_steps):
         im, au, mk = O.synthetic_batch(B, cfg, seed * 1000 + 17 * s + rank)
         loader = [([im, au, mk], torch.ones(1), torch.ones(1))]
-        stats = E.train_one_epoch(run_model, None, None, loader, None, opt, torch.device('cpu'), s, scaler, None,
+        stats = E.train_one_epoch(run_model, None, None, loader, None, opt, torch.device('cpu'), s, scaler, hp.clip_grad,
                                   patch_size=cfg.patch, normlize_target=False, start_steps=s,
                                   lr_schedule_values=lr_sched, wd_schedule_values=wd_sched, args=args)
         grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
@@ -251,6 +251,11 @@ def pack(ref_steps, cfg, seed, B, hp, extra=None):
         d[f"s{s}/cap/vis_out/full"] = r["caps"]["vis_out"].numpy().astype(np.float32)
         if "vis_out1" in r["caps"]:
             d[f"s{s}/cap/vis_out1/full"] = r["caps"]["vis_out1"].numpy().astype(np.float32)
+        if hp.clip_grad is not None:                # --clip_grad (utils/utils.py:487-493): the clip coefficient lives in the Adam moments
+            mn = sorted(r["moments"].keys())
+            d[f"s{s}/moment_names"] = np.array(mn)
+            d[f"s{s}/exp_avg_norms"] = np.array([r["moments"][n][0].double().norm().item() for n in mn])
+            d[f"s{s}/exp_avg_sq_norms"] = np.array([r["moments"][n][1].double().norm().item() for n in mn])
     if extra:
         d.update(extra)
     return d
@@ -377,5 +382,7 @@ if __name__ == "__main__":
             gen_single("vit_base_b2_w1", base, 11, 2, 1, O.StepHyper(lr=1.5e-4 * 2 / 256))
         if a.only in ("", "c0"):                    # BASELINE configs[1]'s loss: loss_weight_contrast = 0 (MIM-only gradients)
             gen_single("tiny_w1_c0", tiny, 5, 4, 1, O.StepHyper(lr=1e-3, w_contrast=0.0))
+        if a.only in ("", "clip"):                  # --clip_grad 1.0 (grad norm ~5: the clip is active), two steps: the second step's moments mix
+            gen_single("tiny_w1_clip", tiny, 13, 4, 2, O.StepHyper(lr=1e-3, clip_grad=1.0))      # both steps' clip coefficients
         if a.only in ("", "mim2"):                  # only_mim_on_ori_img=False: both views masked, MIM loss on both (engine :100-111,138-141)
             gen_single("tiny_w1_mim2", tiny, 9, 4, 1, O.StepHyper(lr=1e-3, only_mim_on_ori_img=False))

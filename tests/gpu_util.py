@@ -38,7 +38,7 @@ def run_engine_steps(model, batches, hp, start=0, opt=None):
     n = len(batches)
     for s, (im, au, mk) in enumerate(batches):
         st = train_one_epoch(model, None, None, [([im, au, mk], torch.ones(1), torch.ones(1))], None, opt, torch.device("cuda:0"),
-                             start + s, NativeScalerWithGradNormCount(), None, patch_size=4, normlize_target=False,
+                             start + s, NativeScalerWithGradNormCount(), getattr(hp, "clip_grad", None), patch_size=4, normlize_target=False,
                              start_steps=start + s, lr_schedule_values=np.full(start + n + 2, hp.lr),
                              wd_schedule_values=np.full(start + n + 2, hp.weight_decay), args=args)
         out.append(st)

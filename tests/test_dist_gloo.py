@@ -127,8 +127,11 @@ def _run(target, world, *args):
     assert not bad, "\n".join(f"rank {r}:\n{v}" for r, v in bad.items())
 
 
-def test_multirank_oracle_matches_reference_fixtures(golden_dir):
-    _run(_oracle_worker, 2, golden_dir)
+@pytest.mark.parametrize("world", [2, 4])
+def test_multirank_oracle_matches_reference_fixtures(golden_dir, world):
+    """World size 4 is where the rank-ordered label offsets 4B * rank (modeling_pretrain_moco_mim_ori.py:453) and the four-way
+    SyncBN sums first differ from the two-rank special case."""
+    _run(_oracle_worker, world, golden_dir)
 
 
 def test_comm_layer_world2():
@@ -161,9 +164,13 @@ def _engine_worker(rank, world, port, golden_dir, q):
         st = train_one_epoch(ddp, None, None, [([im, au, mk], torch.ones(1), torch.ones(1))], None, opt, torch.device("cuda:0"), 0,
                              NativeScalerWithGradNormCount(), None, patch_size=4, normlize_target=False, start_steps=0,
                              lr_schedule_values=np.full(3, hp.lr), wd_schedule_values=np.full(3, hp.weight_decay), args=args)
-        for k in ("loss_pixel", "loss_contrast", "grad_norm"):                  # per-rank meters of the reference (loss is rank-local too)
-            want = float(g[f"s0/stat/{k}"])
-            assert abs(st[k] - want) <= 3e-2 * abs(want) + 2e-3, (k, st[k], want)
+        # train_one_epoch returns the meters synchronised between processes (the reference's MetricLogger.synchronize_between_processes,
+        # utils/utils.py:57-62: global averages), the fixtures hold each rank's own values (the harness runs that barrier as a no-op):
+        # compare with the mean over all ranks' fixtures; the gradient norm is the same on every rank (averaged gradients)
+        allg = [np.load(os.path.join(golden_dir, f"tiny_w{world}_rank{r}.npz")) for r in range(world)]
+        for k in ("loss_pixel", "loss_contrast", "grad_norm"):
+            want = float(np.mean([float(x[f"s0/stat/{k}"]) for x in allg]))
+            assert abs(st[k] - want) <= 2e-2 * abs(want) + 2e-3, (k, st[k], want)
         grads = {n: p.grad.detach().float().cpu() for n, p in model.named_parameters() if p.requires_grad}
         names, norms = g["s0/grad_names"].tolist(), g["s0/grad_norms"]
         tot = float(np.sqrt((norms ** 2).sum()))
@@ -199,6 +206,13 @@ def _engine_worker(rank, world, port, golden_dir, q):
 @pytest.mark.gpu
 def test_engine_two_ranks_on_one_gpu_matches_reference_ddp_fixtures(golden_dir):
     _run(_engine_worker, 2, golden_dir)
+
+
+@pytest.mark.gpu
+def test_engine_four_ranks_on_one_gpu_matches_reference_ddp_fixtures(golden_dir):
+    """The same on four ranks (fixtures tiny_w4_rank{0..3}.npz from the unmodified reference under world-size-4 gloo DDP): label
+    offsets 0 / 16 / 32 / 48, four-way BatchNorm sums, gathered-key order by rank."""
+    _run(_engine_worker, 4, golden_dir)
 
 
 # ---------------------------------------------------------------------------------------------- fine-tune step (row N1)

@@ -531,6 +531,136 @@ def test_rccl_path_world1_matches_local_path():
         assert not m.comm._pending
         rel = ((m.flat_grads - g0).norm() / g0.norm()).item()
         assert rel < 1e-6, rel                                           # every reduction on the gradient path is deterministic
+        # the ORDER of collectives on the communicator (a second step, recorded): it must be what every rank issues, or the first real
+        # multi-GPU step dead-locks.  The committed list was recorded from this path (tools/gpu_collective_order.py).
+        import json
+        m.comm.log = []
+        train_one_epoch(ddp, None, None, [([im, au, mk], torch.ones(1), torch.ones(1))], None, opt, torch.device("cuda:0"), 1,
+                        NativeScalerWithGradNormCount(), None, patch_size=4, normlize_target=False, start_steps=1,
+                        lr_schedule_values=np.full(3, hp.lr), wd_schedule_values=np.full(3, hp.weight_decay), args=args)
+        want = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "collective_order_tiny.json")))
+        got = [[op, n] for op, n in m.comm.log]
+        m.comm.log = None
+        assert got == want["step"], (got[:6], want["step"][:6])
+        # depth + 5 gradient buckets (17 for the 12-block models), one fused key gather, 8 + 8 BatchNorm-statistics messages
+        assert sum(1 for op, _ in got if op.startswith("all_reduce_async:")) == cfg.depth + 5 and sum(1 for op, _ in got if op == "all_gather") == 1
+        assert sum(1 for op, _ in got if op == "all_reduce") == 16
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_clip_grad_two_steps_vs_reference_fixture():
+    """--clip_grad on the pre-training path (utils/utils.py:487-493) against tests/golden/tiny_w1_clip.npz, written by the unmodified reference
+    engine with max_norm = 1.0 (gradient norm 4-5: the clip is active).  Adam's update direction does not depend on the scale of one
+    gradient, so the check is where the coefficient lives: the norms of both Adam moments after each of two steps."""
+    g, cfg, hp, seed, B = _fixture_step0("tiny_w1_clip")
+    assert hp.clip_grad == 1.0
+    batches = [O.synthetic_batch(B, cfg, seed * 1000 + 17 * s) for s in range(2)]
+    model = build_model(cfg, *O.det_state(cfg, seed))
+    stats, opt = run_engine_steps(model, batches, hp)
+    for s in range(2):
+        for k in ("loss", "loss_pixel", "loss_contrast", "grad_norm"):
+            assert close(stats[s][k], float(g[f"s{s}/stat/{k}"]), rtol=3e-2, atol=3e-3), (s, k, stats[s][k], float(g[f"s{s}/stat/{k}"]))
+    names = g["s1/moment_names"].tolist()
+    spec = model.specs                                                    # name -> (offset, numel, ...) of the flat arenas the moments mirror
+    m1 = np.array([opt.exp_avg[spec[n].offset:spec[n].offset + spec[n].numel].double().norm().item() for n in names])
+    m2 = np.array([opt.exp_avg_sq[spec[n].offset:spec[n].offset + spec[n].numel].double().norm().item() for n in names])
+    r1, r2 = g["s1/exp_avg_norms"], g["s1/exp_avg_sq_norms"]
+    tot1, tot2 = np.sqrt((r1 ** 2).sum()), np.sqrt((r2 ** 2).sum())
+    assert abs(np.sqrt((m1 ** 2).sum()) / tot1 - 1) < 3e-2 and abs(np.sqrt((m2 ** 2).sum()) / tot2 - 1) < 6e-2
+    for i, n in enumerate(names):
+        if r1[i] > 1e-2 * tot1:                                           # tensors that carry the update (bf16 noise yardstick: 8 %)
+            assert abs(m1[i] / r1[i] - 1) < 8e-2, (n, m1[i], r1[i])
+    # an unclipped run would be off by the clip coefficient (1 / grad_norm ~ 0.23 at both steps)
+    assert float(g["s0/stat/grad_norm"]) > 2.0 and float(g["s1/stat/grad_norm"]) > 2.0
+
+
+def test_vit_small_b32_every_tensor_gradient_vs_oracle():
+    """Every one of the 183 trainable tensors of the BASELINE model (ViT-S, B = 32) -- weights, biases, LayerNorm and BatchNorm vectors,
+    mask token -- against the fp32 oracle, judged one by one with the CPU bf16-autocast run of the same oracle as the noise yardstick (a
+    bucketed cosine hides a wrong bias next to its block's weight gradients)."""
+    cfg = O.make_config("pretrain_simmim_moco_ori_vit_small_patch4_32x128")
+    seed, B = 37, 32
+    hp = O.StepHyper(lr=1.5e-4 * B / 256)
+    im, au, mk = O.synthetic_batch(B, cfg, seed * 1000)
+    model = build_model(cfg, *O.det_state(cfg, seed))
+    (stats,), _ = run_engine_steps(model, [(im, au, mk)], hp)
+    grads = {n: p.grad.detach().float().cpu().clone() for n, p in model.named_parameters() if p.requires_grad}
+    assert len(grads) == 183
+    hp0 = dataclasses.replace(hp, moco_m=O.adjust_moco_momentum(0.0, 10, hp.moco_m))
+    torch.set_num_threads(max(8, min(64, os.cpu_count() or 8)))
+    ref_m, ref_g, _, _ = O.OracleTrainer(cfg, *O.det_state(cfg, seed)).loss_and_grads(im, au, mk, hp0)
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        _, bf_g, _, _ = O.OracleTrainer(cfg, *O.det_state(cfg, seed)).loss_and_grads(im, au, mk, hp0)
+    cos = torch.nn.functional.cosine_similarity
+    tot = float(torch.sqrt(sum((r.double() ** 2).sum() for r in ref_g.values())))
+    bad, checked = [], 0
+    for n, g in grads.items():
+        r = ref_g[n].reshape(1, -1)
+        if float(r.norm()) < 1e-7 * tot:
+            continue                                                       # (exactly-zero reference gradients: nothing to compare a direction with)
+        checked += 1
+        c_hip, c_bf = cos(g.reshape(1, -1), r).item(), cos(bf_g[n].float().reshape(1, -1), r).item()
+        q_hip, q_bf = (g.norm() / r.norm()).item(), (bf_g[n].float().norm() / r.norm()).item()
+        if (1 - c_hip) > 2 * (1 - c_bf) + 5e-3 or abs(q_hip - 1) > 2 * abs(q_bf - 1) + 3e-2:
+            bad.append((n, round(c_hip, 5), round(c_bf, 5), round(q_hip, 4), round(q_bf, 4)))
+    assert checked >= 180 and not bad, bad
+
+
+def test_twenty_step_trajectory_vs_oracle_band():
+    """Twenty optimisation steps of the tiny model with MOVING schedules (warm-up + cosine lr, weight decay ramp, cosine EMA momentum) and a
+    fresh batch per step: what drifts at step 10 and not at step 2 -- EMA-before-forward ordering, BatchNorm running buffers, schedule
+    indexing, the lagged meter read-back.  Band: at every step the device loss may be at most twice as far from the fp32 oracle's as the
+    CPU bf16-autocast oracle's is (+ 3 %); BatchNorm buffers and counters after step 20."""
+    from dig_amd.optim_factory import create_optimizer
+    from dig_amd.engine_for_pretraining_moco import train_one_epoch
+    from dig_amd.utils import NativeScalerWithGradNormCount
+    from gpu_util import engine_args
+    cfg = O.DiGConfig(**O.TINY)
+    seed, B, n, epochs = 41, 4, 20, 25
+    hp = O.StepHyper(lr=1e-3)
+    lr = np.concatenate([np.linspace(1e-4, 1e-3, 5), 5e-5 + 0.5 * (1e-3 - 5e-5) * (1 + np.cos(np.pi * np.arange(15) / 15))])
+    wd = np.linspace(0.05, 0.1, n)
+    batches = [O.synthetic_batch(B, cfg, 7000 + s) for s in range(n)]
+    model = build_model(cfg, *O.det_state(cfg, seed))
+    args = engine_args(hp, epochs=epochs)
+    opt = create_optimizer(args, model)
+    dev_stats = []
+    for s, (im, au, mk) in enumerate(batches):
+        dev_stats.append(train_one_epoch(model, None, None, [([im, au, mk], torch.ones(1), torch.ones(1))], None, opt, torch.device("cuda:0"), s,
+                                         NativeScalerWithGradNormCount(), None, patch_size=4, normlize_target=False, start_steps=s,
+                                         lr_schedule_values=lr, wd_schedule_values=wd, args=args))
+    def oracle(autocast):
+        tr = O.OracleTrainer(cfg, *O.det_state(cfg, seed))
+        out = []
+        for s, (im, au, mk) in enumerate(batches):
+            hps = dataclasses.replace(hp, lr=float(lr[s]), weight_decay=float(wd[s]), moco_m=O.adjust_moco_momentum(float(s), epochs, hp.moco_m))
+            if autocast:
+                with torch.autocast("cpu", dtype=torch.bfloat16):
+                    m, _, _, _ = tr.step(im, au, mk, hps)
+            else:
+                m, _, _, _ = tr.step(im, au, mk, hps)
+            out.append(m)
+        return out, tr
+    ref, tr = oracle(False)
+    bf, tb = oracle(True)
+    for s in range(n):
+        assert dev_stats[s]["lr"] == pytest.approx(float(lr[s]), rel=1e-6) and dev_stats[s]["weight_decay"] == pytest.approx(float(wd[s]), rel=1e-6)
+        assert dev_stats[s]["moco_m"] == pytest.approx(O.adjust_moco_momentum(float(s), epochs, hp.moco_m), rel=1e-6)
+        for k in ("loss", "loss_pixel", "loss_contrast"):
+            d_hip, d_bf = abs(dev_stats[s][k] - ref[s][k]), abs(bf[s][k] - ref[s][k])
+            assert d_hip <= 2 * d_bf + 3e-2 * abs(ref[s][k]) + 3e-3, (s, k, dev_stats[s][k], ref[s][k], bf[s][k])
+    assert ref[-1]["loss_pixel"] < ref[0]["loss_pixel"] and dev_stats[-1]["loss_pixel"] < dev_stats[0]["loss_pixel"]      # it trains
+    sd = model.state_dict()
+    for k, v in tr.S.items():
+        if k.endswith("num_batches_tracked"):
+            assert int(sd[k]) == n == int(v), k
+        else:
+            a, b, c = sd[k].float().cpu(), v.float(), tb.S[k].float()
+            assert (a - b).norm() <= 2 * (c - b).norm() + 3e-2 * b.norm() + 1e-4 * np.sqrt(b.numel()), (k, float((a - b).norm()), float((c - b).norm()), float(b.norm()))
+    assert opt._step == n
+    # the momentum (EMA) weights followed the schedule: they are compared with the oracle's in the same band
+    for name in ("momentum_encoder.blocks.0.mlp.fc1.weight", "momentum_projection_layer.0.weight", "momentum_encoder.patch_embed.proj.weight"):
+        a, b, c = dict(model.named_parameters())[name].detach().float().cpu(), tr.P[name], tb.P[name].float()
+        assert (a - b).norm() <= 2 * (c - b).norm() + 1e-3 * b.norm(), (name, float((a - b).norm()), float((c - b).norm()))

@@ -8,7 +8,7 @@
 #    gpurun_out/<tag>_pmc_kernel_counters.txt     MFMA / LDS utilisation, occupancy, instruction mix passes
 # Copy what should be judged into profiles/ afterwards.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
@@ -32,6 +32,10 @@ p = "$OUT/${TAG}_pmc_traffic.json"
 d = json.load(open(p))
 d["steps_in_run"] = 7          # --steps 3 --warmup 2 + the two instrumented steps of the roofline probe
 d["lib_sha256_16"] = hashlib.sha256(open("$ROOT/dig_amd/lib/libdig_hip.so", "rb").read()).hexdigest()[:16]
+import sys
+sys.path.insert(0, "$ROOT")
+from dig_amd import build
+d["src_sha256_16"] = build.source_hash()          # what bench.py re-checks: the .so bytes differ between builds of identical sources
 json.dump(d, open(p, "w"), indent=1)
 PY
 rm -rf $OUT/prof_FETCH_SIZE $OUT/prof_WRITE_SIZE
@@ -40,7 +44,7 @@ for set in "MfmaUtil LdsUtil" "VmemLatency OccupancyPercent" "MemUnitStalled" "S
   rm -rf $OUT/prof_pmc
   rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/prof_pmc -- $SHORT > /dev/null 2>&1
   echo "== $set" >> $OUT/${TAG}_pmc_kernel_counters.txt
-  python $ROOT/tools/pmc_summary.py $(ls $OUT/prof_pmc/*/*counter_collection.csv | head -1) | grep -E "gemm|attn|ln_|reduce_partials" >> $OUT/${TAG}_pmc_kernel_counters.txt
+  python $ROOT/tools/pmc_summary.py $(ls $OUT/prof_pmc/*/*counter_collection.csv | head -1) | grep -E "gemm|attn|ln_|reduce_partials|mlp_chain" >> $OUT/${TAG}_pmc_kernel_counters.txt
 done
 rm -rf $OUT/prof_pmc
 cd $ROOT

@@ -7,6 +7,8 @@ import csv, json, re, sys, collections
 
 
 def family(name):
+    if "mlp_chain_kernel" in name:
+        return "mlp_chain"
     if "gemm_pwide_kernel" in name:
         return "fwd"
     m = re.search(r"gemm(?:_wide|_persist)?_kernel<(true|false), (true|false)", name)
