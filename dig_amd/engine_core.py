@@ -14,6 +14,8 @@ import torch
 from . import ops
 
 BF16, F32 = torch.bfloat16, torch.float32
+FWD_FLIP = os.environ.get("DIG_FWD_FLIP", "1") == "1"               # online forward on the high-priority stream, momentum branch on the caller's
+#                                                                     (23.76 -> 23.58 ms per step, two A/B pairs on one box)
 BATCH_REDUCE = os.environ.get("DIG_BATCH_REDUCE", "0") == "1"       # an encoder block's eleven reduction launches as two: fewer launches,
 #                                                                     0.1-0.15 ms SLOWER per step -> opt-in
 FUSED_QV_BIAS_SUMS = os.environ.get("DIG_FUSED_QV_BIAS", "1") != "0"
@@ -340,26 +342,62 @@ class _Step:
         # arena, read-only here) and the inputs, so it overlaps the online forward.  EMA with the current online weights
         # comes first (:526).
         main = torch.cuda.current_stream(dev)
-        side = M._side_stream(dev) if getattr(M, "overlap_streams", True) else main
+        side = M._fwd_stream(dev) if getattr(M, "overlap_streams", True) else main
         dist_mode = comm.world > 1 or getattr(comm, "world_override", False)
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
+        flip = FWD_FLIP and not dist_mode and side is not main
+        if flip:
+            # The big forward kernels own the whole chip one at a time (persistent GEMM tiles, the fused MLP chain), so the two branches
+            # serialise kernel by kernel and the question is only WHO goes first.  The online branch ends in ~60 small head kernels that
+            # leave the chip mostly idle: it runs on the HIGH-priority stream here (the momentum branch on the caller's), finishes its
+            # encoder first, and its heads run inside the momentum encoder's time instead of behind it.
+            hi_st = M._side_stream(dev)
+            hi_st.wait_stream(main)
+            with torch.cuda.stream(hi_st):
+                enc, self.saved_enc = self.encoder_forward(ew_on, images, aug, mask_u8, True)
+                self.enc = enc
+                masked2, self.saved_pix = self.mlp_forward(enc[:B * N], "pix_projector", "online", True)
+                pooled = torch.empty((2 * B * nw, D), device=dev, dtype=BF16)
+                ops.window_pool_fwd(masked2, pooled[:B * nw], B, M.gh, M.gw, nw, D)
+                ops.window_pool_fwd(enc[B * N:], pooled[B * nw:], B, M.gh, M.gw, nw, D)
+                qs, self.saved_proj = self.mlp_forward(pooled, "encoder_projection_layer", "online", True)
+                qs, self.saved_pred = self.mlp_forward(qs, "predictor", "online", True)
             ops.ema_update(M._flat["momentum"], M._flat["online"], M.shadow("momentum"), M.n_ema, m)
             enc_m, _ = self.encoder_forward(ew_mo, images, aug, mask_u8, False)
-            if not dist_mode:
-                masked_m, _ = self.mlp_forward(enc_m[:B * N], "pix_projector_m", "momentum", False)
-                pooled_m = torch.empty((2 * B * nw, D), device=dev, dtype=BF16)
-                ops.window_pool_fwd(masked_m, pooled_m[:B * nw], B, M.gh, M.gw, nw, D)
-                ops.window_pool_fwd(enc_m[B * N:], pooled_m[B * nw:], B, M.gh, M.gw, nw, D)
-                ks, _ = self.mlp_forward(pooled_m, "momentum_projection_layer", "momentum", False)
-                del enc_m, masked_m, pooled_m
+            masked_m, _ = self.mlp_forward(enc_m[:B * N], "pix_projector_m", "momentum", False)
+            pooled_m = torch.empty((2 * B * nw, D), device=dev, dtype=BF16)
+            ops.window_pool_fwd(masked_m, pooled_m[:B * nw], B, M.gh, M.gw, nw, D)
+            ops.window_pool_fwd(enc_m[B * N:], pooled_m[B * nw:], B, M.gh, M.gw, nw, D)
+            ks, _ = self.mlp_forward(pooled_m, "momentum_projection_layer", "momentum", False)
+            del enc_m, masked_m, pooled_m
             self.wT = None
             if torch.is_grad_enabled() and ops.mlp_chain_supported(D, M.F) and (ops.MLP_CHAIN_MASK & 4):
-                self.wT = self.mlp_weight_transposes(ew_on)             # (both modes join the side stream before the backward can start)
+                self.wT = self.mlp_weight_transposes(ew_on)
+            # every tensor the online branch made lives in the high-priority stream's pool and is read on the caller's stream from here
+            # on (decoder, backward).  No record_stream bookkeeping is needed: that pool hands memory out again only to the NEXT forward's
+            # online branch, which starts with hi_st.wait_stream(main), i.e. after everything this step queues on the caller's stream.
+            main.wait_stream(hi_st)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+          if not flip:
+              ops.ema_update(M._flat["momentum"], M._flat["online"], M.shadow("momentum"), M.n_ema, m)
+              enc_m, _ = self.encoder_forward(ew_mo, images, aug, mask_u8, False)
+              if not dist_mode:
+                  masked_m, _ = self.mlp_forward(enc_m[:B * N], "pix_projector_m", "momentum", False)
+                  pooled_m = torch.empty((2 * B * nw, D), device=dev, dtype=BF16)
+                  ops.window_pool_fwd(masked_m, pooled_m[:B * nw], B, M.gh, M.gw, nw, D)
+                  ops.window_pool_fwd(enc_m[B * N:], pooled_m[B * nw:], B, M.gh, M.gw, nw, D)
+                  ks, _ = self.mlp_forward(pooled_m, "momentum_projection_layer", "momentum", False)
+                  del enc_m, masked_m, pooled_m
+              self.wT = None
+              if torch.is_grad_enabled() and ops.mlp_chain_supported(D, M.F) and (ops.MLP_CHAIN_MASK & 4):
+                  self.wT = self.mlp_weight_transposes(ew_on)             # (both modes join the side stream before the backward can start)
         # ---- online branch
-        enc, self.saved_enc = self.encoder_forward(ew_on, images, aug, mask_u8, True)
-        self.enc = enc
-        if not dist_mode:
+        if not flip:
+            enc, self.saved_enc = self.encoder_forward(ew_on, images, aug, mask_u8, True)
+            self.enc = enc
+        if flip:
+            pass
+        elif not dist_mode:
             masked2, self.saved_pix = self.mlp_forward(enc[:B * N], "pix_projector", "online", True)
             pooled = torch.empty((2 * B * nw, D), device=dev, dtype=BF16)
             ops.window_pool_fwd(masked2, pooled[:B * nw], B, M.gh, M.gw, nw, D)

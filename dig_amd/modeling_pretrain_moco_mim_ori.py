@@ -400,6 +400,21 @@ class MoCo_ViT(nn.Module):
             st = self._side = torch.cuda.Stream(device=dev, priority=-1)
         return st
 
+    def _fwd_stream(self, dev):
+        """HIP stream of the gradient-free momentum branch in the FORWARD.  DIG_FWD_MOM_PRIO = high (the weight-gradient stream itself),
+        normal or low: with the big forward kernels owning the whole chip one at a time (persistent GEMM tiles, the fused MLP chain), the
+        two branches serialise kernel by kernel; below the main stream's priority the online encoder gets the chip first and the
+        momentum branch fills the time in which the online branch runs its small head kernels."""
+        import os
+        mode = os.environ.get("DIG_FWD_MOM_PRIO", "high")
+        if mode == "high":
+            return self._side_stream(dev)
+        st = getattr(self, "_fwd_side", None)
+        if st is None or st.device != dev:
+            lo, hi = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, -1)
+            st = self._fwd_side = torch.cuda.Stream(device=dev, priority=(max(lo, hi) if mode == "low" else 0))
+        return st
+
     def _mask_count(self, mask_u8, B):
         """Masked tokens per sample of view 0 (the reference reshapes to [B, -1, C], so it is constant over the
         batch).  Read back once and cached: per-step validation happens where the engine synchronises anyway."""
