@@ -298,9 +298,10 @@ def main():
     import contextlib
     model.overlap_streams = False                     # kernels one at a time, so event brackets time single launches
     model.step_graph = False                          # (and launched eagerly: a replayed graph has no per-launch brackets)
-    probe = GemmProbe() if rank == 0 else contextlib.nullcontext()
+    run(1, a.warmup + a.steps)                        # one plain step in this mode first: the caller's stream pool gets the blocks the
+    probe = GemmProbe() if rank == 0 else contextlib.nullcontext()   # high-priority stream's pool held, so no hipMalloc sits inside a bracket
     with probe:
-        run(2, a.warmup + a.steps)
+        run(2, a.warmup + a.steps + 1)
     model.overlap_streams = True
     if rank == 0:
         summ = probe.summary()

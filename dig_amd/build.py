@@ -10,9 +10,11 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libdig_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-ffp-contract=fast",
          "-Wno-unused-result"]
-# per-file extras.  mlp_chain.hip: the SLP vectoriser packs the GELU polynomial into v_pk_fma_f32 pairs, which cost s_nop hazard
-# padding in a VALU stream that is placed between MFMAs by hand (205 -> 44 s_nop in the S-wave loop without it)
-EXTRA_FLAGS = {"mlp_chain.hip": ["-fno-slp-vectorize"]}
+# -fno-slp-vectorize: the SLP vectoriser packs adjacent fp32 multiplies / FMAs of the epilogues into v_pk_*_f32 pairs, which need s_nop
+# hazard padding and are no faster than two scalar ops on this chip (MI355X_MICROARCH.md: an anti-lever beside MFMAs): 205 -> 44 s_nop in
+# the fused-MLP S-wave loop, and 24.28 -> 24.15 ms per step with it on every file (A/B on one box)
+FLAGS.append("-fno-slp-vectorize")
+EXTRA_FLAGS = {}                                       # per-file extras (none at present)
 
 
 def sources():

@@ -266,9 +266,23 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainParams p) {
           gelu_fast2(v0, v1);
         }
         if (e0 == 0) pk[q].x = pack_bf2(v0, v1);
-        else {
-          pk[q].y = pack_bf2(v0, v1);
-          if (q >= 3) {                                                 // quads 0..2 are written by the hold path of tick 1
+        else pk[q].y = pack_bf2(v0, v1);                                // (the quad goes to LDS at the top of the next k-step: quad_flush)
+      };
+      // LDS writes of finished quads.  They are inline asm (see the note on LDS reads above), so the compiler's lgkmcnt bookkeeping does
+      // not know them: issued BEHIND the fragment prefetch of a k-step they made every `s_waitcnt lgkmcnt(N)` in front of an MFMA wait for
+      // the prefetched fragments as well (the write is the youngest operation).  Issued at the TOP of a k-step, ahead of that k-step's
+      // prefetch, they are older than everything the compiler counts and cost the MFMAs nothing.
+      auto quad_flush = [&](auto tau_tag, auto s_tag) {
+        constexpr int TAU = decltype(tau_tag)::value, S = decltype(s_tag)::value;
+        if (!(G && !(DIG_CHAIN_ABL & 1))) return;
+        if (TAU == 1 && S < 3) {                                        // the three quads tick 0 finished (the P tile was not free yet)
+          lds_write8(quad_addr(S), pk[S]);
+          if (MODE == 1) lds_write8(quad_addr(S) + (unsigned)(X_OFF - P_OFF), pkpre[S]);
+        }
+        constexpr int NP = TAU == 0 ? 6 : 5, P0 = TAU == 0 ? 0 : (TAU == 1 ? 6 : 11);
+        if (TAU > 0 && S >= 1 && S <= NP) {
+          constexpr int PG = P0 + S - 1, q = PG >> 1;                   // the pair k-step S - 1 worked on
+          if ((PG & 1) && q >= 3) {
             lds_write8(quad_addr(q), pk[q]);
             if (MODE == 1) lds_write8(quad_addr(q) + (unsigned)(X_OFF - P_OFF), pkpre_t);
           }
@@ -288,6 +302,7 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainParams p) {
         __builtin_amdgcn_sched_barrier(0);
         auto kstep = [&](auto s_tag, bf16x8 (&cur)[2], bf16x8 (&nxt)[2]) {
           constexpr int S = decltype(s_tag)::value;
+          quad_flush(tau_tag, s_tag);
           if (M1 && S < KS_PER_TICK - 1) {
             nxt[0] = *reinterpret_cast<const bf16x8*>(w + a1off[S + 1]);
             nxt[1] = *reinterpret_cast<const bf16x8*>(w + 8192 + a1off[S + 1]);
@@ -296,10 +311,6 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainParams p) {
           pairwork(tau_tag, s_tag);
           __builtin_amdgcn_sched_barrier(0);
           if (M1 && !(DIG_CHAIN_ABL & 8)) Sc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[1], xf[TAU * KS_PER_TICK + S], Sc[1], 0, 0, 0);
-          if (G && !(DIG_CHAIN_ABL & 1) && TAU == 1 && S < 3) {        // the three quads tick 0 computed (the P tile was not free yet)
-            lds_write8(quad_addr(S), pk[S]);
-            if (MODE == 1) lds_write8(quad_addr(S) + (unsigned)(X_OFF - P_OFF), pkpre[S]);
-          }
           if (S & 1) dma_piece(tau_tag, std::integral_constant<int, (S >> 1)>{});
           if (G && !(DIG_CHAIN_ABL & 1) && MODE == 2 && TAU == 1 && S == 6) colsum_block(0);
           if (G && !(DIG_CHAIN_ABL & 1) && MODE == 2 && TAU == 2 && S == 4) colsum_block(1);
@@ -358,20 +369,19 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainParams p) {
     // of the column blocks per tick (48 registers of loads in flight), instead of in front of the pipeline.
     f32x16 D2[NJB];
     const auto rRes = __builtin_amdgcn_make_buffer_rsrc((void*)p.resid, 0, p.resid ? p.x_bytes : 0, 0x00020000);   // null: zeros; rows beyond R: zeros
-    const unsigned ro = (unsigned)(((size_t)(m0 + pair * 32 + rr) * KD + 4 * hi) * 2);
-    dig_u32x4 rq[4];                                                   // residual quads of one group (2 column blocks) in flight
-    // group k (0..5) = column blocks 2k, 2k + 1: requested in idle tick k, unpacked in tick k + 1 (one tick of latency cover)
+    dig_u32x4 rq[4];                                                   // residual chunks of one group (2 column blocks) in flight
+    const unsigned ro16 = (unsigned)(((size_t)(m0 + pair * 32 + rr) * KD + 16 * hi) * 2);
+    // group k (0..5) = column blocks 2k, 2k + 1: requested in idle tick k, unpacked in tick k + 1 (one tick of latency cover).  A lane
+    // fetches 2 x 16 contiguous bytes per column block (columns 16 hi .. 16 hi + 15) instead of its own four 8-byte quads: half the
+    // load instructions and row segments; v_permlane32_swap then trades the halves so that lane (token, hi) ends up with its quads
+    // 8 g + 4 hi .. + 3 (the inverse of the epilogue's store shuffle).
     auto init_load = [&](auto k_tag) {
       constexpr int K = decltype(k_tag)::value;
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int gp = 0; gp < 2; ++gp) {
-          constexpr int jb0 = 2 * K;
-          const auto w0 = __builtin_amdgcn_raw_buffer_load_b64(rRes, ro + ((jb0 + j) * 32 + (2 * gp) * 8) * 2, 0, 0);
-          const auto w1 = __builtin_amdgcn_raw_buffer_load_b64(rRes, ro + ((jb0 + j) * 32 + (2 * gp + 1) * 8) * 2, 0, 0);
-          rq[2 * j + gp] = dig_u32x4{w0[0], w0[1], w1[0], w1[1]};
-        }
+        for (int c = 0; c < 2; ++c)
+          rq[2 * j + c] = __builtin_amdgcn_raw_buffer_load_b128(rRes, ro16 + ((2 * K + j) * 32 + 8 * c) * 2, 0, 0);
     };
     auto init_finish = [&](auto k_tag) {
       constexpr int K = decltype(k_tag)::value;
@@ -379,15 +389,25 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainParams p) {
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
+        for (int c = 0; c < 2; ++c) {
           constexpr int jb0 = 2 * K;
-          f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-          if (MODE != 2) bv = *reinterpret_cast<const f32x4*>(b2s + (jb0 + j) * 32 + g * 8);
-          const unsigned wx = rq[2 * j + (g >> 1)][2 * (g & 1)], wy = rq[2 * j + (g >> 1)][2 * (g & 1) + 1];
-          D2[jb0 + j][4 * g] = bv[0] + bf2f((bf16_t)(wx & 0xffff));
-          D2[jb0 + j][4 * g + 1] = bv[1] + bf2f((bf16_t)(wx >> 16));
-          D2[jb0 + j][4 * g + 2] = bv[2] + bf2f((bf16_t)(wy & 0xffff));
-          D2[jb0 + j][4 * g + 3] = bv[3] + bf2f((bf16_t)(wy >> 16));
+          // chunk c of the lane's 32 bytes: dwords (x, y) = its low 4 columns, (z, w) = its high 4.  Lower lanes give their high half and
+          // receive the upper lanes' low half: afterwards (x, y) = quad g = c, (z, w) = quad g = c + 2 on every lane.
+          unsigned x = rq[2 * j + c][0], y = rq[2 * j + c][1], z = rq[2 * j + c][2], w = rq[2 * j + c][3];
+          const auto s0 = __builtin_amdgcn_permlane32_swap(x, z, false, false);
+          const auto s1 = __builtin_amdgcn_permlane32_swap(y, w, false, false);
+          x = s0[0]; z = s0[1]; y = s1[0]; w = s1[1];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int g = c + 2 * h;
+            const unsigned wx = h ? z : x, wy = h ? w : y;
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            if (MODE != 2) bv = *reinterpret_cast<const f32x4*>(b2s + (jb0 + j) * 32 + g * 8);
+            D2[jb0 + j][4 * g] = bv[0] + bf2f((bf16_t)(wx & 0xffff));
+            D2[jb0 + j][4 * g + 1] = bv[1] + bf2f((bf16_t)(wx >> 16));
+            D2[jb0 + j][4 * g + 2] = bv[2] + bf2f((bf16_t)(wy & 0xffff));
+            D2[jb0 + j][4 * g + 3] = bv[3] + bf2f((bf16_t)(wy >> 16));
+          }
         }
     };
     // idle tick KT (0..5): unpack the group requested a tick ago, request the next one; the last tick also waits for its own group
