@@ -955,6 +955,37 @@ int dig_mlp_chain_fwd(const void* x_, const void* w1_, const float* b1, const vo
   return DIG_OK;
 }
 
+// rows of y = LN(x): fp32 statistics over the bf16 values, variance as E[x^2] - E[x]^2 (what the fused kernel computes)
+static void ln_rows_cpu(const bf16_t* x, const float* g, const float* b, float eps, bf16_t* y, float* mean, float* rstd, int R, int D) {
+#pragma omp parallel for
+  for (int r = 0; r < R; ++r) {
+    float s1 = 0.f, s2 = 0.f;
+    for (int k = 0; k < D; ++k) { const float v = bf2f(x[(size_t)r * D + k]); s1 += v; s2 += v * v; }
+    const float mu = s1 / D;
+    const float rs = 1.0f / std::sqrt(std::max(s2 / D - mu * mu, 0.f) + eps);
+    if (y) for (int k = 0; k < D; ++k) y[(size_t)r * D + k] = f2bf((bf2f(x[(size_t)r * D + k]) - mu) * (rs * g[k]) + b[k]);
+    if (mean) { mean[r] = mu; rstd[r] = rs; }
+  }
+}
+
+int dig_mlp_chain_fwd_ln(const void* x, const float* ln_g, const float* ln_b, float eps, void* ln_out, float* ln_mean, float* ln_rstd,
+                         const void* w1, const float* b1, const void* w2, const float* b2, void* out, void* pre_out, void* act_out,
+                         const float* nln_g, const float* nln_b, void* nln_out, float* nln_mean, float* nln_rstd, int R, int D, int F,
+                         hipStream_t st) {
+  if (!x || !w1 || !w2 || !out || R <= 0) return DIG_ERR_ARG;
+  if (!dig_mlp_chain_supported(D, F) || F > 2048) return DIG_ERR_UNSUPPORTED;
+  if (!ln_g || !ln_b || (nln_g == nullptr) != (nln_b == nullptr) || (nln_g == nullptr) != (nln_out == nullptr)) return DIG_ERR_ARG;
+  if ((ln_mean == nullptr) != (ln_rstd == nullptr) || (nln_mean == nullptr) != (nln_rstd == nullptr)) return DIG_ERR_ARG;
+  std::vector<bf16_t> tmp;
+  bf16_t* ln = (bf16_t*)ln_out;
+  if (!ln) { tmp.resize((size_t)R * D + 8); ln = (bf16_t*)(((uintptr_t)tmp.data() + 15) & ~(uintptr_t)15); }
+  ln_rows_cpu((const bf16_t*)x, ln_g, ln_b, eps, ln, ln_mean, ln_rstd, R, D);
+  const int rc = dig_mlp_chain_fwd(ln, w1, b1, w2, b2, x, out, pre_out, act_out, R, D, F, st);
+  if (rc != DIG_OK) return rc;
+  if (nln_g) ln_rows_cpu((const bf16_t*)out, nln_g, nln_b, eps, (bf16_t*)nln_out, nln_mean, nln_rstd, R, D);
+  return DIG_OK;
+}
+
 int dig_mlp_chain_bwd(const void* dy_, const void* w2t_, const void* pre_, const void* w1t_, void* dpre_out_, void* dx_out_,
                       float* colsum_partials, int R, int D, int F, hipStream_t) {
   if (!dy_ || !w2t_ || !pre_ || !w1t_ || !dpre_out_ || !dx_out_ || R <= 0) return DIG_ERR_ARG;

@@ -27,6 +27,12 @@ __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsig
 // a hand-rolled integer rounding costs ~10 VALU ops per value and was the largest VALU item of every epilogue)
 typedef __bf16 dig_bf16x2 __attribute__((ext_vector_type(2)));
 typedef float dig_f32x2 __attribute__((ext_vector_type(2)));
+// A dword as a bf16 pair for v_dot2.  hipcc 7.2 folds `bit_cast<bf16x2>(v[q])` of a 4-dword vector element to element 0 for every q (the
+// code then loads and multiplies dword 0 four times); the empty asm keeps the extracted dword a scalar value the fold cannot see through.
+__device__ __forceinline__ dig_bf16x2 dig_as_bf16x2(unsigned u) {
+  asm volatile("" : "+v"(u));
+  return __builtin_bit_cast(dig_bf16x2, u);
+}
 __device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
   const dig_f32x2 v = {lo, hi};
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, dig_bf16x2));

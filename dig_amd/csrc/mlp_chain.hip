@@ -75,6 +75,13 @@ struct ChainParams {
   float* colsum;          // MODE 2: [ceil(R/32)][F] or null
   int R, F;
   unsigned x_bytes, w_bytes, side_bytes;
+  // LayerNorm fused at both ends (LN instantiations only; null = off): X holds RAW rows that are normalised with (ln_g, ln_b) on their way
+  // into the S-waves' registers; the finished output rows are normalised once more with (nln_g, nln_b) -- the next block's norm1
+  const float* ln_g; const float* ln_b;      // [KD]
+  bf16_t* ln_out; float* ln_mean; float* ln_rstd;          // normalised X rows [R, KD] and their statistics [R] (what a backward keeps), or null
+  const float* nln_g; const float* nln_b;    // [KD]
+  bf16_t* nln_out; float* nln_mean; float* nln_rstd;       // LayerNorm of `out` [R, KD] (+ statistics, or null)
+  float ln_eps;
 };
 
 template <int N>
@@ -91,10 +98,11 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(
 // every LDS read below is of that kind (checked in the ISA: no vmcnt(0) inside the tick loops).  LDS writes are inline asm.
 // MODE 0: forward, no side outputs (momentum branch / evaluation);  1: forward + pre-activation and GELU output (online branch:
 // what the backward reads);  2: backward (data gradient through both layers + d(pre-activation) + fc1 bias-gradient partials)
-template <int MODE>
+template <int MODE, bool LN>
 __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int B1S_OFF = X_OFF + (MODE == 1 ? SLOT : 0);          // forward: b1 [F] fp32 in LDS
+  static_assert(!(LN && MODE == 2), "LayerNorm fusion is a forward feature");
+  constexpr int B1S_OFF = X_OFF + (MODE == 1 ? SLOT : 0);          // forward: b1 [F], b2 [KD] (, LN: ln_g, ln_b, nln_g, nln_b [KD] each) fp32 in LDS
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int pair = wave & 3, role = wave >> 2;
@@ -175,11 +183,36 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainParams p) {
   // visible LDS store would drain the DMA just issued; the barrier of tick (0,0) publishes them), then the S-waves' X rows.
   issue_ring(0, 0u, 0u);
   issue_ring(1, (unsigned)(128 * 2), (unsigned)((128 * F) * 2));
-  if (MODE != 2) {
+  // (the vector values are requested first, the S-waves' X rows behind them, and only then are the values written to LDS: the wait in front
+  //  of the first LDS store then covers the ring DMA and these few loads, not the X rows.  Both steps live inside the role branches, so
+  //  that the values are branch-local: kept across the role split they were spilled around the O-waves' loop.)
+  float bv[4], bv2 = 0.f, lnv[4];
+  auto load_vectors = [&]() {
+    if (MODE == 2) return;
     const auto rb1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.bias1, 0, p.bias1 ? F * 4 : 0, 0x00020000);     // null: zeros
     const auto rb2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.bias2, 0, p.bias2 ? KD * 4 : 0, 0x00020000);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) bv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb1, (unsigned)((u * 512 + tid) * 4), 0, 0));
+    bv2 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb2, (unsigned)(tid * 4), 0, 0));
+    if (LN) {
+      const float* const src[4] = {p.ln_g, p.ln_b, p.nln_g, p.nln_b};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const auto rl = __builtin_amdgcn_make_buffer_rsrc((void*)src[u], 0, src[u] ? KD * 4 : 0, 0x00020000);
+        lnv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rl, (unsigned)(tid * 4), 0, 0));
+      }
+    }
+  };
+  // the vector values go to LDS behind the S-waves' X-row requests (stores in inline asm: a visible LDS store would drain the DMA just
+  // issued); the barrier of tick (0, 0) publishes b1 / b2, the LayerNorm vectors need their own barrier (the S-waves read them first)
+  auto stage_vectors = [&]() {
+    if (MODE == 2) return;
+    const auto rb1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.bias1, 0, p.bias1 ? F * 4 : 0, 0x00020000);
     const unsigned base = lds_addr(smem + B1S_OFF);
-    for (int i0 = 0; i0 < F; i0 += 2048) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (u * 512 + tid < F) asm volatile("ds_write_b32 %0, %1" ::"v"(base + (unsigned)((u * 512 + tid) * 4)), "v"(bv[u]) : "memory");
+    for (int i0 = 2048; i0 < F; i0 += 2048) {                          // (hidden widths beyond 2048)
       float v[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) v[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb1, (unsigned)((i0 + u * 512 + tid) * 4), 0, 0));
@@ -187,21 +220,74 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainParams p) {
       for (int u = 0; u < 4; ++u)
         if (i0 + u * 512 + tid < F) asm volatile("ds_write_b32 %0, %1" ::"v"(base + (unsigned)((i0 + u * 512 + tid) * 4)), "v"(v[u]) : "memory");
     }
-    const float v2 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb2, (unsigned)(tid * 4), 0, 0));
-    if (tid < KD) asm volatile("ds_write_b32 %0, %1" ::"v"(base + (unsigned)((F + tid) * 4)), "v"(v2) : "memory");
-  }
+    if (tid < KD) asm volatile("ds_write_b32 %0, %1" ::"v"(base + (unsigned)((F + tid) * 4)), "v"(bv2) : "memory");
+    if (LN) {
+      if (tid < KD) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) asm volatile("ds_write_b32 %0, %1" ::"v"(base + (unsigned)((F + (u + 1) * KD + tid) * 4)), "v"(lnv[u]) : "memory");
+      }
+      wait_lgkm0();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+  };
 
   const int psw = (rr >> 1) & 7;
   if (DIG_CHAIN_PRIO == 1 && role == 0) __builtin_amdgcn_s_setprio(1);
   if (DIG_CHAIN_PRIO == 2 && role == 1) __builtin_amdgcn_s_setprio(1);
   if (role == 0) {
     // =========================================================== S-wave =====================================================
-    bf16x8 xf[KD / 16];
-    {
-      const unsigned xo = (unsigned)(((size_t)(m0 + pair * 32 + rr) * KD + hi * 8) * 2);       // rows beyond R read as zero
+    load_vectors();
+    dig_u32x4 xf[KD / 16];                                              // the 32 x D slice of X as MFMA B fragments (96 VGPRs), as dword vectors
+    const unsigned xo = (unsigned)(((size_t)(m0 + pair * 32 + rr) * KD + hi * 8) * 2);         // rows beyond R read as zero
 #pragma unroll
-      for (int s = 0; s < KD / 16; ++s)
-        xf[s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rX, xo + s * 32, 0, 0));
+    for (int s = 0; s < KD / 16; ++s) xf[s] = __builtin_amdgcn_raw_buffer_load_b128(rX, xo + s * 32, 0, 0);
+    stage_vectors();
+    if (LN && p.ln_g) {
+      // LayerNorm of the lane's token on the way in.  The row is split between lanes rr and rr + 32 (k = 16 s + 8 hi ..): statistics by
+      // v_dot2 on the packed pairs (sum and sum of squares, fp32), one cross-half exchange, then y = (x - mean) rstd g + b in place.
+      float s1 = 0.f, s2 = 0.f;
+      const dig_bf16x2 ones = __builtin_bit_cast(dig_bf16x2, 0x3F803F80u);
+#pragma unroll
+      for (int s = 0; s < KD / 16; ++s) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const dig_bf16x2 pr = dig_as_bf16x2(xf[s][q]);
+          s1 = __builtin_amdgcn_fdot2_f32_bf16(pr, ones, s1, false);
+          s2 = __builtin_amdgcn_fdot2_f32_bf16(pr, pr, s2, false);
+        }
+      }
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      const float mean = s1 * (1.0f / KD);
+      const float rs = rsqrtf(fmaxf(s2 * (1.0f / KD) - mean * mean, 0.f) + p.ln_eps);
+      const float* gs = reinterpret_cast<const float*>(smem + B1S_OFF) + F + KD + 8 * hi;
+#pragma unroll
+      for (int s = 0; s < KD / 16; ++s) {
+        dig_u32x4 w = xf[s];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const f32x4 g4 = *reinterpret_cast<const f32x4*>(gs + 16 * s + 4 * h);
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(gs + KD + 16 * s + 4 * h);
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const unsigned u = w[2 * h + q];
+            const float y0 = fmaf(__uint_as_float(u << 16) - mean, rs * g4[2 * q], b4[2 * q]);
+            const float y1 = fmaf(__uint_as_float(u & 0xffff0000u) - mean, rs * g4[2 * q + 1], b4[2 * q + 1]);
+            w[2 * h + q] = pack_bf2(y0, y1);
+          }
+        }
+        xf[s] = w;
+      }
+      if (p.ln_out) {
+        const auto rLn = __builtin_amdgcn_make_buffer_rsrc((void*)p.ln_out, 0, p.x_bytes, 0x00020000);   // rows beyond R: dropped
+#pragma unroll
+        for (int s = 0; s < KD / 16; ++s) __builtin_amdgcn_raw_buffer_store_b128(xf[s], rLn, xo + s * 32, 0, 0);
+      }
+      if (p.ln_mean && hi == 0 && m0 + pair * 32 + rr < p.R) {
+        p.ln_mean[m0 + pair * 32 + rr] = mean;
+        p.ln_rstd[m0 + pair * 32 + rr] = rs;
+      }
     }
     int a1off[KS_PER_TICK];
 #pragma unroll
@@ -307,10 +393,10 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainParams p) {
             nxt[0] = *reinterpret_cast<const bf16x8*>(w + a1off[S + 1]);
             nxt[1] = *reinterpret_cast<const bf16x8*>(w + 8192 + a1off[S + 1]);
           }
-          if (M1 && !(DIG_CHAIN_ABL & 8)) Sc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[0], xf[TAU * KS_PER_TICK + S], Sc[0], 0, 0, 0);
+          if (M1 && !(DIG_CHAIN_ABL & 8)) Sc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[0], __builtin_bit_cast(bf16x8, xf[TAU * KS_PER_TICK + S]), Sc[0], 0, 0, 0);
           pairwork(tau_tag, s_tag);
           __builtin_amdgcn_sched_barrier(0);
-          if (M1 && !(DIG_CHAIN_ABL & 8)) Sc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[1], xf[TAU * KS_PER_TICK + S], Sc[1], 0, 0, 0);
+          if (M1 && !(DIG_CHAIN_ABL & 8)) Sc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[1], __builtin_bit_cast(bf16x8, xf[TAU * KS_PER_TICK + S]), Sc[1], 0, 0, 0);
           if (S & 1) dma_piece(tau_tag, std::integral_constant<int, (S >> 1)>{});
           if (G && !(DIG_CHAIN_ABL & 1) && MODE == 2 && TAU == 1 && S == 6) colsum_block(0);
           if (G && !(DIG_CHAIN_ABL & 1) && MODE == 2 && TAU == 2 && S == 4) colsum_block(1);
@@ -367,6 +453,8 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainParams p) {
     // Output accumulators start as bias + residual (the epilogue is then a convert-and-store).  The O-wave has nothing to multiply
     // during the first two chunk periods (the S-wave is two chunks ahead), so the residual rows are fetched and unpacked THERE, half
     // of the column blocks per tick (48 registers of loads in flight), instead of in front of the pipeline.
+    load_vectors();
+    stage_vectors();
     f32x16 D2[NJB];
     const auto rRes = __builtin_amdgcn_make_buffer_rsrc((void*)p.resid, 0, p.resid ? p.x_bytes : 0, 0x00020000);   // null: zeros; rows beyond R: zeros
     dig_u32x4 rq[4];                                                   // residual chunks of one group (2 column blocks) in flight
@@ -506,6 +594,35 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainParams p) {
     asm volatile("" : "+v"(tid2));                                    // re-derive the lane's row here: kept live across the loop it would be spilled
     const int row = m0 + pair * 32 + (tid2 & 31), hi2 = (tid2 >> 5) & 1;
     if (row < p.R) {
+      const bool lno = LN && p.nln_out != nullptr;
+      float s1 = 0.f, s2 = 0.f;
+      if (lno) {
+        // LayerNorm of the finished rows (the next block's norm1), taken over the bf16 values that are stored -- what a separate LayerNorm
+        // launch would read back: round the accumulators in place, sum and sum of squares by v_dot2 on the packed pairs
+        const dig_bf16x2 ones = __builtin_bit_cast(dig_bf16x2, 0x3F803F80u);
+#pragma unroll
+        for (int jb = 0; jb < NJB; ++jb)
+#pragma unroll
+          for (int g = 0; g < 8; ++g) {
+            const unsigned u = pack_bf2(D2[jb][2 * g], D2[jb][2 * g + 1]);
+            const dig_bf16x2 pr = __builtin_bit_cast(dig_bf16x2, u);
+            s1 = __builtin_amdgcn_fdot2_f32_bf16(pr, ones, s1, false);
+            s2 = __builtin_amdgcn_fdot2_f32_bf16(pr, pr, s2, false);
+            D2[jb][2 * g] = __uint_as_float(u << 16);
+            D2[jb][2 * g + 1] = __uint_as_float(u & 0xffff0000u);
+          }
+      }
+      auto store_block = [&](bf16_t* dst, unsigned (&Pk)[4][2]) {      // one 32-column block of the lane's row: 16 contiguous columns per lane
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const auto r0 = __builtin_amdgcn_permlane32_swap(Pk[0][k], Pk[2][k], false, false);
+          Pk[0][k] = r0[0]; Pk[2][k] = r0[1];
+          const auto r1 = __builtin_amdgcn_permlane32_swap(Pk[1][k], Pk[3][k], false, false);
+          Pk[1][k] = r1[0]; Pk[3][k] = r1[1];
+        }
+        *reinterpret_cast<uint4*>(dst) = make_uint4(Pk[0][0], Pk[0][1], Pk[2][0], Pk[2][1]);
+        *reinterpret_cast<uint4*>(dst + 8) = make_uint4(Pk[1][0], Pk[1][1], Pk[3][0], Pk[3][1]);
+      };
       bf16_t* orow = p.out + (size_t)row * KD + hi2 * 16;
 #pragma unroll
       for (int jb = 0; jb < NJB; ++jb) {
@@ -515,23 +632,39 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainParams p) {
           Pk[g][0] = pack_bf2(D2[jb][g * 4], D2[jb][g * 4 + 1]);
           Pk[g][1] = pack_bf2(D2[jb][g * 4 + 2], D2[jb][g * 4 + 3]);
         }
+        store_block(orow + jb * 32, Pk);
+      }
+      if (lno) {
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        const float mean = s1 * (1.0f / KD);
+        const float rs = rsqrtf(fmaxf(s2 * (1.0f / KD) - mean * mean, 0.f) + p.ln_eps);
+        const float* ng = reinterpret_cast<const float*>(smem + B1S_OFF) + p.F + 3 * KD + 4 * hi2;
+        bf16_t* nrow = p.nln_out + (size_t)row * KD + hi2 * 16;
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          const auto r0 = __builtin_amdgcn_permlane32_swap(Pk[0][k], Pk[2][k], false, false);
-          Pk[0][k] = r0[0]; Pk[2][k] = r0[1];
-          const auto r1 = __builtin_amdgcn_permlane32_swap(Pk[1][k], Pk[3][k], false, false);
-          Pk[1][k] = r1[0]; Pk[3][k] = r1[1];
+        for (int jb = 0; jb < NJB; ++jb) {
+          unsigned Pk[4][2];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 g4 = *reinterpret_cast<const f32x4*>(ng + jb * 32 + g * 8);
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(ng + KD + jb * 32 + g * 8);
+            float y[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = fmaf(D2[jb][g * 4 + e] - mean, rs * g4[e], b4[e]);
+            Pk[g][0] = pack_bf2(y[0], y[1]);
+            Pk[g][1] = pack_bf2(y[2], y[3]);
+          }
+          store_block(nrow + jb * 32, Pk);
         }
-        *reinterpret_cast<uint4*>(orow + jb * 32) = make_uint4(Pk[0][0], Pk[0][1], Pk[2][0], Pk[2][1]);
-        *reinterpret_cast<uint4*>(orow + jb * 32 + 8) = make_uint4(Pk[1][0], Pk[1][1], Pk[3][0], Pk[3][1]);
+        if (p.nln_mean && hi2 == 0) { p.nln_mean[row] = mean; p.nln_rstd[row] = rs; }
       }
     }
   }
 }
 
-template <int MODE>
+template <int MODE, bool LN = false>
 int launch_chain(const ChainParams& p, hipStream_t stream) {
-  const int lds = X_OFF + (MODE == 0 ? (p.F + KD) * 4 : (MODE == 1 ? SLOT + (p.F + KD) * 4 : 2 * SLOT));
+  const int lds = X_OFF + (MODE == 0 ? (p.F + KD) * 4 : (MODE == 1 ? SLOT + (p.F + KD) * 4 : 2 * SLOT)) + (LN ? 4 * KD * 4 : 0);
 #ifdef DIG_CHAIN_LDS_ALL
   const int lds_launch = 160 * 1024;                                   // (lab build: stamps live in the spare LDS)
 #else
@@ -540,12 +673,19 @@ int launch_chain(const ChainParams& p, hipStream_t stream) {
   if (lds > 160 * 1024) return DIG_ERR_UNSUPPORTED;
   static int attr_lds = 0;
   if (lds_launch > attr_lds) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_chain_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_launch) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_chain_kernel<MODE, LN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_launch) != hipSuccess)
       return DIG_ERR_LAUNCH;
     attr_lds = lds_launch;
   }
-  hipLaunchKernelGGL((mlp_chain_kernel<MODE>), dim3((p.R + BM - 1) / BM), dim3(512), lds_launch, stream, p);
+  hipLaunchKernelGGL((mlp_chain_kernel<MODE, LN>), dim3((p.R + BM - 1) / BM), dim3(512), lds_launch, stream, p);
   return dig_check_launch();
+}
+
+void no_layernorm(ChainParams& p) {
+  p.ln_g = p.ln_b = p.nln_g = p.nln_b = nullptr;
+  p.ln_out = p.nln_out = nullptr;
+  p.ln_mean = p.ln_rstd = p.nln_mean = p.nln_rstd = nullptr;
+  p.ln_eps = 0.f;
 }
 
 int check_common(const void* x, const void* b1, const void* b2, const void* out, int R, int D, int F) {
@@ -574,7 +714,34 @@ extern "C" int dig_mlp_chain_fwd(const void* x, const void* w1, const float* b1,
   p.resid = (const bf16_t*)resid; p.out = (bf16_t*)out; p.side0 = (bf16_t*)act_out; p.side1 = (bf16_t*)pre_out; p.colsum = nullptr;
   p.R = R; p.F = F;
   p.x_bytes = (unsigned)((size_t)R * D * 2); p.w_bytes = (unsigned)((size_t)F * D * 2); p.side_bytes = (unsigned)((size_t)R * F * 2);
+  no_layernorm(p);
   return pre_out ? launch_chain<1>(p, stream) : launch_chain<0>(p, stream);
+}
+
+// The same with the block's LayerNorms fused at both ends: x holds the RAW residual rows (it is also the residual that is added back);
+// they are normalised with (ln_g, ln_b) on the way in -- ln_out / ln_mean / ln_rstd receive what the backward keeps, or are null --
+// and, when nln_g is given, the output rows are normalised again with (nln_g, nln_b) into nln_out (+ nln_mean / nln_rstd, or null).
+extern "C" int dig_mlp_chain_fwd_ln(const void* x, const float* ln_g, const float* ln_b, float eps, void* ln_out, float* ln_mean,
+                                    float* ln_rstd, const void* w1, const float* b1, const void* w2, const float* b2, void* out,
+                                    void* pre_out, void* act_out, const float* nln_g, const float* nln_b, void* nln_out, float* nln_mean,
+                                    float* nln_rstd, int R, int D, int F, hipStream_t stream) {
+  const int rc = check_common(x, w1, w2, out, R, D, F);
+  if (rc != DIG_OK) return rc;
+  if (!ln_g || !ln_b || (nln_g == nullptr) != (nln_b == nullptr) || (nln_g == nullptr) != (nln_out == nullptr)) return DIG_ERR_ARG;
+  if ((ln_mean == nullptr) != (ln_rstd == nullptr) || (nln_mean == nullptr) != (nln_rstd == nullptr)) return DIG_ERR_ARG;
+  if ((pre_out == nullptr) != (act_out == nullptr)) return DIG_ERR_ARG;
+  if (F > 2048) return DIG_ERR_UNSUPPORTED;                                         // (LDS: the LayerNorm vectors sit behind b1 / b2)
+  if ((b1 && !aligned16(b1)) || (b2 && !aligned16(b2)) || (pre_out && !aligned16(pre_out)) || (act_out && !aligned16(act_out)) ||
+      (ln_out && !aligned16(ln_out)) || (nln_out && !aligned16(nln_out)))
+    return DIG_ERR_ALIGN;
+  ChainParams p;
+  p.X = (const bf16_t*)x; p.B1 = (const bf16_t*)w1; p.B2 = (const bf16_t*)w2; p.bias1 = b1; p.bias2 = b2;
+  p.resid = (const bf16_t*)x; p.out = (bf16_t*)out; p.side0 = (bf16_t*)act_out; p.side1 = (bf16_t*)pre_out; p.colsum = nullptr;
+  p.R = R; p.F = F;
+  p.x_bytes = (unsigned)((size_t)R * D * 2); p.w_bytes = (unsigned)((size_t)F * D * 2); p.side_bytes = (unsigned)((size_t)R * F * 2);
+  p.ln_g = ln_g; p.ln_b = ln_b; p.ln_out = (bf16_t*)ln_out; p.ln_mean = ln_mean; p.ln_rstd = ln_rstd;
+  p.nln_g = nln_g; p.nln_b = nln_b; p.nln_out = (bf16_t*)nln_out; p.nln_mean = nln_mean; p.nln_rstd = nln_rstd; p.ln_eps = eps;
+  return pre_out ? launch_chain<1, true>(p, stream) : launch_chain<0, true>(p, stream);
 }
 
 extern "C" int dig_mlp_chain_bwd(const void* dy, const void* w2t, const void* pre, const void* w1t, void* dpre_out, void* dx_out,
@@ -588,6 +755,7 @@ extern "C" int dig_mlp_chain_bwd(const void* dy, const void* w2t, const void* pr
   p.resid = nullptr; p.out = (bf16_t*)dx_out; p.side0 = (bf16_t*)dpre_out; p.side1 = (bf16_t*)pre; p.colsum = colsum_partials;
   p.R = R; p.F = F;
   p.x_bytes = (unsigned)((size_t)R * D * 2); p.w_bytes = (unsigned)((size_t)F * D * 2); p.side_bytes = (unsigned)((size_t)R * F * 2);
+  no_layernorm(p);
   return launch_chain<2>(p, stream);
 }
 

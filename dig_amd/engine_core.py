@@ -14,8 +14,7 @@ import torch
 from . import ops
 
 BF16, F32 = torch.bfloat16, torch.float32
-FWD_FLIP = os.environ.get("DIG_FWD_FLIP", "1") == "1"               # online forward on the high-priority stream, momentum branch on the caller's
-#                                                                     (23.76 -> 23.58 ms per step, two A/B pairs on one box)
+FWD_MODE = os.environ.get("DIG_FWD_MODE", "flip")                   # two-stream plan of the forward (single process): "flip" (default) or "side"
 BATCH_REDUCE = os.environ.get("DIG_BATCH_REDUCE", "0") == "1"       # an encoder block's eleven reduction launches as two: fewer launches,
 #                                                                     0.1-0.15 ms SLOWER per step -> opt-in
 FUSED_QV_BIAS_SUMS = os.environ.get("DIG_FUSED_QV_BIAS", "1") != "0"
@@ -77,6 +76,7 @@ def _weights(model):
 
 class _Step:
     def __init__(self, model):
+        self._keep = []                             # tensors the side stream still reads (see _on_side)
         self.m = model
         self.comm = model.comm or LOCAL
 
@@ -93,11 +93,27 @@ class _Step:
         saved = []
         scale = (D // H) ** -0.5
         chain = ops.mlp_chain_supported(D, M.F) and bool(ops.MLP_CHAIN_MASK & (2 if save else 1))
-        for blk in ew.blocks:
-            ln1, mu1, rs1 = ops.layernorm_fwd(x, blk["norm1.weight"], blk["norm1.bias"], M.ln_eps)
+        chain_ln = chain and ops.MLP_CHAIN_LN and M.F <= 2048
+        nxt = None                                                      # (ln1, mean, rstd) of this block, made by the previous block's launch
+        for i, blk in enumerate(ew.blocks):
+            ln1, mu1, rs1 = nxt if nxt is not None else ops.layernorm_fwd(x, blk["norm1.weight"], blk["norm1.bias"], M.ln_eps)
+            nxt = None
             qkv = ops.linear_fwd(ln1, blk["attn.qkv.weight"], bias=blk["qkv_bias"], alpha=scale, alpha_cols=D)
             ctx, lse = ops.attn_fwd(qkv, 2 * B, H, D)
             x_mid = ops.linear_fwd(ctx, blk["attn.proj.weight"], bias=blk["attn.proj.bias"], resid=x)
+            if chain_ln:
+                # norm2 -> fc1 -> GELU -> fc2 (+ residual) -> the NEXT block's norm1 in one launch: between two blocks the residual stream
+                # is written once and no LayerNorm launch remains (the first block's norm1 is the only stand-alone one)
+                nb = ew.blocks[i + 1] if i + 1 < len(ew.blocks) else None
+                r = ops.mlp_chain_fwd_ln(x_mid, blk["norm2.weight"], blk["norm2.bias"], M.ln_eps, blk["mlp.fc1.weight"], blk["mlp.fc1.bias"],
+                                         blk["mlp.fc2.weight"], blk["mlp.fc2.bias"], nb["norm1.weight"] if nb else None,
+                                         nb["norm1.bias"] if nb else None, save=save)
+                if save:
+                    saved.append((x, ln1, mu1, rs1, qkv, ctx, lse, x_mid, r["ln"], r["ln_mean"], r["ln_rstd"], r["pre"], r["act"]))
+                if nb is not None:
+                    nxt = (r["nln"], r["nln_mean"], r["nln_rstd"])
+                x = r["out"]
+                continue
             ln2, mu2, rs2 = ops.layernorm_fwd(x_mid, blk["norm2.weight"], blk["norm2.bias"], M.ln_eps)
             if chain:
                 # fc1 -> GELU -> fc2 (+ residual) in one launch: the [R, F] hidden tensor is never a GEMM operand in HBM; the online
@@ -139,8 +155,9 @@ class _Step:
         side.wait_stream(main)
         with torch.cuda.stream(side):
             fn()
-        for t in tensors:
-            t.record_stream(side)
+        # the side stream reads tensors of the caller's stream's pool: instead of record_stream (an event on the side stream per block when
+        # it is released: ~120 per backward, 0.5+ ms of queue time) they are kept alive until backward() has joined the two streams
+        self._keep.extend(tensors)
 
     def _grad_ready(self, dev, key):
         """Bucket `key` is final once both streams pass this point.  With a process group the all-reduce is issued from the
@@ -344,86 +361,106 @@ class _Step:
         main = torch.cuda.current_stream(dev)
         side = M._fwd_stream(dev) if getattr(M, "overlap_streams", True) else main
         dist_mode = comm.world > 1 or getattr(comm, "world_override", False)
-        flip = FWD_FLIP and not dist_mode and side is not main
-        if flip:
-            # The big forward kernels own the whole chip one at a time (persistent GEMM tiles, the fused MLP chain), so the two branches
-            # serialise kernel by kernel and the question is only WHO goes first.  The online branch ends in ~60 small head kernels that
-            # leave the chip mostly idle: it runs on the HIGH-priority stream here (the momentum branch on the caller's), finishes its
-            # encoder first, and its heads run inside the momentum encoder's time instead of behind it.
+        mode = FWD_MODE if (not dist_mode and side is not main) else "side"
+
+        def online_heads(enc):
+            masked2, self.saved_pix = self.mlp_forward(enc[:B * N], "pix_projector", "online", True)
+            pooled = torch.empty((2 * B * nw, D), device=dev, dtype=BF16)
+            ops.window_pool_fwd(masked2, pooled[:B * nw], B, M.gh, M.gw, nw, D)
+            ops.window_pool_fwd(enc[B * N:], pooled[B * nw:], B, M.gh, M.gw, nw, D)
+            q, self.saved_proj = self.mlp_forward(pooled, "encoder_projection_layer", "online", True)
+            q, self.saved_pred = self.mlp_forward(q, "predictor", "online", True)
+            return q
+
+        def momentum_branch(heads=True):
+            ops.ema_update(M._flat["momentum"], M._flat["online"], M.shadow("momentum"), M.n_ema, m)
+            enc_m, _ = self.encoder_forward(ew_mo, images, aug, mask_u8, False)
+            k = None
+            if heads:
+                masked_m, _ = self.mlp_forward(enc_m[:B * N], "pix_projector_m", "momentum", False)
+                pooled_m = torch.empty((2 * B * nw, D), device=dev, dtype=BF16)
+                ops.window_pool_fwd(masked_m, pooled_m[:B * nw], B, M.gh, M.gw, nw, D)
+                ops.window_pool_fwd(enc_m[B * N:], pooled_m[B * nw:], B, M.gh, M.gw, nw, D)
+                k, _ = self.mlp_forward(pooled_m, "momentum_projection_layer", "momentum", False)
+            self.wT = None
+            if torch.is_grad_enabled() and ops.mlp_chain_supported(D, M.F) and (ops.MLP_CHAIN_MASK & 4):
+                self.wT = self.mlp_weight_transposes(ew_on)
+            return enc_m, k
+
+        def decoder():
+            # SimMIM decoder on the masked tokens (:560-570; the reference decodes all rows then selects): view 0 only, or both views
+            per = M._mask_count(mask_u8, B)
+            Mrows = mim_views * B * per
+            Mp = (Mrows + 63) // 64 * 64
+            idx, cnt = ops.mask_to_index(mask_u8[:mim_views * B], per)       # token rows b*N + n of enc, views stacked as the encoder stacks them
+            M._last_mask_counts, M._last_idx, M._last_images = cnt, idx[:B], images
+            # view 1's MIM target is cut from the ORIGINAL images with view 1's mask (engine_for_pretraining_moco.py:106-108 indexes
+            # `images_patch`, built from `images`, for every view), so its target indices are relative to `images`
+            # (mask_to_index zero-fills the slots of a sample with fewer masked tokens than `per`; relative to `images` those would be -B*N:
+            #  clamp, so that the target gather of a ragged mask -- reported one step late -- stays inside the image buffer)
+            M._last_idx_views = [idx[:B]] + ([(idx[B:] - B * N).clamp_min_(0)] if mim_views == 2 else [])
+            self.idx, self.Mrows, self.Mp, self.per, self.mim_views = idx, Mrows, Mp, per, mim_views
+            w16, f32 = M._w("online"), M._f32
+            gath = ops.gather_rows(self.enc, idx, Mrows, Mp)
+            h0 = ops.linear_fwd(gath, w16["pix_decoder.0.weight"])
+            h1 = ops.linear_fwd(h0, w16["pix_decoder.1.weight"])
+            h2, mu, rs = ops.layernorm_fwd(h1, f32["pix_decoder.2.weight"], f32["pix_decoder.2.bias"], M.ln_eps, gelu=True)
+            pred = torch.empty((Mp, 64), device=dev, dtype=F32)
+            C = M.dec_classes
+            ops.gemm(h2, w16["pix_decoder.4.weight"], Mp, C, M.dec_dim, out=pred, out_kind=ops.OUT_F32, bias=f32["pix_decoder.4.bias"], ldc=64)
+            self.saved_dec = (gath, h0, h1, h2, mu, rs)
+            return pred[:Mrows, :C].reshape(mim_views * B, per, C), (pred, idx, cnt) + tuple(M._last_idx_views)
+
+        vis_out = None
+        if mode == "flip":
+            # The big forward kernels own the whole chip one at a time (persistent GEMM tiles and the fused MLP chain: one workgroup per CU
+            # with all of its LDS / registers), so the two branches serialise kernel by kernel whatever streams they are on, and the question
+            # is only WHO goes first: the online branch on the HIGH-priority stream, the momentum branch on the caller's (23.76 -> 23.58 ms).
+            # Workgroup dispatch is strictly by priority: the momentum branch's first kernel starts when the online branch is ~0.5 ms into its
+            # ~60 head kernels (rocprofv3 timeline).  Measured alternatives, same box: both encoders on one stream with the online heads and
+            # the SimMIM decoder on the other at higher (24.32 ms), equal (24.33) or lower (24.21) priority against 23.74 -- a small kernel
+            # that holds a few CUs when a persistent one-workgroup-per-CU kernel starts delays that whole kernel by its own length, 72 times.
             hi_st = M._side_stream(dev)
             hi_st.wait_stream(main)
             with torch.cuda.stream(hi_st):
                 enc, self.saved_enc = self.encoder_forward(ew_on, images, aug, mask_u8, True)
                 self.enc = enc
-                masked2, self.saved_pix = self.mlp_forward(enc[:B * N], "pix_projector", "online", True)
-                pooled = torch.empty((2 * B * nw, D), device=dev, dtype=BF16)
-                ops.window_pool_fwd(masked2, pooled[:B * nw], B, M.gh, M.gw, nw, D)
-                ops.window_pool_fwd(enc[B * N:], pooled[B * nw:], B, M.gh, M.gw, nw, D)
-                qs, self.saved_proj = self.mlp_forward(pooled, "encoder_projection_layer", "online", True)
-                qs, self.saved_pred = self.mlp_forward(qs, "predictor", "online", True)
-            ops.ema_update(M._flat["momentum"], M._flat["online"], M.shadow("momentum"), M.n_ema, m)
-            enc_m, _ = self.encoder_forward(ew_mo, images, aug, mask_u8, False)
-            masked_m, _ = self.mlp_forward(enc_m[:B * N], "pix_projector_m", "momentum", False)
-            pooled_m = torch.empty((2 * B * nw, D), device=dev, dtype=BF16)
-            ops.window_pool_fwd(masked_m, pooled_m[:B * nw], B, M.gh, M.gw, nw, D)
-            ops.window_pool_fwd(enc_m[B * N:], pooled_m[B * nw:], B, M.gh, M.gw, nw, D)
-            ks, _ = self.mlp_forward(pooled_m, "momentum_projection_layer", "momentum", False)
-            del enc_m, masked_m, pooled_m
-            self.wT = None
-            if torch.is_grad_enabled() and ops.mlp_chain_supported(D, M.F) and (ops.MLP_CHAIN_MASK & 4):
-                self.wT = self.mlp_weight_transposes(ew_on)
-            # every tensor the online branch made lives in the high-priority stream's pool and is read on the caller's stream from here
-            # on (decoder, backward).  No record_stream bookkeeping is needed: that pool hands memory out again only to the NEXT forward's
-            # online branch, which starts with hi_st.wait_stream(main), i.e. after everything this step queues on the caller's stream.
+                qs = online_heads(enc)
+            enc_m, ks = momentum_branch()
+            del enc_m
             main.wait_stream(hi_st)
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-          if not flip:
-              ops.ema_update(M._flat["momentum"], M._flat["online"], M.shadow("momentum"), M.n_ema, m)
-              enc_m, _ = self.encoder_forward(ew_mo, images, aug, mask_u8, False)
-              if not dist_mode:
-                  masked_m, _ = self.mlp_forward(enc_m[:B * N], "pix_projector_m", "momentum", False)
-                  pooled_m = torch.empty((2 * B * nw, D), device=dev, dtype=BF16)
-                  ops.window_pool_fwd(masked_m, pooled_m[:B * nw], B, M.gh, M.gw, nw, D)
-                  ops.window_pool_fwd(enc_m[B * N:], pooled_m[B * nw:], B, M.gh, M.gw, nw, D)
-                  ks, _ = self.mlp_forward(pooled_m, "momentum_projection_layer", "momentum", False)
-                  del enc_m, masked_m, pooled_m
-              self.wT = None
-              if torch.is_grad_enabled() and ops.mlp_chain_supported(D, M.F) and (ops.MLP_CHAIN_MASK & 4):
-                  self.wT = self.mlp_weight_transposes(ew_on)             # (both modes join the side stream before the backward can start)
-        # ---- online branch
-        if not flip:
+        else:
+            # momentum branch (no grad) on a second HIP stream: it depends only on the pre-step online weights (fp32 arena, read-only
+            # here) and the inputs.  EMA with the current online weights comes first (:526).
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                enc_m, ks = momentum_branch(heads=not dist_mode)
             enc, self.saved_enc = self.encoder_forward(ew_on, images, aug, mask_u8, True)
             self.enc = enc
-        if flip:
-            pass
-        elif not dist_mode:
-            masked2, self.saved_pix = self.mlp_forward(enc[:B * N], "pix_projector", "online", True)
-            pooled = torch.empty((2 * B * nw, D), device=dev, dtype=BF16)
-            ops.window_pool_fwd(masked2, pooled[:B * nw], B, M.gh, M.gw, nw, D)
-            ops.window_pool_fwd(enc[B * N:], pooled[B * nw:], B, M.gh, M.gw, nw, D)
-            qs, self.saved_proj = self.mlp_forward(pooled, "encoder_projection_layer", "online", True)
-            qs, self.saved_pred = self.mlp_forward(qs, "predictor", "online", True)
-            main.wait_stream(side)
-            ks.record_stream(main)
-        else:
-            # with a process group the heads of both branches run together on this stream, after both encoders: one BatchNorm-
-            # statistics all-reduce per layer PAIR, issued in program order (no collective of the momentum branch in front of the
-            # online branch's first one on RCCL's in-order stream)
-            main.wait_stream(side)
-            enc_m.record_stream(main)
-            (masked2, self.saved_pix), (masked_m, _) = self.mlp_forward_pair(enc[:B * N], "pix_projector", "online", True,
-                                                                              enc_m[:B * N], "pix_projector_m", "momentum", False)
-            pooled = torch.empty((2 * B * nw, D), device=dev, dtype=BF16)
-            pooled_m = torch.empty((2 * B * nw, D), device=dev, dtype=BF16)
-            ops.window_pool_fwd(masked2, pooled[:B * nw], B, M.gh, M.gw, nw, D)
-            ops.window_pool_fwd(enc[B * N:], pooled[B * nw:], B, M.gh, M.gw, nw, D)
-            ops.window_pool_fwd(masked_m, pooled_m[:B * nw], B, M.gh, M.gw, nw, D)
-            ops.window_pool_fwd(enc_m[B * N:], pooled_m[B * nw:], B, M.gh, M.gw, nw, D)
-            (qs, self.saved_proj), (ks, _) = self.mlp_forward_pair(pooled, "encoder_projection_layer", "online", True,
-                                                                    pooled_m, "momentum_projection_layer", "momentum", False)
-            qs, self.saved_pred = self.mlp_forward(qs, "predictor", "online", True)
-            del enc_m, masked_m, pooled_m
+            if not dist_mode:
+                qs = online_heads(enc)
+                main.wait_stream(side)
+                if side is not main:
+                    ks.record_stream(main)
+                del enc_m
+            else:
+                # with a process group the heads of both branches run together on this stream, after both encoders: one BatchNorm-
+                # statistics all-reduce per layer PAIR, issued in program order (no collective of the momentum branch in front of the
+                # online branch's first one on RCCL's in-order stream)
+                main.wait_stream(side)
+                enc_m.record_stream(main)
+                (masked2, self.saved_pix), (masked_m, _) = self.mlp_forward_pair(enc[:B * N], "pix_projector", "online", True,
+                                                                                  enc_m[:B * N], "pix_projector_m", "momentum", False)
+                pooled = torch.empty((2 * B * nw, D), device=dev, dtype=BF16)
+                pooled_m = torch.empty((2 * B * nw, D), device=dev, dtype=BF16)
+                ops.window_pool_fwd(masked2, pooled[:B * nw], B, M.gh, M.gw, nw, D)
+                ops.window_pool_fwd(enc[B * N:], pooled[B * nw:], B, M.gh, M.gw, nw, D)
+                ops.window_pool_fwd(masked_m, pooled_m[:B * nw], B, M.gh, M.gw, nw, D)
+                ops.window_pool_fwd(enc_m[B * N:], pooled_m[B * nw:], B, M.gh, M.gw, nw, D)
+                (qs, self.saved_proj), (ks, _) = self.mlp_forward_pair(pooled, "encoder_projection_layer", "online", True,
+                                                                        pooled_m, "momentum_projection_layer", "momentum", False)
+                qs, self.saved_pred = self.mlp_forward(qs, "predictor", "online", True)
+                del enc_m, masked_m, pooled_m
         M._flat["bn_count"] += 1                                            # all 14 BatchNorm layers ran once
         # ---- InfoNCE (:444-461): q1 vs gathered k2, q2 vs gathered k1, labels = arange + n*rank
         n = B * nw                                                          # rows of q1 / q2
@@ -452,28 +489,8 @@ class _Step:
             ops.sgemm(logits, kk, self.dqn[half * n:(half + 1) * n], n, dim, mk, True, 1.0 / M.T)
         contra = (stats[0, 0] + stats[1, 0]) * (2.0 * M.T / n)
         accs = stats[:, 1:].reshape(4) * (100.0 / n)                        # q1_acc1, q1_acc5, q2_acc1, q2_acc5
-        # ---- SimMIM decoder on the masked tokens of view 0 only (:560-570; the reference decodes all rows then selects)
-        per = M._mask_count(mask_u8, B)
-        Mrows = mim_views * B * per
-        Mp = (Mrows + 63) // 64 * 64
-        idx, cnt = ops.mask_to_index(mask_u8[:mim_views * B], per)           # token rows b*N + n of enc, views stacked as the encoder stacks them
-        M._last_mask_counts, M._last_idx, M._last_images = cnt, idx[:B], images
-        # view 1's MIM target is cut from the ORIGINAL images with view 1's mask (engine_for_pretraining_moco.py:106-108 indexes
-        # `images_patch`, built from `images`, for every view), so its target indices are relative to `images`
-        # (mask_to_index zero-fills the slots of a sample with fewer masked tokens than `per`; relative to `images` those would be -B*N:
-        #  clamp, so that the target gather of a ragged mask -- reported one step late -- stays inside the image buffer)
-        M._last_idx_views = [idx[:B]] + ([(idx[B:] - B * N).clamp_min_(0)] if mim_views == 2 else [])
-        self.idx, self.Mrows, self.Mp, self.per, self.mim_views = idx, Mrows, Mp, per, mim_views
-        w16, f32 = M._w("online"), M._f32
-        gath = ops.gather_rows(enc, idx, Mrows, Mp)
-        h0 = ops.linear_fwd(gath, w16["pix_decoder.0.weight"])
-        h1 = ops.linear_fwd(h0, w16["pix_decoder.1.weight"])
-        h2, mu, rs = ops.layernorm_fwd(h1, f32["pix_decoder.2.weight"], f32["pix_decoder.2.bias"], M.ln_eps, gelu=True)
-        pred = torch.empty((Mp, 64), device=dev, dtype=F32)
-        C = M.dec_classes
-        ops.gemm(h2, w16["pix_decoder.4.weight"], Mp, C, M.dec_dim, out=pred, out_kind=ops.OUT_F32, bias=f32["pix_decoder.4.bias"], ldc=64)
-        self.saved_dec = (gath, h0, h1, h2, mu, rs)
-        vis_out = pred[:Mrows, :C].reshape(mim_views * B, per, C)
+        if vis_out is None:
+            vis_out, _ = decoder()
         return contra, accs, vis_out
 
     # ------------------------------------------------------------------ full backward
@@ -536,6 +553,7 @@ class _Step:
         main, side = self._streams(dev)
         if side is not main:
             main.wait_stream(side)                  # every gradient is final on the caller's stream (grad norm / AdamW follow)
+        self._keep.clear()                          # (blocks go back to the caller's stream's pool: its later work is ordered behind the join)
         self.saved_enc = self.saved_pix = self.saved_proj = self.saved_pred = self.saved_dec = self.wT = None
 
 

@@ -83,6 +83,8 @@ MLP_CHAIN = os.environ.get("DIG_MLP_CHAIN", "1") != "0"      # fused fc1 -> GELU
 # ms per step with both branches fused), in the backward the weight-gradient stream loses more than the fused data gradient gains
 # (25.73 ms with bit 2 alone, 24.87 with all three; one box, 40 timed steps each) -- default 3.
 MLP_CHAIN_MASK = int(os.environ.get("DIG_MLP_CHAIN_MASK", "3"))
+# the block's norm2 and the next block's norm1 inside the forward chain launch (dig_mlp_chain_fwd_ln)
+MLP_CHAIN_LN = os.environ.get("DIG_MLP_CHAIN_LN", "1") != "0"
 
 
 def mlp_chain_supported(D, F):
@@ -100,6 +102,32 @@ def mlp_chain_fwd(x, w1, b1, w2, b2, resid, save=False):
     L.call("dig_mlp_chain_fwd", L.ptr(x), L.ptr(w1), L.ptr(b1), L.ptr(w2), L.ptr(b2), L.ptr(resid), L.ptr(out), L.ptr(pre), L.ptr(act),
            rows, D, Fh, L.stream())
     return (out, pre, act) if save else out
+
+
+def mlp_chain_fwd_ln(x, ln_g, ln_b, eps, w1, b1, w2, b2, nln_g=None, nln_b=None, save=False):
+    """The second half of a transformer block with its LayerNorms in one launch: out = x + b2 + gelu(LN(x; ln_g, ln_b) w1^T + b1) w2^T and,
+    when nln_g is given, the next block's norm1 of `out`.  Returns a dict: out; nln / nln_mean / nln_rstd (when nln_g is given; the
+    statistics only with save=True); with save=True also ln, ln_mean, ln_rstd, pre, act -- what the backward reads."""
+    rows, D = x.shape
+    Fh = w1.shape[0]
+    dev = x.device
+    r = {"out": torch.empty((rows, D), device=dev, dtype=BF16)}
+    for k in ("ln", "pre", "act", "nln"):
+        r[k] = None
+    for k in ("ln_mean", "ln_rstd", "nln_mean", "nln_rstd"):
+        r[k] = None
+    if save:
+        r["ln"] = torch.empty((rows, D), device=dev, dtype=BF16)
+        r["ln_mean"], r["ln_rstd"] = torch.empty(rows, device=dev, dtype=F32), torch.empty(rows, device=dev, dtype=F32)
+        r["pre"], r["act"] = torch.empty((rows, Fh), device=dev, dtype=BF16), torch.empty((rows, Fh), device=dev, dtype=BF16)
+    if nln_g is not None:
+        r["nln"] = torch.empty((rows, D), device=dev, dtype=BF16)
+        if save:
+            r["nln_mean"], r["nln_rstd"] = torch.empty(rows, device=dev, dtype=F32), torch.empty(rows, device=dev, dtype=F32)
+    L.call("dig_mlp_chain_fwd_ln", L.ptr(x), L.ptr(ln_g), L.ptr(ln_b), cf(eps), L.ptr(r["ln"]), L.ptr(r["ln_mean"]), L.ptr(r["ln_rstd"]),
+           L.ptr(w1), L.ptr(b1), L.ptr(w2), L.ptr(b2), L.ptr(r["out"]), L.ptr(r["pre"]), L.ptr(r["act"]), L.ptr(nln_g), L.ptr(nln_b),
+           L.ptr(r["nln"]), L.ptr(r["nln_mean"]), L.ptr(r["nln_rstd"]), rows, D, Fh, L.stream())
+    return r
 
 
 def mlp_chain_bwd(dy, w2t, pre, w1t, colsum=True, out=None):

@@ -82,6 +82,12 @@ int dig_reduce_partials_multi(const dig_reduce_seg_t* segs, int n_segs, hipStrea
  *       K-contiguous copies w2t = w2^T [F,D] and w1t = w1^T [D,F] (dig_transpose_bf16, 1.2 MB each, once per step).
  *       colsum_partials (optional): [dig_mlp_chain_colsum_rows(R)][F] fp32 column sums of dpre_out over blocks of 32 rows -- the
  *       fc1 bias gradient after dig_colsum_partials.
+ *   dig_mlp_chain_fwd_ln: the whole second half of Block.forward (modeling_finetune.py:156-158) with its LayerNorms:
+ *       out = x + b2 + gelu_erf(LN(x; ln_g, ln_b) w1^T + b1) w2^T  and, when nln_g is given, nln_out = LN(out; nln_g, nln_b) -- the NEXT
+ *       block's norm1 (:151), so that no LayerNorm launch and no second pass over the residual stream remain between two blocks.
+ *       x holds the RAW residual rows.  LayerNorm statistics are taken in fp32 over the bf16 values that are (or would be) stored,
+ *       variance as E[x^2] - E[x]^2, eps inside the square root.  ln_out / ln_mean / ln_rstd (normalised rows [R,D] bf16, statistics
+ *       [R] fp32: what the backward keeps) and nln_mean / nln_rstd may be null.  F <= 2048.
  *   Supported widths: dig_mlp_chain_supported(D, F) (D == 384, F a multiple of 128, F <= 6144); R is arbitrary (rows beyond R read as
  *   zero and are not written).  All pointers 16-byte aligned, dense row-major tensors.  Anything else: DIG_ERR_UNSUPPORTED (the
  *   caller runs the two dig_gemm_bf16 launches instead).
@@ -89,6 +95,10 @@ int dig_reduce_partials_multi(const dig_reduce_seg_t* segs, int n_segs, hipStrea
 int dig_mlp_chain_supported(int D, int F);
 int dig_mlp_chain_fwd(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, const void* resid, void* out,
                       void* pre_out, void* act_out, int R, int D, int F, hipStream_t stream);
+int dig_mlp_chain_fwd_ln(const void* x, const float* ln_g, const float* ln_b, float eps, void* ln_out, float* ln_mean, float* ln_rstd,
+                         const void* w1, const float* b1, const void* w2, const float* b2, void* out, void* pre_out, void* act_out,
+                         const float* nln_g, const float* nln_b, void* nln_out, float* nln_mean, float* nln_rstd, int R, int D, int F,
+                         hipStream_t stream);
 int dig_mlp_chain_bwd(const void* dy, const void* w2t, const void* pre, const void* w1t, void* dpre_out, void* dx_out,
                       float* colsum_partials, int R, int D, int F, hipStream_t stream);
 int dig_mlp_chain_colsum_rows(int R);

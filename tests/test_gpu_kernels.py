@@ -359,6 +359,47 @@ def test_grad_reduce_batch_equals_single_launches(dev):
             assert rel(u, v) < 1e-6, i
 
 
+@pytest.mark.parametrize("R,Fh", [(128, 128), (4096, 1536), (333, 256), (65536, 1536), (1000, 2048)])
+def test_mlp_chain_fwd_with_layernorms(dev, R, Fh):
+    """dig_mlp_chain_fwd_ln: norm2 on the way in, the next block's norm1 on the way out (modeling_finetune.py:151,156-158), against fp32 torch
+    and against the three launches it replaces (layernorm_fwd + mlp_chain_fwd + layernorm_fwd); both forms (with / without what the backward
+    keeps), with and without the trailing LayerNorm, ragged row counts."""
+    from dig_amd import ops
+    D, eps = 384, 1e-6
+    cpu_limit(dev, 4.0 * R * D * Fh, limit=3e9)
+    g = torch.Generator(device="cpu").manual_seed(7 * R + Fh)
+    rn = lambda *s: torch.randn(*s, generator=g).to(dev)
+    x = (rn(R, D) * 1.7 + 0.3 * rn(R, 1)).bfloat16()                           # rows with different means
+    w1 = (rn(Fh, D) * 0.06).bfloat16(); b1 = rn(Fh) * 0.5
+    w2 = (rn(D, Fh) * 0.04).bfloat16(); b2 = rn(D) * 0.5
+    g1, be1, g2, be2 = 1 + 0.2 * rn(D), 0.3 * rn(D), 1 + 0.2 * rn(D), 0.3 * rn(D)
+    ln_ref = F.layer_norm(x.float(), (D,), g1, be1, eps)
+    pre_ref = ln_ref.bfloat16().float() @ w1.float().t() + b1
+    out_ref = F.gelu(pre_ref).bfloat16().float() @ w2.float().t() + b2 + x.float()
+    nln_ref = F.layer_norm(out_ref.bfloat16().float(), (D,), g2, be2, eps)
+    r = ops.mlp_chain_fwd_ln(x, g1, be1, eps, w1, b1, w2, b2, g2, be2, save=True)
+    assert rel(r["ln"], ln_ref) < 6e-3 and rel(r["pre"], pre_ref) < 1e-2 and rel(r["act"], F.gelu(pre_ref)) < 1e-2
+    assert rel(r["out"], out_ref) < 1e-2 and rel(r["nln"], nln_ref) < 1.5e-2
+    mu = x.float().mean(1); var = x.float().var(1, unbiased=False)
+    assert (r["ln_mean"] - mu).abs().max().item() < 1e-4 * (1 + mu.abs().max().item()) and rel(r["ln_rstd"], (var + eps).rsqrt()) < 1e-4
+    o = r["out"].float()
+    assert (r["nln_mean"] - o.mean(1)).abs().max().item() < 2e-4 * (1 + o.mean(1).abs().max().item())
+    assert rel(r["nln_rstd"], (o.var(1, unbiased=False) + eps).rsqrt()) < 1e-4
+    # the three launches it replaces
+    ln3, mu3, rs3 = ops.layernorm_fwd(x, g1, be1, eps)
+    out3 = ops.mlp_chain_fwd(ln3, w1, b1, w2, b2, x)
+    nln3, _, _ = ops.layernorm_fwd(out3, g2, be2, eps)
+    assert rel(r["ln"], ln3) < 3e-3 and rel(r["out"], out3) < 4e-3 and rel(r["nln"], nln3) < 6e-3
+    assert rel(r["ln_rstd"], rs3) < 1e-5
+    # the gradient-free form: same arithmetic, nothing kept; and without the trailing LayerNorm
+    q = ops.mlp_chain_fwd_ln(x, g1, be1, eps, w1, b1, w2, b2, g2, be2)
+    assert torch.equal(q["out"], r["out"]) and torch.equal(q["nln"], r["nln"]) and q["ln"] is None and q["pre"] is None
+    q = ops.mlp_chain_fwd_ln(x, g1, be1, eps, w1, b1, w2, b2, save=True)
+    assert torch.equal(q["out"], r["out"]) and torch.equal(q["ln"], r["ln"]) and torch.equal(q["pre"], r["pre"]) and q["nln"] is None
+    q2 = ops.mlp_chain_fwd_ln(x, g1, be1, eps, w1, b1, w2, b2, g2, be2, save=True)
+    assert all(torch.equal(q2[k], r[k]) for k in r if r[k] is not None)               # bit-reproducible
+
+
 @pytest.mark.parametrize("R,Fh", [(128, 128), (256, 1536), (4096, 1536), (333, 256), (65536, 1536), (1000, 2048)])
 def test_mlp_chain_fwd_bwd(dev, R, Fh):
     """dig_mlp_chain_fwd / _bwd (fc1 -> GELU -> fc2 and its data gradient in one launch each) against fp32 torch and against the

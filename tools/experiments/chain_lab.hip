@@ -42,11 +42,17 @@ int main(int argc, char** argv) {
   fill_bf16(pre, (size_t)R * F, 5, 2.f);
   unsigned* tl; hipMalloc(&tl, 8 * 320 * 4); hipMemset(tl, 0, 8 * 320 * 4);
   hipMemcpyToSymbol(HIP_SYMBOL(g_tl), &tl, sizeof(tl));
-  for (int mode = 0; mode < 3; ++mode) {
+  // modes 3 / 4: the forward forms with the LayerNorms fused at both ends (dig_mlp_chain_fwd_ln; 4 = with everything the backward keeps)
+  unsigned short *lno, *nlno; float *lg, *lb, *st;
+  hipMalloc(&lno, (size_t)R * D * 2); hipMalloc(&nlno, (size_t)R * D * 2); hipMalloc(&lg, D * 4); hipMalloc(&lb, D * 4); hipMalloc(&st, (size_t)R * 4 * 4);
+  { std::vector<float> one(D, 1.f); hipMemcpy(lg, one.data(), D * 4, hipMemcpyHostToDevice); hipMemset(lb, 0, D * 4); }
+  for (int mode = 0; mode < 5; ++mode) {
     auto fn = [&]() {
       if (mode == 0) dig_mlp_chain_fwd(x, w1, b1, w2, b2, res, out, nullptr, nullptr, R, D, F, 0);
       else if (mode == 1) dig_mlp_chain_fwd(x, w1, b1, w2, b2, res, out, pre, act, R, D, F, 0);
-      else dig_mlp_chain_bwd(x, w1, pre, w2, dpre, out, cs, R, D, F, 0);
+      else if (mode == 2) dig_mlp_chain_bwd(x, w1, pre, w2, dpre, out, cs, R, D, F, 0);
+      else if (mode == 3) dig_mlp_chain_fwd_ln(x, lg, lb, 1e-6f, nullptr, nullptr, nullptr, w1, b1, w2, b2, out, nullptr, nullptr, lg, lb, nlno, nullptr, nullptr, R, D, F, 0);
+      else dig_mlp_chain_fwd_ln(x, lg, lb, 1e-6f, lno, st, st + R, w1, b1, w2, b2, out, pre, act, lg, lb, nlno, st + 2 * R, st + 3 * R, R, D, F, 0);
     };
     for (int it = 0; it < 200; ++it) fn();
     hipDeviceSynchronize();
