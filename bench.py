@@ -71,7 +71,7 @@ def synth_batches(n, B, device, seed):
 
 
 class GemmProbe:
-    """Times every dig_gemm_bf16 and dig_mlp_chain_fwd launch of one step with HIP events on the launch stream (torch's current stream)."""
+    """Times every dig_gemm_bf16 and dig_mlp_chain_fwd(_ln) launch of one step with HIP events on the launch stream (torch's current stream)."""
 
     def __init__(self):
         from dig_amd import ops
@@ -115,11 +115,27 @@ class GemmProbe:
             self.rec.append(("mlp_chain", 4.0 * R * D * Fh, byt, e0, e1))
             return out
         ops.mlp_chain_fwd = timed_chain
+        orig_ln = self._orig_chain_ln = ops.mlp_chain_fwd_ln
+
+        def timed_chain_ln(x, ln_g, ln_b, eps, w1, b1, w2, b2, nln_g=None, nln_b=None, save=False, resid=None):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = orig_ln(x, ln_g, ln_b, eps, w1, b1, w2, b2, nln_g, nln_b, save=save, resid=resid)
+            e1.record()
+            R, D = x.shape
+            Fh = w1.shape[0]
+            # the fused launch with its LayerNorms: raw rows in, output rows and the next block's normalised rows out, both weight matrices
+            # once; the online form also writes what the reference's autograd keeps (norm2's output, the pre-activation, the GELU output)
+            byt = 2.0 * R * D * (2 + (nln_g is not None)) + 2.0 * 2 * D * Fh + ((2.0 * R * D + 2.0 * 2 * R * Fh) if save else 0.0)
+            self.rec.append(("mlp_chain", 4.0 * R * D * Fh, byt, e0, e1))
+            return out
+        ops.mlp_chain_fwd_ln = timed_chain_ln
         return self
 
     def __exit__(self, *a):
         self.ops.gemm = self._orig
         self.ops.mlp_chain_fwd = self._orig_chain
+        self.ops.mlp_chain_fwd_ln = self._orig_chain_ln
 
     def summary(self):
         torch.cuda.synchronize()

@@ -968,21 +968,57 @@ static void ln_rows_cpu(const bf16_t* x, const float* g, const float* b, float e
   }
 }
 
-int dig_mlp_chain_fwd_ln(const void* x, const float* ln_g, const float* ln_b, float eps, void* ln_out, float* ln_mean, float* ln_rstd,
-                         const void* w1, const float* b1, const void* w2, const float* b2, void* out, void* pre_out, void* act_out,
+int dig_mlp_chain_fwd_ln(const void* x, const void* resid, const float* ln_g, const float* ln_b, float eps, void* ln_out, float* ln_mean,
+                         float* ln_rstd, const void* w1, const float* b1, const void* w2, const float* b2, void* out, void* pre_out, void* act_out,
                          const float* nln_g, const float* nln_b, void* nln_out, float* nln_mean, float* nln_rstd, int R, int D, int F,
                          hipStream_t st) {
   if (!x || !w1 || !w2 || !out || R <= 0) return DIG_ERR_ARG;
   if (!dig_mlp_chain_supported(D, F) || F > 2048) return DIG_ERR_UNSUPPORTED;
-  if (!ln_g || !ln_b || (nln_g == nullptr) != (nln_b == nullptr) || (nln_g == nullptr) != (nln_out == nullptr)) return DIG_ERR_ARG;
+  if ((ln_g == nullptr) != (ln_b == nullptr) || (nln_g == nullptr) != (nln_b == nullptr) || (nln_g == nullptr) != (nln_out == nullptr)) return DIG_ERR_ARG;
   if ((ln_mean == nullptr) != (ln_rstd == nullptr) || (nln_mean == nullptr) != (nln_rstd == nullptr)) return DIG_ERR_ARG;
+  if (!ln_g && (ln_out || ln_mean)) return DIG_ERR_ARG;
   std::vector<bf16_t> tmp;
-  bf16_t* ln = (bf16_t*)ln_out;
-  if (!ln) { tmp.resize((size_t)R * D + 8); ln = (bf16_t*)(((uintptr_t)tmp.data() + 15) & ~(uintptr_t)15); }
-  ln_rows_cpu((const bf16_t*)x, ln_g, ln_b, eps, ln, ln_mean, ln_rstd, R, D);
-  const int rc = dig_mlp_chain_fwd(ln, w1, b1, w2, b2, x, out, pre_out, act_out, R, D, F, st);
+  const bf16_t* ln = (const bf16_t*)x;
+  if (ln_g) {
+    bf16_t* lnw = (bf16_t*)ln_out;
+    if (!lnw) { tmp.resize((size_t)R * D + 8); lnw = (bf16_t*)(((uintptr_t)tmp.data() + 15) & ~(uintptr_t)15); }
+    ln_rows_cpu((const bf16_t*)x, ln_g, ln_b, eps, lnw, ln_mean, ln_rstd, R, D);
+    ln = lnw;
+  }
+  const int rc = dig_mlp_chain_fwd(ln, w1, b1, w2, b2, resid, out, pre_out, act_out, R, D, F, st);
   if (rc != DIG_OK) return rc;
   if (nln_g) ln_rows_cpu((const bf16_t*)out, nln_g, nln_b, eps, (bf16_t*)nln_out, nln_mean, nln_rstd, R, D);
+  return DIG_OK;
+}
+
+int dig_panel_gemm_supported(int J, int K) { return J == 384 && K >= 64 && K % 64 == 0 && K <= 8192; }
+
+int dig_panel_gemm_ln_fwd(const void* a_, const void* w_, const float* bias, const void* resid_, void* out_, const float* ln_g, const float* ln_b,
+                          float eps, void* ln_out, float* ln_mean, float* ln_rstd, int R, int J, int K, hipStream_t) {
+  if (!a_ || !w_ || !out_ || R <= 0) return DIG_ERR_ARG;
+  if (!dig_panel_gemm_supported(J, K)) return DIG_ERR_UNSUPPORTED;
+  if ((ln_g == nullptr) != (ln_b == nullptr) || (ln_g == nullptr) != (ln_out == nullptr) || (ln_mean == nullptr) != (ln_rstd == nullptr)) return DIG_ERR_ARG;
+  if (!ln_g && ln_mean) return DIG_ERR_ARG;
+  const bf16_t* a = (const bf16_t*)a_; const bf16_t* w = (const bf16_t*)w_; const bf16_t* resid = (const bf16_t*)resid_;
+  bf16_t* out = (bf16_t*)out_;
+  std::vector<float> W((size_t)J * K);
+  for (size_t i = 0; i < W.size(); ++i) W[i] = bf2f(w[i]);
+#pragma omp parallel
+  {
+    std::vector<float> ar(K);
+#pragma omp for
+    for (int r = 0; r < R; ++r) {
+      for (int k = 0; k < K; ++k) ar[k] = bf2f(a[(size_t)r * K + k]);
+      for (int j = 0; j < J; ++j) {
+        float acc = 0.f;
+        const float* wr = &W[(size_t)j * K];
+        for (int k = 0; k < K; ++k) acc += wr[k] * ar[k];
+        acc += (bias ? bias[j] : 0.f) + (resid ? bf2f(resid[(size_t)r * J + j]) : 0.f);
+        out[(size_t)r * J + j] = f2bf(acc);
+      }
+    }
+  }
+  if (ln_g) ln_rows_cpu(out, ln_g, ln_b, eps, (bf16_t*)ln_out, ln_mean, ln_rstd, R, J);
   return DIG_OK;
 }
 

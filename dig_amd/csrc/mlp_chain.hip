@@ -718,17 +718,20 @@ extern "C" int dig_mlp_chain_fwd(const void* x, const void* w1, const float* b1,
   return pre_out ? launch_chain<1>(p, stream) : launch_chain<0>(p, stream);
 }
 
-// The same with the block's LayerNorms fused at both ends: x holds the RAW residual rows (it is also the residual that is added back);
-// they are normalised with (ln_g, ln_b) on the way in -- ln_out / ln_mean / ln_rstd receive what the backward keeps, or are null --
-// and, when nln_g is given, the output rows are normalised again with (nln_g, nln_b) into nln_out (+ nln_mean / nln_rstd, or null).
-extern "C" int dig_mlp_chain_fwd_ln(const void* x, const float* ln_g, const float* ln_b, float eps, void* ln_out, float* ln_mean,
+// The same with the block's LayerNorms fused at both ends: x holds the RAW residual rows (resid = x is what is added back); they are
+// normalised with (ln_g, ln_b) on the way in -- ln_out / ln_mean / ln_rstd receive what the backward keeps, or are null -- or, with ln_g
+// null, x holds rows that are normalised already (resid = the raw rows).  When nln_g is given, the output rows are normalised again with
+// (nln_g, nln_b) into nln_out (+ nln_mean / nln_rstd, or null).
+extern "C" int dig_mlp_chain_fwd_ln(const void* x, const void* resid, const float* ln_g, const float* ln_b, float eps, void* ln_out, float* ln_mean,
                                     float* ln_rstd, const void* w1, const float* b1, const void* w2, const float* b2, void* out,
                                     void* pre_out, void* act_out, const float* nln_g, const float* nln_b, void* nln_out, float* nln_mean,
                                     float* nln_rstd, int R, int D, int F, hipStream_t stream) {
   const int rc = check_common(x, w1, w2, out, R, D, F);
   if (rc != DIG_OK) return rc;
-  if (!ln_g || !ln_b || (nln_g == nullptr) != (nln_b == nullptr) || (nln_g == nullptr) != (nln_out == nullptr)) return DIG_ERR_ARG;
+  if ((ln_g == nullptr) != (ln_b == nullptr) || (nln_g == nullptr) != (nln_b == nullptr) || (nln_g == nullptr) != (nln_out == nullptr)) return DIG_ERR_ARG;
   if ((ln_mean == nullptr) != (ln_rstd == nullptr) || (nln_mean == nullptr) != (nln_rstd == nullptr)) return DIG_ERR_ARG;
+  if (!ln_g && (ln_out || ln_mean)) return DIG_ERR_ARG;                              // x is normalised already: nothing to report about it
+  if (resid && !aligned16(resid)) return DIG_ERR_ALIGN;
   if ((pre_out == nullptr) != (act_out == nullptr)) return DIG_ERR_ARG;
   if (F > 2048) return DIG_ERR_UNSUPPORTED;                                         // (LDS: the LayerNorm vectors sit behind b1 / b2)
   if ((b1 && !aligned16(b1)) || (b2 && !aligned16(b2)) || (pre_out && !aligned16(pre_out)) || (act_out && !aligned16(act_out)) ||
@@ -736,7 +739,7 @@ extern "C" int dig_mlp_chain_fwd_ln(const void* x, const float* ln_g, const floa
     return DIG_ERR_ALIGN;
   ChainParams p;
   p.X = (const bf16_t*)x; p.B1 = (const bf16_t*)w1; p.B2 = (const bf16_t*)w2; p.bias1 = b1; p.bias2 = b2;
-  p.resid = (const bf16_t*)x; p.out = (bf16_t*)out; p.side0 = (bf16_t*)act_out; p.side1 = (bf16_t*)pre_out; p.colsum = nullptr;
+  p.resid = (const bf16_t*)resid; p.out = (bf16_t*)out; p.side0 = (bf16_t*)act_out; p.side1 = (bf16_t*)pre_out; p.colsum = nullptr;
   p.R = R; p.F = F;
   p.x_bytes = (unsigned)((size_t)R * D * 2); p.w_bytes = (unsigned)((size_t)F * D * 2); p.side_bytes = (unsigned)((size_t)R * F * 2);
   p.ln_g = ln_g; p.ln_b = ln_b; p.ln_out = (bf16_t*)ln_out; p.ln_mean = ln_mean; p.ln_rstd = ln_rstd;

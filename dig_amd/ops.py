@@ -85,6 +85,8 @@ MLP_CHAIN = os.environ.get("DIG_MLP_CHAIN", "1") != "0"      # fused fc1 -> GELU
 MLP_CHAIN_MASK = int(os.environ.get("DIG_MLP_CHAIN_MASK", "3"))
 # the block's norm2 and the next block's norm1 inside the forward chain launch (dig_mlp_chain_fwd_ln)
 MLP_CHAIN_LN = os.environ.get("DIG_MLP_CHAIN_LN", "1") != "0"
+# attention output projection + residual + norm2 on the row-panel GEMM (dig_panel_gemm_ln_fwd) instead of the tiled GEMM + norm2 inside the chain
+PANEL_PROJ = os.environ.get("DIG_PANEL_PROJ", "0") == "1"
 
 
 def mlp_chain_supported(D, F):
@@ -104,10 +106,31 @@ def mlp_chain_fwd(x, w1, b1, w2, b2, resid, save=False):
     return (out, pre, act) if save else out
 
 
-def mlp_chain_fwd_ln(x, ln_g, ln_b, eps, w1, b1, w2, b2, nln_g=None, nln_b=None, save=False):
+def panel_gemm_supported(J, K):
+    return bool(L.lib().dig_panel_gemm_supported(int(J), int(K)))
+
+
+def panel_linear_ln(a, w, bias, resid, ln_g=None, ln_b=None, eps=1e-6, stats=True):
+    """out = a w^T + bias + resid in one launch of the row-panel GEMM and, with ln_g given, LayerNorm(out) from the same accumulators.
+    Returns (out, ln, mean, rstd); the last three are None without ln_g (mean / rstd also with stats=False)."""
+    rows, K = a.shape
+    J = w.shape[0]
+    out = torch.empty((rows, J), device=a.device, dtype=BF16)
+    ln = torch.empty((rows, J), device=a.device, dtype=BF16) if ln_g is not None else None
+    mean = torch.empty(rows, device=a.device, dtype=F32) if (ln_g is not None and stats) else None
+    rstd = torch.empty(rows, device=a.device, dtype=F32) if (ln_g is not None and stats) else None
+    L.call("dig_panel_gemm_ln_fwd", L.ptr(a), L.ptr(w), L.ptr(bias), L.ptr(resid), L.ptr(out), L.ptr(ln_g), L.ptr(ln_b), cf(eps), L.ptr(ln),
+           L.ptr(mean), L.ptr(rstd), rows, J, K, L.stream())
+    return out, ln, mean, rstd
+
+
+def mlp_chain_fwd_ln(x, ln_g, ln_b, eps, w1, b1, w2, b2, nln_g=None, nln_b=None, save=False, resid=None):
     """The second half of a transformer block with its LayerNorms in one launch: out = x + b2 + gelu(LN(x; ln_g, ln_b) w1^T + b1) w2^T and,
     when nln_g is given, the next block's norm1 of `out`.  Returns a dict: out; nln / nln_mean / nln_rstd (when nln_g is given; the
-    statistics only with save=True); with save=True also ln, ln_mean, ln_rstd, pre, act -- what the backward reads."""
+    statistics only with save=True); with save=True also ln, ln_mean, ln_rstd, pre, act -- what the backward reads.
+    ln_g None: x holds rows that are normalised already (panel_linear_ln) and `resid` the raw rows that are added back."""
+    if resid is None:
+        resid = x
     rows, D = x.shape
     Fh = w1.shape[0]
     dev = x.device
@@ -117,14 +140,15 @@ def mlp_chain_fwd_ln(x, ln_g, ln_b, eps, w1, b1, w2, b2, nln_g=None, nln_b=None,
     for k in ("ln_mean", "ln_rstd", "nln_mean", "nln_rstd"):
         r[k] = None
     if save:
-        r["ln"] = torch.empty((rows, D), device=dev, dtype=BF16)
-        r["ln_mean"], r["ln_rstd"] = torch.empty(rows, device=dev, dtype=F32), torch.empty(rows, device=dev, dtype=F32)
+        if ln_g is not None:
+            r["ln"] = torch.empty((rows, D), device=dev, dtype=BF16)
+            r["ln_mean"], r["ln_rstd"] = torch.empty(rows, device=dev, dtype=F32), torch.empty(rows, device=dev, dtype=F32)
         r["pre"], r["act"] = torch.empty((rows, Fh), device=dev, dtype=BF16), torch.empty((rows, Fh), device=dev, dtype=BF16)
     if nln_g is not None:
         r["nln"] = torch.empty((rows, D), device=dev, dtype=BF16)
         if save:
             r["nln_mean"], r["nln_rstd"] = torch.empty(rows, device=dev, dtype=F32), torch.empty(rows, device=dev, dtype=F32)
-    L.call("dig_mlp_chain_fwd_ln", L.ptr(x), L.ptr(ln_g), L.ptr(ln_b), cf(eps), L.ptr(r["ln"]), L.ptr(r["ln_mean"]), L.ptr(r["ln_rstd"]),
+    L.call("dig_mlp_chain_fwd_ln", L.ptr(x), L.ptr(resid), L.ptr(ln_g), L.ptr(ln_b), cf(eps), L.ptr(r["ln"]), L.ptr(r["ln_mean"]), L.ptr(r["ln_rstd"]),
            L.ptr(w1), L.ptr(b1), L.ptr(w2), L.ptr(b2), L.ptr(r["out"]), L.ptr(r["pre"]), L.ptr(r["act"]), L.ptr(nln_g), L.ptr(nln_b),
            L.ptr(r["nln"]), L.ptr(r["nln_mean"]), L.ptr(r["nln_rstd"]), rows, D, Fh, L.stream())
     return r
@@ -170,7 +194,11 @@ def linear_dgrad(dy, w, out=None, gelu_pre=None, colsum=False, drop=None):
     # few rows (the BN-MLP heads on pooled features): 128x64 tiles double the workgroup count (tools/gpu_head_gemm_probe.py).
     # (The 256x192 tile is 8-20 % faster for the tall 384-wide dgrads alone -- tools/experiments/gpu_dgrad_tile_probe.py -- but not in
     #  the step: 25.69 vs 25.77 ms over three A/B pairs; the small 128x128 workgroups share the CUs better with the weight-gradient stream.)
-    return gemm(dy, w, dy.shape[0], w.shape[1], w.shape[0], tb=True, out=out, bk=221 if dy.shape[0] <= 2048 else 0)
+    return gemm(dy, w, dy.shape[0], w.shape[1], w.shape[0], tb=True, out=out, bk=221 if dy.shape[0] <= 2048 else DGRAD_BK)
+
+
+DGRAD_BK = int(os.environ.get("DIG_DGRAD_BK", "0"))                 # tile code of the tall data-gradient GEMMs (0 = 128x128 / BK 32)
+WGRAD_TALL = tuple(int(v) for v in os.environ.get("DIG_WGRAD_TALL", "16,32").split(","))   # (R-splits, tile code) of the 36-tile weight gradients
 
 
 def colsum_partials(parts, out):
@@ -185,7 +213,7 @@ def wgrad_splits(rows, tiles):
     if tiles >= 24:
         # 16 splits x 36 tiles = 576 workgroups: ONE round at three workgroups per CU (24 splits = 864 left a 96-workgroup second round);
         # in the step, same box: 25.22 -> 24.98 ms (tools/experiments/sweep_wgrad_splits.py; 8 / 12 / 32 / 40 splits are slower)
-        want, bk = 16, 32
+        want, bk = WGRAD_TALL
     else:
         want, bk = min(40, 8 * max(1, round(360 / tiles / 8))), 64
     cap = max(1, rows // 512)

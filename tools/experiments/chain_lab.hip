@@ -51,8 +51,8 @@ int main(int argc, char** argv) {
       if (mode == 0) dig_mlp_chain_fwd(x, w1, b1, w2, b2, res, out, nullptr, nullptr, R, D, F, 0);
       else if (mode == 1) dig_mlp_chain_fwd(x, w1, b1, w2, b2, res, out, pre, act, R, D, F, 0);
       else if (mode == 2) dig_mlp_chain_bwd(x, w1, pre, w2, dpre, out, cs, R, D, F, 0);
-      else if (mode == 3) dig_mlp_chain_fwd_ln(x, lg, lb, 1e-6f, nullptr, nullptr, nullptr, w1, b1, w2, b2, out, nullptr, nullptr, lg, lb, nlno, nullptr, nullptr, R, D, F, 0);
-      else dig_mlp_chain_fwd_ln(x, lg, lb, 1e-6f, lno, st, st + R, w1, b1, w2, b2, out, pre, act, lg, lb, nlno, st + 2 * R, st + 3 * R, R, D, F, 0);
+      else if (mode == 3) dig_mlp_chain_fwd_ln(x, x, lg, lb, 1e-6f, nullptr, nullptr, nullptr, w1, b1, w2, b2, out, nullptr, nullptr, lg, lb, nlno, nullptr, nullptr, R, D, F, 0);
+      else dig_mlp_chain_fwd_ln(x, x, lg, lb, 1e-6f, lno, st, st + R, w1, b1, w2, b2, out, pre, act, lg, lb, nlno, st + 2 * R, st + 3 * R, R, D, F, 0);
     };
     for (int it = 0; it < 200; ++it) fn();
     hipDeviceSynchronize();
