@@ -50,6 +50,7 @@ def gemm(A, B, I, J, R, *, ta=False, tb=False, out=None, out_kind=OUT_BF16, bias
 
 
 PERSISTENT_FWD = os.environ.get("DIG_PERSISTENT_FWD", "1") != "0"
+FWD_192_BELOW = int(os.environ.get("DIG_FWD_192_BELOW", "512"))     # output widths = 128 mod 256 below this run on 256x192 tiles (no padded columns)
 DGRAD_GELU_BK = 32    # tile of the fc2 dgrad + GELU' + bias-sum GEMM: 128x128/BK32 beats the 256x256 tile inside the step (A/B: 25.9 vs 26.1 ms)
 def linear_fwd(x, w, *, bias=None, resid=None, act=0, pre=None, alpha=1.0, alpha_cols=0, out=None, out_kind=OUT_BF16, drop=None):
     """y[rows,out] = x[rows,in] @ w[out,in]^T (+bias)(gelu)(+resid)."""
@@ -60,7 +61,7 @@ def linear_fwd(x, w, *, bias=None, resid=None, act=0, pre=None, alpha=1.0, alpha
     rows = x.shape[0]
     if rows >= 8192 and w.shape[0] >= 384 and rows * w.shape[0] >= (1 << 24) and not (drop is not None and act):
         bk = 244
-        if w.shape[0] % 256 == 128 and w.shape[0] < 512:
+        if w.shape[0] % 256 == 128 and w.shape[0] < FWD_192_BELOW:
             # 384 outputs = 1.5 tiles of 256: a quarter of the 256x256 tile's columns would be padding.  The 256x192 tile (12 waves) covers
             # them in two exact tiles and keeps the two-fold reuse of the activation rows: proj 39.4 -> 34.5 us, fc2 114.8 -> 99.2 us alone;
             # in the step 25.98 -> 25.57 ms and the forward family 9.76 -> 9.43 ms (three A/B pairs on one box)
