@@ -4,7 +4,8 @@
 # -> gpurun_out/<tag>_final_bench.json            python bench.py (the driver's command, default flags)
 #    gpurun_out/<tag>_final_kernel_stats.csv      rocprofv3 --kernel-trace --stats of bench.py --steps 30 --warmup 8 --no-cpu-baseline --no-mim-only --no-step-graph
 #    gpurun_out/<tag>_final_bench_under_rocprof.json
-#    gpurun_out/<tag>_pmc_traffic.json            FETCH_SIZE / WRITE_SIZE passes (separate), tagged with the library hash
+#    gpurun_out/<tag>_final_by_queue.txt / _timeline.txt / _gaps.txt   the same kernel trace by queue, as a timeline of one step, idle gaps
+#    gpurun_out/<tag>_pmc_traffic.json            FETCH_SIZE / WRITE_SIZE passes (separate), tagged with the kernel-source hash
 #    gpurun_out/<tag>_pmc_kernel_counters.txt     MFMA / LDS utilisation, occupancy, instruction mix passes
 # Copy what should be judged into profiles/ afterwards.
 set -u
@@ -19,6 +20,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -- pytho
 cp $(ls $OUT/prof_stats/*/*kernel_stats.csv | head -1) $OUT/${TAG}_final_kernel_stats.csv
 f=$(ls $OUT/prof_stats/*/*kernel_trace.csv | head -1)
 python $ROOT/tools/trace_by_queue.py $f 10 10 60 > $OUT/${TAG}_final_by_queue.txt
+python $ROOT/tools/trace_timeline.py $f 12 full > $OUT/${TAG}_final_timeline.txt
+python $ROOT/tools/trace_gaps.py $f 12 8 > $OUT/${TAG}_final_gaps.txt
 rm -rf $OUT/prof_stats
 SHORT="python $ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-mim-only --no-step-graph"
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -30,7 +33,7 @@ python - <<PY
 import hashlib, json
 p = "$OUT/${TAG}_pmc_traffic.json"
 d = json.load(open(p))
-d["steps_in_run"] = 7          # --steps 3 --warmup 2 + the two instrumented steps of the roofline probe
+d["steps_in_run"] = d["kernels"]["adamw"]["launches"]      # one AdamW launch per step: warm-up + timed + the roofline probe's extra steps
 d["lib_sha256_16"] = hashlib.sha256(open("$ROOT/dig_amd/lib/libdig_hip.so", "rb").read()).hexdigest()[:16]
 import sys
 sys.path.insert(0, "$ROOT")
