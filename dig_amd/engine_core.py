@@ -15,6 +15,8 @@ from . import ops
 
 BF16, F32 = torch.bfloat16, torch.float32
 FWD_MODE = os.environ.get("DIG_FWD_MODE", "flip")                   # two-stream plan of the forward (single process): "flip" (default) or "side"
+CHAIN_BWD_EVERY = int(os.environ.get("DIG_CHAIN_BWD_EVERY", "1"))   # with DIG_MLP_CHAIN_MASK bit 2: the fused MLP backward in every k-th block only
+CHAIN_BWD_PHASE = int(os.environ.get("DIG_CHAIN_BWD_PHASE", "0"))
 BATCH_REDUCE = os.environ.get("DIG_BATCH_REDUCE", "0") == "1"       # an encoder block's eleven reduction launches as two: fewer launches,
 #                                                                     0.1-0.15 ms SLOWER per step -> opt-in
 FUSED_QV_BIAS_SUMS = os.environ.get("DIG_FUSED_QV_BIAS", "1") != "0"
@@ -196,7 +198,8 @@ class _Step:
         def on_side(fn, *tensors):
             self._on_side(dev, fn, *tensors)
 
-        chain = ops.mlp_chain_supported(D, M.F) and bool(ops.MLP_CHAIN_MASK & 4)
+        chain_any = ops.mlp_chain_supported(D, M.F) and bool(ops.MLP_CHAIN_MASK & 4)
+        chain = chain_any
         wT = getattr(self, "wT", None)
         if chain and wT is None:
             wT = self.mlp_weight_transposes(ew)
@@ -208,6 +211,7 @@ class _Step:
             blk, g = ew.blocks[i], ew.blocks[i]["g"]
             x, ln1, mu1, rs1, qkv, ctx, lse, x_mid, ln2, mu2, rs2, pre, act = saved[i]
             saved[i] = None
+            chain = chain_any and (i % CHAIN_BWD_EVERY == CHAIN_BWD_PHASE % CHAIN_BWD_EVERY)
             if views == 1:            # only view 0 carries a gradient (zero contrastive weight): rows [0, B*N) of everything
                 Rh = B * N
                 x, ln1, mu1, rs1, qkv, ctx, x_mid, ln2, mu2, rs2, pre, act = (t[:Rh] for t in (x, ln1, mu1, rs1, qkv, ctx, x_mid, ln2, mu2, rs2, pre, act))
