@@ -426,6 +426,42 @@ def test_full_size_loss_decreases_and_is_reproducible(full_size):
     assert abs(float(o1["contra_loss"]) - float(o2["contra_loss"])) <= 1e-6 * abs(float(o1["contra_loss"]))
 
 
+@pytest.mark.parametrize("case", ["tiny", "tiny_both_views", "vit_small_b8"])
+def test_training_state_is_bit_reproducible_and_reads_no_unwritten_memory(case):
+    """Several optimisation steps from the same seeds, three times in one process: as is, again, and after every block the caching allocator
+    holds has been filled with NaN bit patterns (a kernel that reads a `torch.empty` region the step never wrote would produce a NaN or a
+    changed number).  What must repeat bit for bit is every step's gradient norm and the final weights; the loss METERS are per-block partials
+    added with one fp32 atomic per block and may differ in the last bit.  (tools/gpu_poison_check.py is the stand-alone form.)"""
+    cfg = O.DiGConfig(**O.TINY) if case.startswith("tiny") else O.DiGConfig()
+    hp = O.StepHyper(lr=1e-3, only_mim_on_ori_img=(case != "tiny_both_views"))
+    B, n = (4, 6) if case.startswith("tiny") else (8, 3)
+    batches = [O.synthetic_batch(B, cfg, 9100 + s) for s in range(n)]
+
+    def run():
+        model = build_model(cfg, *O.det_state(cfg, 29))
+        stats, _ = run_engine_steps(model, batches, hp)
+        torch.cuda.synchronize()
+        return [float(s["grad_norm"]) for s in stats], model.flat_params.clone(), [float(s["loss"]) for s in stats]
+
+    def poison():
+        held = []
+        for nbytes, count in ((64 << 20, 32), (4 << 20, 128), (256 << 10, 512), (16 << 10, 1024), (512, 2048)):
+            for i in range(count):
+                t = torch.empty(nbytes // 4, device="cuda:0", dtype=torch.int32)
+                t.fill_(0x7FC07FC0 if i % 2 else 0x7FC00001)              # two bf16 NaNs / one fp32 NaN
+                held.append(t)
+        torch.cuda.synchronize()
+        del held
+
+    g1, w1, l1 = run()
+    g2, w2, l2 = run()
+    poison()
+    g3, w3, l3 = run()
+    assert all(v == v for v in g3 + l3) and bool(torch.isfinite(w3).all())
+    assert g1 == g2 == g3 and torch.equal(w1, w2) and torch.equal(w1, w3)
+    assert max(abs(a - b) for a, b in zip(l1, l3)) <= 1e-5 * max(abs(a) for a in l1)
+
+
 def _bucket_cosines(grads, ref_g):
     cos = torch.nn.functional.cosine_similarity
     buckets = {}
