@@ -1158,4 +1158,133 @@ int dig_dropout_apply(const void* in_, void* out_, long long rows, int cols, con
   return DIG_OK;
 }
 
+// ---- grouped weight gradients (csrc/wgrad.hip): same host-side planning and the same two-call protocol (partial slabs now, their
+// sum folded into the gradients by the next call); the slab layout is this build's own ([tile][split][128][128 fn], row-major)
+#define DIG_WGRAD_MAX_PROBS 6
+struct dig_wgrad_prob_t { const void* A; const void* B; float* out; int lda, ldb, ldo, I, J, trans_out; };
+int dig_wgrad_group_supported(int I, int J, int R) {
+  return (I > 0 && J > 0 && R >= 64 && I % 128 == 0 && (J % 384 == 0 || J % 256 == 0) && R % 64 == 0) ? 1 : 0;
+}
+int dig_wgrad_group_fn(int J) { return J % 384 == 0 ? 3 : (J % 256 == 0 ? 2 : 0); }
+int dig_wgrad_group_rows_per_split(int R, int splits) {
+  if (R <= 0 || splits < 1 || R % 64) return 0;
+  return ((R / 64 + splits - 1) / splits) * 64;
+}
+int dig_wgrad_group_effective_splits(int R, int splits) {
+  const int per = dig_wgrad_group_rows_per_split(R, splits);
+  return per ? (R + per - 1) / per : 0;
+}
+long long dig_wgrad_group_slab_bytes(int total_tiles, int splits, int fn) { return (long long)total_tiles * splits * 128 * 128 * fn * 4; }
+int dig_wgrad_group_plan(const int* tiles_per_prob, int n_probs, int R, int max_wg, int* splits_out, unsigned* map_out, int max_out) {
+  if (!tiles_per_prob || !map_out || !splits_out || n_probs < 1 || n_probs > DIG_WGRAD_MAX_PROBS || R < 64 || (R % 64) || max_wg < 8) return DIG_ERR_ARG;
+  int tiles = 0;
+  for (int k = 0; k < n_probs; ++k) {
+    if (tiles_per_prob[k] < 1) return DIG_ERR_ARG;
+    tiles += tiles_per_prob[k];
+  }
+  if (tiles > 65535) return DIG_ERR_ARG;
+  struct Grp { int tile0, n, split; };
+  int last_eff = -1;
+  for (int want = std::max(1, std::min(max_wg / tiles, R / 64));; --want) {
+    const int S = dig_wgrad_group_effective_splits(R, want);
+    if (S == last_eff && want > 1) continue;
+    last_eff = S;
+    std::vector<Grp> groups;
+    int tile0 = 0;
+    for (int k = 0; k < n_probs; ++k) {
+      for (int s = 0; s < S; ++s) groups.push_back({tile0, tiles_per_prob[k], s});
+      tile0 += tiles_per_prob[k];
+    }
+    std::stable_sort(groups.begin(), groups.end(), [](const Grp& a, const Grp& b) { return a.n > b.n; });
+    std::vector<unsigned> bins[8];
+    for (const Grp& g : groups) {
+      int best = 0;
+      for (int x = 1; x < 8; ++x)
+        if (bins[x].size() < bins[best].size()) best = x;
+      for (int t = 0; t < g.n; ++t) bins[best].push_back((unsigned)(g.tile0 + t) | ((unsigned)g.split << 16));
+    }
+    size_t len = 0;
+    for (int x = 0; x < 8; ++x) len = std::max(len, bins[x].size());
+    if ((long long)len * 8 > max_wg && want > 1) continue;
+    if ((long long)len * 8 > max_out || S > 65535) return DIG_ERR_ARG;
+    for (size_t k = 0; k < len; ++k)
+      for (int x = 0; x < 8; ++x) map_out[k * 8 + x] = k < bins[x].size() ? bins[x][k] : 0xffffffffu;
+    *splits_out = S;
+    return (int)(len * 8);
+  }
+}
+int dig_wgrad_group(const dig_wgrad_prob_t* probs, int n_probs, const dig_wgrad_prob_t* fold_probs, int n_fold, int R, int splits,
+                    const unsigned* wg_map, int n_wg, float* slabs, const float* fold_slabs, int fold_splits, int fn, hipStream_t) {
+  if (n_probs < 0 || n_probs > DIG_WGRAD_MAX_PROBS || n_fold < 0 || n_fold > DIG_WGRAD_MAX_PROBS || (n_probs == 0 && n_fold == 0)) return DIG_ERR_ARG;
+  if (fn != 2 && fn != 3) return DIG_ERR_UNSUPPORTED;
+  if (n_wg < 1 || (n_probs > 0 && (!probs || !wg_map || !slabs || R < 64 || (R % 64) || splits < 1))) return DIG_ERR_ARG;
+  if (n_fold > 0 && (!fold_probs || !fold_slabs || fold_splits < 1)) return DIG_ERR_ARG;
+  const int TJ = 128 * fn;
+  auto check = [&](const dig_wgrad_prob_t* q, int n, bool operands, std::vector<int>& tile0) {
+    int tiles = 0;
+    for (int k = 0; k < n; ++k) {
+      if (!q[k].out || q[k].I <= 0 || q[k].J <= 0 || (q[k].I % 128) || (q[k].J % TJ)) return (int)DIG_ERR_ARG;
+      if ((q[k].ldo & 3) || !aligned16(q[k].out)) return (int)DIG_ERR_ALIGN;
+      if (operands) {
+        if (!q[k].A || !q[k].B) return (int)DIG_ERR_ARG;
+        if (!aligned16(q[k].A) || !aligned16(q[k].B) || (q[k].lda & 7) || (q[k].ldb & 7) || q[k].lda < q[k].I || q[k].ldb < q[k].J) return (int)DIG_ERR_ALIGN;
+      }
+      tile0.push_back(tiles);
+      tiles += (q[k].I / 128) * (q[k].J / TJ);
+    }
+    tile0.push_back(tiles);
+    return (int)DIG_OK;
+  };
+  std::vector<int> t0, f0;
+  int rc = check(probs, n_probs, true, t0);
+  if (rc) return rc;
+  rc = check(fold_probs, n_fold, false, f0);
+  if (rc) return rc;
+  if (n_probs && dig_wgrad_group_effective_splits(R, splits) != splits) return DIG_ERR_ARG;
+  const size_t SLAB = (size_t)128 * TJ;
+  // fold of the previous call's slabs (split order)
+  for (int k = 0; k < n_fold; ++k) {
+    const dig_wgrad_prob_t& q = fold_probs[k];
+    const int tj_n = q.J / TJ;
+    for (int T = f0[k]; T < f0[k + 1]; ++T) {
+      const int lt = T - f0[k], ti = lt / tj_n, tj = lt % tj_n;
+#pragma omp parallel for
+      for (int il = 0; il < 128; ++il)
+        for (int jl = 0; jl < TJ; ++jl) {
+          float s = 0.f;
+          for (int sp = 0; sp < fold_splits; ++sp) s += fold_slabs[((size_t)T * fold_splits + sp) * SLAB + (size_t)il * TJ + jl];
+          const int i = ti * 128 + il, j = tj * TJ + jl;
+          if (q.trans_out) q.out[(size_t)j * q.ldo + i] += s; else q.out[(size_t)i * q.ldo + j] += s;
+        }
+    }
+  }
+  if (!n_probs) return DIG_OK;
+  const int per = dig_wgrad_group_rows_per_split(R, splits);
+  for (int w = 0; w < n_wg; ++w) {
+    const unsigned item = wg_map[w];
+    if (item == 0xffffffffu) continue;
+    const int tile = (int)(item & 0xffffu), split = (int)(item >> 16);
+    int pi = 0;
+    while (pi + 1 < n_probs && tile >= t0[pi + 1]) ++pi;
+    if (tile >= t0[n_probs] || split >= splits) return DIG_ERR_ARG;
+    const dig_wgrad_prob_t& q = probs[pi];
+    const bf16_t* A = (const bf16_t*)q.A;
+    const bf16_t* B = (const bf16_t*)q.B;
+    const int tj_n = q.J / TJ, lt = tile - t0[pi], ti = lt / tj_n, tj = lt % tj_n;
+    const int rbeg = split * per, rend = std::min(R, rbeg + per);
+    float* slab = slabs + ((size_t)tile * splits + split) * SLAB;
+#pragma omp parallel for
+    for (int il = 0; il < 128; ++il) {
+      std::vector<float> acc(TJ, 0.f);
+      for (int r = rbeg; r < rend; ++r) {
+        const float a = bf2f(A[(size_t)r * q.lda + ti * 128 + il]);
+        const bf16_t* brow = B + (size_t)r * q.ldb + tj * TJ;
+        for (int jl = 0; jl < TJ; ++jl) acc[jl] += a * bf2f(brow[jl]);
+      }
+      std::memcpy(slab + (size_t)il * TJ, acc.data(), (size_t)TJ * 4);
+    }
+  }
+  return DIG_OK;
+}
+
 }  // extern "C"

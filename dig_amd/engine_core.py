@@ -20,6 +20,9 @@ CHAIN_BWD_PHASE = int(os.environ.get("DIG_CHAIN_BWD_PHASE", "0"))
 BATCH_REDUCE = os.environ.get("DIG_BATCH_REDUCE", "0") == "1"       # an encoder block's eleven reduction launches as two: fewer launches,
 #                                                                     0.1-0.15 ms SLOWER per step -> opt-in
 FUSED_QV_BIAS_SUMS = os.environ.get("DIG_FUSED_QV_BIAS", "1") != "0"
+# weight gradients of an encoder block on the grouped kernel (csrc/wgrad.hip): "block" = one launch per block (default: the block's
+# accumulators are dumped once), "pair" = MLP pair | attention pair, "off" = the tiled split-R launches + their slab sums
+WGRAD_GROUPING = os.environ.get("DIG_WGRAD_GROUPING", "block")
 
 
 class LocalComm:
@@ -79,6 +82,7 @@ def _weights(model):
 class _Step:
     def __init__(self, model):
         self._keep = []                             # tensors the side stream still reads (see _on_side)
+        self._keep_marks = []                       # (event on the side stream, length of _keep it covers): see _release_kept
         self.m = model
         self.comm = model.comm or LOCAL
 
@@ -173,6 +177,26 @@ class _Step:
         # it is released: ~120 per backward, 0.5+ ms of queue time) they are kept alive until backward() has joined the two streams
         self._keep.extend(tensors)
 
+    def _mark_kept(self, dev):
+        """Everything _on_side() has kept so far is dead once the side stream passes this point."""
+        main, side = self._streams(dev)
+        if side is main or not self._keep:
+            return
+        ev = torch.cuda.Event()
+        ev.record(side)
+        self._keep_marks.append((ev, len(self._keep)))
+
+    def _release_kept(self, dev, lag=2):
+        """Drop the kept tensors of marks at least `lag` marks old: the caller's stream waits for that mark (the side stream is never two
+        encoder blocks behind, so the wait is already satisfied when it is reached) and the blocks go back to its pool -- without this
+        every block's gradient temporaries stayed resident until the end of backward (~0.7 GB per ViT-S block at B = 256)."""
+        main, side = self._streams(dev)
+        while len(self._keep_marks) > lag:
+            ev, n = self._keep_marks.pop(0)
+            main.wait_event(ev)
+            del self._keep[:n]
+            self._keep_marks = [(e, m - n) for e, m in self._keep_marks]
+
     def _grad_ready(self, dev, key):
         """Bucket `key` is final once both streams pass this point.  With a process group the all-reduce is issued from the
         side stream after it has waited for the main chain, so the main chain never stalls on a collective."""
@@ -207,6 +231,19 @@ class _Step:
             for pair_ in wT:                                            # made on the side stream in forward(), read here on the main one
                 for t in pair_:
                     t.record_stream(main)
+        # The four weight gradients of a block as ONE grouped launch on the side stream (csrc/wgrad.hip), issued as soon as the block's last
+        # operand (dqkv) exists; its slabs are folded into the gradient arena by the next block's launch (or the flush after block 0), so
+        # block i's bucket is final -- and its all-reduce is issued -- one launch later.  Shapes the grouped kernel does not take (tiny test
+        # models) and the batched-reduction mode keep the per-layer launches.
+        Rg = (B * N) if views == 1 else (2 * B * N)
+        grouped = (ops.WGRAD_GROUP and not BATCH_REDUCE and WGRAD_GROUPING != "off" and
+                   all(ops.wgrad_group_route(o, i_, Rg) is not None for o, i_ in ((M.F, D), (D, M.F), (3 * D, D), (D, D))))
+        grp = ops.WgradGroup(dev) if grouped else None
+        prev_block = None
+
+        def launch_group(*tensors):
+            on_side(grp.launch, *tensors)
+
         for i in reversed(range(M.depth)):
             blk, g = ew.blocks[i], ew.blocks[i]["g"]
             x, ln1, mu1, rs1, qkv, ctx, lse, x_mid, ln2, mu2, rs2, pre, act = saved[i]
@@ -222,17 +259,30 @@ class _Step:
             red = ops.GradReduceBatch() if BATCH_REDUCE else None
             wg = red.wgrad if red else ops.linear_wgrad
             csum = red.colsum_partials if red else ops.colsum_partials
-            on_side(lambda: wg(dx, act, g["mlp.fc2.weight"]), dx, act)
+            held = []                                                        # operands of the grouped launch (kept alive until the streams join)
+            if grp:
+                def wg(dy_, x_, dw_):
+                    assert grp.add(dy_, x_, dw_)
+                    held.extend((dy_, x_))
+                wg(dx, act, g["mlp.fc2.weight"])
+            else:
+                on_side(lambda: wg(dx, act, g["mlp.fc2.weight"]), dx, act)
             if chain:
                 # data gradient through fc2, GELU' and fc1 in one launch (d(pre-activation) leaves it as a side output for the fc1
                 # weight gradient, with its column sums = the fc1 bias gradient)
                 w2t, w1t = wT[i]
                 dln2, dact, bparts = ops.mlp_chain_bwd(dx, w2t, pre, w1t)
-                on_side(lambda: (wg(dact, ln2, g["mlp.fc1.weight"]), csum(bparts, g["mlp.fc1.bias"])), dact, ln2, bparts)
             else:
                 dact, bparts = ops.linear_dgrad(dx, blk["mlp.fc2.weight"], gelu_pre=pre, colsum=True)   # d(pre-activation): GELU' and
-                on_side(lambda: (wg(dact, ln2, g["mlp.fc1.weight"]),                                     # the fc1 bias sums fused
-                                 csum(bparts, g["mlp.fc1.bias"])), dact, ln2, bparts)                    # (0.3 ms/step vs a 201 MB pass)
+                dln2 = None                                                                              # the fc1 bias sums fused
+            if grp:
+                wg(dact, ln2, g["mlp.fc1.weight"])
+                on_side(lambda: csum(bparts, g["mlp.fc1.bias"]), bparts)
+                if WGRAD_GROUPING == "pair":
+                    launch_group(*held)
+            else:
+                on_side(lambda: (wg(dact, ln2, g["mlp.fc1.weight"]), csum(bparts, g["mlp.fc1.bias"])), dact, ln2, bparts)   # (0.3 ms/step vs a 201 MB pass)
+            if dln2 is None:
                 dln2 = ops.linear_dgrad(dact, blk["mlp.fc1.weight"])
             dx_mid, fin2, ws2 = ops.layernorm_bwd(dln2, x_mid, blk["norm2.weight"], blk["norm2.bias"], mu2, rs2, dx, g["norm2.weight"],
                                                   g["norm2.bias"], out=dln2, dres_colsum=g["mlp.fc2.bias"], defer=True)
@@ -241,7 +291,10 @@ class _Step:
             else:
                 on_side(fin2, ws2)
             # x_mid = x + proj(attn(ln1))
-            on_side(lambda: wg(dx_mid, ctx, g["attn.proj.weight"]), dx_mid, ctx)
+            if grp:
+                wg(dx_mid, ctx, g["attn.proj.weight"])
+            else:
+                on_side(lambda: wg(dx_mid, ctx, g["attn.proj.weight"]), dx_mid, ctx)
             dctx = ops.linear_dgrad(dx_mid, blk["attn.proj.weight"])
             gb = g["qkv_bias"]
             if FUSED_QV_BIAS_SUMS:
@@ -249,12 +302,22 @@ class _Step:
                 # kernel as [2B, D] fp32 partials (DPP row reductions of the accumulators, no extra pass over the 150 MB dqkv);
                 # K has no bias
                 dqkv, qs, vs = ops.attn_bwd(qkv, ctx, dctx, lse, views * B, H, D, scale, bias_sums=True)
-                on_side(lambda: (wg(dqkv, ln1, g["attn.qkv.weight"]),
-                                 csum(qs, gb[:D]), csum(vs, gb[2 * D:])), dqkv, ln1, qs, vs)
+                if grp:
+                    wg(dqkv, ln1, g["attn.qkv.weight"])
+                    launch_group(*held)
+                    on_side(lambda: (csum(qs, gb[:D]), csum(vs, gb[2 * D:])), qs, vs)
+                else:
+                    on_side(lambda: (wg(dqkv, ln1, g["attn.qkv.weight"]),
+                                     csum(qs, gb[:D]), csum(vs, gb[2 * D:])), dqkv, ln1, qs, vs)
             else:
                 dqkv = ops.attn_bwd(qkv, ctx, dctx, lse, views * B, H, D, scale)
-                on_side(lambda: (wg(dqkv, ln1, g["attn.qkv.weight"]),
-                                 ops.colsum(dqkv, gb[:D], cols=D), ops.colsum(dqkv[:, 2 * D:], gb[2 * D:], cols=D)), dqkv, ln1)
+                if grp:
+                    wg(dqkv, ln1, g["attn.qkv.weight"])
+                    launch_group(*held)
+                    on_side(lambda: (ops.colsum(dqkv, gb[:D], cols=D), ops.colsum(dqkv[:, 2 * D:], gb[2 * D:], cols=D)), dqkv)
+                else:
+                    on_side(lambda: (wg(dqkv, ln1, g["attn.qkv.weight"]),
+                                     ops.colsum(dqkv, gb[:D], cols=D), ops.colsum(dqkv[:, 2 * D:], gb[2 * D:], cols=D)), dqkv, ln1)
             dln1 = ops.linear_dgrad(dqkv, blk["attn.qkv.weight"], out=dctx)
             dx, fin1, ws1 = ops.layernorm_bwd(dln1, x, blk["norm1.weight"], blk["norm1.bias"], mu1, rs1, dx_mid, g["norm1.weight"],
                                               g["norm1.bias"], out=dln1, dres_colsum=g["attn.proj.bias"], defer=True)
@@ -263,10 +326,22 @@ class _Step:
                 on_side(red.flush, *red.tensors())
             else:
                 on_side(fin1, ws1)
-            del dact, pre, act, dln2, dqkv, dctx
+            del dact, pre, act, dln2, dqkv, dctx, held
+            self._mark_kept(dev)
+            self._release_kept(dev)
             # this block's gradients are final once BOTH streams pass this point: the bucket's all-reduce is issued from the
-            # side stream after it has waited for the main chain, so the main chain itself never stalls on the collective
-            self._grad_ready(dev, f"encoder.blocks.{i}")
+            # side stream after it has waited for the main chain, so the main chain itself never stalls on the collective.
+            # (Grouped weight gradients: block i's slabs are folded by the NEXT launch, so the bucket that is final here is block i + 1's.)
+            if grp:
+                if prev_block is not None:
+                    self._grad_ready(dev, f"encoder.blocks.{prev_block}")
+                prev_block = i
+            else:
+                self._grad_ready(dev, f"encoder.blocks.{i}")
+        if grp:
+            on_side(grp.flush)
+            if prev_block is not None:
+                self._grad_ready(dev, f"encoder.blocks.{prev_block}")
         for half, im in enumerate((images, aug)[:views]):
             ops.patch_embed_bwd_mfma(dx[half * B * N:(half + 1) * B * N], im, mask_u8[half * B:(half + 1) * B], ew.g_pe_w, ew.g_pe_b,
                                      ew.g_mask_token, D, M.gh, M.gw)
@@ -570,6 +645,7 @@ class _Step:
         if side is not main:
             main.wait_stream(side)                  # every gradient is final on the caller's stream (grad norm / AdamW follow)
         self._keep.clear()                          # (blocks go back to the caller's stream's pool: its later work is ordered behind the join)
+        self._keep_marks.clear()
         self.saved_enc = self.saved_pix = self.saved_proj = self.saved_pred = self.saved_dec = self.wT = None
 
 

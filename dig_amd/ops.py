@@ -323,6 +323,111 @@ def linear_wgrad(dy, x, dw, rows=None):
     wgrad(dy, x, dw, dw.shape[0], dw.shape[1], rows)
 
 
+# ---- grouped weight gradients (csrc/wgrad.hip): the Linear layers of a transformer block in ONE launch, slabs folded by the next launch
+WGRAD_GROUP = os.environ.get("DIG_WGRAD_GROUP", "1") != "0"
+WGRAD_GROUP_SLOTS = int(os.environ.get("DIG_WGRAD_SLOTS", "512"))     # workgroups per launch: one round at two per CU on 256 CUs
+_wg_plans, _wg_slabs = {}, {}
+
+
+class _WgProb(ctypes.Structure):
+    """include/dig_hip.h `dig_wgrad_prob_t`."""
+    _fields_ = [("A", ctypes.c_void_p), ("B", ctypes.c_void_p), ("out", ctypes.c_void_p), ("lda", ctypes.c_int), ("ldb", ctypes.c_int),
+                ("ldo", ctypes.c_int), ("I", ctypes.c_int), ("J", ctypes.c_int), ("trans_out", ctypes.c_int)]
+
+
+def wgrad_group_route(out_dim, in_dim, rows, fn=None):
+    """How dW[out_dim, in_dim] = dy^T x joins a group: (trans_out, fn) -- the narrow operand is x (fc1, qkv, proj) or dy (fc2) -- or None.
+    fn: the tile width code of the group it has to match (None: any)."""
+    lib = L.lib()
+    cands = ((0, out_dim, in_dim), (1, in_dim, out_dim))
+    if out_dim < in_dim:                                             # the narrow operand is the model width: the smaller dimension first
+        cands = cands[::-1]
+    for trans, wide, narrow in cands:
+        if narrow <= 512 and lib.dig_wgrad_group_supported(int(wide), int(narrow), int(rows)):
+            f = lib.dig_wgrad_group_fn(int(narrow))
+            if fn is None or f == fn:
+                return trans, f
+    return None
+
+
+class WgradGroup:
+    """Weight gradients dW += dy^T x collected with add() and computed by launch() in one dig_wgrad_group call; each launch leaves fp32
+    partial slabs that the NEXT launch (or flush()) sums -- in split order, deterministic -- into the gradient tensors.  One object per
+    backward pass and stream: add / launch / flush must be issued on the same stream (the kernel boundary orders slabs and fold)."""
+
+    def __init__(self, dev):
+        self.dev, self.cur, self.pending, self.set, self.fn, self.rows = dev, [], None, 0, None, None
+
+    def add(self, dy, x, dw, rows=None):
+        """Queue dw[out, in] += dy[rows, out]^T x[rows, in] for the next launch(); False (nothing queued) when the shape cannot join."""
+        rows = dy.shape[0] if rows is None else rows
+        r = wgrad_group_route(dw.shape[0], dw.shape[1], rows, self.fn) if WGRAD_GROUP else None
+        if r is None or len(self.cur) == 6 or (self.rows not in (None, rows)) or dw.stride(1) != 1:
+            return False
+        trans, self.fn = r
+        self.rows = rows
+        A, B = (x, dy) if trans else (dy, x)
+        self.cur.append((A, B, dw, trans))
+        return True
+
+    def _plan(self, tiles):
+        key = (tuple(tiles), self.rows, WGRAD_GROUP_SLOTS, str(self.dev))
+        pl = _wg_plans.get(key)
+        if pl is None:
+            tp = (ctypes.c_int * len(tiles))(*tiles)
+            cap = 8 * max(WGRAD_GROUP_SLOTS, sum(tiles))
+            buf = (ctypes.c_uint * cap)()
+            sp = ctypes.c_int(0)
+            n = L.lib().dig_wgrad_group_plan(tp, len(tiles), int(self.rows), WGRAD_GROUP_SLOTS, ctypes.byref(sp), buf, cap)
+            if n <= 0:
+                L.check(n or -1, "dig_wgrad_group_plan")
+            import numpy as np
+            m = torch.from_numpy(np.frombuffer(buf, dtype=np.uint32, count=n).view(np.int32).copy())
+            pl = _wg_plans[key] = (sp.value, n, m.to(self.dev))
+        return pl
+
+    def _slabs(self, nbytes):
+        key = (str(self.dev), torch.cuda.current_stream(self.dev).cuda_stream if self.dev.type == "cuda" else 0, self.set)
+        w = _wg_slabs.get(key)
+        if w is None or w.numel() * 4 < nbytes:
+            w = _wg_slabs[key] = torch.empty((max(nbytes, 1 << 26) + 3) // 4, device=self.dev, dtype=F32)
+        return w
+
+    def _structs(self, items):
+        arr = (_WgProb * max(len(items), 1))()
+        for k, (A, B, dw, trans) in enumerate(items):
+            J = dw.shape[0] if trans else dw.shape[1]
+            I = dw.shape[1] if trans else dw.shape[0]
+            arr[k] = _WgProb(A.data_ptr() if A is not None else None, B.data_ptr() if B is not None else None, dw.data_ptr(),
+                             A.stride(0) if A is not None else 0, B.stride(0) if B is not None else 0, dw.stride(0), I, J, trans)
+        return arr
+
+    def launch(self):
+        """Partial products of everything add()ed since the last launch + the fold of the previous launch's slabs."""
+        if not self.cur and self.pending is None:
+            return
+        fn = self.fn
+        tj = 128 * fn
+        tiles = [((dw.shape[1] if t else dw.shape[0]) // 128) * ((dw.shape[0] if t else dw.shape[1]) // tj) for _, _, dw, t in self.cur]
+        if self.cur:
+            splits, n_wg, wmap = self._plan(tiles)
+            slabs = self._slabs(sum(tiles) * splits * 128 * tj * 4)
+        else:
+            splits, n_wg, wmap, slabs = 1, WGRAD_GROUP_SLOTS, None, None
+        pend = self.pending
+        L.call("dig_wgrad_group", self._structs(self.cur), len(self.cur), self._structs(pend[0]) if pend else None, len(pend[0]) if pend else 0,
+               int(self.rows), splits, L.ptr(wmap), n_wg, L.ptr(slabs), L.ptr(pend[1]) if pend else None, pend[2] if pend else 1, fn, L.stream())
+        # the fold list keeps the gradient tensors only (operands are dead once this launch has run)
+        self.pending = ([(None, None, dw, t) for _, _, dw, t in self.cur], slabs, splits) if self.cur else None
+        self.cur = []
+        self.set ^= 1
+
+    def flush(self):
+        """Fold what the last launch left (a fold-only launch); afterwards every gradient add()ed so far is final on this stream."""
+        assert not self.cur, "launch() the queued problems first"
+        self.launch()
+
+
 _ws2 = {}
 
 

@@ -72,6 +72,38 @@ typedef struct dig_reduce_seg { const float* partials; float* out; long long n; 
 int dig_reduce_partials_multi(const dig_reduce_seg_t* segs, int n_segs, hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * Grouped weight gradients (round 4).  Replaces the autograd of the four nn.Linear layers of a transformer Block
+ * (modeling_finetune.py:53-60 Mlp.fc1 / fc2, :91-93 Attention.qkv, :119 Attention.proj): dW = dy^T x with the TOKEN rows as the
+ * reduction dimension, for a LIST of problems in one launch:
+ *     out_p[i, j] (+)= sum_r A_p[r, i] * B_p[r, j]        A_p [R, lda] bf16 = the wide operand  (I_p columns, I_p % 128 == 0)
+ *                                                         B_p [R, ldb] bf16 = the narrow operand (J_p columns, J_p % (128 fn) == 0)
+ *     trans_out 0: out_p is [I_p, ldo] fp32 (fc1, qkv, proj: A = dy, B = x);  1: out_p is [J_p, ldo] (fc2: A = x, B = dy)
+ * fn = 3 (narrow width a multiple of 384: ViT-S) or 2 (a multiple of 256: D = 512), one value per launch; R % 64 == 0.
+ * Tiles of 128 x 128 fn (4 waves, each 4 x fn MFMA accumulators) x S R-splits = one round of workgroups at two per CU; each
+ * workgroup leaves its accumulators as one fp32 slab, and the slabs of launch n are summed in split order (deterministic: no
+ * atomics) and added to out_p by launch n + 1 in its prologue -- the kernel boundary is the only synchronisation.  So:
+ *     dig_wgrad_group(probs_n, n, probs_{n-1}, m, ...)  computes the partial products of probs_n into `slabs` and folds `fold_slabs`
+ *     (written by the previous call with probs_{n-1}, fold_splits) into probs_{n-1}'s gradients;  n_probs = 0 folds only (the
+ *     last pending set);  n_fold = 0: nothing pending.  `slabs` and `fold_slabs` must be different buffers (two alternate).
+ * dig_wgrad_group_plan builds the workgroup table of a launch on the HOST (tiles of one (problem, split) pair on one XCD, the XCDs
+ * loaded evenly) and chooses S; the caller copies map_out to device memory once per configuration and passes it as wg_map.
+ * probs / fold_probs / tiles_per_prob / map_out / splits_out are host memory; out / slabs / wg_map device memory. */
+#define DIG_WGRAD_MAX_PROBS 6
+typedef struct dig_wgrad_prob {
+  const void* A; const void* B; float* out;
+  int lda, ldb, ldo, I, J, trans_out;
+} dig_wgrad_prob_t;
+int dig_wgrad_group_supported(int I, int J, int R);               /* 1: a problem of these sizes can join a group */
+int dig_wgrad_group_fn(int J);                                    /* 3, 2, or 0 (narrow width not supported) */
+int dig_wgrad_group_rows_per_split(int R, int splits);
+int dig_wgrad_group_effective_splits(int R, int splits);
+long long dig_wgrad_group_slab_bytes(int total_tiles, int splits, int fn);
+int dig_wgrad_group_plan(const int* tiles_per_prob, int n_probs, int R, int max_wg, int* splits_out, unsigned* map_out, int max_out);
+int dig_wgrad_group(const dig_wgrad_prob_t* probs, int n_probs, const dig_wgrad_prob_t* fold_probs, int n_fold, int R, int splits,
+                    const unsigned* wg_map, int n_wg, float* slabs, const float* fold_slabs, int fold_splits, int fn,
+                    hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * Fused two-layer MLP ("chain"): Mlp.forward of a transformer block and its data gradient (modeling_finetune.py:53-60 inside
  * Block.forward :150-158) in ONE launch each -- the [R, F] hidden tensor is never a GEMM operand in HBM.
  *   dig_mlp_chain_fwd:  out[R,D] = resid + b2 + gelu_erf(x[R,D] w1[F,D]^T + b1) w2[D,F]^T      (bf16 I/O, fp32 accumulation,

@@ -359,6 +359,46 @@ def test_grad_reduce_batch_equals_single_launches(dev):
             assert rel(u, v) < 1e-6, i
 
 
+@pytest.mark.parametrize("R,D,Fh", [(64, 384, 512), (1024, 384, 1536), (65536, 384, 1536), (32768, 384, 1536), (256, 256, 1024), (8192, 512, 2048)])
+def test_wgrad_group(dev, R, D, Fh):
+    """The grouped weight-gradient kernel (csrc/wgrad.hip) on the four Linear layers of a transformer block, in every launch grouping:
+    each gradient against fp32 torch (fp32 accumulation of bf16 products: tight), the fold of the NEXT launch / the flush as the only
+    place where gradients change, += semantics, transposed output (fc2), and bit-reproducibility (split-ordered fold, no atomics)."""
+    from dig_amd import ops
+    cpu_limit(dev, 2.0 * R * D * (2 * Fh + 4 * D), 5e9)
+    g = torch.Generator(device="cpu").manual_seed(R + D)
+    mk = lambda *sh: (torch.randn(*sh, generator=g) * 0.5).bfloat16().to(dev)
+    dact, act, ln2, dx = mk(R, Fh), mk(R, Fh), mk(R, D), mk(R, D)
+    dqkv, ln1, ctx, dxm = mk(R, 3 * D), mk(R, D), mk(R, D), mk(R, D)
+    layers = [(dx, act, (D, Fh)), (dact, ln2, (Fh, D)), (dxm, ctx, (D, D)), (dqkv, ln1, (3 * D, D))]      # (dy, x, dW shape)
+    refs = [dy.float().t() @ x.float() for dy, x, _ in layers]
+    outs = {}
+    for grouping in ((4,), (2, 2), (1, 1, 1, 1)):
+        dws = [torch.full(sh, 0.25, device=dev) for _, _, sh in layers]
+        grp = ops.WgradGroup(dev)
+        k = 0
+        for n in grouping:
+            for li in range(k, k + n):
+                assert grp.add(layers[li][0], layers[li][1], dws[li])
+            grp.launch()
+            k += n
+        if grouping == (4,):
+            assert all(torch.equal(dw, torch.full_like(dw, 0.25)) for dw in dws)       # nothing is final before the fold
+        grp.flush()
+        for dw, ref in zip(dws, refs):
+            assert rel(dw - 0.25, ref) < 2e-5
+        outs[grouping] = dws
+    # second pass of one grouping: same bits
+    dws = [torch.full(sh, 0.25, device=dev) for _, _, sh in layers]
+    grp = ops.WgradGroup(dev)
+    for (dy, x, _), dw in zip(layers, dws):
+        assert grp.add(dy, x, dw)
+    grp.launch(); grp.flush()
+    assert all(torch.equal(a, b) for a, b in zip(dws, outs[(4,)]))
+    # a shape the kernel does not take is refused, not mangled
+    assert not ops.WgradGroup(dev).add(mk(R, 100), ln2, torch.zeros(100, D, device=dev))
+
+
 @pytest.mark.parametrize("R,K", [(256, 64), (1000, 384), (4096, 1152), (65536, 384), (515, 1536)])
 def test_panel_gemm_ln_fwd(dev, R, K):
     """dig_panel_gemm_ln_fwd (row-panel GEMM: out = a w^T + bias + resid, LayerNorm of the stored rows from the same accumulators) against
