@@ -32,7 +32,7 @@ WORKLOAD_TEXT = {
 }
 PEAK_BF16 = 2.5e15
 PEAK_HBM = 8.0e12                                                      # /opt/skills/guides/MI355X_MICROARCH.md
-PMC_FILE = "r03_pmc_traffic.json"                                      # rocprofv3 --pmc passes of this command (tools/collect_profiles.sh), stamped
+PMC_FILE = "r04_pmc_traffic.json"                                      # rocprofv3 --pmc passes of this command (tools/collect_profiles.sh), stamped
 #                                                                        with the hash of the kernel SOURCES they were measured on
 
 
@@ -71,22 +71,32 @@ def synth_batches(n, B, device, seed):
 
 
 class GemmProbe:
-    """Times every dig_gemm_bf16 and dig_mlp_chain_fwd(_ln) launch of one step with HIP events on the launch stream (torch's current stream)."""
+    """Times every matrix-core launch of a step -- dig_gemm_bf16, the fused MLP launches (dig_mlp_chain_fwd / _fwd_ln / _bwd) and the grouped
+    weight-gradient launch (dig_wgrad_group) -- with HIP events on the stream the launch goes to (torch's current stream at the call).
+    With the two-stream overlap left ON the brackets are the launches' durations IN THE STEP (what rocprofv3 reports for the same command);
+    with `model.overlap_streams = False` they are the durations of the kernels one at a time."""
 
     def __init__(self):
         from dig_amd import ops
         self.ops = ops
         self.rec = []
-        self._orig = ops.gemm
+        self._saved = {}
+
+    def _bracket(self, variant, flops, byt, fn):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn()
+        e1.record()
+        self.rec.append((variant, flops, byt, e0, e1))
+        return out
 
     def __enter__(self):
         ops = self.ops
+        sv = self._saved
+        sv["gemm"], sv["chain"], sv["chain_ln"], sv["chain_bwd"], sv["wg_launch"] = (ops.gemm, ops.mlp_chain_fwd, ops.mlp_chain_fwd_ln,
+                                                                                      ops.mlp_chain_bwd, ops.WgradGroup.launch)
 
         def timed(A, B, I, J, R, **kw):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            out = self._orig(A, B, I, J, R, **kw)
-            e1.record()
             variant = ("wgrad" if kw.get("ta") else ("dgrad" if kw.get("tb") else "fwd"))
             # algorithmic HBM bytes of the launch: both operands once, the output and the residual once (weight gradients: fp32
             # read-modify-write of dW).  NOT counted: the saved pre-activation of fc1 (an implementation choice of the backward),
@@ -97,45 +107,54 @@ class GemmProbe:
             else:
                 byt += I * J * (4.0 if kw.get("out_kind") == ops.OUT_F32 else 2.0)
                 byt += 2.0 * I * J * (kw.get("resid") is not None)
-            self.rec.append((variant, 2.0 * I * J * R, byt, e0, e1))
-            return out
+            return self._bracket(variant, 2.0 * I * J * R, byt, lambda: sv["gemm"](A, B, I, J, R, **kw))
         ops.gemm = timed
-        orig_chain = self._orig_chain = ops.mlp_chain_fwd
 
         def timed_chain(x, w1, b1, w2, b2, resid, save=False):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            out = orig_chain(x, w1, b1, w2, b2, resid, save=save)
-            e1.record()
             R, D = x.shape
             Fh = w1.shape[0]
             # algorithmic HBM bytes of the fused fc1 -> GELU -> fc2 launch: x, residual and output rows once, both weight matrices once;
             # the online form also writes what the reference's autograd keeps for the backward (pre-activation and GELU output)
             byt = 2.0 * R * D * 3 + 2.0 * 2 * D * Fh + (2.0 * 2 * R * Fh if save else 0.0)
-            self.rec.append(("mlp_chain", 4.0 * R * D * Fh, byt, e0, e1))
-            return out
+            return self._bracket("mlp_chain", 4.0 * R * D * Fh, byt, lambda: sv["chain"](x, w1, b1, w2, b2, resid, save=save))
         ops.mlp_chain_fwd = timed_chain
-        orig_ln = self._orig_chain_ln = ops.mlp_chain_fwd_ln
 
         def timed_chain_ln(x, ln_g, ln_b, eps, w1, b1, w2, b2, nln_g=None, nln_b=None, save=False, resid=None):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            out = orig_ln(x, ln_g, ln_b, eps, w1, b1, w2, b2, nln_g, nln_b, save=save, resid=resid)
-            e1.record()
             R, D = x.shape
             Fh = w1.shape[0]
             # the fused launch with its LayerNorms: raw rows in, output rows and the next block's normalised rows out, both weight matrices
             # once; the online form also writes what the reference's autograd keeps (norm2's output, the pre-activation, the GELU output)
             byt = 2.0 * R * D * (2 + (nln_g is not None)) + 2.0 * 2 * D * Fh + ((2.0 * R * D + 2.0 * 2 * R * Fh) if save else 0.0)
-            self.rec.append(("mlp_chain", 4.0 * R * D * Fh, byt, e0, e1))
-            return out
+            return self._bracket("mlp_chain", 4.0 * R * D * Fh, byt,
+                                 lambda: sv["chain_ln"](x, ln_g, ln_b, eps, w1, b1, w2, b2, nln_g, nln_b, save=save, resid=resid))
         ops.mlp_chain_fwd_ln = timed_chain_ln
+
+        def timed_chain_bwd(dy, w2t, pre, w1t, colsum=True, out=None):
+            R, D = dy.shape
+            Fh = w2t.shape[0]
+            # fused data gradient of the MLP: dy and dx rows, the saved pre-activation in, d(pre-activation) out (the fc1 weight gradient
+            # reads it), both weight matrices once
+            byt = 2.0 * R * D * 2 + 2.0 * R * Fh * 2 + 2.0 * 2 * D * Fh
+            return self._bracket("mlp_chain_bwd", 4.0 * R * D * Fh, byt, lambda: sv["chain_bwd"](dy, w2t, pre, w1t, colsum=colsum, out=out))
+        ops.mlp_chain_bwd = timed_chain_bwd
+
+        probe = self
+
+        def timed_wg_launch(grp):
+            if not grp.cur:
+                return sv["wg_launch"](grp)
+            R = grp.rows
+            fl = sum(2.0 * R * dw.shape[0] * dw.shape[1] for _, _, dw, _ in grp.cur)
+            # grouped weight gradients: both operands of every problem once, fp32 read-modify-write of each dW (the slabs are not algorithmic)
+            byt = sum(2.0 * R * (dw.shape[0] + dw.shape[1]) + 8.0 * dw.shape[0] * dw.shape[1] for _, _, dw, _ in grp.cur)
+            return probe._bracket("wgrad_group", fl, byt, lambda: sv["wg_launch"](grp))
+        ops.WgradGroup.launch = timed_wg_launch
         return self
 
     def __exit__(self, *a):
-        self.ops.gemm = self._orig
-        self.ops.mlp_chain_fwd = self._orig_chain
-        self.ops.mlp_chain_fwd_ln = self._orig_chain_ln
+        ops, sv = self.ops, self._saved
+        ops.gemm, ops.mlp_chain_fwd, ops.mlp_chain_fwd_ln, ops.mlp_chain_bwd = sv["gemm"], sv["chain"], sv["chain_ln"], sv["chain_bwd"]
+        ops.WgradGroup.launch = sv["wg_launch"]
 
     def summary(self):
         torch.cuda.synchronize()
@@ -149,10 +168,18 @@ class GemmProbe:
         return {k: {"flops": v[0], "seconds": v[1], "launches": v[2], "bytes": v[3]} for k, v in agg.items()}
 
 
+KERNEL_TEXT = {
+    "mlp_chain": "dig_mlp_chain_fwd (mlp_chain_kernel: fc1 -> GELU -> fc2 + residual (+ LayerNorms) in one launch, S-wave / O-wave role split, v_mfma_f32_32x32x16_bf16)",
+    "mlp_chain_bwd": "dig_mlp_chain_bwd (mlp_chain_kernel<2>: the MLP's two data gradients x GELU' in one launch)",
+    "wgrad_group": "dig_wgrad_group (wgrad_wide_kernel / wgrad_group_kernel: the four weight gradients of a block in one launch, 4 x 3 MFMA blocks per wave, "
+                   "LDS-DMA ring, slabs folded by the next launch)",
+}
+
+
 def cpu_baseline(model_name, budget_s=20.0):
     """The fp32 CPU oracle (oracle/dig_oracle.py, pinned to the reference by tests/golden) on this host's cores, at the two batch sizes
     SURVEY.md 8(d) names: B = 4 (BASELINE configs[0], the reference's own CPU-runnable case) and B = 128 (the per-GPU batch of the
-    metric; one timed step -- about 15 s -- so that the default run stays within minutes)."""
+    metric: one untimed + three timed steps of ~30 s each -- the default run stays within a few minutes)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import dig_oracle as O
     cfg = O.make_config(model_name)
@@ -173,7 +200,11 @@ def cpu_baseline(model_name, budget_s=20.0):
                 return n * Bc / dt, n, dt
     timed(4, 1, 0.0)                                                     # warm-up (thread pool, allocator)
     v4, n4, t4 = timed(4, 6, budget_s * 0.25)
-    v128, n128, t128 = timed(128, 1, 0.0) if budget_s >= 10 else (None, 0, 0.0)
+    if budget_s >= 10:
+        timed(128, 1, 0.0)                                               # one untimed step at the measured batch (first-touch allocation of the
+        v128, n128, t128 = timed(128, 3, 1e9)                            #  32x larger tensors, thread-pool growth), then three timed ones
+    else:
+        v128, n128, t128 = None, 0, 0.0
     cpu_model = "unknown"
     try:
         with open("/proc/cpuinfo") as f:
@@ -185,8 +216,8 @@ def cpu_baseline(model_name, budget_s=20.0):
             "batch_128": {"value": v128, "steps": n128, "seconds": t128}, "batch_4": {"value": v4, "steps": n4, "seconds": t4},
             "threads_note": "16 torch threads: the best of 8/16/32/64/128 on this host class (tools/cpu_baseline_threads.py: 6.5 / 8.5 / 7.4 / "
                             "3.2 / 1.6 samples/s; all 256 logical CPUs are slower, torch's fork/join dominates)",
-            "sample": f"fp32 torch CPU restatement of the reference step (oracle/dig_oracle.py), same model/recipe: {n128} step at batch 128 "
-                      f"(`value`), {n4} steps at batch 4 (BASELINE configs[0]), 1 warm-up step"}
+            "sample": f"fp32 torch CPU restatement of the reference step (oracle/dig_oracle.py), same model/recipe: {n128} warm timed steps at batch 128 "
+                      f"(`value`; one untimed step at that batch first), {n4} steps at batch 4 (BASELINE configs[0])"}
 
 
 def main():
@@ -308,26 +339,33 @@ def main():
                    "replays": model._step_graph.replays, "note": "opt-in (DIG_STEP_GRAPH=1): same launches, bit-identical results, one "
                    "hipGraphLaunch per step; ROCm's graph executor runs the two-branch graph slower than the two eager streams"}
         model.step_graph = False
-    # ---- roofline of the dominant kernel: one extra, instrumented step (outside the timed region)
-    # (EVERY rank runs these two steps -- they contain the step's collectives; only rank 0 instruments its launches)
+    # ---- roofline of the dominant kernel family: instrumented extra steps (outside the timed region)
+    # (EVERY rank runs these steps -- they contain the step's collectives; only rank 0 instruments its launches)
+    # `roofline.frac` = the family's algorithmic FLOP / its launch durations IN THE STEP (both streams running, as in the timed region and
+    # under rocprofv3); the same launches one at a time (stream overlap off) are reported beside it as `roofline.alone`.
     roof = None
     import contextlib
-    model.overlap_streams = False                     # kernels one at a time, so event brackets time single launches
-    model.step_graph = False                          # (and launched eagerly: a replayed graph has no per-launch brackets)
-    run(1, a.warmup + a.steps)                        # one plain step in this mode first: the caller's stream pool gets the blocks the
+    model.step_graph = False                          # (launched eagerly: a replayed graph has no per-launch brackets)
+    pos = a.warmup + a.steps
+    run(1, pos)
+    probe_in = GemmProbe() if rank == 0 else contextlib.nullcontext()
+    with probe_in:
+        run(2, pos + 1)
+    model.overlap_streams = False                     # kernels one at a time
+    run(1, pos + 3)                                   # one plain step in this mode first: the caller's stream pool gets the blocks the
     probe = GemmProbe() if rank == 0 else contextlib.nullcontext()   # high-priority stream's pool held, so no hipMalloc sits inside a bracket
     with probe:
-        run(2, a.warmup + a.steps + 1)
+        run(2, pos + 4)
     model.overlap_streams = True
     if rank == 0:
-        summ = probe.summary()
-        dom = max(summ, key=lambda k: summ[k]["seconds"])
-        d = summ[dom]
+        summ_in, summ = probe_in.summary(), probe.summary()
+        dom = max(summ_in, key=lambda k: summ_in[k]["seconds"])
+        d, da = summ_in[dom], summ.get(dom, summ_in[dom])
         tf = d["flops"] / d["seconds"] / 1e12
         gbs = d["bytes"] / d["seconds"] / 1e9
         # HBM bytes per launch: rocprofv3 --pmc passes (FETCH_SIZE x2 per the gfx950 correction, WRITE_SIZE) over this same command,
-        # collected with tools/collect_pmc.sh and committed with the hash of the library they were measured on; reported only while
-        # that hash still matches the library this run loaded
+        # collected with tools/collect_profiles.sh and committed with the hash of the kernel sources they were measured on; reported only
+        # while that hash still matches the sources this run was built from
         traffic, traffic_src, step_bytes = None, None, None
         try:
             from dig_amd import build as dig_build
@@ -346,20 +384,22 @@ def main():
         # the bounding roofline of this path is bf16 MFMA; the HBM view of the same launches is kept beside it
         mfma_view = {"achieved": tf, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": tf / (PEAK_BF16 / 1e12)}
         hbm_view = {"achieved": gbs, "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": gbs / (PEAK_HBM / 1e9)}
-        # which roof bounds the dominant family: the larger of its MFMA time at 2.5 PFLOP/s and its HBM time at 8 TB/s on algorithmic work
-        bound = "mfma" if d["flops"] / PEAK_BF16 >= d["bytes"] / PEAK_HBM else "hbm"
-        kname = ("dig_mlp_chain_fwd (mlp_chain_kernel: fc1 -> GELU -> fc2 + residual in one launch, S-wave / O-wave role split, v_mfma_f32_32x32x16_bf16)"
-                 if dom == "mlp_chain" else
-                 f"dig_gemm_bf16[{dom}] (gemm_kernel / gemm_wide_kernel / gemm_pwide_kernel, v_mfma_f32_32x32x16_bf16, fused bias/GELU/residual epilogues)")
-        roof = {"bound": bound, **(mfma_view if bound == "mfma" else hbm_view), "traffic": traffic,
-                "kernel": kname,
+        tfa = da["flops"] / da["seconds"] / 1e12
+        kname = KERNEL_TEXT.get(dom, f"dig_gemm_bf16[{dom}] (gemm_kernel / gemm_wide_kernel / gemm_pwide_kernel, v_mfma_f32_32x32x16_bf16, fused bias/GELU/residual epilogues)")
+
+        def by_variant(sm):
+            return {k: {"TFLOP/s": v["flops"] / v["seconds"] / 1e12, "GB/s": v["bytes"] / v["seconds"] / 1e9,
+                        "ms_per_step": v["seconds"] / 2 * 1e3, "launches_per_step": v["launches"] // 2, "avg_launch_us": v["seconds"] / v["launches"] * 1e6}
+                    for k, v in sm.items()}
+        roof = {"bound": "mfma", **mfma_view, "traffic": traffic,
+                "kernel": kname, "measured": "HIP events around every launch of the family on its launch stream, in two extra steps with both streams running (in-step durations)",
                 "traffic_source": traffic_src,
-                "mfma": mfma_view, "hbm": hbm_view, "step_hbm_bytes": step_bytes,
+                "hbm": hbm_view, "step_hbm_bytes": step_bytes,
                 "flops_per_launch": d["flops"] / d["launches"], "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
                 "avg_launch_us": d["seconds"] / d["launches"] * 1e6, "launches_per_step": d["launches"] // 2,
-                "by_variant": {k: {"TFLOP/s": v["flops"] / v["seconds"] / 1e12, "GB/s": v["bytes"] / v["seconds"] / 1e9,
-                                   "ms_per_step": v["seconds"] / 2 * 1e3, "launches_per_step": v["launches"] // 2}
-                               for k, v in summ.items()}}
+                "alone": {"achieved": tfa, "unit": "TFLOP/s", "frac": tfa / (PEAK_BF16 / 1e12), "avg_launch_us": da["seconds"] / da["launches"] * 1e6,
+                          "note": "the same launches with the stream overlap off (one kernel at a time)"},
+                "by_variant": by_variant(summ_in), "by_variant_alone": by_variant(summ)}
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

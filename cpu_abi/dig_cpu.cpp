@@ -1174,7 +1174,11 @@ int dig_wgrad_group_effective_splits(int R, int splits) {
   const int per = dig_wgrad_group_rows_per_split(R, splits);
   return per ? (R + per - 1) / per : 0;
 }
-long long dig_wgrad_group_slab_bytes(int total_tiles, int splits, int fn) { return (long long)total_tiles * splits * 128 * 128 * fn * 4; }
+long long dig_wgrad_group_slab_bytes(int total_tiles, int splits, int fn, int wa) { return (long long)total_tiles * splits * 128 * wa * 128 * fn * 4; }
+int dig_wgrad_group_tiles(int I, int J, int fn, int wa) {
+  if (I <= 0 || J <= 0 || (fn != 2 && fn != 3) || (wa != 1 && wa != 2) || (I % 128) || (J % (128 * fn))) return 0;
+  return ((I + 128 * wa - 1) / (128 * wa)) * (J / (128 * fn));
+}
 int dig_wgrad_group_plan(const int* tiles_per_prob, int n_probs, int R, int max_wg, int* splits_out, unsigned* map_out, int max_out) {
   if (!tiles_per_prob || !map_out || !splits_out || n_probs < 1 || n_probs > DIG_WGRAD_MAX_PROBS || R < 64 || (R % 64) || max_wg < 8) return DIG_ERR_ARG;
   int tiles = 0;
@@ -1214,12 +1218,12 @@ int dig_wgrad_group_plan(const int* tiles_per_prob, int n_probs, int R, int max_
   }
 }
 int dig_wgrad_group(const dig_wgrad_prob_t* probs, int n_probs, const dig_wgrad_prob_t* fold_probs, int n_fold, int R, int splits,
-                    const unsigned* wg_map, int n_wg, float* slabs, const float* fold_slabs, int fold_splits, int fn, hipStream_t) {
+                    const unsigned* wg_map, int n_wg, float* slabs, const float* fold_slabs, int fold_splits, int fn, int wa, hipStream_t) {
   if (n_probs < 0 || n_probs > DIG_WGRAD_MAX_PROBS || n_fold < 0 || n_fold > DIG_WGRAD_MAX_PROBS || (n_probs == 0 && n_fold == 0)) return DIG_ERR_ARG;
-  if (fn != 2 && fn != 3) return DIG_ERR_UNSUPPORTED;
+  if ((fn != 2 && fn != 3) || (wa != 1 && wa != 2)) return DIG_ERR_UNSUPPORTED;
   if (n_wg < 1 || (n_probs > 0 && (!probs || !wg_map || !slabs || R < 64 || (R % 64) || splits < 1))) return DIG_ERR_ARG;
   if (n_fold > 0 && (!fold_probs || !fold_slabs || fold_splits < 1)) return DIG_ERR_ARG;
-  const int TJ = 128 * fn;
+  const int TJ = 128 * fn, TI = 128 * wa;
   auto check = [&](const dig_wgrad_prob_t* q, int n, bool operands, std::vector<int>& tile0) {
     int tiles = 0;
     for (int k = 0; k < n; ++k) {
@@ -1230,7 +1234,7 @@ int dig_wgrad_group(const dig_wgrad_prob_t* probs, int n_probs, const dig_wgrad_
         if (!aligned16(q[k].A) || !aligned16(q[k].B) || (q[k].lda & 7) || (q[k].ldb & 7) || q[k].lda < q[k].I || q[k].ldb < q[k].J) return (int)DIG_ERR_ALIGN;
       }
       tile0.push_back(tiles);
-      tiles += (q[k].I / 128) * (q[k].J / TJ);
+      tiles += ((q[k].I + TI - 1) / TI) * (q[k].J / TJ);
     }
     tile0.push_back(tiles);
     return (int)DIG_OK;
@@ -1241,7 +1245,7 @@ int dig_wgrad_group(const dig_wgrad_prob_t* probs, int n_probs, const dig_wgrad_
   rc = check(fold_probs, n_fold, false, f0);
   if (rc) return rc;
   if (n_probs && dig_wgrad_group_effective_splits(R, splits) != splits) return DIG_ERR_ARG;
-  const size_t SLAB = (size_t)128 * TJ;
+  const size_t SLAB = (size_t)TI * TJ;
   // fold of the previous call's slabs (split order)
   for (int k = 0; k < n_fold; ++k) {
     const dig_wgrad_prob_t& q = fold_probs[k];
@@ -1249,11 +1253,12 @@ int dig_wgrad_group(const dig_wgrad_prob_t* probs, int n_probs, const dig_wgrad_
     for (int T = f0[k]; T < f0[k + 1]; ++T) {
       const int lt = T - f0[k], ti = lt / tj_n, tj = lt % tj_n;
 #pragma omp parallel for
-      for (int il = 0; il < 128; ++il)
+      for (int il = 0; il < TI; ++il)
         for (int jl = 0; jl < TJ; ++jl) {
+          const int i = ti * TI + il, j = tj * TJ + jl;
+          if (i >= q.I) continue;
           float s = 0.f;
           for (int sp = 0; sp < fold_splits; ++sp) s += fold_slabs[((size_t)T * fold_splits + sp) * SLAB + (size_t)il * TJ + jl];
-          const int i = ti * 128 + il, j = tj * TJ + jl;
           if (q.trans_out) q.out[(size_t)j * q.ldo + i] += s; else q.out[(size_t)i * q.ldo + j] += s;
         }
     }
@@ -1274,10 +1279,11 @@ int dig_wgrad_group(const dig_wgrad_prob_t* probs, int n_probs, const dig_wgrad_
     const int rbeg = split * per, rend = std::min(R, rbeg + per);
     float* slab = slabs + ((size_t)tile * splits + split) * SLAB;
 #pragma omp parallel for
-    for (int il = 0; il < 128; ++il) {
+    for (int il = 0; il < TI; ++il) {
       std::vector<float> acc(TJ, 0.f);
+      if (ti * TI + il >= q.I) { std::memcpy(slab + (size_t)il * TJ, acc.data(), (size_t)TJ * 4); continue; }
       for (int r = rbeg; r < rend; ++r) {
-        const float a = bf2f(A[(size_t)r * q.lda + ti * 128 + il]);
+        const float a = bf2f(A[(size_t)r * q.lda + ti * TI + il]);
         const bf16_t* brow = B + (size_t)r * q.ldb + tj * TJ;
         for (int jl = 0; jl < TJ; ++jl) acc[jl] += a * bf2f(brow[jl]);
       }

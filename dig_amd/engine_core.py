@@ -23,6 +23,7 @@ FUSED_QV_BIAS_SUMS = os.environ.get("DIG_FUSED_QV_BIAS", "1") != "0"
 # weight gradients of an encoder block on the grouped kernel (csrc/wgrad.hip): "block" = one launch per block (default: the block's
 # accumulators are dumped once), "pair" = MLP pair | attention pair, "off" = the tiled split-R launches + their slab sums
 WGRAD_GROUPING = os.environ.get("DIG_WGRAD_GROUPING", "block")
+BWD_SINGLE_STREAM = os.environ.get("DIG_BWD_SINGLE", "0") == "1"    # lab switch: the whole backward on the caller's stream (sum of solo kernel times)
 
 
 class LocalComm:
@@ -160,7 +161,7 @@ class _Step:
     def _streams(self, dev):
         M = self.m
         main = torch.cuda.current_stream(dev)
-        side = M._side_stream(dev) if getattr(M, "overlap_streams", True) else main
+        side = M._side_stream(dev) if (getattr(M, "overlap_streams", True) and not BWD_SINGLE_STREAM) else main
         return main, side
 
     def _on_side(self, dev, fn, *tensors):

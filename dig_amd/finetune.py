@@ -497,6 +497,12 @@ class _TrainStep:
                                self.g("encoder.norm.bias"))
         # ---- encoder (same chain as the pre-training backward, one view, no masking)
         scale = (D // H) ** -0.5
+        # the four weight gradients of a block as ONE grouped launch (csrc/wgrad.hip), folded into the gradient arena by the next block's
+        # launch / the flush below -- as in the pre-training backward (engine_core.encoder_backward)
+        Rg = self.B * N
+        grouped = (ops.WGRAD_GROUP and not FT_BATCH_REDUCE and
+                   all(ops.wgrad_group_route(o, i_, Rg) is not None for o, i_ in ((M.F, D), (D, M.F), (3 * D, D), (D, D))))
+        grp = ops.WgradGroup(dev) if grouped else None
         for i in reversed(range(M.frozen_blocks, M.depth)):                   # (frozen blocks are a prefix: the chain stops above them)
             b = f"encoder.blocks.{i}."
             x, ln1, mu1, rs1, qkv, ctx, lse, x_mid, ln2, mu2, rs2, pre, act = self.enc_saved[i]
@@ -509,13 +515,21 @@ class _TrainStep:
             red = ops.GradReduceBatch() if FT_BATCH_REDUCE else None
             wg = red.wgrad if red else ops.linear_wgrad
             csum = red.colsum_partials if red else ops.colsum_partials
+            held = []
+            if grp:
+                def side_wg(dy_, x_, dw_):
+                    assert grp.add(dy_, x_, dw_)
+                    held.extend((dy_, x_))
+            else:
+                def side_wg(dy_, x_, dw_):
+                    self.side(lambda: wg(dy_, x_, dw_), dy_, x_)
             dz = ops.dropout_apply(dx, ds["mlp"])
             if ds["mlp"] is not None:
                 self.side(lambda: ops.colsum(dz, self.g(b + "mlp.fc2.bias")), dz)
-            self.side(lambda: wg(dz, act, self.g(b + "mlp.fc2.weight")), dz, act)
+            side_wg(dz, act, self.g(b + "mlp.fc2.weight"))
             dact, bparts = ops.linear_dgrad(dz, self.w(b + "mlp.fc2.weight"), gelu_pre=pre, colsum=True)
             self.side(lambda: csum(bparts, self.g(b + "mlp.fc1.bias")), bparts)
-            self.side(lambda: wg(dact, ln2, self.g(b + "mlp.fc1.weight")), dact, ln2)
+            side_wg(dact, ln2, self.g(b + "mlp.fc1.weight"))
             dln2 = ops.linear_dgrad(dact, self.w(b + "mlp.fc1.weight"))
             dx_mid, fin2, ws2 = ops.layernorm_bwd(dln2, x_mid, self.p(b + "norm2.weight"), self.p(b + "norm2.bias"), mu2, rs2, dx,
                                                   self.g(b + "norm2.weight"), self.g(b + "norm2.bias"), out=dln2,
@@ -528,16 +542,20 @@ class _TrainStep:
             dz = ops.dropout_apply(dx_mid, ds["proj"])
             if ds["proj"] is not None:
                 self.side(lambda: ops.colsum(dz, self.g(b + "attn.proj.bias")), dz)
-            self.side(lambda: wg(dz, ctx, self.g(b + "attn.proj.weight")), dz, ctx)
+            side_wg(dz, ctx, self.g(b + "attn.proj.weight"))
             dctx = ops.linear_dgrad(dz, self.w(b + "attn.proj.weight"))
             # q_bias / v_bias gradients leave the attention kernel as per-image partial sums (no pass over the 150 MB dqkv)
             if FT_FUSED_QV:
                 dqkv, qs, vs = ops.attn_bwd(qkv, ctx, dctx, lse, self.B, H, D, scale, drop=ds["attn"], bias_sums=True)
-                self.side(lambda: (wg(dqkv, ln1, self.g(b + "attn.qkv.weight")), csum(qs, self.g(b + "attn.q_bias")),
-                                   csum(vs, self.g(b + "attn.v_bias"))), dqkv, ln1, qs, vs)
+                side_wg(dqkv, ln1, self.g(b + "attn.qkv.weight"))
+                if grp:
+                    self.side(grp.launch, *held)
+                self.side(lambda: (csum(qs, self.g(b + "attn.q_bias")), csum(vs, self.g(b + "attn.v_bias"))), qs, vs)
             else:
                 dqkv = ops.attn_bwd(qkv, ctx, dctx, lse, self.B, H, D, scale, drop=ds["attn"])
-                self.side(lambda: wg(dqkv, ln1, self.g(b + "attn.qkv.weight")), dqkv, ln1)
+                side_wg(dqkv, ln1, self.g(b + "attn.qkv.weight"))
+                if grp:
+                    self.side(grp.launch, *held)
                 self.side(lambda: ops.colsum(dqkv, self.g(b + "attn.q_bias"), cols=D), dqkv)
                 self.side(lambda: ops.colsum(dqkv[:, 2 * D:], self.g(b + "attn.v_bias"), cols=D))
             dln1 = ops.linear_dgrad(dqkv, self.w(b + "attn.qkv.weight"), out=dctx)
@@ -550,6 +568,8 @@ class _TrainStep:
                 self.side(red.flush, *red.tensors())
             else:
                 self.side(fin1, ws1)
+        if grp:
+            self.side(grp.flush)                                                # the last block's slabs: folded by a fold-only launch
         if "encoder.patch_embed.proj.weight" in M.frozen:
             return
         dx = ops.dropout_apply(dx, self.ds_pos, out=dx)

@@ -83,7 +83,9 @@ MLP_CHAIN = os.environ.get("DIG_MLP_CHAIN", "1") != "0"      # fused fc1 -> GELU
 # 256 VGPRs, up to 144 KiB of LDS), so nothing of the other HIP stream runs beside it: in the forward that is a net win (24.89 -> 24.03
 # ms per step with both branches fused), in the backward the weight-gradient stream loses more than the fused data gradient gains
 # (25.73 ms with bit 2 alone, 24.87 with all three; one box, 40 timed steps each) -- default 3.
-MLP_CHAIN_MASK = int(os.environ.get("DIG_MLP_CHAIN_MASK", "3"))
+# Round 4: with the weight gradients of a block as ONE grouped launch (csrc/wgrad.hip) that owns the chip as well, nothing is left for the
+# fused backward to starve: 22.92 -> 22.63 ms with bit 2 (two A/B pairs on one box), 22.38 with the 256x192 data-gradient tiles on top -- default 7.
+MLP_CHAIN_MASK = int(os.environ.get("DIG_MLP_CHAIN_MASK", "7"))
 # the block's norm2 and the next block's norm1 inside the forward chain launch (dig_mlp_chain_fwd_ln)
 MLP_CHAIN_LN = os.environ.get("DIG_MLP_CHAIN_LN", "1") != "0"
 # attention output projection + residual + norm2 on the row-panel GEMM (dig_panel_gemm_ln_fwd) instead of the tiled GEMM + norm2 inside the chain
@@ -195,10 +197,24 @@ def linear_dgrad(dy, w, out=None, gelu_pre=None, colsum=False, drop=None):
     # few rows (the BN-MLP heads on pooled features): 128x64 tiles double the workgroup count (tools/gpu_head_gemm_probe.py).
     # (The 256x192 tile is 8-20 % faster for the tall 384-wide dgrads alone -- tools/experiments/gpu_dgrad_tile_probe.py -- but not in
     #  the step: 25.69 vs 25.77 ms over three A/B pairs; the small 128x128 workgroups share the CUs better with the weight-gradient stream.)
-    return gemm(dy, w, dy.shape[0], w.shape[1], w.shape[0], tb=True, out=out, bk=221 if dy.shape[0] <= 2048 else DGRAD_BK)
+    rows, J = dy.shape[0], w.shape[1]
+    if rows <= 2048:
+        bk = 221
+    elif DGRAD_BK >= 0:
+        bk = DGRAD_BK
+    elif rows >= 8192 and drop is None and J % 192 == 0 and J % 256 != 0:
+        bk = 264                                        # 256x192 tiles: exact for the 384-wide data gradients of ViT-S
+    elif rows >= 8192 and drop is None and J % 256 == 0:
+        bk = 244                                        # 256x256 (D = 512)
+    else:
+        bk = 0
+    return gemm(dy, w, rows, J, w.shape[0], tb=True, out=out, bk=bk)
 
 
-DGRAD_BK = int(os.environ.get("DIG_DGRAD_BK", "0"))                 # tile code of the tall data-gradient GEMMs (0 = 128x128 / BK 32)
+# Tile code of the tall data-gradient GEMMs: -1 (default) = by width: 256x192 / 256x256 tiles.  Rounds 1-3 kept 128x128 / BK 32 (code 0) here
+# because the small workgroups shared the CUs with the weight-gradient stream's 128x128 tiles; with the grouped weight-gradient launch the
+# backward is a sum of solo kernel times and the big tile's 8-20 % solo advantage shows in the step (22.63 -> 22.38 ms, two A/B pairs).
+DGRAD_BK = int(os.environ.get("DIG_DGRAD_BK", "-1"))
 WGRAD_TALL = tuple(int(v) for v in os.environ.get("DIG_WGRAD_TALL", "16,32").split(","))   # (R-splits, tile code) of the 36-tile weight gradients
 
 
@@ -325,7 +341,8 @@ def linear_wgrad(dy, x, dw, rows=None):
 
 # ---- grouped weight gradients (csrc/wgrad.hip): the Linear layers of a transformer block in ONE launch, slabs folded by the next launch
 WGRAD_GROUP = os.environ.get("DIG_WGRAD_GROUP", "1") != "0"
-WGRAD_GROUP_SLOTS = int(os.environ.get("DIG_WGRAD_SLOTS", "512"))     # workgroups per launch: one round at two per CU on 256 CUs
+WGRAD_GROUP_WA = int(os.environ.get("DIG_WGRAD_WA", "2"))            # 1: 128-row tiles, 4 waves, two workgroups per CU;  2: 256-row tiles, 8 waves, one per CU
+WGRAD_GROUP_SLOTS = int(os.environ.get("DIG_WGRAD_SLOTS", "0")) or 512 // WGRAD_GROUP_WA     # workgroups per launch: one round on 256 CUs
 _wg_plans, _wg_slabs = {}, {}
 
 
@@ -371,7 +388,7 @@ class WgradGroup:
         return True
 
     def _plan(self, tiles):
-        key = (tuple(tiles), self.rows, WGRAD_GROUP_SLOTS, str(self.dev))
+        key = (tuple(tiles), self.rows, WGRAD_GROUP_SLOTS, WGRAD_GROUP_WA, str(self.dev))
         pl = _wg_plans.get(key)
         if pl is None:
             tp = (ctypes.c_int * len(tiles))(*tiles)
@@ -408,15 +425,17 @@ class WgradGroup:
             return
         fn = self.fn
         tj = 128 * fn
-        tiles = [((dw.shape[1] if t else dw.shape[0]) // 128) * ((dw.shape[0] if t else dw.shape[1]) // tj) for _, _, dw, t in self.cur]
+        wa = WGRAD_GROUP_WA
+        tiles = [L.lib().dig_wgrad_group_tiles(int(dw.shape[1] if t else dw.shape[0]), int(dw.shape[0] if t else dw.shape[1]), fn, wa)
+                 for _, _, dw, t in self.cur]
         if self.cur:
             splits, n_wg, wmap = self._plan(tiles)
-            slabs = self._slabs(sum(tiles) * splits * 128 * tj * 4)
+            slabs = self._slabs(sum(tiles) * splits * 128 * wa * tj * 4)
         else:
             splits, n_wg, wmap, slabs = 1, WGRAD_GROUP_SLOTS, None, None
         pend = self.pending
         L.call("dig_wgrad_group", self._structs(self.cur), len(self.cur), self._structs(pend[0]) if pend else None, len(pend[0]) if pend else 0,
-               int(self.rows), splits, L.ptr(wmap), n_wg, L.ptr(slabs), L.ptr(pend[1]) if pend else None, pend[2] if pend else 1, fn, L.stream())
+               int(self.rows), splits, L.ptr(wmap), n_wg, L.ptr(slabs), L.ptr(pend[1]) if pend else None, pend[2] if pend else 1, fn, wa, L.stream())
         # the fold list keeps the gradient tensors only (operands are dead once this launch has run)
         self.pending = ([(None, None, dw, t) for _, _, dw, t in self.cur], slabs, splits) if self.cur else None
         self.cur = []

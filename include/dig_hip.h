@@ -79,7 +79,11 @@ int dig_reduce_partials_multi(const dig_reduce_seg_t* segs, int n_segs, hipStrea
  *                                                         B_p [R, ldb] bf16 = the narrow operand (J_p columns, J_p % (128 fn) == 0)
  *     trans_out 0: out_p is [I_p, ldo] fp32 (fc1, qkv, proj: A = dy, B = x);  1: out_p is [J_p, ldo] (fc2: A = x, B = dy)
  * fn = 3 (narrow width a multiple of 384: ViT-S) or 2 (a multiple of 256: D = 512), one value per launch; R % 64 == 0.
- * Tiles of 128 x 128 fn (4 waves, each 4 x fn MFMA accumulators) x S R-splits = one round of workgroups at two per CU; each
+ * wa = 1: tiles of 128 x 128 fn, 4 waves (each 4 x fn MFMA accumulators), two workgroups per CU (max_wg 512 on MI355X);
+ * wa = 2: tiles of 256 x 128 fn, 8 waves, one workgroup per CU (max_wg 256): 0.0065 instead of 0.0104 operand bytes per FLOP from L2,
+ * a 7- / 8-slot LDS ring; the last tile of a problem whose I is not a multiple of 256 is computed in full and its surplus rows dropped.
+ * One (fn, wa) pair per chain of launches (a fold reads the slab layout of the launch that wrote it).
+ * Tiles x S R-splits = one round of workgroups; each
  * workgroup leaves its accumulators as one fp32 slab, and the slabs of launch n are summed in split order (deterministic: no
  * atomics) and added to out_p by launch n + 1 in its prologue -- the kernel boundary is the only synchronisation.  So:
  *     dig_wgrad_group(probs_n, n, probs_{n-1}, m, ...)  computes the partial products of probs_n into `slabs` and folds `fold_slabs`
@@ -97,10 +101,11 @@ int dig_wgrad_group_supported(int I, int J, int R);               /* 1: a proble
 int dig_wgrad_group_fn(int J);                                    /* 3, 2, or 0 (narrow width not supported) */
 int dig_wgrad_group_rows_per_split(int R, int splits);
 int dig_wgrad_group_effective_splits(int R, int splits);
-long long dig_wgrad_group_slab_bytes(int total_tiles, int splits, int fn);
+long long dig_wgrad_group_slab_bytes(int total_tiles, int splits, int fn, int wa);
+int dig_wgrad_group_tiles(int I, int J, int fn, int wa);           /* tiles of one problem (0: sizes not supported) */
 int dig_wgrad_group_plan(const int* tiles_per_prob, int n_probs, int R, int max_wg, int* splits_out, unsigned* map_out, int max_out);
 int dig_wgrad_group(const dig_wgrad_prob_t* probs, int n_probs, const dig_wgrad_prob_t* fold_probs, int n_fold, int R, int splits,
-                    const unsigned* wg_map, int n_wg, float* slabs, const float* fold_slabs, int fold_splits, int fn,
+                    const unsigned* wg_map, int n_wg, float* slabs, const float* fold_slabs, int fold_splits, int fn, int wa,
                     hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------

@@ -517,3 +517,120 @@ def test_mlp_chain_fwd_bwd(dev, R, Fh):
     assert rel(dpre, dact) < 2e-3 and rel(dx, ops.linear_dgrad(dact, w1)) < 4e-3
     dx2, dpre2, parts2 = ops.mlp_chain_bwd(dy, w2t, pre, w1t)
     assert torch.equal(dx, dx2) and torch.equal(dpre, dpre2) and torch.equal(parts, parts2)     # bit-reproducible
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# Exact-arithmetic parity: operands drawn from small integers / powers of two, so that every product and every fp32 partial sum is
+# exact WHATEVER the summation order, and the only rounding left is the final fp32 -> bf16 round-to-nearest-even -- which torch's
+# `.bfloat16()` of the exact fp32 result performs identically.  These tests have no tolerance to tune: `torch.equal` or fail.
+def _ints(gen, shape, lo, hi, dev, scale=1.0):
+    return (torch.randint(lo, hi + 1, shape, generator=gen).float() * scale).bfloat16().to(dev)
+
+
+@pytest.mark.parametrize("bk", [0, 32, 64, 244, 264, 544, 564, 212, 221])
+@pytest.mark.parametrize("I,J,R", [(512, 384, 256), (8192, 1152, 384), (1000, 520, 192)])
+def test_gemm_exact_arithmetic(dev, bk, I, J, R):
+    from dig_amd import ops
+    cpu_limit(dev, I * J * R * (1 if bk == 0 else 1e9), 4e9)
+    g = torch.Generator().manual_seed(I + J + R + bk)
+    x, w = _ints(g, (I, R), -2, 2, dev), _ints(g, (J, R), -2, 2, dev, 0.5)
+    bias = torch.randint(-8, 9, (J,), generator=g).float().to(dev)
+    res = _ints(g, (I, J), -16, 16, dev)
+    h = x.float() @ w.float().t()                                      # exact: |h| <= 2 * 1 * R, multiples of 0.5
+    # forward epilogues: bias, power-of-two alpha on a column range, residual; bf16 and fp32 outputs; the pre-activation side output
+    assert torch.equal(ops.gemm(x, w, I, J, R, bias=bias, resid=res, bk=bk), (h + bias + res.float()).bfloat16())
+    ac = (J // 16) * 8
+    ref = h + bias
+    ref[:, :ac] *= 0.125
+    assert torch.equal(ops.gemm(x, w, I, J, R, bias=bias, alpha=0.125, alpha_cols=ac, out_kind=ops.OUT_F32, bk=bk), ref)
+    pre = torch.empty(I, J, device=dev, dtype=torch.bfloat16)
+    ops.gemm(x, w, I, J, R, bias=bias, pre=pre, act=1, bk=bk)
+    assert torch.equal(pre, (h + bias).bfloat16())
+    # data gradient (transpose-read weight operand)
+    if J % 64 == 0 and bk not in (212, 544, 564):
+        dy = _ints(g, (I, J), -2, 2, dev)
+        assert torch.equal(ops.gemm(dy, w, I, R, J, tb=True, bk=bk), (dy.float() @ w.float()).bfloat16())
+    # weight gradient: split-R slabs + ordered sum, fp32 -- exact and therefore equal to torch bit for bit
+    if bk in (0, 32, 64, 244, 264):
+        dy = _ints(g, (I, J), -2, 2, dev)
+        sp = ops.L.lib().dig_gemm_effective_splits(I, 4)
+        ws = torch.empty(sp, J, R, device=dev)
+        ops.gemm(dy, x, J, R, I, ta=True, tb=True, out=ws, out_kind=ops.OUT_F32_PARTIAL, splits=sp, ldc=R, bk=bk or 32)
+        assert torch.equal(ws.sum(0), dy.float().t() @ x.float())
+
+
+@pytest.mark.parametrize("wa", [1, 2])
+@pytest.mark.parametrize("R,D,Fh", [(256, 384, 1536), (16384, 384, 1536), (4096, 512, 2048)])
+def test_wgrad_group_exact_arithmetic(dev, wa, R, D, Fh):
+    """Integer operands: every split count, tile form and fold order of the grouped weight-gradient kernel must give THE fp32 result."""
+    from dig_amd import ops
+    cpu_limit(dev, 2.0 * R * D * (2 * Fh + 4 * D), 5e9)
+    g = torch.Generator().manual_seed(R + D + wa)
+    dact, act, ln2, dx = _ints(g, (R, Fh), -2, 2, dev), _ints(g, (R, Fh), -2, 2, dev), _ints(g, (R, D), -2, 2, dev, 0.5), _ints(g, (R, D), -2, 2, dev, 0.5)
+    dqkv, ln1, ctx, dxm = _ints(g, (R, 3 * D), -2, 2, dev), _ints(g, (R, D), -2, 2, dev, 0.5), _ints(g, (R, D), -2, 2, dev), _ints(g, (R, D), -2, 2, dev, 0.5)
+    layers = [(dx, act, (D, Fh)), (dact, ln2, (Fh, D)), (dxm, ctx, (D, D)), (dqkv, ln1, (3 * D, D))]
+    saved = ops.WGRAD_GROUP_WA, ops.WGRAD_GROUP_SLOTS
+    ops.WGRAD_GROUP_WA, ops.WGRAD_GROUP_SLOTS = wa, 512 // wa
+    try:
+        dws = [torch.full(sh, 3.0, device=dev) for _, _, sh in layers]
+        grp = ops.WgradGroup(dev)
+        for (dy, x, _), dw in zip(layers, dws):
+            assert grp.add(dy, x, dw)
+        grp.launch(); grp.flush()
+        for (dy, x, _), dw in zip(layers, dws):
+            assert torch.equal(dw, 3.0 + dy.float().t() @ x.float())
+    finally:
+        ops.WGRAD_GROUP_WA, ops.WGRAD_GROUP_SLOTS = saved
+
+
+@pytest.mark.parametrize("R", [128, 4096, 1000])
+def test_mlp_chain_fwd_exact_arithmetic(dev, R):
+    """Fused fc1 -> GELU -> fc2 with every pre-activation an integer in GELU's linear tail (x >= 8: gelu(x) rounds to x in bf16, in the
+    kernel's polynomial and in torch alike): hidden values, both GEMMs, both biases and the residual are exact; the output is the
+    round-to-nearest-even of the exact fp32 value."""
+    from dig_amd import ops
+    D, Fh = 384, 1536
+    if not ops.mlp_chain_supported(D, Fh):
+        pytest.skip("fused MLP kernel not built for this width")
+    cpu_limit(dev, 4.0 * R * D * Fh, 4e9)
+    g = torch.Generator().manual_seed(R)
+    # x has 8 nonzeros of +-1 per row, w1 in {-1, 0, 1}: |x w1^T| <= 8; b1 = 24 -> pre-activation in [16, 32]
+    x = torch.zeros(R, D)
+    idx = torch.stack([torch.randperm(D, generator=g)[:8] for _ in range(R)])
+    x.scatter_(1, idx, torch.randint(0, 2, (R, 8), generator=g).float() * 2 - 1)
+    x = x.bfloat16().to(dev)
+    w1 = _ints(g, (Fh, D), -1, 1, dev)
+    b1 = torch.full((Fh,), 24.0, device=dev)
+    # w2 sparse in {-1/8, 0, 1/8}: |hidden w2^T| <= 32 * 1536 / 8, partial sums multiples of 1/8: exact in fp32
+    w2 = (_ints(g, (D, Fh), -1, 1, dev).float() * (torch.rand(D, Fh, generator=g) < 0.05).to(dev) * 0.125).bfloat16()
+    b2 = torch.randint(-4, 5, (D,), generator=g).float().to(dev)
+    res = _ints(g, (R, D), -8, 8, dev)
+    pre_ref = x.float() @ w1.float().t() + b1
+    assert pre_ref.min().item() >= 16 and pre_ref.max().item() <= 32
+    ref = (pre_ref @ w2.float().t() + b2 + res.float()).bfloat16()
+    assert torch.equal(ops.mlp_chain_fwd(x, w1, b1, w2, b2, res), ref)
+    out, pre, act = ops.mlp_chain_fwd(x, w1, b1, w2, b2, res, save=True)
+    assert torch.equal(out, ref) and torch.equal(pre, pre_ref.bfloat16()) and torch.equal(act, pre_ref.bfloat16())
+
+
+def test_attention_exact_arithmetic(dev):
+    """One-hot queries / keys: a score is 256 where query and key share their hot channel and 0 elsewhere, so the softmax is exactly
+    uniform over the matching keys (exp(-256) underflows to 0 in fp32) and the context is the exact mean of their integer value rows."""
+    from dig_amd import ops
+    Bn, H = 2, 6
+    D = H * 64
+    g = torch.Generator().manual_seed(7)
+    qh = torch.randint(0, 64, (Bn, H, 256), generator=g)                  # hot channel of every query
+    kh = torch.arange(256).remainder(64).expand(Bn, H, 256).clone()      # key j is hot in channel j % 64: four keys per channel
+    for b in range(Bn):
+        for h in range(H):
+            kh[b, h] = kh[b, h][torch.randperm(256, generator=g)]
+    v = torch.randint(-8, 9, (Bn, H, 256, 64), generator=g).float() * 4.0  # multiples of 4: the mean of four rows is an integer
+    q = torch.zeros(Bn, H, 256, 64).scatter_(3, qh.unsqueeze(-1), 16.0)
+    k = torch.zeros(Bn, H, 256, 64).scatter_(3, kh.unsqueeze(-1), 16.0)
+    qkv = torch.stack([q, k, v], 0).permute(1, 3, 0, 2, 4).reshape(Bn * 256, 3 * D).bfloat16().to(dev)      # [image, token, (q|k|v), head, 64]
+    ctx, lse = ops.attn_fwd(qkv, Bn, H, D)
+    match = (qh.unsqueeze(-1) == kh.unsqueeze(-2)).float()                # [Bn, H, query, key]
+    ref = (match @ v) / match.sum(-1, keepdim=True)
+    assert torch.equal(ctx.float().cpu().view(Bn, 256, H, 64).permute(0, 2, 1, 3), ref)
+    assert (lse.cpu().view(Bn, H, 256) - (256.0 + math.log(4.0))).abs().max().item() < 1e-3

@@ -7,8 +7,12 @@ import csv, json, re, sys, collections
 
 
 def family(name):
+    if "mlp_chain_kernel<2" in name:
+        return "mlp_chain_bwd"
     if "mlp_chain_kernel" in name:
         return "mlp_chain"
+    if "wgrad_wide_kernel" in name or "wgrad_group_kernel" in name:
+        return "wgrad_group"
     if "gemm_pwide_kernel" in name:
         return "fwd"
     m = re.search(r"gemm(?:_wide|_persist)?_kernel<(true|false), (true|false)", name)
