@@ -72,9 +72,11 @@ def synth_batches(n, B, device, seed):
 
 class GemmProbe:
     """Times every matrix-core launch of a step -- dig_gemm_bf16, the fused MLP launches (dig_mlp_chain_fwd / _fwd_ln / _bwd) and the grouped
-    weight-gradient launch (dig_wgrad_group) -- with HIP events on the stream the launch goes to (torch's current stream at the call).
-    With the two-stream overlap left ON the brackets are the launches' durations IN THE STEP (what rocprofv3 reports for the same command);
-    with `model.overlap_streams = False` they are the durations of the kernels one at a time."""
+    weight-gradient launch (dig_wgrad_group) -- with the library's launch probe (dig_probe_start / dig_probe_stop, csrc/probe.hip): each
+    launch carries the start / stop events of hipExtLaunchKernel ON ITS LAUNCH STREAM, i.e. the kernel's own begin and end on the device,
+    which is what rocprofv3's kernel trace reports.  With the two-stream overlap left ON these are the durations IN THE STEP; with
+    `model.overlap_streams = False` the durations of the kernels one at a time.  The wrappers below only book what each launch computes
+    (family, algorithmic FLOP and bytes), in call order -- the order in which the probe returns the durations."""
 
     def __init__(self):
         from dig_amd import ops
@@ -83,21 +85,20 @@ class GemmProbe:
         self._saved = {}
 
     def _bracket(self, variant, flops, byt, fn):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        out = fn()
-        e1.record()
-        self.rec.append((variant, flops, byt, e0, e1))
-        return out
+        self.rec.append((variant, flops, byt))
+        return fn()
 
     def __enter__(self):
         ops = self.ops
         sv = self._saved
+        ops.L.call("dig_probe_start")
         sv["gemm"], sv["chain"], sv["chain_ln"], sv["chain_bwd"], sv["wg_launch"] = (ops.gemm, ops.mlp_chain_fwd, ops.mlp_chain_fwd_ln,
                                                                                       ops.mlp_chain_bwd, ops.WgradGroup.launch)
 
         def timed(A, B, I, J, R, **kw):
-            variant = ("wgrad" if kw.get("ta") else ("dgrad" if kw.get("tb") else "fwd"))
+            # family = operand form + tile code, i.e. one kernel template as rocprofv3 lists it (fwd:544 = gemm_pwide_kernel<4, ...>,
+            # dgrad:264 = gemm_wide_kernel<false, true, 0, 4, 3, ...>, ...; tools/pmc_traffic.py maps kernel names to the same keys)
+            variant = ("wgrad" if kw.get("ta") else ("dgrad" if kw.get("tb") else "fwd")) + ":" + str(kw.get("bk") or (64 if not (kw.get("ta") or kw.get("tb")) else 32))
             # algorithmic HBM bytes of the launch: both operands once, the output and the residual once (weight gradients: fp32
             # read-modify-write of dW).  NOT counted: the saved pre-activation of fc1 (an implementation choice of the backward),
             # the split-R slabs
@@ -116,7 +117,7 @@ class GemmProbe:
             # algorithmic HBM bytes of the fused fc1 -> GELU -> fc2 launch: x, residual and output rows once, both weight matrices once;
             # the online form also writes what the reference's autograd keeps for the backward (pre-activation and GELU output)
             byt = 2.0 * R * D * 3 + 2.0 * 2 * D * Fh + (2.0 * 2 * R * Fh if save else 0.0)
-            return self._bracket("mlp_chain", 4.0 * R * D * Fh, byt, lambda: sv["chain"](x, w1, b1, w2, b2, resid, save=save))
+            return self._bracket("mlp_chain_online" if save else "mlp_chain_momentum", 4.0 * R * D * Fh, byt, lambda: sv["chain"](x, w1, b1, w2, b2, resid, save=save))
         ops.mlp_chain_fwd = timed_chain
 
         def timed_chain_ln(x, ln_g, ln_b, eps, w1, b1, w2, b2, nln_g=None, nln_b=None, save=False, resid=None):
@@ -125,7 +126,7 @@ class GemmProbe:
             # the fused launch with its LayerNorms: raw rows in, output rows and the next block's normalised rows out, both weight matrices
             # once; the online form also writes what the reference's autograd keeps (norm2's output, the pre-activation, the GELU output)
             byt = 2.0 * R * D * (2 + (nln_g is not None)) + 2.0 * 2 * D * Fh + ((2.0 * R * D + 2.0 * 2 * R * Fh) if save else 0.0)
-            return self._bracket("mlp_chain", 4.0 * R * D * Fh, byt,
+            return self._bracket("mlp_chain_online" if save else "mlp_chain_momentum", 4.0 * R * D * Fh, byt,
                                  lambda: sv["chain_ln"](x, ln_g, ln_b, eps, w1, b1, w2, b2, nln_g, nln_b, save=save, resid=resid))
         ops.mlp_chain_fwd_ln = timed_chain_ln
 
@@ -142,7 +143,9 @@ class GemmProbe:
 
         def timed_wg_launch(grp):
             if not grp.cur:
-                return sv["wg_launch"](grp)
+                if grp.pending is None:
+                    return sv["wg_launch"](grp)
+                return probe._bracket("wgrad_fold", 0.0, 0.0, lambda: sv["wg_launch"](grp))     # the fold-only launch that ends a backward
             R = grp.rows
             fl = sum(2.0 * R * dw.shape[0] * dw.shape[1] for _, _, dw, _ in grp.cur)
             # grouped weight gradients: both operands of every problem once, fp32 read-modify-write of each dW (the slabs are not algorithmic)
@@ -152,24 +155,36 @@ class GemmProbe:
         return self
 
     def __exit__(self, *a):
+        import ctypes
         ops, sv = self.ops, self._saved
         ops.gemm, ops.mlp_chain_fwd, ops.mlp_chain_fwd_ln, ops.mlp_chain_bwd = sv["gemm"], sv["chain"], sv["chain_ln"], sv["chain_bwd"]
         ops.WgradGroup.launch = sv["wg_launch"]
+        torch.cuda.synchronize()
+        cap = len(self.rec) + 64
+        buf = (ctypes.c_float * cap)()
+        lib = ops.L.lib()
+        lib.dig_probe_stop.restype = ctypes.c_int
+        n = lib.dig_probe_stop(buf, cap)
+        # the fold-only launch of the grouped weight gradients (no problems) is a probed launch the wrappers do not book: it is the one
+        # dig_wgrad_group call per backward whose Python-side record is missing -- booked here as ("wgrad_fold", 0 FLOP)
+        if n != len(self.rec):
+            raise RuntimeError(f"launch probe: {n} probed launches, {len(self.rec)} booked")
+        self.us = [float(buf[i]) for i in range(n)]
 
     def summary(self):
-        torch.cuda.synchronize()
         agg = {}
-        for variant, fl, byt, e0, e1 in self.rec:
+        for (variant, fl, byt), us in zip(self.rec, self.us):
             d = agg.setdefault(variant, [0.0, 0.0, 0, 0.0])
             d[0] += fl
-            d[1] += e0.elapsed_time(e1) * 1e-3
+            d[1] += us * 1e-6
             d[2] += 1
             d[3] += byt
         return {k: {"flops": v[0], "seconds": v[1], "launches": v[2], "bytes": v[3]} for k, v in agg.items()}
 
 
 KERNEL_TEXT = {
-    "mlp_chain": "dig_mlp_chain_fwd (mlp_chain_kernel: fc1 -> GELU -> fc2 + residual (+ LayerNorms) in one launch, S-wave / O-wave role split, v_mfma_f32_32x32x16_bf16)",
+    "mlp_chain_online": "dig_mlp_chain_fwd_ln, online form (mlp_chain_kernel<1, true>: norm2 -> fc1 -> GELU -> fc2 + residual -> next norm1 in one launch, writes what the backward reads)",
+    "mlp_chain_momentum": "dig_mlp_chain_fwd_ln, momentum form (mlp_chain_kernel<0, true>: norm2 -> fc1 -> GELU -> fc2 + residual -> next norm1 in one launch, no side outputs)",
     "mlp_chain_bwd": "dig_mlp_chain_bwd (mlp_chain_kernel<2>: the MLP's two data gradients x GELU' in one launch)",
     "wgrad_group": "dig_wgrad_group (wgrad_wide_kernel / wgrad_group_kernel: the four weight gradients of a block in one launch, 4 x 3 MFMA blocks per wave, "
                    "LDS-DMA ring, slabs folded by the next launch)",
@@ -359,7 +374,8 @@ def main():
     model.overlap_streams = True
     if rank == 0:
         summ_in, summ = probe_in.summary(), probe.summary()
-        dom = max(summ_in, key=lambda k: summ_in[k]["seconds"])
+        # the dominant family = the one with the most kernel time in the step.  Families = kernel templates, as rocprofv3 lists them.
+        dom = max((k for k in summ_in if summ_in[k]["flops"] > 0), key=lambda k: summ_in[k]["seconds"])
         d, da = summ_in[dom], summ.get(dom, summ_in[dom])
         tf = d["flops"] / d["seconds"] / 1e12
         gbs = d["bytes"] / d["seconds"] / 1e9
@@ -385,14 +401,16 @@ def main():
         mfma_view = {"achieved": tf, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": tf / (PEAK_BF16 / 1e12)}
         hbm_view = {"achieved": gbs, "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": gbs / (PEAK_HBM / 1e9)}
         tfa = da["flops"] / da["seconds"] / 1e12
-        kname = KERNEL_TEXT.get(dom, f"dig_gemm_bf16[{dom}] (gemm_kernel / gemm_wide_kernel / gemm_pwide_kernel, v_mfma_f32_32x32x16_bf16, fused bias/GELU/residual epilogues)")
+        kname = KERNEL_TEXT.get(dom, f"dig_gemm_bf16[{dom}] (operand form : tile code of include/dig_hip.h; gemm_kernel / gemm_wide_kernel / gemm_pwide_kernel, "
+                                     "v_mfma_f32_32x32x16_bf16, fused bias/GELU/residual epilogues)")
 
         def by_variant(sm):
-            return {k: {"TFLOP/s": v["flops"] / v["seconds"] / 1e12, "GB/s": v["bytes"] / v["seconds"] / 1e9,
+            return {k: {"TFLOP/s": v["flops"] / max(v["seconds"], 1e-12) / 1e12, "GB/s": v["bytes"] / max(v["seconds"], 1e-12) / 1e9,
                         "ms_per_step": v["seconds"] / 2 * 1e3, "launches_per_step": v["launches"] // 2, "avg_launch_us": v["seconds"] / v["launches"] * 1e6}
                     for k, v in sm.items()}
         roof = {"bound": "mfma", **mfma_view, "traffic": traffic,
-                "kernel": kname, "measured": "HIP events around every launch of the family on its launch stream, in two extra steps with both streams running (in-step durations)",
+                "kernel": kname, "measured": "start / stop events of hipExtLaunchKernel on every launch of the family, on its launch stream (dig_probe_start / _stop), in two extra "
+                            "steps with both streams running: the kernels' device-side durations in the step, as rocprofv3's kernel trace reports them",
                 "traffic_source": traffic_src,
                 "hbm": hbm_view, "step_hbm_bytes": step_bytes,
                 "flops_per_launch": d["flops"] / d["launches"], "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],

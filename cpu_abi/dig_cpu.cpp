@@ -1076,6 +1076,15 @@ int dig_transpose_bf16(const void* src_, void* dst_, int rows, int cols, hipStre
   return DIG_OK;
 }
 
+int dig_transpose_bf16_multi(const void* const* srcs, void* const* dsts, int count, int rows, int cols, hipStream_t st) {
+  if (!srcs || !dsts || count < 1 || count > 32 || rows <= 0 || cols <= 0) return DIG_ERR_ARG;
+  for (int k = 0; k < count; ++k) {
+    const int rc = dig_transpose_bf16(srcs[k], dsts[k], rows, cols, st);
+    if (rc) return rc;
+  }
+  return DIG_OK;
+}
+
 int dig_gelu_bwd(const void* dact_, const void* pre_, void* dpre_, long long n, hipStream_t) {
   if (!dact_ || !pre_ || !dpre_ || n <= 0 || (n & 7)) return DIG_ERR_ARG;
   if (!aligned16(dact_) || !aligned16(pre_) || !aligned16(dpre_)) return DIG_ERR_ALIGN;
@@ -1292,5 +1301,9 @@ int dig_wgrad_group(const dig_wgrad_prob_t* probs, int n_probs, const dig_wgrad_
   }
   return DIG_OK;
 }
+
+// launch probe: nothing to time in this build
+int dig_probe_start(void) { return DIG_OK; }
+int dig_probe_stop(float*, int) { return 0; }
 
 }  // extern "C"

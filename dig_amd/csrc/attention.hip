@@ -569,11 +569,12 @@ extern "C" int dig_attn_fwd_dropout(const void* qkv, void* ctx, float* lse, int 
   if (!aligned16(qkv) || !aligned16(ctx)) return DIG_ERR_ALIGN;
   const size_t qb = (size_t)n_img * N_TOK * 3 * embed_dim * 2;
   if (qb >= (1ull << 32)) return DIG_ERR_ARG;
-  static bool attr = false;
-  if (!attr) {
+  static bool attr[DIG_MAX_DEVICES] = {};
+  const int dev = dig_device();
+  if (!attr[dev]) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TILE);
     hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TILE);
-    attr = true;
+    attr[dev] = true;
   }
   if (drop && drop->thr)
     hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3(n_img * heads), dim3(256), 2 * TILE, stream, (const bf16_t*)qkv, (bf16_t*)ctx,
@@ -599,11 +600,12 @@ extern "C" int dig_attn_bwd_dropout(const void* qkv, const void* ctx, const void
   const size_t qb = (size_t)n_img * N_TOK * 3 * embed_dim * 2;
   if (qb >= (1ull << 32)) return DIG_ERR_ARG;
   const int lds = 2 * TILE + 2 * N_TOK * 4 + (q_colsum ? 8 * 128 * 4 : 0);
-  static bool attr = false;
-  if (!attr) {
+  static bool attr[DIG_MAX_DEVICES] = {};
+  const int dev = dig_device();
+  if (!attr[dev]) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TILE + 2 * N_TOK * 4 + 8 * 128 * 4);
     hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TILE + 2 * N_TOK * 4 + 8 * 128 * 4);
-    attr = true;
+    attr[dev] = true;
   }
   if (drop && drop->thr)
     hipLaunchKernelGGL(attn_bwd_kernel<true>, dim3(n_img * heads), dim3(256), lds, stream, (const bf16_t*)qkv, (const bf16_t*)ctx,

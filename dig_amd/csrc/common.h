@@ -1,6 +1,7 @@
 // Shared device helpers for the gfx950 kernels of dig_amd.  Wave = 64 lanes everywhere.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <algorithm>
 #include <cmath>
@@ -186,6 +187,30 @@ __device__ __forceinline__ void dig_drop_apply8(float (&v)[8], const dig_dropout
   } else {
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] *= s;
+  }
+}
+
+// hipFuncSetAttribute and the CU count belong to a DEVICE: the launchers keep their "done once" state per device ordinal (a process that
+// uses a second GPU would otherwise launch with an unset dynamic-LDS limit, or size a persistent grid for the wrong chip).  The writes are
+// idempotent, so two host threads racing on an entry are harmless.
+#define DIG_MAX_DEVICES 64
+static inline int dig_device() {
+  int d = 0;
+  return (hipGetDevice(&d) == hipSuccess && d >= 0 && d < DIG_MAX_DEVICES) ? d : 0;
+}
+
+// ---- launch probe (csrc/probe.hip): the matrix-core launchers go through dig_launch(); with the probe on, a launch carries start / stop
+// events (hipExtLaunchKernel) and its device-side duration can be read back by dig_probe_stop
+bool dig_probe_on();
+void dig_probe_events(hipEvent_t* e0, hipEvent_t* e1);
+template <typename K, typename... Args>
+static inline void dig_launch(K kernel, dim3 grid, dim3 block, unsigned lds, hipStream_t stream, Args... args) {
+  if (dig_probe_on()) {
+    hipEvent_t e0, e1;
+    dig_probe_events(&e0, &e1);
+    hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, e0, e1, 0, args...);
+  } else {
+    hipLaunchKernelGGL(kernel, grid, block, lds, stream, args...);
   }
 }
 

@@ -632,17 +632,18 @@ __global__ __launch_bounds__(64 * WM * WN, (BK == 32 && WM * WN == 8 && FM * FN 
 template <bool TA, bool TB, int OUT, int WM, int WN, int FM, int FN, bool RES, int BK, int NSTG, bool DROP = false>
 int launch_wide(GemmParams p, int splits, hipStream_t stream, DropArg<DROP> da = DropArg<DROP>{}) {
   using Cfg = WideCfg<WM, WN, FM, FN, BK, NSTG>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_set[DIG_MAX_DEVICES] = {};
+  const int dev = dig_device();
+  if (!attr_set[dev]) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wide_kernel<TA, TB, OUT, WM, WN, FM, FN, RES, BK, NSTG, DROP>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
-    attr_set = true;
+    attr_set[dev] = true;
   }
   p.tiles_i = (p.I + Cfg::TBI - 1) / Cfg::TBI;
   p.tiles_j = (p.J + Cfg::TBJ - 1) / Cfg::TBJ;
   p.splits_x = (splits > 1 && splits % 8 == 0) ? splits : 0;
   dim3 grid(p.tiles_i * p.tiles_j * (p.splits_x ? splits : 1), 1, p.splits_x ? 1 : splits);
-  hipLaunchKernelGGL((gemm_wide_kernel<TA, TB, OUT, WM, WN, FM, FN, RES, BK, NSTG, DROP>), grid, dim3(Cfg::NT), Cfg::LDS, stream, p, da);
+  dig_launch(gemm_wide_kernel<TA, TB, OUT, WM, WN, FM, FN, RES, BK, NSTG, DROP>, grid, dim3(Cfg::NT), Cfg::LDS, stream, p, da);
   return dig_check_launch();
 }
 
@@ -864,22 +865,22 @@ template <int WN, bool RES, bool PRE>
 int launch_pwide(GemmParams p, hipStream_t stream) {
   using Cfg = WideCfg<4, WN, 2, 2, 64, 2>;
   constexpr int LDS = 2 * Cfg::STAGE;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_set[DIG_MAX_DEVICES] = {};
+  const int dev = dig_device();
+  if (!attr_set[dev]) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pwide_kernel<WN, RES, PRE>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_set = true;
+    attr_set[dev] = true;
   }
   p.tiles_i = (p.I + Cfg::TBI - 1) / Cfg::TBI;
   p.tiles_j = (p.J + Cfg::TBJ - 1) / Cfg::TBJ;
   const int n_items = p.tiles_i * p.tiles_j;
-  static int n_cu = 0;
-  if (!n_cu) {
-    int dev = 0;
+  static int n_cu[DIG_MAX_DEVICES] = {};
+  if (!n_cu[dev]) {
     hipDeviceProp_t prop;
-    n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    n_cu[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
   }
-  const int grid = std::min(n_items, n_cu);                              // one 16- / 12-wave workgroup per CU
-  hipLaunchKernelGGL((gemm_pwide_kernel<WN, RES, PRE>), dim3(grid), dim3(Cfg::NT), LDS, stream, p, n_items);
+  const int grid = std::min(n_items, n_cu[dev]);                         // one 16- / 12-wave workgroup per CU
+  dig_launch(gemm_pwide_kernel<WN, RES, PRE>, dim3(grid), dim3(Cfg::NT), LDS, stream, p, n_items);
   return dig_check_launch();
 }
 
@@ -926,16 +927,17 @@ __global__ __launch_bounds__(256) void reduce_partials_multi_kernel(ReduceSegs a
 template <bool TA, bool TB, int OUT, int BK, bool RES, int NSTG, bool DROP = false>
 int launch(const GemmParams& p, int splits, hipStream_t stream, DropArg<DROP> da = DropArg<DROP>{}) {
   constexpr int LDS = (NSTG * 2 * BI * BK * 2) > 32768 ? (NSTG * 2 * BI * BK * 2) : 32768;   // ring; >= epilogue staging
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_set[DIG_MAX_DEVICES] = {};
+  const int dev = dig_device();
+  if (!attr_set[dev]) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<TA, TB, OUT, BK, RES, NSTG, DROP>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_set = true;
+    attr_set[dev] = true;
   }
   GemmParams q = p;
   q.splits_x = (splits > 1 && splits % 8 == 0) ? splits : 0;
   dim3 grid(p.tiles_i * p.tiles_j * (q.splits_x ? splits : 1), 1, q.splits_x ? 1 : splits);
-  hipLaunchKernelGGL((gemm_kernel<TA, TB, OUT, BK, RES, NSTG, DROP>), grid, dim3(256), LDS, stream, q, da);
+  dig_launch(gemm_kernel<TA, TB, OUT, BK, RES, NSTG, DROP>, grid, dim3(256), LDS, stream, q, da);
   return dig_check_launch();
 }
 

@@ -671,13 +671,14 @@ int launch_chain(const ChainParams& p, hipStream_t stream) {
   const int lds_launch = lds;
 #endif
   if (lds > 160 * 1024) return DIG_ERR_UNSUPPORTED;
-  static int attr_lds = 0;
-  if (lds_launch > attr_lds) {
+  static int attr_lds[DIG_MAX_DEVICES] = {};
+  const int dev = dig_device();
+  if (lds_launch > attr_lds[dev]) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_chain_kernel<MODE, LN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_launch) != hipSuccess)
       return DIG_ERR_LAUNCH;
-    attr_lds = lds_launch;
+    attr_lds[dev] = lds_launch;
   }
-  hipLaunchKernelGGL((mlp_chain_kernel<MODE, LN>), dim3((p.R + BM - 1) / BM), dim3(512), lds_launch, stream, p);
+  dig_launch(mlp_chain_kernel<MODE, LN>, dim3((p.R + BM - 1) / BM), dim3(512), lds_launch, stream, p);
   return dig_check_launch();
 }
 
@@ -778,6 +779,34 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __res
     const int c = i >> 6, r = i & 63;
     if (c0 + c < cols && r0 + r < rows) dst[(size_t)(c0 + c) * rows + r0 + r] = tile[r][c];
   }
+}
+// the same for a list of equally shaped matrices in ONE launch (all MLP weights of an encoder: 24 launches of ~10 us -> 1)
+#define DIG_TRANSPOSE_MAX 32
+struct TransposeList { const bf16_t* src[DIG_TRANSPOSE_MAX]; bf16_t* dst[DIG_TRANSPOSE_MAX]; };
+__global__ __launch_bounds__(256) void transpose_bf16_multi_kernel(TransposeList l, int rows, int cols) {
+  __shared__ bf16_t tile[64][66];
+  const bf16_t* __restrict__ src = l.src[blockIdx.z];
+  bf16_t* __restrict__ dst = l.dst[blockIdx.z];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    tile[r][c] = (r0 + r < rows && c0 + c < cols) ? src[(size_t)(r0 + r) * cols + c0 + c] : (bf16_t)0;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int c = i >> 6, r = i & 63;
+    if (c0 + c < cols && r0 + r < rows) dst[(size_t)(c0 + c) * rows + r0 + r] = tile[r][c];
+  }
+}
+extern "C" int dig_transpose_bf16_multi(const void* const* srcs, void* const* dsts, int count, int rows, int cols, hipStream_t stream) {
+  if (!srcs || !dsts || count < 1 || count > DIG_TRANSPOSE_MAX || rows <= 0 || cols <= 0) return DIG_ERR_ARG;
+  TransposeList l;
+  for (int k = 0; k < count; ++k) {
+    if (!srcs[k] || !dsts[k]) return DIG_ERR_ARG;
+    l.src[k] = (const bf16_t*)srcs[k]; l.dst[k] = (bf16_t*)dsts[k];
+  }
+  hipLaunchKernelGGL(transpose_bf16_multi_kernel, dim3((cols + 63) / 64, (rows + 63) / 64, count), dim3(256), 0, stream, l, rows, cols);
+  return dig_check_launch();
 }
 extern "C" int dig_transpose_bf16(const void* src, void* dst, int rows, int cols, hipStream_t stream) {
   if (!src || !dst || rows <= 0 || cols <= 0) return DIG_ERR_ARG;

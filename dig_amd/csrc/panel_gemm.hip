@@ -257,11 +257,12 @@ __global__ __launch_bounds__(512) void panel_gemm_kernel(PanelParams p) {
 template <int EPI>
 int launch_panel(const PanelParams& p, hipStream_t stream) {
   constexpr int LDS = V_OFF + 3 * KD * 4;
-  static bool attr = false;
-  if (!attr) {
+  static bool attr[DIG_MAX_DEVICES] = {};
+  const int dev = dig_device();
+  if (!attr[dev]) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&panel_gemm_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
       return DIG_ERR_LAUNCH;
-    attr = true;
+    attr[dev] = true;
   }
   hipLaunchKernelGGL((panel_gemm_kernel<EPI>), dim3((p.R + PBM - 1) / PBM), dim3(512), LDS, stream, p);
   return dig_check_launch();

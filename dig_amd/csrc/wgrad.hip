@@ -484,28 +484,26 @@ __global__ __launch_bounds__(512, 2) void wgrad_wide_kernel(WgParams p) {
 template <int FN, int NSTG>
 int launch_wgrad_wide(const WgParams& p, int n_wg, hipStream_t stream) {
   constexpr int LDS = NSTG * (4 * 16 * 128 + 4 * (128 * FN / 16) * 128);
-  static bool attr_set[64] = {};
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+  static bool attr_set[DIG_MAX_DEVICES] = {};
+  const int dev = dig_device();
+  if (!attr_set[dev]) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_wide_kernel<FN, NSTG>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_set[dev] = true;
   }
-  hipLaunchKernelGGL((wgrad_wide_kernel<FN, NSTG>), dim3(n_wg), dim3(512), LDS, stream, p);
+  dig_launch(wgrad_wide_kernel<FN, NSTG>, dim3(n_wg), dim3(512), LDS, stream, p);
   return dig_check_launch();
 }
 
 template <int FN>
 int launch_wgrad(const WgParams& p, int n_wg, hipStream_t stream) {
   constexpr int LDS = WG_NSTG * (4 * 8 * 128 + 4 * (128 * FN / 16) * 128);
-  static bool attr_set[64] = {};
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+  static bool attr_set[DIG_MAX_DEVICES] = {};
+  const int dev = dig_device();
+  if (!attr_set[dev]) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_group_kernel<FN>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_set[dev] = true;
   }
-  hipLaunchKernelGGL((wgrad_group_kernel<FN>), dim3(n_wg), dim3(256), LDS, stream, p);
+  dig_launch(wgrad_group_kernel<FN>, dim3(n_wg), dim3(256), LDS, stream, p);
   return dig_check_launch();
 }
 

@@ -15,7 +15,7 @@ from . import ops
 
 BF16, F32 = torch.bfloat16, torch.float32
 FWD_MODE = os.environ.get("DIG_FWD_MODE", "flip")                   # two-stream plan of the forward (single process): "flip" (default) or "side"
-CHAIN_BWD_EVERY = int(os.environ.get("DIG_CHAIN_BWD_EVERY", "1"))   # with DIG_MLP_CHAIN_MASK bit 2: the fused MLP backward in every k-th block only
+CHAIN_BWD_EVERY = max(1, int(os.environ.get("DIG_CHAIN_BWD_EVERY", "1")))   # with DIG_MLP_CHAIN_MASK bit 2: the fused MLP backward in every k-th block only
 CHAIN_BWD_PHASE = int(os.environ.get("DIG_CHAIN_BWD_PHASE", "0"))
 BATCH_REDUCE = os.environ.get("DIG_BATCH_REDUCE", "0") == "1"       # an encoder block's eleven reduction launches as two: fewer launches,
 #                                                                     0.1-0.15 ms SLOWER per step -> opt-in
@@ -23,6 +23,12 @@ FUSED_QV_BIAS_SUMS = os.environ.get("DIG_FUSED_QV_BIAS", "1") != "0"
 # weight gradients of an encoder block on the grouped kernel (csrc/wgrad.hip): "block" = one launch per block (default: the block's
 # accumulators are dumped once), "pair" = MLP pair | attention pair, "off" = the tiled split-R launches + their slab sums
 WGRAD_GROUPING = os.environ.get("DIG_WGRAD_GROUPING", "block")
+# The grouped weight-gradient launch owns the chip (one 8-wave workgroup per CU with every register and 140 KiB of LDS), and so do the fused
+# MLP backward and the 256-row data-gradient tiles: beside it on a second stream the chain's next kernel only waits for CUs (its in-step
+# duration grows by the launch's length, the step does not get shorter).  "1": the launch sits IN the data-gradient chain, on the caller's
+# stream, between attention backward and the qkv data gradient -- back-to-back kernel boundaries instead of cross-stream events; the small
+# reductions (bias / LayerNorm-parameter column sums) stay on the second stream.
+WGRAD_INLINE = os.environ.get("DIG_WGRAD_INLINE", "1") == "1"
 BWD_SINGLE_STREAM = os.environ.get("DIG_BWD_SINGLE", "0") == "1"    # lab switch: the whole backward on the caller's stream (sum of solo kernel times)
 
 
@@ -99,7 +105,7 @@ class _Step:
                        ops.L.ptr(x[half * B * N:(half + 1) * B * N]), B, M.gh, M.gw, D, ops.L.stream())
         saved = []
         scale = (D // H) ** -0.5
-        chain = ops.mlp_chain_supported(D, M.F) and bool(ops.MLP_CHAIN_MASK & (2 if save else 1))
+        chain = ops.mlp_chain_supported(D, M.F, R) and bool(ops.MLP_CHAIN_MASK & (2 if save else 1))
         chain_ln = chain and ops.MLP_CHAIN_LN and M.F <= 2048
         panel = chain_ln and ops.PANEL_PROJ and ops.panel_gemm_supported(D, D)
         nxt = None                                                      # (ln1, mean, rstd) of this block, made by the previous block's launch
@@ -155,7 +161,9 @@ class _Step:
     def mlp_weight_transposes(self, ew):
         """K-contiguous copies of the MLP weights for the fused backward (W2^T [F, D], W1^T [D, F]; 1.2 MB each, 24 small launches):
         they depend on nothing but this step's bf16 weight shadow, so forward() queues them on the side stream behind the momentum branch."""
-        return [(ops.transpose_bf16(b["mlp.fc2.weight"]), ops.transpose_bf16(b["mlp.fc1.weight"])) for b in ew.blocks]
+        w2t = ops.transpose_bf16_multi([b["mlp.fc2.weight"] for b in ew.blocks])      # one launch per weight shape
+        w1t = ops.transpose_bf16_multi([b["mlp.fc1.weight"] for b in ew.blocks])
+        return list(zip(w2t, w1t))
 
     # ------------------------------------------------------------------ two-stream helpers (backward)
     def _streams(self, dev):
@@ -223,7 +231,7 @@ class _Step:
         def on_side(fn, *tensors):
             self._on_side(dev, fn, *tensors)
 
-        chain_any = ops.mlp_chain_supported(D, M.F) and bool(ops.MLP_CHAIN_MASK & 4)
+        chain_any = ops.mlp_chain_supported(D, M.F, views * B * N) and bool(ops.MLP_CHAIN_MASK & 4)
         chain = chain_any
         wT = getattr(self, "wT", None)
         if chain and wT is None:
@@ -243,7 +251,10 @@ class _Step:
         prev_block = None
 
         def launch_group(*tensors):
-            on_side(grp.launch, *tensors)
+            if WGRAD_INLINE:
+                grp.launch()                                             # in the data-gradient chain itself (see WGRAD_INLINE)
+            else:
+                on_side(grp.launch, *tensors)
 
         for i in reversed(range(M.depth)):
             blk, g = ew.blocks[i], ew.blocks[i]["g"]
@@ -340,7 +351,10 @@ class _Step:
             else:
                 self._grad_ready(dev, f"encoder.blocks.{i}")
         if grp:
-            on_side(grp.flush)
+            if WGRAD_INLINE:
+                grp.flush()
+            else:
+                on_side(grp.flush)
             if prev_block is not None:
                 self._grad_ready(dev, f"encoder.blocks.{prev_block}")
         for half, im in enumerate((images, aug)[:views]):
@@ -432,8 +446,10 @@ class _Step:
         return dy
 
     # ------------------------------------------------------------------ full forward
-    def forward(self, images, aug, mask_b2n, m, mim_views=1):
-        """mim_views: 1 = only_mim_on_ori_img (the README recipe: the decoder runs on view 0's masked rows), 2 = both views' masked rows
+    def forward(self, images, aug, mask_b2n, m, mim_views=1, training=False):
+        """training: a backward will follow (set by the autograd node: inside its forward() autograd's grad mode is off, so
+        torch.is_grad_enabled() says nothing).
+        mim_views: 1 = only_mim_on_ori_img (the README recipe: the decoder runs on view 0's masked rows), 2 = both views' masked rows
         (modeling_pretrain_moco_mim_ori.py:572-577)."""
         M = self.m
         dev = images.device
@@ -451,7 +467,7 @@ class _Step:
         # arena, read-only here) and the inputs, so it overlaps the online forward.  EMA with the current online weights
         # comes first (:526).
         main = torch.cuda.current_stream(dev)
-        side = M._fwd_stream(dev) if getattr(M, "overlap_streams", True) else main
+        side = M._fwd_stream(dev) if (getattr(M, "overlap_streams", True) and FWD_MODE != "serial") else main
         dist_mode = comm.world > 1 or getattr(comm, "world_override", False)
         mode = FWD_MODE if (not dist_mode and side is not main) else "side"
 
@@ -464,20 +480,23 @@ class _Step:
             q, self.saved_pred = self.mlp_forward(q, "predictor", "online", True)
             return q
 
+        def momentum_heads(enc_m):
+            masked_m, _ = self.mlp_forward(enc_m[:B * N], "pix_projector_m", "momentum", False)
+            pooled_m = torch.empty((2 * B * nw, D), device=dev, dtype=BF16)
+            ops.window_pool_fwd(masked_m, pooled_m[:B * nw], B, M.gh, M.gw, nw, D)
+            ops.window_pool_fwd(enc_m[B * N:], pooled_m[B * nw:], B, M.gh, M.gw, nw, D)
+            k, _ = self.mlp_forward(pooled_m, "momentum_projection_layer", "momentum", False)
+            return k
+
         def momentum_branch(heads=True):
             ops.ema_update(M._flat["momentum"], M._flat["online"], M.shadow("momentum"), M.n_ema, m)
-            enc_m, _ = self.encoder_forward(ew_mo, images, aug, mask_u8, False)
-            k = None
-            if heads:
-                masked_m, _ = self.mlp_forward(enc_m[:B * N], "pix_projector_m", "momentum", False)
-                pooled_m = torch.empty((2 * B * nw, D), device=dev, dtype=BF16)
-                ops.window_pool_fwd(masked_m, pooled_m[:B * nw], B, M.gh, M.gw, nw, D)
-                ops.window_pool_fwd(enc_m[B * N:], pooled_m[B * nw:], B, M.gh, M.gw, nw, D)
-                k, _ = self.mlp_forward(pooled_m, "momentum_projection_layer", "momentum", False)
             self.wT = None
-            if torch.is_grad_enabled() and ops.mlp_chain_supported(D, M.F) and (ops.MLP_CHAIN_MASK & 4):
+            if training and ops.mlp_chain_supported(D, M.F, 2 * B * N) and (ops.MLP_CHAIN_MASK & 4):
+                # K-contiguous copies of the online MLP weights for the fused backward: two launches, in front of the momentum encoder
+                # (they read nothing but this step's bf16 weight shadow)
                 self.wT = self.mlp_weight_transposes(ew_on)
-            return enc_m, k
+            enc_m, _ = self.encoder_forward(ew_mo, images, aug, mask_u8, False)
+            return enc_m, (momentum_heads(enc_m) if heads else None)
 
         def decoder():
             # SimMIM decoder on the masked tokens (:560-570; the reference decodes all rows then selects): view 0 only, or both views
@@ -518,6 +537,8 @@ class _Step:
                 enc, self.saved_enc = self.encoder_forward(ew_on, images, aug, mask_u8, True)
                 self.enc = enc
                 qs = online_heads(enc)
+            # (Measured and not kept, round 4: the online heads + SimMIM decoder held back until both encoders are done, so that they run
+            #  beside the momentum heads instead of between the encoders: 21.84 vs 21.77 ms, two A/B pairs.)
             enc_m, ks = momentum_branch()
             del enc_m
             main.wait_stream(hi_st)
@@ -654,7 +675,7 @@ class _DigFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, model, images, aug, mask, m, mim_views):
         step = _Step(model)
-        contra, accs, vis_out = step.forward(images, aug, mask, m, mim_views)
+        contra, accs, vis_out = step.forward(images, aug, mask, m, mim_views, training=True)
         ctx.step = step
         ctx.set_materialize_grads(False)          # an unused output arrives as None, not as a zero tensor (host-visible)
         ctx.mark_non_differentiable(accs)

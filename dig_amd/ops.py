@@ -92,8 +92,10 @@ MLP_CHAIN_LN = os.environ.get("DIG_MLP_CHAIN_LN", "1") != "0"
 PANEL_PROJ = os.environ.get("DIG_PANEL_PROJ", "0") == "1"
 
 
-def mlp_chain_supported(D, F):
-    return MLP_CHAIN and bool(L.lib().dig_mlp_chain_supported(int(D), int(F)))
+def mlp_chain_supported(D, F, rows=None):
+    """rows: the token rows of the call (the fused kernels address the [rows, F] side tensors with 32-bit byte offsets: beyond 2^32 bytes
+    the entry points return "unsupported", and the caller takes the two-GEMM path instead)."""
+    return MLP_CHAIN and bool(L.lib().dig_mlp_chain_supported(int(D), int(F))) and (rows is None or rows * F * 2 < (1 << 32))
 
 
 def mlp_chain_fwd(x, w1, b1, w2, b2, resid, save=False):
@@ -174,6 +176,18 @@ def transpose_bf16(src, out=None):
     out = torch.empty((cols, rows), device=src.device, dtype=BF16) if out is None else out
     L.call("dig_transpose_bf16", L.ptr(src), L.ptr(out), rows, cols, L.stream())
     return out
+
+
+def transpose_bf16_multi(srcs):
+    """[src^T for src in srcs] for equally shaped bf16 matrices, 32 per launch (dig_transpose_bf16_multi)."""
+    rows, cols = srcs[0].shape
+    outs = [torch.empty((cols, rows), device=s_.device, dtype=BF16) for s_ in srcs]
+    for i in range(0, len(srcs), 32):
+        n = min(32, len(srcs) - i)
+        sp = (ctypes.c_void_p * n)(*[s_.data_ptr() for s_ in srcs[i:i + n]])
+        dp = (ctypes.c_void_p * n)(*[o.data_ptr() for o in outs[i:i + n]])
+        L.call("dig_transpose_bf16_multi", sp, dp, n, rows, cols, L.stream())
+    return outs
 
 
 def dropout_apply(x, drop, out=None):

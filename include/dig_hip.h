@@ -150,6 +150,8 @@ int dig_panel_gemm_ln_fwd(const void* a, const void* w, const float* bias, const
                           float eps, void* ln_out, float* ln_mean, float* ln_rstd, int R, int J, int K, hipStream_t stream);
 /* dst[cols, rows] = src[rows, cols]^T, bf16 */
 int dig_transpose_bf16(const void* src, void* dst, int rows, int cols, hipStream_t stream);
+/* the same for `count` (<= 32) equally shaped matrices in one launch; srcs / dsts are HOST arrays of device pointers */
+int dig_transpose_bf16_multi(const void* const* srcs, void* const* dsts, int count, int rows, int cols, hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Fused self-attention, 256 tokens x head_dim 64 (Attention.forward, modeling_finetune.py:97-118, and its gradient).
@@ -469,6 +471,14 @@ int dig_gru_cell_bwd(const float* ds_a, const float* ds_b, const float* ds_c, co
                      void* dgh, float* ds_prev, int B, int S, hipStream_t stream);
 /* out[r, :cols] (bf16, row stride ld) = table[clamp(tokens[r]), :cols] (fp32 table): tgt_embedding lookups (attn_decoder.py:264). */
 int dig_embed_rows(const long long* tokens, const float* table, void* out, int ld, int rows, int cols, int vocab, hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Launch probe (measurement only; bench.py).  Between dig_probe_start() and dig_probe_stop() every launch of dig_gemm_bf16(_dropout),
+ * dig_mlp_chain_fwd / _fwd_ln / _bwd and dig_wgrad_group carries the start / stop events of hipExtLaunchKernel; dig_probe_stop
+ * synchronises the device and writes the launches' device-side durations (microseconds, in call order) to the HOST array us_out
+ * (at most max_n entries); returns the number of launches recorded.  Off, the launchers are byte-for-byte what they were. */
+int dig_probe_start(void);
+int dig_probe_stop(float* us_out, int max_n);
 
 #ifdef __cplusplus
 }

@@ -10,6 +10,7 @@
 #include <cmath>
 #include <vector>
 #include <algorithm>
+#include "../../dig_amd/csrc/probe.hip"
 #include "../../dig_amd/csrc/gemm.hip"
 #ifdef WG_LAB_TS
 // per-wave phase accounting of the wide kernel's stage loop: [0] wait for own fragment reads, [1] wait for own LDS-DMA pieces, [2] barrier,

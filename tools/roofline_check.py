@@ -8,18 +8,28 @@ u, b = json.load(open(sys.argv[2])), json.load(open(sys.argv[3]))
 
 
 def family(name):
+    """Kernel name (rocprofv3) -> the family key bench.py's probe uses."""
+    import re
     if "mlp_chain_kernel<2" in name:
         return "mlp_chain_bwd"
+    if "mlp_chain_kernel<1" in name:
+        return "mlp_chain_online"
     if "mlp_chain_kernel" in name:
-        return "mlp_chain"
+        return "mlp_chain_momentum"
     if "wgrad_wide_kernel" in name or "wgrad_group_kernel" in name:
         return "wgrad_group"
-    if "gemm_pwide_kernel" in name:
-        return "fwd"
-    m = re.search(r"gemm_(?:wide_)?kernel<(true|false), (true|false), (\d)", name)
-    if not m:
-        return None
-    return "wgrad" if m.group(1) == "true" else ("dgrad" if m.group(2) == "true" else "fwd")
+    m = re.search(r"gemm_pwide_kernel<(\d)", name)
+    if m:
+        return "fwd:" + {"4": "544", "3": "564"}.get(m.group(1), "5xx")
+    m = re.search(r"gemm_wide_kernel<(true|false), (true|false), \d, (\d), (\d)", name)
+    if m:
+        form = "wgrad" if m.group(1) == "true" else ("dgrad" if m.group(2) == "true" else "fwd")
+        return form + ":" + {"44": "244", "43": "264", "12": "212", "21": "221"}.get(m.group(3) + m.group(4), "2xx")
+    m = re.search(r"gemm_kernel<(true|false), (true|false), \d, (\d+)", name)
+    if m:
+        form = "wgrad" if m.group(1) == "true" else ("dgrad" if m.group(2) == "true" else "fwd")
+        return form + ":" + m.group(3)
+    return None
 
 
 fam = {}
