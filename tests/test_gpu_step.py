@@ -713,3 +713,96 @@ def test_twenty_step_trajectory_vs_oracle_band():
     for name in ("momentum_encoder.blocks.0.mlp.fc1.weight", "momentum_projection_layer.0.weight", "momentum_encoder.patch_embed.proj.weight"):
         a, b, c = dict(model.named_parameters())[name].detach().float().cpu(), tr.P[name], tb.P[name].float()
         assert (a - b).norm() <= 2 * (c - b).norm() + 1e-3 * b.norm(), (name, float((a - b).norm()), float((c - b).norm()))
+
+
+def test_vit_small_b32_twenty_step_trajectory_vs_oracle():
+    """Twenty optimisation steps of the FULL ViT-S model at B = 32 (the batch averages over 32 x 179 masked patches and 128 x 128 logits,
+    which damps the chaos that the 8 x 8-logit tiny trajectory shows) with the recipe's schedules in miniature: linear warm-up to the
+    recipe's peak lr for its own global batch (1.5e-4 x 1024 / 256 = 6e-4), cosine decay, weight-decay ramp, cosine EMA momentum, a
+    fresh batch every step.  Band: every loss of every step within 3 % of the fp32 oracle's (+ 3e-3 absolute); no bf16 yardstick."""
+    from dig_amd.optim_factory import create_optimizer
+    from dig_amd.engine_for_pretraining_moco import train_one_epoch
+    from dig_amd.utils import NativeScalerWithGradNormCount
+    from gpu_util import engine_args
+    cfg = O.make_config("pretrain_simmim_moco_ori_vit_small_patch4_32x128")
+    seed, B, n, epochs = 3, 32, 20, 25
+    peak = 6e-4
+    hp = O.StepHyper(lr=peak)
+    lr = np.concatenate([np.linspace(peak / 10, peak, 5), 1e-5 + 0.5 * (peak - 1e-5) * (1 + np.cos(np.pi * np.arange(15) / 15))])
+    wd = np.linspace(0.05, 0.1, n)
+    batches = [O.synthetic_batch(B, cfg, 9000 + s) for s in range(n)]
+    torch.set_num_threads(max(1, min(16, __import__("os").cpu_count() or 8)))
+    tr = O.OracleTrainer(cfg, seed=seed)
+    model = build_model(cfg, {k: v.detach().clone() for k, v in tr.P.items()}, {k: v.detach().clone() for k, v in tr.S.items()})
+    args = engine_args(hp, epochs=epochs)
+    opt = create_optimizer(args, model)
+    worst = {}
+    for s, (im, au, mk) in enumerate(batches):
+        st = train_one_epoch(model, None, None, [([im, au, mk], torch.ones(1), torch.ones(1))], None, opt, torch.device("cuda:0"), s,
+                             NativeScalerWithGradNormCount(), None, patch_size=4, normlize_target=False, start_steps=s,
+                             lr_schedule_values=lr, wd_schedule_values=wd, args=args)
+        hps = dataclasses.replace(hp, lr=float(lr[s]), weight_decay=float(wd[s]), moco_m=O.adjust_moco_momentum(float(s), epochs, hp.moco_m))
+        ref, _, _, _ = tr.step(im, au, mk, hps)
+        for k in ("loss", "loss_pixel", "loss_contrast"):
+            d = abs(st[k] - ref[k])
+            worst[k] = max(worst.get(k, 0.0), d / (3e-2 * abs(ref[k]) + 3e-3))
+            assert d <= 3e-2 * abs(ref[k]) + 3e-3, (s, k, st[k], ref[k])
+    print("worst fraction of the 3 % band used:", {k: round(v, 3) for k, v in worst.items()})
+    assert opt._step == n
+
+
+@pytest.mark.parametrize("switch", ["wgrad_off", "wgrad_pair", "wgrad_wa1", "wgrad_side_stream", "chain_mask3", "dgrad_128", "fwd_side", "fwd_serial",
+                                    "chain_no_ln", "panel_proj", "bwd_single", "chain_bwd_every2"])
+def test_engine_switches_agree_with_the_default_path(switch):
+    """Every non-default execution plan of the step (environment switches of dig_amd/ops.py and engine_core.py: launch groupings, tile
+    codes, stream plans, fusion masks) against the default plan on one ViT-S step from the same state and batch: the losses agree, and
+    every gradient tensor agrees -- to fp32 summation order (1e-5) where only the grouping / placement of launches changes; to 2e-2
+    where a different BACKWARD kernel produces the data gradients (same saved activations, bf16 rounding of the gradient tensors);
+    and, where a different FORWARD kernel re-rounds every activation (the LayerNorm / projection fusions), by direction and length per
+    tensor (cosine >= 0.95, norm within 10 %): twelve blocks of softmax attention amplify a last-bit change of an activation into a
+    ~25 % relative difference of the patch-embedding gradient at random init and B = 8 -- the same spread the fp32 oracle's own bf16
+    autocast shows in test_vit_small_b32_every_tensor_gradient_vs_oracle."""
+    from dig_amd import ops, engine_core
+    cfg = O.make_config("pretrain_simmim_moco_ori_vit_small_patch4_32x128")
+    B = 8
+    P, S = O.init_state(cfg, 11)
+    batch = O.synthetic_batch(B, cfg, 77)
+    hp = O.StepHyper(lr=1e-4)
+
+    def one_step():
+        model = build_model(cfg, {k: v.clone() for k, v in P.items()}, {k: v.clone() for k, v in S.items()})
+        stats, _ = run_engine_steps(model, [batch], hp)
+        torch.cuda.synchronize()
+        return stats[0], model.flat_grads.detach().float().clone(), {n: sp for n, sp in model.specs.items() if sp.arena == "online"}
+
+    ref_stats, ref_g, specs = one_step()
+    plans = {
+        "wgrad_off": [(engine_core, "WGRAD_GROUPING", "off")], "wgrad_pair": [(engine_core, "WGRAD_GROUPING", "pair")],
+        "wgrad_wa1": [(ops, "WGRAD_GROUP_WA", 1), (ops, "WGRAD_GROUP_SLOTS", 512)], "wgrad_side_stream": [(engine_core, "WGRAD_INLINE", False)],
+        "chain_mask3": [(ops, "MLP_CHAIN_MASK", 3)], "dgrad_128": [(ops, "DGRAD_BK", 0)], "fwd_side": [(engine_core, "FWD_MODE", "side")],
+        "fwd_serial": [(engine_core, "FWD_MODE", "serial")], "chain_no_ln": [(ops, "MLP_CHAIN_LN", False)], "panel_proj": [(ops, "PANEL_PROJ", True)],
+        "bwd_single": [(engine_core, "BWD_SINGLE_STREAM", True)], "chain_bwd_every2": [(engine_core, "CHAIN_BWD_EVERY", 2)],
+    }
+    tight = switch in ("wgrad_off", "wgrad_pair", "wgrad_wa1", "wgrad_side_stream", "fwd_side", "fwd_serial", "bwd_single")
+    saved = [(m, k, getattr(m, k)) for m, k, _ in plans[switch]]
+    try:
+        for m, k, v in plans[switch]:
+            setattr(m, k, v)
+        stats, g, _ = one_step()
+    finally:
+        for m, k, v in saved:
+            setattr(m, k, v)
+    for k in ("loss", "loss_pixel", "loss_contrast", "grad_norm"):
+        assert abs(stats[k] - ref_stats[k]) <= (1e-5 if tight else 2e-2) * abs(ref_stats[k]) + 1e-6, (k, stats[k], ref_stats[k])      # (2e-2: this file's bf16 band)
+    tol = 1e-5 if tight else 2e-2
+    fwd_plan = switch in ("chain_no_ln", "panel_proj")
+    for name, sp in specs.items():
+        a, b = g[sp.offset:sp.offset + sp.numel], ref_g[sp.offset:sp.offset + sp.numel]
+        if float(b.norm()) == 0.0:
+            assert float(a.norm()) == 0.0, name
+            continue
+        if fwd_plan:
+            cos = float((a * b).sum() / (a.norm() * b.norm()))
+            assert cos >= 0.95 and abs(float(a.norm() / b.norm()) - 1.0) <= 0.10, (name, cos, float(a.norm() / b.norm()))
+        else:
+            assert float((a - b).norm() / b.norm()) <= tol, (name, float((a - b).norm() / b.norm()))
