@@ -991,37 +991,6 @@ int dig_mlp_chain_fwd_ln(const void* x, const void* resid, const float* ln_g, co
   return DIG_OK;
 }
 
-int dig_panel_gemm_supported(int J, int K) { return J == 384 && K >= 64 && K % 64 == 0 && K <= 8192; }
-
-int dig_panel_gemm_ln_fwd(const void* a_, const void* w_, const float* bias, const void* resid_, void* out_, const float* ln_g, const float* ln_b,
-                          float eps, void* ln_out, float* ln_mean, float* ln_rstd, int R, int J, int K, hipStream_t) {
-  if (!a_ || !w_ || !out_ || R <= 0) return DIG_ERR_ARG;
-  if (!dig_panel_gemm_supported(J, K)) return DIG_ERR_UNSUPPORTED;
-  if ((ln_g == nullptr) != (ln_b == nullptr) || (ln_g == nullptr) != (ln_out == nullptr) || (ln_mean == nullptr) != (ln_rstd == nullptr)) return DIG_ERR_ARG;
-  if (!ln_g && ln_mean) return DIG_ERR_ARG;
-  const bf16_t* a = (const bf16_t*)a_; const bf16_t* w = (const bf16_t*)w_; const bf16_t* resid = (const bf16_t*)resid_;
-  bf16_t* out = (bf16_t*)out_;
-  std::vector<float> W((size_t)J * K);
-  for (size_t i = 0; i < W.size(); ++i) W[i] = bf2f(w[i]);
-#pragma omp parallel
-  {
-    std::vector<float> ar(K);
-#pragma omp for
-    for (int r = 0; r < R; ++r) {
-      for (int k = 0; k < K; ++k) ar[k] = bf2f(a[(size_t)r * K + k]);
-      for (int j = 0; j < J; ++j) {
-        float acc = 0.f;
-        const float* wr = &W[(size_t)j * K];
-        for (int k = 0; k < K; ++k) acc += wr[k] * ar[k];
-        acc += (bias ? bias[j] : 0.f) + (resid ? bf2f(resid[(size_t)r * J + j]) : 0.f);
-        out[(size_t)r * J + j] = f2bf(acc);
-      }
-    }
-  }
-  if (ln_g) ln_rows_cpu(out, ln_g, ln_b, eps, (bf16_t*)ln_out, ln_mean, ln_rstd, R, J);
-  return DIG_OK;
-}
-
 int dig_mlp_chain_bwd(const void* dy_, const void* w2t_, const void* pre_, const void* w1t_, void* dpre_out_, void* dx_out_,
                       float* colsum_partials, int R, int D, int F, hipStream_t) {
   if (!dy_ || !w2t_ || !pre_ || !w1t_ || !dpre_out_ || !dx_out_ || R <= 0) return DIG_ERR_ARG;

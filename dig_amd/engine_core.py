@@ -107,7 +107,6 @@ class _Step:
         scale = (D // H) ** -0.5
         chain = ops.mlp_chain_supported(D, M.F, R) and bool(ops.MLP_CHAIN_MASK & (2 if save else 1))
         chain_ln = chain and ops.MLP_CHAIN_LN and M.F <= 2048
-        panel = chain_ln and ops.PANEL_PROJ and ops.panel_gemm_supported(D, D)
         nxt = None                                                      # (ln1, mean, rstd) of this block, made by the previous block's launch
         for i, blk in enumerate(ew.blocks):
             ln1, mu1, rs1 = nxt if nxt is not None else ops.layernorm_fwd(x, blk["norm1.weight"], blk["norm1.bias"], M.ln_eps)
@@ -116,22 +115,14 @@ class _Step:
             ctx, lse = ops.attn_fwd(qkv, 2 * B, H, D)
             if chain_ln:
                 # norm2 -> fc1 -> GELU -> fc2 (+ residual) -> the NEXT block's norm1 in one launch: between two blocks the residual stream
-                # is written once and no LayerNorm launch remains (the first block's norm1 is the only stand-alone one).  norm2 itself comes
-                # out of the accumulators of the attention output projection (row-panel GEMM: whole rows per workgroup), or is taken on the
-                # way into the MLP launch
+                # is written once and no LayerNorm launch remains (the first block's norm1 is the only stand-alone one); norm2 is taken on
+                # the way into the MLP launch
                 nb = ew.blocks[i + 1] if i + 1 < len(ew.blocks) else None
-                if panel:
-                    x_mid, ln2, mu2, rs2 = ops.panel_linear_ln(ctx, blk["attn.proj.weight"], blk["attn.proj.bias"], x, blk["norm2.weight"],
-                                                               blk["norm2.bias"], M.ln_eps, stats=save)
-                    r = ops.mlp_chain_fwd_ln(ln2, None, None, M.ln_eps, blk["mlp.fc1.weight"], blk["mlp.fc1.bias"], blk["mlp.fc2.weight"],
-                                             blk["mlp.fc2.bias"], nb["norm1.weight"] if nb else None, nb["norm1.bias"] if nb else None,
-                                             save=save, resid=x_mid)
-                else:
-                    x_mid = ops.linear_fwd(ctx, blk["attn.proj.weight"], bias=blk["attn.proj.bias"], resid=x)
-                    r = ops.mlp_chain_fwd_ln(x_mid, blk["norm2.weight"], blk["norm2.bias"], M.ln_eps, blk["mlp.fc1.weight"], blk["mlp.fc1.bias"],
-                                             blk["mlp.fc2.weight"], blk["mlp.fc2.bias"], nb["norm1.weight"] if nb else None,
-                                             nb["norm1.bias"] if nb else None, save=save)
-                    ln2, mu2, rs2 = r["ln"], r["ln_mean"], r["ln_rstd"]
+                x_mid = ops.linear_fwd(ctx, blk["attn.proj.weight"], bias=blk["attn.proj.bias"], resid=x)
+                r = ops.mlp_chain_fwd_ln(x_mid, blk["norm2.weight"], blk["norm2.bias"], M.ln_eps, blk["mlp.fc1.weight"], blk["mlp.fc1.bias"],
+                                         blk["mlp.fc2.weight"], blk["mlp.fc2.bias"], nb["norm1.weight"] if nb else None,
+                                         nb["norm1.bias"] if nb else None, save=save)
+                ln2, mu2, rs2 = r["ln"], r["ln_mean"], r["ln_rstd"]
                 if save:
                     saved.append((x, ln1, mu1, rs1, qkv, ctx, lse, x_mid, ln2, mu2, rs2, r["pre"], r["act"]))
                 if nb is not None:

@@ -88,8 +88,6 @@ MLP_CHAIN = os.environ.get("DIG_MLP_CHAIN", "1") != "0"      # fused fc1 -> GELU
 MLP_CHAIN_MASK = int(os.environ.get("DIG_MLP_CHAIN_MASK", "7"))
 # the block's norm2 and the next block's norm1 inside the forward chain launch (dig_mlp_chain_fwd_ln)
 MLP_CHAIN_LN = os.environ.get("DIG_MLP_CHAIN_LN", "1") != "0"
-# attention output projection + residual + norm2 on the row-panel GEMM (dig_panel_gemm_ln_fwd) instead of the tiled GEMM + norm2 inside the chain
-PANEL_PROJ = os.environ.get("DIG_PANEL_PROJ", "0") == "1"
 
 
 def mlp_chain_supported(D, F, rows=None):
@@ -111,29 +109,11 @@ def mlp_chain_fwd(x, w1, b1, w2, b2, resid, save=False):
     return (out, pre, act) if save else out
 
 
-def panel_gemm_supported(J, K):
-    return bool(L.lib().dig_panel_gemm_supported(int(J), int(K)))
-
-
-def panel_linear_ln(a, w, bias, resid, ln_g=None, ln_b=None, eps=1e-6, stats=True):
-    """out = a w^T + bias + resid in one launch of the row-panel GEMM and, with ln_g given, LayerNorm(out) from the same accumulators.
-    Returns (out, ln, mean, rstd); the last three are None without ln_g (mean / rstd also with stats=False)."""
-    rows, K = a.shape
-    J = w.shape[0]
-    out = torch.empty((rows, J), device=a.device, dtype=BF16)
-    ln = torch.empty((rows, J), device=a.device, dtype=BF16) if ln_g is not None else None
-    mean = torch.empty(rows, device=a.device, dtype=F32) if (ln_g is not None and stats) else None
-    rstd = torch.empty(rows, device=a.device, dtype=F32) if (ln_g is not None and stats) else None
-    L.call("dig_panel_gemm_ln_fwd", L.ptr(a), L.ptr(w), L.ptr(bias), L.ptr(resid), L.ptr(out), L.ptr(ln_g), L.ptr(ln_b), cf(eps), L.ptr(ln),
-           L.ptr(mean), L.ptr(rstd), rows, J, K, L.stream())
-    return out, ln, mean, rstd
-
-
 def mlp_chain_fwd_ln(x, ln_g, ln_b, eps, w1, b1, w2, b2, nln_g=None, nln_b=None, save=False, resid=None):
     """The second half of a transformer block with its LayerNorms in one launch: out = x + b2 + gelu(LN(x; ln_g, ln_b) w1^T + b1) w2^T and,
     when nln_g is given, the next block's norm1 of `out`.  Returns a dict: out; nln / nln_mean / nln_rstd (when nln_g is given; the
     statistics only with save=True); with save=True also ln, ln_mean, ln_rstd, pre, act -- what the backward reads.
-    ln_g None: x holds rows that are normalised already (panel_linear_ln) and `resid` the raw rows that are added back."""
+    ln_g None: x holds rows that are normalised already and `resid` the raw rows that are added back."""
     if resid is None:
         resid = x
     rows, D = x.shape

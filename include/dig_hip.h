@@ -122,7 +122,7 @@ int dig_wgrad_group(const dig_wgrad_prob_t* probs, int n_probs, const dig_wgrad_
  *   dig_mlp_chain_fwd_ln: the whole second half of Block.forward (modeling_finetune.py:156-158) with its LayerNorms:
  *       out = x + b2 + gelu_erf(LN(x; ln_g, ln_b) w1^T + b1) w2^T  and, when nln_g is given, nln_out = LN(out; nln_g, nln_b) -- the NEXT
  *       block's norm1 (:151), so that no LayerNorm launch and no second pass over the residual stream remain between two blocks.
- *       x holds the RAW residual rows and resid == x; or ln_g == NULL: x holds rows that are normalised already (dig_panel_gemm_ln_fwd)
+ *       x holds the RAW residual rows and resid == x; or ln_g == NULL: x holds rows that are normalised already
  *       and resid the raw ones.  LayerNorm statistics are taken in fp32 over the bf16 values that are (or would be) stored,
  *       variance as E[x^2] - E[x]^2, eps inside the square root.  ln_out / ln_mean / ln_rstd (normalised rows [R,D] bf16, statistics
  *       [R] fp32: what the backward keeps) and nln_mean / nln_rstd may be null.  F <= 2048.
@@ -140,14 +140,6 @@ int dig_mlp_chain_fwd_ln(const void* x, const void* resid, const float* ln_g, co
 int dig_mlp_chain_bwd(const void* dy, const void* w2t, const void* pre, const void* w1t, void* dpre_out, void* dx_out,
                       float* colsum_partials, int R, int D, int F, hipStream_t stream);
 int dig_mlp_chain_colsum_rows(int R);
-/* Row-panel GEMM for 384-wide outputs (csrc/panel_gemm.hip): a workgroup owns whole output rows, so row-wise epilogues run out of the
- * accumulators.  dig_panel_gemm_ln_fwd: out[R,J] = a[R,K] w[J,K]^T + bias + resid (bf16), and with ln_g given ln_out = LayerNorm(out; ln_g,
- * ln_b) with its row statistics (fp32 over the stored bf16 values, variance as E[x^2] - E[x]^2) -- the attention output projection, the
- * residual add and norm2 of Block.forward (modeling_finetune.py:152-156) in one launch.  J == 384, K a multiple of 64 (dig_panel_gemm_supported);
- * bias / resid / ln_* may be null (ln_mean and ln_rstd together).  R arbitrary. */
-int dig_panel_gemm_supported(int J, int K);
-int dig_panel_gemm_ln_fwd(const void* a, const void* w, const float* bias, const void* resid, void* out, const float* ln_g, const float* ln_b,
-                          float eps, void* ln_out, float* ln_mean, float* ln_rstd, int R, int J, int K, hipStream_t stream);
 /* dst[cols, rows] = src[rows, cols]^T, bf16 */
 int dig_transpose_bf16(const void* src, void* dst, int rows, int cols, hipStream_t stream);
 /* the same for `count` (<= 32) equally shaped matrices in one launch; srcs / dsts are HOST arrays of device pointers */

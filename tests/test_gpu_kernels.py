@@ -399,36 +399,6 @@ def test_wgrad_group(dev, R, D, Fh):
     assert not ops.WgradGroup(dev).add(mk(R, 100), ln2, torch.zeros(100, D, device=dev))
 
 
-@pytest.mark.parametrize("R,K", [(256, 64), (1000, 384), (4096, 1152), (65536, 384), (515, 1536)])
-def test_panel_gemm_ln_fwd(dev, R, K):
-    """dig_panel_gemm_ln_fwd (row-panel GEMM: out = a w^T + bias + resid, LayerNorm of the stored rows from the same accumulators) against
-    fp32 torch and against the two launches it replaces; without LayerNorm / bias / residual; ragged row counts."""
-    from dig_amd import ops
-    J, eps = 384, 1e-6
-    cpu_limit(dev, 2.0 * R * J * K, limit=3e9)
-    assert ops.panel_gemm_supported(J, K) and not ops.panel_gemm_supported(512, K) and not ops.panel_gemm_supported(J, 96)
-    g = torch.Generator(device="cpu").manual_seed(3 * R + K)
-    rn = lambda *s: torch.randn(*s, generator=g).to(dev)
-    a = rn(R, K).bfloat16()
-    w = (rn(J, K) * (K ** -0.5)).bfloat16(); bias = rn(J) * 0.5
-    res = (rn(R, J) * 1.5 + 0.4 * rn(R, 1)).bfloat16()
-    g1, be1 = 1 + 0.2 * rn(J), 0.3 * rn(J)
-    ref = a.float() @ w.float().t() + bias + res.float()
-    out, ln, mean, rstd = ops.panel_linear_ln(a, w, bias, res, g1, be1, eps)
-    assert rel(out, ref) < 6e-3
-    o = out.float()
-    assert rel(ln, F.layer_norm(o, (J,), g1, be1, eps)) < 6e-3
-    assert (mean - o.mean(1)).abs().max().item() < 2e-4 * (1 + o.mean(1).abs().max().item())
-    assert rel(rstd, (o.var(1, unbiased=False) + eps).rsqrt()) < 1e-4
-    out2 = ops.linear_fwd(a, w, bias=bias, resid=res)
-    ln2, _, rs2 = ops.layernorm_fwd(out2, g1, be1, eps)
-    assert rel(out, out2) < 2e-3 and rel(ln, ln2) < 5e-3 and rel(rstd, rs2) < 1e-3
-    out3, ln3, m3, r3 = ops.panel_linear_ln(a, w, None, None)
-    assert ln3 is None and m3 is None and rel(out3, a.float() @ w.float().t()) < 6e-3
-    out4, ln4, m4, r4 = ops.panel_linear_ln(a, w, bias, res, g1, be1, eps, stats=False)
-    assert torch.equal(out4, out) and torch.equal(ln4, ln) and m4 is None                     # bit-reproducible, statistics optional
-
-
 @pytest.mark.parametrize("R,Fh", [(128, 128), (4096, 1536), (333, 256), (65536, 1536), (1000, 2048)])
 def test_mlp_chain_fwd_with_layernorms(dev, R, Fh):
     """dig_mlp_chain_fwd_ln: norm2 on the way in, the next block's norm1 on the way out (modeling_finetune.py:151,156-158), against fp32 torch
@@ -513,6 +483,10 @@ def test_mlp_chain_fwd_bwd(dev, R, Fh):
     db = torch.randn(Fh, generator=g).to(dev); db0 = db.clone()
     ops.colsum_partials(parts, db)
     assert rel(db - db0, dpre.float().sum(0)) < 1e-4 and rel(db - db0, pp.grad.sum(0)) < 3e-3
+    # the polynomial GELU' (common.h::dgelu_f, |abs err| <= 2.8e-4, systematic in the tails) in aggregate: the fc1 weight gradient built
+    # from the device's d(pre-activation) against the one built from the exact erf-GELU gradient, on N(0, ~1.2) pre-activations
+    if R <= 4096:
+        assert rel(dpre.float().t() @ x.float(), pp.grad.t() @ x.float()) < 3e-3
     dact, bparts = ops.linear_dgrad(dy, w2, gelu_pre=pre, colsum=True)
     assert rel(dpre, dact) < 2e-3 and rel(dx, ops.linear_dgrad(dact, w1)) < 4e-3
     dx2, dpre2, parts2 = ops.mlp_chain_bwd(dy, w2t, pre, w1t)

@@ -9,7 +9,7 @@
 #    gpurun_out/<tag>_pmc_kernel_counters.txt     MFMA / LDS utilisation, occupancy, instruction mix passes
 # Copy what should be judged into profiles/ afterwards.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
@@ -47,7 +47,7 @@ for set in "MfmaUtil LdsUtil" "VmemLatency OccupancyPercent" "MemUnitStalled" "S
   rm -rf $OUT/prof_pmc
   rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/prof_pmc -- $SHORT > /dev/null 2>&1
   echo "== $set" >> $OUT/${TAG}_pmc_kernel_counters.txt
-  python $ROOT/tools/pmc_summary.py $(ls $OUT/prof_pmc/*/*counter_collection.csv | head -1) | grep -E "gemm|attn|ln_|reduce_partials|mlp_chain" >> $OUT/${TAG}_pmc_kernel_counters.txt
+  python $ROOT/tools/pmc_summary.py $(ls $OUT/prof_pmc/*/*counter_collection.csv | head -1) | grep -E "gemm|attn|ln_|reduce_partials|mlp_chain|wgrad" >> $OUT/${TAG}_pmc_kernel_counters.txt
 done
 rm -rf $OUT/prof_pmc
 cd $ROOT
