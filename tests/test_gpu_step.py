@@ -536,17 +536,25 @@ def test_vit_base_b256_full_size_properties():
     assert more[-1]["loss_pixel"] < s1["loss_pixel"]
 
 
-def test_rccl_path_world1_matches_local_path():
+@pytest.mark.parametrize("which", ["tiny", "vit_small"])
+def test_rccl_path_world1_matches_local_path(which):
     """The data-parallel wrapper on a one-rank 'nccl' (= RCCL) group: every collective of the N>1 path is issued
     (BN-statistics all-reduce, key all-gather, 17 gradient-bucket all-reduces, 1/world averaging) and the step must equal
-    the plain single-process step."""
+    the plain single-process step.  `vit_small`: the model of the BASELINE configs, whose encoder blocks run their weight gradients on
+    the grouped launch (a block's bucket becomes final -- and its all-reduce is issued -- one launch later)."""
     import torch.distributed as dist
     from dig_amd.parallel import DistributedDataParallel
-    cfg = O.DiGConfig(**O.TINY)
-    seed, B = 21, 4
+    seed = 21
+    if which == "tiny":
+        cfg, B = O.DiGConfig(**O.TINY), 4
+        P0, S0 = O.det_state(cfg, seed)
+    else:
+        cfg, B = O.make_config("pretrain_simmim_moco_ori_vit_small_patch4_32x128"), 8
+        P0, S0 = O.init_state(cfg, seed)
+    state = lambda: ({k: v.clone() for k, v in P0.items()}, {k: v.clone() for k, v in S0.items()})
     hp = O.StepHyper(lr=1e-3)
     im, au, mk = O.synthetic_batch(B, cfg, 900)
-    base = build_model(cfg, *O.det_state(cfg, seed))
+    base = build_model(cfg, *state())
     (s0,), _ = run_engine_steps(base, [(im, au, mk)], hp)
     g0 = base.flat_grads.clone()
     created = False
@@ -556,7 +564,7 @@ def test_rccl_path_world1_matches_local_path():
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
         created = True
     try:
-        m = build_model(cfg, *O.det_state(cfg, seed))
+        m = build_model(cfg, *state())
         ddp = DistributedDataParallel(m)
         assert m.comm.world == 1
         from gpu_util import engine_args
@@ -574,7 +582,9 @@ def test_rccl_path_world1_matches_local_path():
             assert abs(s1[k] - s0[k]) <= 1e-3 * abs(s0[k]) + 1e-5, (k, s1[k], s0[k])
         assert not m.comm._pending
         rel = ((m.flat_grads - g0).norm() / g0.norm()).item()
-        assert rel < 1e-6, rel                                           # every reduction on the gradient path is deterministic
+        # every reduction on the gradient path is deterministic; the ViT-S forward differs between the two paths in WHICH stream plan runs it
+        # (same kernels, same order per stream), not in arithmetic
+        assert rel < 1e-6, rel
         # the ORDER of collectives on the communicator (a second step, recorded): it must be what every rank issues, or the first real
         # multi-GPU step dead-locks.  The committed list was recorded from this path (tools/gpu_collective_order.py).
         import json
@@ -582,7 +592,7 @@ def test_rccl_path_world1_matches_local_path():
         train_one_epoch(ddp, None, None, [([im, au, mk], torch.ones(1), torch.ones(1))], None, opt, torch.device("cuda:0"), 1,
                         NativeScalerWithGradNormCount(), None, patch_size=4, normlize_target=False, start_steps=1,
                         lr_schedule_values=np.full(3, hp.lr), wd_schedule_values=np.full(3, hp.weight_decay), args=args)
-        want = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "collective_order_tiny.json")))
+        want = json.load(open(os.path.join(os.path.dirname(__file__), "golden", f"collective_order_{which}.json")))
         got = [[op, n] for op, n in m.comm.log]
         m.comm.log = None
         assert got == want["step"], (got[:6], want["step"][:6])

@@ -1,6 +1,6 @@
 """Records the order of collectives one pre-training step of the tiny model issues on its communicator (one-rank RCCL group, collective code
 paths forced) and writes tests/golden/collective_order_tiny.json -- the list tests/test_gpu_step.py::test_rccl_path_world1_matches_local_path
-asserts.  Run on the GPU box: python tools/gpu_collective_order.py gpurun_out/collective_order_tiny.json   (then copy it to tests/golden/)"""
+asserts.  Run on the GPU box: python tools/gpu_collective_order.py gpurun_out/collective_order_tiny.json [tiny | vit_small]   (then copy it to tests/golden/)"""
 import json
 import os
 import sys
@@ -21,10 +21,16 @@ from dig_amd.utils import NativeScalerWithGradNormCount  # noqa: E402
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 os.environ.setdefault("MASTER_PORT", "29641")
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-cfg = O.DiGConfig(**O.TINY)
+which = sys.argv[2] if len(sys.argv) > 2 else "tiny"
+if which == "tiny":
+    cfg, Bn = O.DiGConfig(**O.TINY), 4
+    P, S = O.det_state(cfg, 21)
+else:                                       # ViT-S: the grouped weight-gradient launches shift every block's bucket by one launch
+    cfg, Bn = O.make_config("pretrain_simmim_moco_ori_vit_small_patch4_32x128"), 8
+    P, S = O.init_state(cfg, 21)
 hp = O.StepHyper(lr=1e-3)
-im, au, mk = O.synthetic_batch(4, cfg, 900)
-m = build_model(cfg, *O.det_state(cfg, 21))
+im, au, mk = O.synthetic_batch(Bn, cfg, 900)
+m = build_model(cfg, P, S)
 ddp = DistributedDataParallel(m)
 m.comm.world_override = True
 args = engine_args(hp)
@@ -38,5 +44,5 @@ for s in range(3):
     logs.append([[op, n] for op, n in m.comm.log])
 assert logs[1] == logs[2], "the order of collectives must not depend on the step"
 with open(sys.argv[1], "w") as f:
-    json.dump({"config": "tiny, B = 4, one rank, collective paths forced", "step": logs[1], "first_step": logs[0]}, f, indent=0)
+    json.dump({"config": f"{which}, B = {Bn}, one rank, collective paths forced", "step": logs[1], "first_step": logs[0]}, f, indent=0)
 dist.destroy_process_group()
