@@ -177,6 +177,10 @@ __global__ __launch_bounds__(256) void ln_bwd_finalize_kernel(const float* __res
 }
 
 // ---------------- BatchNorm ----------------
+__device__ __forceinline__ void load8f(const float* p, float* v) {      // 8 consecutive fp32 (32-byte aligned: column groups of 8)
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
 // MODE 0: out[0][c] += sum_r x, out[1][c] += sum_r x^2
 // MODE 1: g = dy * (relu ? (gamma*xhat+beta > 0) : 1); out[0][c] += sum g, out[1][c] += sum g*xhat
 template <int MODE>
@@ -184,57 +188,88 @@ __global__ __launch_bounds__(256) void bn_colstats_kernel(const bf16_t* __restri
                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           int relu, float* __restrict__ out, int rows, int C, int rows_per_block) {
-  __shared__ float red[4][4][64];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int c = blockIdx.x * 128 + lane * 2;
+  // A thread owns one group of 8 columns (16-byte loads; round 4: the 4-byte form ran the backward statistics of a [32 768, 512] layer at
+  // 1.5 TB/s) and walks the rows of its strip; with fewer than 256 column groups several rows are in flight per workgroup (lanes
+  // g = tid / c8 take rows r0 + g, r0 + g + G, ...), and their partial sums are folded through LDS in a fixed order.
+  __shared__ float red[256][17];
+  const int c8 = C >> 3;
+  const int tpr = min(c8, 256);                                      // threads per row pass
+  const int G = 256 / tpr;                                           // rows in flight
+  const int tid = threadIdx.x;
+  const int g = tid / tpr, ct = tid - g * tpr;
+  const int cg = blockIdx.x * 256 + ct;                              // column group (grid.x = ceil(c8 / 256))
+  const bool live = g < G && cg < c8;
+  const int c = cg * 8;
   const int r0 = blockIdx.y * rows_per_block;
   const int r1 = min(rows, r0 + rows_per_block);
-  float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
-  if (c < C) {
-    float mu0 = 0, mu1 = 0, rs0 = 1, rs1 = 1, g0 = 1, g1 = 1, be0 = 0, be1 = 0;
+  float a[8], b[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) a[k] = b[k] = 0.f;
+  if (live) {
+    float mu[8], rs[8], gm[8], bt[8];
     if (MODE == 1) {
-      mu0 = mean[c]; mu1 = mean[c + 1]; rs0 = rstd[c]; rs1 = rstd[c + 1];
-      if (gamma) { g0 = gamma[c]; g1 = gamma[c + 1]; be0 = beta[c]; be1 = beta[c + 1]; }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const float4 m4 = *reinterpret_cast<const float4*>(mean + c + 4 * h), r4 = *reinterpret_cast<const float4*>(rstd + c + 4 * h);
+        mu[4 * h] = m4.x; mu[4 * h + 1] = m4.y; mu[4 * h + 2] = m4.z; mu[4 * h + 3] = m4.w;
+        rs[4 * h] = r4.x; rs[4 * h + 1] = r4.y; rs[4 * h + 2] = r4.z; rs[4 * h + 3] = r4.w;
+        float4 g4 = make_float4(1.f, 1.f, 1.f, 1.f), b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gamma) { g4 = *reinterpret_cast<const float4*>(gamma + c + 4 * h); b4 = *reinterpret_cast<const float4*>(beta + c + 4 * h); }
+        gm[4 * h] = g4.x; gm[4 * h + 1] = g4.y; gm[4 * h + 2] = g4.z; gm[4 * h + 3] = g4.w;
+        bt[4 * h] = b4.x; bt[4 * h + 1] = b4.y; bt[4 * h + 2] = b4.z; bt[4 * h + 3] = b4.w;
+      }
     }
-    for (int r = r0 + wv; r < r1; r += 4) {
-      const unsigned u = *reinterpret_cast<const unsigned*>(x + (size_t)r * C + c);
-      float x0 = bf2f((bf16_t)(u & 0xffff)), x1 = bf2f((bf16_t)(u >> 16));
+    for (int r = r0 + g; r < r1; r += G) {
+      float xv[8];
+      load_row<8>(x + (size_t)r * C + c, xv);
       if (MODE == 0) {
-        a0 += x0; a1 += x1; b0 += x0 * x0; b1 += x1 * x1;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { a[k] += xv[k]; b[k] += xv[k] * xv[k]; }
       } else {
-        const unsigned du = *reinterpret_cast<const unsigned*>(dy + (size_t)r * C + c);
-        float d0 = bf2f((bf16_t)(du & 0xffff)), d1 = bf2f((bf16_t)(du >> 16));
-        x0 = (x0 - mu0) * rs0; x1 = (x1 - mu1) * rs1;
-        if (relu) {
-          if (!(g0 * x0 + be0 > 0.f)) d0 = 0.f;
-          if (!(g1 * x1 + be1 > 0.f)) d1 = 0.f;
+        float dv[8];
+        load_row<8>(dy + (size_t)r * C + c, dv);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float xh = (xv[k] - mu[k]) * rs[k];
+          float d = dv[k];
+          if (relu && !(gm[k] * xh + bt[k] > 0.f)) d = 0.f;
+          a[k] += d; b[k] += d * xh;
         }
-        a0 += d0; a1 += d1; b0 += d0 * x0; b1 += d1 * x1;
       }
     }
   }
-  red[0][wv][lane] = a0; red[1][wv][lane] = a1; red[2][wv][lane] = b0; red[3][wv][lane] = b1;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { red[tid][k] = a[k]; red[tid][8 + k] = b[k]; }
   __syncthreads();
-  if (wv == 0 && c < C) {                       // per-row-strip partials (no atomics: statistics are bit-reproducible)
+  if (g == 0 && cg < c8) {                      // per-row-strip partials (no atomics: statistics are bit-reproducible)
     float* o = out + (size_t)blockIdx.y * 2 * C;
-    o[c] = red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane];
-    o[c + 1] = red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane];
-    o[C + c] = red[2][0][lane] + red[2][1][lane] + red[2][2][lane] + red[2][3][lane];
-    o[C + c + 1] = red[3][0][lane] + red[3][1][lane] + red[3][2][lane] + red[3][3][lane];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float sa = 0.f, sb = 0.f;
+      for (int q = 0; q < G; ++q) { sa += red[q * tpr + ct][k]; sb += red[q * tpr + ct][8 + k]; }
+      o[c + k] = sa;
+      o[C + c + k] = sb;
+    }
   }
 }
 
 // sums[e] = sum_b partial[b][e], e < 2*C  (fixed order)
 __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __restrict__ partial, int nb, int n, float* __restrict__ sums) {
-  __shared__ float red[8][32];
-  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cx;
+  // 8 columns x 32 strip groups per workgroup (round 4: 32 x 8 left a [512 strips, 1 024] problem to 32 workgroups of 64 dependent loads: 20 us)
+  __shared__ float red[32][9];
+  const int cx = threadIdx.x & 7, ry = threadIdx.x >> 3;
+  const int c = blockIdx.x * 8 + cx;
   float a = 0.f;
   if (c < n)
-    for (int b = ry; b < nb; b += 8) a += partial[(size_t)b * n + c];
+    for (int b = ry; b < nb; b += 32) a += partial[(size_t)b * n + c];
   red[ry][cx] = a;
   __syncthreads();
-  if (ry == 0 && c < n) sums[c] = ((red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx])) + ((red[4][cx] + red[5][cx]) + (red[6][cx] + red[7][cx]));
+  if (ry == 0 && c < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 32; ++q) t += red[q][cx];
+    sums[c] = t;
+  }
 }
 
 // y = [relu]( gamma * (x - mean) * rstd + beta );  mean/rstd derived from global sums (sum, sumsq) and 1/n.
@@ -249,14 +284,18 @@ __global__ __launch_bounds__(256) void bn_fwd_apply_kernel(const bf16_t* __restr
   const unsigned t0 = blockIdx.x * blockDim.x + threadIdx.x;
   const int c = (int)(t0 % (unsigned)c8) * 8;
   float mu[8], rs[8], gm[8], bt[8];
+  {
+    float s1[8], s2[8];
+    load8f(sums + c, s1); load8f(sums + C + c, s2);
+    if (gamma) { load8f(gamma + c, gm); load8f(beta + c, bt); }
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    mu[k] = sums[c + k] * inv_n;
-    const float var = fmaxf(sums[C + c + k] * inv_n - mu[k] * mu[k], 0.f);
-    rs[k] = rsqrtf(var + eps);
-    gm[k] = gamma ? gamma[c + k] : 1.f;
-    bt[k] = gamma ? beta[c + k] : 0.f;
-    if (t0 < (unsigned)c8) { mean_out[c + k] = mu[k]; rstd_out[c + k] = rs[k]; }
+    for (int k = 0; k < 8; ++k) {
+      mu[k] = s1[k] * inv_n;
+      const float var = fmaxf(s2[k] * inv_n - mu[k] * mu[k], 0.f);
+      rs[k] = rsqrtf(var + eps);
+      if (!gamma) { gm[k] = 1.f; bt[k] = 0.f; }
+      if (t0 < (unsigned)c8) { mean_out[c + k] = mu[k]; rstd_out[c + k] = rs[k]; }
+    }
   }
   for (size_t i = t0; i < total8; i += (size_t)gridDim.x * blockDim.x) {
     float v[8];
@@ -282,11 +321,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t* __restr
   const unsigned t0 = blockIdx.x * blockDim.x + threadIdx.x;          // (gridDim.x * 256) % (C/8) == 0: fixed column group
   const int c = (int)(t0 % (unsigned)c8) * 8;
   float mu[8], rs[8], gm[8], bt[8], s1[8], s2[8];
+  load8f(mean + c, mu); load8f(rstd + c, rs); load8f(sums + c, s1); load8f(sums + C + c, s2);
+  if (gamma) { load8f(gamma + c, gm); load8f(beta + c, bt); }
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    mu[k] = mean[c + k]; rs[k] = rstd[c + k];
-    gm[k] = gamma ? gamma[c + k] : 1.f; bt[k] = gamma ? beta[c + k] : 0.f;
-    s1[k] = sums[c + k] * inv_n; s2[k] = sums[C + c + k] * inv_n;
+    if (!gamma) { gm[k] = 1.f; bt[k] = 0.f; }
+    s1[k] *= inv_n; s2[k] *= inv_n;
   }
   for (size_t i = t0; i < total8; i += (size_t)gridDim.x * blockDim.x) {
     float v[8], d[8];
@@ -377,10 +417,11 @@ extern "C" int dig_layernorm_bwd(const void* dy, const void* x, const float* gam
   return dig_layernorm_bwd_finalize(workspace, rows, D, dgamma, dbeta, dcolsum, stream);
 }
 
+static inline int bn_col_blocks(int C) { return ((C >> 3) + 255) / 256; }
 static inline int bn_rows_per_block(int rows, int C) {
-  const int cb = (C + 127) / 128;
-  int rpb = 64;
-  while ((long)cb * ((rows + rpb - 1) / rpb) > 2048) rpb *= 2;
+  const int cb = bn_col_blocks(C);
+  int rpb = 32;
+  while ((long)cb * ((rows + rpb - 1) / rpb) > 1024) rpb *= 2;
   return rpb;
 }
 
@@ -392,12 +433,13 @@ extern "C" long long dig_bn_stats_workspace_bytes(int rows, int C) {
 // sums[2,C] = (sum_r x, sum_r x^2), overwritten; two-stage and deterministic
 extern "C" int dig_bn_stats(const void* x, float* sums, float* workspace, int rows, int C, hipStream_t stream) {
   if (!x || !sums || !workspace || rows <= 0 || C <= 0 || (C & 7)) return DIG_ERR_ARG;
-  const int cb = (C + 127) / 128;
+  if (!aligned16(x)) return DIG_ERR_ALIGN;
+  const int cb = bn_col_blocks(C);
   const int rpb = bn_rows_per_block(rows, C);
   const int nb = (rows + rpb - 1) / rpb;
   hipLaunchKernelGGL(bn_colstats_kernel<0>, dim3(cb, nb), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)nullptr, nullptr,
                      nullptr, nullptr, nullptr, 0, workspace, rows, C, rpb);
-  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((2 * C + 31) / 32), dim3(256), 0, stream, workspace, nb, 2 * C, sums);
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((2 * C + 7) / 8), dim3(256), 0, stream, workspace, nb, 2 * C, sums);
   return dig_check_launch();
 }
 
@@ -408,7 +450,7 @@ static inline int bn_apply_grid(size_t total8, int C) {
   int a = c8, b = 256;
   while (b) { const int t = a % b; a = b; b = t; }                     // a = gcd(c8, 256)
   const int unit = c8 / a;                                             // blocks per whole column period
-  const size_t want = std::min<size_t>(2048, (total8 + 255) / 256);
+  const size_t want = std::max<size_t>(std::min<size_t>(256, (total8 + 255) / 256), std::min<size_t>(2048, (total8 + 2047) / 2048));   // ~8 groups per thread
   return (int)std::max<size_t>(1, (want + unit - 1) / unit) * unit;
 }
 
@@ -417,7 +459,7 @@ extern "C" int dig_bn_fwd_apply(const void* x, const float* sums, float n_total,
                                 hipStream_t stream) {
   if (!x || !sums || !y || !mean_out || !rstd_out || rows <= 0 || (C & 7) || n_total <= 0.f) return DIG_ERR_ARG;
   if ((gamma == nullptr) != (beta == nullptr)) return DIG_ERR_ARG;
-  if (!aligned16(x) || !aligned16(y)) return DIG_ERR_ALIGN;
+  if (!aligned16(x) || !aligned16(y) || !aligned16(sums) || (gamma && (!aligned16(gamma) || !aligned16(beta)))) return DIG_ERR_ALIGN;
   const size_t total8 = (size_t)rows * C / 8;
   const int grid = bn_apply_grid(total8, C);
   hipLaunchKernelGGL(bn_fwd_apply_kernel, dim3(grid), dim3(256), 0, stream, (const bf16_t*)x, sums, 1.0f / n_total, eps, gamma,
@@ -428,12 +470,13 @@ extern "C" int dig_bn_fwd_apply(const void* x, const float* sums, float n_total,
 extern "C" int dig_bn_bwd_stats(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
                                 const float* beta, int relu, float* sums, float* workspace, int rows, int C, hipStream_t stream) {
   if (!dy || !x || !mean || !rstd || !sums || !workspace || rows <= 0 || (C & 7)) return DIG_ERR_ARG;
-  const int cb = (C + 127) / 128;
+  if (!aligned16(x) || !aligned16(dy) || !aligned16(mean) || !aligned16(rstd) || (gamma && (!aligned16(gamma) || !aligned16(beta)))) return DIG_ERR_ALIGN;
+  const int cb = bn_col_blocks(C);
   const int rpb = bn_rows_per_block(rows, C);
   const int nb = (rows + rpb - 1) / rpb;
   hipLaunchKernelGGL(bn_colstats_kernel<1>, dim3(cb, nb), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)dy, mean, rstd, gamma,
                      beta, relu, workspace, rows, C, rpb);
-  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((2 * C + 31) / 32), dim3(256), 0, stream, workspace, nb, 2 * C, sums);
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((2 * C + 7) / 8), dim3(256), 0, stream, workspace, nb, 2 * C, sums);
   return dig_check_launch();
 }
 
@@ -441,7 +484,8 @@ extern "C" int dig_bn_bwd_apply(const void* dy, const void* x, const float* mean
                                 const float* beta, int relu, const float* sums, float n_total, void* dx, int rows, int C,
                                 hipStream_t stream) {
   if (!dy || !x || !mean || !rstd || !sums || !dx || rows <= 0 || (C & 7) || n_total <= 0.f) return DIG_ERR_ARG;
-  if (!aligned16(x) || !aligned16(dy) || !aligned16(dx)) return DIG_ERR_ALIGN;
+  if (!aligned16(x) || !aligned16(dy) || !aligned16(dx) || !aligned16(mean) || !aligned16(rstd) || !aligned16(sums) ||
+      (gamma && (!aligned16(gamma) || !aligned16(beta)))) return DIG_ERR_ALIGN;
   const size_t total8 = (size_t)rows * C / 8;
   const int grid = bn_apply_grid(total8, C);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)x, mean, rstd,

@@ -32,6 +32,18 @@ WGRAD_INLINE = os.environ.get("DIG_WGRAD_INLINE", "1") == "1"
 BWD_SINGLE_STREAM = os.environ.get("DIG_BWD_SINGLE", "0") == "1"    # lab switch: the whole backward on the caller's stream (sum of solo kernel times)
 
 
+# Lab: GPU time stamps at the phase boundaries of a step without a profiler (tools/gpu_step_phases.py sets PHASE_MARKS = []): events on the
+# caller's stream, resolved by the tool after a synchronise.
+PHASE_MARKS = None
+
+
+def _mark(name, dev):
+    if PHASE_MARKS is not None:
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(torch.cuda.current_stream(dev))
+        PHASE_MARKS.append((name, ev))
+
+
 class LocalComm:
     world, rank = 1, 0
 
@@ -236,7 +248,7 @@ class _Step:
         # block i's bucket is final -- and its all-reduce is issued -- one launch later.  Shapes the grouped kernel does not take (tiny test
         # models) and the batched-reduction mode keep the per-layer launches.
         Rg = (B * N) if views == 1 else (2 * B * N)
-        grouped = (ops.WGRAD_GROUP and not BATCH_REDUCE and WGRAD_GROUPING != "off" and
+        grouped = (ops.WGRAD_GROUP and WGRAD_GROUPING != "off" and
                    all(ops.wgrad_group_route(o, i_, Rg) is not None for o, i_ in ((M.F, D), (D, M.F), (3 * D, D), (D, D))))
         grp = ops.WgradGroup(dev) if grouped else None
         prev_block = None
@@ -453,6 +465,7 @@ class _Step:
         mask_u8 = mask_b2n.permute(1, 0, 2).reshape(2 * B, N).to(torch.uint8).contiguous()    # rows 0..B-1 = view 0 (:497)
         self.images, self.aug, self.mask_u8 = images, aug, mask_u8
         ew_on, ew_mo = _weights(M)
+        _mark("forward: start", dev)
         ops.cast_f32_to_bf16(M._flat["online"], M.shadow("online"))
         # ---- momentum branch (no grad) on a second HIP stream: it depends only on the pre-step online weights (fp32
         # arena, read-only here) and the inputs, so it overlaps the online forward.  EMA with the current online weights
@@ -565,6 +578,7 @@ class _Step:
                                                                         pooled_m, "momentum_projection_layer", "momentum", False)
                 qs, self.saved_pred = self.mlp_forward(qs, "predictor", "online", True)
                 del enc_m, masked_m, pooled_m
+        _mark("forward: both encoders + heads joined", dev)
         M._flat["bn_count"] += 1                                            # all 14 BatchNorm layers ran once
         # ---- InfoNCE (:444-461): q1 vs gathered k2, q2 vs gathered k1, labels = arange + n*rank
         n = B * nw                                                          # rows of q1 / q2
@@ -595,6 +609,7 @@ class _Step:
         accs = stats[:, 1:].reshape(4) * (100.0 / n)                        # q1_acc1, q1_acc5, q2_acc1, q2_acc5
         if vis_out is None:
             vis_out, _ = decoder()
+        _mark("forward: InfoNCE + SimMIM decoder done", dev)
         return contra, accs, vis_out
 
     # ------------------------------------------------------------------ full backward
@@ -608,6 +623,7 @@ class _Step:
         # the whole augmented view -- is exactly zero in the reference, so nothing is launched for it and the encoder
         # backward runs on view 0's rows only (the gradient arena was zero-filled by optimizer.zero_grad()).
         contrast = g_contra is not None
+        _mark("backward: start (loss, MSE, autograd entry done)", dev)
         views = 2 if (contrast or (g_vis is not None and self.mim_views == 2)) else 1      # encoder rows that carry a gradient
         d_enc = torch.empty_like(self.enc) if contrast else torch.zeros((views * B * N, D), device=dev, dtype=BF16)
         n = B * nw
@@ -648,6 +664,7 @@ class _Step:
         self._grad_ready(dev, "pix_decoder")
         # ---- encoder
         ew_on, _ = _weights(M)
+        _mark("backward: heads + decoder done", dev)
         if views == 2 or g_vis is not None:
             self.encoder_backward(ew_on, self.saved_enc, d_enc, self.images, self.aug, self.mask_u8, views=views)
         else:
@@ -657,6 +674,7 @@ class _Step:
         main, side = self._streams(dev)
         if side is not main:
             main.wait_stream(side)                  # every gradient is final on the caller's stream (grad norm / AdamW follow)
+        _mark("backward: encoder done, streams joined", dev)
         self._keep.clear()                          # (blocks go back to the caller's stream's pool: its later work is ordered behind the join)
         self._keep_marks.clear()
         self.saved_enc = self.saved_pix = self.saved_proj = self.saved_pred = self.saved_dec = self.wT = None

@@ -581,9 +581,15 @@ def gelu_bwd(dact, pre, out):
     L.call("dig_gelu_bwd", L.ptr(dact), L.ptr(pre), L.ptr(out), cll(dact.numel()), L.stream())
 
 
+def _bn_ws_floats(rows, C):
+    f = L.lib().dig_bn_stats_workspace_bytes
+    f.restype = ctypes.c_longlong
+    return int(f(int(rows), int(C))) // 4
+
+
 def bn_stats(x, sums):
     """sums[2,C] = (sum_r x, sum_r x^2) -- overwritten, deterministic."""
-    ws = _workspace2(x.device, 2048 * 2 * 128 + 64 * 2 * x.shape[1])
+    ws = _workspace2(x.device, _bn_ws_floats(x.shape[0], x.shape[1]))
     L.call("dig_bn_stats", L.ptr(x), L.ptr(sums), L.ptr(ws), x.shape[0], x.shape[1], L.stream())
 
 
@@ -602,7 +608,7 @@ def bn_update_running(sums, n_total, momentum, rm, rv):
 
 
 def bn_bwd_stats(dy, x, mean, rstd, gamma, beta, relu, sums):
-    ws = _workspace2(x.device, 2048 * 2 * 128 + 64 * 2 * x.shape[1])
+    ws = _workspace2(x.device, _bn_ws_floats(x.shape[0], x.shape[1]))
     L.call("dig_bn_bwd_stats", L.ptr(dy), L.ptr(x), L.ptr(mean), L.ptr(rstd), L.ptr(gamma), L.ptr(beta), int(relu), L.ptr(sums),
            L.ptr(ws), x.shape[0], x.shape[1], L.stream())
 
