@@ -46,7 +46,15 @@ def ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_get_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def stream():
+    """The caller's current HIP stream as a handle.  torch.cuda.current_stream() builds a Stream object through three Python layers (9 us,
+    200 times per step = a quarter of the host time of a step); the raw getter is one C call."""
+    if _raw_stream is not None and _get_device is not None:
+        return ctypes.c_void_p(_raw_stream(_get_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

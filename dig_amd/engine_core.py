@@ -275,6 +275,17 @@ class _Step:
             wg = red.wgrad if red else ops.linear_wgrad
             csum = red.colsum_partials if red else ops.colsum_partials
             held = []                                                        # operands of the grouped launch (kept alive until the streams join)
+            # With the grouped launch, everything this block hands to the second stream -- the bias / LayerNorm-parameter column sums: five
+            # small launches that only consume what the chain has produced -- goes over in ONE hand-over at the end of the block (one
+            # wait_stream + one stream switch on the host instead of five; the kernels are off the critical path either way)
+            late, late_t = [], []
+
+            def side_later(fn, *tensors):
+                if grp:
+                    late.append(fn)
+                    late_t.extend(tensors)
+                else:
+                    on_side(fn, *tensors)
             if grp:
                 def wg(dy_, x_, dw_):
                     assert grp.add(dy_, x_, dw_)
@@ -292,7 +303,7 @@ class _Step:
                 dln2 = None                                                                              # the fc1 bias sums fused
             if grp:
                 wg(dact, ln2, g["mlp.fc1.weight"])
-                on_side(lambda: csum(bparts, g["mlp.fc1.bias"]), bparts)
+                side_later(lambda: csum(bparts, g["mlp.fc1.bias"]), bparts)
                 if WGRAD_GROUPING == "pair":
                     launch_group(*held)
             else:
@@ -304,7 +315,7 @@ class _Step:
             if red:                                                           # norm2 grads + colsum(dx) = fc2 bias grad: off the chain
                 red.layernorm_finalize(ws2, x_mid.shape[0], D, g["norm2.weight"], g["norm2.bias"], g["mlp.fc2.bias"])
             else:
-                on_side(fin2, ws2)
+                side_later(fin2, ws2)
             # x_mid = x + proj(attn(ln1))
             if grp:
                 wg(dx_mid, ctx, g["attn.proj.weight"])
@@ -320,7 +331,7 @@ class _Step:
                 if grp:
                     wg(dqkv, ln1, g["attn.qkv.weight"])
                     launch_group(*held)
-                    on_side(lambda: (csum(qs, gb[:D]), csum(vs, gb[2 * D:])), qs, vs)
+                    side_later(lambda: (csum(qs, gb[:D]), csum(vs, gb[2 * D:])), qs, vs)
                 else:
                     on_side(lambda: (wg(dqkv, ln1, g["attn.qkv.weight"]),
                                      csum(qs, gb[:D]), csum(vs, gb[2 * D:])), dqkv, ln1, qs, vs)
@@ -329,7 +340,7 @@ class _Step:
                 if grp:
                     wg(dqkv, ln1, g["attn.qkv.weight"])
                     launch_group(*held)
-                    on_side(lambda: (ops.colsum(dqkv, gb[:D], cols=D), ops.colsum(dqkv[:, 2 * D:], gb[2 * D:], cols=D)), dqkv)
+                    side_later(lambda: (ops.colsum(dqkv, gb[:D], cols=D), ops.colsum(dqkv[:, 2 * D:], gb[2 * D:], cols=D)), dqkv)
                 else:
                     on_side(lambda: (wg(dqkv, ln1, g["attn.qkv.weight"]),
                                      ops.colsum(dqkv, gb[:D], cols=D), ops.colsum(dqkv[:, 2 * D:], gb[2 * D:], cols=D)), dqkv, ln1)
@@ -338,10 +349,13 @@ class _Step:
                                               g["norm1.bias"], out=dln1, dres_colsum=g["attn.proj.bias"], defer=True)
             if red:                                                           # norm1 grads + colsum(dx_mid) = proj bias grad
                 red.layernorm_finalize(ws1, x.shape[0], D, g["norm1.weight"], g["norm1.bias"], g["attn.proj.bias"])
-                on_side(red.flush, *red.tensors())
+                side_later(red.flush, *red.tensors())
             else:
-                on_side(fin1, ws1)
-            del dact, pre, act, dln2, dqkv, dctx, held
+                side_later(fin1, ws1)
+            if late:
+                fns = list(late)
+                on_side(lambda: [f() for f in fns], *late_t)
+            del dact, pre, act, dln2, dqkv, dctx, held, late, late_t
             self._mark_kept(dev)
             self._release_kept(dev)
             # this block's gradients are final once BOTH streams pass this point: the bucket's all-reduce is issued from the

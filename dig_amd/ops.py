@@ -19,9 +19,16 @@ GEMM_BK_FWD, GEMM_BK_BWD = 64, 32
 _ws = {}
 
 
+def _stream_id(dev):
+    """Raw handle of the current stream of `dev` (a dictionary key; see _lib.stream for why not torch.cuda.current_stream())."""
+    if L._raw_stream is not None and dev.index is not None:
+        return L._raw_stream(dev.index)
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
 def _workspace(dev, numel):
     """Per-device fp32 scratch for split-R partial slabs (grown on demand, reused across launches on one stream)."""
-    key = (dev, torch.cuda.current_stream(dev).cuda_stream)        # one scratch per stream: launches on a stream are ordered
+    key = (dev, _stream_id(dev))        # one scratch per stream: launches on a stream are ordered
     w = _ws.get(key)
     if w is None or w.numel() < numel:
         w = _ws[key] = torch.empty(max(numel, 1 << 22), device=dev, dtype=F32)
@@ -248,7 +255,7 @@ _ws3 = {}
 
 
 def _batch_workspace(dev, numel):
-    key = (dev, torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0)
+    key = (dev, _stream_id(dev) if dev.type == "cuda" else 0)
     w = _ws3.get(key)
     if w is None or w.numel() < numel:
         w = _ws3[key] = torch.empty(numel, device=dev, dtype=F32)
@@ -398,7 +405,7 @@ class WgradGroup:
         return pl
 
     def _slabs(self, nbytes):
-        key = (str(self.dev), torch.cuda.current_stream(self.dev).cuda_stream if self.dev.type == "cuda" else 0, self.set)
+        key = (str(self.dev), _stream_id(self.dev) if self.dev.type == "cuda" else 0, self.set)
         w = _wg_slabs.get(key)
         if w is None or w.numel() * 4 < nbytes:
             w = _wg_slabs[key] = torch.empty((max(nbytes, 1 << 26) + 3) // 4, device=self.dev, dtype=F32)
@@ -446,7 +453,7 @@ _ws2 = {}
 
 def _workspace2(dev, numel):
     """Second fp32 scratch (column-sum / LayerNorm-backward partials)."""
-    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    key = (dev, _stream_id(dev))
     w = _ws2.get(key)
     if w is None or w.numel() < numel:
         w = _ws2[key] = torch.empty(max(numel, 1 << 20), device=dev, dtype=F32)
