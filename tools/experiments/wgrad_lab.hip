@@ -189,7 +189,7 @@ int main(int argc, char** argv) {
     double acc[8] = {0}; int n = 0;
     for (int w = 0; w < 256 * 8; ++w) if (h[w * 8 + 5]) { for (int k = 0; k < 8; ++k) acc[k] += h[w * 8 + k]; ++n; }
     const int stages = dig_wgrad_group_rows_per_split(R, gs[0].splits) / 16;
-    printf("wide kernel, per wave and stage (%d waves, %d stages; s_memtime ticks = 100 MHz?): own LDS reads %.0f | own DMA %.0f | barrier %.0f | issue+MFMA %.0f | loop %.0f ; drain %.0f total\n",
+    printf("wide kernel, per wave and stage (%d waves, %d stages; s_memtime ticks = shader cycles): own LDS reads %.0f | own DMA %.0f | barrier %.0f | issue+MFMA %.0f | loop %.0f ; drain %.0f total\n",
            n, stages, acc[0] / n / stages, acc[1] / n / stages, acc[2] / n / stages, acc[3] / n / stages, acc[5] / n / stages, acc[4] / n);
     printf("  whole kernel per wave: %.0f ticks, of which before the loop (operand-stream start + fold of the previous launch) %.0f, loop %.0f, after (drain + slab stores) %.0f\n",
            acc[7] / n, acc[6] / n, acc[5] / n, (acc[7] - acc[6] - acc[5]) / n);
