@@ -298,6 +298,7 @@ class _Step:
                 # weight gradient, with its column sums = the fc1 bias gradient)
                 w2t, w1t = wT[i]
                 dln2, dact, bparts = ops.mlp_chain_bwd(dx, w2t, pre, w1t)
+                _mark("blk: fused MLP backward", dev)
             else:
                 dact, bparts = ops.linear_dgrad(dx, blk["mlp.fc2.weight"], gelu_pre=pre, colsum=True)   # d(pre-activation): GELU' and
                 dln2 = None                                                                              # the fc1 bias sums fused
@@ -321,16 +322,20 @@ class _Step:
                 wg(dx_mid, ctx, g["attn.proj.weight"])
             else:
                 on_side(lambda: wg(dx_mid, ctx, g["attn.proj.weight"]), dx_mid, ctx)
+            _mark("blk: LayerNorm backward (norm2)", dev)
             dctx = ops.linear_dgrad(dx_mid, blk["attn.proj.weight"])
+            _mark("blk: proj data gradient", dev)
             gb = g["qkv_bias"]
             if FUSED_QV_BIAS_SUMS:
                 # q_bias / v_bias gradients: per-image column sums of dQ (already carrying the q scale) and dV leave the attention
                 # kernel as [2B, D] fp32 partials (DPP row reductions of the accumulators, no extra pass over the 150 MB dqkv);
                 # K has no bias
                 dqkv, qs, vs = ops.attn_bwd(qkv, ctx, dctx, lse, views * B, H, D, scale, bias_sums=True)
+                _mark("blk: attention backward", dev)
                 if grp:
                     wg(dqkv, ln1, g["attn.qkv.weight"])
                     launch_group(*held)
+                    _mark("blk: grouped weight gradients", dev)
                     side_later(lambda: (csum(qs, gb[:D]), csum(vs, gb[2 * D:])), qs, vs)
                 else:
                     on_side(lambda: (wg(dqkv, ln1, g["attn.qkv.weight"]),
@@ -345,8 +350,10 @@ class _Step:
                     on_side(lambda: (wg(dqkv, ln1, g["attn.qkv.weight"]),
                                      ops.colsum(dqkv, gb[:D], cols=D), ops.colsum(dqkv[:, 2 * D:], gb[2 * D:], cols=D)), dqkv, ln1)
             dln1 = ops.linear_dgrad(dqkv, blk["attn.qkv.weight"], out=dctx)
+            _mark("blk: qkv data gradient", dev)
             dx, fin1, ws1 = ops.layernorm_bwd(dln1, x, blk["norm1.weight"], blk["norm1.bias"], mu1, rs1, dx_mid, g["norm1.weight"],
                                               g["norm1.bias"], out=dln1, dres_colsum=g["attn.proj.bias"], defer=True)
+            _mark("blk: LayerNorm backward (norm1)", dev)
             if red:                                                           # norm1 grads + colsum(dx_mid) = proj bias grad
                 red.layernorm_finalize(ws1, x.shape[0], D, g["norm1.weight"], g["norm1.bias"], g["attn.proj.bias"])
                 side_later(red.flush, *red.tensors())

@@ -44,5 +44,17 @@ for s in range(1, n):                                   # phase k = from mark k-
         acc[k] += prev.elapsed_time(marks[s * per + k][1])
 sys.stdout = out
 print(f"step {acc.sum() / (n - 1):.2f} ms (GPU, between marks; {n - 1} steps)")
+# marks inside the encoder blocks ("blk: ...") are summed over the blocks; an event record costs the stream ~3 us (tools/experiments/
+# boundary_lab.hip), so the per-launch figures carry that much of the tool itself
+blk = {}
 for k in range(per):
+    if names[k].startswith("blk: "):
+        blk[names[k]] = blk.get(names[k], 0.0) + acc[k] / (n - 1)
+shown = set()
+for k in range(per):
+    if names[k].startswith("blk: "):
+        if names[k] not in shown:
+            shown.add(names[k])
+            print(f"  {blk[names[k]]:6.2f} ms  12 x '{names[k]}' = {blk[names[k]] / 12 * 1e3:6.1f} us per block (stream time up to the end of that launch)")
+        continue
     print(f"  {acc[k] / (n - 1):6.2f} ms  up to '{names[k]}'" + ("   (= optimizer of the previous step, loader, input glue)" if k == 0 else ""))
