@@ -145,13 +145,42 @@ class GemmProbe:
             if not grp.cur:
                 if grp.pending is None:
                     return sv["wg_launch"](grp)
-                return probe._bracket("wgrad_fold", 0.0, 0.0, lambda: sv["wg_launch"](grp))     # the fold-only launch that ends a backward
+                return sv["wg_launch"](grp)                   # the fold-only launch that ends a backward: booked by the call hook below
             R = grp.rows
             fl = sum(2.0 * R * dw.shape[0] * dw.shape[1] for _, _, dw, _ in grp.cur)
             # grouped weight gradients: both operands of every problem once, fp32 read-modify-write of each dW (the slabs are not algorithmic)
             byt = sum(2.0 * R * (dw.shape[0] + dw.shape[1]) + 8.0 * dw.shape[0] * dw.shape[1] for _, _, dw, _ in grp.cur)
             return probe._bracket("wgrad_group", fl, byt, lambda: sv["wg_launch"](grp))
         ops.WgradGroup.launch = timed_wg_launch
+
+        # the one-call-per-encoder-block path (dig_encoder_block_fwd / _bwd): the same launches, issued inside the library -- booked here in
+        # the order the call issues them (csrc/encoder_block.inc), with the same family / FLOP / byte rules as the wrappers above
+        sv["call"] = ops.L.call
+
+        def gemm_rec(form, tile, I, J, R, resid=False):
+            byt = 2.0 * I * R + 2.0 * J * R + 2.0 * I * J + 2.0 * I * J * resid
+            return (form + ":" + str(tile), 2.0 * I * J * R, byt)
+
+        def call(name, *args):
+            if name == "dig_encoder_block_fwd":
+                b = args[0]._obj
+                R, D, Fh = b.rows, b.D, b.F
+                self.rec.append(gemm_rec("fwd", b.tile_qkv, R, 3 * D, D))
+                self.rec.append(gemm_rec("fwd", b.tile_proj, R, D, D, resid=True))
+                byt = 2.0 * R * D * (2 + bool(b.next_n1_g)) + 2.0 * 2 * D * Fh + ((2.0 * R * D + 2.0 * 2 * R * Fh) if b.save else 0.0)
+                self.rec.append(("mlp_chain_online" if b.save else "mlp_chain_momentum", 4.0 * R * D * Fh, byt))
+            elif name == "dig_encoder_block_bwd":
+                b = args[0]._obj
+                R, D, Fh = b.rows, b.D, b.F
+                self.rec.append(("mlp_chain_bwd", 4.0 * R * D * Fh, 2.0 * R * D * 2 + 2.0 * R * Fh * 2 + 2.0 * 2 * D * Fh))
+                self.rec.append(gemm_rec("dgrad", b.tile_dgrad, R, D, D))
+                shapes = ((D, Fh), (Fh, D), (D, D), (3 * D, D))
+                self.rec.append(("wgrad_group", sum(2.0 * R * o * i for o, i in shapes), sum(2.0 * R * (o + i) + 8.0 * o * i for o, i in shapes)))
+                self.rec.append(gemm_rec("dgrad", b.tile_dgrad, R, D, 3 * D))
+            elif name == "dig_wgrad_group" and args[1] == 0:
+                self.rec.append(("wgrad_fold", 0.0, 0.0))                     # the fold-only launch that ends a backward
+            return sv["call"](name, *args)
+        ops.L.call = call
         return self
 
     def __exit__(self, *a):
@@ -159,6 +188,7 @@ class GemmProbe:
         ops, sv = self.ops, self._saved
         ops.gemm, ops.mlp_chain_fwd, ops.mlp_chain_fwd_ln, ops.mlp_chain_bwd = sv["gemm"], sv["chain"], sv["chain_ln"], sv["chain_bwd"]
         ops.WgradGroup.launch = sv["wg_launch"]
+        ops.L.call = sv["call"]
         torch.cuda.synchronize()
         cap = len(self.rec) + 64
         buf = (ctypes.c_float * cap)()

@@ -18,6 +18,7 @@
 #include <vector>
 
 typedef void* hipStream_t;
+#include "../include/dig_block_types.h"          // dig_wgrad_prob_t, dig_block_fwd_t, dig_block_bwd_t
 enum { DIG_OK = 0, DIG_ERR_ARG = -1, DIG_ERR_ALIGN = -2, DIG_ERR_LAUNCH = -3, DIG_ERR_UNSUPPORTED = -4 };
 typedef uint16_t bf16_t;
 
@@ -1139,7 +1140,6 @@ int dig_dropout_apply(const void* in_, void* out_, long long rows, int cols, con
 // ---- grouped weight gradients (csrc/wgrad.hip): same host-side planning and the same two-call protocol (partial slabs now, their
 // sum folded into the gradients by the next call); the slab layout is this build's own ([tile][split][128][128 fn], row-major)
 #define DIG_WGRAD_MAX_PROBS 6
-struct dig_wgrad_prob_t { const void* A; const void* B; float* out; int lda, ldb, ldo, I, J, trans_out; };
 int dig_wgrad_group_supported(int I, int J, int R) {
   return (I > 0 && J > 0 && R >= 64 && I % 128 == 0 && (J % 384 == 0 || J % 256 == 0) && R % 64 == 0) ? 1 : 0;
 }
@@ -1276,3 +1276,7 @@ int dig_probe_start(void) { return DIG_OK; }
 int dig_probe_stop(float*, int) { return 0; }
 
 }  // extern "C"
+
+// one call per encoder block: the same sequences as the HIP build (every call here is synchronous, so the hand-over to the side stream is empty)
+#define DIG_BLOCK_HANDOVER(main, side) 0
+#include "../dig_amd/csrc/encoder_block.inc"

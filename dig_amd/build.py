@@ -22,12 +22,13 @@ def sources():
 
 
 def source_hash() -> str:
-    """sha256 (16 hex digits) over the kernel sources (csrc/*.hip, csrc/*.h, include/dig_hip.h, this file's flags): what a measurement
+    """sha256 (16 hex digits) over the kernel sources (csrc/*.hip, csrc/*.h, csrc/*.inc, include/*.h, this file's flags): what a measurement
     file can be stamped with and re-checked against -- the bytes of the built .so differ from build to build of identical sources."""
     import hashlib
     h = hashlib.sha256()
-    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
-    files.append(os.path.join(os.path.dirname(HERE), "include", "dig_hip.h"))
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".inc")))
+    inc = os.path.join(os.path.dirname(HERE), "include")
+    files += sorted(os.path.join(inc, f) for f in os.listdir(inc) if f.endswith(".h"))
     for f in files:
         h.update(os.path.basename(f).encode())
         with open(f, "rb") as fh:
@@ -48,8 +49,9 @@ def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     objdir = os.path.join(LIBDIR, "obj")
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    headers += [os.path.join(os.path.dirname(HERE), "include", "dig_hip.h")]
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
+    inc = os.path.join(os.path.dirname(HERE), "include")
+    headers += [os.path.join(inc, f) for f in os.listdir(inc) if f.endswith(".h")]
     headers = [h for h in headers if os.path.exists(h)]
     jobs = []
     for s in sources():

@@ -7,6 +7,7 @@ backward is the explicit reverse sequence below, activations in bf16, gradients 
 fp32 gradient arena, per-stage callbacks so the data-parallel wrapper can start the RCCL all-reduce of a finished
 parameter range while earlier layers are still in backward.
 """
+import ctypes
 import os
 
 import torch
@@ -98,6 +99,50 @@ def _weights(model):
     return cache[1], cache[2]
 
 
+class _BlockSaved:
+    """What dig_encoder_block_fwd(save = 1) left for the backward of one block: two buffers (bf16 tensors, fp32 statistics) and the block's
+    input rows x / ln1 / mean / rstd, which live in the PREVIOUS block's buffers (or, for block 0, in tensors of their own).  The block-call
+    backward reads addresses (`ptr`); the per-entry-point backward asks for tensors()."""
+    __slots__ = ("b16", "b32", "off", "rows", "D", "F", "n_img", "heads", "inp", "inp_ptr")
+
+    def __init__(self, b16, b32, off, rows, D, F, n_img, heads, inp, inp_ptr):
+        self.b16, self.b32, self.off, self.rows, self.D, self.F, self.n_img, self.heads = b16, b32, off, rows, D, F, n_img, heads
+        self.inp = inp                   # keeps x, ln1, mu1, rs1 alive: 4 tensors (block 0) or the previous block's (b16, b32)
+        self.inp_ptr = inp_ptr           # their addresses: (x, ln1, mu1, rs1)
+
+    def ptr(self, name):
+        return (self.b32 if name in ("lse", "mu2", "rs2", "nmu", "nrs") else self.b16).data_ptr() + self.off[name]
+
+    def _v16(self, buf, base, byte_off, cols):
+        a = (byte_off - base) // 2
+        return buf[a:a + self.rows * cols].view(self.rows, cols)
+
+    def view(self, name):
+        R, D, F = self.rows, self.D, self.F
+        if name == "lse":
+            a = self.off["lse"] // 4
+            return self.b32[a:a + self.n_img * self.heads * 256].view(self.n_img * self.heads, 256)
+        if name in ("mu2", "rs2", "nmu", "nrs"):
+            a = self.off[name] // 4
+            return self.b32[a:a + R]
+        cols = {"qkv": 3 * D, "pre": F, "act": F}.get(name, D)
+        a = self.off[name] // 2
+        return self.b16[a:a + R * cols].view(R, cols)
+
+    def tensors(self):
+        """(x, ln1, mu1, rs1, qkv, ctx, lse, x_mid, ln2, mu2, rs2, pre, act) as tensors (views)."""
+        if len(self.inp) == 4:
+            x, ln1, mu1, rs1 = self.inp
+        else:
+            p = self.inp[2]
+            x, ln1, mu1, rs1 = p.view("out"), p.view("nln"), p.view("nmu"), p.view("nrs")
+        return (x, ln1, mu1, rs1) + tuple(self.view(k) for k in ("qkv", "ctx", "lse", "x_mid", "ln2", "mu2", "rs2", "pre", "act"))
+
+
+def _saved_tensors(s):
+    return s.tensors() if isinstance(s, _BlockSaved) else s
+
+
 class _Step:
     def __init__(self, model):
         self._keep = []                             # tensors the side stream still reads (see _on_side)
@@ -120,6 +165,8 @@ class _Step:
         chain = ops.mlp_chain_supported(D, M.F, R) and bool(ops.MLP_CHAIN_MASK & (2 if save else 1))
         chain_ln = chain and ops.MLP_CHAIN_LN and M.F <= 2048
         nxt = None                                                      # (ln1, mean, rstd) of this block, made by the previous block's launch
+        if chain_ln and ops.BLOCK_CALLS and D == H * 64:
+            return self._encoder_forward_calls(ew, x, 2 * B, save)
         for i, blk in enumerate(ew.blocks):
             ln1, mu1, rs1 = nxt if nxt is not None else ops.layernorm_fwd(x, blk["norm1.weight"], blk["norm1.bias"], M.ln_eps)
             nxt = None
@@ -160,6 +207,132 @@ class _Step:
                 saved.append((x, ln1, mu1, rs1, qkv, ctx, lse, x_mid, ln2, mu2, rs2, pre, act))
             x = x_out
         return x, saved
+
+    def _encoder_forward_calls(self, ew, x, n_img, save):
+        """The block loop of encoder_forward with ONE FFI crossing per block (dig_encoder_block_fwd: qkv GEMM -> attention -> proj GEMM +
+        residual -> norm2 + MLP + residual + the next block's norm1) and two allocations per block (a bf16 buffer, an fp32 one) instead of
+        four crossings and thirteen allocations.  Same kernels, same arguments, same order: bit-identical to the loop above."""
+        M = self.m
+        D, Fh, H = M.D, M.F, M.H
+        R, dev = x.shape[0], x.device
+        off, n16, n32 = ops.block_fwd_layout(R, D, Fh, n_img, H, save)
+        blk0 = ew.blocks[0]
+        ln1, mu1, rs1 = ops.layernorm_fwd(x, blk0["norm1.weight"], blk0["norm1.bias"], M.ln_eps)
+        inp, inp_ptr = (x, ln1, mu1, rs1), (x.data_ptr(), ln1.data_ptr(), mu1.data_ptr(), rs1.data_ptr())
+        stream = ops.L.stream()
+        saved = []
+        nb_blocks = len(ew.blocks)
+        key = ("fwd_call", bool(save), R, n_img)
+        prev = None
+        for i, blk in enumerate(ew.blocks):
+            st = blk.get(key)
+            if st is None:
+                nb = ew.blocks[i + 1] if i + 1 < nb_blocks else None
+                st = blk[key] = ops.BlockFwd(
+                    n_img=n_img, heads=H, D=D, F=Fh, rows=R, save=int(bool(save)),
+                    tile_qkv=ops.fwd_tile_code(R, 3 * D, D) or ops.GEMM_BK_FWD, tile_proj=ops.fwd_tile_code(R, D, D, has_resid=True) or ops.GEMM_BK_FWD,
+                    eps=M.ln_eps, scale=(D // H) ** -0.5,
+                    qkv_w=blk["attn.qkv.weight"].data_ptr(), qkv_b=blk["qkv_bias"].data_ptr(), proj_w=blk["attn.proj.weight"].data_ptr(),
+                    proj_b=blk["attn.proj.bias"].data_ptr(), n2_g=blk["norm2.weight"].data_ptr(), n2_b=blk["norm2.bias"].data_ptr(),
+                    fc1_w=blk["mlp.fc1.weight"].data_ptr(), fc1_b=blk["mlp.fc1.bias"].data_ptr(), fc2_w=blk["mlp.fc2.weight"].data_ptr(),
+                    fc2_b=blk["mlp.fc2.bias"].data_ptr(), next_n1_g=nb["norm1.weight"].data_ptr() if nb else None,
+                    next_n1_b=nb["norm1.bias"].data_ptr() if nb else None)
+            b16 = torch.empty(n16 // 2, device=dev, dtype=BF16)
+            b32 = torch.empty(n32 // 4, device=dev, dtype=F32)
+            p16, p32 = b16.data_ptr(), b32.data_ptr()
+            st.x, st.ln1 = inp_ptr[0], inp_ptr[1]
+            st.qkv, st.ctx, st.x_mid, st.out, st.nln = p16 + off["qkv"], p16 + off["ctx"], p16 + off["x_mid"], p16 + off["out"], p16 + off["nln"]
+            st.lse = p32 + off["lse"]
+            if save:
+                st.ln2, st.pre, st.act = p16 + off["ln2"], p16 + off["pre"], p16 + off["act"]
+                st.mu2, st.rs2, st.nmu, st.nrs = p32 + off["mu2"], p32 + off["rs2"], p32 + off["nmu"], p32 + off["nrs"]
+            ops.L.call("dig_encoder_block_fwd", ctypes.byref(st), stream)
+            cur = _BlockSaved(b16, b32, off, R, D, Fh, n_img, H, inp, inp_ptr)
+            if save:
+                saved.append(cur)
+                inp, inp_ptr = (b16, b32, cur), (p16 + off["out"], p16 + off["nln"], p32 + off["nmu"], p32 + off["nrs"])
+            else:
+                inp, inp_ptr = (b16, b32), (p16 + off["out"], p16 + off["nln"], 0, 0)     # (no chain of blocks: the previous buffers go back to the pool)
+            prev = cur
+        return prev.view("out"), saved
+
+    def _encoder_backward_calls(self, ew, saved, dx, wT, plan, n_img, R):
+        """The block loop of encoder_backward with ONE FFI crossing per block (dig_encoder_block_bwd: the data-gradient chain with the grouped
+        weight gradients in it on this stream, the five parameter-gradient reductions on the side stream behind one event) and two
+        allocations per block.  Same kernels, same arguments, same order as the loop in encoder_backward.  Returns the gradient w.r.t. the
+        patch embedding's output rows."""
+        M = self.m
+        D, Fh, H = M.D, M.F, M.H
+        dev = dx.device
+        main, side = self._streams(dev)
+        off, n16, n32 = ops.block_bwd_layout(R, D, Fh, n_img)
+        grp = plan["group"]
+        stream, side_h = ops.L.stream(), ctypes.c_void_p(side.cuda_stream)
+        probs = ((ops._WgProb * 4)(), (ops._WgProb * 4)())
+        wmap_ptr = plan["wmap"].data_ptr()
+        tile = ops.dgrad_tile_code(R, D) or ops.GEMM_BK_BWD
+        key = ("bwd_call", R, n_img)
+        dy_ptr, dy_owner = dx.data_ptr(), dx
+        prev_block, n_launch, slabs_prev = None, 0, None
+        for i in reversed(range(M.depth)):
+            blk, g, sv = ew.blocks[i], ew.blocks[i]["g"], saved[i]
+            saved[i] = None
+            st = blk.get(key)
+            if st is None:
+                gb = g["qkv_bias"]
+                for k in ("attn.qkv.weight", "attn.proj.weight", "mlp.fc1.weight", "mlp.fc2.weight"):
+                    assert g[k].is_contiguous()
+                st = blk[key] = ops.BlockBwd(
+                    n_img=n_img, heads=H, D=D, F=Fh, rows=R, tile_dgrad=tile, scale=(D // H) ** -0.5,
+                    qkv_w=blk["attn.qkv.weight"].data_ptr(), proj_w=blk["attn.proj.weight"].data_ptr(),
+                    n1_g=blk["norm1.weight"].data_ptr(), n1_b=blk["norm1.bias"].data_ptr(), n2_g=blk["norm2.weight"].data_ptr(),
+                    n2_b=blk["norm2.bias"].data_ptr(),
+                    g_n1_g=g["norm1.weight"].data_ptr(), g_n1_b=g["norm1.bias"].data_ptr(), g_qkv_w=g["attn.qkv.weight"].data_ptr(),
+                    g_q_b=gb.data_ptr(), g_v_b=gb[2 * D:].data_ptr(), g_proj_w=g["attn.proj.weight"].data_ptr(),
+                    g_proj_b=g["attn.proj.bias"].data_ptr(), g_n2_g=g["norm2.weight"].data_ptr(), g_n2_b=g["norm2.bias"].data_ptr(),
+                    g_fc1_w=g["mlp.fc1.weight"].data_ptr(), g_fc1_b=g["mlp.fc1.bias"].data_ptr(), g_fc2_w=g["mlp.fc2.weight"].data_ptr(),
+                    g_fc2_b=g["mlp.fc2.bias"].data_ptr(),
+                    wg_fn=plan["fn"], wg_wa=plan["wa"], wg_splits=plan["splits"], wg_n_wg=plan["n_wg"], wg_fold_splits=plan["splits"],
+                    wg_trans=(ctypes.c_int * 4)(*plan["trans"]))
+            w2t, w1t = wT[i]
+            st.w2t, st.w1t = w2t.data_ptr(), w1t.data_ptr()
+            st.x, st.ln1, st.mu1, st.rs1 = sv.inp_ptr
+            for k in ("qkv", "ctx", "lse", "x_mid", "ln2", "mu2", "rs2", "pre", "act"):
+                setattr(st, k, sv.ptr(k))
+            t16 = torch.empty(n16 // 2, device=dev, dtype=BF16)
+            t32 = torch.empty(n32 // 4, device=dev, dtype=F32)
+            p16, p32 = t16.data_ptr(), t32.data_ptr()
+            st.dy = dy_ptr
+            st.dln2, st.dpre, st.dctx, st.dqkv = p16 + off["dln2"], p16 + off["dpre"], p16 + off["dctx"], p16 + off["dqkv"]
+            st.bparts, st.ws1, st.ws2, st.qs, st.vs = p32 + off["bparts"], p32 + off["ws1"], p32 + off["ws2"], p32 + off["qs"], p32 + off["vs"]
+            slabs = grp._slabs(plan["slab_bytes"])
+            grp.set ^= 1
+            st.wg_map, st.wg_slabs = wmap_ptr, slabs.data_ptr()
+            st.wg_probs = ctypes.addressof(probs[n_launch & 1])
+            st.wg_fold_n = 4 if n_launch else 0
+            st.wg_fold_probs = ctypes.addressof(probs[(n_launch & 1) ^ 1]) if n_launch else None
+            st.wg_fold_slabs = slabs_prev.data_ptr() if n_launch else None
+            st.side = side_h
+            ops.L.call("dig_encoder_block_bwd", ctypes.byref(st), stream)
+            n_launch += 1
+            slabs_prev = slabs
+            if side is not main:
+                self._keep.append(t32)                                   # the side stream's reductions read it
+            dy_ptr, dy_owner = p16 + off["dctx"], t16                    # the next block's incoming gradient lives in this block's buffer
+            del sv
+            self._mark_kept(dev)
+            self._release_kept(dev)
+            # (block i's slabs are folded by the NEXT launch, so the bucket that is final here is block i + 1's)
+            if prev_block is not None:
+                self._grad_ready(dev, f"encoder.blocks.{prev_block}")
+            prev_block = i
+        # fold of the last launch's slabs (a fold-only launch), then the last bucket
+        ops.L.call("dig_wgrad_group", None, 0, ctypes.addressof(probs[(n_launch & 1) ^ 1]), 4, int(R), 1, None, ops.WGRAD_GROUP_SLOTS, None,
+                   ops.L.ptr(slabs_prev), plan["splits"], plan["fn"], plan["wa"], stream)
+        if prev_block is not None:
+            self._grad_ready(dev, f"encoder.blocks.{prev_block}")
+        a = off["dctx"] // 2
+        return dy_owner[a:a + R * D].view(R, D)
 
     def mlp_weight_transposes(self, ew):
         """K-contiguous copies of the MLP weights for the fused backward (W2^T [F, D], W1^T [D, F]; 1.2 MB each, 24 small launches):
@@ -250,6 +423,12 @@ class _Step:
         Rg = (B * N) if views == 1 else (2 * B * N)
         grouped = (ops.WGRAD_GROUP and WGRAD_GROUPING != "off" and
                    all(ops.wgrad_group_route(o, i_, Rg) is not None for o, i_ in ((M.F, D), (D, M.F), (3 * D, D), (D, D))))
+        if (grouped and chain_any and ops.BLOCK_CALLS and WGRAD_INLINE and WGRAD_GROUPING == "block" and CHAIN_BWD_EVERY == 1 and FUSED_QV_BIAS_SUMS
+                and not BATCH_REDUCE and PHASE_MARKS is None and all(isinstance(s_, _BlockSaved) for s_ in saved) and dx.is_contiguous()):
+            plan = ops.wgrad_block_plan(dev, Rg, D, M.F)
+            if plan is not None:
+                dx = self._encoder_backward_calls(ew, saved, dx, wT, plan, B if views == 1 else 2 * B, Rg)
+                grouped = None                                           # the blocks are done: only the patch embedding is left
         grp = ops.WgradGroup(dev) if grouped else None
         prev_block = None
 
@@ -259,9 +438,9 @@ class _Step:
             else:
                 on_side(grp.launch, *tensors)
 
-        for i in reversed(range(M.depth)):
+        for i in reversed(range(M.depth if grouped is not None else 0)):
             blk, g = ew.blocks[i], ew.blocks[i]["g"]
-            x, ln1, mu1, rs1, qkv, ctx, lse, x_mid, ln2, mu2, rs2, pre, act = saved[i]
+            x, ln1, mu1, rs1, qkv, ctx, lse, x_mid, ln2, mu2, rs2, pre, act = _saved_tensors(saved[i])
             saved[i] = None
             chain = chain_any and (i % CHAIN_BWD_EVERY == CHAIN_BWD_PHASE % CHAIN_BWD_EVERY)
             if views == 1:            # only view 0 carries a gradient (zero contrastive weight): rows [0, B*N) of everything

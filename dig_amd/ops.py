@@ -59,28 +59,32 @@ def gemm(A, B, I, J, R, *, ta=False, tb=False, out=None, out_kind=OUT_BF16, bias
 PERSISTENT_FWD = os.environ.get("DIG_PERSISTENT_FWD", "1") != "0"
 FWD_192_BELOW = int(os.environ.get("DIG_FWD_192_BELOW", "512"))     # output widths = 128 mod 256 below this run on 256x192 tiles (no padded columns)
 DGRAD_GELU_BK = 32    # tile of the fc2 dgrad + GELU' + bias-sum GEMM: 128x128/BK32 beats the 256x256 tile inside the step (A/B: 25.9 vs 26.1 ms)
-def linear_fwd(x, w, *, bias=None, resid=None, act=0, pre=None, alpha=1.0, alpha_cols=0, out=None, out_kind=OUT_BF16, drop=None):
-    """y[rows,out] = x[rows,in] @ w[out,in]^T (+bias)(gelu)(+resid)."""
-    K = w.shape[1]
-    # tile variant per layer shape, measured on MI355X (profiles/r01_gemm_variants.txt, tools/gpu_bk_probe.py):
-    #   tall layers: 256x256 tiles (16 waves) halve the L2->LDS operand traffic per FLOP;  small GELU layers: BK=32,
-    #   4 workgroups/CU hide the VALU + double-store epilogue;  everything else: the default 128x128 / BK=64.
-    rows = x.shape[0]
-    if rows >= 8192 and w.shape[0] >= 384 and rows * w.shape[0] >= (1 << 24) and not (drop is not None and act):
+def fwd_tile_code(rows, out_dim, K, *, act=0, has_resid=False, drop=None, out_kind=OUT_BF16):
+    """DIG_GEMM_TILE_* of a forward Linear layer [rows, K] -> [rows, out_dim].
+    Measured on MI355X (profiles/r01_gemm_variants.txt, tools/gpu_bk_probe.py):
+      tall layers: 256x256 tiles (16 waves) halve the L2->LDS operand traffic per FLOP;  small GELU layers: BK=32,
+      4 workgroups/CU hide the VALU + double-store epilogue;  everything else: the default 128x128 / BK=64."""
+    if rows >= 8192 and out_dim >= 384 and rows * out_dim >= (1 << 24) and not (drop is not None and act):
         bk = 244
-        if w.shape[0] % 256 == 128 and w.shape[0] < FWD_192_BELOW:
+        if out_dim % 256 == 128 and out_dim < FWD_192_BELOW:
             # 384 outputs = 1.5 tiles of 256: a quarter of the 256x256 tile's columns would be padding.  The 256x192 tile (12 waves) covers
             # them in two exact tiles and keeps the two-fold reuse of the activation rows: proj 39.4 -> 34.5 us, fc2 114.8 -> 99.2 us alone;
             # in the step 25.98 -> 25.57 ms and the forward family 9.76 -> 9.43 ms (three A/B pairs on one box)
             bk = 264
     elif act == 1:
         bk = 32
-    elif rows <= 2048 and w.shape[0] <= 512 and K >= 2048 and drop is None:
+    elif rows <= 2048 and out_dim <= 512 and K >= 2048 and drop is None:
         bk = 212                                        # few output tiles, long K: 64x128 tiles for more workgroups
     else:
         bk = 0
-    if PERSISTENT_FWD and drop is None and out_kind == OUT_BF16 and ((bk == 244 and resid is None) or bk == 264):
+    if PERSISTENT_FWD and drop is None and out_kind == OUT_BF16 and ((bk == 244 and not has_resid) or bk == 264):
         bk += 300                                       # 544 / 564: the persistent form of the same tile (bit-identical results)
+    return bk
+
+
+def linear_fwd(x, w, *, bias=None, resid=None, act=0, pre=None, alpha=1.0, alpha_cols=0, out=None, out_kind=OUT_BF16, drop=None):
+    """y[rows,out] = x[rows,in] @ w[out,in]^T (+bias)(gelu)(+resid)."""
+    bk = fwd_tile_code(x.shape[0], w.shape[0], w.shape[1], act=act, has_resid=resid is not None, drop=drop, out_kind=out_kind)
     return gemm(x, w, x.shape[0], w.shape[0], w.shape[1], bias=bias, resid=resid, act=act, pre=pre, alpha=alpha,
                 alpha_cols=alpha_cols, out=out, out_kind=out_kind, bk=bk, drop=drop)
 
@@ -199,17 +203,20 @@ def linear_dgrad(dy, w, out=None, gelu_pre=None, colsum=False, drop=None):
     # (The 256x192 tile is 8-20 % faster for the tall 384-wide dgrads alone -- tools/experiments/gpu_dgrad_tile_probe.py -- but not in
     #  the step: 25.69 vs 25.77 ms over three A/B pairs; the small 128x128 workgroups share the CUs better with the weight-gradient stream.)
     rows, J = dy.shape[0], w.shape[1]
+    return gemm(dy, w, rows, J, w.shape[0], tb=True, out=out, bk=dgrad_tile_code(rows, J, drop))
+
+
+def dgrad_tile_code(rows, J, drop=None):
+    """DIG_GEMM_TILE_* of a data-gradient GEMM dx[rows, J] = dy w."""
     if rows <= 2048:
-        bk = 221
-    elif DGRAD_BK >= 0:
-        bk = DGRAD_BK
-    elif rows >= 8192 and drop is None and J % 192 == 0 and J % 256 != 0:
-        bk = 264                                        # 256x192 tiles: exact for the 384-wide data gradients of ViT-S
-    elif rows >= 8192 and drop is None and J % 256 == 0:
-        bk = 244                                        # 256x256 (D = 512)
-    else:
-        bk = 0
-    return gemm(dy, w, rows, J, w.shape[0], tb=True, out=out, bk=bk)
+        return 221
+    if DGRAD_BK >= 0:
+        return DGRAD_BK
+    if rows >= 8192 and drop is None and J % 192 == 0 and J % 256 != 0:
+        return 264                                      # 256x192 tiles: exact for the 384-wide data gradients of ViT-S
+    if rows >= 8192 and drop is None and J % 256 == 0:
+        return 244                                      # 256x256 (D = 512)
+    return 0
 
 
 # Tile code of the tall data-gradient GEMMs: -1 (default) = by width: 256x192 / 256x256 tiles.  Rounds 1-3 kept 128x128 / BK 32 (code 0) here
@@ -446,6 +453,91 @@ class WgradGroup:
         """Fold what the last launch left (a fold-only launch); afterwards every gradient add()ed so far is final on this stream."""
         assert not self.cur, "launch() the queued problems first"
         self.launch()
+
+
+# ---- one FFI crossing per encoder block (include/dig_block_types.h, csrc/encoder_block.hip) -----------------------------------------------
+BLOCK_CALLS = os.environ.get("DIG_BLOCK_CALLS", "1") != "0"
+_VP, _FP, _I, _F = ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+
+
+class BlockFwd(ctypes.Structure):
+    """include/dig_block_types.h `dig_block_fwd_t`."""
+    _fields_ = ([(k, _I) for k in ("n_img", "heads", "D", "F", "rows", "save", "tile_qkv", "tile_proj")] + [("eps", _F), ("scale", _F)] +
+                [(k, _VP) for k in ("qkv_w", "qkv_b", "proj_w", "proj_b", "n2_g", "n2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "next_n1_g", "next_n1_b",
+                                    "x", "ln1", "qkv", "ctx", "lse", "x_mid", "ln2", "mu2", "rs2", "pre", "act", "out", "nln", "nmu", "nrs")])
+
+
+class BlockBwd(ctypes.Structure):
+    """include/dig_block_types.h `dig_block_bwd_t`."""
+    _fields_ = ([(k, _I) for k in ("n_img", "heads", "D", "F", "rows", "tile_dgrad")] + [("scale", _F)] +
+                [(k, _VP) for k in ("qkv_w", "proj_w", "w2t", "w1t", "n1_g", "n1_b", "n2_g", "n2_b",
+                                    "g_n1_g", "g_n1_b", "g_qkv_w", "g_q_b", "g_v_b", "g_proj_w", "g_proj_b", "g_n2_g", "g_n2_b", "g_fc1_w", "g_fc1_b",
+                                    "g_fc2_w", "g_fc2_b",
+                                    "x", "ln1", "mu1", "rs1", "qkv", "ctx", "lse", "x_mid", "ln2", "mu2", "rs2", "pre", "act", "dy",
+                                    "dln2", "dpre", "dctx", "dqkv", "bparts", "ws1", "ws2", "qs", "vs")] +
+                [(k, _I) for k in ("wg_fn", "wg_wa", "wg_splits", "wg_n_wg", "wg_fold_n", "wg_fold_splits")] + [("wg_trans", _I * 4)] +
+                [(k, _VP) for k in ("wg_map", "wg_slabs", "wg_fold_slabs", "wg_probs", "wg_fold_probs", "side")])
+
+
+def _round_up(n, m):
+    return (n + m - 1) // m * m
+
+
+_block_layouts = {}
+
+
+def block_fwd_layout(rows, D, Fh, n_img, heads, save):
+    """Byte offsets of one block's forward outputs inside its two buffers (bf16 tensors; fp32 statistics): ({name: offset}, bytes16, bytes32).
+    Every piece starts on a 256-byte boundary."""
+    key = ("f", rows, D, Fh, n_img, heads, bool(save))
+    lay = _block_layouts.get(key)
+    if lay is None:
+        off, n16, n32 = {}, 0, 0
+        for name, cols in (("qkv", 3 * D), ("ctx", D), ("x_mid", D), ("out", D), ("nln", D)) + ((("ln2", D), ("pre", Fh), ("act", Fh)) if save else ()):
+            off[name] = n16
+            n16 += _round_up(rows * cols * 2, 256)
+        for name, n in (("lse", n_img * heads * 256),) + ((("mu2", rows), ("rs2", rows), ("nmu", rows), ("nrs", rows)) if save else ()):
+            off[name] = n32
+            n32 += _round_up(n * 4, 256)
+        lay = _block_layouts[key] = (off, n16, n32)
+    return lay
+
+
+def block_bwd_layout(rows, D, Fh, n_img):
+    """The same for one block's backward temporaries: dln2, dpre, dctx, dqkv (bf16) and bparts, ws1, ws2, qs, vs (fp32)."""
+    key = ("b", rows, D, Fh, n_img)
+    lay = _block_layouts.get(key)
+    if lay is None:
+        off, n16, n32 = {}, 0, 0
+        for name, cols in (("dln2", D), ("dpre", Fh), ("dctx", D), ("dqkv", 3 * D)):
+            off[name] = n16
+            n16 += _round_up(rows * cols * 2, 256)
+        lib = L.lib()
+        parts = lib.dig_layernorm_bwd_parts(rows) * 3 * D
+        for name, n in (("bparts", lib.dig_mlp_chain_colsum_rows(rows) * Fh), ("ws1", parts), ("ws2", parts), ("qs", n_img * D), ("vs", n_img * D)):
+            off[name] = n32
+            n32 += _round_up(n * 4, 256)
+        lay = _block_layouts[key] = (off, n16, n32)
+    return lay
+
+
+def wgrad_block_plan(dev, rows, D, Fh):
+    """The grouped weight-gradient launch of one encoder block (fc2, fc1, proj, qkv) for dig_encoder_block_bwd: None when a shape cannot
+    join, else a dict with fn, wa, splits, n_wg, wmap (device tensor), slab_bytes, trans (one flag per problem) and `group` (the WgradGroup
+    whose slab sets the launches alternate between)."""
+    grp = WgradGroup(dev)
+    grp.rows = rows
+    trans, tiles = [], []
+    for out_dim, in_dim in ((D, Fh), (Fh, D), (D, D), (3 * D, D)):
+        r = wgrad_group_route(out_dim, in_dim, rows, grp.fn) if WGRAD_GROUP else None
+        if r is None:
+            return None
+        t, grp.fn = r
+        trans.append(t)
+        tiles.append(L.lib().dig_wgrad_group_tiles(int(in_dim if t else out_dim), int(out_dim if t else in_dim), grp.fn, WGRAD_GROUP_WA))
+    splits, n_wg, wmap = grp._plan(tiles)
+    return {"fn": grp.fn, "wa": WGRAD_GROUP_WA, "splits": splits, "n_wg": n_wg, "wmap": wmap, "trans": trans, "group": grp,
+            "slab_bytes": sum(tiles) * splits * 128 * WGRAD_GROUP_WA * 128 * grp.fn * 4}
 
 
 _ws2 = {}

@@ -1,0 +1,60 @@
+/* dig_block_types.h -- argument tables of dig_encoder_block_fwd / dig_encoder_block_bwd (declared in dig_hip.h, which includes this file
+ * after its hipStream_t typedef; the host-only build under cpu_abi/ includes it after its own).  Plain C, device pointers unless stated.
+ *
+ * One call = one encoder block of the DiG ViT (Block.forward, modeling_finetune.py:150-158, called from
+ * PretrainVisionTransformerEncoder.forward_features :312-334) or its gradient: the launch sequence that dig_amd/engine_core.py otherwise
+ * issues entry point by entry point, so that the host pays one FFI crossing per block instead of four (forward) or fifteen (backward).
+ * The functions launch exactly the kernels the per-entry-point sequence launches, with the same arguments, in the same order. */
+#ifndef DIG_BLOCK_TYPES_H
+#define DIG_BLOCK_TYPES_H
+
+typedef struct dig_wgrad_prob {
+  const void* A; const void* B; float* out;
+  int lda, ldb, ldo, I, J, trans_out;
+} dig_wgrad_prob_t;
+
+typedef struct dig_block_fwd {
+  int n_img, heads, D, F, rows;        /* rows = n_img * 256 tokens */
+  int save;                            /* 1: online branch (everything below is written); 0: momentum branch (ln2, mu2, rs2, pre, act, nmu, nrs may be null) */
+  int tile_qkv, tile_proj;             /* DIG_GEMM_TILE_* of the two Linear layers */
+  float eps, scale;                    /* LayerNorm eps; head_dim^-0.5 applied to the q columns in the qkv epilogue */
+  /* parameters: bf16 weights [out, in], fp32 biases and LayerNorm parameters */
+  const void* qkv_w; const float* qkv_b; const void* proj_w; const float* proj_b;
+  const float* n2_g; const float* n2_b; const void* fc1_w; const float* fc1_b; const void* fc2_w; const float* fc2_b;
+  const float* next_n1_g; const float* next_n1_b;     /* norm1 of the FOLLOWING block (null for the last block: nln, nmu, nrs unused) */
+  /* in: the block's input rows and their norm1 (made by the previous block's call or dig_layernorm_fwd) */
+  const void* x; const void* ln1;
+  /* out */
+  void* qkv; void* ctx; float* lse; void* x_mid; void* ln2; float* mu2; float* rs2; void* pre; void* act;
+  void* out; void* nln; float* nmu; float* nrs;
+} dig_block_fwd_t;
+
+typedef struct dig_block_bwd {
+  int n_img, heads, D, F, rows;
+  int tile_dgrad;                      /* DIG_GEMM_TILE_* of the two data-gradient GEMMs (proj, qkv) */
+  float scale;
+  /* parameters; w2t = fc2.weight^T [F, D], w1t = fc1.weight^T [D, F] (dig_transpose_bf16) */
+  const void* qkv_w; const void* proj_w; const void* w2t; const void* w1t;
+  const float* n1_g; const float* n1_b; const float* n2_g; const float* n2_b;
+  /* fp32 gradients, accumulated into (contiguous [out, in] matrices); g_q_b / g_v_b = the q and v thirds of the qkv bias gradient */
+  float* g_n1_g; float* g_n1_b; float* g_qkv_w; float* g_q_b; float* g_v_b; float* g_proj_w; float* g_proj_b;
+  float* g_n2_g; float* g_n2_b; float* g_fc1_w; float* g_fc1_b; float* g_fc2_w; float* g_fc2_b;
+  /* what dig_encoder_block_fwd (save = 1) left */
+  const void* x; const void* ln1; const float* mu1; const float* rs1; const void* qkv; const void* ctx; const float* lse;
+  const void* x_mid; const void* ln2; const float* mu2; const float* rs2; const void* pre; const void* act;
+  const void* dy;                      /* gradient w.r.t. the block's output rows, bf16 [rows, D] */
+  /* temporaries ([rows, D], [rows, F], [rows, D], [rows, 3D] bf16); on return dctx holds the gradient w.r.t. the block's INPUT rows */
+  void* dln2; void* dpre; void* dctx; void* dqkv;
+  /* fp32 partial sums finished on the side stream: [dig_mlp_chain_colsum_rows(rows)][F], 2 x [dig_layernorm_bwd_parts(rows)][3][D], 2 x [n_img][D] */
+  float* bparts; float* ws1; float* ws2; float* qs; float* vs;
+  /* grouped weight gradients (dig_wgrad_group): this block's four problems are written to wg_probs (HOST array of 4) in the order
+   * fc2, fc1, proj, qkv and launched together with the fold of wg_fold_probs (the previous call's wg_probs; wg_fold_n = 0 for the first
+   * block of a backward pass).  wg_trans[k] = 1: problem k puts the activation first and stores its result transposed. */
+  int wg_fn, wg_wa, wg_splits, wg_n_wg, wg_fold_n, wg_fold_splits;
+  int wg_trans[4];
+  const unsigned* wg_map; float* wg_slabs; const float* wg_fold_slabs;
+  dig_wgrad_prob_t* wg_probs; const dig_wgrad_prob_t* wg_fold_probs;
+  hipStream_t side;                    /* stream of the parameter-gradient reductions (may equal the call's stream) */
+} dig_block_bwd_t;
+
+#endif /* DIG_BLOCK_TYPES_H */

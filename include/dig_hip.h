@@ -93,10 +93,7 @@ int dig_reduce_partials_multi(const dig_reduce_seg_t* segs, int n_segs, hipStrea
  * loaded evenly) and chooses S; the caller copies map_out to device memory once per configuration and passes it as wg_map.
  * probs / fold_probs / tiles_per_prob / map_out / splits_out are host memory; out / slabs / wg_map device memory. */
 #define DIG_WGRAD_MAX_PROBS 6
-typedef struct dig_wgrad_prob {
-  const void* A; const void* B; float* out;
-  int lda, ldb, ldo, I, J, trans_out;
-} dig_wgrad_prob_t;
+#include "dig_block_types.h"          /* dig_wgrad_prob_t { A, B, out, lda, ldb, ldo, I, J, trans_out } and the block-call tables */
 int dig_wgrad_group_supported(int I, int J, int R);               /* 1: a problem of these sizes can join a group */
 int dig_wgrad_group_fn(int J);                                    /* 3, 2, or 0 (narrow width not supported) */
 int dig_wgrad_group_rows_per_split(int R, int splits);
@@ -463,6 +460,18 @@ int dig_gru_cell_bwd(const float* ds_a, const float* ds_b, const float* ds_c, co
                      void* dgh, float* ds_prev, int B, int S, hipStream_t stream);
 /* out[r, :cols] (bf16, row stride ld) = table[clamp(tokens[r]), :cols] (fp32 table): tgt_embedding lookups (attn_decoder.py:264). */
 int dig_embed_rows(const long long* tokens, const float* table, void* out, int ld, int rows, int cols, int vocab, hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * One call per encoder block (Block.forward, modeling_finetune.py:150-158, and its gradient): the launch sequences of
+ * dig_amd/engine_core.py's default plan issued from the library -- forward: dig_gemm_bf16 (qkv, q scaled) -> dig_attn_fwd ->
+ * dig_gemm_bf16 (proj + residual) -> dig_mlp_chain_fwd_ln;  backward: dig_mlp_chain_bwd -> dig_layernorm_bwd_partials (norm2) ->
+ * dig_gemm_bf16 (proj data gradient) -> dig_attn_bwd (with the q / v bias sums) -> dig_wgrad_group (the block's four weight gradients +
+ * the fold of the previous block's) -> dig_gemm_bf16 (qkv data gradient) -> dig_layernorm_bwd_partials (norm1) on `stream`, then the five
+ * parameter-gradient reductions (dig_colsum_partials x 3, dig_layernorm_bwd_finalize x 2) on b->side behind one event.  Same kernels,
+ * same arguments, same order as the per-entry-point path: results are bit-identical to it.  The tables are HOST memory.
+ * Returns the first non-zero code of the sequence (nothing after it is launched). */
+int dig_encoder_block_fwd(const dig_block_fwd_t* b, hipStream_t stream);
+int dig_encoder_block_bwd(const dig_block_bwd_t* b, hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Launch probe (measurement only; bench.py).  Between dig_probe_start() and dig_probe_stop() every launch of dig_gemm_bf16(_dropout),

@@ -1,4 +1,4 @@
-"""The C-ABI library builds, loads without a GPU and exports every symbol include/dig_hip.h declares (no compute)."""
+"""The C-ABI library builds, loads without a GPU and exports every symbol include/*.h declares (no compute)."""
 import ctypes
 import os
 import re
@@ -9,7 +9,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def declared_symbols():
-    txt = open(os.path.join(ROOT, "include", "dig_hip.h")).read()
+    inc = os.path.join(ROOT, "include")
+    txt = "".join(open(os.path.join(inc, f)).read() for f in sorted(os.listdir(inc)) if f.endswith(".h"))
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(dig_[a-z0-9_]+)\s*\(", txt)))
 
@@ -37,7 +38,7 @@ def test_every_exported_entry_point_is_declared(lib):
     src = ""
     csrc = os.path.join(ROOT, "dig_amd", "csrc")
     for f in os.listdir(csrc):
-        if f.endswith(".hip"):
+        if f.endswith((".hip", ".inc")):
             src += open(os.path.join(csrc, f)).read()
     exported = set(re.findall(r'extern "C" (?:int|long long) (dig_[a-z0-9_]+)\(', src))
     assert exported == set(declared_symbols())

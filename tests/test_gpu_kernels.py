@@ -608,3 +608,139 @@ def test_attention_exact_arithmetic(dev):
     ref = (match @ v) / match.sum(-1, keepdim=True)
     assert torch.equal(ctx.float().cpu().view(Bn, 256, H, 64).permute(0, 2, 1, 3), ref)
     assert (lse.cpu().view(Bn, H, 256) - (256.0 + math.log(4.0))).abs().max().item() < 1e-3
+
+
+@pytest.mark.parametrize("n_img", [2, 64])
+def test_encoder_block_calls_equal_the_entry_point_sequence(dev, n_img):
+    """dig_encoder_block_fwd / dig_encoder_block_bwd (one FFI crossing per encoder block; include/dig_block_types.h) against the sequence of
+    entry points they stand for (dig_amd/engine_core.py's per-entry-point plan): every output, every gradient and the fold of the grouped
+    weight gradients across two consecutive blocks, bit for bit; both forward forms (online: everything kept; momentum: nothing kept)."""
+    from dig_amd import ops
+    D, Fh, H, eps = 384, 1536, 6, 1e-6
+    R = n_img * 256
+    cpu_limit(dev, 40.0 * R * D * D, 2e10)
+    scale = (D // H) ** -0.5
+    g = torch.Generator(device="cpu").manual_seed(n_img)
+    bf = lambda *sh, s=0.5: (torch.randn(*sh, generator=g) * s).bfloat16().to(dev)
+    f32 = lambda *sh, s=0.1, b=0.0: (torch.randn(*sh, generator=g) * s + b).to(dev)
+    P = {"qkv_w": bf(3 * D, D, s=0.05), "qkv_b": f32(3 * D), "proj_w": bf(D, D, s=0.05), "proj_b": f32(D), "n1_g": f32(D, b=1.0), "n1_b": f32(D),
+         "n2_g": f32(D, b=1.0), "n2_b": f32(D), "fc1_w": bf(Fh, D, s=0.05), "fc1_b": f32(Fh), "fc2_w": bf(D, Fh, s=0.03), "fc2_b": f32(D),
+         "nn1_g": f32(D, b=1.0), "nn1_b": f32(D)}
+    P["qkv_b"][D:2 * D] = 0                                           # K has no bias
+    x = bf(R, D, s=1.0)
+    ln1, mu1, rs1 = ops.layernorm_fwd(x, P["n1_g"], P["n1_b"], eps)
+
+    def fwd_entry_points(save, last):
+        qkv = ops.linear_fwd(ln1, P["qkv_w"], bias=P["qkv_b"], alpha=scale, alpha_cols=D)
+        ctx, lse = ops.attn_fwd(qkv, n_img, H, D)
+        x_mid = ops.linear_fwd(ctx, P["proj_w"], bias=P["proj_b"], resid=x)
+        r = ops.mlp_chain_fwd_ln(x_mid, P["n2_g"], P["n2_b"], eps, P["fc1_w"], P["fc1_b"], P["fc2_w"], P["fc2_b"],
+                                 None if last else P["nn1_g"], None if last else P["nn1_b"], save=save)
+        return dict(r, qkv=qkv, ctx=ctx, lse=lse, x_mid=x_mid)
+
+    def fwd_block_call(save, last):
+        off, n16, n32 = ops.block_fwd_layout(R, D, Fh, n_img, H, save)
+        b16, b32 = torch.full((n16 // 2,), 7.0, device=dev, dtype=torch.bfloat16), torch.full((n32 // 4,), 7.0, device=dev)
+        p16, p32 = b16.data_ptr(), b32.data_ptr()
+        st = ops.BlockFwd(n_img=n_img, heads=H, D=D, F=Fh, rows=R, save=int(save), tile_qkv=ops.fwd_tile_code(R, 3 * D, D) or ops.GEMM_BK_FWD,
+                          tile_proj=ops.fwd_tile_code(R, D, D, has_resid=True) or ops.GEMM_BK_FWD, eps=eps, scale=scale,
+                          qkv_w=P["qkv_w"].data_ptr(), qkv_b=P["qkv_b"].data_ptr(), proj_w=P["proj_w"].data_ptr(), proj_b=P["proj_b"].data_ptr(),
+                          n2_g=P["n2_g"].data_ptr(), n2_b=P["n2_b"].data_ptr(), fc1_w=P["fc1_w"].data_ptr(), fc1_b=P["fc1_b"].data_ptr(),
+                          fc2_w=P["fc2_w"].data_ptr(), fc2_b=P["fc2_b"].data_ptr(), next_n1_g=None if last else P["nn1_g"].data_ptr(),
+                          next_n1_b=None if last else P["nn1_b"].data_ptr(), x=x.data_ptr(), ln1=ln1.data_ptr())
+        for k in off:
+            setattr(st, k, (p32 if k in ("lse", "mu2", "rs2", "nmu", "nrs") else p16) + off[k])
+        ops.L.call("dig_encoder_block_fwd", ctypes.byref(st), ops.L.stream())
+
+        def v(name, cols=D):
+            if name == "lse":
+                return b32[off[name] // 4:][:n_img * H * 256].view(n_img * H, 256)
+            if name in ("mu2", "rs2", "nmu", "nrs"):
+                return b32[off[name] // 4:][:R]
+            return b16[off[name] // 2:][:R * cols].view(R, cols)
+        return v
+
+    names = {"qkv": ("qkv", 3 * D), "ctx": ("ctx", D), "lse": ("lse", 0), "x_mid": ("x_mid", D), "out": ("out", D), "ln": ("ln2", D),
+             "ln_mean": ("mu2", 0), "ln_rstd": ("rs2", 0), "pre": ("pre", Fh), "act": ("act", Fh), "nln": ("nln", D), "nln_mean": ("nmu", 0),
+             "nln_rstd": ("nrs", 0)}
+    for save, last in ((True, False), (False, False), (True, True), (False, True)):
+        ref, v = fwd_entry_points(save, last), fwd_block_call(save, last)
+        for k, (nm, cols) in names.items():
+            if ref.get(k) is not None:
+                assert torch.equal(ref[k], v(nm, cols)), (k, save, last)
+    # ---- backward over two "blocks" (the same saved tensors twice, two incoming gradients): the second call folds the first one's slabs
+    sv = fwd_entry_points(True, False)
+    w2t, w1t = ops.transpose_bf16(P["fc2_w"]), ops.transpose_bf16(P["fc1_w"])
+    dys = [bf(R, D, s=0.02), bf(R, D, s=0.02)]
+    gnames = ("n1_g", "n1_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "n2_g", "n2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")
+    mkgrads = lambda: [{k: torch.full(P[k].shape, 0.125, device=dev, dtype=torch.float32) for k in gnames} for _ in range(2)]
+
+    def bwd_entry_points(G):
+        grp, outs = ops.WgradGroup(dev), []
+        for dy, gk in zip(dys, G):
+            assert grp.add(dy, sv["act"], gk["fc2_w"])
+            dln2, dpre, bparts = ops.mlp_chain_bwd(dy, w2t, sv["pre"], w1t)
+            assert grp.add(dpre, sv["ln"], gk["fc1_w"])
+            dx_mid, fin2, ws2 = ops.layernorm_bwd(dln2, sv["x_mid"], P["n2_g"], P["n2_b"], sv["ln_mean"], sv["ln_rstd"], dy, gk["n2_g"], gk["n2_b"],
+                                                  out=dln2, dres_colsum=gk["fc2_b"], defer=True)
+            assert grp.add(dx_mid, sv["ctx"], gk["proj_w"])
+            dctx = ops.linear_dgrad(dx_mid, P["proj_w"])
+            dqkv, qs, vs = ops.attn_bwd(sv["qkv"], sv["ctx"], dctx, sv["lse"], n_img, H, D, scale, bias_sums=True)
+            assert grp.add(dqkv, ln1, gk["qkv_w"])
+            grp.launch()
+            dln1 = ops.linear_dgrad(dqkv, P["qkv_w"], out=dctx)
+            dx, fin1, ws1 = ops.layernorm_bwd(dln1, x, P["n1_g"], P["n1_b"], mu1, rs1, dx_mid, gk["n1_g"], gk["n1_b"], out=dln1,
+                                              dres_colsum=gk["proj_b"], defer=True)
+            ops.colsum_partials(bparts, gk["fc1_b"]); fin2()
+            ops.colsum_partials(qs, gk["qkv_b"][:D]); ops.colsum_partials(vs, gk["qkv_b"][2 * D:]); fin1()
+            outs.append(dx.clone())
+        grp.flush()
+        return outs
+
+    def bwd_block_calls(G):
+        plan = ops.wgrad_block_plan(dev, R, D, Fh)
+        assert plan is not None
+        off, n16, n32 = ops.block_bwd_layout(R, D, Fh, n_img)
+        probs, outs, keep, slabs_prev = ((ops._WgProb * 4)(), (ops._WgProb * 4)()), [], [], None
+        for n, (dy, gk) in enumerate(zip(dys, G)):
+            t16, t32 = torch.empty(n16 // 2, device=dev, dtype=torch.bfloat16), torch.empty(n32 // 4, device=dev)
+            keep += [t16, t32]
+            p16, p32 = t16.data_ptr(), t32.data_ptr()
+            slabs = plan["group"]._slabs(plan["slab_bytes"])
+            plan["group"].set ^= 1
+            st = ops.BlockBwd(n_img=n_img, heads=H, D=D, F=Fh, rows=R, tile_dgrad=ops.dgrad_tile_code(R, D) or ops.GEMM_BK_BWD, scale=scale,
+                              qkv_w=P["qkv_w"].data_ptr(), proj_w=P["proj_w"].data_ptr(), w2t=w2t.data_ptr(), w1t=w1t.data_ptr(),
+                              n1_g=P["n1_g"].data_ptr(), n1_b=P["n1_b"].data_ptr(), n2_g=P["n2_g"].data_ptr(), n2_b=P["n2_b"].data_ptr(),
+                              g_n1_g=gk["n1_g"].data_ptr(), g_n1_b=gk["n1_b"].data_ptr(), g_qkv_w=gk["qkv_w"].data_ptr(), g_q_b=gk["qkv_b"].data_ptr(),
+                              g_v_b=gk["qkv_b"][2 * D:].data_ptr(), g_proj_w=gk["proj_w"].data_ptr(), g_proj_b=gk["proj_b"].data_ptr(),
+                              g_n2_g=gk["n2_g"].data_ptr(), g_n2_b=gk["n2_b"].data_ptr(), g_fc1_w=gk["fc1_w"].data_ptr(), g_fc1_b=gk["fc1_b"].data_ptr(),
+                              g_fc2_w=gk["fc2_w"].data_ptr(), g_fc2_b=gk["fc2_b"].data_ptr(),
+                              x=x.data_ptr(), ln1=ln1.data_ptr(), mu1=mu1.data_ptr(), rs1=rs1.data_ptr(), qkv=sv["qkv"].data_ptr(), ctx=sv["ctx"].data_ptr(),
+                              lse=sv["lse"].data_ptr(), x_mid=sv["x_mid"].data_ptr(), ln2=sv["ln"].data_ptr(), mu2=sv["ln_mean"].data_ptr(),
+                              rs2=sv["ln_rstd"].data_ptr(), pre=sv["pre"].data_ptr(), act=sv["act"].data_ptr(), dy=dy.data_ptr(),
+                              wg_fn=plan["fn"], wg_wa=plan["wa"], wg_splits=plan["splits"], wg_n_wg=plan["n_wg"], wg_fold_n=4 if n else 0,
+                              wg_fold_splits=plan["splits"], wg_trans=(ctypes.c_int * 4)(*plan["trans"]), wg_map=plan["wmap"].data_ptr(),
+                              wg_slabs=slabs.data_ptr(), wg_fold_slabs=slabs_prev.data_ptr() if n else None,
+                              wg_probs=ctypes.addressof(probs[n & 1]), wg_fold_probs=ctypes.addressof(probs[(n & 1) ^ 1]) if n else None,
+                              side=ops.L.stream())
+            for k in ("dln2", "dpre", "dctx", "dqkv"):
+                setattr(st, k, p16 + off[k])
+            for k in ("bparts", "ws1", "ws2", "qs", "vs"):
+                setattr(st, k, p32 + off[k])
+            ops.L.call("dig_encoder_block_bwd", ctypes.byref(st), ops.L.stream())
+            slabs_prev = slabs
+            outs.append(t16[off["dctx"] // 2:][:R * D].view(R, D).clone())
+        ops.L.call("dig_wgrad_group", None, 0, ctypes.addressof(probs[(len(dys) & 1) ^ 1]), 4, R, 1, None, ops.WGRAD_GROUP_SLOTS, None,
+                   ops.L.ptr(slabs_prev), plan["splits"], plan["fn"], plan["wa"], ops.L.stream())
+        return outs
+
+    Ga, Gb = mkgrads(), mkgrads()
+    dxa, dxb = bwd_entry_points(Ga), bwd_block_calls(Gb)
+    for a, b in zip(dxa, dxb):
+        assert torch.equal(a, b)
+    for ga, gb_ in zip(Ga, Gb):
+        for k in gnames:
+            assert torch.equal(ga[k], gb_[k]), k
+            assert not torch.equal(ga[k], torch.full_like(ga[k], 0.125)) or k == "qkv_b", k
+    # a table with a missing pointer is refused
+    assert ops.L.lib().dig_encoder_block_fwd(ctypes.byref(ops.BlockFwd(n_img=n_img, heads=H, D=D, F=Fh, rows=R)), None) == -1

@@ -762,7 +762,7 @@ def test_vit_small_b32_twenty_step_trajectory_vs_oracle():
 
 
 @pytest.mark.parametrize("switch", ["wgrad_off", "wgrad_pair", "wgrad_wa1", "wgrad_side_stream", "chain_mask3", "dgrad_128", "fwd_side", "fwd_serial",
-                                    "chain_no_ln", "bwd_single", "chain_bwd_every2"])
+                                    "chain_no_ln", "bwd_single", "chain_bwd_every2", "per_entry_point"])
 def test_engine_switches_agree_with_the_default_path(switch):
     """Every non-default execution plan of the step (environment switches of dig_amd/ops.py and engine_core.py: launch groupings, tile
     codes, stream plans, fusion masks) against the default plan on one ViT-S step from the same state and batch: the losses agree, and
@@ -771,7 +771,9 @@ def test_engine_switches_agree_with_the_default_path(switch):
     and, where a different FORWARD kernel re-rounds every activation (the LayerNorm fusion), by direction and length per
     tensor (cosine >= 0.95, norm within 10 %): twelve blocks of softmax attention amplify a last-bit change of an activation into a
     ~25 % relative difference of the patch-embedding gradient at random init and B = 8 -- the same spread the fp32 oracle's own bf16
-    autocast shows in test_vit_small_b32_every_tensor_gradient_vs_oracle."""
+    autocast shows in test_vit_small_b32_every_tensor_gradient_vs_oracle.
+    "per_entry_point" turns the one-call-per-encoder-block path (dig_encoder_block_fwd / _bwd, the default) off: the per-entry-point plan
+    launches the same kernels with the same arguments in the same order, so every gradient (and the gradient norm) must agree BIT FOR BIT."""
     from dig_amd import ops, engine_core
     cfg = O.make_config("pretrain_simmim_moco_ori_vit_small_patch4_32x128")
     B = 8
@@ -792,6 +794,7 @@ def test_engine_switches_agree_with_the_default_path(switch):
         "chain_mask3": [(ops, "MLP_CHAIN_MASK", 3)], "dgrad_128": [(ops, "DGRAD_BK", 0)], "fwd_side": [(engine_core, "FWD_MODE", "side")],
         "fwd_serial": [(engine_core, "FWD_MODE", "serial")], "chain_no_ln": [(ops, "MLP_CHAIN_LN", False)],
         "bwd_single": [(engine_core, "BWD_SINGLE_STREAM", True)], "chain_bwd_every2": [(engine_core, "CHAIN_BWD_EVERY", 2)],
+        "per_entry_point": [(ops, "BLOCK_CALLS", False)],
     }
     tight = switch in ("wgrad_off", "wgrad_pair", "wgrad_wa1", "wgrad_side_stream", "fwd_side", "fwd_serial", "bwd_single")
     saved = [(m, k, getattr(m, k)) for m, k, _ in plans[switch]]
@@ -802,6 +805,14 @@ def test_engine_switches_agree_with_the_default_path(switch):
     finally:
         for m, k, v in saved:
             setattr(m, k, v)
+    if switch == "per_entry_point":
+        assert ops.BLOCK_CALLS, "the block-call path is the default"
+        # (the REPORTED loss scalars are accumulated with one fp32 atomic per workgroup / row -- csrc/elementwise.hip, csrc/loss.hip -- and
+        #  move in the last bit from run to run of the SAME plan; nothing that feeds a gradient does)
+        assert all(abs(stats[k] - ref_stats[k]) <= 1e-6 * abs(ref_stats[k]) for k in ("loss", "loss_pixel", "loss_contrast")), (stats, ref_stats)
+        assert stats["grad_norm"] == ref_stats["grad_norm"]
+        assert torch.equal(g, ref_g)
+        return
     for k in ("loss", "loss_pixel", "loss_contrast", "grad_norm"):
         assert abs(stats[k] - ref_stats[k]) <= (1e-5 if tight else 2e-2) * abs(ref_stats[k]) + 1e-6, (k, stats[k], ref_stats[k])      # (2e-2: this file's bf16 band)
     tol = 1e-5 if tight else 2e-2
