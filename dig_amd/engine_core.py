@@ -643,7 +643,9 @@ class _Step:
                 ops.axpy_f32(g32[f"{pre}.{3 * l + 1}.weight"], sums[1])
             self.comm.all_reduce_(sums)
             dh = ops.bn_bwd_apply(dy, h, mean, rstd, gamma, beta, not last, sums, n_total)
-            self._on_side(dy.device, lambda: ops.linear_wgrad(dh, x, g32[f"{pre}.{3 * l}.weight"]), dh, x)
+            # (every head weight is used once per forward: right after zero_grad() its gradient can be written instead of added)
+            asg = getattr(self, "_assign", False)
+            self._on_side(dy.device, lambda: ops.linear_wgrad(dh, x, g32[f"{pre}.{3 * l}.weight"], assign=asg), dh, x)
             if l > 0 or need_dx:
                 dy = ops.linear_dgrad(dh, w16[f"{pre}.{3 * l}.weight"], out=dx_out if l == 0 else None)
         return dy
@@ -823,6 +825,8 @@ class _Step:
         # the whole augmented view -- is exactly zero in the reference, so nothing is launched for it and the encoder
         # backward runs on view 0's rows only (the gradient arena was zero-filled by optimizer.zero_grad()).
         contrast = g_contra is not None
+        # the arena is known to be zero only right after optimizer.zero_grad(): a second backward() without it accumulates, as torch does
+        self._assign, M._grads_fresh = bool(getattr(M, "_grads_fresh", False)), False
         _mark("backward: start (loss, MSE, autograd entry done)", dev)
         views = 2 if (contrast or (g_vis is not None and self.mim_views == 2)) else 1      # encoder rows that carry a gradient
         d_enc = torch.empty_like(self.enc) if contrast else torch.zeros((views * B * N, D), device=dev, dtype=BF16)

@@ -341,10 +341,20 @@ class GradReduceBatch:
         self._flush_vecs()
 
 
-def linear_wgrad(dy, x, dw, rows=None):
-    """dw[out,in] += dy[rows,out]^T @ x[rows,in]."""
+WGRAD_ASSIGN = os.environ.get("DIG_WGRAD_ASSIGN", "1") != "0"
+
+
+def linear_wgrad(dy, x, dw, rows=None, assign=False):
+    """dw[out,in] += dy[rows,out]^T @ x[rows,in].
+    assign=True: the caller states that dw is still zero (its only contribution of this backward pass).  For a SHORT reduction with many
+    output tiles (the BatchNorm-MLP heads: <= 2048 pooled rows, up to 4096 x 4096 outputs) the product is then written straight into dw as
+    the one "slab" of a one-split launch -- no fp32 slab round trip, no dig_reduce_partials (4096 x 4096: 79 + 70 us -> one launch)."""
     rows = dy.shape[0] if rows is None else rows
-    wgrad(dy, x, dw, dw.shape[0], dw.shape[1], rows)
+    I, J = dw.shape
+    if assign and WGRAD_ASSIGN and rows <= 2048 and dw.is_contiguous() and ((I + 127) // 128) * ((J + 127) // 128) >= 64:
+        gemm(dy, x, I, J, rows, ta=True, tb=True, out=dw, out_kind=OUT_F32_PARTIAL, splits=1, ldc=J, bk=32)
+        return
+    wgrad(dy, x, dw, I, J, rows)
 
 
 # ---- grouped weight gradients (csrc/wgrad.hip): the Linear layers of a transformer block in ONE launch, slabs folded by the next launch

@@ -59,6 +59,7 @@ class FusedAdamW(torch.optim.Optimizer):
             ops.fill_f32(g, 0.0)
         else:
             g.zero_()
+        self.model._grads_fresh = True          # the next backward may WRITE single-contribution gradients instead of adding (engine_core)
 
     @torch.no_grad()
     def step(self, closure=None, grad_scale: float = 1.0, finite_gate=None, dev_scalars=None):

@@ -744,3 +744,25 @@ def test_encoder_block_calls_equal_the_entry_point_sequence(dev, n_img):
             assert not torch.equal(ga[k], torch.full_like(ga[k], 0.125)) or k == "qkv_b", k
     # a table with a missing pointer is refused
     assert ops.L.lib().dig_encoder_block_fwd(ctypes.byref(ops.BlockFwd(n_img=n_img, heads=H, D=D, F=Fh, rows=R)), None) == -1
+
+
+@pytest.mark.parametrize("rows,I,J", [(1024, 4096, 4096), (512, 1024, 1024), (1024, 4096, 384)])
+def test_linear_wgrad_assign_writes_what_the_accumulating_form_adds(dev, rows, I, J):
+    """ops.linear_wgrad(assign=True) -- the heads' weight gradients right after zero_grad(): one launch that WRITES dw -- against the slab
+    form that adds into a zeroed dw (same fp32 products, another split of the token sum) and against fp32 torch; stale contents of dw are
+    overwritten, not added to; shapes below the tile threshold keep the accumulating form."""
+    from dig_amd import ops
+    cpu_limit(dev, 2.0 * rows * I * J, 3e9)
+    g = torch.Generator(device="cpu").manual_seed(rows + I)
+    dy = (torch.randn(rows, I, generator=g) * 0.5).bfloat16().to(dev)
+    x = (torch.randn(rows, J, generator=g) * 0.5).bfloat16().to(dev)
+    ref = dy.float().t() @ x.float()
+    a = torch.zeros(I, J, device=dev)
+    ops.linear_wgrad(dy, x, a)
+    b = torch.full((I, J), 3.0, device=dev)
+    ops.linear_wgrad(dy, x, b, assign=True)
+    tiles = ((I + 127) // 128) * ((J + 127) // 128)
+    if tiles >= 64:
+        assert rel(b, ref) < 2e-5 and rel(b, a) < 2e-5
+    else:
+        assert rel(b - 3.0, ref) < 2e-5                     # too few tiles for a one-split launch: the accumulating form ran

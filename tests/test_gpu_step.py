@@ -806,6 +806,13 @@ def test_engine_switches_agree_with_the_default_path(switch):
         for m, k, v in saved:
             setattr(m, k, v)
     if switch == "per_entry_point":
+        # gradients may be WRITTEN instead of added only right after zero_grad(): the flag is consumed by the backward
+        m_ = build_model(cfg, {k: v.clone() for k, v in P.items()}, {k: v.clone() for k, v in S.items()})
+        assert not getattr(m_, "_grads_fresh", False)
+        _, opt_ = run_engine_steps(m_, [batch], hp)
+        assert m_._grads_fresh is False
+        opt_.zero_grad()
+        assert m_._grads_fresh is True
         assert ops.BLOCK_CALLS, "the block-call path is the default"
         # (the REPORTED loss scalars are accumulated with one fp32 atomic per workgroup / row -- csrc/elementwise.hip, csrc/loss.hip -- and
         #  move in the last bit from run to run of the SAME plan; nothing that feeds a gradient does)
