@@ -8,7 +8,10 @@ fp32 gradient arena, per-stage callbacks so the data-parallel wrapper can start 
 parameter range while earlier layers are still in backward.
 """
 import ctypes
+import itertools
 import os
+import weakref
+from typing import Optional, Tuple
 
 import torch
 
@@ -901,6 +904,59 @@ class _DigFn(torch.autograd.Function):
         return None, None, None, None, None, None, None
 
 
+# ---- the step as registered PyTorch operators ---------------------------------------------------------------------------------------------
+# `dig::pretrain_step_fwd` / `dig::pretrain_step_bwd` (torch.library): what MoCo_ViT.forward dispatches and what its autograd formula calls.
+# The operators take the online parameter arena and the gradient arena as tensor arguments, the model object (and with it the state its
+# forward updates: momentum parameters, BatchNorm running statistics) through a registry key, and hand the activations from forward to backward
+# through a step handle.  They are
+# the same code the autograd.Function form runs (DIG_STEP_OPS=0) -- one dispatcher hop per direction (~40 us of host time per step).
+# No fake (meta) implementation: the SimMIM output's row count is the number of masked tokens, a value read from the mask on the host.
+STEP_OPS = os.environ.get("DIG_STEP_OPS", "1") != "0"
+_MODELS = weakref.WeakValueDictionary()
+_LIVE_STEPS = {}
+_handles = itertools.count(1)
+
+
+@torch.library.custom_op("dig::pretrain_step_fwd", mutates_args=(), device_types="cuda")
+def pretrain_step_fwd(anchor: torch.Tensor, online: torch.Tensor, images: torch.Tensor, aug: torch.Tensor, mask: torch.Tensor, m: float,
+                      m_dev: Optional[torch.Tensor], mim_views: int, model_key: int, handle: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """(contra_loss, [q1_acc1, q1_acc5, q2_acc1, q2_acc5], vis_out) of MoCo_ViT.forward (modeling_pretrain_moco_mim_ori.py:484-592).
+    handle != 0: a backward will follow; the step's saved activations wait under that handle.
+    Like the reference's forward (`_momentum_update_key_encoder` :526, BatchNorm running statistics) it updates MODULE STATE -- the momentum
+    arena and the running statistics of the model behind `model_key` -- which is not part of the operator's argument list (torch.library
+    registers autograd formulas for operators without mutated ARGUMENTS only)."""
+    step = _Step(_MODELS[model_key])
+    contra, accs, vis_out = step.forward(images, aug, mask, m_dev if m_dev is not None else m, mim_views, training=handle != 0)
+    if handle:
+        _LIVE_STEPS[handle] = step
+    return contra, accs, vis_out
+
+
+@torch.library.custom_op("dig::pretrain_step_bwd", mutates_args=("grads",), device_types="cuda")
+def pretrain_step_bwd(grads: torch.Tensor, g_contra: Optional[torch.Tensor], g_vis: Optional[torch.Tensor], handle: int) -> None:
+    """Accumulates the gradients of every online parameter into `grads` (the flat arena the parameters' .grad are views of)."""
+    _LIVE_STEPS.pop(handle).backward(g_contra, g_vis)
+
+
+def _step_setup_context(ctx, inputs, output):
+    ctx.handle, ctx.model_key = inputs[-1], inputs[-2]
+    ctx.step = _LIVE_STEPS.pop(ctx.handle, None)  # the saved activations live and die with the autograd graph, not with the table
+    ctx.set_materialize_grads(False)              # an unused output arrives as None, not as a zero tensor (host-visible)
+    ctx.mark_non_differentiable(output[1])
+
+
+def _step_backward(ctx, g_contra, g_accs, g_vis):
+    step, ctx.step = ctx.step, None
+    if step is None:
+        raise RuntimeError("dig::pretrain_step_fwd: backward called twice (the step's activations are released by the first backward)")
+    _LIVE_STEPS[ctx.handle] = step
+    torch.ops.dig.pretrain_step_bwd(_MODELS[ctx.model_key].flat_grads, g_contra, g_vis, ctx.handle)
+    return (None,) * 10
+
+
+pretrain_step_fwd.register_autograd(_step_backward, setup_context=_step_setup_context)
+
+
 def dig_forward(model, image, aug_image, vis_mask_pos, m, only_mim_on_ori_img=True):
     if not image.is_cuda:
         raise RuntimeError("dig_amd.MoCo_ViT runs on an MI355X (cuda device) only; there is no CPU fallback")
@@ -914,7 +970,14 @@ def dig_forward(model, image, aug_image, vis_mask_pos, m, only_mim_on_ori_img=Tr
     anchor = getattr(model, "_anchor", None)
     if anchor is None or anchor.device != image.device:
         anchor = model._anchor = torch.zeros(1, device=image.device, requires_grad=True)
-    if torch.is_grad_enabled():
+    if STEP_OPS:
+        key = id(model)
+        _MODELS[key] = model
+        contra, accs, vis_out = torch.ops.dig.pretrain_step_fwd(
+            anchor, model._flat["online"], image, aug_image, mask,
+            0.0 if isinstance(m, torch.Tensor) else m, m if isinstance(m, torch.Tensor) else None, mim_views, key,
+            next(_handles) if torch.is_grad_enabled() else 0)
+    elif torch.is_grad_enabled():
         contra, accs, vis_out = _DigFn.apply(anchor, model, image, aug_image, mask, m, mim_views)
     else:
         contra, accs, vis_out = _Step(model).forward(image, aug_image, mask, m, mim_views)

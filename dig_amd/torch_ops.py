@@ -10,9 +10,9 @@
 each with a fake (meta) implementation -- so they trace under `torch.compile` / `make_fx` as opaque calls -- and an autograd formula whose
 backward is again made of registered operators (`dig::*_bwd`), i.e. visible to the dispatcher all the way.  Tensors are bf16 activations /
 weights and fp32 LayerNorm parameters and biases, as everywhere in this package; weight gradients come back in the weight's dtype.  The
-pre-training step itself does not go through these operators: it is one autograd node over flat arenas (`engine_core._DigFn`), which is what
-makes its two-stream backward and bucketed collectives possible; the operators are the "one op at a time" integration level of
-INTEGRATION.md section 2.  There is no CPU implementation: the operators are registered for CUDA (= HIP) tensors only.
+pre-training step itself is dispatched as two registered operators of its own, `dig::pretrain_step_fwd` / `dig::pretrain_step_bwd`
+(`dig_amd/engine_core.py`: one node over flat arenas, which is what makes its two-stream backward and bucketed collectives possible); the
+operators below are the "one op at a time" integration level of INTEGRATION.md section 2.  There is no CPU implementation: the operators are registered for CUDA (= HIP) tensors only.
 """
 from typing import Optional, Tuple
 

@@ -762,7 +762,7 @@ def test_vit_small_b32_twenty_step_trajectory_vs_oracle():
 
 
 @pytest.mark.parametrize("switch", ["wgrad_off", "wgrad_pair", "wgrad_wa1", "wgrad_side_stream", "chain_mask3", "dgrad_128", "fwd_side", "fwd_serial",
-                                    "chain_no_ln", "bwd_single", "chain_bwd_every2", "per_entry_point"])
+                                    "chain_no_ln", "bwd_single", "chain_bwd_every2", "per_entry_point", "autograd_function"])
 def test_engine_switches_agree_with_the_default_path(switch):
     """Every non-default execution plan of the step (environment switches of dig_amd/ops.py and engine_core.py: launch groupings, tile
     codes, stream plans, fusion masks) against the default plan on one ViT-S step from the same state and batch: the losses agree, and
@@ -794,7 +794,7 @@ def test_engine_switches_agree_with_the_default_path(switch):
         "chain_mask3": [(ops, "MLP_CHAIN_MASK", 3)], "dgrad_128": [(ops, "DGRAD_BK", 0)], "fwd_side": [(engine_core, "FWD_MODE", "side")],
         "fwd_serial": [(engine_core, "FWD_MODE", "serial")], "chain_no_ln": [(ops, "MLP_CHAIN_LN", False)],
         "bwd_single": [(engine_core, "BWD_SINGLE_STREAM", True)], "chain_bwd_every2": [(engine_core, "CHAIN_BWD_EVERY", 2)],
-        "per_entry_point": [(ops, "BLOCK_CALLS", False)],
+        "per_entry_point": [(ops, "BLOCK_CALLS", False)], "autograd_function": [(engine_core, "STEP_OPS", False)],
     }
     tight = switch in ("wgrad_off", "wgrad_pair", "wgrad_wa1", "wgrad_side_stream", "fwd_side", "fwd_serial", "bwd_single")
     saved = [(m, k, getattr(m, k)) for m, k, _ in plans[switch]]
@@ -805,6 +805,11 @@ def test_engine_switches_agree_with_the_default_path(switch):
     finally:
         for m, k, v in saved:
             setattr(m, k, v)
+    if switch == "autograd_function":
+        # the default dispatches the step as the registered operators dig::pretrain_step_fwd / _bwd; the autograd.Function form runs the same code
+        assert engine_core.STEP_OPS and torch.ops.dig.pretrain_step_fwd is not None and not engine_core._LIVE_STEPS
+        assert stats["grad_norm"] == ref_stats["grad_norm"] and torch.equal(g, ref_g)
+        return
     if switch == "per_entry_point":
         # gradients may be WRITTEN instead of added only right after zero_grad(): the flag is consumed by the backward
         m_ = build_model(cfg, {k: v.clone() for k, v in P.items()}, {k: v.clone() for k, v in S.items()})
