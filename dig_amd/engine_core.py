@@ -746,6 +746,7 @@ class _Step:
                 enc, self.saved_enc = self.encoder_forward(ew_on, images, aug, mask_u8, True)
                 self.enc = enc
                 qs = online_heads(enc)
+            # (Measured and not kept, round 4: the SimMIM decoder right behind the online heads instead of after the join: 21.06 vs 21.07 ms.)
             # (Measured and not kept, round 4: the online heads + SimMIM decoder held back until both encoders are done, so that they run
             #  beside the momentum heads instead of between the encoders: 21.84 vs 21.77 ms, two A/B pairs.)
             enc_m, ks = momentum_branch()
