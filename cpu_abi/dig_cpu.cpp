@@ -509,6 +509,15 @@ int dig_bn_bwd_stats(const void* dy_, const void* x_, const float* mean, const f
   return DIG_OK;
 }
 
+int dig_bn_bwd_stats_acc(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta, int relu,
+                         float* sums, float* dbeta_acc, float* dgamma_acc, float* workspace, int rows, int C, hipStream_t st) {
+  if ((dbeta_acc == nullptr) != (dgamma_acc == nullptr)) return DIG_ERR_ARG;
+  const int rc = dig_bn_bwd_stats(dy, x, mean, rstd, gamma, beta, relu, sums, workspace, rows, C, st);
+  if (rc || !dbeta_acc) return rc;
+  for (int c = 0; c < C; ++c) { dbeta_acc[c] += sums[c]; dgamma_acc[c] += sums[C + c]; }
+  return DIG_OK;
+}
+
 int dig_bn_bwd_apply(const void* dy_, const void* x_, const float* mean, const float* rstd, const float* gamma, const float* beta, int relu,
                      const float* sums, float n_total, void* dx_, int rows, int C, hipStream_t) {
   if (!dy_ || !x_ || !mean || !rstd || !sums || !dx_ || rows <= 0 || C <= 0 || (C & 7) || n_total <= 0.f) return DIG_ERR_ARG;

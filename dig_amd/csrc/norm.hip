@@ -254,7 +254,10 @@ __global__ __launch_bounds__(256) void bn_colstats_kernel(const bf16_t* __restri
 }
 
 // sums[e] = sum_b partial[b][e], e < 2*C  (fixed order)
-__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __restrict__ partial, int nb, int n, float* __restrict__ sums) {
+// acc0 / acc1 (optional, [n / 2] each): += the first / second half of sums -- the BatchNorm affine gradients (dbeta, dgamma) taken from the LOCAL
+// sums before any cross-rank reduction touches them (two axpy launches per layer folded into this one)
+__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __restrict__ partial, int nb, int n, float* __restrict__ sums,
+                                                                float* __restrict__ acc0, float* __restrict__ acc1) {
   // 8 columns x 32 strip groups per workgroup (round 4: 32 x 8 left a [512 strips, 1 024] problem to 32 workgroups of 64 dependent loads: 20 us)
   __shared__ float red[32][9];
   const int cx = threadIdx.x & 7, ry = threadIdx.x >> 3;
@@ -269,6 +272,10 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __r
 #pragma unroll
     for (int q = 0; q < 32; ++q) t += red[q][cx];
     sums[c] = t;
+    if (acc0) {
+      const int h = n >> 1;
+      if (c < h) acc0[c] += t; else acc1[c - h] += t;
+    }
   }
 }
 
@@ -439,7 +446,7 @@ extern "C" int dig_bn_stats(const void* x, float* sums, float* workspace, int ro
   const int nb = (rows + rpb - 1) / rpb;
   hipLaunchKernelGGL(bn_colstats_kernel<0>, dim3(cb, nb), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)nullptr, nullptr,
                      nullptr, nullptr, nullptr, 0, workspace, rows, C, rpb);
-  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((2 * C + 7) / 8), dim3(256), 0, stream, workspace, nb, 2 * C, sums);
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((2 * C + 7) / 8), dim3(256), 0, stream, workspace, nb, 2 * C, sums, (float*)nullptr, (float*)nullptr);
   return dig_check_launch();
 }
 
@@ -467,17 +474,24 @@ extern "C" int dig_bn_fwd_apply(const void* x, const float* sums, float n_total,
   return dig_check_launch();
 }
 
-extern "C" int dig_bn_bwd_stats(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
-                                const float* beta, int relu, float* sums, float* workspace, int rows, int C, hipStream_t stream) {
+extern "C" int dig_bn_bwd_stats_acc(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                                    const float* beta, int relu, float* sums, float* dbeta_acc, float* dgamma_acc, float* workspace, int rows, int C,
+                                    hipStream_t stream) {
   if (!dy || !x || !mean || !rstd || !sums || !workspace || rows <= 0 || (C & 7)) return DIG_ERR_ARG;
+  if ((dbeta_acc == nullptr) != (dgamma_acc == nullptr)) return DIG_ERR_ARG;
   if (!aligned16(x) || !aligned16(dy) || !aligned16(mean) || !aligned16(rstd) || (gamma && (!aligned16(gamma) || !aligned16(beta)))) return DIG_ERR_ALIGN;
   const int cb = bn_col_blocks(C);
   const int rpb = bn_rows_per_block(rows, C);
   const int nb = (rows + rpb - 1) / rpb;
   hipLaunchKernelGGL(bn_colstats_kernel<1>, dim3(cb, nb), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)dy, mean, rstd, gamma,
                      beta, relu, workspace, rows, C, rpb);
-  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((2 * C + 7) / 8), dim3(256), 0, stream, workspace, nb, 2 * C, sums);
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((2 * C + 7) / 8), dim3(256), 0, stream, workspace, nb, 2 * C, sums, dbeta_acc, dgamma_acc);
   return dig_check_launch();
+}
+
+extern "C" int dig_bn_bwd_stats(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                                const float* beta, int relu, float* sums, float* workspace, int rows, int C, hipStream_t stream) {
+  return dig_bn_bwd_stats_acc(dy, x, mean, rstd, gamma, beta, relu, sums, nullptr, nullptr, workspace, rows, C, stream);
 }
 
 extern "C" int dig_bn_bwd_apply(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,

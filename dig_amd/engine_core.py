@@ -640,10 +640,9 @@ class _Step:
             gamma = None if last else f32[f"{pre}.{3 * l + 1}.weight"]
             beta = None if last else f32[f"{pre}.{3 * l + 1}.bias"]
             sums = torch.empty((2, d2), device=dy.device, dtype=F32)
-            ops.bn_bwd_stats(dy, h, mean, rstd, gamma, beta, not last, sums)
-            if not last:                                                   # local sums are the affine gradients
-                ops.axpy_f32(g32[f"{pre}.{3 * l + 1}.bias"], sums[0])
-                ops.axpy_f32(g32[f"{pre}.{3 * l + 1}.weight"], sums[1])
+            # (the LOCAL sums are the affine gradients: accumulated by the statistics launch itself)
+            ops.bn_bwd_stats(dy, h, mean, rstd, gamma, beta, not last, sums, None if last else g32[f"{pre}.{3 * l + 1}.bias"],
+                             None if last else g32[f"{pre}.{3 * l + 1}.weight"])
             self.comm.all_reduce_(sums)
             dh = ops.bn_bwd_apply(dy, h, mean, rstd, gamma, beta, not last, sums, n_total)
             # (every head weight is used once per forward: right after zero_grad() its gradient can be written instead of added)

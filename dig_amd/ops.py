@@ -716,10 +716,12 @@ def bn_update_running(sums, n_total, momentum, rm, rv):
     L.call("dig_bn_update_running", L.ptr(sums), cf(n_total), cf(momentum), L.ptr(rm), L.ptr(rv), rm.numel(), L.stream())
 
 
-def bn_bwd_stats(dy, x, mean, rstd, gamma, beta, relu, sums):
+def bn_bwd_stats(dy, x, mean, rstd, gamma, beta, relu, sums, dbeta=None, dgamma=None):
+    """sums[0] = sum g, sums[1] = sum g * x_hat over this rank's rows; dbeta / dgamma (both or neither): the layer's affine gradients,
+    += those LOCAL sums in the same launch."""
     ws = _workspace2(x.device, _bn_ws_floats(x.shape[0], x.shape[1]))
-    L.call("dig_bn_bwd_stats", L.ptr(dy), L.ptr(x), L.ptr(mean), L.ptr(rstd), L.ptr(gamma), L.ptr(beta), int(relu), L.ptr(sums),
-           L.ptr(ws), x.shape[0], x.shape[1], L.stream())
+    L.call("dig_bn_bwd_stats_acc", L.ptr(dy), L.ptr(x), L.ptr(mean), L.ptr(rstd), L.ptr(gamma), L.ptr(beta), int(relu), L.ptr(sums),
+           L.ptr(dbeta), L.ptr(dgamma), L.ptr(ws), x.shape[0], x.shape[1], L.stream())
 
 
 def bn_bwd_apply(dy, x, mean, rstd, gamma, beta, relu, sums, n_total):
@@ -742,6 +744,10 @@ def l2norm_bwd(dy, y, inv):
     return dx
 
 
+SGEMM_SPLIT_SMALL = os.environ.get("DIG_SGEMM_SPLIT_SMALL", "1") != "0"
+SGEMM_SPLIT_MIN_R = 256          # (the 512 x 512 x 256 logits: 16.5 -> 13.0 us; the 512 x 256 x 512 logit gradient: 36.3 -> 14.8 us)
+
+
 def sgemm(A, B, C, I, J, R, trans_b, alpha):
     """fp32 C = alpha * A[I,R] * (B[R,J] if trans_b else B[J,R]^T).  A long reduction (the logit gradient against keys gathered
     from many ranks) is split into fp32 slabs and summed in a fixed order (deterministic)."""
@@ -750,6 +756,10 @@ def sgemm(A, B, C, I, J, R, trans_b, alpha):
         sp = R // 512
         while sp > 1 and R % (64 * sp):
             sp -= 1
+    elif SGEMM_SPLIT_SMALL and R >= SGEMM_SPLIT_MIN_R and I * J <= (1 << 18) and C.stride(0) == J and R % 256 == 0:
+        # few output tiles (the logit gradient against this rank's own keys: 512 x 256 outputs = 128 workgroups walking R = 512): four
+        # R-slices of 128 make it one round of 512 workgroups; the slab sum is a 2 MB pass (50.8 -> ~25 us per launch, twice per step)
+        sp = R // 128
     if sp > 1:
         ws = _workspace(A.device, sp * I * J)
         L.call("dig_sgemm", L.ptr(A), L.ptr(B), L.ptr(ws), I, J, R, A.stride(0), B.stride(0), J, int(trans_b), cf(alpha), sp, L.stream())

@@ -196,6 +196,10 @@ int dig_bn_update_running(const float* sums, float n_total, float momentum, floa
                           hipStream_t stream);
 int dig_bn_bwd_stats(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
                      int relu, float* sums, float* workspace, int rows, int C, hipStream_t stream);
+/* dig_bn_bwd_stats that also accumulates the layer's affine gradients from the LOCAL sums (before any cross-rank reduction of `sums`):
+ * dbeta_acc[c] += sums[0][c], dgamma_acc[c] += sums[1][c]  (both or neither; the two axpy launches per layer of the backward) */
+int dig_bn_bwd_stats_acc(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                         int relu, float* sums, float* dbeta_acc, float* dgamma_acc, float* workspace, int rows, int C, hipStream_t stream);
 int dig_bn_bwd_apply(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
                      int relu, const float* sums, float n_total, void* dx, int rows, int C, hipStream_t stream);
 

@@ -181,6 +181,10 @@ def test_batchnorm(dev, rows, C, affine, relu):
     assert rel(rm, trm) < 1e-4 and rel(rv, trv) < 1e-4                 # running stats incl. the n/(n-1) factor
     if affine:
         assert rel(s2[1], gf.grad) < 1e-4 and rel(s2[0], bf.grad) < 1e-4
+    # the same launch accumulating the affine gradients from the local sums (dig_bn_bwd_stats_acc): sums unchanged, acc += sums, bit for bit
+    s3, db, dg = torch.empty(2, C, device=dev), torch.full((C,), 0.5, device=dev), torch.full((C,), -0.25, device=dev)
+    ops.bn_bwd_stats(dy, x, mean, rstd, gamma, beta, relu, s3, db, dg)
+    assert torch.equal(s3, s2) and torch.equal(db, 0.5 + s2[0]) and torch.equal(dg, -0.25 + s2[1])
 
 
 @pytest.mark.parametrize("Bn,D", [(6, 384), (3, 128)])
