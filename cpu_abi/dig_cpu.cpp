@@ -779,6 +779,22 @@ int dig_sgemm(const float* A, const float* B, float* C, int I, int J, int R, int
   return DIG_OK;
 }
 
+int dig_infonce_finish(const float* stats6, float loss_scale, float acc_scale, float* contra, float* accs4, hipStream_t) {
+  if (!stats6 || !contra || !accs4) return DIG_ERR_ARG;
+  contra[0] = (stats6[0] + stats6[3]) * loss_scale;
+  for (int k = 0; k < 4; ++k) accs4[k] = stats6[(k >> 1) * 3 + 1 + (k & 1)] * acc_scale;
+  return DIG_OK;
+}
+int dig_step_meters(const float* loss, const float* contra, const float* pixel, const float* accs4, const int* counts, int n_counts,
+                    const float* grad_norm, float* out10, hipStream_t) {
+  if (!loss || !contra || !pixel || !accs4 || !counts || n_counts <= 0 || !out10) return DIG_ERR_ARG;
+  int lo = counts[0], hi = counts[0];
+  for (int i = 1; i < n_counts; ++i) { lo = std::min(lo, counts[i]); hi = std::max(hi, counts[i]); }
+  out10[0] = loss[0]; out10[1] = contra[0]; out10[2] = pixel[0];
+  for (int k = 0; k < 4; ++k) out10[3 + k] = accs4[k];
+  out10[7] = (float)lo; out10[8] = (float)hi; out10[9] = grad_norm ? grad_norm[0] : NAN;
+  return DIG_OK;
+}
 int dig_ce_rows(float* logits, int n, int m, int label_offset, float gscale, float* out3, hipStream_t) {
   if (!logits || !out3 || n <= 0 || m <= 0 || label_offset < 0 || label_offset + n > m) return DIG_ERR_ARG;
   for (int i = 0; i < n; ++i) {

@@ -118,7 +118,43 @@ __global__ __launch_bounds__(256) void ce_rows_kernel(float* __restrict__ logits
   }
 }
 
+// The scalar tail of the InfoNCE pair (modeling_pretrain_moco_mim_ori.py:444-461, 2 T * mean CE of both directions) and of a step's log line
+// (engine_for_pretraining_moco.py:146-183): a handful of fp32 scalars combined in ONE launch each instead of five to seven framework ones.
+__global__ void infonce_finish_kernel(const float* __restrict__ stats6, float loss_scale, float acc_scale, float* __restrict__ contra,
+                                      float* __restrict__ accs4) {
+  if (threadIdx.x == 0) contra[0] = (stats6[0] + stats6[3]) * loss_scale;
+  if (threadIdx.x < 4) accs4[threadIdx.x] = stats6[(threadIdx.x >> 1) * 3 + 1 + (threadIdx.x & 1)] * acc_scale;
+}
+
+__global__ __launch_bounds__(64) void step_meters_kernel(const float* __restrict__ loss, const float* __restrict__ contra, const float* __restrict__ pixel,
+                                                        const float* __restrict__ accs4, const int* __restrict__ counts, int n_counts,
+                                                        const float* __restrict__ grad_norm, float* __restrict__ out10) {
+  int lo = 0x7fffffff, hi = -0x7fffffff - 1;
+  for (int i = threadIdx.x; i < n_counts; i += 64) { const int c = counts[i]; lo = min(lo, c); hi = max(hi, c); }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o, 64)); hi = max(hi, __shfl_xor(hi, o, 64)); }
+  if (threadIdx.x == 0) {
+    out10[0] = loss[0]; out10[1] = contra[0]; out10[2] = pixel[0];
+    out10[7] = (float)lo; out10[8] = (float)hi;
+    out10[9] = grad_norm ? grad_norm[0] : __builtin_nanf("");
+  }
+  if (threadIdx.x < 4) out10[3 + threadIdx.x] = accs4[threadIdx.x];
+}
+
 }  // namespace
+
+extern "C" int dig_infonce_finish(const float* stats6, float loss_scale, float acc_scale, float* contra, float* accs4, hipStream_t stream) {
+  if (!stats6 || !contra || !accs4) return DIG_ERR_ARG;
+  hipLaunchKernelGGL(infonce_finish_kernel, dim3(1), dim3(64), 0, stream, stats6, loss_scale, acc_scale, contra, accs4);
+  return dig_check_launch();
+}
+
+extern "C" int dig_step_meters(const float* loss, const float* contra, const float* pixel, const float* accs4, const int* counts, int n_counts,
+                               const float* grad_norm, float* out10, hipStream_t stream) {
+  if (!loss || !contra || !pixel || !accs4 || !counts || n_counts <= 0 || !out10) return DIG_ERR_ARG;
+  hipLaunchKernelGGL(step_meters_kernel, dim3(1), dim3(64), 0, stream, loss, contra, pixel, accs4, counts, n_counts, grad_norm, out10);
+  return dig_check_launch();
+}
 
 extern "C" int dig_l2norm_fwd(const float* x, float* y, float* inv_norm, int n, int C, float eps, hipStream_t stream) {
   if (!x || !y || !inv_norm || n <= 0 || C <= 0) return DIG_ERR_ARG;

@@ -810,8 +810,7 @@ class _Step:
             ops.sgemm(qn[half * n:(half + 1) * n], kk, logits, n, mk, dim, False, 1.0 / M.T)
             ops.ce_rows(logits, n * comm.rank, gs, stats[half])
             ops.sgemm(logits, kk, self.dqn[half * n:(half + 1) * n], n, dim, mk, True, 1.0 / M.T)
-        contra = (stats[0, 0] + stats[1, 0]) * (2.0 * M.T / n)
-        accs = stats[:, 1:].reshape(4) * (100.0 / n)                        # q1_acc1, q1_acc5, q2_acc1, q2_acc5
+        contra, accs = ops.infonce_finish(stats, 2.0 * M.T / n, 100.0 / n)   # accs: q1_acc1, q1_acc5, q2_acc1, q2_acc5
         if vis_out is None:
             vis_out, _ = decoder()
         _mark("forward: InfoNCE + SimMIM decoder done", dev)

@@ -141,6 +141,16 @@ def _step_body(model, core, optimizer, loss_scaler, max_norm, args, normlize_tar
     # and its per-step torch.cuda.synchronize() (:159) drain the HIP queues twice per step and leave the GPU waiting
     # on kernel launches (measured: 1.1 ms of a 28.7 ms step).  The non-finite-loss exit (:148-150) and the
     # ragged-mask check therefore fire one step late -- before anything is logged or saved for that step.
+    a1 = out_dict['q1_acc1']
+    f32s = (loss, contra_loss, loss_pixel, a1)
+    if (all(isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 for t in f32s) and loss.numel() == 1 and loss_pixel.numel() == 1
+            and all(out_dict[k].data_ptr() == a1.data_ptr() + 4 * j for j, k in enumerate(('q1_acc1', 'q1_acc5', 'q2_acc1', 'q2_acc5')))
+            and core._last_mask_counts.dtype == torch.int32 and core._last_mask_counts.is_contiguous()
+            and (grad_norm is None or (isinstance(grad_norm, torch.Tensor) and grad_norm.dtype == torch.float32 and grad_norm.numel() == 1))):
+        # one launch for the ten logged values (the accuracies are four consecutive floats of one tensor)
+        from . import ops
+        return ops.step_meters(loss.detach(), contra_loss.detach(), loss_pixel.detach(), a1, core._last_mask_counts,
+                               None if grad_norm is None else grad_norm.detach()), grad_norm is not None
     dev_vals = torch.stack([loss.detach().reshape(()), contra_loss.detach().reshape(()), loss_pixel.detach().reshape(()),
                             out_dict['q1_acc1'][0], out_dict['q1_acc5'][0], out_dict['q2_acc1'][0], out_dict['q2_acc5'][0],
                             core._last_mask_counts.min().float(), core._last_mask_counts.max().float(),

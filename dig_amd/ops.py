@@ -772,6 +772,22 @@ def ce_rows(logits, label_offset, gscale, out3):
     L.call("dig_ce_rows", L.ptr(logits), logits.shape[0], logits.shape[1], label_offset, cf(gscale), L.ptr(out3), L.stream())
 
 
+def infonce_finish(stats, loss_scale, acc_scale):
+    """(contra [1], accs [4]) from the two dig_ce_rows triples `stats` [2, 3] in one launch."""
+    contra = torch.empty((), device=stats.device, dtype=F32)
+    accs = torch.empty(4, device=stats.device, dtype=F32)
+    L.call("dig_infonce_finish", L.ptr(stats), cf(loss_scale), cf(acc_scale), L.ptr(contra), L.ptr(accs), L.stream())
+    return contra, accs
+
+
+def step_meters(loss, contra, pixel, accs4, counts, grad_norm):
+    """The ten logged values of a step as one fp32 vector (one launch): loss, contra, pixel, accs4, min / max of counts, grad_norm (None -> NaN)."""
+    out = torch.empty(10, device=loss.device, dtype=F32)
+    L.call("dig_step_meters", L.ptr(loss), L.ptr(contra), L.ptr(pixel), L.ptr(accs4), L.ptr(counts), counts.numel(), L.ptr(grad_norm), L.ptr(out),
+           L.stream())
+    return out
+
+
 def cast_f32_to_bf16(x, y, n=None):
     L.call("dig_cast_f32_to_bf16", L.ptr(x), L.ptr(y), cll(x.numel() if n is None else n), L.stream())
 

@@ -251,6 +251,13 @@ int dig_l2norm_bwd(const float* dy, const float* y, const float* inv_norm, float
 int dig_sgemm(const float* A, const float* B, float* C, int I, int J, int R, int lda, int ldb, int ldc, int trans_b, float alpha,
               int r_splits /* >1: C is [r_splits][I][ldc] partial slabs over R, summed by dig_reduce_partials */, hipStream_t stream);
 int dig_ce_rows(float* logits, int n, int m, int label_offset, float gscale, float* out3, hipStream_t stream);
+/* The scalar tails, one launch each.  dig_infonce_finish: stats6 = the two out3 triples of the q1/k2 and q2/k1 dig_ce_rows launches ->
+ * contra[0] = (stats6[0] + stats6[3]) * loss_scale (2 T / n: modeling_pretrain_moco_mim_ori.py:459-461), accs4 = (q1_acc1, q1_acc5, q2_acc1,
+ * q2_acc5) = the hit counts * acc_scale.  dig_step_meters: the ten values a step logs (engine_for_pretraining_moco.py:146-183) as one
+ * vector: loss, contra, pixel, accs4[0..3], min and max of counts[n_counts] (masked tokens per sample), grad_norm (NULL -> NaN). */
+int dig_infonce_finish(const float* stats6, float loss_scale, float acc_scale, float* contra, float* accs4, hipStream_t stream);
+int dig_step_meters(const float* loss, const float* contra, const float* pixel, const float* accs4, const int* counts, int n_counts,
+                    const float* grad_norm, float* out10, hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Flat-arena optimizer (custom_optim/adamw.py:55-121 + _functional.py:115-140 as one kernel; EMA

@@ -770,3 +770,20 @@ def test_linear_wgrad_assign_writes_what_the_accumulating_form_adds(dev, rows, I
         assert rel(b, ref) < 2e-5 and rel(b, a) < 2e-5
     else:
         assert rel(b - 3.0, ref) < 2e-5                     # too few tiles for a one-split launch: the accumulating form ran
+
+
+def test_scalar_tails_of_infonce_and_the_log_line(dev):
+    """dig_infonce_finish / dig_step_meters: the handful of scalars behind `contra_loss`, the four accuracies and a step's log line, against
+    the framework expressions they replace (exact: one multiply / one copy per value)."""
+    from dig_amd import ops
+    stats = torch.tensor([[3.5, 7.0, 40.0], [2.25, 9.0, 61.0]], device=dev)
+    contra, accs = ops.infonce_finish(stats, 2.0 * 0.2 / 512, 100.0 / 512)
+    assert torch.equal(contra, (stats[0, 0] + stats[1, 0]) * (2.0 * 0.2 / 512)) and contra.dim() == 0
+    assert torch.equal(accs, stats[:, 1:].reshape(4) * (100.0 / 512))
+    counts = torch.tensor([179, 180, 12, 179, 255, 179, 178], device=dev, dtype=torch.int32).repeat(37)
+    loss, pix, gn = torch.tensor(0.4772, device=dev), torch.tensor(0.0845, device=dev), torch.tensor(0.1073, device=dev)
+    v = ops.step_meters(loss, contra, pix, accs, counts, gn)
+    ref = torch.stack([loss, contra, pix, accs[0], accs[1], accs[2], accs[3], counts.min().float(), counts.max().float(), gn])
+    assert torch.equal(v, ref)
+    v = ops.step_meters(loss, contra, pix, accs, counts[:1], None)
+    assert torch.equal(v[:9], torch.stack([loss, contra, pix, accs[0], accs[1], accs[2], accs[3], counts[0].float(), counts[0].float()])) and bool(torch.isnan(v[9]))
