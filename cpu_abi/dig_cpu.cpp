@@ -665,6 +665,26 @@ int dig_window_pool_bwd(const void* dpool_, void* dx_, int n_img, int gh, int gw
 }
 
 // ------------------------------------------------------------------------------------------------------------------ SimMIM plumbing
+}  // extern "C"
+template <typename T>
+static void mask_views_u8_host(const T* mask, unsigned char* out, int B, int V, int N, int keep_views) {
+  for (int v = 0; v < V; ++v)
+    for (int b = 0; b < B; ++b)
+      for (int n = 0; n < N; ++n) out[((size_t)v * B + b) * N + n] = (v < keep_views && mask[((size_t)b * V + v) * N + n] != (T)0) ? 1 : 0;
+}
+extern "C" {
+int dig_mask_views_u8(const void* mask, int elem_kind, int B, int V, int N, int keep_views, unsigned char* out, hipStream_t) {
+  if (!mask || !out || B <= 0 || V <= 0 || N <= 0 || keep_views < 0) return DIG_ERR_ARG;
+  switch (elem_kind) {
+    case 0: mask_views_u8_host((const unsigned char*)mask, out, B, V, N, keep_views); break;
+    case 1: mask_views_u8_host((const float*)mask, out, B, V, N, keep_views); break;
+    case 2: mask_views_u8_host((const double*)mask, out, B, V, N, keep_views); break;
+    case 3: mask_views_u8_host((const int*)mask, out, B, V, N, keep_views); break;
+    case 4: mask_views_u8_host((const long long*)mask, out, B, V, N, keep_views); break;
+    default: return DIG_ERR_UNSUPPORTED;
+  }
+  return DIG_OK;
+}
 int dig_mask_to_index(const unsigned char* mask, int* idx, int* count, int B, int N, int max_per_sample, hipStream_t) {
   if (!mask || !idx || !count || B <= 0 || N <= 0 || max_per_sample <= 0) return DIG_ERR_ARG;
   for (int b = 0; b < B; ++b) {

@@ -488,6 +488,35 @@ extern "C" int dig_window_pool_bwd(const void* dpool, void* dx, int n_img, int g
   return dig_check_launch();
 }
 
+// out[v * B + b][n] = (mask[b][v][n] != 0) && v < keep_views: the loader's [B, V, N] mask (any of five element types) as the view-major
+// uint8 rows the encoder reads, with the views that are not masked (only_mim_on_ori_img: view 1) zeroed -- the bool cast, the fill, the
+// permute copy and the uint8 cast of engine_for_pretraining_moco.py:99-104 / modeling_pretrain_moco_mim_ori.py:497 in one launch
+template <typename T>
+__global__ void mask_views_u8_kernel(const T* __restrict__ mask, unsigned char* __restrict__ out, int B, int V, int N, int keep_views) {
+  const size_t total = (size_t)B * V * N;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int n = (int)(e % N);
+    const size_t r = e / N;
+    const int b = (int)(r % B), v = (int)(r / B);
+    out[e] = (v < keep_views && mask[((size_t)b * V + v) * N + n] != (T)0) ? 1 : 0;
+  }
+}
+
+extern "C" int dig_mask_views_u8(const void* mask, int elem_kind, int B, int V, int N, int keep_views, unsigned char* out, hipStream_t stream) {
+  if (!mask || !out || B <= 0 || V <= 0 || N <= 0 || keep_views < 0) return DIG_ERR_ARG;
+  const size_t total = (size_t)B * V * N;
+  const int grid = (int)std::min<size_t>(1024, (total + 255) / 256);
+  switch (elem_kind) {                                                 // 0: 1-byte (bool / uint8), 1: fp32, 2: fp64, 3: int32, 4: int64
+    case 0: hipLaunchKernelGGL(mask_views_u8_kernel<unsigned char>, dim3(grid), dim3(256), 0, stream, (const unsigned char*)mask, out, B, V, N, keep_views); break;
+    case 1: hipLaunchKernelGGL(mask_views_u8_kernel<float>, dim3(grid), dim3(256), 0, stream, (const float*)mask, out, B, V, N, keep_views); break;
+    case 2: hipLaunchKernelGGL(mask_views_u8_kernel<double>, dim3(grid), dim3(256), 0, stream, (const double*)mask, out, B, V, N, keep_views); break;
+    case 3: hipLaunchKernelGGL(mask_views_u8_kernel<int>, dim3(grid), dim3(256), 0, stream, (const int*)mask, out, B, V, N, keep_views); break;
+    case 4: hipLaunchKernelGGL(mask_views_u8_kernel<long long>, dim3(grid), dim3(256), 0, stream, (const long long*)mask, out, B, V, N, keep_views); break;
+    default: return DIG_ERR_UNSUPPORTED;
+  }
+  return dig_check_launch();
+}
+
 extern "C" int dig_mask_to_index(const unsigned char* mask, int* idx, int* count, int B, int N, int max_per_sample,
                                  hipStream_t stream) {
   if (!mask || !idx || !count || B <= 0 || N <= 0 || max_per_sample <= 0) return DIG_ERR_ARG;

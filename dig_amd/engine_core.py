@@ -666,7 +666,10 @@ class _Step:
         self._bn_touched = []
         images = images.contiguous().float()
         aug = aug.contiguous().float()
-        mask_u8 = mask_b2n.permute(1, 0, 2).reshape(2 * B, N).to(torch.uint8).contiguous()    # rows 0..B-1 = view 0 (:497)
+        if mask_b2n.dtype == torch.uint8 and mask_b2n.dim() == 2 and tuple(mask_b2n.shape) == (2 * B, N):
+            mask_u8 = mask_b2n if mask_b2n.is_contiguous() else mask_b2n.contiguous()      # prepared by the engine: view-major rows already
+        else:
+            mask_u8 = mask_b2n.permute(1, 0, 2).reshape(2 * B, N).to(torch.uint8).contiguous()    # rows 0..B-1 = view 0 (:497)
         self.images, self.aug, self.mask_u8 = images, aug, mask_u8
         ew_on, ew_mo = _weights(M)
         _mark("forward: start", dev)
@@ -963,8 +966,8 @@ def dig_forward(model, image, aug_image, vis_mask_pos, m, only_mim_on_ori_img=Tr
         raise RuntimeError("model and inputs are on different devices (call model.to(device))")
     mim_views = 1 if only_mim_on_ori_img else 2
     mask = vis_mask_pos
-    if mask.dim() == 2:
-        mask = mask.view(image.shape[0], -1, model.N)
+    if mask.dim() == 2 and not (mask.dtype == torch.uint8 and tuple(mask.shape) == (2 * image.shape[0], model.N)):
+        mask = mask.view(image.shape[0], -1, model.N)           # ([2 B, N] uint8 = the engine's prepared view-major rows: taken as they are)
     m = m if isinstance(m, torch.Tensor) else float(m)          # a device [m, 1-m] pair under graph capture (step_graph.py)
     anchor = getattr(model, "_anchor", None)
     if anchor is None or anchor.device != image.device:

@@ -107,9 +107,18 @@ def _step_body(model, core, optimizer, loss_scaler, max_norm, args, normlize_tar
     (moco_m = device [m, 1-m], w_contrast = device scalar, AdamW scalars from device memory).  Returns the ten logged values as one
     device vector and whether a gradient norm is among them."""
     B = images.shape[0]
-    bool_vis_masked_pos = bool_vis_masked_pos.flatten(1).to(torch.bool).view(B, args.num_view, -1)
-    if args.only_mim_on_ori_img:
-        bool_vis_masked_pos[:, 1, :].fill_(0)                           # only the original view is masked (:103-104)
+    prepared = None
+    if bool_vis_masked_pos.is_cuda and args.num_view == 2 and bool_vis_masked_pos.is_contiguous():
+        # the bool cast, the view-1 fill (:103-104) and the model's view-major uint8 copy in ONE launch (dig_mask_views_u8); the model takes
+        # the prepared [2 B, N] uint8 rows as they are
+        from . import ops
+        prepared = ops.mask_views_u8(bool_vis_masked_pos.view(B, args.num_view, -1), 1 if args.only_mim_on_ori_img else args.num_view)
+    if prepared is not None:
+        bool_vis_masked_pos = prepared
+    else:
+        bool_vis_masked_pos = bool_vis_masked_pos.flatten(1).to(torch.bool).view(B, args.num_view, -1)
+        if args.only_mim_on_ori_img:
+            bool_vis_masked_pos[:, 1, :].fill_(0)                       # only the original view is masked (:103-104)
 
     out_dict = model(images, aug_images, bool_vis_masked_pos, moco_m, args.only_mim_on_ori_img)
     loss = 0.

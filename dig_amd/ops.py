@@ -653,6 +653,20 @@ def window_pool_bwd(dpool, dx, n_img, gh, gw, nwin, D, accumulate):
     L.call("dig_window_pool_bwd", L.ptr(dpool), L.ptr(dx), n_img, gh, gw, nwin, D, int(accumulate), L.stream())
 
 
+_MASK_KINDS = {torch.bool: 0, torch.uint8: 0, torch.float32: 1, torch.float64: 2, torch.int32: 3, torch.int64: 4}
+
+
+def mask_views_u8(mask_bvn, keep_views):
+    """[B, V, N] mask of any of those element types -> uint8 [V * B, N], view major, views >= keep_views zeroed; None for other inputs."""
+    kind = _MASK_KINDS.get(mask_bvn.dtype)
+    if kind is None or mask_bvn.dim() != 3 or not mask_bvn.is_contiguous():
+        return None
+    B, V, N = mask_bvn.shape
+    out = torch.empty((V * B, N), device=mask_bvn.device, dtype=torch.uint8)
+    L.call("dig_mask_views_u8", L.ptr(mask_bvn), kind, B, V, N, int(keep_views), L.ptr(out), L.stream())
+    return out
+
+
 def mask_to_index(mask_u8, max_per_sample):
     B, N = mask_u8.shape
     idx = torch.zeros((B, max_per_sample), device=mask_u8.device, dtype=torch.int32)   # ragged masks are reported one step late

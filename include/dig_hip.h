@@ -224,6 +224,10 @@ int dig_colsum_masked(const void* x, const unsigned char* mask, float* out_unmas
 int dig_window_pool_fwd(const void* x, void* out, int out_is_f32, int n_img, int gh, int gw, int nwin, int D, hipStream_t stream);
 int dig_window_pool_bwd(const void* dpool, void* dx, int n_img, int gh, int gw, int nwin, int D, int accumulate, hipStream_t stream);
 
+/* The loader's mask [B, V, N] (elem_kind 0: 1-byte bool / uint8, 1: fp32, 2: fp64, 3: int32, 4: int64; non-zero = masked) as the view-major
+ * uint8 rows [V * B, N] the encoder reads, views >= keep_views zeroed (only_mim_on_ori_img: keep_views = 1) -- the bool cast, fill, permute
+ * copy and uint8 cast of engine_for_pretraining_moco.py:99-104 and modeling_pretrain_moco_mim_ori.py:497 in one launch. */
+int dig_mask_views_u8(const void* mask, int elem_kind, int B, int V, int N, int keep_views, unsigned char* out, hipStream_t stream);
 /* ------------------------------------------------------------------------------------------------------------------
  * SimMIM target / decoder plumbing (engine_for_pretraining_moco.py:85-111,141; modeling_pretrain_moco_mim_ori.py:560-570).
  *   dig_mask_to_index: idx[b][j] = b*N + (j-th set position of mask[b,:]) in ascending order -- the order boolean

@@ -787,3 +787,22 @@ def test_scalar_tails_of_infonce_and_the_log_line(dev):
     assert torch.equal(v, ref)
     v = ops.step_meters(loss, contra, pix, accs, counts[:1], None)
     assert torch.equal(v[:9], torch.stack([loss, contra, pix, accs[0], accs[1], accs[2], accs[3], counts[0].float(), counts[0].float()])) and bool(torch.isnan(v[9]))
+
+
+@pytest.mark.parametrize("dtype", [torch.bool, torch.uint8, torch.float32, torch.float64, torch.int32, torch.int64])
+@pytest.mark.parametrize("keep", [1, 2])
+def test_mask_views_u8(dev, dtype, keep):
+    """dig_mask_views_u8 against the expressions it replaces (engine_for_pretraining_moco.py:99-104: bool cast, view-1 fill;
+    modeling_pretrain_moco_mim_ori.py:497: view-major rows), bit-exact for every mask element type the loaders produce."""
+    from dig_amd import ops
+    B, V, N = 5, 2, 256
+    g = torch.Generator(device="cpu").manual_seed(3)
+    m = (torch.rand(B, V, N, generator=g) < 0.7)
+    src = (m.to(dtype) * (3 if dtype not in (torch.bool,) else 1)).to(dtype).to(dev)              # non-zero, not just one
+    ref = src.flatten(1).to(torch.bool).view(B, V, -1).clone()
+    if keep == 1:
+        ref[:, 1, :].fill_(0)
+    ref = ref.permute(1, 0, 2).reshape(V * B, N).to(torch.uint8).contiguous()
+    out = ops.mask_views_u8(src, keep)
+    assert out is not None and out.dtype == torch.uint8 and torch.equal(out, ref)
+    assert ops.mask_views_u8(src.to(torch.float16), keep) is None                                 # other element types: the caller's torch path
