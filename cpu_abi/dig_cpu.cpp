@@ -487,6 +487,15 @@ int dig_bn_update_running(const float* sums, float n_total, float momentum, floa
   return DIG_OK;
 }
 
+int dig_bn_fwd_apply_running(const void* x, const float* sums, float n_total, float eps, const float* gamma, const float* beta, int relu, void* y,
+                             float* mean_out, float* rstd_out, float momentum, float* running_mean, float* running_var, int rows, int C,
+                             hipStream_t st) {
+  if ((running_mean == nullptr) != (running_var == nullptr) || (running_mean && n_total <= 1.f)) return DIG_ERR_ARG;
+  const int rc = dig_bn_fwd_apply(x, sums, n_total, eps, gamma, beta, relu, y, mean_out, rstd_out, rows, C, st);
+  if (rc || !running_mean) return rc;
+  return dig_bn_update_running(sums, n_total, momentum, running_mean, running_var, C, st);
+}
+
 int dig_bn_bwd_stats(const void* dy_, const void* x_, const float* mean, const float* rstd, const float* gamma, const float* beta, int relu,
                      float* sums, float* workspace, int rows, int C, hipStream_t) {
   if (!dy_ || !x_ || !mean || !rstd || !sums || !workspace || rows <= 0 || C <= 0 || (C & 7)) return DIG_ERR_ARG;

@@ -284,7 +284,8 @@ __global__ __launch_bounds__(256) void bn_fwd_apply_kernel(const bf16_t* __restr
                                                            float inv_n, float eps, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, int relu, bf16_t* __restrict__ y,
                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                           size_t total8, int C) {
+                                                           size_t total8, int C, float n_total, float momentum,
+                                                           float* __restrict__ run_mean, float* __restrict__ run_var) {
   // the launch makes (gridDim.x * 256) a multiple of C/8, so a thread keeps one 8-column group for its whole row walk and the
   // per-column scale / shift are computed once (they used to be re-derived, with a 64-bit modulo, for every element)
   const int c8 = C >> 3;
@@ -301,7 +302,15 @@ __global__ __launch_bounds__(256) void bn_fwd_apply_kernel(const bf16_t* __restr
       const float var = fmaxf(s2[k] * inv_n - mu[k] * mu[k], 0.f);
       rs[k] = rsqrtf(var + eps);
       if (!gamma) { gm[k] = 1.f; bt[k] = 0.f; }
-      if (t0 < (unsigned)c8) { mean_out[c + k] = mu[k]; rstd_out[c + k] = rs[k]; }
+      if (t0 < (unsigned)c8) {
+        mean_out[c + k] = mu[k]; rstd_out[c + k] = rs[k];
+        if (run_mean) {                                                  // the running statistics, with bn_running_kernel's own expressions
+          const float mr = s1[k] / n_total;
+          const float vr = fmaxf(s2[k] / n_total - mr * mr, 0.f);
+          run_mean[c + k] = run_mean[c + k] * (1.f - momentum) + mr * momentum;
+          run_var[c + k] = run_var[c + k] * (1.f - momentum) + vr * (n_total / (n_total - 1.f)) * momentum;
+        }
+      }
     }
   }
   for (size_t i = t0; i < total8; i += (size_t)gridDim.x * blockDim.x) {
@@ -461,17 +470,24 @@ static inline int bn_apply_grid(size_t total8, int C) {
   return (int)std::max<size_t>(1, (want + unit - 1) / unit) * unit;
 }
 
-extern "C" int dig_bn_fwd_apply(const void* x, const float* sums, float n_total, float eps, const float* gamma,
-                                const float* beta, int relu, void* y, float* mean_out, float* rstd_out, int rows, int C,
-                                hipStream_t stream) {
+extern "C" int dig_bn_fwd_apply_running(const void* x, const float* sums, float n_total, float eps, const float* gamma,
+                                        const float* beta, int relu, void* y, float* mean_out, float* rstd_out, float momentum,
+                                        float* running_mean, float* running_var, int rows, int C, hipStream_t stream) {
   if (!x || !sums || !y || !mean_out || !rstd_out || rows <= 0 || (C & 7) || n_total <= 0.f) return DIG_ERR_ARG;
+  if ((running_mean == nullptr) != (running_var == nullptr) || (running_mean && n_total <= 1.f)) return DIG_ERR_ARG;
   if ((gamma == nullptr) != (beta == nullptr)) return DIG_ERR_ARG;
   if (!aligned16(x) || !aligned16(y) || !aligned16(sums) || (gamma && (!aligned16(gamma) || !aligned16(beta)))) return DIG_ERR_ALIGN;
   const size_t total8 = (size_t)rows * C / 8;
   const int grid = bn_apply_grid(total8, C);
   hipLaunchKernelGGL(bn_fwd_apply_kernel, dim3(grid), dim3(256), 0, stream, (const bf16_t*)x, sums, 1.0f / n_total, eps, gamma,
-                     beta, relu, (bf16_t*)y, mean_out, rstd_out, total8, C);
+                     beta, relu, (bf16_t*)y, mean_out, rstd_out, total8, C, n_total, momentum, running_mean, running_var);
   return dig_check_launch();
+}
+
+extern "C" int dig_bn_fwd_apply(const void* x, const float* sums, float n_total, float eps, const float* gamma,
+                                const float* beta, int relu, void* y, float* mean_out, float* rstd_out, int rows, int C,
+                                hipStream_t stream) {
+  return dig_bn_fwd_apply_running(x, sums, n_total, eps, gamma, beta, relu, y, mean_out, rstd_out, 0.f, nullptr, nullptr, rows, C, stream);
 }
 
 extern "C" int dig_bn_bwd_stats_acc(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,

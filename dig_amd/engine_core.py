@@ -587,9 +587,8 @@ class _Step:
             self.comm.all_reduce_(sums)
             gamma = None if last else f32[f"{pre}.{3 * l + 1}.weight"]
             beta = None if last else f32[f"{pre}.{3 * l + 1}.bias"]
-            y, mean, rstd = ops.bn_fwd_apply(h, sums, n_total, M.bn_eps, gamma, beta, relu=not last)
             rm, rv, i_bn = M._bn_views[f"{pre}.{3 * l + 1}"]
-            ops.bn_update_running(sums, n_total, M.bn_momentum, rm, rv)
+            y, mean, rstd = ops.bn_fwd_apply(h, sums, n_total, M.bn_eps, gamma, beta, relu=not last, running=(rm, rv, M.bn_momentum))
             self._bn_touched.append(i_bn)
             if save:
                 saved.append((x, h, mean, rstd))
@@ -619,9 +618,8 @@ class _Step:
                 n_total = float(xs[k].shape[0] * self.comm.world)
                 gamma = None if last else f32[f"{pre}.{3 * l + 1}.weight"]
                 beta = None if last else f32[f"{pre}.{3 * l + 1}.bias"]
-                y, mean, rstd = ops.bn_fwd_apply(hs[k], sums[k], n_total, M.bn_eps, gamma, beta, relu=not last)
                 rm, rv, i_bn = M._bn_views[f"{pre}.{3 * l + 1}"]
-                ops.bn_update_running(sums[k], n_total, M.bn_momentum, rm, rv)
+                y, mean, rstd = ops.bn_fwd_apply(hs[k], sums[k], n_total, M.bn_eps, gamma, beta, relu=not last, running=(rm, rv, M.bn_momentum))
                 self._bn_touched.append(i_bn)
                 if save:
                     saved[k].append((xs[k], hs[k], mean, rstd))

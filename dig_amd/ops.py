@@ -716,13 +716,15 @@ def bn_stats(x, sums):
     L.call("dig_bn_stats", L.ptr(x), L.ptr(sums), L.ptr(ws), x.shape[0], x.shape[1], L.stream())
 
 
-def bn_fwd_apply(x, sums, n_total, eps, gamma, beta, relu):
+def bn_fwd_apply(x, sums, n_total, eps, gamma, beta, relu, running=None):
+    """running = (running_mean, running_var, momentum): the running statistics are updated by the same launch (dig_bn_update_running's math)."""
     rows, C = x.shape
     y = torch.empty_like(x)
     mean = torch.empty(C, device=x.device, dtype=F32)
     rstd = torch.empty(C, device=x.device, dtype=F32)
-    L.call("dig_bn_fwd_apply", L.ptr(x), L.ptr(sums), cf(n_total), cf(eps), L.ptr(gamma), L.ptr(beta), int(relu), L.ptr(y),
-           L.ptr(mean), L.ptr(rstd), rows, C, L.stream())
+    rm, rv, mom = running if running is not None else (None, None, 0.0)
+    L.call("dig_bn_fwd_apply_running", L.ptr(x), L.ptr(sums), cf(n_total), cf(eps), L.ptr(gamma), L.ptr(beta), int(relu), L.ptr(y),
+           L.ptr(mean), L.ptr(rstd), cf(mom), L.ptr(rm), L.ptr(rv), rows, C, L.stream())
     return y, mean, rstd
 
 

@@ -194,6 +194,10 @@ int dig_bn_fwd_apply(const void* x, const float* sums, float n_total, float eps,
                      void* y, float* mean_out, float* rstd_out, int rows, int C, hipStream_t stream);
 int dig_bn_update_running(const float* sums, float n_total, float momentum, float* running_mean, float* running_var, int C,
                           hipStream_t stream);
+/* dig_bn_fwd_apply + dig_bn_update_running in one launch (running_mean / running_var both or neither; n_total > 1 with them) */
+int dig_bn_fwd_apply_running(const void* x, const float* sums, float n_total, float eps, const float* gamma, const float* beta, int relu,
+                             void* y, float* mean_out, float* rstd_out, float momentum, float* running_mean, float* running_var, int rows,
+                             int C, hipStream_t stream);
 int dig_bn_bwd_stats(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
                      int relu, float* sums, float* workspace, int rows, int C, hipStream_t stream);
 /* dig_bn_bwd_stats that also accumulates the layer's affine gradients from the LOCAL sums (before any cross-rank reduction of `sums`):

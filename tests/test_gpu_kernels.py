@@ -181,6 +181,11 @@ def test_batchnorm(dev, rows, C, affine, relu):
     assert rel(rm, trm) < 1e-4 and rel(rv, trv) < 1e-4                 # running stats incl. the n/(n-1) factor
     if affine:
         assert rel(s2[1], gf.grad) < 1e-4 and rel(s2[0], bf.grad) < 1e-4
+    # the forward apply updating the running statistics itself (dig_bn_fwd_apply_running): same outputs, same running statistics
+    rm2, rv2 = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    y2, mean2, rstd2 = ops.bn_fwd_apply(x, sums, float(rows), 1e-5, gamma, beta, relu, running=(rm2, rv2, 0.1))
+    assert torch.equal(y2, y) and torch.equal(mean2, mean) and torch.equal(rstd2, rstd)
+    assert rel(rm2, rm) < 1e-6 and rel(rv2, rv) < 1e-6
     # the same launch accumulating the affine gradients from the local sums (dig_bn_bwd_stats_acc): sums unchanged, acc += sums, bit for bit
     s3, db, dg = torch.empty(2, C, device=dev), torch.full((C,), 0.5, device=dev), torch.full((C,), -0.25, device=dev)
     ops.bn_bwd_stats(dy, x, mean, rstd, gamma, beta, relu, s3, db, dg)
