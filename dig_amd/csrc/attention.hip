@@ -112,12 +112,40 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& a, int u) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Store one lane-row of a 32 x 64 result held as two 32x32 MFMA accumulators (lane = row, registers = 4-column groups
+// interleaved between the two lane halves).  v_permlane32_swap trades column groups between lane l and l+32 so that each
+// lane owns 16 contiguous columns per accumulator: 4 x 16-byte stores per row instead of 8 x 8-byte ones.
+__device__ __forceinline__ void store_rows(bf16_t* row, const f32x16 (&acc)[2], int hi) {
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt) {
+    unsigned P[4][2];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      P[g][0] = pack_bf2(acc[dt][g * 4], acc[dt][g * 4 + 1]);
+      P[g][1] = pack_bf2(acc[dt][g * 4 + 2], acc[dt][g * 4 + 3]);
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const auto r0 = __builtin_amdgcn_permlane32_swap(P[0][k], P[2][k], false, false);
+      P[0][k] = r0[0]; P[2][k] = r0[1];
+      const auto r1 = __builtin_amdgcn_permlane32_swap(P[1][k], P[3][k], false, false);
+      P[1][k] = r1[0]; P[3][k] = r1[1];
+    }
+    bf16_t* o = row + dt * 32 + hi * 16;
+    *reinterpret_cast<uint4*>(o) = make_uint4(P[0][0], P[0][1], P[2][0], P[2][1]);
+    *reinterpret_cast<uint4*>(o + 8) = make_uint4(P[1][0], P[1][1], P[3][0], P[3][1]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
 // DROP: attention dropout (Attention.attn_drop, modeling_finetune.py:116 / MultiHeadAttention.attn_drop,
 // transformer_layer.py:271): the probabilities are normalised by the FULL row sum, then masked and scaled by 1/(1-p); the mask
 // comes from dig_drop_keep(key, (query << 16) | key_index, image * H + head) and is regenerated in the backward.
-template <bool DROP>
+// FULL: all eight 32-query blocks exist (self-attention over the 256 tokens): no per-block guards -- the guarded form costs the encoder's
+// launches 3 us of 51 (tools/experiments/attn_fwd_lab.hip)
+template <bool DROP, bool FULL>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
                                                           float* __restrict__ lse, int D, int H, unsigned qkv_bytes, dig_dropout_t drop,
                                                           int nqb) {
@@ -141,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
   for (int ps = 0; ps < 2; ++ps) {
     const int q = (wave * 2 + ps) * 32 + (lane & 31);
     const bf16_t* qp = qkv + (tok0 + q) * ld + h * DH + hi * 8;
-    if (wave * 2 + ps < nqb) {                                           // nqb < 8: only the first nqb 32-query blocks exist (padded cross-attention)
+    if (FULL || wave * 2 + ps < nqb) {                                   // nqb < 8: only the first nqb 32-query blocks exist (padded cross-attention)
 #pragma unroll
       for (int s = 0; s < 4; ++s) qf[ps][s] = *reinterpret_cast<const bf16x8*>(qp + s * 16);
     }
@@ -151,15 +179,26 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
 #pragma unroll
   for (int ps = 0; ps < 2; ++ps) {
     const int qb = wave * 2 + ps;
-    if (qb >= nqb) continue;
+    if (!FULL && qb >= nqb) continue;
     f32x16 sc[8];
 #pragma unroll
-    for (int kt = 0; kt < 8; ++kt) {
+    for (int kt = 0; kt < 8; ++kt)
 #pragma unroll
       for (int e = 0; e < 16; ++e) sc[kt][e] = 0.f;
+    if (!DROP) {
+      // k step outer, key tile inner: consecutive MFMAs go to eight independent accumulators (each accumulator still sums k in order)
 #pragma unroll
       for (int s = 0; s < 4; ++s)
-        sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_direct(Kt, kt * 32, s, lane), qf[ps][s], sc[kt], 0, 0, 0);
+#pragma unroll
+        for (int kt = 0; kt < 8; ++kt)
+          sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_direct(Kt, kt * 32, s, lane), qf[ps][s], sc[kt], 0, 0, 0);
+    } else {
+      // (the dropout form keeps the key tile outer: with the mask arithmetic in the same registers the other order spills)
+#pragma unroll
+      for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+          sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_direct(Kt, kt * 32, s, lane), qf[ps][s], sc[kt], 0, 0, 0);
     }
     float m = -3.0e38f;
 #pragma unroll
@@ -208,43 +247,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int d = dt * 32 + 8 * g + 4 * hi;
-        *reinterpret_cast<uint2*>(op + d) = make_uint2(pack_bf2(oa[dt][g * 4] * inv, oa[dt][g * 4 + 1] * inv),
-                                                       pack_bf2(oa[dt][g * 4 + 2] * inv, oa[dt][g * 4 + 3] * inv));
-      }
+      for (int e = 0; e < 16; ++e) oa[dt][e] *= inv;
+    store_rows(op, oa, hi);                                              // 16-byte stores: a lane pair trades column groups (v_permlane32_swap)
     if (hi == 0) lse[(size_t)blockIdx.x * N_TOK + q] = m + __logf(l);
   }
 }
 
 // ------------------------------------------------------------------------------------------------
 // backward: dqkv = d/d(qkv) given d(ctx); phase A (dQ, a wave owns query blocks), phase B (dK, dV, a wave owns key blocks)
-// ------------------------------------------------------------------------------------------------
-// Store one lane-row of a 32 x 64 result held as two 32x32 MFMA accumulators (lane = row, registers = 4-column groups
-// interleaved between the two lane halves).  v_permlane32_swap trades column groups between lane l and l+32 so that each
-// lane owns 16 contiguous columns per accumulator: 4 x 16-byte stores per row instead of 8 x 8-byte ones.
-__device__ __forceinline__ void store_rows(bf16_t* row, const f32x16 (&acc)[2], int hi) {
-#pragma unroll
-  for (int dt = 0; dt < 2; ++dt) {
-    unsigned P[4][2];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      P[g][0] = pack_bf2(acc[dt][g * 4], acc[dt][g * 4 + 1]);
-      P[g][1] = pack_bf2(acc[dt][g * 4 + 2], acc[dt][g * 4 + 3]);
-    }
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const auto r0 = __builtin_amdgcn_permlane32_swap(P[0][k], P[2][k], false, false);
-      P[0][k] = r0[0]; P[2][k] = r0[1];
-      const auto r1 = __builtin_amdgcn_permlane32_swap(P[1][k], P[3][k], false, false);
-      P[1][k] = r1[0]; P[3][k] = r1[1];
-    }
-    bf16_t* o = row + dt * 32 + hi * 16;
-    *reinterpret_cast<uint4*>(o) = make_uint4(P[0][0], P[0][1], P[2][0], P[2][1]);
-    *reinterpret_cast<uint4*>(o + 8) = make_uint4(P[1][0], P[1][1], P[3][0], P[3][1]);
-  }
-}
-
 // Column sums of a 32 x 64 block held as two 32x32 accumulators (lane & 31 = row; registers = columns): reduce over the 32
 // rows of each lane half with DPP adds (quad xor 1, quad xor 2, half-row mirror, row mirror, row_bcast15 -- no LDS traffic;
 // __shfl_xor lowers to ds_bpermute, 160 LDS round trips per block), then lanes 16 and 48 write their 2 x 16 columns into out[64].
@@ -572,16 +582,19 @@ extern "C" int dig_attn_fwd_dropout(const void* qkv, void* ctx, float* lse, int 
   static bool attr[DIG_MAX_DEVICES] = {};
   const int dev = dig_device();
   if (!attr[dev]) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TILE);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TILE);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TILE);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TILE);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TILE);
     attr[dev] = true;
   }
-  if (drop && drop->thr)
-    hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3(n_img * heads), dim3(256), 2 * TILE, stream, (const bf16_t*)qkv, (bf16_t*)ctx,
-                       lse, embed_dim, heads, (unsigned)qb, *drop, nqb);
-  else
-    hipLaunchKernelGGL(attn_fwd_kernel<false>, dim3(n_img * heads), dim3(256), 2 * TILE, stream, (const bf16_t*)qkv, (bf16_t*)ctx,
-                       lse, embed_dim, heads, (unsigned)qb, dig_dropout_t{}, nqb);
+  const bool dropping = drop && drop->thr;
+  const dig_dropout_t dr = dropping ? *drop : dig_dropout_t{};
+#define DIG_ATTN_FWD_LAUNCH(DR, FU)                                                                                                       \
+  hipLaunchKernelGGL((attn_fwd_kernel<DR, FU>), dim3(n_img * heads), dim3(256), 2 * TILE, stream, (const bf16_t*)qkv, (bf16_t*)ctx, lse, \
+                     embed_dim, heads, (unsigned)qb, dr, nqb)
+  if (dropping) DIG_ATTN_FWD_LAUNCH(true, false);                       // (the unguarded dropout form spills 36 registers: it keeps the guards)
+  else { if (nqb == 8) DIG_ATTN_FWD_LAUNCH(false, true); else DIG_ATTN_FWD_LAUNCH(false, false); }
+#undef DIG_ATTN_FWD_LAUNCH
   return dig_check_launch();
 }
 
