@@ -133,6 +133,109 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_abl(const bf16_t* __restrict_
   }
 }
 
+// ---- K before V: asm LDS-DMA (unseen by the compiler), Q K^T starts when Q and K have landed, V is awaited in front of P V
+__device__ __forceinline__ void lab_dma16b(unsigned lds_dst, unsigned voff, dig_u32x4 rsrc, unsigned soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_dst), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+__global__ __launch_bounds__(256, 2) void attn_fwd_kfirst(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx, float* __restrict__ lse, int D, int H,
+                                                          unsigned qkv_bytes) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* Kt = smem;
+  unsigned char* Vt = smem + TILE;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int img = blockIdx.x / H, h = blockIdx.x - img * H;
+  const int ld = 3 * D;
+  const size_t tok0 = (size_t)img * N_TOK;
+  const int hi = lane >> 5;
+  dig_u32x4 rs;
+  {
+    const unsigned long long a = (unsigned long long)qkv;
+    rs[0] = __builtin_amdgcn_readfirstlane((unsigned)a); rs[1] = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu);
+    rs[2] = __builtin_amdgcn_readfirstlane(qkv_bytes); rs[3] = 0x00020000u;
+  }
+  const unsigned lds0 = (unsigned)(uintptr_t)LDS_PTR(smem);
+  const unsigned base = (unsigned)((tok0 * ld + h * DH) * 2);
+  // Q fragments first (needed first), as ONE asm block of 8 loads so that the compiler's own waits do not order them behind the DMA
+  bf16x8 qf[2][4];
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps) {
+    const int q = (wave * 2 + ps) * 32 + (lane & 31);
+    const bf16_t* qp = qkv + (tok0 + q) * ld + h * DH + hi * 8;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[ps][s] = *reinterpret_cast<const bf16x8*>(qp + s * 16);
+  }
+  const int prow = tid >> 3;
+  const unsigned pvoff = (unsigned)((prow * ld + (((tid & 7) ^ swz(prow)) * 8)) * 2);
+#pragma unroll
+  for (int t = 1; t < 3; ++t)
+#pragma unroll
+    for (int it = 0; it < 8; ++it)
+      lab_dma16b(lds0 + (unsigned)((t - 1) * TILE) + (unsigned)((it * 256 + wave * 64) * 16), pvoff, rs, base + (unsigned)(t * D * 2) + (unsigned)(it * 32 * ld * 2));
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                  // the Q loads and the K tile (8 + 8 of the 24 requests) have landed
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps) {
+    const int qb = wave * 2 + ps;
+    f32x16 sc[8];
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) sc[kt][e] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int kt = 0; kt < 8; ++kt)
+        sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_direct(Kt, kt * 32, s, lane), qf[ps][s], sc[kt], 0, 0, 0);
+    float m = -3.0e38f;
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) m = fmaxf(m, sc[kt][e]);
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float l = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float p = __expf(sc[kt][e] - m);
+        sc[kt][e] = p;
+        l += p;
+      }
+    l += __shfl_xor(l, 32, 64);
+    if (ps == 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // V
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+    f32x16 oa[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) oa[dt][e] = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const bf16x8 pf = pack8(sc[kt], u);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+          oa[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Vt, kt * 32 + u * 16, dt * 32, lane), pf, oa[dt], 0, 0, 0);
+      }
+    }
+    const float inv = 1.0f / l;
+    const int q = qb * 32 + (lane & 31);
+    bf16_t* op = ctx + (tok0 + q) * D + h * DH;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) oa[dt][e] *= inv;
+    store_rows(op, oa, hi);
+    if (hi == 0) lse[(size_t)blockIdx.x * N_TOK + q] = m + __logf(l);
+  }
+}
+
 // ---- the persistent form: 8 waves (a wave = one block of 32 queries), K / V double-buffered in LDS, Q through LDS, the next (image, head)'s
 // three tiles on their way (LDS-DMA from inline asm, unseen by the compiler) while the current one is multiplied
 __device__ __forceinline__ void lab_dma16(unsigned lds_dst, unsigned voff, dig_u32x4 rsrc, unsigned soff) {
@@ -296,6 +399,26 @@ int main() {
   run<24>("no staging / loads, no stores (compute only)", qkv, ctx, lse);
   run<25>("... and no softmax arithmetic (MFMAs only)", qkv, ctx, lse);
   run<30>("... no MFMAs instead (softmax arithmetic only)", qkv, ctx, lse);
+  {
+    unsigned short* ctx3; float* lse3;
+    hipMalloc(&ctx3, nc * 2); hipMalloc(&lse3, (size_t)Bn * H * 256 * 4);
+    hipMemset(ctx3, 0xff, nc * 2);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kfirst), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TILE);
+    dig_attn_fwd(qkv, ctx, lse, Bn, H, D, 0);
+    hipLaunchKernelGGL(attn_fwd_kfirst, dim3(Bn * H), dim3(256), 2 * TILE, 0, qkv, ctx3, lse3, D, H, (unsigned)(nq * 2));
+    hipDeviceSynchronize();
+    std::vector<unsigned short> a(nc), b(nc);
+    hipMemcpy(a.data(), ctx, nc * 2, hipMemcpyDeviceToHost); hipMemcpy(b.data(), ctx3, nc * 2, hipMemcpyDeviceToHost);
+    size_t bad = 0;
+    for (size_t i = 0; i < nc; ++i) bad += a[i] != b[i];
+    printf("K-first form vs product: %zu of %zu context values differ\n", bad, nc);
+    for (int it = 0; it < 200; ++it) hipLaunchKernelGGL(attn_fwd_kfirst, dim3(Bn * H), dim3(256), 2 * TILE, 0, qkv, ctx3, lse3, D, H, (unsigned)(nq * 2));
+    hipEventRecord(e0, 0);
+    for (int it = 0; it < 100; ++it) hipLaunchKernelGGL(attn_fwd_kfirst, dim3(Bn * H), dim3(256), 2 * TILE, 0, qkv, ctx3, lse3, D, H, (unsigned)(nq * 2));
+    hipEventRecord(e1, 0); hipEventSynchronize(e1);
+    hipEventElapsedTime(&ms, e0, e1);
+    printf("K-first form (asm LDS-DMA, Q K^T starts before V has landed): %7.1f us\n", ms / 100 * 1e3);
+  }
   {
     // the persistent form: results against the product kernel, then time
     unsigned short* ctx2; float* lse2;
