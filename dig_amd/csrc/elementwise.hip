@@ -55,6 +55,86 @@ __global__ void patch_embed_fwd_kernel(const float* __restrict__ img, const floa
   }
 }
 
+// The same on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32: exact f32 products, f32 accumulation = an fmaf chain): the thread-per-channel
+// form above spends one LDS operand read per FMA and runs at a fifth of the fp32 rate (37 us per 128-image view; 4 launches per step at the
+// head of both encoders).  A wave owns 32 tokens; its 48 patch values per token sit in registers (lane = token, 24 values per lane half: the
+// k pairs are chosen so that a lane reads 12 aligned float2), the weights are staged once per workgroup into LDS as Wt[k'][D] and feed the
+// A operand; D / 32 column blocks x 24 MFMAs per token tile.  Swapped roles (A = weights, B = patches) leave a lane with ITS token's
+// channels in registers: bias / mask token / position are added in that layout and stored as 8-byte bf16 groups.
+// k' = 2 j + h with j = c * 8 + p1 * 2 + q  <->  conv weight index (c, p1, p2 = 2 h + q).
+__global__ __launch_bounds__(512) void patch_embed_fwd_mfma_kernel(const float* __restrict__ img, const float* __restrict__ W,
+                                                                   const float* __restrict__ bias, const unsigned char* __restrict__ mask,
+                                                                   const float* __restrict__ mask_token, const float* __restrict__ pos,
+                                                                   bf16_t* __restrict__ out, int n_tok, int D, int gh, int gw, int Himg, int Wimg) {
+  extern __shared__ __attribute__((aligned(16))) float Wt[];           // [48][D + 1] (odd pitch: the transposing fill is conflict-free)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hi = lane >> 5, tl = lane & 31;
+  const int WP = D + 1;
+  if (tid < 480) {                                                     // 10 weight rows per pass, a thread keeps its k (and k')
+    const int k = tid % 48, d0 = tid / 48;
+    const int c = k >> 4, p1 = (k >> 2) & 3, p2 = k & 3;
+    const int kk = 2 * (c * 8 + p1 * 2 + (p2 & 1)) + (p2 >> 1);
+    for (int d = d0; d < D; d += 10) Wt[kk * WP + d] = W[d * 48 + k];
+  }
+  __syncthreads();
+  const int ntok_img = gh * gw;
+  const int n_tiles = (n_tok + 31) / 32;
+  // 8 waves: a pair of waves shares a token tile and splits the column blocks (two waves per SIMD: one's epilogue loads / stores under
+  // the other's MFMA chain)
+  const int half = wave & 1, ncb = D / 32, cb0 = half * ((ncb + 1) / 2), cb1 = half ? ncb : (ncb + 1) / 2;
+  for (int tile = blockIdx.x * 4 + (wave >> 1); tile < n_tiles; tile += gridDim.x * 4) {
+    const int t = tile * 32 + tl;
+    const bool tok_ok = t < n_tok;
+    const int tc = tok_ok ? t : n_tok - 1;
+    const int b = tc / ntok_img, n = tc - b * ntok_img;
+    const int ph = n / gw, pw = n - ph * gw;
+    float pv[24];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int p1 = 0; p1 < 4; ++p1) {
+        const float2 v = *reinterpret_cast<const float2*>(img + (((size_t)b * 3 + c) * Himg + ph * 4 + p1) * Wimg + pw * 4 + 2 * hi);
+        pv[c * 8 + p1 * 2] = v.x; pv[c * 8 + p1 * 2 + 1] = v.y;
+      }
+    const bool masked = mask && mask[tc];
+    const float* posr = pos + (size_t)n * D;
+    bf16_t* orow = out + (size_t)tc * D;
+    for (int cb = cb0; cb < cb1; ++cb) {
+      f32x16 acc;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+      const int ch = cb * 32 + 16 * hi;
+      float4 b4[4], m4[4], p4[4];                                          // the epilogue's operands: requested in front of the MFMA chain
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        b4[g] = *reinterpret_cast<const float4*>(bias + ch + 4 * g); m4[g] = *reinterpret_cast<const float4*>(mask_token + ch + 4 * g);
+        p4[g] = *reinterpret_cast<const float4*>(posr + ch + 4 * g);
+      }
+      const float* wl = Wt + hi * WP + cb * 32 + tl;
+#pragma unroll
+      for (int j = 0; j < 24; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wl[2 * j * WP], pv[j], acc, 0, 0, 0);
+      // acc: lane = token, registers = channels 8 g + 4 hi + (0..3); after the swaps lane (token, hi) owns channels 16 hi .. 16 hi + 15
+      float x[16];
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const auto s0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[qd]), __float_as_uint(acc[8 + qd]), false, false);
+        const auto s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[4 + qd]), __float_as_uint(acc[12 + qd]), false, false);
+        x[qd] = __uint_as_float(s0[0]); x[4 + qd] = __uint_as_float(s0[1]);
+        x[8 + qd] = __uint_as_float(s1[0]); x[12 + qd] = __uint_as_float(s1[1]);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        x[4 * g] = (masked ? m4[g].x : x[4 * g] + b4[g].x) + p4[g].x; x[4 * g + 1] = (masked ? m4[g].y : x[4 * g + 1] + b4[g].y) + p4[g].y;
+        x[4 * g + 2] = (masked ? m4[g].z : x[4 * g + 2] + b4[g].z) + p4[g].z; x[4 * g + 3] = (masked ? m4[g].w : x[4 * g + 3] + b4[g].w) + p4[g].w;
+      }
+      if (tok_ok) {
+        *reinterpret_cast<uint4*>(orow + ch) = make_uint4(pack_bf2(x[0], x[1]), pack_bf2(x[2], x[3]), pack_bf2(x[4], x[5]), pack_bf2(x[6], x[7]));
+        *reinterpret_cast<uint4*>(orow + ch + 8) = make_uint4(pack_bf2(x[8], x[9]), pack_bf2(x[10], x[11]), pack_bf2(x[12], x[13]), pack_bf2(x[14], x[15]));
+      }
+    }
+  }
+}
+
 // grid: chunks of tokens; block: D threads.  dW[d][k] += sum_t (1-m_t) dy[t,d] patch[t,k]; dbias[d]; dmask_token[d]
 __global__ void patch_embed_bwd_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ img,
                                        const unsigned char* __restrict__ mask, float* __restrict__ dW, float* __restrict__ dbias,
@@ -452,6 +532,20 @@ extern "C" int dig_patch_embed_fwd(const float* img, const float* W, const float
                                    hipStream_t stream) {
   if (!img || !W || !bias || !mask_token || !pos || !out || n_img <= 0 || D <= 0 || D > 1024 || (D & 63)) return DIG_ERR_ARG;
   const int n_tok = n_img * gh * gw;
+  if ((D & 31) == 0 && 48 * D * 4 <= 96 * 1024 && aligned16(img) && aligned16(bias) && aligned16(mask_token) && aligned16(pos) && aligned16(out)) {
+    // fp32 MFMA form (exact f32 arithmetic, another summation order than the thread-per-channel kernel: both add k in a fixed order)
+    static bool attr[DIG_MAX_DEVICES] = {};
+    const int dev = dig_device();
+    if (!attr[dev]) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(patch_embed_fwd_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      attr[dev] = true;
+    }
+    const int tiles = (n_tok + 31) / 32;
+    const int grid = std::min(256, (tiles + 3) / 4);
+    hipLaunchKernelGGL(patch_embed_fwd_mfma_kernel, dim3(grid), dim3(512), 48 * (D + 1) * 4, stream, img, W, bias, mask, mask_token, pos, (bf16_t*)out,
+                       n_tok, D, gh, gw, gh * 4, gw * 4);
+    return dig_check_launch();
+  }
   hipLaunchKernelGGL(patch_embed_fwd_kernel, dim3((n_tok + PE_TOK - 1) / PE_TOK), dim3(D), 0, stream, img, W, bias, mask,
                      mask_token, pos, (bf16_t*)out, n_tok, D, gh, gw, gh * 4, gw * 4);
   return dig_check_launch();
