@@ -749,6 +749,11 @@ int dig_mim_target(const float* img, const int* idx, float* target, int M, int g
   return DIG_OK;
 }
 
+int dig_mse_fwd_bwd(const float* pred, int ld_pred, const float* target, int M, int C, float gscale, float* loss, void* dpred_, int ld_dpred, hipStream_t);
+int dig_mse_fwd_bwd_ws(const float* pred, int ld_pred, const float* target, int M, int C, float gscale, float* loss, void* dpred, int ld_dpred,
+                       float*, hipStream_t st) {
+  return dig_mse_fwd_bwd(pred, ld_pred, target, M, C, gscale, loss, dpred, ld_dpred, st);
+}
 int dig_mse_fwd_bwd(const float* pred, int ld_pred, const float* target, int M, int C, float gscale, float* loss, void* dpred_, int ld_dpred,
                     hipStream_t) {
   if (!pred || !target || M <= 0 || C <= 0 || ld_pred < C || (dpred_ && ld_dpred < C)) return DIG_ERR_ARG;
@@ -808,6 +813,10 @@ int dig_sgemm(const float* A, const float* B, float* C, int I, int J, int R, int
   return DIG_OK;
 }
 
+int dig_ce_rows(float* logits, int n, int m, int label_offset, float gscale, float* out3, hipStream_t);
+int dig_ce_rows_ws(float* logits, int n, int m, int label_offset, float gscale, float* out3, float*, hipStream_t st) {
+  return dig_ce_rows(logits, n, m, label_offset, gscale, out3, st);         // (the host build sums in row order anyway)
+}
 int dig_infonce_finish(const float* stats6, float loss_scale, float acc_scale, float* contra, float* accs4, hipStream_t) {
   if (!stats6 || !contra || !accs4) return DIG_ERR_ARG;
   contra[0] = (stats6[0] + stats6[3]) * loss_scale;

@@ -214,6 +214,41 @@ static inline void dig_launch(K kernel, dim3 grid, dim3 block, unsigned lds, hip
   }
 }
 
+// Deterministic grid-wide sum without a second launch: every workgroup leaves its NV partial values in ws[1 + NV * block + v], then takes a
+// ticket (ws[0], an integer: the only atomic); the workgroup that draws the last ticket sums all partials IN BLOCK ORDER (a fixed tree over
+// its 256 threads) and returns true on its thread 0 with the totals in tot[]; it also resets the ticket for the next launch.  The fences
+// make the partials of the other XCDs' L2s visible (release before the ticket, acquire after it).  ws: 1 + NV * gridDim.x floats, zero once.
+template <int NV>
+__device__ __forceinline__ bool dig_grid_sum_last(float* __restrict__ ws, const float (&mine)[NV], float (&tot)[NV], float* red /* [256] LDS */) {
+  __shared__ unsigned last_flag;
+  const unsigned nblk = gridDim.x * gridDim.y * gridDim.z, blk = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) ws[1 + NV * blk + v] = mine[v];
+    __threadfence();
+    last_flag = (atomicAdd(reinterpret_cast<unsigned*>(ws), 1u) == nblk - 1) ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!last_flag) return false;
+  __threadfence();
+  bool ret = false;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    float a = 0.f;
+    for (unsigned b = threadIdx.x; b < nblk; b += blockDim.x) a += __hip_atomic_load(ws + 1 + NV * b + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (unsigned st = blockDim.x >> 1; st > 0; st >>= 1) {
+      if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) { tot[v] = red[0]; ret = true; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) reinterpret_cast<unsigned*>(ws)[0] = 0u;
+  return ret;
+}
+
 static inline int dig_check_launch() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? DIG_OK : DIG_ERR_LAUNCH;

@@ -301,7 +301,8 @@ __global__ void mim_target_kernel(const float* __restrict__ img, const int* __re
 
 // loss += sum (pred - target)^2 * inv_count ;  dpred = gscale * 2 * (pred - target) * inv_count (bf16, ld_d, pad cols zeroed)
 __global__ void mse_fwd_bwd_kernel(const float* __restrict__ pred, int ld_p, const float* __restrict__ target, int M, int C,
-                                   float inv_count, float gscale, float* __restrict__ loss, bf16_t* __restrict__ dpred, int ld_d) {
+                                   float inv_count, float gscale, float* __restrict__ loss, bf16_t* __restrict__ dpred, int ld_d,
+                                   float* __restrict__ ws) {
   float acc = 0.f;
   const int total = M * ld_d;
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
@@ -318,7 +319,17 @@ __global__ void mse_fwd_bwd_kernel(const float* __restrict__ pred, int ld_p, con
   __shared__ float part[4];
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0 && loss) atomicAdd(loss, (part[0] + part[1] + part[2] + part[3]) * inv_count);   // one atomic per block
+  if (!loss) return;
+  const float bs = (part[0] + part[1] + part[2] + part[3]) * inv_count;
+  if (!ws) {
+    if (threadIdx.x == 0) atomicAdd(loss, bs);                                                         // one atomic per block
+    return;
+  }
+  // with a workspace: the block sums are added in block order by the last workgroup to finish (bit-reproducible loss value)
+  __shared__ float red[256];
+  const float mine[1] = {bs};
+  float tot[1];
+  if (dig_grid_sum_last<1>(ws, mine, tot, red)) loss[0] += tot[0];
 }
 
 __global__ void add_bf16_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, bf16_t* __restrict__ o, size_t n8) {
@@ -639,14 +650,18 @@ extern "C" int dig_mim_target(const float* img, const int* idx, float* target, i
   return dig_check_launch();
 }
 
-extern "C" int dig_mse_fwd_bwd(const float* pred, int ld_pred, const float* target, int M, int C, float gscale, float* loss,
-                               void* dpred, int ld_dpred, hipStream_t stream) {
+extern "C" int dig_mse_fwd_bwd_ws(const float* pred, int ld_pred, const float* target, int M, int C, float gscale, float* loss,
+                                  void* dpred, int ld_dpred, float* workspace, hipStream_t stream) {
   if (!pred || !target || M <= 0 || C <= 0 || ld_pred < C || (dpred && ld_dpred < C)) return DIG_ERR_ARG;
   const int ldd = dpred ? ld_dpred : C;
   const int total = M * ldd;
   hipLaunchKernelGGL(mse_fwd_bwd_kernel, dim3(std::min(256, (total + 255) / 256)), dim3(256), 0, stream, pred, ld_pred, target, M, C,
-                     1.0f / ((float)M * C), gscale, loss, (bf16_t*)dpred, ldd);
+                     1.0f / ((float)M * C), gscale, loss, (bf16_t*)dpred, ldd, workspace);
   return dig_check_launch();
+}
+extern "C" int dig_mse_fwd_bwd(const float* pred, int ld_pred, const float* target, int M, int C, float gscale, float* loss,
+                               void* dpred, int ld_dpred, hipStream_t stream) {
+  return dig_mse_fwd_bwd_ws(pred, ld_pred, target, M, C, gscale, loss, dpred, ld_dpred, nullptr, stream);
 }
 
 extern "C" int dig_add_bf16(const void* a, const void* b, void* out, long long n, hipStream_t stream) {

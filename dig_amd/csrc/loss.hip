@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const float* __restrict__ A,
 // Per row i of logits [n, m]: lse, loss_i = lse - logit[label], rank of the label among the row, and (in place)
 // dlogits = gscale * (softmax - onehot).  out[0] += sum_i loss_i, out[1] += #top1, out[2] += #top5.
 __global__ __launch_bounds__(256) void ce_rows_kernel(float* __restrict__ logits, int n, int m, int label_offset, float gscale,
-                                                      float* __restrict__ out) {
+                                                      float* __restrict__ out, float* __restrict__ ws) {
   __shared__ float red[8];
   const int i = blockIdx.x;
   float* row = logits + (size_t)i * m;
@@ -111,11 +111,19 @@ __global__ __launch_bounds__(256) void ce_rows_kernel(float* __restrict__ logits
     const float p = __expf(row[j] - mx) * inv;
     row[j] = gscale * (p - (j == label ? 1.f : 0.f));
   }
-  if (threadIdx.x == 0) {
-    atomicAdd(out, lse - zl);
-    if (gt < 0.5f) atomicAdd(out + 1, 1.f);
-    if (gt < 4.5f) atomicAdd(out + 2, 1.f);
+  if (!ws) {
+    if (threadIdx.x == 0) {
+      atomicAdd(out, lse - zl);
+      if (gt < 0.5f) atomicAdd(out + 1, 1.f);
+      if (gt < 4.5f) atomicAdd(out + 2, 1.f);
+    }
+    return;
   }
+  // with a workspace: the rows' values are added in row order by the last workgroup to finish (bit-reproducible loss value)
+  __shared__ float red2[256];
+  const float mine[3] = {lse - zl, gt < 0.5f ? 1.f : 0.f, gt < 4.5f ? 1.f : 0.f};
+  float tot[3];
+  if (dig_grid_sum_last<3>(ws, mine, tot, red2)) { out[0] += tot[0]; out[1] += tot[1]; out[2] += tot[2]; }
 }
 
 // The scalar tail of the InfoNCE pair (modeling_pretrain_moco_mim_ori.py:444-461, 2 T * mean CE of both directions) and of a step's log line
@@ -181,8 +189,11 @@ extern "C" int dig_sgemm(const float* A, const float* B, float* C, int I, int J,
   return dig_check_launch();
 }
 
-extern "C" int dig_ce_rows(float* logits, int n, int m, int label_offset, float gscale, float* out3, hipStream_t stream) {
+extern "C" int dig_ce_rows_ws(float* logits, int n, int m, int label_offset, float gscale, float* out3, float* workspace, hipStream_t stream) {
   if (!logits || !out3 || n <= 0 || m <= 0 || label_offset < 0 || label_offset + n > m) return DIG_ERR_ARG;
-  hipLaunchKernelGGL(ce_rows_kernel, dim3(n), dim3(256), 0, stream, logits, n, m, label_offset, gscale, out3);
+  hipLaunchKernelGGL(ce_rows_kernel, dim3(n), dim3(256), 0, stream, logits, n, m, label_offset, gscale, out3, workspace);
   return dig_check_launch();
+}
+extern "C" int dig_ce_rows(float* logits, int n, int m, int label_offset, float gscale, float* out3, hipStream_t stream) {
+  return dig_ce_rows_ws(logits, n, m, label_offset, gscale, out3, nullptr, stream);
 }

@@ -692,8 +692,22 @@ def mim_target(img, idx, M, gh, gw, normalize=False):
     return tgt
 
 
+_loss_ws = {}
+
+
+def _loss_workspace(dev, tag, numel):
+    """Zero-initialised fp32 scratch of the deterministic loss reductions (the kernels leave its ticket word at zero)."""
+    key = (str(dev), tag, _stream_id(dev) if dev.type == "cuda" else 0)
+    w = _loss_ws.get(key)
+    if w is None or w.numel() < numel:
+        w = _loss_ws[key] = torch.zeros(max(numel, 4096), device=dev, dtype=F32)
+    return w
+
+
 def mse_fwd_bwd(pred, ld_pred, target, M, C, gscale, loss, dpred, ld_dpred):
-    L.call("dig_mse_fwd_bwd", L.ptr(pred), ld_pred, L.ptr(target), M, C, cf(gscale), L.ptr(loss), L.ptr(dpred), ld_dpred, L.stream())
+    """loss += mean((pred - target)^2) with the block sums added in block order (no floating-point atomics: the logged value is bit-stable)."""
+    L.call("dig_mse_fwd_bwd_ws", L.ptr(pred), ld_pred, L.ptr(target), M, C, cf(gscale), L.ptr(loss), L.ptr(dpred), ld_dpred,
+           L.ptr(_loss_workspace(pred.device, "mse", 257)), L.stream())
 
 
 def add_bf16(a, b, out):
@@ -785,7 +799,10 @@ def sgemm(A, B, C, I, J, R, trans_b, alpha):
 
 
 def ce_rows(logits, label_offset, gscale, out3):
-    L.call("dig_ce_rows", L.ptr(logits), logits.shape[0], logits.shape[1], label_offset, cf(gscale), L.ptr(out3), L.stream())
+    """The rows' loss / hit counts are added in row order (no floating-point atomics)."""
+    n = logits.shape[0]
+    L.call("dig_ce_rows_ws", L.ptr(logits), n, logits.shape[1], label_offset, cf(gscale), L.ptr(out3),
+           L.ptr(_loss_workspace(logits.device, "ce", 1 + 3 * n)), L.stream())
 
 
 def infonce_finish(stats, loss_scale, acc_scale):

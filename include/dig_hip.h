@@ -259,6 +259,13 @@ int dig_l2norm_bwd(const float* dy, const float* y, const float* inv_norm, float
 int dig_sgemm(const float* A, const float* B, float* C, int I, int J, int R, int lda, int ldb, int ldc, int trans_b, float alpha,
               int r_splits /* >1: C is [r_splits][I][ldc] partial slabs over R, summed by dig_reduce_partials */, hipStream_t stream);
 int dig_ce_rows(float* logits, int n, int m, int label_offset, float gscale, float* out3, hipStream_t stream);
+/* The two loss reductions with a caller-owned workspace instead of floating-point atomics: the partial sums (one per workgroup / row) are
+ * added in a fixed order by the last workgroup to finish, so the logged loss values are bit-reproducible (gradients never depended on
+ * them).  workspace: 257 floats (dig_mse_fwd_bwd_ws) / 1 + 3 n floats (dig_ce_rows_ws), ZERO before the first use; a launch leaves
+ * workspace[0] at zero again, so launches on one stream can share it.  NULL workspace = the atomic forms above. */
+int dig_mse_fwd_bwd_ws(const float* pred, int ld_pred, const float* target, int M, int C, float gscale, float* loss, void* dpred,
+                       int ld_dpred, float* workspace, hipStream_t stream);
+int dig_ce_rows_ws(float* logits, int n, int m, int label_offset, float gscale, float* out3, float* workspace, hipStream_t stream);
 /* The scalar tails, one launch each.  dig_infonce_finish: stats6 = the two out3 triples of the q1/k2 and q2/k1 dig_ce_rows launches ->
  * contra[0] = (stats6[0] + stats6[3]) * loss_scale (2 T / n: modeling_pretrain_moco_mim_ori.py:459-461), accs4 = (q1_acc1, q1_acc5, q2_acc1,
  * q2_acc5) = the hit counts * acc_scale.  dig_step_meters: the ten values a step logs (engine_for_pretraining_moco.py:146-183) as one

@@ -811,3 +811,34 @@ def test_mask_views_u8(dev, dtype, keep):
     out = ops.mask_views_u8(src, keep)
     assert out is not None and out.dtype == torch.uint8 and torch.equal(out, ref)
     assert ops.mask_views_u8(src.to(torch.float16), keep) is None                                 # other element types: the caller's torch path
+
+
+def test_loss_reductions_with_a_workspace_are_fixed_order(dev):
+    """dig_mse_fwd_bwd_ws / dig_ce_rows_ws: the same values as the atomic forms up to summation order, the same BITS from launch to launch,
+    the ticket word left at zero (a second launch on the same workspace gives the same result), += into the output."""
+    from dig_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(5)
+    M, C = 4099, 48
+    pred = torch.randn(M, 64, generator=g).to(dev); target = torch.randn(M, C, generator=g).to(dev)
+    outs = []
+    for _ in range(3):
+        loss = torch.full((1,), 0.5, device=dev)
+        dpred = torch.empty(M, C, device=dev, dtype=torch.bfloat16)
+        ops.mse_fwd_bwd(pred, 64, target, M, C, 1.0, loss, dpred, C)
+        outs.append(loss.clone())
+    ref = ((pred[:, :C] - target) ** 2).mean()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+    assert abs(float(outs[0]) - 0.5 - float(ref)) < 1e-5 * float(ref)
+    n, m = 512, 1024
+    logits0 = (torch.randn(n, m, generator=g) * 3).to(dev)
+    res = []
+    for _ in range(3):
+        lg = logits0.clone(); out3 = torch.zeros(3, device=dev)
+        ops.ce_rows(lg, 128, 0.25, out3)
+        res.append((out3.clone(), lg))
+    assert all(torch.equal(res[0][0], r[0]) and torch.equal(res[0][1], r[1]) for r in res[1:])
+    lbl = torch.arange(n, device=dev) + 128
+    ref_loss = torch.nn.functional.cross_entropy(logits0, lbl, reduction="sum")
+    assert abs(float(res[0][0][0]) - float(ref_loss)) < 1e-5 * float(ref_loss)
+    top5 = logits0.topk(5, dim=1).indices
+    assert float(res[0][0][1]) == float((top5[:, 0] == lbl).sum()) and float(res[0][0][2]) == float((top5 == lbl[:, None]).any(1).sum())
