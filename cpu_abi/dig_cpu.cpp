@@ -180,6 +180,16 @@ int dig_gemm_bf16(const void* A, const void* B, void* C, int I, int J, int R, in
                                act, splits, a_rows, b_rows, bk, colsum_partials, nullptr, stream);
 }
 
+int dig_reduce_partials_bf16(const float* partials, int splits, long long n, void* out_, hipStream_t) {
+  if (!partials || !out_ || splits < 1 || n <= 0 || (n & 3)) return DIG_ERR_ARG;
+  bf16_t* out = (bf16_t*)out_;
+  for (long long e = 0; e < n; ++e) {
+    float a = 0.f;
+    for (int s = 0; s < splits; ++s) a += partials[(long long)s * n + e];
+    out[e] = f2bf(a);
+  }
+  return DIG_OK;
+}
 int dig_reduce_partials(const float* partials, int splits, long long n, float* out, int accumulate, hipStream_t) {
   if (!partials || !out || splits < 1 || n <= 0 || (n & 3)) return DIG_ERR_ARG;
   if (!aligned16(partials) || !aligned16(out)) return DIG_ERR_ALIGN;

@@ -897,6 +897,18 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
   }
 }
 
+// out_bf16[e] = bf16(sum_s part[s][e]): the combine of a split-R forward layer / data gradient (fixed order)
+__global__ __launch_bounds__(256) void reduce_partials_bf16_kernel(const float* __restrict__ part, int splits, long long n4, bf16_t* __restrict__ out) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < splits; ++s) {
+      const float4 b = reinterpret_cast<const float4*>(part)[(long long)s * n4 + i];
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    reinterpret_cast<uint2*>(out)[i] = make_uint2(pack_bf2(a.x, a.y), pack_bf2(a.z, a.w));
+  }
+}
+
 // the same for up to DIG_REDUCE_MAX_SEGS slab sets in ONE launch (the four weight gradients of an encoder block): blocks
 // [first[k], first[k+1]) walk segment k
 struct ReduceSegs {
@@ -1022,7 +1034,9 @@ extern "C" int dig_gemm_bf16_dropout(const void* A, const void* B, void* C, int 
   }
   DIG_GEMM_WCASE(false, false, 0)
   DIG_GEMM_WCASE(false, false, 1)
-  DIG_GEMM_WCASE(false, true, 0)
+  DIG_GEMM_WCASE(false, false, 2)                                      // split-R slabs of a forward layer / a data gradient: the few-row,
+  DIG_GEMM_WCASE(false, true, 0)                                       // narrow-output, long-K layers of the BatchNorm-MLP heads
+  DIG_GEMM_WCASE(false, true, 2)                                       // (dig_reduce_partials_bf16 combines them)
   DIG_GEMM_WCASE(true, true, 2)
 #undef DIG_GEMM_WCASE
 #define DIG_GEMM_CASE(ta, tb, o)                                                \
@@ -1069,6 +1083,15 @@ extern "C" int dig_reduce_partials_multi(const dig_reduce_seg_t* segs, int n_seg
   }
   a.first[n_segs] = blocks;
   hipLaunchKernelGGL(reduce_partials_multi_kernel, dim3(blocks), dim3(256), 0, stream, a);
+  return dig_check_launch();
+}
+
+extern "C" int dig_reduce_partials_bf16(const float* partials, int splits, long long n, void* out, hipStream_t stream) {
+  if (!partials || !out || splits < 1 || n <= 0 || (n & 3)) return DIG_ERR_ARG;
+  if (!aligned16(partials) || (((uintptr_t)out) & 7u)) return DIG_ERR_ALIGN;
+  const long long n4 = n / 4;
+  hipLaunchKernelGGL(reduce_partials_bf16_kernel, dim3((unsigned)std::min<long long>(2048, (n4 + 255) / 256)), dim3(256), 0, stream, partials,
+                     splits, n4, (bf16_t*)out);
   return dig_check_launch();
 }
 

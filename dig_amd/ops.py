@@ -82,8 +82,33 @@ def fwd_tile_code(rows, out_dim, K, *, act=0, has_resid=False, drop=None, out_ki
     return bk
 
 
+NARROW_SPLIT = os.environ.get("DIG_NARROW_SPLIT", "1") != "0"
+
+
+def narrow_splits(rows, out_cols, K):
+    """R-slices for a few-row, narrow-output, long-K layer (the 4096 -> 256 / 384 layers of the BatchNorm-MLP heads and their data
+    gradients: 1024 x 256 outputs are 32 workgroups walking 64 K-steps; eight slices of 512 make them 256 workgroups + a 1 MB combine:
+    67-73 us in the step -> ~20), or 1."""
+    if NARROW_SPLIT and rows <= 2048 and out_cols <= 512 and K >= 2048 and K % 512 == 0 and (rows * out_cols) % 4 == 0:
+        return L.lib().dig_gemm_effective_splits(int(K), K // 512)
+    return 1
+
+
+def _split_gemm_bf16(A, B, I, J, R, tb, bk, sp, out):
+    ws = _workspace(A.device, sp * I * J)
+    gemm(A, B, I, J, R, tb=tb, out=ws, out_kind=OUT_F32_PARTIAL, splits=sp, ldc=J, bk=bk)
+    if out is None:
+        out = torch.empty((I, J), device=A.device, dtype=BF16)
+    L.call("dig_reduce_partials_bf16", L.ptr(ws), sp, cll(I * J), L.ptr(out), L.stream())
+    return out
+
+
 def linear_fwd(x, w, *, bias=None, resid=None, act=0, pre=None, alpha=1.0, alpha_cols=0, out=None, out_kind=OUT_BF16, drop=None):
     """y[rows,out] = x[rows,in] @ w[out,in]^T (+bias)(gelu)(+resid)."""
+    if bias is None and resid is None and not act and pre is None and alpha == 1.0 and drop is None and out_kind == OUT_BF16 and (out is None or out.is_contiguous()):
+        sp = narrow_splits(x.shape[0], w.shape[0], w.shape[1])
+        if sp > 1:
+            return _split_gemm_bf16(x, w, x.shape[0], w.shape[0], w.shape[1], False, 212, sp, out)
     bk = fwd_tile_code(x.shape[0], w.shape[0], w.shape[1], act=act, has_resid=resid is not None, drop=drop, out_kind=out_kind)
     return gemm(x, w, x.shape[0], w.shape[0], w.shape[1], bias=bias, resid=resid, act=act, pre=pre, alpha=alpha,
                 alpha_cols=alpha_cols, out=out, out_kind=out_kind, bk=bk, drop=drop)
@@ -203,6 +228,10 @@ def linear_dgrad(dy, w, out=None, gelu_pre=None, colsum=False, drop=None):
     # (The 256x192 tile is 8-20 % faster for the tall 384-wide dgrads alone -- tools/experiments/gpu_dgrad_tile_probe.py -- but not in
     #  the step: 25.69 vs 25.77 ms over three A/B pairs; the small 128x128 workgroups share the CUs better with the weight-gradient stream.)
     rows, J = dy.shape[0], w.shape[1]
+    if drop is None and (out is None or out.is_contiguous()):
+        sp = narrow_splits(rows, J, w.shape[0])
+        if sp > 1:
+            return _split_gemm_bf16(dy, w, rows, J, w.shape[0], True, 221, sp, out)
     return gemm(dy, w, rows, J, w.shape[0], tb=True, out=out, bk=dgrad_tile_code(rows, J, drop))
 
 

@@ -65,6 +65,10 @@ int dig_gemm_bf16(const void* A, const void* B, void* C, int I, int J, int R, in
 int dig_gemm_effective_splits(int R, int splits);
 /* out[e] (+)= sum_s partials[s][e], e < n  (deterministic split-R combine; accumulate=1 adds into the gradient arena) */
 int dig_reduce_partials(const float* partials, int splits, long long n, float* out, int accumulate, hipStream_t stream);
+/* out_bf16[e] = bf16(sum_s partials[s][e]), e < n (n % 4 == 0): the combine of a split-R FORWARD layer or DATA gradient (dig_gemm_bf16 with
+ * out_kind 2 and non-transposed A: tile codes 212 / 221) -- the few-row, narrow-output, long-K layers of the BatchNorm-MLP heads
+ * (1024 x 256 outputs over K = 4096: 32 workgroups walking 64 K-steps each become 256) */
+int dig_reduce_partials_bf16(const float* partials, int splits, long long n, void* out, hipStream_t stream);
 /* out += sum_s partials[s] for up to DIG_REDUCE_MAX_SEGS slab sets in one launch (the weight gradients of one encoder block:
  * 4 reduce launches -> 1; same fixed summation order per element as dig_reduce_partials with accumulate = 1).  `segs` is host memory. */
 #define DIG_REDUCE_MAX_SEGS 8

@@ -842,3 +842,31 @@ def test_loss_reductions_with_a_workspace_are_fixed_order(dev):
     assert abs(float(res[0][0][0]) - float(ref_loss)) < 1e-5 * float(ref_loss)
     top5 = logits0.topk(5, dim=1).indices
     assert float(res[0][0][1]) == float((top5[:, 0] == lbl).sum()) and float(res[0][0][2]) == float((top5 == lbl[:, None]).any(1).sum())
+
+
+@pytest.mark.parametrize("rows,out_dim,K", [(1024, 256, 4096), (1024, 384, 4096), (512, 256, 2048)])
+def test_narrow_long_k_layers_in_r_slices(dev, rows, out_dim, K):
+    """The R-sliced form of the heads' few-row, narrow-output, long-K layers (dig_gemm_bf16 out_kind 2 with non-transposed A +
+    dig_reduce_partials_bf16) against the one-launch form and fp32 torch: forward y = x W^T and data gradient dx = dy W; exact on
+    small-integer operands."""
+    from dig_amd import ops
+    cpu_limit(dev, 4.0 * rows * out_dim * K, 4e10)
+    assert ops.narrow_splits(rows, out_dim, K) == K // 512 and ops.narrow_splits(65536, out_dim, K) == 1 and ops.narrow_splits(rows, 4096, K) == 1
+    g = torch.Generator(device="cpu").manual_seed(rows + K)
+    x = (torch.randn(rows, K, generator=g) * 0.5).bfloat16().to(dev)
+    w = (torch.randn(out_dim, K, generator=g) * 0.05).bfloat16().to(dev)
+    y = ops.linear_fwd(x, w)
+    ops.NARROW_SPLIT = False
+    try:
+        y1 = ops.linear_fwd(x, w)
+    finally:
+        ops.NARROW_SPLIT = True
+    ref = x.float() @ w.float().t()
+    assert rel(y, ref) < 5e-3 and rel(y, y1) < 5e-3
+    dy = (torch.randn(rows, K, generator=g) * 0.5).bfloat16().to(dev)
+    w2 = (torch.randn(K, out_dim, generator=g) * 0.05).bfloat16().to(dev)          # a layer out_dim -> K: its data gradient is [rows, K] x [K, out_dim]
+    dx = ops.linear_dgrad(dy, w2)
+    assert rel(dx, dy.float() @ w2.float()) < 5e-3
+    xi = torch.randint(-2, 3, (rows, K), generator=g).bfloat16().to(dev)
+    wi = torch.randint(-1, 2, (out_dim, K), generator=g).bfloat16().to(dev)
+    assert torch.equal(ops.linear_fwd(xi, wi).float(), (xi.float() @ wi.float().t()).bfloat16().float())
