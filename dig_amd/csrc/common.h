@@ -231,22 +231,30 @@ __device__ __forceinline__ bool dig_grid_sum_last(float* __restrict__ ws, const 
   __syncthreads();
   if (!last_flag) return false;
   __threadfence();
-  bool ret = false;
+  // thread t adds blocks t, t + T, ... in order; a wave folds its 64 sums with a fixed butterfly; thread 0 adds the waves in order
+  float a[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) a[v] = 0.f;
+  for (unsigned b = threadIdx.x; b < nblk; b += blockDim.x) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) a[v] += __hip_atomic_load(ws + 1 + NV * b + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
-    float a = 0.f;
-    for (unsigned b = threadIdx.x; b < nblk; b += blockDim.x) a += __hip_atomic_load(ws + 1 + NV * b + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    red[threadIdx.x] = a;
-    __syncthreads();
-    for (unsigned st = blockDim.x >> 1; st > 0; st >>= 1) {
-      if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) { tot[v] = red[0]; ret = true; }
-    __syncthreads();
+    a[v] = wave_sum(a[v]);
+    if ((threadIdx.x & 63) == 0) red[(threadIdx.x >> 6) * NV + v] = a[v];
   }
-  if (threadIdx.x == 0) reinterpret_cast<unsigned*>(ws)[0] = 0u;
-  return ret;
+  __syncthreads();
+  if (threadIdx.x != 0) return false;
+  const unsigned nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    float t = 0.f;
+    for (unsigned w = 0; w < nw; ++w) t += red[w * NV + v];
+    tot[v] = t;
+  }
+  reinterpret_cast<unsigned*>(ws)[0] = 0u;
+  return true;
 }
 
 static inline int dig_check_launch() {
