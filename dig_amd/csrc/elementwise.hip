@@ -209,6 +209,88 @@ __global__ void window_pool_fwd_kernel(const bf16_t* __restrict__ x, OutT* __res
   }
 }
 
+__device__ __forceinline__ void ld8_bf16(const bf16_t* p, float* v) {
+  const uint4 u = *reinterpret_cast<const uint4*>(p);
+  const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { v[2 * k] = bf2f((bf16_t)(w[k] & 0xffff)); v[2 * k + 1] = bf2f((bf16_t)(w[k] >> 16)); }
+}
+__device__ __forceinline__ void st8_bf16(bf16_t* p, const float* v) {
+  *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+}
+
+// The same with 16-byte loads (D % 8 == 0, D / 8 <= 256): a workgroup = one (image, window); thread (g, ch) adds tokens g, g + G, ... of its
+// 8 channels (G = 256 / (D / 8) token rows in flight instead of one 4-byte load per thread at a time: 20 -> 6 us for 128 x 4 windows), the
+// G partial sums are folded through LDS in g order (fixed order: bit-reproducible)
+template <typename OutT>
+__global__ __launch_bounds__(256) void window_pool_fwd16_kernel(const bf16_t* __restrict__ x, OutT* __restrict__ out, int n_img, int gh, int gw,
+                                                                int nwin, int D) {
+  __shared__ float red[256][9];
+  const int idx = blockIdx.x;
+  const int img = idx / nwin, win = idx - img * nwin;
+  const int wlen = gw / nwin, ntw = gh * wlen;
+  const int c8 = D >> 3, G = 256 / c8;
+  const int tid = threadIdx.x, g = tid / c8, ch = tid - g * c8;
+  float a[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) a[k] = 0.f;
+  if (g < G) {
+    for (int t = g; t < ntw; t += G) {
+      const int r = t / wlen, c = t - r * wlen;
+      const int n = r * gw + win * wlen + c;
+      float v[8];
+      ld8_bf16(x + ((size_t)img * gh * gw + n) * D + ch * 8, v);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) a[k] += v[k];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) red[tid][k] = a[k];
+  __syncthreads();
+  if (g == 0) {
+    const float inv = 1.0f / ntw;
+    float s[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float t = 0.f;
+      for (int q = 0; q < G; ++q) t += red[q * c8 + ch][k];
+      s[k] = t * inv;
+    }
+    if constexpr (sizeof(OutT) == 4) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) out[(size_t)idx * D + ch * 8 + k] = s[k];
+    } else {
+      st8_bf16(out + (size_t)idx * D + ch * 8, s);
+    }
+  }
+}
+
+// dx[img, n, :] (+)= dpool[img*nwin + win(n), :] / (gh*wlen) with 16-byte accesses: one item = 8 channels of one token
+__global__ __launch_bounds__(256) void window_pool_bwd16_kernel(const bf16_t* __restrict__ dpool, bf16_t* __restrict__ dx, int n_img, int gh, int gw,
+                                                                int nwin, int D, int accumulate) {
+  const int c8 = D >> 3, ntok = gh * gw, wlen = gw / nwin;
+  const size_t total = (size_t)n_img * ntok * c8;
+  const float inv = 1.0f / (gh * wlen);
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int ch = (int)(e % c8);
+    const size_t t = e / c8;
+    const int img = (int)(t / ntok), n = (int)(t - (size_t)img * ntok);
+    const int win = (n % gw) / wlen;
+    float v[8];
+    ld8_bf16(dpool + ((size_t)img * nwin + win) * D + ch * 8, v);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] *= inv;
+    bf16_t* o = dx + t * D + ch * 8;
+    if (accumulate) {
+      float w[8];
+      ld8_bf16(o, w);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] += w[k];
+    }
+    st8_bf16(o, v);
+  }
+}
+
 // dx[img, n, :] (+)= dpool[img*nwin + win(n), :] / (gh*wlen)
 __global__ void window_pool_bwd_kernel(const bf16_t* __restrict__ dpool, bf16_t* __restrict__ dx, int n_img, int gh, int gw,
                                        int nwin, int D, int accumulate) {
@@ -576,6 +658,13 @@ extern "C" int dig_patch_embed_bwd(const void* dy, const float* img, const unsig
 extern "C" int dig_window_pool_fwd(const void* x, void* out, int out_is_f32, int n_img, int gh, int gw, int nwin, int D,
                                    hipStream_t stream) {
   if (!x || !out || n_img <= 0 || nwin <= 0 || gw % nwin || (D & 1)) return DIG_ERR_ARG;
+  if ((D & 7) == 0 && D / 8 <= 256 && aligned16(x) && aligned16(out)) {
+    if (out_is_f32)
+      hipLaunchKernelGGL(window_pool_fwd16_kernel<float>, dim3(n_img * nwin), dim3(256), 0, stream, (const bf16_t*)x, (float*)out, n_img, gh, gw, nwin, D);
+    else
+      hipLaunchKernelGGL(window_pool_fwd16_kernel<bf16_t>, dim3(n_img * nwin), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)out, n_img, gh, gw, nwin, D);
+    return dig_check_launch();
+  }
   if (out_is_f32)
     hipLaunchKernelGGL(window_pool_fwd_kernel<float>, dim3(n_img * nwin), dim3(std::min(256, D / 2)), 0, stream, (const bf16_t*)x,
                        (float*)out, n_img, gh, gw, nwin, D);
@@ -588,6 +677,12 @@ extern "C" int dig_window_pool_fwd(const void* x, void* out, int out_is_f32, int
 extern "C" int dig_window_pool_bwd(const void* dpool, void* dx, int n_img, int gh, int gw, int nwin, int D, int accumulate,
                                    hipStream_t stream) {
   if (!dpool || !dx || n_img <= 0 || nwin <= 0 || gw % nwin || (D & 1)) return DIG_ERR_ARG;
+  if ((D & 7) == 0 && aligned16(dpool) && aligned16(dx)) {
+    const size_t total = (size_t)n_img * gh * gw * (D / 8);
+    hipLaunchKernelGGL(window_pool_bwd16_kernel, dim3((unsigned)std::min<size_t>(2048, (total + 255) / 256)), dim3(256), 0, stream,
+                       (const bf16_t*)dpool, (bf16_t*)dx, n_img, gh, gw, nwin, D, accumulate);
+    return dig_check_launch();
+  }
   hipLaunchKernelGGL(window_pool_bwd_kernel, dim3(n_img * gh * gw), dim3(std::min(256, D / 2)), 0, stream, (const bf16_t*)dpool,
                      (bf16_t*)dx, n_img, gh, gw, nwin, D, accumulate);
   return dig_check_launch();
