@@ -24,6 +24,7 @@
 // Workgroup -> (tile, split) comes from a host-built table (dig_wgrad_group_plan): all tiles of one (problem, split) pair sit on
 // ONE XCD (block b runs on XCD b % 8), so the narrow operand's row window is fetched from HBM once and re-read from that XCD's L2.
 #include "common.h"
+#include "lds_dma.h"
 #include <type_traits>
 #include <vector>
 
@@ -65,24 +66,6 @@ struct WgParams {
   const float* fold_slabs;
   const unsigned* wg_map;
 };
-
-// LDS-DMA the compiler does not see (see the header): M0 = LDS destination of the wave (lane l lands at +16 l), written in the same
-// statement that reads it
-__device__ __forceinline__ void dma16(unsigned lds_dst, unsigned voff, dig_u32x4 rsrc, unsigned soff) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_dst), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
-}
-template <int N>
-__device__ __forceinline__ void wg_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
-__device__ __forceinline__ dig_u32x4 make_rsrc(const void* base, unsigned bytes) {
-  const unsigned long long a = (unsigned long long)base;
-  dig_u32x4 r;
-  r[0] = __builtin_amdgcn_readfirstlane((unsigned)a);
-  r[1] = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu);
-  r[2] = __builtin_amdgcn_readfirstlane(bytes);
-  r[3] = 0x00020000u;
-  return r;
-}
 
 typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_p;
 __device__ __forceinline__ bf16x8 tr_frag(unsigned base, int off_lo, int off_hi) {

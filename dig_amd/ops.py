@@ -639,6 +639,25 @@ def attn_fwd(qkv, n_img, heads, D, drop=None, q_rows=256):
     return ctx, lse
 
 
+ATTN_BLOCK = os.environ.get("DIG_ATTN_BLOCK", "1") != "0"    # the fused attention sub-block (csrc/attn_block.hip) where the widths allow it
+
+
+def attn_block_supported(heads, D):
+    return ATTN_BLOCK and bool(L.lib().dig_attn_block_supported(int(heads), int(D)))
+
+
+def attn_block_fwd(ln1, x, qkv_w, qkv_b, proj_w, proj_b, n_img, heads, D, scale, save=False):
+    """x_mid = x + proj(attention(ln1)) in one launch.  Returns (x_mid, ctx, qkv, lse); qkv / lse are None unless save."""
+    rows = ln1.shape[0]
+    x_mid = torch.empty((rows, D), device=ln1.device, dtype=BF16)
+    ctx = torch.empty((rows, D), device=ln1.device, dtype=BF16)
+    qkv = torch.empty((rows, 3 * D), device=ln1.device, dtype=BF16) if save else None
+    lse = torch.empty((n_img * heads, 256), device=ln1.device, dtype=F32) if save else None
+    L.call("dig_attn_block_fwd", L.ptr(ln1), L.ptr(x), L.ptr(qkv_w), L.ptr(qkv_b), L.ptr(proj_w), L.ptr(proj_b), L.ptr(qkv), L.ptr(ctx),
+           L.ptr(lse), L.ptr(x_mid), n_img, heads, D, cf(scale), L.stream())
+    return x_mid, ctx, qkv, lse
+
+
 def attn_bwd(qkv, ctx, dctx, lse, n_img, heads, D, scale, bias_sums=False, drop=None, q_rows=256):
     """dqkv (dq pre-multiplied by `scale`).  bias_sums=True also returns the per-image column sums of the dq and dv parts
     ([n_img, D] fp32 each): the q_bias / v_bias gradient partials for colsum_partials()."""

@@ -158,6 +158,21 @@ int dig_attn_fwd(const void* qkv, void* ctx, float* lse, int n_img, int heads, i
 int dig_attn_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse, void* dqkv, int n_img, int heads,
                  int embed_dim, float scale, float* q_colsum, float* v_colsum, hipStream_t stream);
 
+/* The attention sub-block of an encoder block in ONE launch (csrc/attn_block.hip; D = 384, 6 heads of 64, 256 tokens per image):
+ *     x_mid = x + proj(softmax(q k^T) v) + proj_b,   (q | k | v) = ln1 qkv_w^T + qkv_b, q scaled by `scale`
+ * = Attention.forward (modeling_finetune.py:87-120) + the first residual add of Block.forward (:156): what dig_gemm_bf16 (qkv) ->
+ * dig_attn_fwd -> dig_gemm_bf16 (proj + residual) compute, without qkv / ctx as GEMM operands in HBM.  One workgroup per image.
+ * ln1, x, x_mid: bf16 [n_img*256, embed_dim]; qkv_w bf16 [3*embed_dim, embed_dim], qkv_b fp32 [3*embed_dim] (q_bias | 0 | v_bias) or NULL;
+ * proj_w bf16 [embed_dim, embed_dim], proj_b fp32 [embed_dim] or NULL.  ctx (bf16 [n_img*256, embed_dim]) is always written.
+ * qkv (bf16 [n_img*256, 3*embed_dim]) and lse (fp32 [n_img*heads, 256]): both or neither -- what dig_attn_bwd and the weight gradients
+ * read (online branch); the values of qkv are bit-identical to the dig_gemm_bf16 launch's.  The softmax runs over two halves of the keys
+ * (running maximum, fp32), so ctx / x_mid agree with the three-launch path to bf16 rounding, not bit for bit.
+ * dig_attn_block_supported: 1 if (heads, embed_dim) has a kernel (6, 384), else the caller keeps the three launches. */
+int dig_attn_block_supported(int heads, int embed_dim);
+int dig_attn_block_fwd(const void* ln1, const void* x, const void* qkv_w, const float* qkv_b, const void* proj_w, const float* proj_b,
+                       void* qkv, void* ctx, float* lse, void* x_mid, int n_img, int heads, int embed_dim, float scale,
+                       hipStream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * LayerNorm over the last dim D in {64,128,192,256,384,512} (nn.LayerNorm(eps=1e-6): modeling_finetune.py:134,140;
  * pix_decoder LN + GELU: modeling_pretrain_moco_mim_ori.py:424-425 when fuse_gelu=1).
