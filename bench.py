@@ -71,8 +71,9 @@ def synth_batches(n, B, device, seed):
 
 
 class GemmProbe:
-    """Times every matrix-core launch of a step -- dig_gemm_bf16, the fused MLP launches (dig_mlp_chain_fwd / _fwd_ln / _bwd) and the grouped
-    weight-gradient launch (dig_wgrad_group) -- with the library's launch probe (dig_probe_start / dig_probe_stop, csrc/probe.hip): each
+    """Times every matrix-core launch of a step -- dig_gemm_bf16, the fused attention sub-block (dig_attn_block_fwd), the attention kernels
+    (dig_attn_fwd / _bwd), the fused MLP launches (dig_mlp_chain_fwd / _fwd_ln / _bwd) and the grouped weight-gradient launch
+    (dig_wgrad_group) -- with the library's launch probe (dig_probe_start / dig_probe_stop, csrc/probe.hip): each
     launch carries the start / stop events of hipExtLaunchKernel ON ITS LAUNCH STREAM, i.e. the kernel's own begin and end on the device,
     which is what rocprofv3's kernel trace reports.  With the two-stream overlap left ON these are the durations IN THE STEP; with
     `model.overlap_streams = False` the durations of the kernels one at a time.  The wrappers below only book what each launch computes
@@ -139,6 +140,34 @@ class GemmProbe:
             return self._bracket("mlp_chain_bwd", 4.0 * R * D * Fh, byt, lambda: sv["chain_bwd"](dy, w2t, pre, w1t, colsum=colsum, out=out))
         ops.mlp_chain_bwd = timed_chain_bwd
 
+        def attn_block_rec(R, D, save, n_img, heads):
+            # the fused attention sub-block: qkv Linear + scores + context + proj Linear; algorithmic bytes = ln1, x and x_mid rows, both weight
+            # matrices once; the online form also writes what the backward reads (qkv, ctx, lse)
+            fl = 2.0 * R * D * 3 * D + 4.0 * R * 256 * D + 2.0 * R * D * D
+            byt = 2.0 * R * D * 3 + 2.0 * 4 * D * D + ((2.0 * R * 3 * D + 2.0 * R * D + 4.0 * n_img * heads * 256) if save else 0.0)
+            return ("attn_block_online" if save else "attn_block_momentum", fl, byt)
+        sv["attn_block"] = ops.attn_block_fwd
+
+        def attn_rec(bwd, R, D):
+            # attention proper, per (image, head): scores + context (forward: 2 matrix products of 2 x 256 x 256 x 64), backward: scores again,
+            # dP, dV, dK, dQ (5); bytes: qkv (+ ctx, dctx, lse) in, ctx / dqkv out
+            return ("attn_bwd" if bwd else "attn_fwd", (10.0 if bwd else 4.0) * R * 256 * D, 2.0 * R * D * (9 if bwd else 4))
+        sv["attn_fwd"], sv["attn_bwd"] = ops.attn_fwd, ops.attn_bwd
+
+        def timed_attn_fwd(qkv, n_img, heads, D, drop=None, q_rows=256):
+            self.rec.append(attn_rec(False, qkv.shape[0], D))
+            return sv["attn_fwd"](qkv, n_img, heads, D, drop=drop, q_rows=q_rows)
+
+        def timed_attn_bwd(qkv, ctx, dctx, lse, n_img, heads, D, scale, bias_sums=False, drop=None, q_rows=256):
+            self.rec.append(attn_rec(True, qkv.shape[0], D))
+            return sv["attn_bwd"](qkv, ctx, dctx, lse, n_img, heads, D, scale, bias_sums=bias_sums, drop=drop, q_rows=q_rows)
+        ops.attn_fwd, ops.attn_bwd = timed_attn_fwd, timed_attn_bwd
+
+        def timed_attn_block(ln1, x, qkv_w, qkv_b, proj_w, proj_b, n_img, heads, D, scale, save=False):
+            self.rec.append(attn_block_rec(ln1.shape[0], D, save, n_img, heads))
+            return sv["attn_block"](ln1, x, qkv_w, qkv_b, proj_w, proj_b, n_img, heads, D, scale, save=save)
+        ops.attn_block_fwd = timed_attn_block
+
         probe = self
 
         def timed_wg_launch(grp):
@@ -165,8 +194,12 @@ class GemmProbe:
             if name == "dig_encoder_block_fwd":
                 b = args[0]._obj
                 R, D, Fh = b.rows, b.D, b.F
-                self.rec.append(gemm_rec("fwd", b.tile_qkv, R, 3 * D, D))
-                self.rec.append(gemm_rec("fwd", b.tile_proj, R, D, D, resid=True))
+                if b.fuse_attn and ops.attn_block_supported(b.heads, D):
+                    self.rec.append(attn_block_rec(R, D, bool(b.save), b.n_img, b.heads))
+                else:
+                    self.rec.append(gemm_rec("fwd", b.tile_qkv, R, 3 * D, D))
+                    self.rec.append(attn_rec(False, R, D))
+                    self.rec.append(gemm_rec("fwd", b.tile_proj, R, D, D, resid=True))
                 byt = 2.0 * R * D * (2 + bool(b.next_n1_g)) + 2.0 * 2 * D * Fh + ((2.0 * R * D + 2.0 * 2 * R * Fh) if b.save else 0.0)
                 self.rec.append(("mlp_chain_online" if b.save else "mlp_chain_momentum", 4.0 * R * D * Fh, byt))
             elif name == "dig_encoder_block_bwd":
@@ -174,6 +207,7 @@ class GemmProbe:
                 R, D, Fh = b.rows, b.D, b.F
                 self.rec.append(("mlp_chain_bwd", 4.0 * R * D * Fh, 2.0 * R * D * 2 + 2.0 * R * Fh * 2 + 2.0 * 2 * D * Fh))
                 self.rec.append(gemm_rec("dgrad", b.tile_dgrad, R, D, D))
+                self.rec.append(attn_rec(True, R, D))
                 shapes = ((D, Fh), (Fh, D), (D, D), (3 * D, D))
                 self.rec.append(("wgrad_group", sum(2.0 * R * o * i for o, i in shapes), sum(2.0 * R * (o + i) + 8.0 * o * i for o, i in shapes)))
                 self.rec.append(gemm_rec("dgrad", b.tile_dgrad, R, D, 3 * D))
@@ -188,6 +222,8 @@ class GemmProbe:
         ops, sv = self.ops, self._saved
         ops.gemm, ops.mlp_chain_fwd, ops.mlp_chain_fwd_ln, ops.mlp_chain_bwd = sv["gemm"], sv["chain"], sv["chain_ln"], sv["chain_bwd"]
         ops.WgradGroup.launch = sv["wg_launch"]
+        ops.attn_block_fwd = sv["attn_block"]
+        ops.attn_fwd, ops.attn_bwd = sv["attn_fwd"], sv["attn_bwd"]
         ops.L.call = sv["call"]
         torch.cuda.synchronize()
         cap = len(self.rec) + 64
@@ -216,6 +252,11 @@ KERNEL_TEXT = {
     "mlp_chain_online": "dig_mlp_chain_fwd_ln, online form (mlp_chain_kernel<1, true>: norm2 -> fc1 -> GELU -> fc2 + residual -> next norm1 in one launch, writes what the backward reads)",
     "mlp_chain_momentum": "dig_mlp_chain_fwd_ln, momentum form (mlp_chain_kernel<0, true>: norm2 -> fc1 -> GELU -> fc2 + residual -> next norm1 in one launch, no side outputs)",
     "mlp_chain_bwd": "dig_mlp_chain_bwd (mlp_chain_kernel<2>: the MLP's two data gradients x GELU' in one launch)",
+    "attn_bwd": "dig_attn_bwd (attn_bwd_kernel: dq, dk, dv of the softmax attention given d(ctx), one workgroup per (image, head), + the q / v bias sums)",
+    "attn_fwd": "dig_attn_fwd (attn_fwd_kernel: softmax(q k^T) v, one workgroup per (image, head))",
+    "attn_block_online": "dig_attn_block_fwd, online form (attn_block_kernel<true>: qkv Linear -> softmax(q k^T) v -> proj Linear + residual in one launch, one "
+                         "workgroup per image; writes qkv, ctx, lse for the backward)",
+    "attn_block_momentum": "dig_attn_block_fwd, momentum form (attn_block_kernel<false>: the same launch with nothing kept)",
     "wgrad_group": "dig_wgrad_group (wgrad_wide_kernel / wgrad_group_kernel: the four weight gradients of a block in one launch, 4 x 3 MFMA blocks per wave, "
                    "LDS-DMA ring, slabs folded by the next launch)",
 }
@@ -404,14 +445,13 @@ def main():
     model.overlap_streams = True
     if rank == 0:
         summ_in, summ = probe_in.summary(), probe.summary()
-        # The dominant family = the kernel template (as rocprofv3 lists them) with the most kernel time of its own per step, i.e. measured
-        # one kernel at a time; families within 5 % of the top are ranked by the FLOP they carry.  (In the step the forward kernels of the
-        # two encoder branches run CONCURRENTLY on two streams -- that overlap is worth 1 ms per step -- so their in-step spans count the
-        # shared chip twice and would crown whichever kernel happens to have a neighbour; rocprofv3, which serialises the two queues,
-        # would not see those spans either.)  `frac` is then that family's FLOP over its IN-STEP durations.
+        # The dominant family = the kernel template instantiation (as rocprofv3 lists them) with the most kernel time per step, measured one
+        # kernel at a time -- the serialisation rocprofv3's kernel trace applies, so this is the top row of its summary -- with no tie-break on
+        # the work a family carries: the kernel that OWNS the step, whatever its efficiency.  `frac` is that family's FLOP over its IN-STEP
+        # durations (both streams running, as in the timed region).  Beside it: `best` = the most efficient family among those with >= 5 % of
+        # the matrix-core kernel time, `weighted` = all matrix-core families together (sum of FLOP / sum of in-step durations).
         cand = [k for k in summ if summ[k]["flops"] > 0]
-        top = max(summ[k]["seconds"] for k in cand)
-        dom = max((k for k in cand if summ[k]["seconds"] >= 0.95 * top), key=lambda k: summ[k]["flops"])
+        dom = max(cand, key=lambda k: summ[k]["seconds"])
         d, da = summ_in.get(dom, summ[dom]), summ[dom]
         tf = d["flops"] / d["seconds"] / 1e12
         gbs = d["bytes"] / d["seconds"] / 1e9
@@ -445,7 +485,18 @@ def main():
                         "ms_per_step": v["seconds"] / 2 * 1e3, "launches_per_step": v["launches"] // 2, "avg_launch_us": v["seconds"] / v["launches"] * 1e6,
                         "flops_per_launch": v["flops"] / v["launches"]}
                     for k, v in sm.items()}
+        tot_s = sum(summ_in[k]["seconds"] for k in summ_in if summ_in[k]["flops"] > 0)
+        tot_f = sum(summ_in[k]["flops"] for k in summ_in)
+        big = [k for k in summ_in if summ_in[k]["flops"] > 0 and summ_in[k]["seconds"] >= 0.05 * tot_s]
+        best = max(big, key=lambda k: summ_in[k]["flops"] / summ_in[k]["seconds"])
+        best_tf = summ_in[best]["flops"] / summ_in[best]["seconds"] / 1e12
+        tot_sa = sum(summ[k]["seconds"] for k in summ if summ[k]["flops"] > 0)
         roof = {"bound": "mfma", **mfma_view, "traffic": traffic,
+                "best": {"family": best, "achieved": best_tf, "unit": "TFLOP/s", "frac": best_tf / (PEAK_BF16 / 1e12),
+                         "note": "the most efficient family with >= 5 % of the matrix-core kernel time (in the step)"},
+                "weighted": {"achieved": tot_f / tot_s / 1e12, "unit": "TFLOP/s", "frac": tot_f / tot_s / PEAK_BF16,
+                             "alone_frac": tot_f / tot_sa / PEAK_BF16, "ms_per_step": tot_s / 2 * 1e3,
+                             "note": "all matrix-core launches of the step: sum of FLOP / sum of in-step durations (alone_frac: one kernel at a time)"},
                 "kernel": kname, "family": dom, "measured": "start / stop events of hipExtLaunchKernel on every launch of the family, on its launch stream (dig_probe_start / _stop), in two extra "
                             "steps with both streams running: the kernels' device-side durations in the step, as rocprofv3's kernel trace reports them",
                 "traffic_source": traffic_src,

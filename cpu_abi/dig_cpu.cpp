@@ -274,6 +274,30 @@ int dig_attn_fwd(const void* qkv, void* ctx, float* lse, int n_img, int heads, i
   return dig_attn_fwd_dropout(qkv, ctx, lse, n_img, heads, embed_dim, nullptr, N_TOK, stream);
 }
 
+// the attention sub-block in one call (HIP: csrc/attn_block.hip): here the same three steps, one after the other.  qkv / lse null: the
+// momentum branch keeps nothing (the q | k | v rows then live in a temporary)
+int dig_attn_block_supported(int heads, int embed_dim) { return (heads == 6 && embed_dim == 384) ? 1 : 0; }
+int dig_attn_block_fwd(const void* ln1, const void* x, const void* qkv_w, const float* qkv_b, const void* proj_w, const float* proj_b,
+                       void* qkv, void* ctx, float* lse, void* x_mid, int n_img, int heads, int embed_dim, float scale, hipStream_t stream) {
+  if (!ln1 || !x || !qkv_w || !proj_w || !ctx || !x_mid || n_img <= 0) return DIG_ERR_ARG;
+  if ((qkv == nullptr) != (lse == nullptr)) return DIG_ERR_ARG;
+  if (!dig_attn_block_supported(heads, embed_dim)) return DIG_ERR_UNSUPPORTED;
+  const int D = embed_dim, R = n_img * N_TOK;
+  std::vector<bf16_t> tq;
+  std::vector<float> tl;
+  if (!qkv) {
+    tq.resize((size_t)R * 3 * D + 8);
+    tl.resize((size_t)n_img * heads * N_TOK);
+    qkv = (void*)(((uintptr_t)tq.data() + 15) & ~(uintptr_t)15);
+    lse = tl.data();
+  }
+  int rc = dig_gemm_bf16(ln1, qkv_w, qkv, R, 3 * D, D, D, D, 3 * D, 0, 0, 0, qkv_b, nullptr, 0, nullptr, 0, scale, D, 0, 1, 0, 0, 0, nullptr, stream);
+  if (rc) return rc;
+  rc = dig_attn_fwd(qkv, ctx, lse, n_img, heads, D, stream);
+  if (rc) return rc;
+  return dig_gemm_bf16(ctx, proj_w, x_mid, R, D, D, D, D, D, 0, 0, 0, proj_b, x, D, nullptr, 0, 1.0f, 0, 0, 1, 0, 0, 0, nullptr, stream);
+}
+
 int dig_attn_bwd_dropout(const void* qkv_, const void* ctx_, const void* dctx_, const float* lse, void* dqkv_, int n_img, int heads,
                          int embed_dim, float scale, float* q_colsum, float* v_colsum, const dig_dropout_t* drop, int q_rows, hipStream_t) {
   if (!qkv_ || !ctx_ || !dctx_ || !lse || !dqkv_ || n_img <= 0 || heads <= 0 || embed_dim != heads * DH || q_rows < 1 || q_rows > N_TOK) return DIG_ERR_ARG;

@@ -481,8 +481,8 @@ extern "C" int dig_attn_fwd_dropout(const void* qkv, void* ctx, float* lse, int 
   const bool dropping = drop && drop->thr;
   const dig_dropout_t dr = dropping ? *drop : dig_dropout_t{};
 #define DIG_ATTN_FWD_LAUNCH(DR, FU)                                                                                                       \
-  hipLaunchKernelGGL((attn_fwd_kernel<DR, FU>), dim3(n_img * heads), dim3(256), 2 * TILE, stream, (const bf16_t*)qkv, (bf16_t*)ctx, lse, \
-                     embed_dim, heads, (unsigned)qb, dr, nqb)
+  dig_launch(attn_fwd_kernel<DR, FU>, dim3(n_img * heads), dim3(256), 2 * TILE, stream, (const bf16_t*)qkv, (bf16_t*)ctx, lse, embed_dim, \
+             heads, (unsigned)qb, dr, nqb)
   if (dropping) DIG_ATTN_FWD_LAUNCH(true, false);                       // (the unguarded dropout form spills 36 registers: it keeps the guards)
   else { if (nqb == 8) DIG_ATTN_FWD_LAUNCH(false, true); else DIG_ATTN_FWD_LAUNCH(false, false); }
 #undef DIG_ATTN_FWD_LAUNCH
@@ -512,13 +512,12 @@ extern "C" int dig_attn_bwd_dropout(const void* qkv, const void* ctx, const void
     attr[dev] = true;
   }
   if (drop && drop->thr)
-    hipLaunchKernelGGL(attn_bwd_kernel<true>, dim3(n_img * heads), dim3(256), lds, stream, (const bf16_t*)qkv, (const bf16_t*)ctx,
-                       (const bf16_t*)dctx, lse, (bf16_t*)dqkv, embed_dim, heads, scale, (unsigned)qb, (unsigned)(qb / 3), q_colsum,
-                       v_colsum, *drop, nqb);
+    dig_launch(attn_bwd_kernel<true>, dim3(n_img * heads), dim3(256), (unsigned)lds, stream, (const bf16_t*)qkv, (const bf16_t*)ctx,
+               (const bf16_t*)dctx, lse, (bf16_t*)dqkv, embed_dim, heads, scale, (unsigned)qb, (unsigned)(qb / 3), q_colsum, v_colsum, *drop, nqb);
   else
-    hipLaunchKernelGGL(attn_bwd_kernel<false>, dim3(n_img * heads), dim3(256), lds, stream, (const bf16_t*)qkv, (const bf16_t*)ctx,
-                       (const bf16_t*)dctx, lse, (bf16_t*)dqkv, embed_dim, heads, scale, (unsigned)qb, (unsigned)(qb / 3), q_colsum,
-                       v_colsum, dig_dropout_t{}, nqb);
+    dig_launch(attn_bwd_kernel<false>, dim3(n_img * heads), dim3(256), (unsigned)lds, stream, (const bf16_t*)qkv, (const bf16_t*)ctx,
+               (const bf16_t*)dctx, lse, (bf16_t*)dqkv, embed_dim, heads, scale, (unsigned)qb, (unsigned)(qb / 3), q_colsum, v_colsum,
+               dig_dropout_t{}, nqb);
   return dig_check_launch();
 }
 

@@ -173,14 +173,21 @@ class _Step:
         for i, blk in enumerate(ew.blocks):
             ln1, mu1, rs1 = nxt if nxt is not None else ops.layernorm_fwd(x, blk["norm1.weight"], blk["norm1.bias"], M.ln_eps)
             nxt = None
-            qkv = ops.linear_fwd(ln1, blk["attn.qkv.weight"], bias=blk["qkv_bias"], alpha=scale, alpha_cols=D)
-            ctx, lse = ops.attn_fwd(qkv, 2 * B, H, D)
+            fused_attn = ops.attn_block_supported(H, D)
+            if fused_attn:
+                # qkv Linear -> attention -> proj Linear + residual in one launch (csrc/attn_block.hip); qkv / lse exist only where kept
+                x_mid, ctx, qkv, lse = ops.attn_block_fwd(ln1, x, blk["attn.qkv.weight"], blk["qkv_bias"], blk["attn.proj.weight"],
+                                                          blk["attn.proj.bias"], 2 * B, H, D, scale, save=save)
+            else:
+                qkv = ops.linear_fwd(ln1, blk["attn.qkv.weight"], bias=blk["qkv_bias"], alpha=scale, alpha_cols=D)
+                ctx, lse = ops.attn_fwd(qkv, 2 * B, H, D)
             if chain_ln:
                 # norm2 -> fc1 -> GELU -> fc2 (+ residual) -> the NEXT block's norm1 in one launch: between two blocks the residual stream
                 # is written once and no LayerNorm launch remains (the first block's norm1 is the only stand-alone one); norm2 is taken on
                 # the way into the MLP launch
                 nb = ew.blocks[i + 1] if i + 1 < len(ew.blocks) else None
-                x_mid = ops.linear_fwd(ctx, blk["attn.proj.weight"], bias=blk["attn.proj.bias"], resid=x)
+                if not fused_attn:
+                    x_mid = ops.linear_fwd(ctx, blk["attn.proj.weight"], bias=blk["attn.proj.bias"], resid=x)
                 r = ops.mlp_chain_fwd_ln(x_mid, blk["norm2.weight"], blk["norm2.bias"], M.ln_eps, blk["mlp.fc1.weight"], blk["mlp.fc1.bias"],
                                          blk["mlp.fc2.weight"], blk["mlp.fc2.bias"], nb["norm1.weight"] if nb else None,
                                          nb["norm1.bias"] if nb else None, save=save)
@@ -191,7 +198,8 @@ class _Step:
                     nxt = (r["nln"], r["nln_mean"], r["nln_rstd"])
                 x = r["out"]
                 continue
-            x_mid = ops.linear_fwd(ctx, blk["attn.proj.weight"], bias=blk["attn.proj.bias"], resid=x)
+            if not fused_attn:
+                x_mid = ops.linear_fwd(ctx, blk["attn.proj.weight"], bias=blk["attn.proj.bias"], resid=x)
             ln2, mu2, rs2 = ops.layernorm_fwd(x_mid, blk["norm2.weight"], blk["norm2.bias"], M.ln_eps)
             if chain:
                 # fc1 -> GELU -> fc2 (+ residual) in one launch: the [R, F] hidden tensor is never a GEMM operand in HBM; the online
@@ -234,7 +242,7 @@ class _Step:
                 st = blk[key] = ops.BlockFwd(
                     n_img=n_img, heads=H, D=D, F=Fh, rows=R, save=int(bool(save)),
                     tile_qkv=ops.fwd_tile_code(R, 3 * D, D) or ops.GEMM_BK_FWD, tile_proj=ops.fwd_tile_code(R, D, D, has_resid=True) or ops.GEMM_BK_FWD,
-                    eps=M.ln_eps, scale=(D // H) ** -0.5,
+                    fuse_attn=int(ops.attn_block_supported(H, D)), eps=M.ln_eps, scale=(D // H) ** -0.5,
                     qkv_w=blk["attn.qkv.weight"].data_ptr(), qkv_b=blk["qkv_bias"].data_ptr(), proj_w=blk["attn.proj.weight"].data_ptr(),
                     proj_b=blk["attn.proj.bias"].data_ptr(), n2_g=blk["norm2.weight"].data_ptr(), n2_b=blk["norm2.bias"].data_ptr(),
                     fc1_w=blk["mlp.fc1.weight"].data_ptr(), fc1_b=blk["mlp.fc1.bias"].data_ptr(), fc2_w=blk["mlp.fc2.weight"].data_ptr(),

@@ -501,7 +501,7 @@ _VP, _FP, _I, _F = ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_floa
 
 class BlockFwd(ctypes.Structure):
     """include/dig_block_types.h `dig_block_fwd_t`."""
-    _fields_ = ([(k, _I) for k in ("n_img", "heads", "D", "F", "rows", "save", "tile_qkv", "tile_proj")] + [("eps", _F), ("scale", _F)] +
+    _fields_ = ([(k, _I) for k in ("n_img", "heads", "D", "F", "rows", "save", "tile_qkv", "tile_proj", "fuse_attn", "reserved0")] + [("eps", _F), ("scale", _F)] +
                 [(k, _VP) for k in ("qkv_w", "qkv_b", "proj_w", "proj_b", "n2_g", "n2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "next_n1_g", "next_n1_b",
                                     "x", "ln1", "qkv", "ctx", "lse", "x_mid", "ln2", "mu2", "rs2", "pre", "act", "out", "nln", "nmu", "nrs")])
 

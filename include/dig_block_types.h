@@ -17,6 +17,9 @@ typedef struct dig_block_fwd {
   int n_img, heads, D, F, rows;        /* rows = n_img * 256 tokens */
   int save;                            /* 1: online branch (everything below is written); 0: momentum branch (ln2, mu2, rs2, pre, act, nmu, nrs may be null) */
   int tile_qkv, tile_proj;             /* DIG_GEMM_TILE_* of the two Linear layers */
+  int fuse_attn;                       /* 1: qkv GEMM -> attention -> proj GEMM + residual as ONE launch (dig_attn_block_fwd) where dig_attn_block_supported(heads, D);
+                                          qkv / lse are then written only when save = 1 (ctx always: it is the launch's scratch) */
+  int reserved0;
   float eps, scale;                    /* LayerNorm eps; head_dim^-0.5 applied to the q columns in the qkv epilogue */
   /* parameters: bf16 weights [out, in], fp32 biases and LayerNorm parameters */
   const void* qkv_w; const float* qkv_b; const void* proj_w; const float* proj_b;

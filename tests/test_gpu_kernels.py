@@ -619,6 +619,104 @@ def test_attention_exact_arithmetic(dev):
     assert (lse.cpu().view(Bn, H, 256) - (256.0 + math.log(4.0))).abs().max().item() < 1e-3
 
 
+def _attn_block_reference(ln1, x, wq, bq, wp, bp, n_img, H, D, scale):
+    """Attention.forward + the residual add (modeling_finetune.py:87-120, :156) in fp32 torch on the bf16 operands."""
+    qkv = ln1.float() @ wq.float().t() + bq
+    qkv[:, :D] *= scale
+    q, k, v = qkv.bfloat16().float().view(n_img, 256, 3, H, D // H).permute(2, 0, 3, 1, 4)      # (the q | k | v rows are bf16 tensors in the reference's autocast step too)
+    s = q @ k.transpose(-1, -2)
+    ctx = (torch.softmax(s, dim=-1) @ v).permute(0, 2, 1, 3).reshape(n_img * 256, D)
+    return x.float() + ctx @ wp.float().t() + bp, ctx, qkv, torch.logsumexp(s, dim=-1).reshape(n_img * H, 256)
+
+
+@pytest.mark.parametrize("n_img,spike", [(1, False), (3, True), (64, False)])
+def test_attn_block_fwd(dev, n_img, spike):
+    """dig_attn_block_fwd (qkv Linear -> attention -> proj Linear + residual in one launch, csrc/attn_block.hip) against fp32 torch and
+    against the three launches it replaces: the q | k | v rows bit for bit, lse to fp32 round-off, ctx / x_mid to bf16 rounding; the form
+    that keeps nothing (momentum branch) writes the same ctx / x_mid as the form that keeps qkv and lse."""
+    from dig_amd import ops
+    D, H = 384, 6
+    if not ops.attn_block_supported(H, D):
+        pytest.skip("DIG_ATTN_BLOCK=0")
+    R = n_img * 256
+    cpu_limit(dev, 2.0 * R * D * 4 * D + 4.0 * R * 256 * D, 3e9)
+    scale = (D // H) ** -0.5
+    ln1, x = torch.randn(R, D, device=dev).bfloat16(), torch.randn(R, D, device=dev).bfloat16()
+    wq, wp = (torch.randn(3 * D, D, device=dev) * 0.05).bfloat16(), (torch.randn(D, D, device=dev) * 0.05).bfloat16()
+    bq, bp = torch.randn(3 * D, device=dev) * 0.3, torch.randn(D, device=dev) * 0.3
+    bq[D:2 * D] = 0
+    if spike:                                                          # one dominant key in the SECOND half of the keys: the running maximum moves
+        ln1[200] *= 4.0
+        ln1[256 + 7] *= 5.0
+    x_mid, ctx, qkv, lse = ops.attn_block_fwd(ln1, x, wq, bq, wp, bp, n_img, H, D, scale, save=True)
+    rx, rctx, rqkv, rlse = _attn_block_reference(ln1, x, wq, bq, wp, bp, n_img, H, D, scale)
+    assert rel(qkv, rqkv) < 1e-2 and rel(ctx, rctx) < 1e-2 and rel(x_mid, rx) < 1e-2
+    assert (lse - rlse).abs().max().item() < 2e-2
+    x_mid0, ctx0, qkv0, lse0 = ops.attn_block_fwd(ln1, x, wq, bq, wp, bp, n_img, H, D, scale, save=False)
+    assert qkv0 is None and lse0 is None and torch.equal(ctx0, ctx) and torch.equal(x_mid0, x_mid)
+    # the three launches
+    qkv3 = ops.linear_fwd(ln1, wq, bias=bq, alpha=scale, alpha_cols=D)
+    ctx3, lse3 = ops.attn_fwd(qkv3, n_img, H, D)
+    x_mid3 = ops.linear_fwd(ctx3, wp, bias=bp, resid=x)
+    assert torch.equal(qkv, qkv3)
+    assert (lse - lse3).abs().max().item() < 1e-4
+    assert rel(ctx, ctx3.float()) < 2e-3 and rel(x_mid, x_mid3.float()) < 2e-3
+    # fed with the fused launch's qkv / ctx / lse, the backward kernels give what they give for the three launches' (same values up to rounding)
+    dctx = torch.randn(R, D, device=dev).bfloat16()
+    assert rel(ops.attn_bwd(qkv, ctx, dctx, lse, n_img, H, D, scale), ops.attn_bwd(qkv3, ctx3, dctx, lse3, n_img, H, D, scale).float()) < 2e-3
+
+
+def test_attn_block_fwd_exact_arithmetic(dev):
+    """Every product and every fp32 sum of the fused launch is exact here, so the result must EQUAL the definition.  ln1 carries three 64-channel
+    patterns (a one-hot query pattern, a one-hot key pattern with every channel hot in four tokens, integer values); the qkv weight routes them
+    into every head through head-specific channel permutations (one 1 per row), so a score is 256 where query and key meet and 0 elsewhere:
+    exp(-256) is 0 in fp32, the softmax is exactly uniform over the four matching keys wherever they sit in the two halves of the key loop (a
+    first half without a match is multiplied by exp(0 - 256) = 0 when the second one raises the maximum), the context is the integer mean of
+    their value rows, and the projection (one +-1/2 per row) + bias + residual stays in bf16's exact range."""
+    from dig_amd import ops
+    D, H, n_img = 384, 6, 2
+    if not ops.attn_block_supported(H, D):
+        pytest.skip("DIG_ATTN_BLOCK=0")
+    R = n_img * 256
+    g = torch.Generator().manual_seed(11)
+    a = torch.randint(0, 64, (R,), generator=g)                                    # hot query channel of a token
+    b = torch.stack([torch.arange(256).remainder(64)[torch.randperm(256, generator=g)] for _ in range(n_img)]).reshape(R)
+    vals = torch.randint(-8, 9, (R, 64), generator=g).float() * 4.0
+    ln1 = torch.zeros(R, D)
+    ln1[torch.arange(R), a] = 128.0                                                # q = 128 * scale = 16
+    ln1[torch.arange(R), 64 + b] = 16.0
+    ln1[:, 128:192] = vals
+    pq = [torch.randperm(64, generator=g) for _ in range(H)]
+    pk = [torch.randperm(64, generator=g) for _ in range(H)]
+    pv = [torch.randperm(64, generator=g) for _ in range(H)]
+    wq = torch.zeros(3 * D, D)
+    for h in range(H):
+        d = torch.arange(64)
+        wq[h * 64 + d, pq[h]] = 1.0
+        wq[D + h * 64 + d, 64 + pk[h]] = 1.0
+        wq[2 * D + h * 64 + d, 128 + pv[h]] = 1.0
+    bq = torch.zeros(3 * D)
+    bq[2 * D:] = torch.randint(-2, 3, (D,), generator=g).float() * 4.0             # v_bias: multiples of 4
+    wp = torch.zeros(D, D)
+    wp[torch.arange(D), torch.randperm(D, generator=g)] = torch.randint(0, 2, (D,), generator=g).float() - 0.5
+    bp = torch.randint(-4, 5, (D,), generator=g).float()
+    x = torch.randint(-8, 9, (R, D), generator=g).float()
+    scale = 0.125
+    # the definition, in exact arithmetic
+    qkv = ln1 @ wq.t() + bq
+    q, k, v = qkv.view(n_img, 256, 3, H, 64).permute(2, 0, 3, 1, 4)
+    match = ((q * scale) @ k.transpose(-1, -2) == 256.0).float()
+    assert bool((match.sum(-1) == 4).all())
+    rctx = ((match @ v) / 4.0).permute(0, 2, 1, 3).reshape(R, D)
+    rx = x + rctx @ wp.t() + bp
+    qkv[:, :D] *= scale
+    to = lambda t: t.to(dev)
+    x_mid, ctx, qkv_d, lse = ops.attn_block_fwd(to(ln1.bfloat16()), to(x.bfloat16()), to(wq.bfloat16()), to(bq), to(wp.bfloat16()), to(bp),
+                                                n_img, H, D, scale, save=True)
+    assert torch.equal(qkv_d.float().cpu(), qkv) and torch.equal(ctx.float().cpu(), rctx) and torch.equal(x_mid.float().cpu(), rx)
+    assert (lse.cpu() - (256.0 + math.log(4.0))).abs().max().item() < 1e-4
+
+
 @pytest.mark.parametrize("n_img", [2, 64])
 def test_encoder_block_calls_equal_the_entry_point_sequence(dev, n_img):
     """dig_encoder_block_fwd / dig_encoder_block_bwd (one FFI crossing per encoder block; include/dig_block_types.h) against the sequence of
@@ -639,20 +737,23 @@ def test_encoder_block_calls_equal_the_entry_point_sequence(dev, n_img):
     x = bf(R, D, s=1.0)
     ln1, mu1, rs1 = ops.layernorm_fwd(x, P["n1_g"], P["n1_b"], eps)
 
-    def fwd_entry_points(save, last):
-        qkv = ops.linear_fwd(ln1, P["qkv_w"], bias=P["qkv_b"], alpha=scale, alpha_cols=D)
-        ctx, lse = ops.attn_fwd(qkv, n_img, H, D)
-        x_mid = ops.linear_fwd(ctx, P["proj_w"], bias=P["proj_b"], resid=x)
+    def fwd_entry_points(save, last, fuse=True):
+        if fuse and ops.attn_block_supported(H, D):
+            x_mid, ctx, qkv, lse = ops.attn_block_fwd(ln1, x, P["qkv_w"], P["qkv_b"], P["proj_w"], P["proj_b"], n_img, H, D, scale, save=save)
+        else:
+            qkv = ops.linear_fwd(ln1, P["qkv_w"], bias=P["qkv_b"], alpha=scale, alpha_cols=D)
+            ctx, lse = ops.attn_fwd(qkv, n_img, H, D)
+            x_mid = ops.linear_fwd(ctx, P["proj_w"], bias=P["proj_b"], resid=x)
         r = ops.mlp_chain_fwd_ln(x_mid, P["n2_g"], P["n2_b"], eps, P["fc1_w"], P["fc1_b"], P["fc2_w"], P["fc2_b"],
                                  None if last else P["nn1_g"], None if last else P["nn1_b"], save=save)
         return dict(r, qkv=qkv, ctx=ctx, lse=lse, x_mid=x_mid)
 
-    def fwd_block_call(save, last):
+    def fwd_block_call(save, last, fuse=True):
         off, n16, n32 = ops.block_fwd_layout(R, D, Fh, n_img, H, save)
         b16, b32 = torch.full((n16 // 2,), 7.0, device=dev, dtype=torch.bfloat16), torch.full((n32 // 4,), 7.0, device=dev)
         p16, p32 = b16.data_ptr(), b32.data_ptr()
         st = ops.BlockFwd(n_img=n_img, heads=H, D=D, F=Fh, rows=R, save=int(save), tile_qkv=ops.fwd_tile_code(R, 3 * D, D) or ops.GEMM_BK_FWD,
-                          tile_proj=ops.fwd_tile_code(R, D, D, has_resid=True) or ops.GEMM_BK_FWD, eps=eps, scale=scale,
+                          tile_proj=ops.fwd_tile_code(R, D, D, has_resid=True) or ops.GEMM_BK_FWD, fuse_attn=int(fuse), eps=eps, scale=scale,
                           qkv_w=P["qkv_w"].data_ptr(), qkv_b=P["qkv_b"].data_ptr(), proj_w=P["proj_w"].data_ptr(), proj_b=P["proj_b"].data_ptr(),
                           n2_g=P["n2_g"].data_ptr(), n2_b=P["n2_b"].data_ptr(), fc1_w=P["fc1_w"].data_ptr(), fc1_b=P["fc1_b"].data_ptr(),
                           fc2_w=P["fc2_w"].data_ptr(), fc2_b=P["fc2_b"].data_ptr(), next_n1_g=None if last else P["nn1_g"].data_ptr(),
@@ -672,11 +773,11 @@ def test_encoder_block_calls_equal_the_entry_point_sequence(dev, n_img):
     names = {"qkv": ("qkv", 3 * D), "ctx": ("ctx", D), "lse": ("lse", 0), "x_mid": ("x_mid", D), "out": ("out", D), "ln": ("ln2", D),
              "ln_mean": ("mu2", 0), "ln_rstd": ("rs2", 0), "pre": ("pre", Fh), "act": ("act", Fh), "nln": ("nln", D), "nln_mean": ("nmu", 0),
              "nln_rstd": ("nrs", 0)}
-    for save, last in ((True, False), (False, False), (True, True), (False, True)):
-        ref, v = fwd_entry_points(save, last), fwd_block_call(save, last)
+    for save, last, fuse in ((True, False, True), (False, False, True), (True, True, True), (False, True, True), (True, False, False), (False, True, False)):
+        ref, v = fwd_entry_points(save, last, fuse), fwd_block_call(save, last, fuse)
         for k, (nm, cols) in names.items():
             if ref.get(k) is not None:
-                assert torch.equal(ref[k], v(nm, cols)), (k, save, last)
+                assert torch.equal(ref[k], v(nm, cols)), (k, save, last, fuse)
     # ---- backward over two "blocks" (the same saved tensors twice, two incoming gradients): the second call folds the first one's slabs
     sv = fwd_entry_points(True, False)
     w2t, w1t = ops.transpose_bf16(P["fc2_w"]), ops.transpose_bf16(P["fc1_w"])
