@@ -17,6 +17,9 @@ import time
 import types
 
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")        # before HIP initialises: see dig_amd/__init__.py
+# this process also measures the captured (HIP-graph) form of the step beside the eager one (`step_graph` in the line): the graph executor's
+# queue count for it (dig_amd/__init__.py sets it only under DIG_STEP_GRAPH=1); eager launches -- the headline -- do not read it
+os.environ.setdefault("DEBUG_HIP_FORCE_GRAPH_QUEUES", "2")
 
 import numpy as np
 import torch

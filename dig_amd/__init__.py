@@ -8,7 +8,11 @@ import os as _os
 # stream shares a queue with the main stream and every launch serialises (measured: 28.2 -> 30.9 ms per step under
 # torch.distributed).  Must be set before the HIP runtime initialises, i.e. before the first device call of the process.
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-# The captured training step (dig_amd/step_graph.py) is a two-branch graph; ROCm's graph executor deals a forked graph's nodes over
+# The captured training step (dig_amd/step_graph.py, opt-in) is a two-branch graph; ROCm's graph executor deals a forked graph's nodes over
 # this many internal queues, and with more than two the data-gradient chain hops queues at every fork (ViT-S step replay: 26.3 ms
-# with 2 queues, 36.9 with 3, 35.1 with the default 4, 42.0 with 8).  Single-stream graphs (the evaluation decode) are not affected.
-_os.environ.setdefault("DEBUG_HIP_FORCE_GRAPH_QUEUES", "2")
+# with 2 queues, 36.9 with 3, 35.1 with the default 4, 42.0 with 8).  The runtime reads the variable when it initialises, so it is set here --
+# but only for a process that asked for the captured step (DIG_STEP_GRAPH=1): every other process keeps the runtime's default.  A caller that
+# turns the captured step on programmatically (`model.step_graph = True`: bench.py's extra measurement) sets the variable itself before the
+# first device call.
+if _os.environ.get("DIG_STEP_GRAPH", "0") == "1":
+    _os.environ.setdefault("DEBUG_HIP_FORCE_GRAPH_QUEUES", "2")

@@ -510,7 +510,10 @@ int fill_probs(const dig_wgrad_prob_t* in, int n, int fn, int wa, WgProb* out, i
 
 // C-ABI: see include/dig_hip.h
 extern "C" int dig_wgrad_group_supported(int I, int J, int R) {
-  return (I > 0 && J > 0 && R >= 64 && I % 128 == 0 && (J % 384 == 0 || J % 256 == 0) && R % 64 == 0) ? 1 : 0;
+  // (operands are addressed through 32-bit buffer offsets: R rows of at least I / J columns each must stay below 4 GiB -- the launcher
+  //  checks the real leading dimensions again)
+  return (I > 0 && J > 0 && R >= 64 && I % 128 == 0 && (J % 384 == 0 || J % 256 == 0) && R % 64 == 0 &&
+          (unsigned long long)R * (unsigned)I * 2ull < (1ull << 32) && (unsigned long long)R * (unsigned)J * 2ull < (1ull << 32)) ? 1 : 0;
 }
 extern "C" int dig_wgrad_group_fn(int J) { return J % 384 == 0 ? 3 : (J % 256 == 0 ? 2 : 0); }
 

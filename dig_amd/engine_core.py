@@ -478,7 +478,8 @@ class _Step:
                     on_side(fn, *tensors)
             if grp:
                 def wg(dy_, x_, dw_):
-                    assert grp.add(dy_, x_, dw_)
+                    if not grp.add(dy_, x_, dw_):                    # (never inside an assert: python -O would drop the weight gradient)
+                        raise RuntimeError("grouped weight gradient: a problem of this block does not fit the group's plan")
                     held.extend((dy_, x_))
                 wg(dx, act, g["mlp.fc2.weight"])
             else:

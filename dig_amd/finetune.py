@@ -518,7 +518,8 @@ class _TrainStep:
             held = []
             if grp:
                 def side_wg(dy_, x_, dw_):
-                    assert grp.add(dy_, x_, dw_)
+                    if not grp.add(dy_, x_, dw_):                    # (never inside an assert: python -O would drop the weight gradient)
+                        raise RuntimeError("grouped weight gradient: a problem of this block does not fit the group's plan")
                     held.extend((dy_, x_))
             else:
                 def side_wg(dy_, x_, dw_):

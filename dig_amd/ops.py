@@ -428,6 +428,8 @@ class WgradGroup:
         r = wgrad_group_route(dw.shape[0], dw.shape[1], rows, self.fn) if WGRAD_GROUP else None
         if r is None or len(self.cur) == 6 or (self.rows not in (None, rows)) or dw.stride(1) != 1:
             return False
+        if rows * max(dy.stride(0), x.stride(0)) * 2 >= 1 << 32:      # 32-bit buffer offsets in the kernel: the caller's tiled path takes it
+            return False
         trans, self.fn = r
         self.rows = rows
         A, B = (x, dy) if trans else (dy, x)

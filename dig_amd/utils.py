@@ -6,6 +6,7 @@ optimizer step -- runs as flat-arena kernels), get_grad_norm_ (:507-519), Smooth
 init_distributed_mode (:375-407), save_model / auto_load_model (:546-651)."""
 import datetime
 import glob
+import json
 import math
 import os
 import time
@@ -215,6 +216,64 @@ class MetricLogger:
 
 
 # ------------------------------------------------------------------------------------------------ checkpoints
+class _JsonlScalarWriter:
+    """SummaryWriter's add_scalar / flush / close on a JSON-lines file (`scalars.jsonl` in the log directory: one {"tag", "value", "step",
+    "wall_time"} object per line) -- what TensorboardLogger writes through when neither tensorboardX nor torch.utils.tensorboard can be imported."""
+
+    def __init__(self, log_dir):
+        os.makedirs(log_dir, exist_ok=True)
+        self.path = os.path.join(log_dir, "scalars.jsonl")
+        self._f = open(self.path, "a", encoding="utf-8")
+
+    def add_scalar(self, tag, value, step=None):
+        self._f.write(json.dumps({"tag": tag, "value": float(value), "step": None if step is None else int(step), "wall_time": time.time()}) + "\n")
+
+    def flush(self):
+        self._f.flush()
+
+    def close(self):
+        self._f.close()
+
+
+class TensorboardLogger(object):
+    """utils/utils.py:285-306 of the reference: the scalar writer `run_mae_pretraining_moco.py --log_dir` builds on rank 0 and hands to
+    train_one_epoch (`update(head=..., **scalars)` per step, `set_step()`, `flush()` per epoch).  The reference writes through tensorboardX;
+    here: tensorboardX if it is installed, else torch.utils.tensorboard, else a JSON-lines file with the same tags and steps."""
+
+    def __init__(self, log_dir):
+        writer = None
+        try:
+            from tensorboardX import SummaryWriter
+            writer = SummaryWriter(logdir=log_dir)
+        except ImportError:
+            try:
+                from torch.utils.tensorboard import SummaryWriter
+                writer = SummaryWriter(log_dir=log_dir)
+            except ImportError:
+                writer = _JsonlScalarWriter(log_dir)
+        self.writer = writer
+        self.step = 0
+
+    def set_step(self, step=None):
+        if step is not None:
+            self.step = step
+        else:
+            self.step += 1
+
+    def update(self, head='scalar', step=None, **kwargs):
+        for k, v in kwargs.items():
+            if v is None:
+                continue
+            if isinstance(v, torch.Tensor):
+                v = v.item()
+            if not isinstance(v, (float, int)):
+                raise TypeError(f"TensorboardLogger.update: {k} is {type(v).__name__}, not a scalar")
+            self.writer.add_scalar(head + "/" + k, v, self.step if step is None else step)
+
+    def flush(self):
+        self.writer.flush()
+
+
 def _to_cpu(obj):
     if isinstance(obj, torch.Tensor):
         return obj.detach().cpu().clone()

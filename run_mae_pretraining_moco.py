@@ -220,12 +220,20 @@ def main(args):
     print("Max WD = %.7f, Min WD = %.7f" % (max(wd_schedule_values), min(wd_schedule_values)))
     utils.auto_load_model(args=args, model=model, model_without_ddp=model_without_ddp, optimizer=optimizer, loss_scaler=loss_scaler)
 
+    # rank 0 writes the step scalars (loss, lr, weight decay, gradient norm) when --log_dir is given  (run_mae_pretraining_moco.py:357-361)
+    log_writer = None
+    if utils.get_rank() == 0 and args.log_dir is not None:
+        os.makedirs(args.log_dir, exist_ok=True)
+        log_writer = utils.TensorboardLogger(log_dir=args.log_dir)
+
     print(f"Start training for {args.epochs} epochs")
     start_time = time.time()
     for epoch in range(args.start_epoch, args.epochs):
         if hasattr(loader, "set_epoch"):
             loader.set_epoch(epoch)
-        train_stats = train_one_epoch(model, None, None, loader, None, optimizer, device, epoch, loss_scaler, args.clip_grad, log_writer=None,
+        if log_writer is not None:
+            log_writer.set_step(epoch * steps_per_epoch)
+        train_stats = train_one_epoch(model, None, None, loader, None, optimizer, device, epoch, loss_scaler, args.clip_grad, log_writer=log_writer,
                                       start_steps=epoch * steps_per_epoch, lr_schedule_values=lr_schedule_values,
                                       wd_schedule_values=wd_schedule_values, momentum_schedule=None, patch_size=patch_size[0],
                                       normlize_target=args.normlize_target, args=args)
@@ -233,6 +241,8 @@ def main(args):
             utils.save_model(args=args, model=model, model_without_ddp=model_without_ddp, optimizer=optimizer, loss_scaler=loss_scaler, epoch=epoch)
         log_stats = {**{f"train_{k}": v for k, v in train_stats.items()}, "epoch": epoch, "n_parameters": n_parameters}
         if args.output_dir and utils.is_main_process():
+            if log_writer is not None:
+                log_writer.flush()
             with open(os.path.join(args.output_dir, "log.txt"), mode="a", encoding="utf-8") as f:
                 f.write(json.dumps(log_stats) + "\n")
     print("Training time {}".format(str(datetime.timedelta(seconds=int(time.time() - start_time)))))

@@ -284,3 +284,25 @@ def test_pretrain_driver_parses_the_readme_command_and_shards_image_folders(tmp_
         assert all(len(b) == 4 for b in e0) and e0 != e1
         seen.append({sh for b in e0 for sh in b})
     assert not (seen[0] & seen[1])                                          # every crop has a distinct shape here: shards are disjoint
+
+
+def test_tensorboard_logger_surface(tmp_path):
+    """utils.TensorboardLogger (reference utils/utils.py:285-306): update(head=..., **scalars) / set_step() / flush(), as train_one_epoch
+    and the driver call them; without tensorboardX / tensorboard the scalars land in scalars.jsonl with the reference's tags and steps."""
+    import json
+    import torch
+    from dig_amd import utils
+    lw = utils.TensorboardLogger(log_dir=str(tmp_path))
+    lw.set_step(40)
+    lw.update(loss=1.5, head="loss")
+    lw.update(lr=torch.tensor(2e-4), min_lr=None, head="opt")
+    lw.set_step()
+    lw.update(grad_norm=3, head="opt")
+    lw.flush()
+    assert lw.step == 41
+    with pytest.raises(TypeError):
+        lw.update(loss="x", head="loss")
+    if isinstance(lw.writer, utils._JsonlScalarWriter):
+        rows = [json.loads(l) for l in open(tmp_path / "scalars.jsonl")]
+        assert [(r["tag"], r["step"]) for r in rows] == [("loss/loss", 40), ("opt/lr", 40), ("opt/grad_norm", 41)]
+        assert rows[0]["value"] == 1.5 and abs(rows[1]["value"] - 2e-4) < 1e-9
