@@ -23,7 +23,7 @@
 //   * projection: the wave re-reads ITS OWN 32 context rows (L2-warm, written by itself) as operand fragments in place of the ln1
 //     rows and runs six more blocks of the same tick loop over Wproj; the residual rows arrive by LDS-DMA into the (now free) K region,
 //     bias + residual are added in registers and x_mid is stored with 16-byte row stores.
-// LDS: ring 72 KiB + K 32 KiB + V 32 KiB + bias vectors 6 KiB = 142 KiB.  MFMAs per wave: 24 blocks x 48 + 6 heads x 64 = 1 536.
+// LDS: ring 72 KiB + K 32 KiB + V 32 KiB + bias vectors 6 KiB + store staging 16 KiB = 158 KiB.  MFMAs per wave: 24 blocks x 48 + 6 heads x 64 = 1 536.
 #include "common.h"
 #include "lds_dma.h"
 #include "attn_tiles.h"
@@ -36,8 +36,20 @@
 #ifndef DIG_AB_NSPLIT
 #define DIG_AB_NSPLIT 2                   // key parts of the online softmax (2: 64 score registers live, 4: 32)
 #endif
+#ifndef DIG_AB_NT
+#define DIG_AB_NT 1                       // non-temporal stores: bit 0 qkv (read again only by the backward: with the default policy the 150 MB of
+                                          // write-allocated lines cost the online form 15 us of 147; lab), 1 x_mid, 2 ctx (both re-read at once: default policy)
+#endif
+#ifndef DIG_AB_SKEW
+#define DIG_AB_SKEW 0
+#endif
 #ifndef DIG_AB_ABL
-#define DIG_AB_ABL 0                      // lab ablations: 1 no attention MFMAs / softmax, 2 no tick MFMAs, 4 no HBM stores
+#define DIG_AB_ABL 0                      // lab ablations: 1 no attention MFMAs, 2 no tick MFMAs, 4 no HBM stores, 8 no softmax arithmetic, 16 no ring DMA
+#endif
+#ifndef DIG_AB_TS                         // lab: per-wave time accounting (phase k starts here): 0 wait + barrier, 1 tick, 2 block epilogue, 3 attention, 4 row loads
+#define DIG_AB_TS(k)
+#define DIG_AB_TS_BEGIN()
+#define DIG_AB_TS_END()
 #endif
 
 namespace {
@@ -49,7 +61,8 @@ constexpr int RING_OFF = 0;
 constexpr int K_OFF = 3 * SLOTB;          // K fragments [key tile 8][k-step 4][lane 64] x 16 B;  projection phase: residual staging, 4 KiB per wave
 constexpr int V_OFF = K_OFF + 32768;      // V [256 keys][64] in layout U
 constexpr int VEC_OFF = V_OFF + 32768;    // fp32: qkv bias [1152], proj bias [384]
-constexpr int LDS_BYTES = VEC_OFF + (3 * KD + KD) * 4;
+constexpr int STG_OFF = VEC_OFF + (3 * KD + KD) * 4;   // store staging: 2 KiB per wave = [16 rows][64 columns]
+constexpr int LDS_BYTES = STG_OFF + 8 * 2048;
 constexpr int NTICK = 48;                 // 24 blocks x 2 ticks
 
 struct AbParams {
@@ -74,33 +87,46 @@ __device__ __forceinline__ void ab_wait_vm() {
 }
 __device__ __forceinline__ void ab_wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-// 16-byte row stores of a lane's 64 results (two 32-column blocks) given as packed pairs P[b][g][k] = (acc[b][4g + 2k], acc[b][4g + 2k + 1])
-__device__ __forceinline__ void store_rows_packed(bf16_t* row, unsigned (&P)[2][4][2], int hi) {
+// Row stores of a wave's finished block: 32 token rows x 64 columns, lane (row rr, half hi) holding its row's packed pairs
+// P[b][g][k] = columns 32 b + 8 g + 4 hi + 2 k + 0..1.  Written row-per-lane (each lane 16 bytes of its own row) a store instruction makes 64
+// separate 16-byte write requests, and at 256 workgroups x 8 waves the L2's request rate, not its bandwidth, prices the epilogue (lab: the
+// stores cost the momentum form 44 of 136 us).  So the block goes through 2 KiB of wave-private LDS, 16 rows at a time, and leaves in FULL
+// 128-byte lines: 8 adjacent lanes per row.  Still four 16-byte store instructions per block (the vmcnt arithmetic does not change).
+template <bool NT = false>
+__device__ __forceinline__ void store_block_lines(bf16_t* blk /* &T[wave's first row][first column] */, int ld, unsigned (&P)[2][4][2],
+                                                  unsigned char* stg, int lane) {
+  const int rr = lane & 31, hi = lane >> 5;
+  const int wr = (rr & 15) * 128 + hi * 8, ws = rr & 7;                   // write: row rr & 15, 16-byte position (4 b + g) ^ (row & 7)
+  const int r8 = lane >> 3, c = lane & 7;                                  // read: rows r8 / 8 + r8 of the pass, chunk c
 #pragma unroll
-  for (int dt = 0; dt < 2; ++dt) {
-    unsigned Q[4][2];
+  for (int pass = 0; pass < 2; ++pass) {
+    if ((rr >> 4) == pass) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) { Q[g][0] = P[dt][g][0]; Q[g][1] = P[dt][g][1]; }
+      for (int b = 0; b < 2; ++b)
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const auto r0 = __builtin_amdgcn_permlane32_swap(Q[0][k], Q[2][k], false, false);
-      Q[0][k] = r0[0]; Q[2][k] = r0[1];
-      const auto r1 = __builtin_amdgcn_permlane32_swap(Q[1][k], Q[3][k], false, false);
-      Q[1][k] = r1[0]; Q[3][k] = r1[1];
+        for (int g = 0; g < 4; ++g) *reinterpret_cast<uint2*>(stg + wr + (((4 * b + g) ^ ws) << 4)) = make_uint2(P[b][g][0], P[b][g][1]);
     }
-    bf16_t* o = row + dt * 32 + hi * 16;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    // (rows r8 and 8 + r8 of the pass: (8 + r8) & 7 == r8 & 7, one position for both)
+    const dig_u32x4 v0 = *reinterpret_cast<const dig_u32x4*>(stg + r8 * 128 + ((c ^ (r8 & 7)) << 4));
+    const dig_u32x4 v1 = *reinterpret_cast<const dig_u32x4*>(stg + (8 + r8) * 128 + ((c ^ (r8 & 7)) << 4));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
     if (!(DIG_AB_ABL & 4)) {
-      *reinterpret_cast<uint4*>(o) = make_uint4(Q[0][0], Q[0][1], Q[2][0], Q[2][1]);
-      *reinterpret_cast<uint4*>(o + 8) = make_uint4(Q[1][0], Q[1][1], Q[3][0], Q[3][1]);
+      dig_u32x4* d0 = reinterpret_cast<dig_u32x4*>(blk + (size_t)(16 * pass + r8) * ld + c * 8);
+      dig_u32x4* d1 = reinterpret_cast<dig_u32x4*>(blk + (size_t)(16 * pass + 8 + r8) * ld + c * 8);
+      if (NT) { __builtin_nontemporal_store(v0, d0); __builtin_nontemporal_store(v1, d1); }
+      else { *d0 = v0; *d1 = v1; }
     }
   }
 }
 
 // SAVE: online branch (qkv and lse are written).  Stores a wave issues behind a block's last ring pieces (they enter the vmcnt arithmetic):
 template <bool SAVE> struct AbCounts {
-  static constexpr int E_BLK = SAVE ? 4 : 0;                 // q / k / v rows of a block -> qkv
-  static constexpr int E_ATT = 4 + (SAVE ? 1 : 0);           // context rows (+ lse)
-  static constexpr int E_OUT = 4;                            // x_mid rows of a projection block
+  static constexpr int E_BLK = (DIG_AB_ABL & 4) ? 0 : (SAVE ? 4 : 0);           // q / k / v rows of a block -> qkv
+  static constexpr int E_ATT = (DIG_AB_ABL & 4) ? 0 : 4 + (SAVE ? 1 : 0);       // context rows (+ lse)
+  static constexpr int E_OUT = (DIG_AB_ABL & 4) ? 0 : 4;                        // x_mid rows of a projection block
   static constexpr int E_RES = 4;                            // residual pieces of a projection block (LDS-DMA, in front of the tick's ring pieces)
 };
 
@@ -119,6 +145,12 @@ __global__ __launch_bounds__(512) void attn_block_kernel(AbParams p) {
   const int tid0 = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   const int img = blockIdx.x;
+  DIG_AB_TS_BEGIN()
+#if DIG_AB_SKEW
+  // start skew: the workgroups of a launch run their 24 blocks in lock-step (they start together and do identical work), so every block
+  // epilogue is a chip-wide burst of stores; a start delay spread over one block period de-phases the CUs
+  for (int i = 0; i < (int)((blockIdx.x >> 3) & 15); ++i) __builtin_amdgcn_s_sleep(DIG_AB_SKEW);
+#endif
 
   const dig_u32x4 rWq = make_rsrc(p.Wqkv, 3u * KD * KD * 2u);
   const dig_u32x4 rWp = make_rsrc(p.Wp, (unsigned)(KD * KD * 2));
@@ -144,6 +176,7 @@ __global__ __launch_bounds__(512) void attn_block_kernel(AbParams p) {
     src_off = (unsigned)(row0 * KD * 2);
   };
   auto issue_piece = [&](int slot, int tau, int k, unsigned voff) {
+    if (DIG_AB_ABL & 16) voff = 0x7fffff00u;                                        // (lab: out-of-range source offsets -- the DMA is issued, nothing is fetched)
     dma16(lds0 + (unsigned)(RING_OFF + slot * SLOTB + k * 8192 + wave * 1024), voff, src_rs, src_off + (unsigned)(tau * 192 * 2));
   };
 #pragma unroll
@@ -182,10 +215,12 @@ __global__ __launch_bounds__(512) void attn_block_kernel(AbParams p) {
   auto tick = [&](auto slot_tag, auto tau_tag, auto nw_tag, auto pre_tag, f32x16 (&acc)[2], auto&& pre_fn) {
     constexpr int SLOT = decltype(slot_tag)::value, TAU = decltype(tau_tag)::value, NW = decltype(nw_tag)::value;
     constexpr int FREE = (SLOT + 2) % 3;
+    DIG_AB_TS(0)
     ab_wait_vm<NW>();
     ab_wait_lgkm0();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    DIG_AB_TS(1)
     if (decltype(pre_tag)::value) pre_fn();                                         // (projection: the block's residual pieces, in front of the ring pieces)
     const int tid = ab_opaque(tid0);
     const int rr = tid & 31, hi = (tid >> 5) & 1;
@@ -222,6 +257,7 @@ __global__ __launch_bounds__(512) void attn_block_kernel(AbParams p) {
     kstep(std::integral_constant<int, 6>{}, fa, fb); kstep(std::integral_constant<int, 7>{}, fb, fa);
     kstep(std::integral_constant<int, 8>{}, fa, fb); kstep(std::integral_constant<int, 9>{}, fb, fa);
     kstep(std::integral_constant<int, 10>{}, fa, fb); kstep(std::integral_constant<int, 11>{}, fb, fa);
+    DIG_AB_TS(2)
   };
   auto no_pre = []() {};
   using FALSE_ = std::false_type;
@@ -239,7 +275,7 @@ __global__ __launch_bounds__(512) void attn_block_kernel(AbParams p) {
         P[b][g][1] = pack_bf2((acc[b][4 * g + 2] + b4[2]) * al, (acc[b][4 * g + 3] + b4[3]) * al);
       }
   };
-  auto token_row = [&](int tid) { return (size_t)((unsigned)img * 256u + (unsigned)(wave * 32 + (tid & 31))); };
+  const size_t wave_row0 = (DIG_AB_ABL & 32) ? (size_t)wave * 32 : (size_t)img * 256 + wave * 32;   // first of the wave's 32 token rows (lab bit 32: every image writes image 0's rows: no HBM write volume)
 
   bf16x8 Qp[4];                                                                     // q_h of the wave's 32 tokens: B fragments of S^T = K Q^T, k-step (b, u)
 
@@ -272,7 +308,7 @@ __global__ __launch_bounds__(512) void attn_block_kernel(AbParams p) {
 #pragma unroll
         for (int u = 0; u < 2; ++u)
           Qp[2 * b + u] = __builtin_bit_cast(bf16x8, make_uint4(P[b][2 * u][0], P[b][2 * u][1], P[b][2 * u + 1][0], P[b][2 * u + 1][1]));
-      if (SAVE) store_rows_packed(p.qkv + token_row(tid) * (3 * KD) + h * 64, P, hi);
+      if (SAVE) store_block_lines<(DIG_AB_NT & 1) != 0>(p.qkv + wave_row0 * (3 * KD) + h * 64, 3 * KD, P, smem + STG_OFF + wave * 2048, tid & 63);
     }
     __builtin_amdgcn_sched_barrier(0);
     // k_h: A fragments of S^T for key tile `wave`, k-step (b, u): the lane's own 16 bytes
@@ -289,7 +325,7 @@ __global__ __launch_bounds__(512) void attn_block_kernel(AbParams p) {
 #pragma unroll
         for (int u = 0; u < 2; ++u)
           *reinterpret_cast<uint4*>(kw + (2 * b + u) * 1024) = make_uint4(P[b][2 * u][0], P[b][2 * u][1], P[b][2 * u + 1][0], P[b][2 * u + 1][1]);
-      if (SAVE) store_rows_packed(p.qkv + token_row(tid) * (3 * KD) + KD + h * 64, P, hi);
+      if (SAVE) store_block_lines<(DIG_AB_NT & 1) != 0>(p.qkv + wave_row0 * (3 * KD) + KD + h * 64, 3 * KD, P, smem + STG_OFF + wave * 2048, tid & 63);
     }
     __builtin_amdgcn_sched_barrier(0);
     // v_h: layout U, row = key (its ticks request the next head's q rows, or the first projection block)
@@ -307,7 +343,7 @@ __global__ __launch_bounds__(512) void attn_block_kernel(AbParams p) {
       for (int b = 0; b < 2; ++b)
 #pragma unroll
         for (int g = 0; g < 4; ++g) *reinterpret_cast<uint2*>(smem + (vw ^ ((4 * b + g) << 4))) = make_uint2(P[b][g][0], P[b][g][1]);
-      if (SAVE) store_rows_packed(p.qkv + token_row(tid) * (3 * KD) + 2 * KD + h * 64, P, hi);
+      if (SAVE) store_block_lines<(DIG_AB_NT & 1) != 0>(p.qkv + wave_row0 * (3 * KD) + 2 * KD + h * 64, 3 * KD, P, smem + STG_OFF + wave * 2048, tid & 63);
     }
     ab_wait_lgkm0();
     __builtin_amdgcn_s_barrier();
@@ -315,6 +351,7 @@ __global__ __launch_bounds__(512) void attn_block_kernel(AbParams p) {
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- attention: S^T[key, query] per 32-key tile (lane = query, registers = keys)
+    DIG_AB_TS(3)
     const int tid = ab_opaque(tid0);
     const int lane = tid & 63, hi = lane >> 5;
     f32x16 O[2];
@@ -393,7 +430,7 @@ __global__ __launch_bounds__(512) void attn_block_kernel(AbParams p) {
         float la = 0.f, lb = 0.f;
 #pragma unroll
         for (int e = 0; e < 16; e += 2) {
-          const float pa = __expf(S[kt][e] - m), pb = __expf(S[kt][e + 1] - m);
+          const float pa = (DIG_AB_ABL & 8) ? S[kt][e] : __expf(S[kt][e] - m), pb = (DIG_AB_ABL & 8) ? S[kt][e + 1] : __expf(S[kt][e + 1] - m);
           S[kt][e] = pa; S[kt][e + 1] = pb;
           la += pa; lb += pb;
         }
@@ -420,11 +457,17 @@ __global__ __launch_bounds__(512) void attn_block_kernel(AbParams p) {
       l = lo + up;
     }
     const float inv = 1.0f / l;
+    {
+      unsigned Pc[2][4][2];
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+      for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) O[dt][e] *= inv;
-    if (!(DIG_AB_ABL & 4)) store_rows(p.ctx + token_row(tid) * KD + h * 64, O, hi);
+        for (int g = 0; g < 4; ++g) {
+          Pc[dt][g][0] = pack_bf2(O[dt][4 * g] * inv, O[dt][4 * g + 1] * inv);
+          Pc[dt][g][1] = pack_bf2(O[dt][4 * g + 2] * inv, O[dt][4 * g + 3] * inv);
+        }
+      store_block_lines<(DIG_AB_NT & 4) != 0>(p.ctx + wave_row0 * KD + h * 64, KD, Pc, smem + STG_OFF + wave * 2048, lane);
+    }
     if (SAVE && hi == 0 && !(DIG_AB_ABL & 4)) p.lse[((size_t)img * NH + h) * 256 + wave * 32 + (lane & 31)] = m + __logf(l);
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -433,6 +476,7 @@ __global__ __launch_bounds__(512) void attn_block_kernel(AbParams p) {
   for (int h = 1; h < NH; ++h) head(FALSE_{}, h);
 
   // ---- projection: the wave's own context rows take the place of the ln1 rows
+  DIG_AB_TS(4)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                   // the wave's context stores are complete (same wave: visible to its loads)
   load_rows(p.ctx);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -480,7 +524,7 @@ __global__ __launch_bounds__(512) void attn_block_kernel(AbParams p) {
           P[b][g][0] = pack_bf2(v0, v1);
           P[b][g][1] = pack_bf2(v2, v3);
         }
-      store_rows_packed(p.out + token_row(tid) * KD + jb * 64, P, hi);
+      store_block_lines<(DIG_AB_NT & 2) != 0>(p.out + wave_row0 * KD + jb * 64, KD, P, smem + STG_OFF + wave * 2048, tid & 63);
       __builtin_amdgcn_sched_barrier(0);
     };
     block(I0{}, I1{}, std::integral_constant<int, FIRST ? 0 : C::E_OUT>{}, jb0);
@@ -490,6 +534,7 @@ __global__ __launch_bounds__(512) void attn_block_kernel(AbParams p) {
   triple(TRUE_{}, 0);
   triple(FALSE_{}, 3);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                   // the run-ahead pieces still on their way into LDS
+  DIG_AB_TS_END()
 }
 
 }  // namespace

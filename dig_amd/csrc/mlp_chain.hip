@@ -44,6 +44,9 @@
 #ifndef DIG_CHAIN_ABL
 #define DIG_CHAIN_ABL 0
 #endif
+#ifndef DIG_CHAIN_SIDE_AUX
+#define DIG_CHAIN_SIDE_AUX 2                // cache policy of the online forward's side-output stores (2 = nt)
+#endif
 #ifndef DIG_CHAIN_PRIO
 #define DIG_CHAIN_PRIO 0                  // 1: S-waves at s_setprio 1, 2: O-waves (static, for the whole kernel)
 #endif
@@ -282,7 +285,7 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainParams p) {
       if (p.ln_out) {
         const auto rLn = __builtin_amdgcn_make_buffer_rsrc((void*)p.ln_out, 0, p.x_bytes, 0x00020000);   // rows beyond R: dropped
 #pragma unroll
-        for (int s = 0; s < KD / 16; ++s) __builtin_amdgcn_raw_buffer_store_b128(xf[s], rLn, xo + s * 32, 0, 0);
+        for (int s = 0; s < KD / 16; ++s) __builtin_amdgcn_raw_buffer_store_b128(xf[s], rLn, xo + s * 32, 0, DIG_CHAIN_SIDE_AUX);   // (kept for the backward only)
       }
       if (p.ln_mean && hi == 0 && m0 + pair * 32 + rr < p.R) {
         p.ln_mean[m0 + pair * 32 + rr] = mean;
@@ -564,10 +567,12 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainParams p) {
             const int ch = cp ^ ((row >> 1) & 7);
             const unsigned go = (unsigned)(((size_t)(m0 + pair * 32 + row) * F + (c - 2) * FC + 8 * ch) * 2);   // rows beyond R: dropped
             const dig_u32x4 a = *reinterpret_cast<const dig_u32x4*>(pt + row * 128 + cp * 16);
-            __builtin_amdgcn_raw_buffer_store_b128(a, rS0, go, 0, 0);
+            // (forward: the GELU output and the pre-activation are read again only by the backward -- non-temporal stores, aux = 2: the 400 MB of a
+            //  launch do not go through write-allocated L2 lines)
+            __builtin_amdgcn_raw_buffer_store_b128(a, rS0, go, 0, MODE == 1 ? DIG_CHAIN_SIDE_AUX : 0);
             if (MODE == 1) {
               const dig_u32x4 b = *reinterpret_cast<const dig_u32x4*>(pt + (X_OFF - P_OFF) + row * 128 + cp * 16);
-              __builtin_amdgcn_raw_buffer_store_b128(b, rSide1, go, 0, 0);
+              __builtin_amdgcn_raw_buffer_store_b128(b, rSide1, go, 0, DIG_CHAIN_SIDE_AUX);
             }
           }
         }
