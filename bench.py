@@ -428,6 +428,24 @@ def main():
                    "replays": model._step_graph.replays, "note": "opt-in (DIG_STEP_GRAPH=1): same launches, bit-identical results, one "
                    "hipGraphLaunch per step; ROCm's graph executor runs the two-branch graph slower than the two eager streams"}
         model.step_graph = False
+    # ---- one-rank RCCL path (DIG_FORCE_DIST=1 under torch.distributed.run with one rank): the collectives of a step, counted on an extra step
+    dist_info = None
+    if force_dist and rank == 0 and getattr(model, "comm", None) is not None and hasattr(model.comm, "log"):
+        model.comm.log = []
+        run(1, a.warmup + a.steps)
+        torch.cuda.synchronize()
+        lg, model.comm.log = model.comm.log, None
+        kinds = {}
+        for op, n in lg:
+            k = op.split(":")[0]
+            kinds.setdefault(k, [0, 0])
+            kinds[k][0] += 1
+            kinds[k][1] += n
+        dist_info = {"world": world, "collectives_per_step": len(lg),
+                     "by_kind": {k: {"count": v[0], "elements": v[1]} for k, v in kinds.items()},
+                     "note": "every collective DistComm issues in one step (all-reduce of the BatchNorm statistics, fused key all-gather, 17 gradient buckets)"}
+    elif force_dist:
+        run(1, a.warmup + a.steps)                    # (every rank runs the same extra step: it contains collectives)
     # ---- roofline of the dominant kernel family: instrumented extra steps (outside the timed region)
     # (EVERY rank runs these steps -- they contain the step's collectives; only rank 0 instruments its launches)
     # `roofline.frac` = the family's algorithmic FLOP / its launch durations IN THE STEP (both streams running, as in the timed region and
@@ -535,7 +553,7 @@ def main():
             # the whole step against the HBM roof: PMC-measured bytes of every kernel family per step (profiles/r03_pmc_traffic.json,
             # same kernel sources) / step time / 8 TB/s -- the roof that actually prices this model width
             "step_hbm_frac": (roof["step_hbm_bytes"] / (dt / a.steps) / PEAK_HBM) if roof and roof.get("step_hbm_bytes") and B == 128 and a.model == "small" and a.workload == "mim_moco" else None,
-            "host_ms_per_step": host_ms, "step_graph": graphed,
+            "host_ms_per_step": host_ms, "step_graph": graphed, "dist": dist_info,
             "roofline": roof, ("mim_only" if a.workload == "mim_moco" else "mim_moco"): mim_only}
     if not a.no_cpu_baseline and world == 1:
         line["cpu_baseline"] = cpu_baseline(model_name, a.cpu_budget)

@@ -274,6 +274,9 @@ int dig_attn_fwd(const void* qkv, void* ctx, float* lse, int n_img, int heads, i
   return dig_attn_fwd_dropout(qkv, ctx, lse, n_img, heads, embed_dim, nullptr, N_TOK, stream);
 }
 
+// (one backward form in this build: the switch of the HIP build is accepted and ignored)
+int dig_attn_bwd_mode(int) { return 0; }
+
 // the attention sub-block in one call (HIP: csrc/attn_block.hip): here the same three steps, one after the other.  qkv / lse null: the
 // momentum branch keeps nothing (the q | k | v rows then live in a temporary)
 int dig_attn_block_supported(int heads, int embed_dim) { return (heads == 6 && embed_dim == 384) ? 1 : 0; }

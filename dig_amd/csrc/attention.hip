@@ -20,6 +20,12 @@
 #include "common.h"
 
 // phase time stamps for tools/experiments/attn_bwd_lab.hip (empty in the product build)
+#ifndef DIG_ATTN_SP_LAB
+#define DIG_ATTN_SP_LAB 0                    // lab: 1 no barrier between the steps (wrong sums: timing only)
+#endif
+#ifndef DIG_ATTN_BWD_SP_DEFAULT
+#define DIG_ATTN_BWD_SP_DEFAULT 0
+#endif
 #ifndef DIG_ATTN_TS
 #define DIG_ATTN_TS(i)
 #endif
@@ -461,7 +467,226 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const bf16_t* __restri
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// backward, single pass: one 8-wave workgroup per (image, head), Q / K / V / dO / O read ONCE, five matrix products per (query tile, key tile)
+// pair instead of the two-phase kernel's seven.
+//   * wave w owns the 32 keys 32 w ..: their K / V rows sit in its registers (B operands: lane = key), dK^T / dV^T accumulate in registers
+//     over the eight query tiles exactly as in phase B above;
+//   * the same dS tile also feeds dQ (contraction over KEYS): a lane-owns-a-key accumulator cannot be multiplied along its lane dimension,
+//     so the wave parks the bf16 dS tile in 2 KiB of its own LDS ([key][query] rows) and reads it back with the transposing read as the B
+//     operand of dQ^T[d, q] += K^T[d, key] dS^T[key, q] (K^T fragments: the wave's K block, transposed once through LDS at the start);
+//   * the eight waves' dQ^T contributions to one query tile are summed in LDS in fp32, in a FIXED order: at step s wave w works on query
+//     tile (w + s) mod 8, so no two waves touch one tile within a step, a workgroup barrier separates the steps, and tile t receives wave
+//     (t - s) mod 8's term at step s -- bit-reproducible, no atomics.  The partial tiles live in LDS in accumulator-register order
+//     (lane-linear 16-byte pieces: conflict-free), the last step's owner scales, rounds and stores the rows.
+// LDS: Q 32 KiB + dO 32 KiB + dQ 64 KiB + dS 16 KiB + lse / delta 2 KiB (+ 8 KiB column sums) = 146 (154) KiB: one workgroup per CU.
+// ------------------------------------------------------------------------------------------------
+constexpr int SP_DQ_OFF = 2 * TILE;
+constexpr int SP_DS_OFF = SP_DQ_OFF + 65536;
+constexpr int SP_VEC_OFF = SP_DS_OFF + 8 * 2048;
+constexpr int SP_CS_OFF = SP_VEC_OFF + 2 * N_TOK * 4;
+// the dS tile of a wave: [32 keys][32 queries] bf16, rows of 64 bytes in 8-byte pieces, piece index XORed with (row >> 1) & 7 (writes of a
+// 16-lane group then cover all banks; a transposing read touches 4 rows x 4 pieces per 16 lanes: distinct banks with or without the XOR)
+__device__ __forceinline__ int sp_ds_addr(int row, int col) { return row * 64 + ((((col >> 2) ^ (row >> 1)) & 7) << 3) + (col & 3) * 2; }
+
+template <bool BIAS>
+__global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ ctx,
+                                                          const bf16_t* __restrict__ dctx, const float* __restrict__ lse,
+                                                          bf16_t* __restrict__ dqkv, int D, int H, float scale, unsigned qkv_bytes,
+                                                          unsigned ctx_bytes, float* __restrict__ qsum, float* __restrict__ vsum) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* Qs = smem;
+  unsigned char* Gs = smem + TILE;
+  float* lse_s = reinterpret_cast<float*>(smem + SP_VEC_OFF);            // [256]  -lse
+  float* del_s = lse_s + N_TOK;                                          // [256]  -delta
+  float* csum_s = reinterpret_cast<float*>(smem + SP_CS_OFF);            // BIAS: [8][2][64] column sums of dQ and dV per 32-row block
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int img = blockIdx.x / H, h = blockIdx.x - img * H;
+  const int ld = 3 * D;
+  const size_t tok0 = (size_t)img * N_TOK;
+  const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)qkv, 0, qkv_bytes, 0x00020000);
+  const auto rg = __builtin_amdgcn_make_buffer_rsrc((void*)dctx, 0, ctx_bytes, 0x00020000);
+  const unsigned base = (unsigned)((tok0 * ld + h * DH) * 2);
+  const int hi = lane >> 5, rr = lane & 31;
+  const FragOff fo = frag_offsets(lane);
+  // O rows for delta: 8 lanes cover one 128-byte row, 64 rows per pass
+  bf16x8 orow[4];
+#pragma unroll
+  for (int ps = 0; ps < 4; ++ps)
+    orow[ps] = *reinterpret_cast<const bf16x8*>(ctx + (tok0 + ps * 64 + (tid >> 3)) * D + h * DH + (tid & 7) * 8);
+  stage_tile<512>(Qs, rs, base, ld, tid, wave);                                           // Q
+  stage_tile<512>(Gs, rg, (unsigned)((tok0 * D + h * DH) * 2), D, tid, wave);             // dO
+  // this wave's K / V rows as B operands (lane = key)
+  bf16x8 kf[4], vf[4];
+  {
+    const bf16_t* kp = qkv + (tok0 + wave * 32 + rr) * ld + D + h * DH + hi * 8;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      kf[s] = *reinterpret_cast<const bf16x8*>(kp + s * 16);
+      vf[s] = *reinterpret_cast<const bf16x8*>(kp + D + s * 16);
+    }
+  }
+  if (tid < N_TOK) lse_s[tid] = -lse[(size_t)blockIdx.x * N_TOK + tid];
+  // the wave's K block once more, in layout U inside its (not yet used) dQ region: the source of the transposed fragments K^T[d, key]
+  unsigned char* kst = smem + SP_DQ_OFF + wave * 8192;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) *reinterpret_cast<bf16x8*>(kst + u_addr(rr, 16 * s + 8 * hi)) = kf[s];
+  __syncthreads();
+  // delta[q] = sum_d dO[q, d] O[q, d]
+#pragma unroll
+  for (int ps = 0; ps < 4; ++ps) {
+    const int row = ps * 64 + (tid >> 3), c = tid & 7;
+    const bf16x8 gv = *reinterpret_cast<const bf16x8*>(Gs + row * 128 + ((c ^ swz(row)) << 4));
+    float acc = 0.f;
+    const uint4 ow = __builtin_bit_cast(uint4, orow[ps]), gw = __builtin_bit_cast(uint4, gv);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(dig_bf16x2, ow.x), __builtin_bit_cast(dig_bf16x2, gw.x), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(dig_bf16x2, ow.y), __builtin_bit_cast(dig_bf16x2, gw.y), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(dig_bf16x2, ow.z), __builtin_bit_cast(dig_bf16x2, gw.z), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(dig_bf16x2, ow.w), __builtin_bit_cast(dig_bf16x2, gw.w), acc, false);
+    acc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc), 0xB1, 0xF, 0xF, true));
+    acc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc), 0x4E, 0xF, 0xF, true));
+    acc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc), 0x104, 0xF, 0xF, true));
+    if (c == 0) del_s[row] = -acc;
+  }
+  bf16x8 ktf[2][2];                                                      // K^T[d = 32 dt + (lane & 31), keys of 16-key half u] (frag_tr's row order)
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) ktf[u][dt] = frag_tr_o(kst + u * 2048, fo, dt);
+  __syncthreads();
+
+  f32x16 dk[2], dv[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { dk[dt][e] = 0.f; dv[dt][e] = 0.f; }
+  unsigned char* dss = smem + SP_DS_OFF + wave * 2048;
+  // transposed dS fragment addresses (rows = keys {16 u + 4 hi + 0..3 | + 8}, column = query lane & 31)
+  int dsr[2][2];
+  {
+    const int i = lane & 15, col = ((lane >> 4) & 1) * 16 + (i & 3) * 4;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      dsr[u][0] = sp_ds_addr(16 * u + 4 * hi + (i >> 2), col);
+      dsr[u][1] = sp_ds_addr(16 * u + 8 + 4 * hi + (i >> 2), col);
+    }
+  }
+  typedef __attribute__((address_space(3))) bf16x4* lds4_p;
+#pragma unroll 1
+  for (int s = 0; s < 8; ++s) {
+    const int qt = (wave + s) & 7;
+    const unsigned char* Qt = Qs + qt * 4096;
+    const unsigned char* Gt = Gs + qt * 4096;
+    f32x16 st, dp;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int qr = qt * 32 + 8 * g + 4 * hi;
+      const float4 l4 = *reinterpret_cast<const float4*>(lse_s + qr);
+      const float4 d4 = *reinterpret_cast<const float4*>(del_s + qr);
+      st[g * 4] = l4.x; st[g * 4 + 1] = l4.y; st[g * 4 + 2] = l4.z; st[g * 4 + 3] = l4.w;
+      dp[g * 4] = d4.x; dp[g * 4 + 1] = d4.y; dp[g * 4 + 2] = d4.z; dp[g * 4 + 3] = d4.w;
+    }
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4) {
+      st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_direct_o(Qt, fo, k4), kf[k4], st, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_direct_o(Gt, fo, k4), vf[k4], dp, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float pe = __expf(st[e]);
+      st[e] = pe;
+      dp[e] = pe * dp[e];
+    }
+    bf16x8 pf[2], ds[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { pf[u] = pack8(st, u); ds[u] = pack8(dp, u); }
+    // dS -> the wave's LDS tile: lane (key rr, half hi) holds queries 8 g + 4 hi + 0..3 of its key
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const uint4 w = __builtin_bit_cast(uint4, ds[g >> 1]);
+      *reinterpret_cast<uint2*>(dss + sp_ds_addr(rr, 8 * g + 4 * hi)) = (g & 1) ? make_uint2(w.z, w.w) : make_uint2(w.x, w.y);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_o(Gt + u * 2048, fo, dt), pf[u], dv[dt], 0, 0, 0);
+        dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_o(Qt + u * 2048, fo, dt), ds[u], dk[dt], 0, 0, 0);
+      }
+    // dQ^T[d, q] of this (key block, query tile) pair
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    f32x16 dq[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) dq[dt][e] = 0.f;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_p)(dss + dsr[u][0]));
+      const bf16x4 h4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_p)(dss + dsr[u][1]));
+      const bf16x8 dst = __builtin_shufflevector(lo, h4, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[u][dt], dst, dq[dt], 0, 0, 0);
+    }
+    // into the tile's fp32 sum (accumulator-register order: piece r = 4 dt + g of lane l at (r 64 + l) 16 bytes)
+    float* acc = reinterpret_cast<float*>(smem + SP_DQ_OFF + qt * 8192) + lane * 4;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 v = {dq[dt][4 * g], dq[dt][4 * g + 1], dq[dt][4 * g + 2], dq[dt][4 * g + 3]};
+        f32x4* a = reinterpret_cast<f32x4*>(acc + (dt * 4 + g) * 256);
+        if (s > 0) v += *a;
+        *a = v;
+      }
+#if !(DIG_ATTN_SP_LAB & 1)
+    __syncthreads();
+#endif
+  }
+  // ---- results: dK, dV rows of the wave's keys; dQ rows of query tile `wave`
+  {
+    const int key = wave * 32 + rr;
+    bf16_t* okp = dqkv + (tok0 + key) * ld + D + h * DH;
+    store_rows(okp, dk, hi);
+    store_rows(okp + D, dv, hi);
+    if (BIAS) wave_colsum(dv, csum_s + wave * 128 + 64, lane);
+    f32x16 dq[2];
+    const float* acc = reinterpret_cast<const float*>(smem + SP_DQ_OFF + wave * 8192) + lane * 4;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(acc + (dt * 4 + g) * 256);
+        dq[dt][4 * g] = v[0] * scale; dq[dt][4 * g + 1] = v[1] * scale; dq[dt][4 * g + 2] = v[2] * scale; dq[dt][4 * g + 3] = v[3] * scale;
+      }
+    store_rows(dqkv + (tok0 + key) * ld + h * DH, dq, hi);
+    if (BIAS) wave_colsum(dq, csum_s + wave * 128, lane);
+  }
+  if (BIAS) {
+    __syncthreads();
+    if (tid < 128) {
+      float a = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) a += csum_s[w * 128 + tid];
+      float* dst = tid < 64 ? qsum : vsum;
+      dst[(size_t)img * D + h * DH + (tid & 63)] = a;
+    }
+  }
+}
+
 }  // namespace
+
+// which backward kernel dig_attn_bwd launches for full self-attention without dropout: 1 = single pass (attn_bwd_sp_kernel), 0 = two phases
+static int g_attn_bwd_single_pass = DIG_ATTN_BWD_SP_DEFAULT;
+extern "C" int dig_attn_bwd_mode(int single_pass) {
+  const int old = g_attn_bwd_single_pass;
+  if (single_pass == 0 || single_pass == 1) g_attn_bwd_single_pass = single_pass;
+  return old;
+}
 
 extern "C" int dig_attn_fwd_dropout(const void* qkv, void* ctx, float* lse, int n_img, int heads, int embed_dim,
                                     const dig_dropout_t* drop, int q_rows, hipStream_t stream) {
@@ -503,9 +728,24 @@ extern "C" int dig_attn_bwd_dropout(const void* qkv, const void* ctx, const void
   if (!aligned16(qkv) || !aligned16(ctx) || !aligned16(dctx) || !aligned16(dqkv)) return DIG_ERR_ALIGN;
   const size_t qb = (size_t)n_img * N_TOK * 3 * embed_dim * 2;
   if (qb >= (1ull << 32)) return DIG_ERR_ARG;
+  const int dev = dig_device();
+  if (g_attn_bwd_single_pass && !(drop && drop->thr) && nqb == 8) {
+    static bool sp_attr[DIG_MAX_DEVICES] = {};
+    if (!sp_attr[dev]) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_sp_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, SP_CS_OFF);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_sp_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, SP_CS_OFF + 8 * 128 * 4);
+      sp_attr[dev] = true;
+    }
+    if (q_colsum)
+      dig_launch(attn_bwd_sp_kernel<true>, dim3(n_img * heads), dim3(512), (unsigned)(SP_CS_OFF + 8 * 128 * 4), stream, (const bf16_t*)qkv, (const bf16_t*)ctx,
+                 (const bf16_t*)dctx, lse, (bf16_t*)dqkv, embed_dim, heads, scale, (unsigned)qb, (unsigned)(qb / 3), q_colsum, v_colsum);
+    else
+      dig_launch(attn_bwd_sp_kernel<false>, dim3(n_img * heads), dim3(512), (unsigned)SP_CS_OFF, stream, (const bf16_t*)qkv, (const bf16_t*)ctx,
+                 (const bf16_t*)dctx, lse, (bf16_t*)dqkv, embed_dim, heads, scale, (unsigned)qb, (unsigned)(qb / 3), q_colsum, v_colsum);
+    return dig_check_launch();
+  }
   const int lds = 2 * TILE + 2 * N_TOK * 4 + (q_colsum ? 8 * 128 * 4 : 0);
   static bool attr[DIG_MAX_DEVICES] = {};
-  const int dev = dig_device();
   if (!attr[dev]) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TILE + 2 * N_TOK * 4 + 8 * 128 * 4);
     hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TILE + 2 * N_TOK * 4 + 8 * 128 * 4);

@@ -36,6 +36,14 @@
 #ifndef DIG_AB_NSPLIT
 #define DIG_AB_NSPLIT 2                   // key parts of the online softmax (2: 64 score registers live, 4: 32)
 #endif
+#ifndef DIG_AB_P0
+#define DIG_AB_P0 2                        // k-steps of a tick behind which the three ring pieces of tick t + 2 are issued
+#define DIG_AB_P1 5
+#define DIG_AB_P2 8
+#endif
+#ifndef DIG_AB_PRIO
+#define DIG_AB_PRIO 0                      // 1: waves 4-7 at s_setprio 1 for the whole kernel
+#endif
 #ifndef DIG_AB_NT
 #define DIG_AB_NT 1                       // non-temporal stores: bit 0 qkv (read again only by the backward: with the default policy the 150 MB of
                                           // write-allocated lines cost the online form 15 us of 147; lab), 1 x_mid, 2 ctx (both re-read at once: default policy)
@@ -146,6 +154,9 @@ __global__ __launch_bounds__(512) void attn_block_kernel(AbParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   const int img = blockIdx.x;
   DIG_AB_TS_BEGIN()
+#if DIG_AB_PRIO
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
 #if DIG_AB_SKEW
   // start skew: the workgroups of a launch run their 24 blocks in lock-step (they start together and do identical work), so every block
   // epilogue is a chip-wide burst of stores; a start delay spread over one block period de-phases the CUs
@@ -246,9 +257,9 @@ __global__ __launch_bounds__(512) void attn_block_kernel(AbParams p) {
       } else {
         asm volatile("" ::"v"(cur[0]), "v"(cur[1]));
       }
-      if (S == 2) issue_piece(FREE, TAU, 0, piece_voff(tid, 0));
-      if (S == 5) issue_piece(FREE, TAU, 1, piece_voff(tid, 1));
-      if (S == 8) issue_piece(FREE, TAU, 2, piece_voff(tid, 2));
+      if (S == DIG_AB_P0) issue_piece(FREE, TAU, 0, piece_voff(tid, 0));
+      if (S == DIG_AB_P1) issue_piece(FREE, TAU, 1, piece_voff(tid, 1));
+      if (S == DIG_AB_P2) issue_piece(FREE, TAU, 2, piece_voff(tid, 2));
       __builtin_amdgcn_sched_barrier(0);
     };
     kstep(std::integral_constant<int, 0>{}, fa, fb); kstep(std::integral_constant<int, 1>{}, fb, fa);

@@ -356,7 +356,7 @@ class _Step:
     def _streams(self, dev):
         M = self.m
         main = torch.cuda.current_stream(dev)
-        side = M._side_stream(dev) if (getattr(M, "overlap_streams", True) and not BWD_SINGLE_STREAM) else main
+        side = M._bwd_side_stream(dev) if (getattr(M, "overlap_streams", True) and not BWD_SINGLE_STREAM) else main
         return main, side
 
     def _on_side(self, dev, fn, *tensors):

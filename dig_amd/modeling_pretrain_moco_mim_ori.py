@@ -400,6 +400,19 @@ class MoCo_ViT(nn.Module):
             st = self._side = torch.cuda.Stream(device=dev, priority=-1)
         return st
 
+    def _bwd_side_stream(self, dev):
+        """HIP stream of the backward's parameter-gradient reductions (bias / LayerNorm column sums: a few small launches per encoder block
+        that only consume what the data-gradient chain has produced).  DIG_BWD_SIDE_PRIO = high (the stream above), normal or low."""
+        import os
+        mode = os.environ.get("DIG_BWD_SIDE_PRIO", "high")
+        if mode == "high":
+            return self._side_stream(dev)
+        st = getattr(self, "_bwd_side", None)
+        if st is None or st.device != dev:
+            lo, hi = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, -1)
+            st = self._bwd_side = torch.cuda.Stream(device=dev, priority=(max(lo, hi) if mode == "low" else 0))
+        return st
+
     def _fwd_stream(self, dev):
         """HIP stream of the gradient-free momentum branch in the FORWARD.  DIG_FWD_MOM_PRIO = high (the weight-gradient stream itself),
         normal or low: with the big forward kernels owning the whole chip one at a time (persistent GEMM tiles, the fused MLP chain), the

@@ -660,6 +660,15 @@ def attn_block_fwd(ln1, x, qkv_w, qkv_b, proj_w, proj_b, n_img, heads, D, scale,
     return x_mid, ctx, qkv, lse
 
 
+def attn_bwd_mode(single_pass=None):
+    """Select (True / False) or query (None) the kernel behind attn_bwd for full self-attention: single pass or two phases.  Returns the previous setting."""
+    return bool(L.lib().dig_attn_bwd_mode(-1 if single_pass is None else int(bool(single_pass))))
+
+
+if os.environ.get("DIG_ATTN_BWD_SP") in ("0", "1"):
+    attn_bwd_mode(os.environ["DIG_ATTN_BWD_SP"] == "1")
+
+
 def attn_bwd(qkv, ctx, dctx, lse, n_img, heads, D, scale, bias_sums=False, drop=None, q_rows=256):
     """dqkv (dq pre-multiplied by `scale`).  bias_sums=True also returns the per-image column sums of the dq and dv parts
     ([n_img, D] fp32 each): the q_bias / v_bias gradient partials for colsum_partials()."""

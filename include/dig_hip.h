@@ -157,6 +157,11 @@ int dig_attn_fwd(const void* qkv, void* ctx, float* lse, int n_img, int heads, i
  * i.e. the q_bias / v_bias gradient partials, finished by dig_colsum_partials(.., n_img, embed_dim, ..). */
 int dig_attn_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse, void* dqkv, int n_img, int heads,
                  int embed_dim, float scale, float* q_colsum, float* v_colsum, hipStream_t stream);
+/* Which kernel dig_attn_bwd launches for full self-attention (256 query rows) without dropout: 1 = the single-pass kernel (one 8-wave workgroup
+ * per (image, head): q / k / v / dctx read once, five matrix products per tile pair, the dQ terms of the eight key blocks summed in LDS in a fixed
+ * order), 0 = the two-phase kernel (two 4-wave workgroups per CU, seven products).  Same results up to fp32 summation order; both are
+ * bit-reproducible run to run.  Returns the previous setting; any other argument only queries.  Process-wide. */
+int dig_attn_bwd_mode(int single_pass);
 
 /* The attention sub-block of an encoder block in ONE launch (csrc/attn_block.hip; D = 384, 6 heads of 64, 256 tokens per image):
  *     x_mid = x + proj(softmax(q k^T) v) + proj_b,   (q | k | v) = ln1 qkv_w^T + qkv_b, q scaled by `scale`

@@ -107,8 +107,23 @@ def test_gemm_wide_tile_variants(dev, I, J, R, bk):
     assert rel(ws.sum(0), dy.float().t() @ x.float()) < 2e-5
 
 
+@pytest.mark.parametrize("single_pass", [False, True])
 @pytest.mark.parametrize("Bn,H,scale,spike", [(2, 2, 1.0, False), (4, 6, 0.125, False), (3, 8, 0.125, True)])
-def test_attention_fwd_bwd(dev, Bn, H, scale, spike):
+def test_attention_fwd_bwd(dev, Bn, H, scale, spike, single_pass):
+    """single_pass: the backward as one 8-wave workgroup per (image, head) (dig_attn_bwd_mode(1): five matrix products per tile pair, dQ summed
+    in LDS in a fixed order) instead of the default two-phase kernel -- same bands."""
+    from dig_amd import ops
+    if single_pass and dev.type == "cpu":
+        pytest.skip("one backward form in the CPU build")
+    prev = ops.attn_bwd_mode(single_pass) if dev.type != "cpu" else False
+    try:
+        _attention_fwd_bwd(dev, Bn, H, scale, spike)
+    finally:
+        if dev.type != "cpu":
+            ops.attn_bwd_mode(prev)
+
+
+def _attention_fwd_bwd(dev, Bn, H, scale, spike):
     from dig_amd import ops
     D = H * 64
     qkv = torch.randn(Bn * 256, 3 * D, device=dev).bfloat16()
@@ -130,6 +145,7 @@ def test_attention_fwd_bwd(dev, Bn, H, scale, spike):
         assert rel(dqkv[:, lo:lo + D], g[:, lo:lo + D]) < 2e-2
     dqkv2, qs, vs = ops.attn_bwd(qkv, ctx, dctx, lse, Bn, H, D, scale, bias_sums=True)      # fused q_bias / v_bias gradients
     assert torch.equal(dqkv2, dqkv)
+    assert torch.equal(ops.attn_bwd(qkv, ctx, dctx, lse, Bn, H, D, scale), dqkv)            # bit-reproducible run to run
     bq, bv = torch.randn(D, device=dev), torch.randn(D, device=dev)
     bq0, bv0 = bq.clone(), bv.clone()
     ops.colsum_partials(qs, bq); ops.colsum_partials(vs, bv)
