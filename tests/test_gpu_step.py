@@ -761,8 +761,42 @@ def test_vit_small_b32_twenty_step_trajectory_vs_oracle():
     assert opt._step == n
 
 
+def test_vit_base_b16_every_tensor_gradient_vs_oracle():
+    """BASELINE configs[3]'s model (the "base" factory: D = 512, 8 heads, F = 2048) at B = 16: every trainable tensor against the fp32 oracle
+    with the bf16-autocast yardstick, as for ViT-S above -- the D = 512 forms of the grouped weight gradients (fn = 2) and the 256-row
+    data-gradient tiles are on this path, the fused MLP / attention launches (D = 384 only) are not."""
+    cfg = O.make_config("pretrain_simmim_moco_ori_vit_base_patch4_32x128")
+    seed, B = 41, 16
+    hp = O.StepHyper(lr=1.5e-4 * B / 256)
+    im, au, mk = O.synthetic_batch(B, cfg, seed * 1000)
+    model = build_model(cfg, *O.det_state(cfg, seed))
+    (stats,), _ = run_engine_steps(model, [(im, au, mk)], hp)
+    grads = {n: p.grad.detach().float().cpu().clone() for n, p in model.named_parameters() if p.requires_grad}
+    hp0 = dataclasses.replace(hp, moco_m=O.adjust_moco_momentum(0.0, 10, hp.moco_m))
+    torch.set_num_threads(max(8, min(64, os.cpu_count() or 8)))
+    ref_m, ref_g, _, _ = O.OracleTrainer(cfg, *O.det_state(cfg, seed)).loss_and_grads(im, au, mk, hp0)
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        _, bf_g, _, _ = O.OracleTrainer(cfg, *O.det_state(cfg, seed)).loss_and_grads(im, au, mk, hp0)
+    for k in ("loss", "loss_pixel", "loss_contrast"):
+        assert close(stats[k], ref_m[k]), (k, stats[k], ref_m[k])
+    cos = torch.nn.functional.cosine_similarity
+    tot = float(torch.sqrt(sum((r.double() ** 2).sum() for r in ref_g.values())))
+    bad, checked = [], 0
+    for n, g in grads.items():
+        r = ref_g[n].reshape(1, -1)
+        if float(r.norm()) < 1e-7 * tot:
+            continue
+        checked += 1
+        c_hip, c_bf = cos(g.reshape(1, -1), r).item(), cos(bf_g[n].float().reshape(1, -1), r).item()
+        q_hip, q_bf = (g.norm() / r.norm()).item(), (bf_g[n].float().norm() / r.norm()).item()
+        if (1 - c_hip) > 2 * (1 - c_bf) + 5e-3 or abs(q_hip - 1) > 2 * abs(q_bf - 1) + 3e-2:
+            bad.append((n, round(c_hip, 5), round(c_bf, 5), round(q_hip, 4), round(q_bf, 4)))
+    assert checked >= len(grads) - 4 and not bad, bad
+
+
 @pytest.mark.parametrize("switch", ["wgrad_off", "wgrad_pair", "wgrad_wa1", "wgrad_side_stream", "chain_mask3", "dgrad_128", "fwd_side", "fwd_serial",
-                                    "chain_no_ln", "bwd_single", "chain_bwd_every2", "per_entry_point", "autograd_function"])
+                                    "chain_no_ln", "bwd_single", "chain_bwd_every2", "per_entry_point", "autograd_function", "attn_three_launches",
+                                    "attn_bwd_single_pass"])
 def test_engine_switches_agree_with_the_default_path(switch):
     """Every non-default execution plan of the step (environment switches of dig_amd/ops.py and engine_core.py: launch groupings, tile
     codes, stream plans, fusion masks) against the default plan on one ViT-S step from the same state and batch: the losses agree, and
@@ -795,16 +829,24 @@ def test_engine_switches_agree_with_the_default_path(switch):
         "fwd_serial": [(engine_core, "FWD_MODE", "serial")], "chain_no_ln": [(ops, "MLP_CHAIN_LN", False)],
         "bwd_single": [(engine_core, "BWD_SINGLE_STREAM", True)], "chain_bwd_every2": [(engine_core, "CHAIN_BWD_EVERY", 2)],
         "per_entry_point": [(ops, "BLOCK_CALLS", False)], "autograd_function": [(engine_core, "STEP_OPS", False)],
+        # the attention sub-block as three launches (qkv GEMM -> dig_attn_fwd -> proj GEMM) instead of dig_attn_block_fwd: a different FORWARD kernel
+        "attn_three_launches": [(ops, "ATTN_BLOCK", False)],
+        "attn_bwd_single_pass": [],                                       # (a library-wide mode, set below: a different BACKWARD kernel)
     }
     tight = switch in ("wgrad_off", "wgrad_pair", "wgrad_wa1", "wgrad_side_stream", "fwd_side", "fwd_serial", "bwd_single")
     saved = [(m, k, getattr(m, k)) for m, k, _ in plans[switch]]
+    prev_mode = ops.attn_bwd_mode(True) if switch == "attn_bwd_single_pass" else None
     try:
         for m, k, v in plans[switch]:
             setattr(m, k, v)
+        if switch == "attn_three_launches":                               # (the cached block-call tables carry the fuse flag)
+            assert ops.attn_block_supported(cfg.heads, cfg.embed_dim) is False
         stats, g, _ = one_step()
     finally:
         for m, k, v in saved:
             setattr(m, k, v)
+        if prev_mode is not None:
+            ops.attn_bwd_mode(prev_mode)
     if switch == "autograd_function":
         # the default dispatches the step as the registered operators dig::pretrain_step_fwd / _bwd; the autograd.Function form runs the same code
         assert engine_core.STEP_OPS and torch.ops.dig.pretrain_step_fwd is not None and not engine_core._LIVE_STEPS
@@ -826,7 +868,7 @@ def test_engine_switches_agree_with_the_default_path(switch):
     for k in ("loss", "loss_pixel", "loss_contrast", "grad_norm"):
         assert abs(stats[k] - ref_stats[k]) <= (1e-5 if tight else 2e-2) * abs(ref_stats[k]) + 1e-6, (k, stats[k], ref_stats[k])      # (2e-2: this file's bf16 band)
     tol = 1e-5 if tight else 2e-2
-    fwd_plan = switch == "chain_no_ln"
+    fwd_plan = switch in ("chain_no_ln", "attn_three_launches")
     for name, sp in specs.items():
         a, b = g[sp.offset:sp.offset + sp.numel], ref_g[sp.offset:sp.offset + sp.numel]
         if float(b.norm()) == 0.0:

@@ -17,6 +17,14 @@ def family(name):
         return "mlp_chain_momentum"
     if "wgrad_wide_kernel" in name or "wgrad_group_kernel" in name:
         return "wgrad_group"
+    if "attn_block_kernel<true" in name:
+        return "attn_block_online"
+    if "attn_block_kernel" in name:
+        return "attn_block_momentum"
+    if "attn_bwd" in name:
+        return "attn_bwd"
+    if "attn_fwd" in name:
+        return "attn_fwd"
     m = re.search(r"gemm_pwide_kernel<(\d)", name)
     if m:
         return "fwd:" + {"4": "544", "3": "564"}.get(m.group(1), "5xx")

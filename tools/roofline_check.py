@@ -18,6 +18,14 @@ def family(name):
         return "mlp_chain_momentum"
     if "wgrad_wide_kernel" in name or "wgrad_group_kernel" in name:
         return "wgrad_group"
+    if "attn_block_kernel<true" in name:
+        return "attn_block_online"
+    if "attn_block_kernel" in name:
+        return "attn_block_momentum"
+    if "attn_bwd" in name:
+        return "attn_bwd"
+    if "attn_fwd" in name:
+        return "attn_fwd"
     m = re.search(r"gemm_pwide_kernel<(\d)", name)
     if m:
         return "fwd:" + {"4": "544", "3": "564"}.get(m.group(1), "5xx")
@@ -63,4 +71,11 @@ if v:
     out.append(f"bench line's dominant family: {dom} ({fl / 1e9:.1f} GFLOP per launch).  rocprofv3 average over its {c_fl} FLOP-carrying launches: {t_fl / c_fl / 1e3:.1f} us = "
                f"{rp / 1e12:.0f} TFLOP/s = {rp / 2.5e15:.3f} of the 2.5 PF bf16 roof; the bench line's roofline.frac (in-step, unprofiled run) is {b['roofline']['frac']:.3f}, "
                f"ratio {b['roofline']['frac'] / (rp / 2.5e15):.2f}")
+# the family the bench line names must be the one that owns the step: the kernel template instantiation with the largest total duration in the
+# rocprofv3 summary (every kernel of the trace, matrix-core or not)
+top = max(rows, key=lambda r: float(r["TotalDurationNs"]))
+top_family = family(top["Name"])
+out.append(f"top row of the rocprofv3 summary: {top['Name'][:60]} ({float(top['Percentage']):.2f} % of kernel time) = family {top_family}; "
+           f"bench line's roofline.family: {b['roofline'].get('family')} (profiled process: {u['roofline'].get('family')})")
 print("\n".join(out))
+assert top_family == b["roofline"].get("family") == u["roofline"].get("family"), "roofline.family is not the top kernel of the rocprofv3 summary"
