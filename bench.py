@@ -272,10 +272,25 @@ def cpu_baseline(model_name, budget_s=20.0):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import dig_oracle as O
     cfg = O.make_config(model_name)
-    # thread count: the best of 8 / 16 / 32 / 64 / 128 on the MI355X host (2 x EPYC 9575F, 256 hardware threads) is 16 --
-    # 6.5 / 8.5 / 7.4 / 3.2 / 1.6 samples/s (tools/cpu_baseline_threads.py): torch's default of 128 threads spends its time in fork/join
-    torch.set_num_threads(max(1, min(16, os.cpu_count() or 8)))
+    # thread count: measured in this run.  One step at batch 16 per candidate (after an untimed one), the best rate wins -- on the MI355X host
+    # (2 x EPYC 9575F, 256 hardware threads) that has been 16 threads (tools/cpu_baseline_threads.py: 6.5 / 8.5 / 7.4 / 3.2 / 1.6 samples/s
+    # at 8 / 16 / 32 / 64 / 128): torch's default of 128 threads spends its time in fork/join.  ~10 s of the budget.
     tr = O.OracleTrainer(cfg, seed=0)
+    ncpu = os.cpu_count() or 8
+    sweep = {}
+    if budget_s >= 10:
+        im_s, au_s, mk_s = O.synthetic_batch(16, cfg, 4321)
+        hp_s = O.StepHyper(lr=1.5e-4 * 16 / 256)
+        for nt in (8, 16, 32, 64):
+            if nt > ncpu:
+                break
+            torch.set_num_threads(nt)
+            tr.step(im_s, au_s, mk_s, hp_s)
+            t0 = time.perf_counter()
+            tr.step(im_s, au_s, mk_s, hp_s)
+            sweep[nt] = 16 / (time.perf_counter() - t0)
+    best_nt = max(sweep, key=sweep.get) if sweep else max(1, min(16, ncpu))
+    torch.set_num_threads(best_nt)
 
     def timed(Bc, max_steps, budget):
         im, au, mk = O.synthetic_batch(Bc, cfg, 1234)
@@ -303,8 +318,9 @@ def cpu_baseline(model_name, budget_s=20.0):
     return {"value": v128 if v128 is not None else v4, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
             "host_cpu": cpu_model, "host_logical_cpus": os.cpu_count(),
             "batch_128": {"value": v128, "steps": n128, "seconds": t128}, "batch_4": {"value": v4, "steps": n4, "seconds": t4},
-            "threads_note": "16 torch threads: the best of 8/16/32/64/128 on this host class (tools/cpu_baseline_threads.py: 6.5 / 8.5 / 7.4 / "
-                            "3.2 / 1.6 samples/s; all 256 logical CPUs are slower, torch's fork/join dominates)",
+            "thread_sweep_batch16": {str(k): round(v, 2) for k, v in sweep.items()},
+            "threads_note": f"{best_nt} torch threads: the best of the in-run sweep (`thread_sweep_batch16`, samples/s of one warm step at batch 16 per "
+                            "candidate); all 256 logical CPUs are slower, torch's fork/join dominates (tools/cpu_baseline_threads.py)",
             "sample": f"fp32 torch CPU restatement of the reference step (oracle/dig_oracle.py), same model/recipe: {n128} warm timed steps at batch 128 "
                       f"(`value`; one untimed step at that batch first), {n4} steps at batch 4 (BASELINE configs[0])"}
 

@@ -517,6 +517,7 @@ class BlockBwd(ctypes.Structure):
                                     "x", "ln1", "mu1", "rs1", "qkv", "ctx", "lse", "x_mid", "ln2", "mu2", "rs2", "pre", "act", "dy",
                                     "dln2", "dpre", "dctx", "dqkv", "bparts", "ws1", "ws2", "qs", "vs")] +
                 [(k, _I) for k in ("wg_fn", "wg_wa", "wg_splits", "wg_n_wg", "wg_fold_n", "wg_fold_splits")] + [("wg_trans", _I * 4)] +
+                [("wg_defer", _I), ("reserved1", _I)] +
                 [(k, _VP) for k in ("wg_map", "wg_slabs", "wg_fold_slabs", "wg_probs", "wg_fold_probs", "side")])
 
 

@@ -55,6 +55,9 @@ typedef struct dig_block_bwd {
    * block of a backward pass).  wg_trans[k] = 1: problem k puts the activation first and stores its result transposed. */
   int wg_fn, wg_wa, wg_splits, wg_n_wg, wg_fold_n, wg_fold_splits;
   int wg_trans[4];
+  int wg_defer;                        /* 1: wg_probs is filled but dig_wgrad_group is NOT launched: the caller launches the blocks' weight gradients
+                                          itself, behind the last data gradient (lab switch: the data-gradient chain then runs uninterrupted) */
+  int reserved1;
   const unsigned* wg_map; float* wg_slabs; const float* wg_fold_slabs;
   dig_wgrad_prob_t* wg_probs; const dig_wgrad_prob_t* wg_fold_probs;
   hipStream_t side;                    /* stream of the parameter-gradient reductions (may equal the call's stream) */
