@@ -35,7 +35,7 @@ WORKLOAD_TEXT = {
 }
 PEAK_BF16 = 2.5e15
 PEAK_HBM = 8.0e12                                                      # /opt/skills/guides/MI355X_MICROARCH.md
-PMC_FILE = "r04_pmc_traffic.json"                                      # rocprofv3 --pmc passes of this command (tools/collect_profiles.sh), stamped
+PMC_FILE = "r05_pmc_traffic.json"                                      # rocprofv3 --pmc passes of this command (tools/collect_profiles.sh), stamped
 #                                                                        with the hash of the kernel SOURCES they were measured on
 
 
@@ -182,7 +182,11 @@ class GemmProbe:
             fl = sum(2.0 * R * dw.shape[0] * dw.shape[1] for _, _, dw, _ in grp.cur)
             # grouped weight gradients: both operands of every problem once, fp32 read-modify-write of each dW (the slabs are not algorithmic)
             byt = sum(2.0 * R * (dw.shape[0] + dw.shape[1]) + 8.0 * dw.shape[0] * dw.shape[1] for _, _, dw, _ in grp.cur)
-            return probe._bracket("wgrad_group", fl, byt, lambda: sv["wg_launch"](grp))
+            probe._in_wg = True                               # (the launch goes through ops.L.call: the call hook below must not book it again)
+            try:
+                return probe._bracket("wgrad_group", fl, byt, lambda: sv["wg_launch"](grp))
+            finally:
+                probe._in_wg = False
         ops.WgradGroup.launch = timed_wg_launch
 
         # the one-call-per-encoder-block path (dig_encoder_block_fwd / _bwd): the same launches, issued inside the library -- booked here in
@@ -212,10 +216,15 @@ class GemmProbe:
                 self.rec.append(gemm_rec("dgrad", b.tile_dgrad, R, D, D))
                 self.rec.append(attn_rec(True, R, D))
                 shapes = ((D, Fh), (Fh, D), (D, D), (3 * D, D))
-                self.rec.append(("wgrad_group", sum(2.0 * R * o * i for o, i in shapes), sum(2.0 * R * (o + i) + 8.0 * o * i for o, i in shapes)))
+                if not b.wg_defer:                                            # (deferred plan: the grouped launch is issued by the caller, booked below)
+                    self.rec.append(("wgrad_group", sum(2.0 * R * o * i for o, i in shapes), sum(2.0 * R * (o + i) + 8.0 * o * i for o, i in shapes)))
                 self.rec.append(gemm_rec("dgrad", b.tile_dgrad, R, D, 3 * D))
             elif name == "dig_wgrad_group" and args[1] == 0:
                 self.rec.append(("wgrad_fold", 0.0, 0.0))                     # the fold-only launch that ends a backward
+            elif name == "dig_wgrad_group" and not getattr(self, "_in_wg", False):   # a grouped launch issued directly (the deferred plan): its problem table
+                pr = (ops._WgProb * int(args[1])).from_address(int(args[0]))
+                R = int(args[4])
+                self.rec.append(("wgrad_group", sum(2.0 * R * q.I * q.J for q in pr), sum(2.0 * R * (q.I + q.J) + 8.0 * q.I * q.J for q in pr)))
             return sv["call"](name, *args)
         ops.L.call = call
         return self
@@ -566,7 +575,7 @@ def main():
                                    f"T 0.2, 4 windows, mask 0.7, 2 views, AdamW wd 0.1, {B} samples/GPU, random-init weights",
                        "global_batch": B * world, "parallelism": f"dp{world}", "loss": float(stats.get("loss", float('nan')))},
             "step_mfma_frac": (value / world * fl / PEAK_BF16) if fl else None,
-            # the whole step against the HBM roof: PMC-measured bytes of every kernel family per step (profiles/r03_pmc_traffic.json,
+            # the whole step against the HBM roof: PMC-measured bytes of every kernel family per step (profiles/r05_pmc_traffic.json,
             # same kernel sources) / step time / 8 TB/s -- the roof that actually prices this model width
             "step_hbm_frac": (roof["step_hbm_bytes"] / (dt / a.steps) / PEAK_HBM) if roof and roof.get("step_hbm_bytes") and B == 128 and a.model == "small" and a.workload == "mim_moco" else None,
             "host_ms_per_step": host_ms, "step_graph": graphed, "dist": dist_info,

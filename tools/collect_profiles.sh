@@ -9,7 +9,7 @@
 #    gpurun_out/<tag>_pmc_kernel_counters.txt     MFMA / LDS utilisation, occupancy, instruction mix passes
 # Copy what should be judged into profiles/ afterwards.
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
