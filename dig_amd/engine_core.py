@@ -1017,12 +1017,21 @@ def dig_forward(model, image, aug_image, vis_mask_pos, m, only_mim_on_ori_img=Tr
     if anchor is None or anchor.device != image.device:
         anchor = model._anchor = torch.zeros(1, device=image.device, requires_grad=True)
     if STEP_OPS:
+        # The operator is EAGER-ONLY: it updates module state that is not in its argument list (momentum arena, BatchNorm statistics, the
+        # bf16 weight shadows) and its third output's shape depends on the mask, so a tracing compiler must neither dedupe / reorder it nor
+        # see it at all.
+        if torch.compiler.is_compiling():
+            raise RuntimeError("dig::pretrain_step_fwd is an eager-only operator (it updates the momentum encoder and the BatchNorm statistics "
+                               "of the module): call the model outside torch.compile")
         key = id(model)
         _MODELS[key] = model
-        contra, accs, vis_out = torch.ops.dig.pretrain_step_fwd(
-            anchor, model._flat["online"], image, aug_image, mask,
-            0.0 if isinstance(m, torch.Tensor) else m, m if isinstance(m, torch.Tensor) else None, mim_views, key,
-            next(_handles) if torch.is_grad_enabled() else 0)
+        handle = next(_handles) if torch.is_grad_enabled() else 0
+        try:
+            contra, accs, vis_out = torch.ops.dig.pretrain_step_fwd(
+                anchor, model._flat["online"], image, aug_image, mask,
+                0.0 if isinstance(m, torch.Tensor) else m, m if isinstance(m, torch.Tensor) else None, mim_views, key, handle)
+        finally:
+            _LIVE_STEPS.pop(handle, None)           # (normally taken over by the autograd context in _step_setup_context: never left behind)
     elif torch.is_grad_enabled():
         contra, accs, vis_out = _DigFn.apply(anchor, model, image, aug_image, mask, m, mim_views)
     else:

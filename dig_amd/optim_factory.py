@@ -59,7 +59,11 @@ class FusedAdamW(torch.optim.Optimizer):
             ops.fill_f32(g, 0.0)
         else:
             g.zero_()
-        self.model._grads_fresh = True          # the next backward may WRITE single-contribution gradients instead of adding (engine_core)
+        # The next backward of the model's own step may WRITE the single-contribution gradients of the BatchNorm-MLP heads instead of adding to
+        # zeros (engine_core: one launch less per head layer).  CONTRACT: nothing else may add into those .grad views between this call and
+        # that backward (an extra autograd path through the head weights, a regulariser, a hook) -- it would be overwritten; call
+        # `model._grads_fresh = False` after zero_grad() to get torch's accumulate-always behaviour.
+        self.model._grads_fresh = True
 
     @torch.no_grad()
     def step(self, closure=None, grad_scale: float = 1.0, finite_gate=None, dev_scalars=None):
