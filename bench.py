@@ -142,6 +142,15 @@ class GemmProbe:
             byt = 2.0 * R * D * 2 + 2.0 * R * Fh * 2 + 2.0 * 2 * D * Fh
             return self._bracket("mlp_chain_bwd", 4.0 * R * D * Fh, byt, lambda: sv["chain_bwd"](dy, w2t, pre, w1t, colsum=colsum, out=out))
         ops.mlp_chain_bwd = timed_chain_bwd
+        sv["chain_bwd_ln"] = ops.mlp_chain_bwd_ln
+
+        def timed_chain_bwd_ln(dy, w2t, pre, w1t, x_mid, ln_g, ln_mean, ln_rstd, colsum=True, out=None):
+            R, D = dy.shape
+            Fh = w2t.shape[0]
+            byt = 2.0 * R * D * 3 + 2.0 * R * Fh * 2 + 2.0 * 2 * D * Fh                   # + the rows norm2 normalised
+            return self._bracket("mlp_chain_bwd", 4.0 * R * D * Fh, byt,
+                                 lambda: sv["chain_bwd_ln"](dy, w2t, pre, w1t, x_mid, ln_g, ln_mean, ln_rstd, colsum=colsum, out=out))
+        ops.mlp_chain_bwd_ln = timed_chain_bwd_ln
 
         def attn_block_rec(R, D, save, n_img, heads):
             # the fused attention sub-block: qkv Linear + scores + context + proj Linear; algorithmic bytes = ln1, x and x_mid rows, both weight
@@ -212,7 +221,8 @@ class GemmProbe:
             elif name == "dig_encoder_block_bwd":
                 b = args[0]._obj
                 R, D, Fh = b.rows, b.D, b.F
-                self.rec.append(("mlp_chain_bwd", 4.0 * R * D * Fh, 2.0 * R * D * 2 + 2.0 * R * Fh * 2 + 2.0 * 2 * D * Fh))
+                # (fuse_ln2: norm2's backward rides in the launch -- one more [R, D] operand, x_mid; dy and the output are the chain's own)
+                self.rec.append(("mlp_chain_bwd", 4.0 * R * D * Fh, 2.0 * R * D * (3 if b.fuse_ln2 else 2) + 2.0 * R * Fh * 2 + 2.0 * 2 * D * Fh))
                 self.rec.append(gemm_rec("dgrad", b.tile_dgrad, R, D, D))
                 self.rec.append(attn_rec(True, R, D))
                 shapes = ((D, Fh), (Fh, D), (D, D), (3 * D, D))
@@ -233,6 +243,7 @@ class GemmProbe:
         import ctypes
         ops, sv = self.ops, self._saved
         ops.gemm, ops.mlp_chain_fwd, ops.mlp_chain_fwd_ln, ops.mlp_chain_bwd = sv["gemm"], sv["chain"], sv["chain_ln"], sv["chain_bwd"]
+        ops.mlp_chain_bwd_ln = sv["chain_bwd_ln"]
         ops.WgradGroup.launch = sv["wg_launch"]
         ops.attn_block_fwd = sv["attn_block"]
         ops.attn_fwd, ops.attn_bwd = sv["attn_fwd"], sv["attn_bwd"]
@@ -263,7 +274,7 @@ class GemmProbe:
 KERNEL_TEXT = {
     "mlp_chain_online": "dig_mlp_chain_fwd_ln, online form (mlp_chain_kernel<1, true>: norm2 -> fc1 -> GELU -> fc2 + residual -> next norm1 in one launch, writes what the backward reads)",
     "mlp_chain_momentum": "dig_mlp_chain_fwd_ln, momentum form (mlp_chain_kernel<0, true>: norm2 -> fc1 -> GELU -> fc2 + residual -> next norm1 in one launch, no side outputs)",
-    "mlp_chain_bwd": "dig_mlp_chain_bwd (mlp_chain_kernel<2>: the MLP's two data gradients x GELU' in one launch)",
+    "mlp_chain_bwd": "dig_mlp_chain_bwd_ln (mlp_chain_kernel<2>: the MLP's two data gradients x GELU' and norm2's backward in one launch)",
     "attn_bwd": "dig_attn_bwd (attn_bwd_kernel: dq, dk, dv of the softmax attention given d(ctx), one workgroup per (image, head), + the q / v bias sums)",
     "attn_fwd": "dig_attn_fwd (attn_fwd_kernel: softmax(q k^T) v, one workgroup per (image, head))",
     "attn_block_online": "dig_attn_block_fwd, online form (attn_block_kernel<true>: qkv Linear -> softmax(q k^T) v -> proj Linear + residual in one launch, one "

@@ -464,6 +464,22 @@ int dig_layernorm_bwd_finalize(const float* workspace, int rows, int D, float* d
   return DIG_OK;
 }
 
+int dig_layernorm_bwd_finalize_parts(const float* workspace, int parts, int D, float* dgamma, float* dbeta, float* dcolsum, hipStream_t) {
+  if (!workspace || !dgamma || !dbeta || parts <= 0 || D <= 0 || (D & 15)) return DIG_ERR_ARG;
+  for (int c = 0; c < D; ++c) {
+    float a = 0.f, b = 0.f, e = 0.f;
+    for (int p = 0; p < parts; ++p) {
+      a += workspace[(size_t)p * 3 * D + c];
+      b += workspace[(size_t)p * 3 * D + D + c];
+      e += workspace[(size_t)p * 3 * D + 2 * D + c];
+    }
+    dgamma[c] += a;
+    dbeta[c] += b;
+    if (dcolsum) dcolsum[c] += e;
+  }
+  return DIG_OK;
+}
+
 int dig_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean, const float* rstd,
                       const void* dres, void* dx, float* dgamma, float* dbeta, float* dcolsum, float* workspace, int rows, int D,
                       int fuse_gelu, hipStream_t stream) {
@@ -1133,6 +1149,47 @@ int dig_mlp_chain_bwd(const void* dy_, const void* w2t_, const void* pre_, const
         for (int r = pr * 32; r < std::min(R, pr * 32 + 32); ++r) a += bf2f(dpre[(size_t)r * F + f]);
         colsum_partials[(size_t)pr * F + f] = a;
       }
+  }
+  return DIG_OK;
+}
+
+int dig_mlp_chain_ln_parts(int R) { return (R + 127) / 128; }
+
+// dig_mlp_chain_bwd, then norm2's backward on its result: partial row p = 128-row block p
+int dig_mlp_chain_bwd_ln(const void* dy_, const void* w2t, const void* pre, const void* w1t, void* dpre_out, const void* x_mid_,
+                         const float* ln_g, const float* ln_mean, const float* ln_rstd, void* dx_mid_out, float* colsum_partials,
+                         float* ln_partials, int R, int D, int F, hipStream_t stream) {
+  if (!x_mid_ || !ln_g || !ln_mean || !ln_rstd || !ln_partials || !dx_mid_out) return DIG_ERR_ARG;
+  if (!aligned16(x_mid_)) return DIG_ERR_ALIGN;
+  const int rc = dig_mlp_chain_bwd(dy_, w2t, pre, w1t, dpre_out, dx_mid_out, colsum_partials, R, D, F, stream);
+  if (rc != DIG_OK) return rc;
+  const bf16_t* dy = (const bf16_t*)dy_; const bf16_t* x = (const bf16_t*)x_mid_;
+  bf16_t* dx = (bf16_t*)dx_mid_out;
+  const int np = dig_mlp_chain_ln_parts(R);
+#pragma omp parallel for
+  for (int pr = 0; pr < np; ++pr) {
+    float* w = ln_partials + (size_t)pr * 3 * D;
+    std::fill(w, w + 3 * D, 0.f);
+    std::vector<float> xh(D), d(D);
+    for (int r = pr * 128; r < std::min(R, pr * 128 + 128); ++r) {
+      float c1 = 0.f, c2 = 0.f;
+      for (int c = 0; c < D; ++c) {
+        xh[c] = (bf2f(x[(size_t)r * D + c]) - ln_mean[r]) * ln_rstd[r];
+        const float g = bf2f(dx[(size_t)r * D + c]);
+        w[c] += g * xh[c];
+        w[D + c] += g;
+        d[c] = g * ln_g[c];
+        c1 += d[c];
+        c2 += d[c] * xh[c];
+      }
+      c1 /= D;
+      c2 /= D;
+      for (int c = 0; c < D; ++c) {
+        const float e = bf2f(dy[(size_t)r * D + c]);
+        w[2 * D + c] += e;
+        dx[(size_t)r * D + c] = f2bf(e + ln_rstd[r] * (d[c] - c1 - xh[c] * c2));
+      }
+    }
   }
   return DIG_OK;
 }

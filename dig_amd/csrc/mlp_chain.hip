@@ -85,6 +85,10 @@ struct ChainParams {
   const float* nln_g; const float* nln_b;    // [KD]
   bf16_t* nln_out; float* nln_mean; float* nln_rstd;       // LayerNorm of `out` [R, KD] (+ statistics, or null)
   float ln_eps;
+  // MODE 2 with LN (dig_mlp_chain_bwd_ln): the LayerNorm BACKWARD of norm2 fused behind the data gradient.  X = dy is also the gradient of the
+  // residual path; resid = the rows norm2 normalised (x_mid); ln_g = its gamma; out receives dx_mid = dy + LN'(dX) instead of dX
+  const float* lnb_mean; const float* lnb_rstd;            // [R] statistics the forward kept
+  float* lnb_ws;                                           // [ceil(R/128)][3][KD] fp32 partial column sums: d(gamma), d(beta), column sums of dy
 };
 
 template <int N>
@@ -104,7 +108,11 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(
 template <int MODE, bool LN>
 __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  static_assert(!(LN && MODE == 2), "LayerNorm fusion is a forward feature");
+  constexpr bool LNB = LN && MODE == 2;                             // backward with norm2's backward in the O-waves' epilogue
+  constexpr int LNB_RS = KD * 2 + 8;                                // LNB: row pitch of the data-gradient tile [BM][KD] bf16 at LDS offset 0
+  constexpr int LNB_ROWSUM = BM * LNB_RS;                           //      [8 waves][32] fp32 row sums
+  constexpr int LNB_COLRED = LNB_ROWSUM + 8 * 32 * 4;               //      [8 waves][3][KD] fp32 column sums
+  static_assert(!LNB || LNB_COLRED + 8 * 3 * KD * 4 <= X_OFF + 2 * SLOT, "LayerNorm-backward phase: LDS map");
   constexpr int B1S_OFF = X_OFF + (MODE == 1 ? SLOT : 0);          // forward: b1 [F], b2 [KD] (, LN: ln_g, ln_b, nln_g, nln_b [KD] each) fp32 in LDS
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -235,6 +243,37 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainParams p) {
     }
   };
 
+  // ---- LNB: the rows of the LayerNorm-backward phase behind the role split.  Wave w owns tokens 16 w .. 16 w + 15 of the workgroup; a lane holds
+  // the column pairs q = lane + 64 j (j < 3) of each: dword loads and stores of 256 contiguous bytes.  x_mid and dy rows are requested as soon
+  // as a wave has left the pipeline (S-waves: in front of the barrier they wait at for the O-waves; O-waves: behind their tile stores).
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  unsigned xr[LNB ? 16 : 1][3], yr[LNB ? 16 : 1][3];
+  float ln_m = 0.f, ln_r = 0.f;                                      // statistics of token (lane & 15) of the wave's 16
+  f32x2 gm[3];                                                        // gamma of the lane's columns
+  auto ln_rows_load = [&]() {
+    if constexpr (LNB) {
+      int t = threadIdx.x;
+      asm volatile("" : "+v"(t));
+      const unsigned vo = (unsigned)((t & 63) * 4);
+      const int rc = min(m0 + wave * 16 + (t & 15), p.R - 1);
+      ln_m = p.lnb_mean[rc];
+      ln_r = p.lnb_rstd[rc];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) gm[j] = *reinterpret_cast<const f32x2*>(p.ln_g + 2 * ((t & 63) + 64 * j));
+      const auto rXm = __builtin_amdgcn_make_buffer_rsrc((void*)p.resid, 0, p.x_bytes, 0x00020000);      // rows beyond R: zeros
+      const auto rDy = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, p.x_bytes, 0x00020000);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const unsigned so = (unsigned)(m0 + wave * 16 + i) * (unsigned)(KD * 2);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          xr[i][j] = __builtin_amdgcn_raw_buffer_load_b32(rXm, vo + (unsigned)(256 * j), so, 0);
+          yr[i][j] = __builtin_amdgcn_raw_buffer_load_b32(rDy, vo + (unsigned)(256 * j), so, 0);
+        }
+      }
+    }
+  };
+
   const int psw = (rr >> 1) & 7;
   if (DIG_CHAIN_PRIO == 1 && role == 0) __builtin_amdgcn_s_setprio(1);
   if (DIG_CHAIN_PRIO == 2 && role == 1) __builtin_amdgcn_s_setprio(1);
@@ -246,7 +285,7 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainParams p) {
 #pragma unroll
     for (int s = 0; s < KD / 16; ++s) xf[s] = __builtin_amdgcn_raw_buffer_load_b128(rX, xo + s * 32, 0, 0);
     stage_vectors();
-    if (LN && p.ln_g) {
+    if (LN && MODE != 2 && p.ln_g) {
       // LayerNorm of the lane's token on the way in.  The row is split between lanes rr and rr + 32 (k = 16 s + 8 hi ..): statistics by
       // v_dot2 on the packed pairs (sum and sum of squares, fp32), one cross-half exchange, then y = (x - mean) rstd g + b in place.
       float s1 = 0.f, s2 = 0.f;
@@ -451,6 +490,12 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainParams p) {
     if (DIG_CHAIN_ABL & 1) asm volatile("" ::"v"(Sa[0]), "v"(Sa[1]), "v"(Sb[0]), "v"(Sb[1]));
     DIG_CHAIN_T(3)
     DIG_CHAIN_T_END()
+    if constexpr (LNB) {
+      wait_vm<0>();                                                    // this wave's last (past-the-end) DMA has landed
+      ln_rows_load();
+      __builtin_amdgcn_s_barrier();                                    // every wave has left the rings and tiles: the O-waves store their rows there
+      asm volatile("" ::: "memory");
+    }
   } else {
     // =========================================================== O-wave =====================================================
     // Output accumulators start as bias + residual (the epilogue is then a convert-and-store).  The O-wave has nothing to multiply
@@ -459,7 +504,8 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainParams p) {
     load_vectors();
     stage_vectors();
     f32x16 D2[NJB];
-    const auto rRes = __builtin_amdgcn_make_buffer_rsrc((void*)p.resid, 0, p.resid ? p.x_bytes : 0, 0x00020000);   // null: zeros; rows beyond R: zeros
+    const auto rRes = __builtin_amdgcn_make_buffer_rsrc((void*)p.resid, 0, (p.resid && !LNB) ? p.x_bytes : 0, 0x00020000);   // null: zeros; rows beyond R: zeros
+    // (LNB: resid holds the rows norm2 normalised -- an operand of the epilogue, not a term of the accumulators)
     dig_u32x4 rq[4];                                                   // residual chunks of one group (2 column blocks) in flight
     const unsigned ro16 = (unsigned)(((size_t)(m0 + pair * 32 + rr) * KD + 16 * hi) * 2);
     // group k (0..5) = column blocks 2k, 2k + 1: requested in idle tick k, unpacked in tick k + 1 (one tick of latency cover).  A lane
@@ -598,6 +644,33 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainParams p) {
     int tid2 = threadIdx.x;
     asm volatile("" : "+v"(tid2));                                    // re-derive the lane's row here: kept live across the loop it would be spilled
     const int row = m0 + pair * 32 + (tid2 & 31), hi2 = (tid2 >> 5) & 1;
+    auto store_block = [&](bf16_t* dst, unsigned (&Pk)[4][2]) {      // one 32-column block of the lane's row: 16 contiguous columns per lane
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const auto r0 = __builtin_amdgcn_permlane32_swap(Pk[0][k], Pk[2][k], false, false);
+        Pk[0][k] = r0[0]; Pk[2][k] = r0[1];
+        const auto r1 = __builtin_amdgcn_permlane32_swap(Pk[1][k], Pk[3][k], false, false);
+        Pk[1][k] = r1[0]; Pk[3][k] = r1[1];
+      }
+      *reinterpret_cast<uint4*>(dst) = make_uint4(Pk[0][0], Pk[0][1], Pk[2][0], Pk[2][1]);
+      *reinterpret_cast<uint4*>(dst + 8) = make_uint4(Pk[1][0], Pk[1][1], Pk[3][0], Pk[3][1]);
+    };
+    if constexpr (LNB) {
+      // ---- norm2's backward follows for all eight waves (below the role split): the data gradient goes to LDS as the bf16 rows a separate
+      // LayerNorm launch would read back -- [128 tokens][KD] bf16, row pitch LNB_RS (8 bytes of padding: the 32 tokens of a wave's store
+      // land in different banks), over the rings and tiles every wave has left behind the barrier.
+      wait_vm<0>();                                                    // this wave's last (past-the-end) ring DMA has landed
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const unsigned gbase = lds_addr(smem) + (unsigned)((pair * 32 + (tid2 & 31)) * LNB_RS + hi2 * 8);
+#pragma unroll
+      for (int jb = 0; jb < NJB; ++jb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          lds_write8(gbase + (unsigned)((jb * 16 + 4 * g) * 4),
+                     make_uint2(pack_bf2(D2[jb][4 * g], D2[jb][4 * g + 1]), pack_bf2(D2[jb][4 * g + 2], D2[jb][4 * g + 3])));
+      ln_rows_load();
+    } else
     if (row < p.R) {
       const bool lno = LN && p.nln_out != nullptr;
       float s1 = 0.f, s2 = 0.f;
@@ -617,17 +690,6 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainParams p) {
             D2[jb][2 * g + 1] = __uint_as_float(u & 0xffff0000u);
           }
       }
-      auto store_block = [&](bf16_t* dst, unsigned (&Pk)[4][2]) {      // one 32-column block of the lane's row: 16 contiguous columns per lane
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          const auto r0 = __builtin_amdgcn_permlane32_swap(Pk[0][k], Pk[2][k], false, false);
-          Pk[0][k] = r0[0]; Pk[2][k] = r0[1];
-          const auto r1 = __builtin_amdgcn_permlane32_swap(Pk[1][k], Pk[3][k], false, false);
-          Pk[1][k] = r1[0]; Pk[3][k] = r1[1];
-        }
-        *reinterpret_cast<uint4*>(dst) = make_uint4(Pk[0][0], Pk[0][1], Pk[2][0], Pk[2][1]);
-        *reinterpret_cast<uint4*>(dst + 8) = make_uint4(Pk[1][0], Pk[1][1], Pk[3][0], Pk[3][1]);
-      };
       bf16_t* orow = p.out + (size_t)row * KD + hi2 * 16;
 #pragma unroll
       for (int jb = 0; jb < NJB; ++jb) {
@@ -665,6 +727,102 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainParams p) {
       }
     }
   }
+  if constexpr (LNB) {
+    // =========================================== norm2's backward on the workgroup's 128 rows, all eight waves =====================
+    // dx_mid = dy + rstd (gamma g - mean_c(gamma g) - xhat mean_c(gamma g xhat)), g = the data gradient in LDS.  A wave takes 16 tokens, a
+    // lane 6 columns of each: the two row sums of the 16 tokens are reduced together (32 values: halves traded by v_permlane32_swap, rows by
+    // v_permlane16_swap, the last 16 lanes by DPP -- 80 operations instead of 192 cross-lane round trips) and come back as wave-uniform
+    // scalars; the parameter-gradient column sums (d gamma, d beta, column sums of dy = fc2's bias gradient) are plain per-lane sums over the
+    // wave's tokens, summed over the eight waves through LDS in a fixed order: ONE partial row per workgroup.
+    wait_lgkm0();                                                      // (O-waves: the tile stores)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    const int ln = t & 63;
+    const int r0 = m0 + wave * 16;
+    auto lo16 = [](unsigned u) { return __uint_as_float(u << 16); };
+    auto up16 = [](unsigned u) { return __uint_as_float(u & 0xffff0000u); };
+    auto fbits = [](float f) { return __float_as_uint(f); };
+    const float ln_n = -ln_m * ln_r;                                   // xhat = x rstd + nmr
+    const unsigned char* grow = smem + (wave * 16) * LNB_RS + ln * 4;
+    float rstd[16], nmr[16];                                           // (wave-uniform)
+    float v[32];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      rstd[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ln_r), i));
+      nmr[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ln_n), i));
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const unsigned gw = *reinterpret_cast<const unsigned*>(grow + i * LNB_RS + 256 * j);
+        const float a0 = lo16(gw) * gm[j][0], a1 = up16(gw) * gm[j][1];
+        s1 += a0 + a1;
+        s2 = fmaf(a0, fmaf(lo16(xr[i][j]), rstd[i], nmr[i]), s2);
+        s2 = fmaf(a1, fmaf(up16(xr[i][j]), rstd[i], nmr[i]), s2);
+      }
+      v[i] = s1; v[16 + i] = s2;
+    }
+    float w16[16], u8[8];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {                                     // lower half of the wave: values j, upper half: values 16 + j
+      const auto r = __builtin_amdgcn_permlane32_swap(fbits(v[j]), fbits(v[j + 16]), false, false);
+      const unsigned a = r[0], b = r[1];
+      w16[j] = __uint_as_float(a) + __uint_as_float(b);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {                                      // row q of 16 lanes: values 8 q + j
+      const auto r = __builtin_amdgcn_permlane16_swap(fbits(w16[j]), fbits(w16[j + 8]), false, false);
+      const unsigned a = r[0], b = r[1];
+      float x = __uint_as_float(a) + __uint_as_float(b);
+      x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));      // lanes ^ 1
+      x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));      // lanes ^ 2
+      x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, true));     // row_half_mirror
+      x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xF, 0xF, true));     // row_mirror
+      u8[j] = x * (1.0f / KD);
+    }
+    const auto rOut = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, p.x_bytes, 0x00020000);          // rows beyond R: not written
+    const unsigned vo = (unsigned)(ln * 4);
+    f32x2 dg[3], db[3], dc[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { dg[j] = f32x2{0.f, 0.f}; db[j] = f32x2{0.f, 0.f}; dc[j] = f32x2{0.f, 0.f}; }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float c1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, u8[i & 7]), 16 * (i >> 3)));
+      const float c2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, u8[i & 7]), 32 + 16 * (i >> 3)));
+      const unsigned so = (unsigned)(r0 + i) * (unsigned)(KD * 2);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const unsigned gw = *reinterpret_cast<const unsigned*>(grow + i * LNB_RS + 256 * j);
+        const float g0 = lo16(gw), g1 = up16(gw);
+        const float xh0 = fmaf(lo16(xr[i][j]), rstd[i], nmr[i]), xh1 = fmaf(up16(xr[i][j]), rstd[i], nmr[i]);
+        const float y0 = lo16(yr[i][j]), y1 = up16(yr[i][j]);
+        const float d0 = fmaf(rstd[i], fmaf(-xh0, c2, g0 * gm[j][0] - c1), y0);
+        const float d1 = fmaf(rstd[i], fmaf(-xh1, c2, g1 * gm[j][1] - c1), y1);
+        __builtin_amdgcn_raw_buffer_store_b32(pack_bf2(d0, d1), rOut, vo + (unsigned)(256 * j), so, 0);
+        dg[j][0] = fmaf(g0, xh0, dg[j][0]); dg[j][1] = fmaf(g1, xh1, dg[j][1]);
+        db[j][0] += g0; db[j][1] += g1;
+        dc[j][0] += y0; dc[j][1] += y1;
+      }
+    }
+    float* cr = reinterpret_cast<float*>(smem + LNB_COLRED) + wave * (3 * KD) + 2 * ln;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      *reinterpret_cast<f32x2*>(cr + 128 * j) = dg[j];
+      *reinterpret_cast<f32x2*>(cr + KD + 128 * j) = db[j];
+      *reinterpret_cast<f32x2*>(cr + 2 * KD + 128 * j) = dc[j];
+    }
+    wait_lgkm0();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const float* cs = reinterpret_cast<const float*>(smem + LNB_COLRED);
+    for (int c = t; c < 3 * KD; c += 512) {
+      float a = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) a += cs[w * (3 * KD) + c];
+      p.lnb_ws[(size_t)blockIdx.x * (3 * KD) + c] = a;
+    }
+  }
 }
 
 template <int MODE, bool LN = false>
@@ -692,6 +850,8 @@ void no_layernorm(ChainParams& p) {
   p.ln_out = p.nln_out = nullptr;
   p.ln_mean = p.ln_rstd = p.nln_mean = p.nln_rstd = nullptr;
   p.ln_eps = 0.f;
+  p.lnb_mean = p.lnb_rstd = nullptr;
+  p.lnb_ws = nullptr;
 }
 
 int check_common(const void* x, const void* b1, const void* b2, const void* out, int R, int D, int F) {
@@ -753,6 +913,26 @@ extern "C" int dig_mlp_chain_fwd_ln(const void* x, const void* resid, const floa
   return pre_out ? launch_chain<1, true>(p, stream) : launch_chain<0, true>(p, stream);
 }
 
+// dig_mlp_chain_bwd with norm2's backward behind it: dx_mid = dy + LN2'(dX) in place of dX, and the three parameter-gradient partial sums
+// ([dig_mlp_chain_ln_parts(R)][3][D] fp32: d(gamma), d(beta), column sums of dy = fc2's bias gradient) for dig_layernorm_bwd_finalize_parts
+extern "C" int dig_mlp_chain_bwd_ln(const void* dy, const void* w2t, const void* pre, const void* w1t, void* dpre_out, const void* x_mid,
+                                    const float* ln_g, const float* ln_mean, const float* ln_rstd, void* dx_mid_out, float* colsum_partials,
+                                    float* ln_partials, int R, int D, int F, hipStream_t stream) {
+  const int rc = check_common(dy, w2t, w1t, dx_mid_out, R, D, F);
+  if (rc != DIG_OK) return rc;
+  if (!pre || !dpre_out || !x_mid || !ln_g || !ln_mean || !ln_rstd || !ln_partials) return DIG_ERR_ARG;
+  if ((size_t)(R + BM) * D * 2 >= (1ull << 32)) return DIG_ERR_UNSUPPORTED;       // (row offsets of the LayerNorm phase are 32-bit)
+  if (!aligned16(pre) || !aligned16(dpre_out) || !aligned16(x_mid) || (colsum_partials && !aligned16(colsum_partials))) return DIG_ERR_ALIGN;
+  ChainParams p;
+  p.X = (const bf16_t*)dy; p.B1 = (const bf16_t*)w2t; p.B2 = (const bf16_t*)w1t; p.bias1 = nullptr; p.bias2 = nullptr;
+  p.resid = (const bf16_t*)x_mid; p.out = (bf16_t*)dx_mid_out; p.side0 = (bf16_t*)dpre_out; p.side1 = (bf16_t*)pre; p.colsum = colsum_partials;
+  p.R = R; p.F = F;
+  p.x_bytes = (unsigned)((size_t)R * D * 2); p.w_bytes = (unsigned)((size_t)F * D * 2); p.side_bytes = (unsigned)((size_t)R * F * 2);
+  no_layernorm(p);
+  p.ln_g = ln_g; p.lnb_mean = ln_mean; p.lnb_rstd = ln_rstd; p.lnb_ws = ln_partials;
+  return launch_chain<2, true>(p, stream);
+}
+
 extern "C" int dig_mlp_chain_bwd(const void* dy, const void* w2t, const void* pre, const void* w1t, void* dpre_out, void* dx_out,
                                  float* colsum_partials, int R, int D, int F, hipStream_t stream) {
   const int rc = check_common(dy, w2t, w1t, dx_out, R, D, F);
@@ -767,6 +947,9 @@ extern "C" int dig_mlp_chain_bwd(const void* dy, const void* w2t, const void* pr
   no_layernorm(p);
   return launch_chain<2>(p, stream);
 }
+
+// number of partial rows dig_mlp_chain_bwd_ln writes into ln_partials ([rows][3][D] fp32): one per workgroup of 128 tokens
+extern "C" int dig_mlp_chain_ln_parts(int R) { return (R + BM - 1) / BM; }
 
 // number of partial rows dig_mlp_chain_bwd writes into colsum_partials ([rows][F] fp32)
 extern "C" int dig_mlp_chain_colsum_rows(int R) { return ((R + BM - 1) / BM) * 4; }

@@ -424,6 +424,14 @@ extern "C" int dig_layernorm_bwd_finalize(const float* workspace, int rows, int 
   return dig_check_launch();
 }
 
+// the same over a workspace of `parts` partial rows written by another producer (dig_mlp_chain_bwd_ln: one per 32 rows)
+extern "C" int dig_layernorm_bwd_finalize_parts(const float* workspace, int parts, int D, float* dgamma, float* dbeta, float* dcolsum,
+                                                hipStream_t stream) {
+  if (!workspace || !dgamma || !dbeta || parts <= 0 || D <= 0 || (D & 15)) return DIG_ERR_ARG;
+  hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((3 * D) / 16), dim3(256), 0, stream, workspace, parts, D, dgamma, dbeta, dcolsum);
+  return dig_check_launch();
+}
+
 extern "C" int dig_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean,
                                  const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta, float* dcolsum,
                                  float* workspace, int rows, int D, int fuse_gelu, hipStream_t stream) {

@@ -328,6 +328,7 @@ class _Step:
             grp.set ^= 1
             st.wg_map, st.wg_slabs = wmap_ptr, slabs.data_ptr()
             st.wg_defer = int(defer)
+            st.fuse_ln2 = int(ops.MLP_CHAIN_LNB)
             if defer:
                 own = (ops._WgProb * 4)()
                 deferred.append((own, t16, sv, i))
@@ -525,7 +526,14 @@ class _Step:
                 # data gradient through fc2, GELU' and fc1 in one launch (d(pre-activation) leaves it as a side output for the fc1
                 # weight gradient, with its column sums = the fc1 bias gradient)
                 w2t, w1t = wT[i]
-                dln2, dact, bparts = ops.mlp_chain_bwd(dx, w2t, pre, w1t)
+                if ops.MLP_CHAIN_LNB and red is None:
+                    # ... with norm2's backward in the same launch: dx_mid = dx + LN2'(d ln2) leaves it, the three parameter-gradient
+                    # sums of norm2 / fc2's bias as partial rows
+                    dx_mid, dact, bparts, lnp = ops.mlp_chain_bwd_ln(dx, w2t, pre, w1t, x_mid, blk["norm2.weight"], mu2, rs2)
+                    dln2 = dx_mid
+                else:
+                    dln2, dact, bparts = ops.mlp_chain_bwd(dx, w2t, pre, w1t)
+                    lnp = None
                 _mark("blk: fused MLP backward", dev)
             else:
                 dact, bparts = ops.linear_dgrad(dx, blk["mlp.fc2.weight"], gelu_pre=pre, colsum=True)   # d(pre-activation): GELU' and
@@ -539,12 +547,15 @@ class _Step:
                 on_side(lambda: (wg(dact, ln2, g["mlp.fc1.weight"]), csum(bparts, g["mlp.fc1.bias"])), dact, ln2, bparts)   # (0.3 ms/step vs a 201 MB pass)
             if dln2 is None:
                 dln2 = ops.linear_dgrad(dact, blk["mlp.fc1.weight"])
-            dx_mid, fin2, ws2 = ops.layernorm_bwd(dln2, x_mid, blk["norm2.weight"], blk["norm2.bias"], mu2, rs2, dx, g["norm2.weight"],
-                                                  g["norm2.bias"], out=dln2, dres_colsum=g["mlp.fc2.bias"], defer=True)
-            if red:                                                           # norm2 grads + colsum(dx) = fc2 bias grad: off the chain
-                red.layernorm_finalize(ws2, x_mid.shape[0], D, g["norm2.weight"], g["norm2.bias"], g["mlp.fc2.bias"])
+            if chain and lnp is not None:
+                side_later(lambda lnp=lnp, g=g: ops.layernorm_finalize_parts(lnp, g["norm2.weight"], g["norm2.bias"], g["mlp.fc2.bias"]), lnp)
             else:
-                side_later(fin2, ws2)
+                dx_mid, fin2, ws2 = ops.layernorm_bwd(dln2, x_mid, blk["norm2.weight"], blk["norm2.bias"], mu2, rs2, dx, g["norm2.weight"],
+                                                      g["norm2.bias"], out=dln2, dres_colsum=g["mlp.fc2.bias"], defer=True)
+                if red:                                                       # norm2 grads + colsum(dx) = fc2 bias grad: off the chain
+                    red.layernorm_finalize(ws2, x_mid.shape[0], D, g["norm2.weight"], g["norm2.bias"], g["mlp.fc2.bias"])
+                else:
+                    side_later(fin2, ws2)
             # x_mid = x + proj(attn(ln1))
             if grp:
                 wg(dx_mid, ctx, g["attn.proj.weight"])

@@ -187,6 +187,30 @@ def mlp_chain_bwd(dy, w2t, pre, w1t, colsum=True, out=None):
     return dx, dpre, parts
 
 
+MLP_CHAIN_LNB = os.environ.get("DIG_CHAIN_LNB", "1") != "0"     # norm2's backward inside the fused MLP backward launch
+
+
+def mlp_chain_bwd_ln(dy, w2t, pre, w1t, x_mid, ln_g, ln_mean, ln_rstd, colsum=True, out=None):
+    """mlp_chain_bwd with norm2's backward behind it in the same launch: dx_mid = dy + LN'(dpre w1).  Returns (dx_mid, dpre, parts, ln_parts):
+    ln_parts = [n, 3, D] fp32 partial sums (d gamma, d beta, column sums of dy) for layernorm_finalize_parts."""
+    rows, D = dy.shape
+    Fh = w2t.shape[0]
+    dx = torch.empty((rows, D), device=dy.device, dtype=BF16) if out is None else out
+    dpre = torch.empty((rows, Fh), device=dy.device, dtype=BF16)
+    n = L.lib().dig_mlp_chain_colsum_rows(rows)
+    parts = torch.empty((n, Fh), device=dy.device, dtype=F32) if colsum else None
+    ln_parts = torch.empty((L.lib().dig_mlp_chain_ln_parts(rows), 3, D), device=dy.device, dtype=F32)
+    L.call("dig_mlp_chain_bwd_ln", L.ptr(dy), L.ptr(w2t), L.ptr(pre), L.ptr(w1t), L.ptr(dpre), L.ptr(x_mid), L.ptr(ln_g), L.ptr(ln_mean),
+           L.ptr(ln_rstd), L.ptr(dx), L.ptr(parts), L.ptr(ln_parts), rows, D, Fh, L.stream())
+    return dx, dpre, parts, ln_parts
+
+
+def layernorm_finalize_parts(ln_parts, dgamma, dbeta, dcolsum=None):
+    """dgamma / dbeta / dcolsum += the column sums of ln_parts [n, 3, D] (dig_layernorm_bwd_finalize_parts)."""
+    n, _, D = ln_parts.shape
+    L.call("dig_layernorm_bwd_finalize_parts", L.ptr(ln_parts), n, D, L.ptr(dgamma), L.ptr(dbeta), L.ptr(dcolsum), L.stream())
+
+
 def transpose_bf16(src, out=None):
     rows, cols = src.shape
     out = torch.empty((cols, rows), device=src.device, dtype=BF16) if out is None else out
@@ -517,7 +541,7 @@ class BlockBwd(ctypes.Structure):
                                     "x", "ln1", "mu1", "rs1", "qkv", "ctx", "lse", "x_mid", "ln2", "mu2", "rs2", "pre", "act", "dy",
                                     "dln2", "dpre", "dctx", "dqkv", "bparts", "ws1", "ws2", "qs", "vs")] +
                 [(k, _I) for k in ("wg_fn", "wg_wa", "wg_splits", "wg_n_wg", "wg_fold_n", "wg_fold_splits")] + [("wg_trans", _I * 4)] +
-                [("wg_defer", _I), ("reserved1", _I)] +
+                [("wg_defer", _I), ("fuse_ln2", _I)] +
                 [(k, _VP) for k in ("wg_map", "wg_slabs", "wg_fold_slabs", "wg_probs", "wg_fold_probs", "side")])
 
 
@@ -556,7 +580,8 @@ def block_bwd_layout(rows, D, Fh, n_img):
             n16 += _round_up(rows * cols * 2, 256)
         lib = L.lib()
         parts = lib.dig_layernorm_bwd_parts(rows) * 3 * D
-        for name, n in (("bparts", lib.dig_mlp_chain_colsum_rows(rows) * Fh), ("ws1", parts), ("ws2", parts), ("qs", n_img * D), ("vs", n_img * D)):
+        parts2 = max(parts, lib.dig_mlp_chain_ln_parts(rows) * 3 * D)                 # (ws2 with fuse_ln2: one partial row per 128 tokens)
+        for name, n in (("bparts", lib.dig_mlp_chain_colsum_rows(rows) * Fh), ("ws1", parts), ("ws2", parts2), ("qs", n_img * D), ("vs", n_img * D)):
             off[name] = n32
             n32 += _round_up(n * 4, 256)
         lay = _block_layouts[key] = (off, n16, n32)

@@ -48,7 +48,8 @@ typedef struct dig_block_bwd {
   const void* dy;                      /* gradient w.r.t. the block's output rows, bf16 [rows, D] */
   /* temporaries ([rows, D], [rows, F], [rows, D], [rows, 3D] bf16); on return dctx holds the gradient w.r.t. the block's INPUT rows */
   void* dln2; void* dpre; void* dctx; void* dqkv;
-  /* fp32 partial sums finished on the side stream: [dig_mlp_chain_colsum_rows(rows)][F], 2 x [dig_layernorm_bwd_parts(rows)][3][D], 2 x [n_img][D] */
+  /* fp32 partial sums finished on the side stream: [dig_mlp_chain_colsum_rows(rows)][F], 2 x [dig_layernorm_bwd_parts(rows)][3][D] (ws2 with
+   * fuse_ln2: [max(that, dig_mlp_chain_ln_parts(rows))][3][D]), 2 x [n_img][D] */
   float* bparts; float* ws1; float* ws2; float* qs; float* vs;
   /* grouped weight gradients (dig_wgrad_group): this block's four problems are written to wg_probs (HOST array of 4) in the order
    * fc2, fc1, proj, qkv and launched together with the fold of wg_fold_probs (the previous call's wg_probs; wg_fold_n = 0 for the first
@@ -57,7 +58,8 @@ typedef struct dig_block_bwd {
   int wg_trans[4];
   int wg_defer;                        /* 1: wg_probs is filled but dig_wgrad_group is NOT launched: the caller launches the blocks' weight gradients
                                           itself, behind the last data gradient (lab switch: the data-gradient chain then runs uninterrupted) */
-  int reserved1;
+  int fuse_ln2;                        /* 1: norm2's backward inside the fused MLP backward launch (dig_mlp_chain_bwd_ln) instead of its own launch; ws2 then
+                                          holds [dig_mlp_chain_ln_parts(rows)][3][D] and is reduced by dig_layernorm_bwd_finalize_parts */
   const unsigned* wg_map; float* wg_slabs; const float* wg_fold_slabs;
   dig_wgrad_prob_t* wg_probs; const dig_wgrad_prob_t* wg_fold_probs;
   hipStream_t side;                    /* stream of the parameter-gradient reductions (may equal the call's stream) */

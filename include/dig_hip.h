@@ -127,6 +127,11 @@ int dig_wgrad_group(const dig_wgrad_prob_t* probs, int n_probs, const dig_wgrad_
  *       and resid the raw ones.  LayerNorm statistics are taken in fp32 over the bf16 values that are (or would be) stored,
  *       variance as E[x^2] - E[x]^2, eps inside the square root.  ln_out / ln_mean / ln_rstd (normalised rows [R,D] bf16, statistics
  *       [R] fp32: what the backward keeps) and nln_mean / nln_rstd may be null.  F <= 2048.
+ *   dig_mlp_chain_bwd_ln: dig_mlp_chain_bwd with norm2's backward behind it (the first half of Block's gradient, modeling_finetune.py:157-158
+ *       read backwards, in one launch): dx_mid_out[R,D] = dy + LN'(dpre_out w1; x_mid, ln_g, ln_mean, ln_rstd) -- the gradient w.r.t. the
+ *       rows norm2 normalised, the data gradient of the MLP rounded to bf16 in between exactly as the two-launch path stores it -- and
+ *       ln_partials = [dig_mlp_chain_ln_parts(R)][3][D] fp32 partial column sums over blocks of 128 rows: d(gamma), d(beta) of norm2 and the
+ *       column sums of dy (= fc2's bias gradient), the layout dig_layernorm_bwd_finalize_parts reduces.  dx_mid_out must not alias dy / x_mid.
  *   Supported widths: dig_mlp_chain_supported(D, F) (D == 384, F a multiple of 128, F <= 6144); R is arbitrary (rows beyond R read as
  *   zero and are not written).  All pointers 16-byte aligned, dense row-major tensors.  Anything else: DIG_ERR_UNSUPPORTED (the
  *   caller runs the two dig_gemm_bf16 launches instead).
@@ -140,7 +145,11 @@ int dig_mlp_chain_fwd_ln(const void* x, const void* resid, const float* ln_g, co
                          hipStream_t stream);
 int dig_mlp_chain_bwd(const void* dy, const void* w2t, const void* pre, const void* w1t, void* dpre_out, void* dx_out,
                       float* colsum_partials, int R, int D, int F, hipStream_t stream);
+int dig_mlp_chain_bwd_ln(const void* dy, const void* w2t, const void* pre, const void* w1t, void* dpre_out, const void* x_mid,
+                         const float* ln_g, const float* ln_mean, const float* ln_rstd, void* dx_mid_out, float* colsum_partials,
+                         float* ln_partials, int R, int D, int F, hipStream_t stream);
 int dig_mlp_chain_colsum_rows(int R);
+int dig_mlp_chain_ln_parts(int R);
 /* dst[cols, rows] = src[rows, cols]^T, bf16 */
 int dig_transpose_bf16(const void* src, void* dst, int rows, int cols, hipStream_t stream);
 /* the same for `count` (<= 32) equally shaped matrices in one launch; srcs / dsts are HOST arrays of device pointers */
@@ -199,6 +208,9 @@ int dig_layernorm_bwd_partials(const void* dy, const void* x, const float* gamma
                                hipStream_t stream);
 int dig_layernorm_bwd_finalize(const float* workspace, int rows, int D, float* dgamma, float* dbeta, float* dcolsum,
                                hipStream_t stream);
+/* dig_layernorm_bwd_finalize over a workspace of `parts` partial rows ([parts][3][D]) that another producer wrote (dig_mlp_chain_bwd_ln) */
+int dig_layernorm_bwd_finalize_parts(const float* workspace, int parts, int D, float* dgamma, float* dbeta, float* dcolsum,
+                                     hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * BatchNorm1d in training mode, split so that the [2,C] statistics vector can be all-reduced between the halves

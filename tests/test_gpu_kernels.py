@@ -518,6 +518,47 @@ def test_mlp_chain_fwd_bwd(dev, R, Fh):
     assert torch.equal(dx, dx2) and torch.equal(dpre, dpre2) and torch.equal(parts, parts2)     # bit-reproducible
 
 
+@pytest.mark.parametrize("R,Fh", [(128, 128), (333, 256), (4096, 1536), (1000, 2048), (65536, 1536)])
+def test_mlp_chain_bwd_ln(dev, R, Fh):
+    """dig_mlp_chain_bwd_ln (the MLP's data gradient AND norm2's backward in one launch) against the two launches it replaces
+    (dig_mlp_chain_bwd -> dig_layernorm_bwd_partials / _finalize) and against fp32 torch autograd of the same half block; ragged rows."""
+    from dig_amd import ops
+    D = 384
+    cpu_limit(dev, 4.0 * R * D * Fh, limit=3e9)
+    g = torch.Generator(device="cpu").manual_seed(7 * R + Fh)
+    rn = lambda *s: torch.randn(*s, generator=g).to(dev)
+    x_mid = (rn(R, D) * 1.3 + 0.2).bfloat16()
+    gam, bet = 1.0 + 0.3 * rn(D), 0.1 * rn(D)
+    w1 = (rn(Fh, D) * 0.06).bfloat16(); b1 = rn(Fh) * 0.5
+    w2 = (rn(D, Fh) * 0.04).bfloat16()
+    dy = rn(R, D).bfloat16()
+    ln2, mu, rs = ops.layernorm_fwd(x_mid, gam, bet, 1e-6)
+    pre = torch.empty((R, Fh), device=dev, dtype=torch.bfloat16)
+    ops.linear_fwd(ln2, w1, bias=b1, act=1, pre=pre)
+    w2t, w1t = ops.transpose_bf16(w2), ops.transpose_bf16(w1)
+    # the two launches
+    dln2, dpre0, parts0 = ops.mlp_chain_bwd(dy, w2t, pre, w1t)
+    dgam0, dbet0, dcol0 = torch.zeros(D, device=dev), torch.zeros(D, device=dev), torch.zeros(D, device=dev)
+    dxm0 = ops.layernorm_bwd(dln2, x_mid, gam, bet, mu, rs, dy, dgam0, dbet0, dres_colsum=dcol0)
+    # one launch
+    dxm, dpre, parts, lnp = ops.mlp_chain_bwd_ln(dy, w2t, pre, w1t, x_mid, gam, mu, rs)
+    assert torch.equal(dpre, dpre0) and torch.equal(parts, parts0)                 # the MLP half is the same arithmetic
+    seed = rn(3, D)
+    dgam, dbet, dcol = seed[0].clone(), seed[1].clone(), seed[2].clone()
+    ops.layernorm_finalize_parts(lnp, dgam, dbet, dcol)
+    dgam, dbet, dcol = dgam - seed[0], dbet - seed[1], dcol - seed[2]              # (finalize accumulates)
+    assert rel(dxm, dxm0) < 4e-3
+    assert rel(dgam, dgam0) < 2e-3 and rel(dbet, dbet0) < 1e-4 and rel(dcol, dcol0) < 1e-4
+    assert rel(dcol, dy.float().sum(0)) < 1e-4 and rel(dbet, dln2.float().sum(0)) < 1e-4
+    # fp32 autograd of y = x_mid + (dln2 flowing into LN): d x_mid = dy + LN'(dln2)
+    xm = x_mid.float().requires_grad_(True)
+    gp = gam.clone().requires_grad_(True)
+    F.layer_norm(xm, (D,), gp, bet, 1e-6).backward(dln2.float())
+    assert rel(dxm, xm.grad + dy.float()) < 1e-2 and rel(dgam, gp.grad) < 3e-3
+    again = ops.mlp_chain_bwd_ln(dy, w2t, pre, w1t, x_mid, gam, mu, rs)
+    assert all(torch.equal(a, b) for a, b in zip(again, (dxm, dpre, parts, lnp)))  # bit-reproducible
+
+
 # ------------------------------------------------------------------------------------------------------------------------------------
 # Exact-arithmetic parity: operands drawn from small integers / powers of two, so that every product and every fp32 partial sum is
 # exact WHATEVER the summation order, and the only rounding left is the final fp32 -> bf16 round-to-nearest-even -- which torch's
@@ -801,14 +842,18 @@ def test_encoder_block_calls_equal_the_entry_point_sequence(dev, n_img):
     gnames = ("n1_g", "n1_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "n2_g", "n2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")
     mkgrads = lambda: [{k: torch.full(P[k].shape, 0.125, device=dev, dtype=torch.float32) for k in gnames} for _ in range(2)]
 
-    def bwd_entry_points(G):
+    def bwd_entry_points(G, fuse_ln2):
         grp, outs = ops.WgradGroup(dev), []
         for dy, gk in zip(dys, G):
             assert grp.add(dy, sv["act"], gk["fc2_w"])
-            dln2, dpre, bparts = ops.mlp_chain_bwd(dy, w2t, sv["pre"], w1t)
+            if fuse_ln2:
+                dx_mid, dpre, bparts, lnp = ops.mlp_chain_bwd_ln(dy, w2t, sv["pre"], w1t, sv["x_mid"], P["n2_g"], sv["ln_mean"], sv["ln_rstd"])
+                fin2 = lambda lnp=lnp, gk=gk: ops.layernorm_finalize_parts(lnp, gk["n2_g"], gk["n2_b"], gk["fc2_b"])
+            else:
+                dln2, dpre, bparts = ops.mlp_chain_bwd(dy, w2t, sv["pre"], w1t)
+                dx_mid, fin2, ws2 = ops.layernorm_bwd(dln2, sv["x_mid"], P["n2_g"], P["n2_b"], sv["ln_mean"], sv["ln_rstd"], dy, gk["n2_g"],
+                                                      gk["n2_b"], out=dln2, dres_colsum=gk["fc2_b"], defer=True)
             assert grp.add(dpre, sv["ln"], gk["fc1_w"])
-            dx_mid, fin2, ws2 = ops.layernorm_bwd(dln2, sv["x_mid"], P["n2_g"], P["n2_b"], sv["ln_mean"], sv["ln_rstd"], dy, gk["n2_g"], gk["n2_b"],
-                                                  out=dln2, dres_colsum=gk["fc2_b"], defer=True)
             assert grp.add(dx_mid, sv["ctx"], gk["proj_w"])
             dctx = ops.linear_dgrad(dx_mid, P["proj_w"])
             dqkv, qs, vs = ops.attn_bwd(sv["qkv"], sv["ctx"], dctx, sv["lse"], n_img, H, D, scale, bias_sums=True)
@@ -823,7 +868,7 @@ def test_encoder_block_calls_equal_the_entry_point_sequence(dev, n_img):
         grp.flush()
         return outs
 
-    def bwd_block_calls(G):
+    def bwd_block_calls(G, fuse_ln2):
         plan = ops.wgrad_block_plan(dev, R, D, Fh)
         assert plan is not None
         off, n16, n32 = ops.block_bwd_layout(R, D, Fh, n_img)
@@ -848,7 +893,7 @@ def test_encoder_block_calls_equal_the_entry_point_sequence(dev, n_img):
                               wg_fold_splits=plan["splits"], wg_trans=(ctypes.c_int * 4)(*plan["trans"]), wg_map=plan["wmap"].data_ptr(),
                               wg_slabs=slabs.data_ptr(), wg_fold_slabs=slabs_prev.data_ptr() if n else None,
                               wg_probs=ctypes.addressof(probs[n & 1]), wg_fold_probs=ctypes.addressof(probs[(n & 1) ^ 1]) if n else None,
-                              side=ops.L.stream())
+                              side=ops.L.stream(), fuse_ln2=int(fuse_ln2))
             for k in ("dln2", "dpre", "dctx", "dqkv"):
                 setattr(st, k, p16 + off[k])
             for k in ("bparts", "ws1", "ws2", "qs", "vs"):
@@ -860,14 +905,15 @@ def test_encoder_block_calls_equal_the_entry_point_sequence(dev, n_img):
                    ops.L.ptr(slabs_prev), plan["splits"], plan["fn"], plan["wa"], ops.L.stream())
         return outs
 
-    Ga, Gb = mkgrads(), mkgrads()
-    dxa, dxb = bwd_entry_points(Ga), bwd_block_calls(Gb)
-    for a, b in zip(dxa, dxb):
-        assert torch.equal(a, b)
-    for ga, gb_ in zip(Ga, Gb):
-        for k in gnames:
-            assert torch.equal(ga[k], gb_[k]), k
-            assert not torch.equal(ga[k], torch.full_like(ga[k], 0.125)) or k == "qkv_b", k
+    for fuse_ln2 in (True, False):                                    # norm2's backward inside the fused MLP launch / as its own launch
+        Ga, Gb = mkgrads(), mkgrads()
+        dxa, dxb = bwd_entry_points(Ga, fuse_ln2), bwd_block_calls(Gb, fuse_ln2)
+        for a, b in zip(dxa, dxb):
+            assert torch.equal(a, b)
+        for ga, gb_ in zip(Ga, Gb):
+            for k in gnames:
+                assert torch.equal(ga[k], gb_[k]), (k, fuse_ln2)
+                assert not torch.equal(ga[k], torch.full_like(ga[k], 0.125)) or k == "qkv_b", k
     # a table with a missing pointer is refused
     assert ops.L.lib().dig_encoder_block_fwd(ctypes.byref(ops.BlockFwd(n_img=n_img, heads=H, D=D, F=Fh, rows=R)), None) == -1
 

@@ -51,13 +51,22 @@ def main():
         dact, parts = ops.linear_dgrad(dy, w2, gelu_pre=pre, colsum=True)
         return ops.linear_dgrad(dact, w1)
 
+    gam = 1.0 + 0.3 * torch.randn(D, device=dev); bet = torch.zeros(D, device=dev)
+    _, mu, rs = ops.layernorm_fwd(res, gam, bet, 1e-6)
+
+    def chain_then_ln():
+        dln2, dpre, parts = ops.mlp_chain_bwd(dy, w2t, pre, w1t)
+        return ops.layernorm_bwd(dln2, res, gam, bet, mu, rs, dy, None, None, out=dln2, defer=True)
+
     unfused_online()
     rows = [("fwd momentum: fc1+gelu, fc2+res (2 launches)", unfused_mom),
             ("fwd momentum: chain", lambda: ops.mlp_chain_fwd(x, w1, b1, w2, b2, res)),
             ("fwd online: fc1+gelu+pre, fc2+res (2 launches)", unfused_online),
             ("fwd online: chain + pre/act", lambda: ops.mlp_chain_fwd(x, w1, b1, w2, b2, res, save=True)),
             ("bwd: fc2 dgrad*gelu'+colsum, fc1 dgrad (2 launches)", unfused_bwd),
-            ("bwd: chain", lambda: ops.mlp_chain_bwd(dy, w2t, pre, w1t))]
+            ("bwd: chain", lambda: ops.mlp_chain_bwd(dy, w2t, pre, w1t)),
+            ("bwd: chain, then norm2's backward (2 launches)", chain_then_ln),
+            ("bwd: chain with norm2's backward in it", lambda: ops.mlp_chain_bwd_ln(dy, w2t, pre, w1t, res, gam, mu, rs))]
     for name, fn in rows:
         us = timeit(fn)
         print(f"{name:58s} {us:8.1f} us  {flop / us * 1e-6:7.1f} TFLOP/s", flush=True)
