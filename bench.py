@@ -144,12 +144,14 @@ class GemmProbe:
         ops.mlp_chain_bwd = timed_chain_bwd
         sv["chain_bwd_ln"] = ops.mlp_chain_bwd_ln
 
-        def timed_chain_bwd_ln(dy, w2t, pre, w1t, x_mid, ln_g, ln_mean, ln_rstd, colsum=True, out=None):
+        def timed_chain_bwd_ln(dy, w2t, pre, w1t, x_mid, ln_g, ln_mean, ln_rstd, colsum=True, out=None, projt=None, dctx=None):
             R, D = dy.shape
             Fh = w2t.shape[0]
-            byt = 2.0 * R * D * 3 + 2.0 * R * Fh * 2 + 2.0 * 2 * D * Fh                   # + the rows norm2 normalised
-            return self._bracket("mlp_chain_bwd", 4.0 * R * D * Fh, byt,
-                                 lambda: sv["chain_bwd_ln"](dy, w2t, pre, w1t, x_mid, ln_g, ln_mean, ln_rstd, colsum=colsum, out=out))
+            pj = projt is not None
+            byt = 2.0 * R * D * (3 + pj) + 2.0 * R * Fh * 2 + 2.0 * 2 * D * Fh + 2.0 * D * D * pj      # + the rows norm2 normalised (, dctx, Wproj)
+            return self._bracket("mlp_chain_bwd", 4.0 * R * D * Fh + 2.0 * R * D * D * pj, byt,
+                                 lambda: sv["chain_bwd_ln"](dy, w2t, pre, w1t, x_mid, ln_g, ln_mean, ln_rstd, colsum=colsum, out=out, projt=projt,
+                                                            dctx=dctx))
         ops.mlp_chain_bwd_ln = timed_chain_bwd_ln
 
         def attn_block_rec(R, D, save, n_img, heads):
@@ -222,8 +224,11 @@ class GemmProbe:
                 b = args[0]._obj
                 R, D, Fh = b.rows, b.D, b.F
                 # (fuse_ln2: norm2's backward rides in the launch -- one more [R, D] operand, x_mid; dy and the output are the chain's own)
-                self.rec.append(("mlp_chain_bwd", 4.0 * R * D * Fh, 2.0 * R * D * (3 if b.fuse_ln2 else 2) + 2.0 * R * Fh * 2 + 2.0 * 2 * D * Fh))
-                self.rec.append(gemm_rec("dgrad", b.tile_dgrad, R, D, D))
+                proj_in = bool(b.fuse_ln2 and b.projt)                        # ... and the projection's data gradient: its FLOP, dctx out, the weight
+                self.rec.append(("mlp_chain_bwd", 4.0 * R * D * Fh + 2.0 * R * D * D * proj_in,
+                                 2.0 * R * D * ((3 if b.fuse_ln2 else 2) + proj_in) + 2.0 * R * Fh * 2 + 2.0 * 2 * D * Fh + 2.0 * D * D * proj_in))
+                if not proj_in:
+                    self.rec.append(gemm_rec("dgrad", b.tile_dgrad, R, D, D))
                 self.rec.append(attn_rec(True, R, D))
                 shapes = ((D, Fh), (Fh, D), (D, D), (3 * D, D))
                 if not b.wg_defer:                                            # (deferred plan: the grouped launch is issued by the caller, booked below)

@@ -1194,6 +1194,35 @@ int dig_mlp_chain_bwd_ln(const void* dy_, const void* w2t, const void* pre, cons
   return DIG_OK;
 }
 
+int dig_mlp_chain_bwd_ln_proj(const void* dy, const void* w2t, const void* pre, const void* w1t, void* dpre_out, const void* x_mid,
+                              const float* ln_g, const float* ln_mean, const float* ln_rstd, void* dx_mid_out, float* colsum_partials,
+                              float* ln_partials, const void* projt_, void* dctx_out_, int R, int D, int F, hipStream_t stream) {
+  if ((projt_ == nullptr) != (dctx_out_ == nullptr)) return DIG_ERR_ARG;
+  const int rc = dig_mlp_chain_bwd_ln(dy, w2t, pre, w1t, dpre_out, x_mid, ln_g, ln_mean, ln_rstd, dx_mid_out, colsum_partials, ln_partials, R, D, F,
+                                      stream);
+  if (rc != DIG_OK || !projt_) return rc;
+  if (!aligned16(projt_) || !aligned16(dctx_out_)) return DIG_ERR_ALIGN;
+  const bf16_t* dx = (const bf16_t*)dx_mid_out; const bf16_t* pt = (const bf16_t*)projt_;
+  bf16_t* dc = (bf16_t*)dctx_out_;
+  std::vector<float> W((size_t)D * D);
+  for (size_t i = 0; i < W.size(); ++i) W[i] = bf2f(pt[i]);          // [in][out]
+#pragma omp parallel
+  {
+    std::vector<float> xr(D);
+#pragma omp for
+    for (int r = 0; r < R; ++r) {
+      for (int o = 0; o < D; ++o) xr[o] = bf2f(dx[(size_t)r * D + o]);
+      for (int i = 0; i < D; ++i) {
+        float a = 0.f;
+        const float* w = &W[(size_t)i * D];
+        for (int o = 0; o < D; ++o) a += w[o] * xr[o];
+        dc[(size_t)r * D + i] = f2bf(a);
+      }
+    }
+  }
+  return DIG_OK;
+}
+
 int dig_transpose_bf16(const void* src_, void* dst_, int rows, int cols, hipStream_t) {
   if (!src_ || !dst_ || rows <= 0 || cols <= 0) return DIG_ERR_ARG;
   const bf16_t* src = (const bf16_t*)src_; bf16_t* dst = (bf16_t*)dst_;

@@ -41,6 +41,10 @@
 #define DIG_CHAIN_T_BEGIN()
 #define DIG_CHAIN_T_END()
 #endif
+#ifndef DIG_CHAIN_LNB_ABL             // lab (tools/gpu_chain_ln_lab.py), norm2's backward phase: 1 dy rows read from x_mid's addresses (no dy traffic),
+#define DIG_CHAIN_LNB_ABL 0           // 2 no row loads at all, 4 no dx_mid stores; projection phase: 8 no MFMAs / fragment reads, 16 no weight DMA,
+                                      // 32 no dctx stores (results are wrong)
+#endif
 #ifndef DIG_CHAIN_ABL
 #define DIG_CHAIN_ABL 0
 #endif
@@ -89,6 +93,8 @@ struct ChainParams {
   // residual path; resid = the rows norm2 normalised (x_mid); ln_g = its gamma; out receives dx_mid = dy + LN'(dX) instead of dX
   const float* lnb_mean; const float* lnb_rstd;            // [R] statistics the forward kept
   float* lnb_ws;                                           // [ceil(R/128)][3][KD] fp32 partial column sums: d(gamma), d(beta), column sums of dy
+  // ... and the attention projection's data gradient behind that (optional): proj_out[R, KD] = out Wproj, projt = Wproj^T [KD in][KD out]
+  const bf16_t* projt; bf16_t* proj_out;
 };
 
 template <int N>
@@ -109,9 +115,8 @@ template <int MODE, bool LN>
 __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr bool LNB = LN && MODE == 2;                             // backward with norm2's backward in the O-waves' epilogue
-  constexpr int LNB_RS = KD * 2 + 8;                                // LNB: row pitch of the data-gradient tile [BM][KD] bf16 at LDS offset 0
-  constexpr int LNB_ROWSUM = BM * LNB_RS;                           //      [8 waves][32] fp32 row sums
-  constexpr int LNB_COLRED = LNB_ROWSUM + 8 * 32 * 4;               //      [8 waves][3][KD] fp32 column sums
+  constexpr int LNB_RS = KD * 2 + 16;                               // LNB: row pitch of the data-gradient tile [BM][KD] bf16 at LDS offset 0
+  constexpr int LNB_COLRED = BM * LNB_RS;                           //      [8 waves][3][KD] fp32 column sums
   static_assert(!LNB || LNB_COLRED + 8 * 3 * KD * 4 <= X_OFF + 2 * SLOT, "LayerNorm-backward phase: LDS map");
   constexpr int B1S_OFF = X_OFF + (MODE == 1 ? SLOT : 0);          // forward: b1 [F], b2 [KD] (, LN: ln_g, ln_b, nln_g, nln_b [KD] each) fp32 in LDS
   const int tid = threadIdx.x, lane = tid & 63;
@@ -264,11 +269,12 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainParams p) {
       const auto rDy = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, p.x_bytes, 0x00020000);
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const unsigned so = (unsigned)(m0 + wave * 16 + i) * (unsigned)(KD * 2);
+        const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((m0 + wave * 16 + i) * (KD * 2));
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
+          if (DIG_CHAIN_LNB_ABL & 2) { xr[i][j] = yr[i][j] = 0x3f803f80u; continue; }
           xr[i][j] = __builtin_amdgcn_raw_buffer_load_b32(rXm, vo + (unsigned)(256 * j), so, 0);
-          yr[i][j] = __builtin_amdgcn_raw_buffer_load_b32(rDy, vo + (unsigned)(256 * j), so, 0);
+          yr[i][j] = __builtin_amdgcn_raw_buffer_load_b32((DIG_CHAIN_LNB_ABL & 1) ? rXm : rDy, vo + (unsigned)(256 * j), so, 0);
         }
       }
     }
@@ -657,7 +663,7 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainParams p) {
     };
     if constexpr (LNB) {
       // ---- norm2's backward follows for all eight waves (below the role split): the data gradient goes to LDS as the bf16 rows a separate
-      // LayerNorm launch would read back -- [128 tokens][KD] bf16, row pitch LNB_RS (8 bytes of padding: the 32 tokens of a wave's store
+      // LayerNorm launch would read back -- [128 tokens][KD] bf16, row pitch LNB_RS (16 bytes of padding: the 32 tokens of a wave's store
       // land in different banks), over the rings and tiles every wave has left behind the barrier.
       wait_vm<0>();                                                    // this wave's last (past-the-end) ring DMA has landed
       __builtin_amdgcn_s_barrier();
@@ -790,16 +796,23 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainParams p) {
     for (int i = 0; i < 16; ++i) {
       const float c1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, u8[i & 7]), 16 * (i >> 3)));
       const float c2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, u8[i & 7]), 32 + 16 * (i >> 3)));
-      const unsigned so = (unsigned)(r0 + i) * (unsigned)(KD * 2);
+      const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((r0 + i) * (KD * 2));   // (left to the compiler it sits in a VGPR: a waterfall loop per store)
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         const unsigned gw = *reinterpret_cast<const unsigned*>(grow + i * LNB_RS + 256 * j);
         const float g0 = lo16(gw), g1 = up16(gw);
-        const float xh0 = fmaf(lo16(xr[i][j]), rstd[i], nmr[i]), xh1 = fmaf(up16(xr[i][j]), rstd[i], nmr[i]);
+        unsigned xw = xr[i][j];
+        asm volatile("" : "+v"(xw));                                   // (or the first pass's 96 xhat values are kept for this one, in scratch)
+        const float xh0 = fmaf(lo16(xw), rstd[i], nmr[i]), xh1 = fmaf(up16(xw), rstd[i], nmr[i]);
         const float y0 = lo16(yr[i][j]), y1 = up16(yr[i][j]);
         const float d0 = fmaf(rstd[i], fmaf(-xh0, c2, g0 * gm[j][0] - c1), y0);
         const float d1 = fmaf(rstd[i], fmaf(-xh1, c2, g1 * gm[j][1] - c1), y1);
-        __builtin_amdgcn_raw_buffer_store_b32(pack_bf2(d0, d1), rOut, vo + (unsigned)(256 * j), so, 0);
+        const unsigned ow = pack_bf2(d0, d1);
+        if (!(DIG_CHAIN_LNB_ABL & 4)) __builtin_amdgcn_raw_buffer_store_b32(ow, rOut, vo + (unsigned)(256 * j), so, 0);
+        else asm volatile("" ::"v"(ow));
+        // the lane's own words of the tile, for the projection phase (unconditional: 48 branches here made the compiler sink the column sums
+        // behind them and keep their operands in scratch)
+        asm volatile("ds_write_b32 %0, %1" ::"v"(lds_addr(grow) + (unsigned)(i * LNB_RS + 256 * j)), "v"(ow) : "memory");
         dg[j][0] = fmaf(g0, xh0, dg[j][0]); dg[j][1] = fmaf(g1, xh1, dg[j][1]);
         db[j][0] += g0; db[j][1] += g1;
         dc[j][0] += y0; dc[j][1] += y1;
@@ -821,6 +834,122 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainParams p) {
 #pragma unroll
       for (int w = 0; w < 8; ++w) a += cs[w * (3 * KD) + c];
       p.lnb_ws[(size_t)blockIdx.x * (3 * KD) + c] = a;
+    }
+    if (p.projt) {
+      // ================================ the attention projection's data gradient on the rows just made =============================
+      // dctx[128, KD] = dx_mid[128, KD] Wproj: the tile in LDS holds dx_mid (bf16, what the GEMM launch would read back).  Wave (tg, ch)
+      // takes tokens 32 tg .. + 31 and output columns 192 ch .. + 191: its 32 x 384 slice of the tile goes to registers as MFMA
+      // fragments (96), then the LDS is Wproj^T's -- [384 i][192 o] at a time (two halves of the reduction, 147 KB each, ring-slot swizzle,
+      // fetched by LDS-DMA, every wave 18 pieces) -- and each half is 12 k-steps x 6 column blocks of MFMAs per wave.
+      const int tg = wave & 3, ch = wave >> 2;
+      int t3 = threadIdx.x;
+      asm volatile("" : "+v"(t3));                                     // (addresses derived from here: hoisted into the LayerNorm phase they were spilled there)
+      const int ln3 = t3 & 63, rr2 = ln3 & 31, hh = ln3 >> 5;
+      bf16x8 xa[KD / 16];
+      {
+        const unsigned char* arow = smem + (tg * 32 + rr2) * LNB_RS + hh * 16;
+#pragma unroll
+        for (int s = 0; s < KD / 16; ++s) xa[s] = *reinterpret_cast<const bf16x8*>(arow + s * 32);
+      }
+      wait_lgkm0();
+      __builtin_amdgcn_s_barrier();                                    // every wave holds its rows (and has read the column sums): the LDS is free
+      asm volatile("" ::: "memory");
+      const auto rW = __builtin_amdgcn_make_buffer_rsrc((void*)p.projt, 0, KD * KD * 2, 0x00020000);
+      f32x16 acc[6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+      const int pswp = (rr2 >> 1) & 7;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int tt = 0; tt < 18; ++tt) {
+          const unsigned U = (unsigned)(64 * (wave + 8 * tt) + ln3); // 16-byte unit of the half image: row n = U / 24, swizzled chunk U % 24
+          const unsigned n = U / 24u, cq = U - 24u * n;
+          const unsigned c = (cq & 24u) | ((cq & 7u) ^ ((n >> 1) & 7u));
+          if (!(DIG_CHAIN_LNB_ABL & 16))
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, LDS_PTR(smem + (wave + 8 * tt) * 1024), 16, n * (unsigned)(KD * 2) + 16u * c,
+                                                     (unsigned)(half * KD), 0, 0);
+        }
+        wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // the six weight fragments of k-step s + 1 are requested in front of the MFMAs of k-step s (left to the compiler, every MFMA waited
+        // for its own LDS read: 19 us of the launch instead of 8)
+        const unsigned char* wbase = smem + (ch * 6 * 32 + rr2) * KD;
+        auto wload = [&](int s, bf16x8 (&w)[6]) {
+          const int u = 2 * s + hh;                                   // the lane's 16-byte chunk of the row, ring-slot swizzle
+          const unsigned char* q = wbase + (((u & 24) | ((u & 7) ^ pswp)) << 4);
+#pragma unroll
+          for (int j = 0; j < 6; ++j) w[j] = *reinterpret_cast<const bf16x8*>(q + j * 32 * KD);
+        };
+        bf16x8 wa[6], wb[6];
+        if (!(DIG_CHAIN_LNB_ABL & 8)) {
+          wload(0, wa);
+          auto kstep = [&](auto s_tag, bf16x8 (&cur)[6], bf16x8 (&nxt)[6]) {
+            constexpr int S = decltype(s_tag)::value;
+            if (S + 1 < 12) wload(S + 1, nxt);
+            __builtin_amdgcn_sched_barrier(0);                         // (the requests stay in front: the scheduler moves them behind the MFMAs)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[j], xa[half * 12 + S], acc[j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          };
+          kstep(std::integral_constant<int, 0>{}, wa, wb); kstep(std::integral_constant<int, 1>{}, wb, wa);
+          kstep(std::integral_constant<int, 2>{}, wa, wb); kstep(std::integral_constant<int, 3>{}, wb, wa);
+          kstep(std::integral_constant<int, 4>{}, wa, wb); kstep(std::integral_constant<int, 5>{}, wb, wa);
+          kstep(std::integral_constant<int, 6>{}, wa, wb); kstep(std::integral_constant<int, 7>{}, wb, wa);
+          kstep(std::integral_constant<int, 8>{}, wa, wb); kstep(std::integral_constant<int, 9>{}, wb, wa);
+          kstep(std::integral_constant<int, 10>{}, wa, wb); kstep(std::integral_constant<int, 11>{}, wb, wa);
+        }
+        if (half == 0) {
+          __builtin_amdgcn_s_barrier();                                // every wave is done with the first half before the second lands on it
+          asm volatile("" ::: "memory");
+        }
+      }
+      // rows out through LDS (the weight image is dead behind the barrier): lanes l and l + 32 trade column groups (store_block of the
+      // O-waves) and put 16-byte pieces into the [128][KD] tile; then a wave writes 16 whole 768-byte rows -- as 32-byte pieces straight from
+      // the accumulators the stores cost 16 us of the launch (every instruction touched 32 lines, a quarter of each).  Rows beyond R are dropped.
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const auto rPo = __builtin_amdgcn_make_buffer_rsrc((void*)p.proj_out, 0, p.x_bytes, 0x00020000);
+      const unsigned po = lds_addr(smem) + (unsigned)((tg * 32 + rr2) * LNB_RS + hh * 32);
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        unsigned Pk[4][2];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          Pk[g][0] = pack_bf2(acc[j][4 * g], acc[j][4 * g + 1]);
+          Pk[g][1] = pack_bf2(acc[j][4 * g + 2], acc[j][4 * g + 3]);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const auto q0 = __builtin_amdgcn_permlane32_swap(Pk[0][k], Pk[2][k], false, false);
+          Pk[0][k] = q0[0]; Pk[2][k] = q0[1];
+          const auto q1 = __builtin_amdgcn_permlane32_swap(Pk[1][k], Pk[3][k], false, false);
+          Pk[1][k] = q1[0]; Pk[3][k] = q1[1];
+        }
+        const unsigned co = po + (unsigned)(((ch * 6 + j) * 32) * 2);
+        asm volatile("ds_write_b128 %0, %1" ::"v"(co), "v"(dig_u32x4{Pk[0][0], Pk[0][1], Pk[2][0], Pk[2][1]}) : "memory");
+        asm volatile("ds_write_b128 %0, %1" ::"v"(co + 16u), "v"(dig_u32x4{Pk[1][0], Pk[1][1], Pk[3][0], Pk[3][1]}) : "memory");
+      }
+      wait_lgkm0();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (!(DIG_CHAIN_LNB_ABL & 32)) {
+        int t4 = threadIdx.x;
+        asm volatile("" : "+v"(t4));
+        const unsigned lo4 = (unsigned)((t4 & 63) * 4);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((m0 + wave * 16 + i) * (KD * 2));
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            const unsigned wv = *reinterpret_cast<const unsigned*>(smem + (wave * 16 + i) * LNB_RS + lo4 + 256 * j);
+            __builtin_amdgcn_raw_buffer_store_b32(wv, rPo, lo4 + (unsigned)(256 * j), so, 0);
+          }
+        }
+      }
     }
   }
 }
@@ -852,6 +981,7 @@ void no_layernorm(ChainParams& p) {
   p.ln_eps = 0.f;
   p.lnb_mean = p.lnb_rstd = nullptr;
   p.lnb_ws = nullptr;
+  p.projt = nullptr; p.proj_out = nullptr;
 }
 
 int check_common(const void* x, const void* b1, const void* b2, const void* out, int R, int D, int F) {
@@ -914,15 +1044,18 @@ extern "C" int dig_mlp_chain_fwd_ln(const void* x, const void* resid, const floa
 }
 
 // dig_mlp_chain_bwd with norm2's backward behind it: dx_mid = dy + LN2'(dX) in place of dX, and the three parameter-gradient partial sums
-// ([dig_mlp_chain_ln_parts(R)][3][D] fp32: d(gamma), d(beta), column sums of dy = fc2's bias gradient) for dig_layernorm_bwd_finalize_parts
-extern "C" int dig_mlp_chain_bwd_ln(const void* dy, const void* w2t, const void* pre, const void* w1t, void* dpre_out, const void* x_mid,
-                                    const float* ln_g, const float* ln_mean, const float* ln_rstd, void* dx_mid_out, float* colsum_partials,
-                                    float* ln_partials, int R, int D, int F, hipStream_t stream) {
+// ([dig_mlp_chain_ln_parts(R)][3][D] fp32: d(gamma), d(beta), column sums of dy = fc2's bias gradient) for dig_layernorm_bwd_finalize_parts;
+// with projt / dctx_out, the attention projection's data gradient dctx = dx_mid Wproj behind that (projt = Wproj^T, dig_transpose_bf16)
+extern "C" int dig_mlp_chain_bwd_ln_proj(const void* dy, const void* w2t, const void* pre, const void* w1t, void* dpre_out, const void* x_mid,
+                                         const float* ln_g, const float* ln_mean, const float* ln_rstd, void* dx_mid_out, float* colsum_partials,
+                                         float* ln_partials, const void* projt, void* dctx_out, int R, int D, int F, hipStream_t stream) {
   const int rc = check_common(dy, w2t, w1t, dx_mid_out, R, D, F);
   if (rc != DIG_OK) return rc;
-  if (!pre || !dpre_out || !x_mid || !ln_g || !ln_mean || !ln_rstd || !ln_partials) return DIG_ERR_ARG;
+  if (!pre || !dpre_out || !x_mid || !ln_g || !ln_mean || !ln_rstd || !ln_partials || ((projt == nullptr) != (dctx_out == nullptr))) return DIG_ERR_ARG;
   if ((size_t)(R + BM) * D * 2 >= (1ull << 32)) return DIG_ERR_UNSUPPORTED;       // (row offsets of the LayerNorm phase are 32-bit)
-  if (!aligned16(pre) || !aligned16(dpre_out) || !aligned16(x_mid) || (colsum_partials && !aligned16(colsum_partials))) return DIG_ERR_ALIGN;
+  if (!aligned16(pre) || !aligned16(dpre_out) || !aligned16(x_mid) || (colsum_partials && !aligned16(colsum_partials)) ||
+      (projt && (!aligned16(projt) || !aligned16(dctx_out))))
+    return DIG_ERR_ALIGN;
   ChainParams p;
   p.X = (const bf16_t*)dy; p.B1 = (const bf16_t*)w2t; p.B2 = (const bf16_t*)w1t; p.bias1 = nullptr; p.bias2 = nullptr;
   p.resid = (const bf16_t*)x_mid; p.out = (bf16_t*)dx_mid_out; p.side0 = (bf16_t*)dpre_out; p.side1 = (bf16_t*)pre; p.colsum = colsum_partials;
@@ -930,7 +1063,15 @@ extern "C" int dig_mlp_chain_bwd_ln(const void* dy, const void* w2t, const void*
   p.x_bytes = (unsigned)((size_t)R * D * 2); p.w_bytes = (unsigned)((size_t)F * D * 2); p.side_bytes = (unsigned)((size_t)R * F * 2);
   no_layernorm(p);
   p.ln_g = ln_g; p.lnb_mean = ln_mean; p.lnb_rstd = ln_rstd; p.lnb_ws = ln_partials;
+  p.projt = (const bf16_t*)projt; p.proj_out = (bf16_t*)dctx_out;
   return launch_chain<2, true>(p, stream);
+}
+
+extern "C" int dig_mlp_chain_bwd_ln(const void* dy, const void* w2t, const void* pre, const void* w1t, void* dpre_out, const void* x_mid,
+                                    const float* ln_g, const float* ln_mean, const float* ln_rstd, void* dx_mid_out, float* colsum_partials,
+                                    float* ln_partials, int R, int D, int F, hipStream_t stream) {
+  return dig_mlp_chain_bwd_ln_proj(dy, w2t, pre, w1t, dpre_out, x_mid, ln_g, ln_mean, ln_rstd, dx_mid_out, colsum_partials, ln_partials, nullptr,
+                                   nullptr, R, D, F, stream);
 }
 
 extern "C" int dig_mlp_chain_bwd(const void* dy, const void* w2t, const void* pre, const void* w1t, void* dpre_out, void* dx_out,

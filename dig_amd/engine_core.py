@@ -313,8 +313,9 @@ class _Step:
                     g_fc2_b=g["mlp.fc2.bias"].data_ptr(),
                     wg_fn=plan["fn"], wg_wa=plan["wa"], wg_splits=plan["splits"], wg_n_wg=plan["n_wg"], wg_fold_splits=plan["splits"],
                     wg_trans=(ctypes.c_int * 4)(*plan["trans"]))
-            w2t, w1t = wT[i]
+            w2t, w1t, projt = wT[i]
             st.w2t, st.w1t = w2t.data_ptr(), w1t.data_ptr()
+            st.projt = projt.data_ptr() if (ops.MLP_CHAIN_LNB and ops.MLP_CHAIN_PROJ) else None
             st.x, st.ln1, st.mu1, st.rs1 = sv.inp_ptr
             for k in ("qkv", "ctx", "lse", "x_mid", "ln2", "mu2", "rs2", "pre", "act"):
                 setattr(st, k, sv.ptr(k))
@@ -388,7 +389,8 @@ class _Step:
         they depend on nothing but this step's bf16 weight shadow, so forward() queues them on the side stream behind the momentum branch."""
         w2t = ops.transpose_bf16_multi([b["mlp.fc2.weight"] for b in ew.blocks])      # one launch per weight shape
         w1t = ops.transpose_bf16_multi([b["mlp.fc1.weight"] for b in ew.blocks])
-        return list(zip(w2t, w1t))
+        projt = ops.transpose_bf16_multi([b["attn.proj.weight"] for b in ew.blocks])   # (the projection's data gradient inside the fused MLP backward)
+        return list(zip(w2t, w1t, projt))
 
     # ------------------------------------------------------------------ two-stream helpers (backward)
     def _streams(self, dev):
@@ -525,8 +527,12 @@ class _Step:
             if chain:
                 # data gradient through fc2, GELU' and fc1 in one launch (d(pre-activation) leaves it as a side output for the fc1
                 # weight gradient, with its column sums = the fc1 bias gradient)
-                w2t, w1t = wT[i]
-                if ops.MLP_CHAIN_LNB and red is None:
+                w2t, w1t, projt = wT[i]
+                dctx = None
+                if ops.MLP_CHAIN_LNB and red is None and ops.MLP_CHAIN_PROJ:
+                    dx_mid, dact, bparts, lnp, dctx = ops.mlp_chain_bwd_ln(dx, w2t, pre, w1t, x_mid, blk["norm2.weight"], mu2, rs2, projt=projt)
+                    dln2 = dx_mid
+                elif ops.MLP_CHAIN_LNB and red is None:
                     # ... with norm2's backward in the same launch: dx_mid = dx + LN2'(d ln2) leaves it, the three parameter-gradient
                     # sums of norm2 / fc2's bias as partial rows
                     dx_mid, dact, bparts, lnp = ops.mlp_chain_bwd_ln(dx, w2t, pre, w1t, x_mid, blk["norm2.weight"], mu2, rs2)
@@ -562,7 +568,8 @@ class _Step:
             else:
                 on_side(lambda: wg(dx_mid, ctx, g["attn.proj.weight"]), dx_mid, ctx)
             _mark("blk: LayerNorm backward (norm2)", dev)
-            dctx = ops.linear_dgrad(dx_mid, blk["attn.proj.weight"])
+            if not chain or dctx is None:
+                dctx = ops.linear_dgrad(dx_mid, blk["attn.proj.weight"])
             _mark("blk: proj data gradient", dev)
             gb = g["qkv_bias"]
             if FUSED_QV_BIAS_SUMS:

@@ -188,11 +188,17 @@ def mlp_chain_bwd(dy, w2t, pre, w1t, colsum=True, out=None):
 
 
 MLP_CHAIN_LNB = os.environ.get("DIG_CHAIN_LNB", "1") != "0"     # norm2's backward inside the fused MLP backward launch
+# ... and the attention projection's data gradient behind it (dig_mlp_chain_bwd_ln_proj).  Opt-in: alone the launch beats the two it replaces by
+# 12 us (245 against 258), in the step it loses 0.05 ms -- the phase is LDS-bandwidth bound (every weight fragment feeds one MFMA) and the GEMM
+# launch it replaces overlaps the side stream's work better (profiles/r05_step_ab.txt)
+MLP_CHAIN_PROJ = os.environ.get("DIG_CHAIN_PROJ", "0") == "1"
 
 
-def mlp_chain_bwd_ln(dy, w2t, pre, w1t, x_mid, ln_g, ln_mean, ln_rstd, colsum=True, out=None):
+def mlp_chain_bwd_ln(dy, w2t, pre, w1t, x_mid, ln_g, ln_mean, ln_rstd, colsum=True, out=None, projt=None, dctx=None):
     """mlp_chain_bwd with norm2's backward behind it in the same launch: dx_mid = dy + LN'(dpre w1).  Returns (dx_mid, dpre, parts, ln_parts):
-    ln_parts = [n, 3, D] fp32 partial sums (d gamma, d beta, column sums of dy) for layernorm_finalize_parts."""
+    ln_parts = [n, 3, D] fp32 partial sums (d gamma, d beta, column sums of dy) for layernorm_finalize_parts.
+    projt (= proj.weight^T, transpose_bf16): the attention projection's data gradient dctx = dx_mid proj.weight rides in the launch as
+    well and is returned as a fifth value."""
     rows, D = dy.shape
     Fh = w2t.shape[0]
     dx = torch.empty((rows, D), device=dy.device, dtype=BF16) if out is None else out
@@ -200,6 +206,11 @@ def mlp_chain_bwd_ln(dy, w2t, pre, w1t, x_mid, ln_g, ln_mean, ln_rstd, colsum=Tr
     n = L.lib().dig_mlp_chain_colsum_rows(rows)
     parts = torch.empty((n, Fh), device=dy.device, dtype=F32) if colsum else None
     ln_parts = torch.empty((L.lib().dig_mlp_chain_ln_parts(rows), 3, D), device=dy.device, dtype=F32)
+    if projt is not None:
+        dctx = torch.empty((rows, D), device=dy.device, dtype=BF16) if dctx is None else dctx
+        L.call("dig_mlp_chain_bwd_ln_proj", L.ptr(dy), L.ptr(w2t), L.ptr(pre), L.ptr(w1t), L.ptr(dpre), L.ptr(x_mid), L.ptr(ln_g), L.ptr(ln_mean),
+               L.ptr(ln_rstd), L.ptr(dx), L.ptr(parts), L.ptr(ln_parts), L.ptr(projt), L.ptr(dctx), rows, D, Fh, L.stream())
+        return dx, dpre, parts, ln_parts, dctx
     L.call("dig_mlp_chain_bwd_ln", L.ptr(dy), L.ptr(w2t), L.ptr(pre), L.ptr(w1t), L.ptr(dpre), L.ptr(x_mid), L.ptr(ln_g), L.ptr(ln_mean),
            L.ptr(ln_rstd), L.ptr(dx), L.ptr(parts), L.ptr(ln_parts), rows, D, Fh, L.stream())
     return dx, dpre, parts, ln_parts
@@ -535,7 +546,7 @@ class BlockFwd(ctypes.Structure):
 class BlockBwd(ctypes.Structure):
     """include/dig_block_types.h `dig_block_bwd_t`."""
     _fields_ = ([(k, _I) for k in ("n_img", "heads", "D", "F", "rows", "tile_dgrad")] + [("scale", _F)] +
-                [(k, _VP) for k in ("qkv_w", "proj_w", "w2t", "w1t", "n1_g", "n1_b", "n2_g", "n2_b",
+                [(k, _VP) for k in ("qkv_w", "proj_w", "w2t", "w1t", "projt", "n1_g", "n1_b", "n2_g", "n2_b",
                                     "g_n1_g", "g_n1_b", "g_qkv_w", "g_q_b", "g_v_b", "g_proj_w", "g_proj_b", "g_n2_g", "g_n2_b", "g_fc1_w", "g_fc1_b",
                                     "g_fc2_w", "g_fc2_b",
                                     "x", "ln1", "mu1", "rs1", "qkv", "ctx", "lse", "x_mid", "ln2", "mu2", "rs2", "pre", "act", "dy",

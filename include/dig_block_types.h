@@ -38,6 +38,8 @@ typedef struct dig_block_bwd {
   float scale;
   /* parameters; w2t = fc2.weight^T [F, D], w1t = fc1.weight^T [D, F] (dig_transpose_bf16) */
   const void* qkv_w; const void* proj_w; const void* w2t; const void* w1t;
+  const void* projt;                   /* proj.weight^T [D, D] (dig_transpose_bf16), or NULL: with fuse_ln2, non-NULL puts the projection's data gradient
+                                          into the fused MLP backward launch as well (dig_mlp_chain_bwd_ln_proj) instead of its own GEMM launch */
   const float* n1_g; const float* n1_b; const float* n2_g; const float* n2_b;
   /* fp32 gradients, accumulated into (contiguous [out, in] matrices); g_q_b / g_v_b = the q and v thirds of the qkv bias gradient */
   float* g_n1_g; float* g_n1_b; float* g_qkv_w; float* g_q_b; float* g_v_b; float* g_proj_w; float* g_proj_b;

@@ -148,6 +148,12 @@ int dig_mlp_chain_bwd(const void* dy, const void* w2t, const void* pre, const vo
 int dig_mlp_chain_bwd_ln(const void* dy, const void* w2t, const void* pre, const void* w1t, void* dpre_out, const void* x_mid,
                          const float* ln_g, const float* ln_mean, const float* ln_rstd, void* dx_mid_out, float* colsum_partials,
                          float* ln_partials, int R, int D, int F, hipStream_t stream);
+/* ... and, behind norm2's backward, the attention projection's data gradient on the same rows (Attention.proj, modeling_finetune.py:113 read
+ * backwards): dctx_out[R,D] = dx_mid_out proj_w, with projt = proj_w^T [D in, D out] (dig_transpose_bf16).  projt / dctx_out: both or neither
+ * (neither: dig_mlp_chain_bwd_ln). */
+int dig_mlp_chain_bwd_ln_proj(const void* dy, const void* w2t, const void* pre, const void* w1t, void* dpre_out, const void* x_mid,
+                              const float* ln_g, const float* ln_mean, const float* ln_rstd, void* dx_mid_out, float* colsum_partials,
+                              float* ln_partials, const void* projt, void* dctx_out, int R, int D, int F, hipStream_t stream);
 int dig_mlp_chain_colsum_rows(int R);
 int dig_mlp_chain_ln_parts(int R);
 /* dst[cols, rows] = src[rows, cols]^T, bf16 */

@@ -557,6 +557,13 @@ def test_mlp_chain_bwd_ln(dev, R, Fh):
     assert rel(dxm, xm.grad + dy.float()) < 1e-2 and rel(dgam, gp.grad) < 3e-3
     again = ops.mlp_chain_bwd_ln(dy, w2t, pre, w1t, x_mid, gam, mu, rs)
     assert all(torch.equal(a, b) for a, b in zip(again, (dxm, dpre, parts, lnp)))  # bit-reproducible
+    # ... and with the attention projection's data gradient behind it: everything else unchanged, dctx = dx_mid Wproj against the GEMM launch
+    # on the same bf16 rows (same products, another summation order) and against fp32 torch
+    wp = (rn(D, D) * 0.05).bfloat16()
+    out5 = ops.mlp_chain_bwd_ln(dy, w2t, pre, w1t, x_mid, gam, mu, rs, projt=ops.transpose_bf16(wp))
+    assert all(torch.equal(a, b) for a, b in zip(out5[:4], (dxm, dpre, parts, lnp)))
+    assert rel(out5[4], ops.linear_dgrad(dxm, wp)) < 2e-3 and rel(out5[4], dxm.float() @ wp.float()) < 5e-3
+    assert torch.equal(out5[4], ops.mlp_chain_bwd_ln(dy, w2t, pre, w1t, x_mid, gam, mu, rs, projt=ops.transpose_bf16(wp))[4])
 
 
 # ------------------------------------------------------------------------------------------------------------------------------------
@@ -846,8 +853,12 @@ def test_encoder_block_calls_equal_the_entry_point_sequence(dev, n_img):
         grp, outs = ops.WgradGroup(dev), []
         for dy, gk in zip(dys, G):
             assert grp.add(dy, sv["act"], gk["fc2_w"])
+            dctx = None
             if fuse_ln2:
-                dx_mid, dpre, bparts, lnp = ops.mlp_chain_bwd_ln(dy, w2t, sv["pre"], w1t, sv["x_mid"], P["n2_g"], sv["ln_mean"], sv["ln_rstd"])
+                r5 = ops.mlp_chain_bwd_ln(dy, w2t, sv["pre"], w1t, sv["x_mid"], P["n2_g"], sv["ln_mean"], sv["ln_rstd"],
+                                          projt=projt if fuse_ln2 == 2 else None)
+                dx_mid, dpre, bparts, lnp = r5[:4]
+                dctx = r5[4] if fuse_ln2 == 2 else None
                 fin2 = lambda lnp=lnp, gk=gk: ops.layernorm_finalize_parts(lnp, gk["n2_g"], gk["n2_b"], gk["fc2_b"])
             else:
                 dln2, dpre, bparts = ops.mlp_chain_bwd(dy, w2t, sv["pre"], w1t)
@@ -855,7 +866,8 @@ def test_encoder_block_calls_equal_the_entry_point_sequence(dev, n_img):
                                                       gk["n2_b"], out=dln2, dres_colsum=gk["fc2_b"], defer=True)
             assert grp.add(dpre, sv["ln"], gk["fc1_w"])
             assert grp.add(dx_mid, sv["ctx"], gk["proj_w"])
-            dctx = ops.linear_dgrad(dx_mid, P["proj_w"])
+            if dctx is None:
+                dctx = ops.linear_dgrad(dx_mid, P["proj_w"])
             dqkv, qs, vs = ops.attn_bwd(sv["qkv"], sv["ctx"], dctx, sv["lse"], n_img, H, D, scale, bias_sums=True)
             assert grp.add(dqkv, ln1, gk["qkv_w"])
             grp.launch()
@@ -893,7 +905,7 @@ def test_encoder_block_calls_equal_the_entry_point_sequence(dev, n_img):
                               wg_fold_splits=plan["splits"], wg_trans=(ctypes.c_int * 4)(*plan["trans"]), wg_map=plan["wmap"].data_ptr(),
                               wg_slabs=slabs.data_ptr(), wg_fold_slabs=slabs_prev.data_ptr() if n else None,
                               wg_probs=ctypes.addressof(probs[n & 1]), wg_fold_probs=ctypes.addressof(probs[(n & 1) ^ 1]) if n else None,
-                              side=ops.L.stream(), fuse_ln2=int(fuse_ln2))
+                              side=ops.L.stream(), fuse_ln2=int(bool(fuse_ln2)), projt=projt.data_ptr() if fuse_ln2 == 2 else None)
             for k in ("dln2", "dpre", "dctx", "dqkv"):
                 setattr(st, k, p16 + off[k])
             for k in ("bparts", "ws1", "ws2", "qs", "vs"):
@@ -905,7 +917,8 @@ def test_encoder_block_calls_equal_the_entry_point_sequence(dev, n_img):
                    ops.L.ptr(slabs_prev), plan["splits"], plan["fn"], plan["wa"], ops.L.stream())
         return outs
 
-    for fuse_ln2 in (True, False):                                    # norm2's backward inside the fused MLP launch / as its own launch
+    projt = ops.transpose_bf16(P["proj_w"])
+    for fuse_ln2 in (2, 1, 0):                # norm2's backward (2: and the projection's data gradient) inside the fused MLP launch / as its own launch
         Ga, Gb = mkgrads(), mkgrads()
         dxa, dxb = bwd_entry_points(Ga, fuse_ln2), bwd_block_calls(Gb, fuse_ln2)
         for a, b in zip(dxa, dxb):

@@ -796,7 +796,7 @@ def test_vit_base_b16_every_tensor_gradient_vs_oracle():
 
 @pytest.mark.parametrize("switch", ["wgrad_off", "wgrad_pair", "wgrad_wa1", "wgrad_side_stream", "chain_mask3", "dgrad_128", "fwd_side", "fwd_serial",
                                     "chain_no_ln", "bwd_single", "chain_bwd_every2", "per_entry_point", "autograd_function", "attn_three_launches",
-                                    "attn_bwd_single_pass", "wgrad_inline", "ln2_bwd_own_launch"])
+                                    "attn_bwd_single_pass", "wgrad_inline", "ln2_bwd_own_launch", "proj_dgrad_in_chain"])
 def test_engine_switches_agree_with_the_default_path(switch):
     """Every non-default execution plan of the step (environment switches of dig_amd/ops.py and engine_core.py: launch groupings, tile
     codes, stream plans, fusion masks) against the default plan on one ViT-S step from the same state and batch: the losses agree, and
@@ -834,6 +834,8 @@ def test_engine_switches_agree_with_the_default_path(switch):
         "attn_bwd_single_pass": [],                                       # (a library-wide mode, set below: a different BACKWARD kernel)
         # norm2's backward as its own launch behind dig_mlp_chain_bwd instead of inside dig_mlp_chain_bwd_ln: a different BACKWARD kernel
         "ln2_bwd_own_launch": [(ops, "MLP_CHAIN_LNB", False)],
+        # the projection's data gradient behind norm2's backward in dig_mlp_chain_bwd_ln_proj instead of its own GEMM launch (opt-in plan)
+        "proj_dgrad_in_chain": [(ops, "MLP_CHAIN_PROJ", True)],
         "wgrad_inline": [(engine_core, "WGRAD_DEFER", "0")],              # the grouped launch of a block inside its data-gradient chain (the plan under a
                                                                           # process group) instead of all twelve behind the last data gradient: same sums
     }

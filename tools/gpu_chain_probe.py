@@ -54,6 +54,13 @@ def main():
     gam = 1.0 + 0.3 * torch.randn(D, device=dev); bet = torch.zeros(D, device=dev)
     _, mu, rs = ops.layernorm_fwd(res, gam, bet, 1e-6)
 
+    wp = (torch.randn(D, D, device=dev) * 0.05).bfloat16()
+    wpt = ops.transpose_bf16(wp)
+
+    def chain_ln_then_proj():
+        dxm = ops.mlp_chain_bwd_ln(dy, w2t, pre, w1t, res, gam, mu, rs)[0]
+        return ops.linear_dgrad(dxm, wp)
+
     def chain_then_ln():
         dln2, dpre, parts = ops.mlp_chain_bwd(dy, w2t, pre, w1t)
         return ops.layernorm_bwd(dln2, res, gam, bet, mu, rs, dy, None, None, out=dln2, defer=True)
@@ -66,7 +73,9 @@ def main():
             ("bwd: fc2 dgrad*gelu'+colsum, fc1 dgrad (2 launches)", unfused_bwd),
             ("bwd: chain", lambda: ops.mlp_chain_bwd(dy, w2t, pre, w1t)),
             ("bwd: chain, then norm2's backward (2 launches)", chain_then_ln),
-            ("bwd: chain with norm2's backward in it", lambda: ops.mlp_chain_bwd_ln(dy, w2t, pre, w1t, res, gam, mu, rs))]
+            ("bwd: chain with norm2's backward in it", lambda: ops.mlp_chain_bwd_ln(dy, w2t, pre, w1t, res, gam, mu, rs)),
+            ("bwd: chain + norm2's backward, then proj dgrad (2 launches)", chain_ln_then_proj),
+            ("bwd: chain + norm2's backward + proj dgrad", lambda: ops.mlp_chain_bwd_ln(dy, w2t, pre, w1t, res, gam, mu, rs, projt=wpt))]
     for name, fn in rows:
         us = timeit(fn)
         print(f"{name:58s} {us:8.1f} us  {flop / us * 1e-6:7.1f} TFLOP/s", flush=True)
