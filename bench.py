@@ -124,14 +124,14 @@ class GemmProbe:
             return self._bracket("mlp_chain_online" if save else "mlp_chain_momentum", 4.0 * R * D * Fh, byt, lambda: sv["chain"](x, w1, b1, w2, b2, resid, save=save))
         ops.mlp_chain_fwd = timed_chain
 
-        def timed_chain_ln(x, ln_g, ln_b, eps, w1, b1, w2, b2, nln_g=None, nln_b=None, save=False, resid=None):
+        def timed_chain_ln(x, ln_g, ln_b, eps, w1, b1, w2, b2, nln_g=None, nln_b=None, save=False, resid=None, drop=None):
             R, D = x.shape
             Fh = w1.shape[0]
             # the fused launch with its LayerNorms: raw rows in, output rows and the next block's normalised rows out, both weight matrices
             # once; the online form also writes what the reference's autograd keeps (norm2's output, the pre-activation, the GELU output)
             byt = 2.0 * R * D * (2 + (nln_g is not None)) + 2.0 * 2 * D * Fh + ((2.0 * R * D + 2.0 * 2 * R * Fh) if save else 0.0)
             return self._bracket("mlp_chain_online" if save else "mlp_chain_momentum", 4.0 * R * D * Fh, byt,
-                                 lambda: sv["chain_ln"](x, ln_g, ln_b, eps, w1, b1, w2, b2, nln_g, nln_b, save=save, resid=resid))
+                                 lambda: sv["chain_ln"](x, ln_g, ln_b, eps, w1, b1, w2, b2, nln_g, nln_b, save=save, resid=resid, drop=drop))
         ops.mlp_chain_fwd_ln = timed_chain_ln
 
         def timed_chain_bwd(dy, w2t, pre, w1t, colsum=True, out=None):

@@ -1035,8 +1035,9 @@ int dig_colsum_partials(const float* partials, int n_parts, int C, float* out, h
 int dig_mlp_chain_supported(int D, int F) { return D == 384 && F >= 128 && F % 128 == 0 && F <= 6144; }
 int dig_mlp_chain_colsum_rows(int R) { return ((R + 127) / 128) * 4; }
 
-int dig_mlp_chain_fwd(const void* x_, const void* w1_, const float* b1, const void* w2_, const float* b2, const void* resid_, void* out_,
-                      void* pre_out_, void* act_out_, int R, int D, int F, hipStream_t) {
+// drop (or null): out = resid + drop_path(dropout(fc2(.) + b2)), the mask rule of dig_gemm_bf16_dropout (element index r * D + j)
+static int chain_fwd_cpu(const void* x_, const void* w1_, const float* b1, const void* w2_, const float* b2, const void* resid_, void* out_,
+                         void* pre_out_, void* act_out_, int R, int D, int F, const dig_dropout_t* drop) {
   if (!x_ || !w1_ || !w2_ || !out_ || R <= 0) return DIG_ERR_ARG;
   if (!dig_mlp_chain_supported(D, F)) return DIG_ERR_UNSUPPORTED;
   if ((pre_out_ == nullptr) != (act_out_ == nullptr)) return DIG_ERR_ARG;
@@ -1062,14 +1063,20 @@ int dig_mlp_chain_fwd(const void* x_, const void* w1_, const float* b1, const vo
         h[f] = bf2f(g);
       }
       for (int j = 0; j < D; ++j) {
-        float a = (b2 ? b2[j] : 0.f) + (resid ? bf2f(resid[(size_t)r * D + j]) : 0.f);
+        float a = (b2 ? b2[j] : 0.f) + ((resid && !drop) ? bf2f(resid[(size_t)r * D + j]) : 0.f);
         const float* w = &W2[(size_t)j * F];
         for (int f = 0; f < F; ++f) a += w[f] * h[f];
+        if (drop) a = drop_apply(a, *drop, r, j, D) + (resid ? bf2f(resid[(size_t)r * D + j]) : 0.f);
         out[(size_t)r * D + j] = f2bf(a);
       }
     }
   }
   return DIG_OK;
+}
+
+int dig_mlp_chain_fwd(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, const void* resid, void* out,
+                      void* pre_out, void* act_out, int R, int D, int F, hipStream_t) {
+  return chain_fwd_cpu(x, w1, b1, w2, b2, resid, out, pre_out, act_out, R, D, F, nullptr);
 }
 
 // rows of y = LN(x): fp32 statistics over the bf16 values, variance as E[x^2] - E[x]^2 (what the fused kernel computes)
@@ -1085,10 +1092,12 @@ static void ln_rows_cpu(const bf16_t* x, const float* g, const float* b, float e
   }
 }
 
-int dig_mlp_chain_fwd_ln(const void* x, const void* resid, const float* ln_g, const float* ln_b, float eps, void* ln_out, float* ln_mean,
-                         float* ln_rstd, const void* w1, const float* b1, const void* w2, const float* b2, void* out, void* pre_out, void* act_out,
-                         const float* nln_g, const float* nln_b, void* nln_out, float* nln_mean, float* nln_rstd, int R, int D, int F,
-                         hipStream_t st) {
+int dig_mlp_chain_fwd_ln_dropout(const void* x, const void* resid, const float* ln_g, const float* ln_b, float eps, void* ln_out, float* ln_mean,
+                                 float* ln_rstd, const void* w1, const float* b1, const void* w2, const float* b2, void* out, void* pre_out,
+                                 void* act_out, const float* nln_g, const float* nln_b, void* nln_out, float* nln_mean, float* nln_rstd, int R, int D,
+                                 int F, const dig_dropout_t* drop, hipStream_t st) {
+  if (drop && !(drop->thr || drop->pthr)) drop = nullptr;
+  if (drop && ((drop->pthr && drop->rows_per_sample <= 0) || (size_t)R * D >= (1ull << 32))) return DIG_ERR_ARG;
   if (!x || !w1 || !w2 || !out || R <= 0) return DIG_ERR_ARG;
   if (!dig_mlp_chain_supported(D, F) || F > 2048) return DIG_ERR_UNSUPPORTED;
   if ((ln_g == nullptr) != (ln_b == nullptr) || (nln_g == nullptr) != (nln_b == nullptr) || (nln_g == nullptr) != (nln_out == nullptr)) return DIG_ERR_ARG;
@@ -1102,10 +1111,19 @@ int dig_mlp_chain_fwd_ln(const void* x, const void* resid, const float* ln_g, co
     ln_rows_cpu((const bf16_t*)x, ln_g, ln_b, eps, lnw, ln_mean, ln_rstd, R, D);
     ln = lnw;
   }
-  const int rc = dig_mlp_chain_fwd(ln, w1, b1, w2, b2, resid, out, pre_out, act_out, R, D, F, st);
+  (void)st;
+  const int rc = chain_fwd_cpu(ln, w1, b1, w2, b2, resid, out, pre_out, act_out, R, D, F, drop);
   if (rc != DIG_OK) return rc;
   if (nln_g) ln_rows_cpu((const bf16_t*)out, nln_g, nln_b, eps, (bf16_t*)nln_out, nln_mean, nln_rstd, R, D);
   return DIG_OK;
+}
+
+int dig_mlp_chain_fwd_ln(const void* x, const void* resid, const float* ln_g, const float* ln_b, float eps, void* ln_out, float* ln_mean,
+                         float* ln_rstd, const void* w1, const float* b1, const void* w2, const float* b2, void* out, void* pre_out, void* act_out,
+                         const float* nln_g, const float* nln_b, void* nln_out, float* nln_mean, float* nln_rstd, int R, int D, int F,
+                         hipStream_t st) {
+  return dig_mlp_chain_fwd_ln_dropout(x, resid, ln_g, ln_b, eps, ln_out, ln_mean, ln_rstd, w1, b1, w2, b2, out, pre_out, act_out, nln_g, nln_b, nln_out,
+                                      nln_mean, nln_rstd, R, D, F, nullptr, st);
 }
 
 int dig_mlp_chain_bwd(const void* dy_, const void* w2t_, const void* pre_, const void* w1t_, void* dpre_out_, void* dx_out_,

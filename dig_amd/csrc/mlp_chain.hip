@@ -93,6 +93,8 @@ struct ChainParams {
   // residual path; resid = the rows norm2 normalised (x_mid); ln_g = its gamma; out receives dx_mid = dy + LN'(dX) instead of dX
   const float* lnb_mean; const float* lnb_rstd;            // [R] statistics the forward kept
   float* lnb_ws;                                           // [ceil(R/128)][3][KD] fp32 partial column sums: d(gamma), d(beta), column sums of dy
+  // forward with DROP: out = resid + drop_path(dropout(fc2(.) + b2)) (Mlp.drop behind fc2 and the block's drop_path, modeling_finetune.py:59,158)
+  dig_dropout_t drop;
   // ... and the attention projection's data gradient behind that (optional): proj_out[R, KD] = out Wproj, projt = Wproj^T [KD in][KD out]
   const bf16_t* projt; bf16_t* proj_out;
 };
@@ -111,8 +113,9 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(
 // every LDS read below is of that kind (checked in the ISA: no vmcnt(0) inside the tick loops).  LDS writes are inline asm.
 // MODE 0: forward, no side outputs (momentum branch / evaluation);  1: forward + pre-activation and GELU output (online branch:
 // what the backward reads);  2: backward (data gradient through both layers + d(pre-activation) + fc1 bias-gradient partials)
-template <int MODE, bool LN>
+template <int MODE, bool LN, bool DROP>
 __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainParams p) {
+  static_assert(!(DROP && MODE == 2), "dropout: forward forms only (the backward takes the masked gradient as its input)");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr bool LNB = LN && MODE == 2;                             // backward with norm2's backward in the O-waves' epilogue
   constexpr int LNB_RS = KD * 2 + 16;                               // LNB: row pitch of the data-gradient tile [BM][KD] bf16 at LDS offset 0
@@ -510,8 +513,9 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainParams p) {
     load_vectors();
     stage_vectors();
     f32x16 D2[NJB];
-    const auto rRes = __builtin_amdgcn_make_buffer_rsrc((void*)p.resid, 0, (p.resid && !LNB) ? p.x_bytes : 0, 0x00020000);   // null: zeros; rows beyond R: zeros
-    // (LNB: resid holds the rows norm2 normalised -- an operand of the epilogue, not a term of the accumulators)
+    const auto rRes = __builtin_amdgcn_make_buffer_rsrc((void*)p.resid, 0, (p.resid && !LNB && !DROP) ? p.x_bytes : 0, 0x00020000);   // null: zeros; rows beyond R: zeros
+    // (LNB: resid holds the rows norm2 normalised -- an operand of the epilogue, not a term of the accumulators.  DROP: the residual rows
+    //  are added behind the mask, in the epilogue: the accumulators start as the bias alone)
     dig_u32x4 rq[4];                                                   // residual chunks of one group (2 column blocks) in flight
     const unsigned ro16 = (unsigned)(((size_t)(m0 + pair * 32 + rr) * KD + 16 * hi) * 2);
     // group k (0..5) = column blocks 2k, 2k + 1: requested in idle tick k, unpacked in tick k + 1 (one tick of latency cover).  A lane
@@ -680,32 +684,102 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainParams p) {
     if (row < p.R) {
       const bool lno = LN && p.nln_out != nullptr;
       float s1 = 0.f, s2 = 0.f;
-      if (lno) {
-        // LayerNorm of the finished rows (the next block's norm1), taken over the bf16 values that are stored -- what a separate LayerNorm
-        // launch would read back: round the accumulators in place, sum and sum of squares by v_dot2 on the packed pairs
-        const dig_bf16x2 ones = __builtin_bit_cast(dig_bf16x2, 0x3F803F80u);
-#pragma unroll
-        for (int jb = 0; jb < NJB; ++jb)
-#pragma unroll
-          for (int g = 0; g < 8; ++g) {
-            const unsigned u = pack_bf2(D2[jb][2 * g], D2[jb][2 * g + 1]);
-            const dig_bf16x2 pr = __builtin_bit_cast(dig_bf16x2, u);
-            s1 = __builtin_amdgcn_fdot2_f32_bf16(pr, ones, s1, false);
-            s2 = __builtin_amdgcn_fdot2_f32_bf16(pr, pr, s2, false);
-            D2[jb][2 * g] = __uint_as_float(u << 16);
-            D2[jb][2 * g + 1] = __uint_as_float(u & 0xffff0000u);
-          }
-      }
       bf16_t* orow = p.out + (size_t)row * KD + hi2 * 16;
+      if constexpr (DROP) {
+        // ---- out = resid + drop_path(dropout(acc)), one column block at a time: keep / drop of element (row, col) from the keyed counter hash
+        // of its index row * KD + col (common.h dig_drop_keep: the GEMM epilogue's rule, the same pattern bit for bit), drop-path per sample; the
+        // residual rows are fetched here (the prologue's 32-byte pieces and lane exchange), the block is rounded, counted into the next
+        // LayerNorm's sums and stored at once.  (As a pass of its own over the accumulators in front of the usual epilogue it cost 1-2 KB of
+        // scratch: the compiler rebuilt every accumulator tuple.)
+        // (the nine key words are read from the kernel-argument segment HERE: as ordinary members of p they are fetched at the kernel's entry
+        //  and held across the main loop, whose scalar registers are full -- the spill costs the loop a vector register it does not have)
+        typedef const __attribute__((address_space(4))) unsigned char* kptr_t;
+        kptr_t ka = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ka));
+        const __attribute__((address_space(4))) unsigned* kw =
+            reinterpret_cast<const __attribute__((address_space(4))) unsigned*>(ka + offsetof(ChainParams, drop));
+        dig_dropout_t d;
+        d.k0 = kw[0]; d.k1 = kw[1]; d.thr = kw[2]; d.scale = __uint_as_float(kw[3]);
+        d.pk0 = kw[4]; d.pk1 = kw[5]; d.pthr = kw[6]; d.pscale = __uint_as_float(kw[7]); d.rows_per_sample = (int)kw[8];
+        float sc = d.thr ? d.scale : 1.f;
+        if (d.pthr) sc = dig_drop_keep(d.pk0, d.pk1, (unsigned)(row / d.rows_per_sample), 0u, d.pthr) ? sc * d.pscale : 0.f;
+        const auto rRes2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.resid, 0, p.resid ? p.x_bytes : 0, 0x00020000);
+        const unsigned ro = (unsigned)(((size_t)row * KD + 16 * hi2) * 2);
+        const unsigned ebase = (unsigned)row * (unsigned)KD + 4u * (unsigned)hi2;
+        const dig_bf16x2 ones = __builtin_bit_cast(dig_bf16x2, 0x3F803F80u);
+        dig_u32x4 qa[2], qb[2];
+        auto dload = [&](int jb, dig_u32x4 (&r)[2]) {
 #pragma unroll
-      for (int jb = 0; jb < NJB; ++jb) {
-        unsigned Pk[4][2];
+          for (int c = 0; c < 2; ++c) r[c] = __builtin_amdgcn_raw_buffer_load_b128(rRes2, ro + (unsigned)((jb * 32 + 8 * c) * 2), 0, 0);
+        };
+        auto dblock = [&](auto jb_tag, dig_u32x4 (&cur)[2], dig_u32x4 (&nxt)[2]) {
+          constexpr int jb = decltype(jb_tag)::value;
+          if (jb + 1 < NJB) dload(jb + 1, nxt);
+          unsigned rw[4][2];                                            // the residual pairs in accumulator order: rw[g][k] = columns 8 g + 4 hi + 2 k, + 1
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          Pk[g][0] = pack_bf2(D2[jb][g * 4], D2[jb][g * 4 + 1]);
-          Pk[g][1] = pack_bf2(D2[jb][g * 4 + 2], D2[jb][g * 4 + 3]);
+          for (int c = 0; c < 2; ++c) {
+            const auto s0 = __builtin_amdgcn_permlane32_swap(cur[c][0], cur[c][2], false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(cur[c][1], cur[c][3], false, false);
+            rw[c][0] = s0[0]; rw[c + 2][0] = s0[1];
+            rw[c][1] = s1[0]; rw[c + 2][1] = s1[1];
+          }
+          unsigned Pk[4][2];
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+              const unsigned idx = ebase + (unsigned)(jb * 32 + 8 * g + 2 * k);
+              // (thr = 0, drop-path alone: every hash passes -- no branch here)
+              const float v0 = (dig_drop_keep(d.k0, d.k1, idx, 0u, d.thr) ? D2[jb][4 * g + 2 * k] * sc : 0.f) + __uint_as_float(rw[g][k] << 16);
+              const float v1 = (dig_drop_keep(d.k0, d.k1, idx + 1u, 0u, d.thr) ? D2[jb][4 * g + 2 * k + 1] * sc : 0.f) +
+                               __uint_as_float(rw[g][k] & 0xffff0000u);
+              const unsigned u = pack_bf2(v0, v1);
+              Pk[g][k] = u;
+              if (lno) {
+                const dig_bf16x2 pr = __builtin_bit_cast(dig_bf16x2, u);
+                s1 = __builtin_amdgcn_fdot2_f32_bf16(pr, ones, s1, false);
+                s2 = __builtin_amdgcn_fdot2_f32_bf16(pr, pr, s2, false);
+                D2[jb][4 * g + 2 * k] = __uint_as_float(u << 16);
+                D2[jb][4 * g + 2 * k + 1] = __uint_as_float(u & 0xffff0000u);
+              }
+            }
+          store_block(orow + jb * 32, Pk);
+          __builtin_amdgcn_sched_barrier(0);                           // (the hashes of later blocks hoisted in front cost registers)
+        };
+        dload(0, qa);
+        dblock(std::integral_constant<int, 0>{}, qa, qb); dblock(std::integral_constant<int, 1>{}, qb, qa);
+        dblock(std::integral_constant<int, 2>{}, qa, qb); dblock(std::integral_constant<int, 3>{}, qb, qa);
+        dblock(std::integral_constant<int, 4>{}, qa, qb); dblock(std::integral_constant<int, 5>{}, qb, qa);
+        dblock(std::integral_constant<int, 6>{}, qa, qb); dblock(std::integral_constant<int, 7>{}, qb, qa);
+        dblock(std::integral_constant<int, 8>{}, qa, qb); dblock(std::integral_constant<int, 9>{}, qb, qa);
+        dblock(std::integral_constant<int, 10>{}, qa, qb); dblock(std::integral_constant<int, 11>{}, qb, qa);
+      } else {
+        if (lno) {
+          // LayerNorm of the finished rows (the next block's norm1), taken over the bf16 values that are stored -- what a separate LayerNorm
+          // launch would read back: round the accumulators in place, sum and sum of squares by v_dot2 on the packed pairs
+          const dig_bf16x2 ones = __builtin_bit_cast(dig_bf16x2, 0x3F803F80u);
+#pragma unroll
+          for (int jb = 0; jb < NJB; ++jb)
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+              const unsigned u = pack_bf2(D2[jb][2 * g], D2[jb][2 * g + 1]);
+              const dig_bf16x2 pr = __builtin_bit_cast(dig_bf16x2, u);
+              s1 = __builtin_amdgcn_fdot2_f32_bf16(pr, ones, s1, false);
+              s2 = __builtin_amdgcn_fdot2_f32_bf16(pr, pr, s2, false);
+              D2[jb][2 * g] = __uint_as_float(u << 16);
+              D2[jb][2 * g + 1] = __uint_as_float(u & 0xffff0000u);
+            }
         }
-        store_block(orow + jb * 32, Pk);
+#pragma unroll
+        for (int jb = 0; jb < NJB; ++jb) {
+          unsigned Pk[4][2];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            Pk[g][0] = pack_bf2(D2[jb][g * 4], D2[jb][g * 4 + 1]);
+            Pk[g][1] = pack_bf2(D2[jb][g * 4 + 2], D2[jb][g * 4 + 3]);
+          }
+          store_block(orow + jb * 32, Pk);
+        }
       }
       if (lno) {
         s1 += __shfl_xor(s1, 32, 64);
@@ -954,7 +1028,7 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainParams p) {
   }
 }
 
-template <int MODE, bool LN = false>
+template <int MODE, bool LN = false, bool DROP = false>
 int launch_chain(const ChainParams& p, hipStream_t stream) {
   const int lds = X_OFF + (MODE == 0 ? (p.F + KD) * 4 : (MODE == 1 ? SLOT + (p.F + KD) * 4 : 2 * SLOT)) + (LN ? 4 * KD * 4 : 0);
 #ifdef DIG_CHAIN_LDS_ALL
@@ -966,11 +1040,11 @@ int launch_chain(const ChainParams& p, hipStream_t stream) {
   static int attr_lds[DIG_MAX_DEVICES] = {};
   const int dev = dig_device();
   if (lds_launch > attr_lds[dev]) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_chain_kernel<MODE, LN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_launch) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_chain_kernel<MODE, LN, DROP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_launch) != hipSuccess)
       return DIG_ERR_LAUNCH;
     attr_lds[dev] = lds_launch;
   }
-  dig_launch(mlp_chain_kernel<MODE, LN>, dim3((p.R + BM - 1) / BM), dim3(512), lds_launch, stream, p);
+  dig_launch(mlp_chain_kernel<MODE, LN, DROP>, dim3((p.R + BM - 1) / BM), dim3(512), lds_launch, stream, p);
   return dig_check_launch();
 }
 
@@ -982,6 +1056,7 @@ void no_layernorm(ChainParams& p) {
   p.lnb_mean = p.lnb_rstd = nullptr;
   p.lnb_ws = nullptr;
   p.projt = nullptr; p.proj_out = nullptr;
+  p.drop = dig_dropout_t{};
 }
 
 int check_common(const void* x, const void* b1, const void* b2, const void* out, int R, int D, int F) {
@@ -1018,10 +1093,12 @@ extern "C" int dig_mlp_chain_fwd(const void* x, const void* w1, const float* b1,
 // normalised with (ln_g, ln_b) on the way in -- ln_out / ln_mean / ln_rstd receive what the backward keeps, or are null -- or, with ln_g
 // null, x holds rows that are normalised already (resid = the raw rows).  When nln_g is given, the output rows are normalised again with
 // (nln_g, nln_b) into nln_out (+ nln_mean / nln_rstd, or null).
-extern "C" int dig_mlp_chain_fwd_ln(const void* x, const void* resid, const float* ln_g, const float* ln_b, float eps, void* ln_out, float* ln_mean,
-                                    float* ln_rstd, const void* w1, const float* b1, const void* w2, const float* b2, void* out,
-                                    void* pre_out, void* act_out, const float* nln_g, const float* nln_b, void* nln_out, float* nln_mean,
-                                    float* nln_rstd, int R, int D, int F, hipStream_t stream) {
+// drop (optional): out = resid + drop_path(dropout(fc2(.) + b2)) -- Mlp.drop behind fc2 and the block's drop_path on the MLP branch
+extern "C" int dig_mlp_chain_fwd_ln_dropout(const void* x, const void* resid, const float* ln_g, const float* ln_b, float eps, void* ln_out,
+                                            float* ln_mean, float* ln_rstd, const void* w1, const float* b1, const void* w2, const float* b2,
+                                            void* out, void* pre_out, void* act_out, const float* nln_g, const float* nln_b, void* nln_out,
+                                            float* nln_mean, float* nln_rstd, int R, int D, int F, const dig_dropout_t* drop,
+                                            hipStream_t stream) {
   const int rc = check_common(x, w1, w2, out, R, D, F);
   if (rc != DIG_OK) return rc;
   if ((ln_g == nullptr) != (ln_b == nullptr) || (nln_g == nullptr) != (nln_b == nullptr) || (nln_g == nullptr) != (nln_out == nullptr)) return DIG_ERR_ARG;
@@ -1038,9 +1115,24 @@ extern "C" int dig_mlp_chain_fwd_ln(const void* x, const void* resid, const floa
   p.resid = (const bf16_t*)resid; p.out = (bf16_t*)out; p.side0 = (bf16_t*)act_out; p.side1 = (bf16_t*)pre_out; p.colsum = nullptr;
   p.R = R; p.F = F;
   p.x_bytes = (unsigned)((size_t)R * D * 2); p.w_bytes = (unsigned)((size_t)F * D * 2); p.side_bytes = (unsigned)((size_t)R * F * 2);
+  no_layernorm(p);
   p.ln_g = ln_g; p.ln_b = ln_b; p.ln_out = (bf16_t*)ln_out; p.ln_mean = ln_mean; p.ln_rstd = ln_rstd;
   p.nln_g = nln_g; p.nln_b = nln_b; p.nln_out = (bf16_t*)nln_out; p.nln_mean = nln_mean; p.nln_rstd = nln_rstd; p.ln_eps = eps;
+  if (drop && (drop->thr || drop->pthr)) {
+    if (drop->pthr && drop->rows_per_sample <= 0) return DIG_ERR_ARG;
+    if ((size_t)R * D >= (1ull << 32)) return DIG_ERR_UNSUPPORTED;                  // (element index of the mask hash: 32 bits)
+    p.drop = *drop;
+    return pre_out ? launch_chain<1, true, true>(p, stream) : launch_chain<0, true, true>(p, stream);
+  }
   return pre_out ? launch_chain<1, true>(p, stream) : launch_chain<0, true>(p, stream);
+}
+
+extern "C" int dig_mlp_chain_fwd_ln(const void* x, const void* resid, const float* ln_g, const float* ln_b, float eps, void* ln_out, float* ln_mean,
+                                    float* ln_rstd, const void* w1, const float* b1, const void* w2, const float* b2, void* out,
+                                    void* pre_out, void* act_out, const float* nln_g, const float* nln_b, void* nln_out, float* nln_mean,
+                                    float* nln_rstd, int R, int D, int F, hipStream_t stream) {
+  return dig_mlp_chain_fwd_ln_dropout(x, resid, ln_g, ln_b, eps, ln_out, ln_mean, ln_rstd, w1, b1, w2, b2, out, pre_out, act_out, nln_g, nln_b, nln_out,
+                                      nln_mean, nln_rstd, R, D, F, nullptr, stream);
 }
 
 // dig_mlp_chain_bwd with norm2's backward behind it: dx_mid = dy + LN2'(dX) in place of dX, and the three parameter-gradient partial sums

@@ -27,6 +27,9 @@ from .recognizer import RecModel, _encoder_pos, _sinusoid
 BF16, F32 = torch.bfloat16, torch.float32
 cf = ctypes.c_float
 FT_FUSED_QV = os.environ.get("DIG_FT_FUSED_QV", "1") != "0"
+# the encoder's MLP half as the pre-training step's fused launches: norm2 -> fc1 -> GELU -> fc2 -> Mlp.drop / drop_path -> + residual -> next norm1 in
+# one forward launch (dig_mlp_chain_fwd_ln_dropout), both data gradients in one backward launch (dig_mlp_chain_bwd on the masked gradient)
+FT_MLP_CHAIN = os.environ.get("DIG_FT_MLP_CHAIN", "1") != "0"
 FT_BATCH_REDUCE = os.environ.get("DIG_FT_BATCH_REDUCE", "0") == "1"      # opt-in: fewer launches, ~0.3 ms slower per step
 CLS_PAD = 128                     # classifier rows padded to a multiple of 64 (it is a non-transposed GEMM operand in backward)
 
@@ -363,24 +366,44 @@ class _TrainStep:
         x = ops.dropout_apply(x, self.ds_pos, out=x)
         scale = (D // H) ** -0.5
         self.enc_saved = []
+        self.use_chain = use_chain = FT_MLP_CHAIN and M.F <= 2048 and ops.mlp_chain_supported(D, M.F, B * N)
+        ln_next = None                                                          # norm1 of the next block, when the fused MLP launch made it
         for i in range(M.depth):
             b = f"encoder.blocks.{i}."
             ds = self.ds_enc[i]
             qo = M._offsets[b + "attn.q_bias"][0]
             qkv_bias = M.flat_params[qo:qo + 3 * D]                             # q_bias | 0 | v_bias (arena layout)
-            ln1, mu1, rs1 = ops.layernorm_fwd(x, self.p(b + "norm1.weight"), self.p(b + "norm1.bias"), 1e-6)
+            if ln_next is not None:
+                ln1, mu1, rs1 = ln_next
+            else:
+                ln1, mu1, rs1 = ops.layernorm_fwd(x, self.p(b + "norm1.weight"), self.p(b + "norm1.bias"), 1e-6)
             qkv = ops.linear_fwd(ln1, self.w(b + "attn.qkv.weight"), bias=qkv_bias, alpha=scale, alpha_cols=D)
             ctx, lse = ops.attn_fwd(qkv, B, H, D, drop=ds["attn"])
             # x + drop_path(proj_drop(proj(.))) / x + drop_path(drop(fc2(.))) (modeling_finetune.py:120,59,156-158): GEMM epilogue
             x_mid = ops.linear_fwd(ctx, self.w(b + "attn.proj.weight"), bias=self.p(b + "attn.proj.bias"), resid=x, drop=ds["proj"])
-            ln2, mu2, rs2 = ops.layernorm_fwd(x_mid, self.p(b + "norm2.weight"), self.p(b + "norm2.bias"), 1e-6)
             frozen = i < M.frozen_blocks                                        # no gradient flows into a frozen block: nothing is kept
-            pre = None if frozen else torch.empty((B * N, M.F), device=dev, dtype=BF16)
-            act = ops.linear_fwd(ln2, self.w(b + "mlp.fc1.weight"), bias=self.p(b + "mlp.fc1.bias"), act=1, pre=pre)
-            x_out = ops.linear_fwd(act, self.w(b + "mlp.fc2.weight"), bias=self.p(b + "mlp.fc2.bias"), resid=x_mid, drop=ds["mlp"])
+            ln_next = None
+            if use_chain:
+                # (the LayerNorm behind it -- the next block's norm1, or the encoder's final norm -- rides along where its statistics are kept)
+                nb = "encoder.norm." if i + 1 == M.depth else f"encoder.blocks.{i + 1}.norm1."
+                r = ops.mlp_chain_fwd_ln(x_mid, self.p(b + "norm2.weight"), self.p(b + "norm2.bias"), 1e-6, self.w(b + "mlp.fc1.weight"),
+                                         self.p(b + "mlp.fc1.bias"), self.w(b + "mlp.fc2.weight"), self.p(b + "mlp.fc2.bias"),
+                                         nln_g=None if frozen else self.p(nb + "weight"), nln_b=None if frozen else self.p(nb + "bias"),
+                                         save=not frozen, drop=ds["mlp"])
+                x_out, ln2, mu2, rs2, pre, act = r["out"], r["ln"], r["ln_mean"], r["ln_rstd"], r["pre"], r["act"]
+                if not frozen:
+                    ln_next = (r["nln"], r["nln_mean"], r["nln_rstd"])
+            else:
+                ln2, mu2, rs2 = ops.layernorm_fwd(x_mid, self.p(b + "norm2.weight"), self.p(b + "norm2.bias"), 1e-6)
+                pre = None if frozen else torch.empty((B * N, M.F), device=dev, dtype=BF16)
+                act = ops.linear_fwd(ln2, self.w(b + "mlp.fc1.weight"), bias=self.p(b + "mlp.fc1.bias"), act=1, pre=pre)
+                x_out = ops.linear_fwd(act, self.w(b + "mlp.fc2.weight"), bias=self.p(b + "mlp.fc2.bias"), resid=x_mid, drop=ds["mlp"])
             self.enc_saved.append(None if frozen else (x, ln1, mu1, rs1, qkv, ctx, lse, x_mid, ln2, mu2, rs2, pre, act))
             x = x_out
-        enc, emu, ers = ops.layernorm_fwd(x, self.p("encoder.norm.weight"), self.p("encoder.norm.bias"), 1e-6)
+        if ln_next is not None:
+            enc, emu, ers = ln_next
+        else:
+            enc, emu, ers = ops.layernorm_fwd(x, self.p("encoder.norm.weight"), self.p("encoder.norm.bias"), 1e-6)
         self.enc_last = (x, emu, ers, enc)
         return enc
 
@@ -503,6 +526,12 @@ class _TrainStep:
         grouped = (ops.WGRAD_GROUP and not FT_BATCH_REDUCE and
                    all(ops.wgrad_group_route(o, i_, Rg) is not None for o, i_ in ((M.F, D), (D, M.F), (3 * D, D), (D, D))))
         grp = ops.WgradGroup(dev) if grouped else None
+        wT = None
+        if getattr(self, "use_chain", False) and M.frozen_blocks < M.depth:
+            # K-contiguous copies of the MLP weights for the fused backward (one launch per weight shape, 1.2 MB per matrix)
+            blocks = [f"encoder.blocks.{i}." for i in range(M.frozen_blocks, M.depth)]
+            wT = dict(zip(blocks, zip(ops.transpose_bf16_multi([self.w(b_ + "mlp.fc2.weight") for b_ in blocks]),
+                                      ops.transpose_bf16_multi([self.w(b_ + "mlp.fc1.weight") for b_ in blocks]))))
         for i in reversed(range(M.frozen_blocks, M.depth)):                   # (frozen blocks are a prefix: the chain stops above them)
             b = f"encoder.blocks.{i}."
             x, ln1, mu1, rs1, qkv, ctx, lse, x_mid, ln2, mu2, rs2, pre, act = self.enc_saved[i]
@@ -528,10 +557,15 @@ class _TrainStep:
             if ds["mlp"] is not None:
                 self.side(lambda: ops.colsum(dz, self.g(b + "mlp.fc2.bias")), dz)
             side_wg(dz, act, self.g(b + "mlp.fc2.weight"))
-            dact, bparts = ops.linear_dgrad(dz, self.w(b + "mlp.fc2.weight"), gelu_pre=pre, colsum=True)
+            if wT is not None:                                                  # both data gradients of the MLP in one launch
+                dln2, dact, bparts = ops.mlp_chain_bwd(dz, wT[b][0], pre, wT[b][1])
+            else:
+                dact, bparts = ops.linear_dgrad(dz, self.w(b + "mlp.fc2.weight"), gelu_pre=pre, colsum=True)
+                dln2 = None
             self.side(lambda: csum(bparts, self.g(b + "mlp.fc1.bias")), bparts)
             side_wg(dact, ln2, self.g(b + "mlp.fc1.weight"))
-            dln2 = ops.linear_dgrad(dact, self.w(b + "mlp.fc1.weight"))
+            if dln2 is None:
+                dln2 = ops.linear_dgrad(dact, self.w(b + "mlp.fc1.weight"))
             dx_mid, fin2, ws2 = ops.layernorm_bwd(dln2, x_mid, self.p(b + "norm2.weight"), self.p(b + "norm2.bias"), mu2, rs2, dx,
                                                   self.g(b + "norm2.weight"), self.g(b + "norm2.bias"), out=dln2,
                                                   dres_colsum=self.g(b + "mlp.fc2.bias") if ds["mlp"] is None else None, defer=True)

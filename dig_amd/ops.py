@@ -145,11 +145,12 @@ def mlp_chain_fwd(x, w1, b1, w2, b2, resid, save=False):
     return (out, pre, act) if save else out
 
 
-def mlp_chain_fwd_ln(x, ln_g, ln_b, eps, w1, b1, w2, b2, nln_g=None, nln_b=None, save=False, resid=None):
+def mlp_chain_fwd_ln(x, ln_g, ln_b, eps, w1, b1, w2, b2, nln_g=None, nln_b=None, save=False, resid=None, drop=None):
     """The second half of a transformer block with its LayerNorms in one launch: out = x + b2 + gelu(LN(x; ln_g, ln_b) w1^T + b1) w2^T and,
     when nln_g is given, the next block's norm1 of `out`.  Returns a dict: out; nln / nln_mean / nln_rstd (when nln_g is given; the
     statistics only with save=True); with save=True also ln, ln_mean, ln_rstd, pre, act -- what the backward reads.
-    ln_g None: x holds rows that are normalised already and `resid` the raw rows that are added back."""
+    ln_g None: x holds rows that are normalised already and `resid` the raw rows that are added back.
+    drop (dropout.DropSpec or None): out = resid + drop_path(dropout(fc2(.) + b2)) -- Mlp.drop behind fc2 and the MLP branch's drop_path."""
     if resid is None:
         resid = x
     rows, D = x.shape
@@ -169,9 +170,10 @@ def mlp_chain_fwd_ln(x, ln_g, ln_b, eps, w1, b1, w2, b2, nln_g=None, nln_b=None,
         r["nln"] = torch.empty((rows, D), device=dev, dtype=BF16)
         if save:
             r["nln_mean"], r["nln_rstd"] = torch.empty(rows, device=dev, dtype=F32), torch.empty(rows, device=dev, dtype=F32)
-    L.call("dig_mlp_chain_fwd_ln", L.ptr(x), L.ptr(resid), L.ptr(ln_g), L.ptr(ln_b), cf(eps), L.ptr(r["ln"]), L.ptr(r["ln_mean"]), L.ptr(r["ln_rstd"]),
-           L.ptr(w1), L.ptr(b1), L.ptr(w2), L.ptr(b2), L.ptr(r["out"]), L.ptr(r["pre"]), L.ptr(r["act"]), L.ptr(nln_g), L.ptr(nln_b),
-           L.ptr(r["nln"]), L.ptr(r["nln_mean"]), L.ptr(r["nln_rstd"]), rows, D, Fh, L.stream())
+    L.call("dig_mlp_chain_fwd_ln_dropout", L.ptr(x), L.ptr(resid), L.ptr(ln_g), L.ptr(ln_b), cf(eps), L.ptr(r["ln"]), L.ptr(r["ln_mean"]),
+           L.ptr(r["ln_rstd"]), L.ptr(w1), L.ptr(b1), L.ptr(w2), L.ptr(b2), L.ptr(r["out"]), L.ptr(r["pre"]), L.ptr(r["act"]), L.ptr(nln_g),
+           L.ptr(nln_b), L.ptr(r["nln"]), L.ptr(r["nln_mean"]), L.ptr(r["nln_rstd"]), rows, D, Fh, ctypes.byref(drop) if drop is not None else None,
+           L.stream())
     return r
 
 

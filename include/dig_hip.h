@@ -480,6 +480,14 @@ int dig_gemm_bf16_dropout(const void* A, const void* B, void* C, int I, int J, i
                           int trans_b, int out_kind, const float* bias, const void* resid, int ldr, void* pre_act, int ldp, float alpha,
                           int alpha_cols, int act, int splits, int a_rows, int b_rows, int bk, float* colsum_partials,
                           const dig_dropout_t* drop, hipStream_t stream);
+/* dig_mlp_chain_fwd_ln with Mlp.drop behind fc2 and the block's drop_path on the MLP branch (modeling_finetune.py:59,158):
+ * out = resid + drop_path(dropout(gelu_erf(LN(x) w1^T + b1) w2^T + b2)); the mask rule and element index (row * D + col) are
+ * dig_gemm_bf16_dropout's, so the pattern is the two-GEMM path's bit for bit.  drop = NULL or both thresholds 0: dig_mlp_chain_fwd_ln.
+ * (The backward takes the masked gradient dig_dropout_apply(dy) as its input: dig_mlp_chain_bwd / _bwd_ln as they are.) */
+int dig_mlp_chain_fwd_ln_dropout(const void* x, const void* resid, const float* ln_g, const float* ln_b, float eps, void* ln_out, float* ln_mean,
+                                 float* ln_rstd, const void* w1, const float* b1, const void* w2, const float* b2, void* out, void* pre_out,
+                                 void* act_out, const float* nln_g, const float* nln_b, void* nln_out, float* nln_mean, float* nln_rstd, int R, int D,
+                                 int F, const dig_dropout_t* drop, hipStream_t stream);
 /* out = dropout/drop-path(in) on a [rows, cols] bf16 tensor (cols % 8 == 0, in-place allowed): pos_drop / embedding dropout in the
  * forward, and the gradient of any dropped branch in the backward (same mask, same scale). */
 int dig_dropout_apply(const void* in, void* out, long long rows, int cols, const dig_dropout_t* drop, hipStream_t stream);

@@ -518,6 +518,47 @@ def test_mlp_chain_fwd_bwd(dev, R, Fh):
     assert torch.equal(dx, dx2) and torch.equal(dpre, dpre2) and torch.equal(parts, parts2)     # bit-reproducible
 
 
+@pytest.mark.parametrize("R,Fh,p_el,p_path,save", [(512, 256, 0.1, 0.0, True), (768, 1536, 0.1, 0.2, True), (333, 128, 0.0, 0.3, False),
+                                                   (4096, 1536, 0.25, 0.1, False)])
+def test_mlp_chain_fwd_ln_dropout(dev, R, Fh, p_el, p_path, save):
+    """dig_mlp_chain_fwd_ln_dropout (the fine-tune encoder's MLP half: Mlp.drop behind fc2 + drop_path of the branch, modeling_finetune.py:59,158)
+    against the launches it replaces -- LayerNorm, fc1 + GELU, fc2 with the GEMM dropout epilogue + residual, the next LayerNorm: the same keyed
+    mask (dropped elements return the residual value exactly, in the same places), kept values to the fused-vs-unfused yardstick."""
+    from dig_amd import ops, dropout as DR
+    D = 384
+    cpu_limit(dev, 4.0 * R * D * Fh, limit=3e9)
+    g = torch.Generator(device="cpu").manual_seed(R + Fh)
+    rn = lambda *s: torch.randn(*s, generator=g).to(dev)
+    x = (rn(R, D) * 1.2).bfloat16()
+    gam, bet, ngam, nbet = 1.0 + 0.2 * rn(D), 0.1 * rn(D), 1.0 + 0.2 * rn(D), 0.1 * rn(D)
+    w1 = (rn(Fh, D) * 0.06).bfloat16(); b1 = rn(Fh) * 0.5
+    w2 = (rn(D, Fh) * 0.04).bfloat16(); b2 = rn(D) * 0.5
+    spec = DR.DropPlan(1234, 5).spec(DR.enc_site(3, 3), p_el, DR.enc_site(3, 4), p_path, 64)
+    r = ops.mlp_chain_fwd_ln(x, gam, bet, 1e-6, w1, b1, w2, b2, nln_g=ngam, nln_b=nbet, save=save, drop=spec)
+    ln2, mu, rs = ops.layernorm_fwd(x, gam, bet, 1e-6)
+    pre = torch.empty((R, Fh), device=dev, dtype=torch.bfloat16)
+    act = ops.linear_fwd(ln2, w1, bias=b1, act=1, pre=pre)
+    out = ops.linear_fwd(act, w2, bias=b2, resid=x, drop=spec)
+    nln, nmu, nrs = ops.layernorm_fwd(out, ngam, nbet, 1e-6)
+    assert rel(r["out"], out) < 4e-3 and rel(r["nln"], nln) < 1e-2
+    same_a, same_b = r["out"] == x, out == x                           # dropped elements (and drop-path rows): the residual value itself
+    assert float((same_a != same_b).float().mean()) < 1e-4
+    if p_path == 0.0:                                                  # (drop-path acts on R / 64 samples: too few for a rate at these sizes)
+        assert abs(float(same_b.float().mean()) - p_el) < 0.02
+    else:
+        rows_dropped = same_b.all(dim=1).view(-1)                      # a dropped sample: 64 whole rows return the residual
+        assert bool(rows_dropped.any()) and not bool(rows_dropped.all())
+        assert torch.equal(rows_dropped, same_a.all(dim=1).view(-1))
+    if save:
+        assert rel(r["pre"], pre) < 2e-3 and rel(r["act"], act) < 2e-3 and rel(r["ln"], ln2) < 1e-2
+        assert rel(r["nln_mean"], nmu) < 1e-2
+    plain = ops.mlp_chain_fwd_ln(x, gam, bet, 1e-6, w1, b1, w2, b2, nln_g=ngam, nln_b=nbet, save=save)
+    none = ops.mlp_chain_fwd_ln(x, gam, bet, 1e-6, w1, b1, w2, b2, nln_g=ngam, nln_b=nbet, save=save, drop=DR.DropPlan(1, 1).spec(7, 0.0))
+    assert torch.equal(plain["out"], none["out"])                      # no rate: the plain launch
+    again = ops.mlp_chain_fwd_ln(x, gam, bet, 1e-6, w1, b1, w2, b2, nln_g=ngam, nln_b=nbet, save=save, drop=spec)
+    assert torch.equal(again["out"], r["out"]) and torch.equal(again["nln"], r["nln"])
+
+
 @pytest.mark.parametrize("R,Fh", [(128, 128), (333, 256), (4096, 1536), (1000, 2048), (65536, 1536)])
 def test_mlp_chain_bwd_ln(dev, R, Fh):
     """dig_mlp_chain_bwd_ln (the MLP's data gradient AND norm2's backward in one launch) against the two launches it replaces
