@@ -539,11 +539,13 @@ int dig_embed_rows(const long long* tokens, const float* table, void* out, int l
 
 /* ------------------------------------------------------------------------------------------------------------------
  * One call per encoder block (Block.forward, modeling_finetune.py:150-158, and its gradient): the launch sequences of
- * dig_amd/engine_core.py's default plan issued from the library -- forward: dig_gemm_bf16 (qkv, q scaled) -> dig_attn_fwd ->
- * dig_gemm_bf16 (proj + residual) -> dig_mlp_chain_fwd_ln;  backward: dig_mlp_chain_bwd -> dig_layernorm_bwd_partials (norm2) ->
- * dig_gemm_bf16 (proj data gradient) -> dig_attn_bwd (with the q / v bias sums) -> dig_wgrad_group (the block's four weight gradients +
- * the fold of the previous block's) -> dig_gemm_bf16 (qkv data gradient) -> dig_layernorm_bwd_partials (norm1) on `stream`, then the five
- * parameter-gradient reductions (dig_colsum_partials x 3, dig_layernorm_bwd_finalize x 2) on b->side behind one event.  Same kernels,
+ * dig_amd/engine_core.py's default plan issued from the library -- forward: dig_attn_block_fwd (fuse_attn; else dig_gemm_bf16 (qkv, q
+ * scaled) -> dig_attn_fwd -> dig_gemm_bf16 (proj + residual)) -> dig_mlp_chain_fwd_ln;  backward: dig_mlp_chain_bwd_ln (fuse_ln2: the MLP's
+ * data gradients and norm2's backward in one launch, with projt also the projection's data gradient; else dig_mlp_chain_bwd ->
+ * dig_layernorm_bwd_partials (norm2)) -> dig_gemm_bf16 (proj data gradient) -> dig_attn_bwd (with the q / v bias sums) -> dig_wgrad_group (the
+ * block's four weight gradients + the fold of the previous block's; not with wg_defer) -> dig_gemm_bf16 (qkv data gradient) ->
+ * dig_layernorm_bwd_partials (norm1) on `stream`, then the five parameter-gradient reductions (dig_colsum_partials x 3,
+ * dig_layernorm_bwd_finalize(_parts) x 2) on b->side behind one event.  Same kernels,
  * same arguments, same order as the per-entry-point path: results are bit-identical to it.  The tables are HOST memory.
  * Returns the first non-zero code of the sequence (nothing after it is launched). */
 int dig_encoder_block_fwd(const dig_block_fwd_t* b, hipStream_t stream);
