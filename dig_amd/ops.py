@@ -58,7 +58,18 @@ def gemm(A, B, I, J, R, *, ta=False, tb=False, out=None, out_kind=OUT_BF16, bias
 
 PERSISTENT_FWD = os.environ.get("DIG_PERSISTENT_FWD", "1") != "0"
 FWD_192_BELOW = int(os.environ.get("DIG_FWD_192_BELOW", "512"))     # output widths = 128 mod 256 below this run on 256x192 tiles (no padded columns)
-DGRAD_GELU_BK = 32    # tile of the fc2 dgrad + GELU' + bias-sum GEMM: 128x128/BK32 beats the 256x256 tile inside the step (A/B: 25.9 vs 26.1 ms)
+# Tile of the fc2 dgrad + GELU' + bias-sum GEMM (the models the fused MLP backward does not take: D = 512).  -1 = by shape: the 256x256 tile for
+# tall problems with a 256-multiple width (round 1 kept 128x128 / BK32 everywhere: it shared the CUs better with the weight-gradient stream
+# of that time, 25.9 vs 26.1 ms; with the grouped weight gradients the backward is a sum of solo kernel times -- see DGRAD_BK below)
+DGRAD_GELU_BK = int(os.environ.get("DIG_DGRAD_GELU_BK", "-1"))
+
+
+def dgrad_gelu_tile_code(rows, J, drop=None):
+    if DGRAD_GELU_BK >= 0:
+        return DGRAD_GELU_BK
+    return 244 if (rows >= 8192 and drop is None and J % 256 == 0) else 32
+
+
 def fwd_tile_code(rows, out_dim, K, *, act=0, has_resid=False, drop=None, out_kind=OUT_BF16):
     """DIG_GEMM_TILE_* of a forward Linear layer [rows, K] -> [rows, out_dim].
     Measured on MI355X (profiles/r01_gemm_variants.txt, tools/gpu_bk_probe.py):
@@ -258,7 +269,7 @@ def linear_dgrad(dy, w, out=None, gelu_pre=None, colsum=False, drop=None):
     bias gradient of the layer that produced gelu_pre, for colsum_partials()."""
     if gelu_pre is not None:
         parts = torch.empty(((dy.shape[0] + 63) // 64, w.shape[1]), device=dy.device, dtype=F32) if colsum else None
-        dx = gemm(dy, w, dy.shape[0], w.shape[1], w.shape[0], tb=True, out=out, act=2, resid=gelu_pre, bk=DGRAD_GELU_BK, colsum_partials=parts,
+        dx = gemm(dy, w, dy.shape[0], w.shape[1], w.shape[0], tb=True, out=out, act=2, resid=gelu_pre, bk=dgrad_gelu_tile_code(dy.shape[0], w.shape[1], drop), colsum_partials=parts,
                   drop=drop)
         return (dx, parts) if colsum else dx
     # few rows (the BN-MLP heads on pooled features): 128x64 tiles double the workgroup count (tools/gpu_head_gemm_probe.py).
