@@ -7,8 +7,8 @@
 //
 // What this is NOT: it is not the oracle (tests compare it, like the HIP library, against fp32 torch references and oracle/), and
 // it is not a fallback -- nothing under dig_amd/ loads it; the product raises without libdig_hip.so (dig_amd/_lib.py).  Entry
-// points outside the pre-training step (recognition decode, fine-tune sequence attention, GRU head, input transform) are not built
-// here; tests/test_cpu_abi.py lists the exported subset.
+// points outside the pre-training step (recognition decode, fine-tune sequence attention, GRU head, input transform) are in
+// dig_cpu_rec.cpp; together the two files export every entry point the header declares (tests/test_cpu_abi.py).
 //
 // Build: make -C cpu_abi   (g++ -O2 -fopenmp -shared -fPIC; __graft_entry__.build() runs it)
 #include <algorithm>

@@ -55,15 +55,16 @@ def resize_normalize(crops, out_h=32, out_w=128, mean=0.5, std=0.5, device="cuda
     sizes = hs.astype(np.int64) * ws.astype(np.int64) * 3
     offs = np.zeros(n, dtype=np.int64)
     np.cumsum(sizes[:-1], out=offs[1:])
-    packed = torch.empty(int(sizes.sum()), dtype=torch.uint8).pin_memory()
+    dev = torch.device(device)
+    pin = (lambda t: t.pin_memory()) if dev.type == "cuda" else (lambda t: t)       # (pinned staging only where there is a device to copy to)
+    packed = pin(torch.empty(int(sizes.sum()), dtype=torch.uint8))
     flat = packed.numpy()
     for c, o, s in zip(crops, offs, sizes):
         if c.dtype != np.uint8 or c.ndim != 3 or c.shape[2] != 3:
             raise ValueError("crops must be HxWx3 uint8 (the RGB image PIL decodes)")
         flat[o:o + s] = np.ascontiguousarray(c).reshape(-1)
-    dev = torch.device(device)
     d_packed = packed.to(dev, non_blocking=True)
-    d_meta = torch.from_numpy(np.concatenate([offs, hs.astype(np.int64), ws.astype(np.int64)])).pin_memory().to(dev, non_blocking=True)
+    d_meta = pin(torch.from_numpy(np.concatenate([offs, hs.astype(np.int64), ws.astype(np.int64)]))).to(dev, non_blocking=True)
     d_off, d_h, d_w = d_meta[:n], d_meta[n:2 * n].to(torch.int32), d_meta[2 * n:].to(torch.int32)
     out = torch.empty((n, 3, out_h, out_w), device=dev, dtype=torch.float32)
     L.call("dig_resize_bicubic_normalize_u8", L.ptr(d_packed), L.ptr(d_off), L.ptr(d_h), L.ptr(d_w), n, L.ptr(out), out_h, out_w,

@@ -759,8 +759,8 @@ class _SeqCEFn(torch.autograd.Function):
         B, T, C = x.shape
         Cp = (C + 7) // 8 * 8
         dl = torch.empty((B * T, Cp), device=x.device, dtype=BF16)
-        L.call("dig_seq_cross_entropy_bwd", L.ptr(x), C, L.ptr(target), L.ptr(length), L.ptr(g.reshape(1).float().contiguous()), B, T, C, L.ptr(dl),
-               Cp, L.stream())
+        gs = g.reshape(1).float().contiguous()                         # (named: a converted copy must outlive the call)
+        L.call("dig_seq_cross_entropy_bwd", L.ptr(x), C, L.ptr(target), L.ptr(length), L.ptr(gs), B, T, C, L.ptr(dl), Cp, L.stream())
         return dl[:, :C].float().reshape(B, T, C), None, None
 
 
@@ -797,8 +797,9 @@ class _SeqLSCEFn(torch.autograd.Function):
         B, T, C = x.shape
         Cp = (C + 7) // 8 * 8
         dl = torch.empty((B * T, Cp), device=x.device, dtype=BF16)
-        L.call("dig_seq_ls_cross_entropy_bwd", L.ptr(x), C, L.ptr(target), L.ptr(length), L.ptr(g.reshape(1).float().contiguous()), B, T, C,
-               cf(ctx.smoothing), L.ptr(dl), Cp, L.stream())
+        gs = g.reshape(1).float().contiguous()
+        L.call("dig_seq_ls_cross_entropy_bwd", L.ptr(x), C, L.ptr(target), L.ptr(length), L.ptr(gs), B, T, C, cf(ctx.smoothing), L.ptr(dl), Cp,
+               L.stream())
         return dl[:, :C].float().reshape(B, T, C), None, None, None
 
 

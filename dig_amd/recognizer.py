@@ -392,8 +392,8 @@ def accuracy(pred_tokens, target_tokens, voc):
     dev = pred_tokens.device
     canon = class_canon(voc).to(dev)
     match = torch.empty(B, device=dev, dtype=torch.uint8)
-    L.call("dig_string_match", L.ptr(pred_tokens.contiguous()), L.ptr(target_tokens.to(dev).contiguous()), L.ptr(canon), len(voc),
-           voc.index("EOS"), B, T, L.ptr(match), L.stream())
+    pred, targ = pred_tokens.contiguous(), target_tokens.to(dev).contiguous()
+    L.call("dig_string_match", L.ptr(pred), L.ptr(targ), L.ptr(canon), len(voc), voc.index("EOS"), B, T, L.ptr(match), L.stream())
     return match.float().mean()
 
 
@@ -402,8 +402,8 @@ def recognition_f_measure(pred_tokens, target_tokens, voc):
     B, T = pred_tokens.shape
     dev = pred_tokens.device
     f = torch.empty(B, device=dev, dtype=torch.float64)
-    L.call("dig_char_fmeasure", L.ptr(pred_tokens.contiguous()), L.ptr(target_tokens.to(dev).contiguous()), L.ptr(class_canon(voc).to(dev)),
-           len(voc), voc.index("EOS"), B, T, L.ptr(f), L.stream())
+    pred, targ, canon = pred_tokens.contiguous(), target_tokens.to(dev).contiguous(), class_canon(voc).to(dev)   # (named: alive across the call)
+    L.call("dig_char_fmeasure", L.ptr(pred), L.ptr(targ), L.ptr(canon), len(voc), voc.index("EOS"), B, T, L.ptr(f), L.stream())
     return f.mean()
 
 
@@ -417,6 +417,6 @@ class SeqCrossEntropyLoss(torch.nn.Module):
         inp = input.detach().float().contiguous()
         rows = torch.empty(B * T, device=dev, dtype=F32)
         loss = torch.empty(1, device=dev, dtype=F32)
-        L.call("dig_seq_cross_entropy", L.ptr(inp), L.ptr(target.to(dev).long().contiguous()), L.ptr(length.to(dev).long().contiguous()), B, T, C,
-               L.ptr(rows), L.ptr(loss), L.stream())
+        tgt, lens = target.to(dev).long().contiguous(), length.to(dev).long().contiguous()
+        L.call("dig_seq_cross_entropy", L.ptr(inp), L.ptr(tgt), L.ptr(lens), B, T, C, L.ptr(rows), L.ptr(loss), L.stream())
         return loss[0]

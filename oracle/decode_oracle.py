@@ -307,7 +307,9 @@ def str_list(tokens, voc):
                 break
             if t != unk:
                 chars.append(voc[int(t)])
-        out.append("".join(c for c in "".join(chars) if c in keep).lower())
+        # (_normalize_text filters the LIST of class strings, element by element, with `x in digits + letters` -- a substring test: a
+        #  multi-character class such as PADDING is dropped whole, metrics.py:14-16,56-57)
+        out.append("".join(c for c in chars if c in keep).lower())
     return out
 
 

@@ -14,7 +14,8 @@ CPU_LIB = os.path.join(ROOT, "cpu_abi", "libdig_cpu.so")
 
 def build():
     src = os.path.join(ROOT, "cpu_abi", "dig_cpu.cpp")
-    deps = [src, os.path.join(ROOT, "dig_amd", "csrc", "encoder_block.inc"), os.path.join(ROOT, "include", "dig_block_types.h")]
+    deps = [src, os.path.join(ROOT, "cpu_abi", "dig_cpu_rec.cpp"), os.path.join(ROOT, "dig_amd", "csrc", "encoder_block.inc"),
+            os.path.join(ROOT, "include", "dig_block_types.h")]
     if not os.path.exists(CPU_LIB) or os.path.getmtime(CPU_LIB) < max(os.path.getmtime(d) for d in deps):
         subprocess.run(["make", "-C", os.path.join(ROOT, "cpu_abi")], check=True, capture_output=True)
     return CPU_LIB

@@ -1,4 +1,4 @@
-"""cpu_abi/libdig_cpu.so: the plain-C++ build of the pre-training entry points of include/dig_hip.h ("a CPU build of
+"""cpu_abi/libdig_cpu.so: the plain-C++ build of the entry points of include/dig_hip.h ("a CPU build of
 the same ABI so the parity tests run in a GPU-less container").  The operator parity itself is tests/test_gpu_kernels.py, which runs
 every test on both builds; here: what the build exports, that its prototypes are the header's, that it rejects bad arguments with
 the ABI's error codes, and (on the GPU box) that the integer / byte operators of both builds agree bit for bit."""
@@ -10,17 +10,10 @@ import torch
 from cpu_abi_util import build, cpu_abi_backend, exported
 from test_abi_symbols import declared_symbols
 
-# entry points of the recognition rows (N1 / N3 / N4), which the CPU build leaves out
-NOT_BUILT_PREFIXES = ("dig_decode_", "dig_seq_", "dig_beam_", "dig_softmax_argmax", "dig_string_match", "dig_char_fmeasure",
-                      "dig_resize_", "dig_random_masks", "dig_addattn_", "dig_gru_", "dig_embed_rows")
-
-
-def test_exports_the_pretraining_subset_of_the_header():
+def test_exports_every_entry_point_of_the_header():
+    """dig_cpu.cpp (the pre-training step) + dig_cpu_rec.cpp (the recognition rows N1 / N3 / N4): the whole header, nothing else."""
     exp, decl = set(exported()), set(declared_symbols())
-    assert exp <= decl, sorted(exp - decl)                                 # nothing that the header does not declare
-    missing = sorted(s for s in decl - exp if not s.startswith(NOT_BUILT_PREFIXES))
-    assert not missing, missing                                            # every pre-training entry point is there
-    assert len(exp) >= 55
+    assert exp == decl, (sorted(exp - decl), sorted(decl - exp))
 
 
 def test_product_never_loads_the_cpu_build():

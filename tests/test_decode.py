@@ -141,11 +141,10 @@ def test_device_recognizer_vs_reference_fixture():
     assert abs(float(out[0].sum(-1).mean()) - 1.0) < 1e-4
 
 
-@pytest.mark.gpu
-def test_decode_attention_kernels_vs_torch():
+def test_decode_attention_kernels_vs_torch(abi_dev):
     import ctypes
     from dig_amd import _lib as L
-    dev = torch.device("cuda:0")
+    dev = abi_dev
     torch.manual_seed(0)
     B, T, H, Nm, hk = 7, 9, 3, 200, 192
     qkv = torch.randn(B, T, 3 * hk, device=dev).to(torch.bfloat16)
@@ -172,12 +171,11 @@ def test_decode_attention_kernels_vs_torch():
     assert (probs - logits[:, :97].softmax(-1)).abs().max().item() < 1e-6 and torch.equal(tok, logits[:, :97].argmax(-1)) and int(tok[2]) == 5
 
 
-@pytest.mark.gpu
-def test_beam_step_kernel_vs_torch():
+def test_beam_step_kernel_vs_torch(abi_dev):
     """dig_beam_step against the reference's own expressions (log_softmax + topk over [B, bw*C], decoder.py:291-301) on random logits,
     with -inf running scores (dead slots) and EOS masking."""
     from dig_amd import _lib as L
-    dev = torch.device("cuda:0")
+    dev = abi_dev
     torch.manual_seed(1)
     for B, bw, C, ld, eos in ((7, 5, 97, 104, 94), (3, 1, 97, 97, 94), (4, 8, 20, 24, 3)):
         S = B * bw
@@ -276,8 +274,8 @@ def test_oracle_string_accuracy_rules():
     assert D.str_list(pred, voc) == ["hello", "ab", "xyz", "qr"] and D.accuracy(pred, targ, voc) == 0.75
 
 
-@pytest.mark.gpu
-def test_device_string_accuracy_matches_oracle():
+def test_device_string_accuracy_matches_oracle(abi_dev):
+    dev0 = str(abi_dev)
     from dig_amd.recognizer import accuracy
     voc = D.vocabulary()
     rng = np.random.RandomState(0)
@@ -288,13 +286,13 @@ def test_device_string_accuracy_matches_oracle():
     pred[flip] = rng.randint(0, 97, size=int(flip.sum()))
     pred[::7, 3] = 94; targ[::5, 6] = 94                                         # early EOS on either side
     want = D.accuracy(pred, targ, voc)
-    got = accuracy(torch.from_numpy(pred).to("cuda:0"), torch.from_numpy(targ).to("cuda:0"), voc).item()
+    got = accuracy(torch.from_numpy(pred).to(dev0), torch.from_numpy(targ).to(dev0), voc).item()
     assert 0.05 < want < 0.95 and abs(got - want) < 1e-7
     p1, t1 = D.str_list(pred, voc), D.str_list(targ, voc)                        # and sample by sample
     from dig_amd import _lib as L
     from dig_amd.recognizer import class_canon
-    match = torch.empty(B, dtype=torch.uint8, device="cuda:0")
-    pd, td, cn = torch.from_numpy(pred).to("cuda:0"), torch.from_numpy(targ).to("cuda:0"), class_canon(voc).to("cuda:0")
+    match = torch.empty(B, dtype=torch.uint8, device=dev0)
+    pd, td, cn = torch.from_numpy(pred).to(dev0), torch.from_numpy(targ).to(dev0), class_canon(voc).to(dev0)
     L.call("dig_string_match", L.ptr(pd), L.ptr(td), L.ptr(cn), 97, 94, B, T, L.ptr(match), L.stream())
     assert match.cpu().numpy().astype(bool).tolist() == [a == b for a, b in zip(p1, t1)]
 
@@ -308,6 +306,28 @@ def test_oracle_seq_ce_and_fmeasure_rules():
     enc = lambda w, n=8: [voc.index(c) for c in w] + [94] + [95] * (n - len(w) - 1)
     f = D.recognition_f_measure(np.array([enc("aab"), enc("xyz")]), np.array([enc("ab"), enc("xw")]), voc)
     assert abs(f - (1.0 * 2 / (2 + 1e-5) * 2 / (2 + 1e-5) * 2 / (2 * 2 / (2 + 1e-5) + 1e-5) + 2 * (1 / (3 + 1e-5)) * (1 / (2 + 1e-5)) / (1 / (3 + 1e-5) + 1 / (2 + 1e-5) + 1e-5)) / 2) < 1e-9
+
+
+def test_device_seq_ce_and_fmeasure_kernels_match_oracle(abi_dev):
+    """dig_seq_cross_entropy and dig_char_fmeasure (the evaluation loop's loss and character F-measure) against the oracle functions on random
+    label rows with early EOS, dropped classes and zero-length samples."""
+    from dig_amd.recognizer import SeqCrossEntropyLoss, recognition_f_measure
+    voc = D.vocabulary()
+    g = torch.Generator().manual_seed(3)
+    B, T = 37, 25
+    inp = torch.randn(B, T, 97, generator=g) * 2
+    tgt = torch.randint(0, 97, (B, T), generator=g)
+    lens = torch.randint(0, T + 1, (B,), generator=g)
+    got = SeqCrossEntropyLoss()(inp.to(abi_dev), tgt.to(abi_dev), lens.to(abi_dev)).item()
+    assert abs(got - D.seq_cross_entropy(inp, tgt, lens).item()) < 1e-4 * abs(got)
+    rng = np.random.RandomState(5)
+    targ = rng.randint(0, 97, size=(B, T))
+    pred = targ.copy()
+    flip = rng.rand(B, T) < 0.2
+    pred[flip] = rng.randint(0, 97, size=int(flip.sum()))
+    pred[::4, 5] = 94; targ[::3, 9] = 94
+    f = recognition_f_measure(torch.from_numpy(pred).to(abi_dev), torch.from_numpy(targ).to(abi_dev), voc).item()
+    assert abs(f - D.recognition_f_measure(pred, targ, voc)) < 1e-12
 
 
 @pytest.mark.gpu

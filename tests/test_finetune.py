@@ -56,12 +56,11 @@ def test_layer_ids_follow_reference_rule():
 
 
 # ------------------------------------------------------------------------------------------------ device kernels
-@pytest.mark.gpu
 @pytest.mark.parametrize("Lk,causal", [(25, True), (256, False), (9, True), (100, False)])
-def test_seq_attention_fwd_bwd_vs_torch(Lk, causal):
+def test_seq_attention_fwd_bwd_vs_torch(abi_dev, Lk, causal):
     import ctypes
     from dig_amd import _lib as L
-    dev = torch.device("cuda:0")
+    dev = abi_dev
     torch.manual_seed(1)
     B, H, Lq = 5, 3, (Lk if causal else 25)
     hk = H * 64
@@ -93,10 +92,9 @@ def test_seq_attention_fwd_bwd_vs_torch(Lk, causal):
     assert rel(dq, qf.grad) < 2e-2 and rel(dkv, kvf.grad) < 2e-2
 
 
-@pytest.mark.gpu
-def test_seq_embedding_and_cross_entropy_kernels_vs_torch():
+def test_seq_embedding_and_cross_entropy_kernels_vs_torch(abi_dev):
     from dig_amd import _lib as L
-    dev = torch.device("cuda:0")
+    dev = abi_dev
     torch.manual_seed(2)
     B, T, d, V, C, Cp = 7, 25, 128, 98, 97, 104
     tok = torch.randint(0, V, (B, T), device=dev)
@@ -130,7 +128,8 @@ def test_seq_embedding_and_cross_entropy_kernels_vs_torch():
     L.call("dig_seq_cross_entropy_bwd", L.ptr(logits), Cp, L.ptr(tgt), L.ptr(lens), L.ptr(g), B, T, C, L.ptr(dl), Cp, L.stream())
     assert (dl.float().view(B, T, Cp)[..., :C] - lf.grad).abs().max().item() < 2e-3 and float(dl.float().view(B, T, Cp)[..., C:].abs().max()) == 0.0
     rows = torch.empty(B * T, device=dev); out = torch.empty(1, device=dev)
-    L.call("dig_seq_cross_entropy", L.ptr(logits[..., :C].contiguous()), L.ptr(tgt), L.ptr(lens), B, T, C, L.ptr(rows), L.ptr(out), L.stream())
+    lc = logits[..., :C].contiguous()
+    L.call("dig_seq_cross_entropy", L.ptr(lc), L.ptr(tgt), L.ptr(lens), B, T, C, L.ptr(rows), L.ptr(out), L.stream())
     assert abs(out.item() - loss.item()) < 1e-4 * abs(loss.item())
 
 
@@ -358,13 +357,12 @@ def test_dropout_keys_and_mask_statistics():
     assert abs(np.corrcoef(keep, other)[0, 1]) < 5e-3
 
 
-@pytest.mark.gpu
-def test_dropout_kernels_reproduce_the_oracle_masks():
+def test_dropout_kernels_reproduce_the_oracle_masks(abi_dev):
     """dig_dropout_apply, the GEMM dropout epilogue (forward with residual + drop-path, and the GELU' backward form) and the
     attention kernels with attention dropout: the keep/drop pattern is the oracle's, bit for bit."""
     import ctypes
     from dig_amd import _lib as L, ops, dropout as DR
-    dev = torch.device("cuda:0")
+    dev = abi_dev
     g = torch.Generator().manual_seed(4)
     dr = F.DropOracle(77, 3, drop=0.1, attn_drop=0.1, drop_path=0.25, depth=4, decoder_dropout=0.1)
     plan = DR.DropPlan(77, 3)
@@ -412,11 +410,10 @@ def _attn_ref(q, k, v, mask, dr, site, p):
     return dr.attn(site, s.softmax(-1), p) @ v
 
 
-@pytest.mark.gpu
-def test_attention_dropout_kernels_vs_torch_with_oracle_masks():
+def test_attention_dropout_kernels_vs_torch_with_oracle_masks(abi_dev):
     from dig_amd import _lib as L, ops, dropout as DR
     import ctypes
-    dev = torch.device("cuda:0")
+    dev = abi_dev
     g = torch.Generator().manual_seed(8)
     dr = F.DropOracle(5, 11, attn_drop=0.1, decoder_dropout=0.1)
     plan = DR.DropPlan(5, 11)
@@ -631,11 +628,10 @@ def test_oracle_label_smoothing_loss_matches_reference_fixture():
         assert abs(closed.item() - loss) <= 2e-5 * abs(loss)
 
 
-@pytest.mark.gpu
-def test_device_label_smoothing_loss_vs_reference_fixture():
+def test_device_label_smoothing_loss_vs_reference_fixture(abi_dev):
     from dig_amd.finetune import SeqLabelSmoothingCrossEntropyLoss
     for x, t, l, sm, loss, grad in _ls_cases():
-        xd = x.to("cuda:0").requires_grad_(True)
+        xd = x.clone().to(abi_dev).requires_grad_(True)
         got = SeqLabelSmoothingCrossEntropyLoss(sm)(xd, t, l)
         (got * 0.5).backward()
         assert abs(got.item() - loss) <= 2e-5 * abs(loss)
@@ -673,11 +669,10 @@ def test_oracle_gru_attention_head_matches_reference_fixture():
     np.testing.assert_allclose(probs.numpy(), g["sample_probs"], atol=3e-5)
 
 
-@pytest.mark.gpu
-def test_gru_attention_kernels_vs_torch():
+def test_gru_attention_kernels_vs_torch(abi_dev):
     """dig_addattn_fwd / _bwd / _bwd_tokens and dig_gru_cell_fwd / _bwd against torch autograd on the same (bf16-rounded) operands."""
     from dig_amd import _lib as L
-    dev = torch.device("cuda:0")
+    dev = abi_dev
     g = torch.Generator().manual_seed(12)
     B, N, A, X, T = 5, 256, 64, 128, 3
     xproj = torch.randn(B, N, A, generator=g).bfloat16(); x = torch.randn(B, N, X, generator=g).bfloat16()

@@ -1,5 +1,6 @@
 """Row N3 (input transform either side of the hot path): the numpy oracle against the Pillow-generated golden vectors
-(CPU), and the HIP kernels against the oracle bit for bit (GPU)."""
+(CPU), and the kernels against the oracle bit for bit -- the HIP build on the GPU, the plain-C++ build of the same entry points
+(cpu_abi/dig_cpu_rec.cpp) in the GPU-less container (`abi_dev`, tests/conftest.py)."""
 import os
 
 import numpy as np
@@ -40,10 +41,10 @@ def test_oracle_masks_are_fixed_size_subsets():
     assert IO.philox4x32_10((0, 0, 0, 0), (0, 0)) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]   # Random123 known answer
 
 
-@pytest.mark.gpu
-def test_device_resize_normalize_bit_exact():
+def test_device_resize_normalize_bit_exact(abi_dev):
     import torch
-    from dig_amd.datasets import resize_normalize
+    from dig_amd.datasets import resize_normalize as _rn
+    resize_normalize = lambda crops, h, w: _rn(crops, h, w, device=abi_dev)
     z, n = _cases()
     crops = [z[f"in_{i}"] for i in range(n)]
     out = resize_normalize(crops, 32, 128).cpu().numpy()
@@ -60,17 +61,16 @@ def test_device_resize_normalize_bit_exact():
         assert np.array_equal(o, IO.transform(c, 48, 160))
 
 
-@pytest.mark.gpu
-def test_device_masks_match_oracle_and_are_uniform():
+def test_device_masks_match_oracle_and_are_uniform(abi_dev):
     import torch
     from dig_amd.datasets import RandomMaskingGenerator
-    g = RandomMaskingGenerator((8, 32), 0.7, num_view=2, seed=0x1234567890AB, device="cuda:0")
+    g = RandomMaskingGenerator((8, 32), 0.7, num_view=2, seed=0x1234567890AB, device=abi_dev)
     m0 = g(6).cpu().numpy()
     m1 = g(6).cpu().numpy()
     assert m0.shape == (6, 2, 256) and (m0.sum(-1) == 179).all() and (m1.sum(-1) == 179).all()
     assert np.array_equal(m0.reshape(12, 256), IO.random_masks(12, 256, 179, 0x1234567890AB, 0))
     assert np.array_equal(m1.reshape(12, 256), IO.random_masks(12, 256, 179, 0x1234567890AB, 1))
-    big = RandomMaskingGenerator((8, 32), 0.7, num_view=2, seed=5, device="cuda:0")(4096).float()      # 8192 rows
+    big = RandomMaskingGenerator((8, 32), 0.7, num_view=2, seed=5, device=abi_dev)(4096).float()       # 8192 rows
     freq = big.mean((0, 1)).cpu().numpy()                                                                # per-patch masking rate
     assert abs(freq.mean() - 179 / 256) < 1e-6
     assert np.abs(freq - 179 / 256).max() < 5 * np.sqrt(0.7 * 0.3 / 8192)                             # 5 sigma per position
