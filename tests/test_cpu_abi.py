@@ -79,3 +79,46 @@ def test_hip_and_cpu_builds_agree_bit_for_bit_on_integer_and_byte_work():
         ref = run(cpu)
     for i, (x, y) in enumerate(zip(hip, ref)):
         assert torch.equal(x.view(torch.int16) if x.dtype == torch.bfloat16 else x, y.view(torch.int16) if y.dtype == torch.bfloat16 else y), i
+
+
+@pytest.mark.gpu
+def test_hip_and_cpu_builds_agree_bit_for_bit_on_the_recognition_rows_integer_work():
+    """bicubic resize + normalise (fixed-point Pillow arithmetic), Philox mask generator, token embedding rows, string match, beam-step symbols /
+    predecessors and the greedy token of dig_softmax_argmax: same bits from both builds (cpu_abi/dig_cpu_rec.cpp)."""
+    import numpy as np
+    from dig_amd import _lib as L
+    from dig_amd.datasets import resize_normalize, RandomMaskingGenerator
+    rng = np.random.RandomState(3)
+    crops = [rng.randint(0, 256, size=(rng.randint(4, 90), rng.randint(8, 400), 3)).astype(np.uint8) for _ in range(12)]
+    g = torch.Generator().manual_seed(9)
+    tok = torch.randint(-2, 101, (57,), generator=g)                      # (out-of-range tokens are clamped)
+    table = torch.randn(99, 40, generator=g)
+    pred = torch.randint(0, 97, (64, 25), generator=g); targ = pred.clone()
+    targ[torch.rand(64, 25, generator=g) < 0.05] = 3
+    canon = torch.tensor([(i % 37) if i < 94 else 0 for i in range(97)], dtype=torch.uint8)
+    B, bw, C, ld = 6, 5, 97, 104
+    logits = torch.randn(B * bw, ld, generator=g) * 3
+    seq0 = -torch.rand(B * bw, generator=g) * 4
+
+    def run(d):
+        out = [resize_normalize(crops, 32, 128, device=d), RandomMaskingGenerator((8, 32), 0.7, num_view=2, seed=77, device=d)(9)]
+        emb = torch.empty(57, 48, dtype=torch.bfloat16, device=d)
+        t_, tb = tok.to(d), table.to(d)
+        L.call("dig_embed_rows", L.ptr(t_), L.ptr(tb), L.ptr(emb), 48, 57, 40, 99, L.stream())
+        out.append(emb[:, :40].contiguous())
+        match = torch.empty(64, dtype=torch.uint8, device=d)
+        p_, q_, c_ = pred.to(d), targ.to(d), canon.to(d)
+        L.call("dig_string_match", L.ptr(p_), L.ptr(q_), L.ptr(c_), 97, 94, 64, 25, L.ptr(match), L.stream())
+        out.append(match)
+        lg, seq = logits.to(d), seq0.clone().to(d)
+        sym = torch.empty(B * bw, dtype=torch.int64, device=d); prd = torch.empty_like(sym); st = torch.empty(B * bw, device=d)
+        L.call("dig_beam_step", L.ptr(lg), ld, L.ptr(seq), B, bw, C, 94, L.ptr(sym), L.ptr(prd), L.ptr(st), L.stream())
+        probs = torch.empty(B * bw, C, device=d); tk = torch.empty(B * bw, dtype=torch.int64, device=d)
+        L.call("dig_softmax_argmax", L.ptr(lg), ld, L.ptr(probs), L.ptr(tk), B * bw, C, L.stream())
+        out += [sym, prd, tk]
+        return [t.cpu() for t in out]
+    hip = run(torch.device("cuda:0"))
+    with cpu_abi_backend() as cpu:
+        ref = run(cpu)
+    for i, (x, y) in enumerate(zip(hip, ref)):
+        assert torch.equal(x.view(torch.int16) if x.dtype == torch.bfloat16 else x, y.view(torch.int16) if y.dtype == torch.bfloat16 else y), i
