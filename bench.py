@@ -350,6 +350,25 @@ def cpu_baseline(model_name, budget_s=20.0):
                       f"(`value`; one untimed step at that batch first), {n4} steps at batch 4 (BASELINE configs[0])"}
 
 
+def _self_launch(n):
+    """Re-executes this command under `python -m torch.distributed.run --nnodes=1 --nproc-per-node n` on 127.0.0.1 with a free port.  With
+    DIG_SHARE_GPU=1 (test harness: every rank on device 0) the backend defaults to gloo -- RCCL refuses two ranks on one device."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if env.get("DIG_SHARE_GPU") == "1":
+        env.setdefault("DIG_DIST_BACKEND", "gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    r = subprocess.run(cmd, env=env)
+    if r.returncode:
+        raise SystemExit(r.returncode)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -366,6 +385,10 @@ def main():
     ap.add_argument("--no-step-graph", action="store_true", help="skip the extra measurement of the HIP-graph replay of the step")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     a = ap.parse_args()
+    if a.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU over RCCL -- the reference's own launch line is
+        # `torch.distributed.launch --nproc_per_node=8`, README.md:53), rank 0's single JSON line comes back on our stdout
+        return _self_launch(a.gpus)
 
     import dig_amd.utils as U
     from dig_amd.registry import create_model

@@ -18,6 +18,7 @@
 // without any data movement (the V / K / Q / dO operand is fetched with the matching row permutation by
 // the transpose read).
 #include "common.h"
+#include <atomic>
 
 // phase time stamps for tools/experiments/attn_bwd_lab.hip (empty in the product build)
 #ifndef DIG_ATTN_SP_LAB
@@ -681,11 +682,11 @@ __global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const bf16_t* __restri
 }  // namespace
 
 // which backward kernel dig_attn_bwd launches for full self-attention without dropout: 1 = single pass (attn_bwd_sp_kernel), 0 = two phases
-static int g_attn_bwd_single_pass = DIG_ATTN_BWD_SP_DEFAULT;
+// (read by dig_attn_bwd on autograd's thread while a caller's thread may set it: an atomic, read once per launch)
+static std::atomic<int> g_attn_bwd_single_pass{DIG_ATTN_BWD_SP_DEFAULT};
 extern "C" int dig_attn_bwd_mode(int single_pass) {
-  const int old = g_attn_bwd_single_pass;
-  if (single_pass == 0 || single_pass == 1) g_attn_bwd_single_pass = single_pass;
-  return old;
+  if (single_pass == 0 || single_pass == 1) return g_attn_bwd_single_pass.exchange(single_pass, std::memory_order_relaxed);
+  return g_attn_bwd_single_pass.load(std::memory_order_relaxed);
 }
 
 extern "C" int dig_attn_fwd_dropout(const void* qkv, void* ctx, float* lse, int n_img, int heads, int embed_dim,
@@ -729,7 +730,7 @@ extern "C" int dig_attn_bwd_dropout(const void* qkv, const void* ctx, const void
   const size_t qb = (size_t)n_img * N_TOK * 3 * embed_dim * 2;
   if (qb >= (1ull << 32)) return DIG_ERR_ARG;
   const int dev = dig_device();
-  if (g_attn_bwd_single_pass && !(drop && drop->thr) && nqb == 8) {
+  if (g_attn_bwd_single_pass.load(std::memory_order_relaxed) && !(drop && drop->thr) && nqb == 8) {
     static bool sp_attr[DIG_MAX_DEVICES] = {};
     if (!sp_attr[dev]) {
       hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_sp_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, SP_CS_OFF);

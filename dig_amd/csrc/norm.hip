@@ -424,7 +424,7 @@ extern "C" int dig_layernorm_bwd_finalize(const float* workspace, int rows, int 
   return dig_check_launch();
 }
 
-// the same over a workspace of `parts` partial rows written by another producer (dig_mlp_chain_bwd_ln: one per 32 rows)
+// the same over a workspace of `parts` partial rows written by another producer (dig_mlp_chain_bwd_ln: one per 128 rows = one per workgroup, dig_mlp_chain_ln_parts)
 extern "C" int dig_layernorm_bwd_finalize_parts(const float* workspace, int parts, int D, float* dgamma, float* dbeta, float* dcolsum,
                                                 hipStream_t stream) {
   if (!workspace || !dgamma || !dbeta || parts <= 0 || D <= 0 || (D & 15)) return DIG_ERR_ARG;

@@ -37,7 +37,12 @@ WGRAD_INLINE = os.environ.get("DIG_WGRAD_INLINE", "1") == "1"
 # (default): deferred in a single process (nothing waits for a block's gradients before the optimizer: 19.96 -> 19.83 ms per step, A/B on one
 # box), inline under a process group (a block's bucket must be final as early as possible: its all-reduce overlaps the rest of the backward).
 # "1" / "0" force either plan.  Deferring keeps every block's gradient temporaries alive until the end of the backward (~0.45 GB per ViT-S block).
-WGRAD_DEFER = os.environ.get("DIG_WGRAD_DEFER", "auto")
+# "auto" also checks the device's free memory against what the deferred plan keeps alive (depth x the block's bf16 temporaries + the saved
+# activations no longer released block by block: ~5.4 GB more at the end of the backward for ViT-S at B = 128) and stays inline when that
+# would not leave a quarter of the free memory.
+WGRAD_DEFER = os.environ.get("DIG_WGRAD_DEFER", "auto").strip().lower()
+if WGRAD_DEFER not in ("auto", "0", "1"):
+    raise ValueError(f"DIG_WGRAD_DEFER={WGRAD_DEFER!r}: one of auto, 0, 1")
 BWD_SINGLE_STREAM = os.environ.get("DIG_BWD_SINGLE", "0") == "1"    # lab switch: the whole backward on the caller's stream (sum of solo kernel times)
 
 
@@ -239,6 +244,7 @@ class _Step:
         saved = []
         nb_blocks = len(ew.blocks)
         key = ("fwd_call", bool(save), R, n_img)
+        fuse_attn = int(ops.attn_block_supported(H, D))
         prev = None
         for i, blk in enumerate(ew.blocks):
             st = blk.get(key)
@@ -247,7 +253,7 @@ class _Step:
                 st = blk[key] = ops.BlockFwd(
                     n_img=n_img, heads=H, D=D, F=Fh, rows=R, save=int(bool(save)),
                     tile_qkv=ops.fwd_tile_code(R, 3 * D, D) or ops.GEMM_BK_FWD, tile_proj=ops.fwd_tile_code(R, D, D, has_resid=True) or ops.GEMM_BK_FWD,
-                    fuse_attn=int(ops.attn_block_supported(H, D)), eps=M.ln_eps, scale=(D // H) ** -0.5,
+                    fuse_attn=fuse_attn, eps=M.ln_eps, scale=(D // H) ** -0.5,
                     qkv_w=blk["attn.qkv.weight"].data_ptr(), qkv_b=blk["qkv_bias"].data_ptr(), proj_w=blk["attn.proj.weight"].data_ptr(),
                     proj_b=blk["attn.proj.bias"].data_ptr(), n2_g=blk["norm2.weight"].data_ptr(), n2_b=blk["norm2.bias"].data_ptr(),
                     fc1_w=blk["mlp.fc1.weight"].data_ptr(), fc1_b=blk["mlp.fc1.bias"].data_ptr(), fc2_w=blk["mlp.fc2.weight"].data_ptr(),
@@ -256,6 +262,7 @@ class _Step:
             b16 = torch.empty(n16 // 2, device=dev, dtype=BF16)
             b32 = torch.empty(n32 // 4, device=dev, dtype=F32)
             p16, p32 = b16.data_ptr(), b32.data_ptr()
+            st.fuse_attn = fuse_attn                                  # (a switch, like fuse_ln2 / wg_defer of the backward: read on every call)
             st.x, st.ln1 = inp_ptr[0], inp_ptr[1]
             st.qkv, st.ctx, st.x_mid, st.out, st.nln = p16 + off["qkv"], p16 + off["ctx"], p16 + off["x_mid"], p16 + off["out"], p16 + off["nln"]
             st.lse = p32 + off["lse"]
@@ -291,8 +298,7 @@ class _Step:
         dy_ptr, dy_owner = dx.data_ptr(), dx
         prev_block, n_launch, slabs_prev = None, 0, None
         deferred = []                                                    # deferred plan: (problem table, temporaries kept alive) per block
-        defer = (WGRAD_DEFER is True or WGRAD_DEFER == "1" or
-                 (WGRAD_DEFER == "auto" and self.comm is LOCAL))
+        defer = WGRAD_DEFER == "1" or (WGRAD_DEFER == "auto" and self.comm is LOCAL and self._defer_fits(dev, M.depth * n16))
         for i in reversed(range(M.depth)):
             blk, g, sv = ew.blocks[i], ew.blocks[i]["g"], saved[i]
             saved[i] = None
@@ -383,6 +389,18 @@ class _Step:
             self._grad_ready(dev, f"encoder.blocks.{prev_block}")
         a = off["dctx"] // 2
         return dy_owner[a:a + R * D].view(R, D)
+
+    def _defer_fits(self, dev, extra_bytes):
+        """The deferred weight-gradient plan keeps `extra_bytes` of gradient temporaries (and every block's saved activations) alive until
+        the end of the backward: taken only while that leaves three quarters of what the device (and torch's pool) has free.  The answer
+        is cached per size: one hipMemGetInfo per new shape, not per step."""
+        cache = self.m.__dict__.setdefault("_defer_fits_cache", {})
+        key = (dev.index, extra_bytes)
+        if key not in cache:
+            free, _ = torch.cuda.mem_get_info(dev)
+            pooled = torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+            cache[key] = extra_bytes <= (free + pooled) // 4
+        return cache[key]
 
     def mlp_weight_transposes(self, ew):
         """K-contiguous copies of the MLP weights for the fused backward (W2^T [F, D], W1^T [D, F]; 1.2 MB each, 24 small launches):

@@ -48,6 +48,19 @@ class DiGConfig:
     ln_eps: float = 1e-6        # partial(nn.LayerNorm, eps=1e-6)
     bn_eps: float = 1e-5        # nn.BatchNorm1d default
     bn_momentum: float = 0.1
+    # which objectives the model carries (MoCo_ViT(use_pixel_target, use_moco_target), modeling_pretrain_moco_mim_ori.py:340-426):
+    #   "simmim_moco" both (the pretrain_simmim_moco_ori_* factories), "moco" = Dis-only (pretrain_moco_ori_*, :627-653,709-735,818-843:
+    #   no mask, no pix_projector, no decoder), "simmim" = Gen-only (pretrain_simmim_ori_*, :655-681,737-763,845-871: the encoder keeps its
+    #   final LayerNorm, no momentum networks, no heads; the patch embedding keeps nn.Conv2d's default init)
+    kind: str = "simmim_moco"
+
+    @property
+    def use_moco(self) -> bool:
+        return self.kind in ("simmim_moco", "moco")
+
+    @property
+    def use_pixel(self) -> bool:
+        return self.kind in ("simmim_moco", "simmim")
 
     @property
     def grid(self) -> Tuple[int, int]:
@@ -70,6 +83,12 @@ CONFIGS = {
     "pretrain_simmim_moco_ori_vit_tiny_patch4_32x128": dict(embed_dim=192, depth=12, heads=3),
     "pretrain_simmim_moco_ori_vit_small_patch4_32x128": dict(embed_dim=384, depth=12, heads=6),
     "pretrain_simmim_moco_ori_vit_base_patch4_32x128": dict(embed_dim=512, depth=12, heads=8),
+    "pretrain_moco_ori_vit_tiny_patch4_32x128": dict(embed_dim=192, depth=12, heads=3, kind="moco"),
+    "pretrain_moco_ori_vit_small_patch4_32x128": dict(embed_dim=384, depth=12, heads=6, kind="moco"),
+    "pretrain_moco_ori_vit_base_patch4_32x128": dict(embed_dim=512, depth=12, heads=8, kind="moco"),
+    "pretrain_simmim_ori_vit_tiny_patch4_32x128": dict(embed_dim=192, depth=12, heads=3, kind="simmim"),
+    "pretrain_simmim_ori_vit_small_patch4_32x128": dict(embed_dim=384, depth=12, heads=6, kind="simmim"),
+    "pretrain_simmim_ori_vit_base_patch4_32x128": dict(embed_dim=512, depth=12, heads=8, kind="simmim"),
 }
 
 
@@ -103,6 +122,9 @@ def _encoder_param_shapes(cfg: DiGConfig, pre: str) -> "OrderedDict[str, tuple]"
         o[b + "mlp.fc1.bias"] = (Fh,)
         o[b + "mlp.fc2.weight"] = (D, Fh)
         o[b + "mlp.fc2.bias"] = (D,)
+    if not cfg.use_moco:                                                # Gen-only keeps encoder.norm (the moco branch replaces it by
+        o[pre + "norm.weight"] = (D,)                                   # nn.Identity, modeling_pretrain_moco_mim_ori.py:362-363)
+        o[pre + "norm.bias"] = (D,)
     return o
 
 
@@ -134,29 +156,33 @@ def _mlp_buffer_shapes(pre: str, dims) -> "OrderedDict[str, tuple]":
 def mlp_specs(cfg: DiGConfig) -> "OrderedDict[str, list]":
     """The five BN-MLPs of MoCo_ViT (modeling_pretrain_moco_mim_ori.py:366-369, 415-416)."""
     D = cfg.embed_dim
-    return OrderedDict([
-        ("encoder_projection_layer.", _mlp_dims(3, D, cfg.moco_mlp_dim, cfg.moco_dim)),
-        ("momentum_projection_layer.", _mlp_dims(3, D, cfg.moco_mlp_dim, cfg.moco_dim)),
-        ("predictor.", _mlp_dims(2, cfg.moco_dim, cfg.moco_mlp_dim, cfg.moco_dim)),
-        ("pix_projector.", _mlp_dims(3, D, cfg.pix_mlp_dim, D)),
-        ("pix_projector_m.", _mlp_dims(3, D, cfg.pix_mlp_dim, D)),
-    ])
+    o = OrderedDict()
+    if cfg.use_moco:
+        o["encoder_projection_layer."] = _mlp_dims(3, D, cfg.moco_mlp_dim, cfg.moco_dim)
+        o["momentum_projection_layer."] = _mlp_dims(3, D, cfg.moco_mlp_dim, cfg.moco_dim)
+        o["predictor."] = _mlp_dims(2, cfg.moco_dim, cfg.moco_mlp_dim, cfg.moco_dim)
+    if cfg.use_moco and cfg.use_pixel:                                  # `if use_moco_target and use_pix_projector`, :412-420
+        o["pix_projector."] = _mlp_dims(3, D, cfg.pix_mlp_dim, D)
+        o["pix_projector_m."] = _mlp_dims(3, D, cfg.pix_mlp_dim, D)
+    return o
 
 
 def param_shapes(cfg: DiGConfig) -> "OrderedDict[str, tuple]":
     """All 356 (ViT-S) parameters in reference named_parameters() order."""
     o = OrderedDict()
     o.update(_encoder_param_shapes(cfg, "encoder."))
-    o.update(_encoder_param_shapes(cfg, "momentum_encoder."))
+    if cfg.use_moco:
+        o.update(_encoder_param_shapes(cfg, "momentum_encoder."))
     for pre, dims in mlp_specs(cfg).items():
         o.update(_mlp_param_shapes(pre, dims))
-    Dd = cfg.dec_dim                                                      # pix_decoder, :422-426
-    o["pix_decoder.0.weight"] = (Dd, cfg.embed_dim)
-    o["pix_decoder.1.weight"] = (Dd, Dd)
-    o["pix_decoder.2.weight"] = (Dd,)
-    o["pix_decoder.2.bias"] = (Dd,)
-    o["pix_decoder.4.weight"] = (cfg.dec_classes, Dd)
-    o["pix_decoder.4.bias"] = (cfg.dec_classes,)
+    if cfg.use_pixel:
+        Dd = cfg.dec_dim                                                  # pix_decoder, :422-426
+        o["pix_decoder.0.weight"] = (Dd, cfg.embed_dim)
+        o["pix_decoder.1.weight"] = (Dd, Dd)
+        o["pix_decoder.2.weight"] = (Dd,)
+        o["pix_decoder.2.bias"] = (Dd,)
+        o["pix_decoder.4.weight"] = (cfg.dec_classes, Dd)
+        o["pix_decoder.4.bias"] = (cfg.dec_classes,)
     return o
 
 
@@ -204,11 +230,16 @@ def init_state(cfg: DiGConfig, seed: int = 0, dtype=torch.float32):
         if name.endswith("mask_token"):
             t = torch.zeros(shp, dtype=dtype)
         elif name.endswith("patch_embed.proj.weight"):
-            t = uni(shp, math.sqrt(6.0 / float(3 * cfg.patch * cfg.patch + cfg.embed_dim)))
+            if cfg.use_moco:                                              # :353-355 (inside `if use_moco_target`)
+                t = uni(shp, math.sqrt(6.0 / float(3 * cfg.patch * cfg.patch + cfg.embed_dim)))
+            else:                                                         # Gen-only: nn.Conv2d's own init, U(+-1/sqrt(fan_in))
+                t = uni(shp, 1.0 / math.sqrt(cfg.in_chans * cfg.patch * cfg.patch))
+        elif name.endswith("patch_embed.proj.bias") and not cfg.use_moco:
+            t = uni(shp, 1.0 / math.sqrt(cfg.in_chans * cfg.patch * cfg.patch))
         elif name.startswith("encoder."):
             if len(shp) == 2:
                 t = uni(shp, math.sqrt(6.0 / (shp[0] + shp[1])))           # xavier_uniform_
-            elif name.endswith("norm1.weight") or name.endswith("norm2.weight"):
+            elif name.endswith(("norm1.weight", "norm2.weight", "norm.weight")):
                 t = torch.ones(shp, dtype=dtype)
             else:
                 t = torch.zeros(shp, dtype=dtype)
@@ -225,9 +256,11 @@ def init_state(cfg: DiGConfig, seed: int = 0, dtype=torch.float32):
         else:                                                             # BN beta
             t = torch.zeros(shp, dtype=dtype)
         P[name] = t
+    shapes = param_shapes(cfg)
     for src, dst in ema_pairs(list(P.keys())):
-        P[dst] = P[src].clone()
-    P = OrderedDict((k, P[k]) for k in param_shapes(cfg))                 # reference order
+        if dst in shapes:
+            P[dst] = P[src].clone()
+    P = OrderedDict((k, P[k]) for k in shapes)                            # reference order
     S = OrderedDict()
     for name, shp in buffer_shapes(cfg).items():
         if name.endswith("running_var"):
@@ -343,6 +376,8 @@ def encoder(P, pre, images, mask, cfg: DiGConfig, taps=None):
         x = block(x, P, f"{pre}blocks.{i}.", cfg, taps)
         if taps is not None:
             taps[f"{pre}blocks.{i}"] = x
+    if pre + "norm.weight" in P:                                          # x = self.norm(x), modeling_pretrain_vit.py:104 (Gen-only)
+        x = layer_norm(x, P[pre + "norm.weight"], P[pre + "norm.bias"], cfg.ln_eps)
     return x
 
 
@@ -388,7 +423,11 @@ def window_pool(x, cfg: DiGConfig):
     to (1, num_windows)."""
     Bn, N, C = x.shape
     gh, gw = cfg.grid
-    assert gw % cfg.num_windows == 0
+    if gw % cfg.num_windows:
+        # uneven windows (the argparse default --num_windows 5 on 32 columns, run_mae_pretraining_moco.py:143): adaptive_avg_pool2d's
+        # bins [floor(i gw / nw), ceil((i + 1) gw / nw)) overlap by a column
+        y = F.adaptive_avg_pool2d(x.reshape(Bn, gh, gw, C).permute(0, 3, 1, 2), (1, cfg.num_windows))
+        return y.reshape(Bn, C, cfg.num_windows).permute(0, 2, 1)
     return x.reshape(Bn, gh, cfg.num_windows, gw // cfg.num_windows, C).mean(dim=(1, 3))
 
 
@@ -414,48 +453,65 @@ def ema_update(P, m: float):
     """_update_momentum_encoder, :428-442 (parameters only; BN buffers are not EMA'd)."""
     with torch.no_grad():
         for src, dst in ema_pairs([n for n in P if is_trainable(n)]):
+            if dst not in P:                                              # (Gen-only models have no momentum networks)
+                continue
             P[dst].copy_(P[dst] * m + P[src].detach() * (1.0 - m))
 
 
 def model_forward(P, S, images, aug_images, mask, m: float, cfg: DiGConfig, comm=None,
                   only_mim_on_ori_img: bool = True, taps=None, do_ema: bool = True):
-    """MoCo_ViT.forward, modeling_pretrain_moco_mim_ori.py:488-577.  mask: bool [B, num_view, N]."""
+    """MoCo_ViT.forward, modeling_pretrain_moco_mim_ori.py:488-577.  mask: bool [B, num_view, N] (ignored by the Dis-only models:
+    `if not self.use_pixel_target: vis_mask_pos = None`, :493-494)."""
     comm = comm or LocalComm()
     B = images.shape[0]
     N, D = cfg.num_patches, cfg.embed_dim
     specs = mlp_specs(cfg)
     allim = torch.cat([images, aug_images], 0)
     num_view = mask.shape[1]
-    mflat = mask.permute(1, 0, 2).reshape(-1, N)                          # rows 0..B-1 = view 0 (:497)
+    mflat = mask.permute(1, 0, 2).reshape(-1, N) if cfg.use_pixel else None     # rows 0..B-1 = view 0 (:497)
     enc = encoder(P, "encoder.", allim, mflat, cfg, taps)
-    masked = bn_mlp(enc[:B].reshape(B * N, D), P, S, "pix_projector.", specs["pix_projector."], cfg, comm, taps)
-    feat = torch.cat([masked.reshape(B, N, D), enc[B:]], 0)
-    pooled = window_pool(feat, cfg).reshape(2 * B * cfg.num_windows, D)
-    qs = bn_mlp(pooled, P, S, "encoder_projection_layer.", specs["encoder_projection_layer."], cfg, comm, taps)
-    qs = bn_mlp(qs, P, S, "predictor.", specs["predictor."], cfg, comm, taps)
-    half = B * cfg.num_windows
-    q1, q2 = qs[:half], qs[half:]
-    with torch.no_grad():
-        if do_ema:
-            ema_update(P, m)
-        enc_m = encoder(P, "momentum_encoder.", allim, mflat, cfg)
-        masked_m = bn_mlp(enc_m[:B].reshape(B * N, D), P, S, "pix_projector_m.", specs["pix_projector_m."], cfg, comm)
-        feat_m = torch.cat([masked_m.reshape(B, N, D), enc_m[B:]], 0)
-        pooled_m = window_pool(feat_m, cfg).reshape(2 * B * cfg.num_windows, D)
-        ks = bn_mlp(pooled_m, P, S, "momentum_projection_layer.", specs["momentum_projection_layer."], cfg, comm)
-        k1, k2 = ks[:half], ks[half:]
-    l1, a11, a15 = info_nce(q1, k2, cfg.T, comm)
-    l2, a21, a25 = info_nce(q2, k1, cfg.T, comm)
-    out = {"contra_loss": l1 + l2, "q1_acc1": a11, "q1_acc5": a15, "q2_acc1": a21, "q2_acc5": a25}
-    h = F.linear(enc, P["pix_decoder.0.weight"])                          # :422-426, on raw encoder output (:561)
-    h = F.linear(h, P["pix_decoder.1.weight"])
-    h = F.gelu(layer_norm(h, P["pix_decoder.2.weight"], P["pix_decoder.2.bias"], cfg.ln_eps))
-    dec = F.linear(h, P["pix_decoder.4.weight"], P["pix_decoder.4.bias"])
-    C = dec.shape[-1]
-    views = range(1) if only_mim_on_ori_img else range(num_view)
-    out["vis_out"] = [dec[v * B:(v + 1) * B][mflat[v * B:(v + 1) * B]].reshape(B, -1, C) for v in views]
+    has_pp = "pix_projector." in specs                                    # hasattr(self, 'pix_projector'), :500
+    out = {}
+    if cfg.use_moco:
+        if has_pp:
+            masked = bn_mlp(enc[:B].reshape(B * N, D), P, S, "pix_projector.", specs["pix_projector."], cfg, comm, taps)
+            feat = torch.cat([masked.reshape(B, N, D), enc[B:]], 0)
+        else:
+            feat = enc
+        pooled = window_pool(feat, cfg).reshape(2 * B * cfg.num_windows, D)
+        qs = bn_mlp(pooled, P, S, "encoder_projection_layer.", specs["encoder_projection_layer."], cfg, comm, taps)
+        qs = bn_mlp(qs, P, S, "predictor.", specs["predictor."], cfg, comm, taps)
+        half = B * cfg.num_windows
+        q1, q2 = qs[:half], qs[half:]
+        with torch.no_grad():
+            if do_ema:
+                ema_update(P, m)
+            enc_m = encoder(P, "momentum_encoder.", allim, mflat, cfg)
+            if has_pp:
+                masked_m = bn_mlp(enc_m[:B].reshape(B * N, D), P, S, "pix_projector_m.", specs["pix_projector_m."], cfg, comm)
+                feat_m = torch.cat([masked_m.reshape(B, N, D), enc_m[B:]], 0)
+            else:
+                feat_m = enc_m
+            pooled_m = window_pool(feat_m, cfg).reshape(2 * B * cfg.num_windows, D)
+            ks = bn_mlp(pooled_m, P, S, "momentum_projection_layer.", specs["momentum_projection_layer."], cfg, comm)
+            k1, k2 = ks[:half], ks[half:]
+        l1, a11, a15 = info_nce(q1, k2, cfg.T, comm)
+        l2, a21, a25 = info_nce(q2, k1, cfg.T, comm)
+        out.update({"contra_loss": l1 + l2, "q1_acc1": a11, "q1_acc5": a15, "q2_acc1": a21, "q2_acc5": a25})
+        if taps is not None:
+            taps.update(q1=q1, q2=q2, k1=k1, k2=k2, feat=feat, pooled=pooled)
+    if cfg.use_pixel:
+        h = F.linear(enc, P["pix_decoder.0.weight"])                      # :422-426, on raw encoder output (:561)
+        h = F.linear(h, P["pix_decoder.1.weight"])
+        h = F.gelu(layer_norm(h, P["pix_decoder.2.weight"], P["pix_decoder.2.bias"], cfg.ln_eps))
+        dec = F.linear(h, P["pix_decoder.4.weight"], P["pix_decoder.4.bias"])
+        C = dec.shape[-1]
+        views = range(1) if only_mim_on_ori_img else range(num_view)
+        out["vis_out"] = [dec[v * B:(v + 1) * B][mflat[v * B:(v + 1) * B]].reshape(B, -1, C) for v in views]
+        if taps is not None:
+            taps.update(dec=dec)
     if taps is not None:
-        taps.update(enc=enc, q1=q1, q2=q2, k1=k1, k2=k2, dec=dec, feat=feat, pooled=pooled)
+        taps.update(enc=enc)
     return out
 
 
@@ -593,12 +649,21 @@ class OracleTrainer:
         out = model_forward(self.P, self.S, images, aug_images, mask, hp.moco_m, cfg, self.comm,
                             hp.only_mim_on_ori_img, taps)
         nv = 1 if hp.only_mim_on_ori_img else mask_f.shape[1]
-        loss_pixel = sum((1.0 / nv) * F.mse_loss(out["vis_out"][i], labels[i]) for i in range(nv))
-        loss = out["contra_loss"] * hp.w_contrast + loss_pixel * hp.w_pixel
+        # engine_for_pretraining_moco.py:119-144: each term only `if '<key>' in out_dict` (the single-objective models leave one out)
+        loss = 0.0
+        loss_pixel = None
+        if "contra_loss" in out:
+            loss = loss + out["contra_loss"] * hp.w_contrast
+        if "vis_out" in out:
+            loss_pixel = sum((1.0 / nv) * F.mse_loss(out["vis_out"][i], labels[i]) for i in range(nv))
+            loss = loss + loss_pixel * hp.w_pixel
         loss.backward()
         grads = {}
-        for n in train:
+        self.never_grad = set()               # `p.grad is None`: the reference's AdamW skips such a parameter altogether (custom_optim/adamw.py:78-79:
+        for n in train:                       #  no decay, no state) -- Dis-only's encoder.mask_token, which its unmasked encoder never reads
             g = self.P[n].grad
+            if g is None:
+                self.never_grad.add(n)
             grads[n] = torch.zeros_like(self.P[n]) if g is None else g.detach()
             self.P[n].requires_grad_(False)
             self.P[n].grad = None
@@ -612,9 +677,13 @@ class OracleTrainer:
                 k = grads[n].numel()
                 grads[n] = flat[o:o + k].view_as(grads[n])
                 o += k
-        metrics = {"loss": float(loss.detach()), "loss_pixel": float(loss_pixel.detach()), "loss_contrast": float(out["contra_loss"].detach()),
-                   "q1_acc1": float(out["q1_acc1"]), "q1_acc5": float(out["q1_acc5"]),
-                   "q2_acc1": float(out["q2_acc1"]), "q2_acc5": float(out["q2_acc5"])}
+        metrics = {"loss": float(loss.detach())}
+        if loss_pixel is not None:
+            metrics["loss_pixel"] = float(loss_pixel.detach())
+        if "contra_loss" in out:
+            metrics.update({"loss_contrast": float(out["contra_loss"].detach()),
+                            "q1_acc1": float(out["q1_acc1"]), "q1_acc5": float(out["q1_acc5"]),
+                            "q2_acc1": float(out["q2_acc1"]), "q2_acc5": float(out["q2_acc5"])})
         gn = torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values()))       # get_grad_norm_, utils.py:507-519
         metrics["grad_norm"] = float(gn)
         return metrics, grads, out, labels
@@ -629,6 +698,8 @@ class OracleTrainer:
         with torch.no_grad():
             for names, wd in ((self.decay, hp.weight_decay), (self.no_decay, 0.0)):
                 for n in names:
+                    if n in self.never_grad:
+                        continue
                     adamw_update(self.P[n], grads[n], self.exp_avg[n], self.exp_avg_sq[n], self.step_count,
                                  hp.lr, wd, hp.beta1, hp.beta2, hp.eps)
         return metrics, grads, out, labels
@@ -672,9 +743,12 @@ def det_state(cfg: DiGConfig, seed: int = 0, momentum_delta: float = 0.01):
         else:                                                             # biases, betas, q_bias, v_bias
             t = det_tensor(name, shp, seed, 0.02)
         P[name] = t
+    shapes = param_shapes(cfg)
     for src, dst in ema_pairs(list(P.keys())):
+        if dst not in shapes:
+            continue
         P[dst] = P[src] + det_tensor(dst, P[src].shape, seed, momentum_delta * float(P[src].std() if P[src].numel() > 1 else 1.0))
-    P = OrderedDict((k, P[k].contiguous()) for k in param_shapes(cfg))
+    P = OrderedDict((k, P[k].contiguous()) for k in shapes)
     S = OrderedDict()
     for name, shp in buffer_shapes(cfg).items():
         if name.endswith("running_var"):

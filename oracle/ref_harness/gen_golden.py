@@ -40,7 +40,7 @@ def build_ref_model(cfg: O.DiGConfig):
                       encoder_depth=cfg.depth, encoder_num_heads=cfg.heads, encoder_num_classes=0,
                       decoder_num_classes=cfg.dec_classes, decoder_embed_dim=cfg.dec_dim, decoder_depth=4,
                       decoder_num_heads=3, mlp_ratio=cfg.mlp_ratio, qkv_bias=True,
-                      norm_layer=partial(nn.LayerNorm, eps=1e-6), use_pixel_target=True, use_moco_target=True,
+                      norm_layer=partial(nn.LayerNorm, eps=1e-6), use_pixel_target=cfg.use_pixel, use_moco_target=cfg.use_moco,
                       mlp_dim=cfg.moco_mlp_dim, dim=cfg.moco_dim, T=cfg.T, num_windows=cfg.num_windows,
                       patchnet_name='no_patchtrans')
 
@@ -99,15 +99,18 @@ def run_reference_steps(cfg, seed, B, n_steps, hp, world=1, rank=0, sync_bn=Fals
     scaler = ScalerCPU(ref_utils)
     caps = {}
     model.encoder.register_forward_hook(lambda m, i, o: caps.__setitem__("enc", o.detach().clone()))
-    model.predictor.register_forward_hook(lambda m, i, o: caps.__setitem__("qs", o.detach().clone()))
-    model.momentum_projection_layer.register_forward_hook(lambda m, i, o: caps.__setitem__("ks", o.detach().clone()))
+    if cfg.use_moco:
+        model.predictor.register_forward_hook(lambda m, i, o: caps.__setitem__("qs", o.detach().clone()))
+        model.momentum_projection_layer.register_forward_hook(lambda m, i, o: caps.__setitem__("ks", o.detach().clone()))
     fwd = model.forward
 
     def wrapped(*a, **k):
         out = fwd(*a, **k)
-        caps["vis_out"] = out["vis_out"][0].detach().clone()
-        if len(out["vis_out"]) > 1:                     # only_mim_on_ori_img=False: the second view's masked predictions
-            caps["vis_out1"] = out["vis_out"][1].detach().clone()
+        assert ("vis_out" in out) == cfg.use_pixel and ("contra_loss" in out) == cfg.use_moco
+        if "vis_out" in out:
+            caps["vis_out"] = out["vis_out"][0].detach().clone()
+            if len(out["vis_out"]) > 1:                 # only_mim_on_ori_img=False: the second view's masked predictions
+                caps["vis_out1"] = out["vis_out"][1].detach().clone()
         return out
     model.forward = wrapped
     run_model = model
@@ -175,12 +178,17 @@ def run_oracle_steps(cfg, seed, B, n_steps, hp, comm=None, rank=0, teacher=None)
         hps = dataclasses.replace(hp, moco_m=O.adjust_moco_momentum(float(s), 10, hp.moco_m))
         taps = {}
         metrics, grads, out, labels = tr.step(im, au, mk, hps, taps)
-        steps.append(dict(stats=metrics, grads={k: v.clone() for k, v in grads.items()},
+        caps = dict(enc=taps["enc"].detach())
+        if cfg.use_moco:
+            caps.update(qs=torch.cat([taps["q1"], taps["q2"]]).detach(), ks=torch.cat([taps["k1"], taps["k2"]]).detach())
+        if cfg.use_pixel:
+            caps["vis_out"] = out["vis_out"][0].detach()
+            if len(out["vis_out"]) > 1:
+                caps["vis_out1"] = out["vis_out"][1].detach()
+        # (the reference leaves `.grad = None` on a parameter its forward never reads -- Dis-only's mask_token: not in its gradient list)
+        steps.append(dict(stats=metrics, grads={k: v.clone() for k, v in grads.items() if k not in tr.never_grad},
                           params={k: v.detach().clone() for k, v in tr.P.items()},
-                          bufs={k: v.clone() for k, v in tr.S.items()},
-                          caps=dict(enc=taps["enc"].detach(), qs=torch.cat([taps["q1"], taps["q2"]]).detach(),
-                                    ks=torch.cat([taps["k1"], taps["k2"]]).detach(), vis_out=out["vis_out"][0].detach(),
-                                    **({"vis_out1": out["vis_out"][1].detach()} if len(out["vis_out"]) > 1 else {}))))
+                          bufs={k: v.clone() for k, v in tr.S.items()}, caps=caps))
     return steps
 
 
@@ -208,7 +216,12 @@ def check_adamw_formula(ref_step0, cfg, seed, hp, m0):
 def compare(ref_steps, ora_steps, rtol=2e-4, atol=2e-5, tag="", lr=1e-3):
     worst = 0.0
     for s, (r, o) in enumerate(zip(ref_steps, ora_steps)):
+        logged = ("loss", "loss_pixel", "loss_contrast", "q1_acc1", "q1_acc5", "q2_acc1", "q2_acc5")
+        assert {k for k in logged if k in r["stats"]} == {k for k in logged if k in o["stats"]}, (r["stats"].keys(), o["stats"].keys())
+        assert set(r["grads"]) == set(o["grads"]), set(r["grads"]) ^ set(o["grads"])
         for k in ("loss", "loss_pixel", "loss_contrast", "q1_acc1", "q1_acc5", "q2_acc1", "q2_acc5", "grad_norm"):
+            if k not in r["stats"]:
+                continue
             a, b = float(r["stats"][k]), float(o["stats"][k])
             assert abs(a - b) <= 1e-4 * max(1.0, abs(a)), (tag, s, k, a, b)
         for grp in ("caps", "grads", "params", "bufs"):
@@ -228,12 +241,14 @@ def compare(ref_steps, ora_steps, rtol=2e-4, atol=2e-5, tag="", lr=1e-3):
 
 def pack(ref_steps, cfg, seed, B, hp, extra=None):
     d = {"seed": np.int64(seed), "B": np.int64(B), "n_steps": np.int64(len(ref_steps)),
-         "cfg_keys": np.array(list(vars(cfg).keys())), "cfg_vals": np.array([float(v) for v in vars(cfg).values()]),
+         "cfg_keys": np.array([k for k, v in vars(cfg).items() if not isinstance(v, str)]),
+         "cfg_vals": np.array([float(v) for v in vars(cfg).values() if not isinstance(v, str)]), "cfg_kind": np.array(cfg.kind),
          "hp_keys": np.array([k for k, v in vars(hp).items() if isinstance(v, (int, float)) and v is not None]),
          "hp_vals": np.array([float(v) for k, v in vars(hp).items() if isinstance(v, (int, float)) and v is not None])}
     for s, r in enumerate(ref_steps):
         for k in ("loss", "loss_pixel", "loss_contrast", "q1_acc1", "q1_acc5", "q2_acc1", "q2_acc5", "grad_norm", "moco_m"):
-            d[f"s{s}/stat/{k}"] = np.float64(r["stats"][k])
+            if k in r["stats"]:                     # (a single-objective model logs its own loss only)
+                d[f"s{s}/stat/{k}"] = np.float64(r["stats"][k])
         names = sorted(r["grads"].keys())
         d[f"s{s}/grad_names"] = np.array(names)
         d[f"s{s}/grad_norms"] = np.array([r["grads"][n].double().norm().item() for n in names])
@@ -248,7 +263,8 @@ def pack(ref_steps, cfg, seed, B, hp, extra=None):
         for k, v in r["caps"].items():
             d[f"s{s}/cap/{k}/norm"] = np.float64(v.double().norm().item())
             d[f"s{s}/cap/{k}/samples"] = v.reshape(-1)[sample_index(v.numel(), 64)].numpy()
-        d[f"s{s}/cap/vis_out/full"] = r["caps"]["vis_out"].numpy().astype(np.float32)
+        if "vis_out" in r["caps"]:
+            d[f"s{s}/cap/vis_out/full"] = r["caps"]["vis_out"].numpy().astype(np.float32)
         if "vis_out1" in r["caps"]:
             d[f"s{s}/cap/vis_out1/full"] = r["caps"]["vis_out1"].numpy().astype(np.float32)
         if hp.clip_grad is not None:                # --clip_grad (utils/utils.py:487-493): the clip coefficient lives in the Adam moments
@@ -384,5 +400,17 @@ if __name__ == "__main__":
             gen_single("tiny_w1_c0", tiny, 5, 4, 1, O.StepHyper(lr=1e-3, w_contrast=0.0))
         if a.only in ("", "clip"):                  # --clip_grad 1.0 (grad norm ~5: the clip is active), two steps: the second step's moments mix
             gen_single("tiny_w1_clip", tiny, 13, 4, 2, O.StepHyper(lr=1e-3, clip_grad=1.0))      # both steps' clip coefficients
+        if a.only in ("", "dis"):                   # Dis-only (pretrain_moco_ori_*: use_pixel_target=False): no mask, no pix_projector, no decoder
+            import dataclasses
+            gen_single("tiny_dis_w1", dataclasses.replace(tiny, kind="moco"), 21, 4, 2, hp)
+        if a.only in ("", "gen"):                   # Gen-only (pretrain_simmim_ori_*: use_moco_target=False): encoder + final norm + decoder
+            import dataclasses
+            gen_single("tiny_gen_w1", dataclasses.replace(tiny, kind="simmim"), 23, 4, 2, hp)
+        if a.only in ("", "gen2"):                  # ... with the MIM loss on both views
+            import dataclasses
+            gen_single("tiny_gen_w1_mim2", dataclasses.replace(tiny, kind="simmim"), 25, 4, 1, O.StepHyper(lr=1e-3, only_mim_on_ori_img=False))
+        if a.only in ("", "nw5"):                   # the argparse default --num_windows 5: uneven adaptive_avg_pool2d windows on 32 columns
+            import dataclasses
+            gen_single("tiny_w1_nw5", dataclasses.replace(tiny, num_windows=5), 27, 4, 1, hp)
         if a.only in ("", "mim2"):                  # only_mim_on_ori_img=False: both views masked, MIM loss on both (engine :100-111,138-141)
             gen_single("tiny_w1_mim2", tiny, 9, 4, 1, O.StepHyper(lr=1e-3, only_mim_on_ori_img=False))

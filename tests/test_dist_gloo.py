@@ -345,3 +345,52 @@ def test_bench_harness_two_ranks_on_one_gpu():
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["steps"] == 1 and line["value"] > 0 and line["scaling"] == "weak"
     assert line["roofline"]["achieved"] > 0 and line["config"]["global_batch"] == 16
+
+
+@pytest.mark.gpu
+def test_bench_plain_command_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (the shape of the driver's N = 1 command): bench.py re-executes itself under
+    torch.distributed.run on 127.0.0.1 and rank 0's single JSON line comes back on stdout.  DIG_SHARE_GPU=1 puts both ranks on device 0
+    over gloo (one GPU on the test box); without it every rank takes its own device over RCCL."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DIG_SHARE_GPU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "DIG_DIST_BACKEND"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "8", "--no-mim-only",
+           "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2" and line["config"]["global_batch"] == 16 and line["value"] > 0
+
+
+def test_bench_self_launch_command_line(monkeypatch):
+    """Host logic of the self-launch (no GPU): the command bench.py builds for `--gpus N` is the driver's own launch line."""
+    import importlib.util
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return subprocess.CompletedProcess(cmd, 0)
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    monkeypatch.delenv("RANK", raising=False)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setenv("DIG_SHARE_GPU", "1")
+    monkeypatch.delenv("DIG_DIST_BACKEND", raising=False)
+    bench.main()
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
+    assert seen["env"]["DIG_DIST_BACKEND"] == "gloo" and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

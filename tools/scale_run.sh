@@ -17,8 +17,8 @@ for N in 1 2 4 8; do
   if [ "$N" -eq 1 ]; then
     python $ROOT/bench.py --gpus 1 --steps $STEPS --warmup $WARMUP --no-cpu-baseline > $OUT/scale_$N.json 2> $OUT/scale_$N.err
   else
-    NCCL_DEBUG=INFO NCCL_DEBUG_SUBSYS=INIT python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port $((29500 + N)) \
-      $ROOT/bench.py --gpus $N --steps $STEPS --warmup $WARMUP --no-cpu-baseline > $OUT/scale_$N.json 2> $OUT/scale_$N.err
+    # the plain command: bench.py starts its own N ranks under torch.distributed.run (RCCL, one device per rank)
+    NCCL_DEBUG=INFO NCCL_DEBUG_SUBSYS=INIT python $ROOT/bench.py --gpus $N --steps $STEPS --warmup $WARMUP --no-cpu-baseline > $OUT/scale_$N.json 2> $OUT/scale_$N.err
     ranks=$(grep -c "Init COMPLETE\|init complete\|comm .* rank" $OUT/scale_$N.err || true)
     echo "N=$N: RCCL init lines in the log: $ranks"
   fi
