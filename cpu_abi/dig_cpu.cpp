@@ -689,18 +689,25 @@ int dig_colsum_masked(const void* x_, const unsigned char* mask, float* out_unma
   return DIG_OK;
 }
 
+// adaptive_avg_pool2d's bins: [floor(win gw / nwin), ceil((win + 1) gw / nwin)) (equal windows when nwin divides gw)
+static inline void pool_window(int win, int gw, int nwin, int& c_lo, int& wlen) {
+  c_lo = (win * gw) / nwin;
+  wlen = ((win + 1) * gw + nwin - 1) / nwin - c_lo;
+}
+
 int dig_window_pool_fwd(const void* x_, void* out, int out_is_f32, int n_img, int gh, int gw, int nwin, int D, hipStream_t) {
-  if (!x_ || !out || n_img <= 0 || nwin <= 0 || gw % nwin || (D & 1)) return DIG_ERR_ARG;
+  if (!x_ || !out || n_img <= 0 || nwin <= 0 || nwin > gw || (D & 1)) return DIG_ERR_ARG;
   const bf16_t* x = (const bf16_t*)x_;
-  const int wlen = gw / nwin;
-  const float inv = 1.0f / (gh * wlen);
 #pragma omp parallel for
   for (int idx = 0; idx < n_img * nwin; ++idx) {
     const int img = idx / nwin, win = idx % nwin;
+    int c_lo, wlen;
+    pool_window(win, gw, nwin, c_lo, wlen);
+    const float inv = 1.0f / (gh * wlen);
     for (int d = 0; d < D; ++d) {
       float a = 0.f;
       for (int r = 0; r < gh; ++r)
-        for (int c = 0; c < wlen; ++c) a += bf2f(x[((size_t)img * gh * gw + r * gw + win * wlen + c) * D + d]);
+        for (int c = 0; c < wlen; ++c) a += bf2f(x[((size_t)img * gh * gw + r * gw + c_lo + c) * D + d]);
       if (out_is_f32) ((float*)out)[(size_t)idx * D + d] = a * inv;
       else ((bf16_t*)out)[(size_t)idx * D + d] = f2bf(a * inv);
     }
@@ -709,16 +716,21 @@ int dig_window_pool_fwd(const void* x_, void* out, int out_is_f32, int n_img, in
 }
 
 int dig_window_pool_bwd(const void* dpool_, void* dx_, int n_img, int gh, int gw, int nwin, int D, int accumulate, hipStream_t) {
-  if (!dpool_ || !dx_ || n_img <= 0 || nwin <= 0 || gw % nwin || (D & 1)) return DIG_ERR_ARG;
+  if (!dpool_ || !dx_ || n_img <= 0 || nwin <= 0 || nwin > gw || (D & 1)) return DIG_ERR_ARG;
   const bf16_t* dpool = (const bf16_t*)dpool_;
   bf16_t* dx = (bf16_t*)dx_;
   const int ntok = gh * gw;
-  const float inv = 1.0f / (gh * (gw / nwin));
 #pragma omp parallel for
   for (int t = 0; t < n_img * ntok; ++t) {
-    const int img = t / ntok, n = t % ntok, win = (n % gw) / (gw / nwin);
+    const int img = t / ntok, n = t % ntok, col = n % gw, w0 = (col * nwin) / gw;
     for (int d = 0; d < D; ++d) {
-      float a = bf2f(dpool[((size_t)img * nwin + win) * D + d]) * inv;
+      float a = 0.f;
+      for (int win = std::max(0, w0 - 1); win <= std::min(nwin - 1, w0 + 1); ++win) {
+        int c_lo, wlen;
+        pool_window(win, gw, nwin, c_lo, wlen);
+        if (col < c_lo || col >= c_lo + wlen) continue;
+        a += bf2f(dpool[((size_t)img * nwin + win) * D + d]) * (1.0f / (gh * wlen));
+      }
       if (accumulate) a += bf2f(dx[(size_t)t * D + d]);
       dx[(size_t)t * D + d] = f2bf(a);
     }
@@ -913,7 +925,11 @@ static int adamw_core(float* p, const float* g, float* m, float* v, bf16_t* shad
   if (finite_gate && !std::isfinite(finite_gate[0])) return DIG_OK;
 #pragma omp parallel for
   for (long long i = 0; i < n; ++i) {
-    const int grp = group[i >> 8];
+    const int grp = group[i >> 8] & 0x7f;                                // (bit 7: a weight of dig_adamw_step_tr's table -- same update)
+    if (grp == 2) {                                                      // a parameter without a gradient: untouched
+      if (shadow) shadow[i] = f2bf(p[i]);
+      continue;
+    }
     const float lr = grp ? lr1 : lr0, wd = grp ? wd1 : wd0;
     const float gk = g[i] * grad_scale;
     float P = p[i] * (1.0f - lr * wd);
@@ -930,6 +946,26 @@ int dig_adamw_bias_corrections(float beta1, float beta2, int step, float* out2) 
   if (!out2 || step < 1) return DIG_ERR_ARG;
   out2[0] = (float)(1.0 / (1.0 - std::pow((double)beta1, (double)step)));
   out2[1] = (float)(1.0 / std::sqrt(1.0 - std::pow((double)beta2, (double)step)));
+  return DIG_OK;
+}
+
+struct AdamTrMat { long long off, dst_off; int rows, cols, tile0, pad; };
+
+int dig_adamw_step_tr(float* p, const float* g, float* m, float* v, void* bf16_shadow, long long n, const unsigned char* group_flags, float lr0,
+                      float wd0, float lr1, float wd1, float beta1, float beta2, float eps, int step, float grad_scale, const float* finite_gate,
+                      const void* mats, int n_mats, int n_tiles, void* tr_out, hipStream_t) {
+  if (!p || !g || !m || !v || !group_flags || n <= 0 || (n & 255) || step < 1 || !mats || n_mats < 1 || n_tiles < 1 || !tr_out) return DIG_ERR_ARG;
+  if (!aligned16(p) || !aligned16(g) || !aligned16(m) || !aligned16(v)) return DIG_ERR_ALIGN;
+  if (finite_gate && !std::isfinite(finite_gate[0])) return DIG_OK;
+  float bc[2];
+  dig_adamw_bias_corrections(beta1, beta2, step, bc);
+  const int rc = adamw_core(p, g, m, v, (bf16_t*)bf16_shadow, n, group_flags, lr0, wd0, lr1, wd1, beta1, beta2, eps, bc[0], bc[1], grad_scale, finite_gate);
+  if (rc != DIG_OK) return rc;
+  const AdamTrMat* mt = (const AdamTrMat*)mats;
+  bf16_t* out = (bf16_t*)tr_out;
+  for (int k = 0; k < n_mats; ++k)
+    for (int r = 0; r < mt[k].rows; ++r)
+      for (int c = 0; c < mt[k].cols; ++c) out[mt[k].dst_off + (long long)c * mt[k].rows + r] = f2bf(p[mt[k].off + (long long)r * mt[k].cols + c]);
   return DIG_OK;
 }
 

@@ -183,19 +183,28 @@ __global__ void patch_embed_bwd_kernel(const bf16_t* __restrict__ dy, const floa
   atomicAdd(dmask_token + d, am);
 }
 
-// x [n_img, gh*gw, D] bf16 -> out [n_img*nwin, D] (fp32 or bf16): mean over all gh rows and gw/nwin columns
+// Column range of pooling window `win`: adaptive_avg_pool2d's bins [floor(win gw / nwin), ceil((win + 1) gw / nwin)) -- equal windows when nwin
+// divides gw (README: --num_windows 4 on 32 columns), bins of 7 / 7 / 8 / 7 / 7 columns that overlap by one for the argparse default of 5
+// (run_mae_pretraining_moco.py:143; PatchNet.forward, modeling_pretrain_moco_mim_ori.py:189-193)
+__device__ __forceinline__ void pool_window(int win, int gw, int nwin, int& c_lo, int& wlen) {
+  c_lo = (win * gw) / nwin;
+  wlen = ((win + 1) * gw + nwin - 1) / nwin - c_lo;
+}
+
+// x [n_img, gh*gw, D] bf16 -> out [n_img*nwin, D] (fp32 or bf16): mean over all gh rows and the window's columns
 template <typename OutT>
 __global__ void window_pool_fwd_kernel(const bf16_t* __restrict__ x, OutT* __restrict__ out, int n_img, int gh, int gw,
                                        int nwin, int D) {
   const int idx = blockIdx.x;                 // img * nwin + win
   const int img = idx / nwin, win = idx - img * nwin;
-  const int wlen = gw / nwin;
+  int c_lo, wlen;
+  pool_window(win, gw, nwin, c_lo, wlen);
   const float inv = 1.0f / (gh * wlen);
   for (int d2 = threadIdx.x; d2 < D / 2; d2 += blockDim.x) {
     float a0 = 0.f, a1 = 0.f;
     for (int r = 0; r < gh; ++r)
       for (int c = 0; c < wlen; ++c) {
-        const int n = r * gw + win * wlen + c;
+        const int n = r * gw + c_lo + c;
         const unsigned u = *reinterpret_cast<const unsigned*>(x + ((size_t)img * gh * gw + n) * D + d2 * 2);
         a0 += bf2f((bf16_t)(u & 0xffff));
         a1 += bf2f((bf16_t)(u >> 16));
@@ -228,7 +237,9 @@ __global__ __launch_bounds__(256) void window_pool_fwd16_kernel(const bf16_t* __
   __shared__ float red[256][9];
   const int idx = blockIdx.x;
   const int img = idx / nwin, win = idx - img * nwin;
-  const int wlen = gw / nwin, ntw = gh * wlen;
+  int c_lo, wlen;
+  pool_window(win, gw, nwin, c_lo, wlen);
+  const int ntw = gh * wlen;
   const int c8 = D >> 3, G = 256 / c8;
   const int tid = threadIdx.x, g = tid / c8, ch = tid - g * c8;
   float a[8];
@@ -237,7 +248,7 @@ __global__ __launch_bounds__(256) void window_pool_fwd16_kernel(const bf16_t* __
   if (g < G) {
     for (int t = g; t < ntw; t += G) {
       const int r = t / wlen, c = t - r * wlen;
-      const int n = r * gw + win * wlen + c;
+      const int n = r * gw + c_lo + c;
       float v[8];
       ld8_bf16(x + ((size_t)img * gh * gw + n) * D + ch * 8, v);
 #pragma unroll
@@ -265,21 +276,31 @@ __global__ __launch_bounds__(256) void window_pool_fwd16_kernel(const bf16_t* __
   }
 }
 
-// dx[img, n, :] (+)= dpool[img*nwin + win(n), :] / (gh*wlen) with 16-byte accesses: one item = 8 channels of one token
+// dx[img, n, :] (+)= sum over the windows that hold n's column of dpool[img*nwin + win, :] / (gh*wlen(win)) with 16-byte accesses: one item =
+// 8 channels of one token.  (One window per column when nwin divides gw; neighbouring uneven windows share a column: both contribute, in
+// window order.)
 __global__ __launch_bounds__(256) void window_pool_bwd16_kernel(const bf16_t* __restrict__ dpool, bf16_t* __restrict__ dx, int n_img, int gh, int gw,
                                                                 int nwin, int D, int accumulate) {
-  const int c8 = D >> 3, ntok = gh * gw, wlen = gw / nwin;
+  const int c8 = D >> 3, ntok = gh * gw;
   const size_t total = (size_t)n_img * ntok * c8;
-  const float inv = 1.0f / (gh * wlen);
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
     const int ch = (int)(e % c8);
     const size_t t = e / c8;
     const int img = (int)(t / ntok), n = (int)(t - (size_t)img * ntok);
-    const int win = (n % gw) / wlen;
+    const int col = n % gw, w0 = (col * nwin) / gw;
     float v[8];
-    ld8_bf16(dpool + ((size_t)img * nwin + win) * D + ch * 8, v);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] *= inv;
+    for (int k = 0; k < 8; ++k) v[k] = 0.f;
+    for (int win = max(0, w0 - 1); win <= min(nwin - 1, w0 + 1); ++win) {
+      int c_lo, wlen;
+      pool_window(win, gw, nwin, c_lo, wlen);
+      if (col < c_lo || col >= c_lo + wlen) continue;
+      const float inv = 1.0f / (gh * wlen);
+      float u[8];
+      ld8_bf16(dpool + ((size_t)img * nwin + win) * D + ch * 8, u);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] += u[k] * inv;
+    }
     bf16_t* o = dx + t * D + ch * 8;
     if (accumulate) {
       float w[8];
@@ -297,11 +318,18 @@ __global__ void window_pool_bwd_kernel(const bf16_t* __restrict__ dpool, bf16_t*
   const int t = blockIdx.x;                    // token index over n_img*gh*gw
   const int ntok = gh * gw;
   const int img = t / ntok, n = t - img * ntok;
-  const int win = (n % gw) / (gw / nwin);
-  const float inv = 1.0f / (gh * (gw / nwin));
+  const int col = n % gw, w0 = (col * nwin) / gw;
   for (int d2 = threadIdx.x; d2 < D / 2; d2 += blockDim.x) {
-    const unsigned u = *reinterpret_cast<const unsigned*>(dpool + ((size_t)img * nwin + win) * D + d2 * 2);
-    float a0 = bf2f((bf16_t)(u & 0xffff)) * inv, a1 = bf2f((bf16_t)(u >> 16)) * inv;
+    float a0 = 0.f, a1 = 0.f;
+    for (int win = max(0, w0 - 1); win <= min(nwin - 1, w0 + 1); ++win) {
+      int c_lo, wlen;
+      pool_window(win, gw, nwin, c_lo, wlen);
+      if (col < c_lo || col >= c_lo + wlen) continue;
+      const float inv = 1.0f / (gh * wlen);
+      const unsigned u = *reinterpret_cast<const unsigned*>(dpool + ((size_t)img * nwin + win) * D + d2 * 2);
+      a0 += bf2f((bf16_t)(u & 0xffff)) * inv;
+      a1 += bf2f((bf16_t)(u >> 16)) * inv;
+    }
     unsigned* o = reinterpret_cast<unsigned*>(dx + (size_t)t * D + d2 * 2);
     if (accumulate) {
       const unsigned v = *o;
@@ -657,7 +685,7 @@ extern "C" int dig_patch_embed_bwd(const void* dy, const float* img, const unsig
 
 extern "C" int dig_window_pool_fwd(const void* x, void* out, int out_is_f32, int n_img, int gh, int gw, int nwin, int D,
                                    hipStream_t stream) {
-  if (!x || !out || n_img <= 0 || nwin <= 0 || gw % nwin || (D & 1)) return DIG_ERR_ARG;
+  if (!x || !out || n_img <= 0 || nwin <= 0 || nwin > gw || (D & 1)) return DIG_ERR_ARG;
   if ((D & 7) == 0 && D / 8 <= 256 && aligned16(x) && aligned16(out)) {
     if (out_is_f32)
       hipLaunchKernelGGL(window_pool_fwd16_kernel<float>, dim3(n_img * nwin), dim3(256), 0, stream, (const bf16_t*)x, (float*)out, n_img, gh, gw, nwin, D);
@@ -676,7 +704,7 @@ extern "C" int dig_window_pool_fwd(const void* x, void* out, int out_is_f32, int
 
 extern "C" int dig_window_pool_bwd(const void* dpool, void* dx, int n_img, int gh, int gw, int nwin, int D, int accumulate,
                                    hipStream_t stream) {
-  if (!dpool || !dx || n_img <= 0 || nwin <= 0 || gw % nwin || (D & 1)) return DIG_ERR_ARG;
+  if (!dpool || !dx || n_img <= 0 || nwin <= 0 || nwin > gw || (D & 1)) return DIG_ERR_ARG;
   if ((D & 7) == 0 && aligned16(dpool) && aligned16(dx)) {
     const size_t total = (size_t)n_img * gh * gw * (D / 8);
     hipLaunchKernelGGL(window_pool_bwd16_kernel, dim3((unsigned)std::min<size_t>(2048, (total + 255) / 256)), dim3(256), 0, stream,

@@ -12,39 +12,96 @@
 
 namespace {
 
-// group[i >> 8] selects the param group (0 = decay, 1 = no_decay) of element i; parameters are padded to 256 elements.
+// One element's AdamW update (custom_optim/_functional.py:115-140), shared by the flat and the tiled loop: identical arithmetic, in this order.
+__device__ __forceinline__ void adamw_elem(float& P, float G, float& M, float& V, float decay, float step_size, float beta1, float beta2, float eps,
+                                           float inv_sqrt_bc2, float grad_scale) {
+  const float gk = G * grad_scale;
+  P *= decay;
+  M = M * beta1 + gk * (1.0f - beta1);
+  V = V * beta2 + gk * gk * (1.0f - beta2);
+  const float denom = sqrtf(V) * inv_sqrt_bc2 + eps;
+  P -= step_size * (M / denom);
+}
+
+// A 2-D weight whose updated values also leave the launch TRANSPOSED in bf16 (W^T [cols, rows]: the K-contiguous operand of the fused MLP
+// backward): element offset in the arena, element offset of W^T in `tr_out`, shape (multiples of 64), index of its first 64 x 64 tile.
+struct AdamTrMat { long long off, dst_off; int rows, cols, tile0, pad; };
+static_assert(sizeof(AdamTrMat) == 32, "dig_adamw_step_tr's table records are 32 bytes");
+
+// group[i >> 8] (parameters are padded to 256 elements) selects the param group of element i: 0 = decay, 1 = no_decay, 2 = a parameter that
+// never receives a gradient and is left untouched, as the reference's AdamW skips `p.grad is None` (custom_optim/adamw.py:78-79);
+// bit 7 = the granule belongs to a weight of the `mats` table: the flat loop leaves it to the tile workgroups (blocks >= flat_blocks).
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, bf16_t* __restrict__ shadow, long long n4,
                                                     const unsigned char* __restrict__ group, float lr0, float wd0, float lr1,
                                                     float wd1, float beta1, float beta2, float eps, float inv_bc1,
                                                     float inv_sqrt_bc2, float grad_scale, const float* __restrict__ finite_gate,
-                                                    const float* __restrict__ dev_scalars) {
+                                                    const float* __restrict__ dev_scalars, const AdamTrMat* __restrict__ mats, int n_mats,
+                                                    bf16_t* __restrict__ tr_out, int flat_blocks) {
   if (finite_gate && !isfinite(finite_gate[0])) return;                 // non-finite gradients: the whole update is a no-op (GradScaler's inf-skip)
   if (dev_scalars) {                                                    // per-step scalars from memory: a captured graph replays with new values
     lr0 = dev_scalars[0]; wd0 = dev_scalars[1]; lr1 = dev_scalars[2]; wd1 = dev_scalars[3];
     inv_bc1 = dev_scalars[4]; inv_sqrt_bc2 = dev_scalars[5];
   }
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
-    const int grp = group[i >> 6];
+  if (mats && (int)blockIdx.x >= flat_blocks) {
+    // ---- one 64 x 64 tile of a listed weight: the same update, + the bf16 shadow, + the tile transposed through LDS into W^T
+    __shared__ bf16_t tile[64][68];
+    const int t = (int)blockIdx.x - flat_blocks;
+    int k = 0;
+    while (k + 1 < n_mats && mats[k + 1].tile0 <= t) ++k;
+    const AdamTrMat mt = mats[k];
+    const int tcn = mt.cols >> 6, local = t - mt.tile0;
+    const int r0 = (local / tcn) << 6, c0 = (local % tcn) << 6;
+    const int grp = group[mt.off >> 8] & 1;
     const float lr = grp ? lr1 : lr0, wd = grp ? wd1 : wd0;
-    float4 pp = reinterpret_cast<float4*>(p)[i];
-    float4 gg = reinterpret_cast<const float4*>(g)[i];
-    float4 mm = reinterpret_cast<float4*>(m)[i];
-    float4 vv = reinterpret_cast<float4*>(v)[i];
-    float P[4] = {pp.x, pp.y, pp.z, pp.w}, G[4] = {gg.x, gg.y, gg.z, gg.w}, M[4] = {mm.x, mm.y, mm.z, mm.w}, V[4] = {vv.x, vv.y, vv.z, vv.w};
     const float decay = 1.0f - lr * wd, step_size = lr * inv_bc1;
+    const int c4 = threadIdx.x & 15;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float gk = G[k] * grad_scale;
-      P[k] *= decay;
-      M[k] = M[k] * beta1 + gk * (1.0f - beta1);
-      V[k] = V[k] * beta2 + gk * gk * (1.0f - beta2);
-      const float denom = sqrtf(V[k]) * inv_sqrt_bc2 + eps;
-      P[k] -= step_size * (M[k] / denom);
+    for (int q = 0; q < 4; ++q) {
+      const int r = (threadIdx.x >> 4) + 16 * q;
+      const long long i = (mt.off + (long long)(r0 + r) * mt.cols + c0 + c4 * 4) >> 2;
+      float4 pp = reinterpret_cast<float4*>(p)[i];
+      float4 gg = reinterpret_cast<const float4*>(g)[i];
+      float4 mm = reinterpret_cast<float4*>(m)[i];
+      float4 vv = reinterpret_cast<float4*>(v)[i];
+      float P[4] = {pp.x, pp.y, pp.z, pp.w}, G[4] = {gg.x, gg.y, gg.z, gg.w}, M[4] = {mm.x, mm.y, mm.z, mm.w}, V[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) adamw_elem(P[e], G[e], M[e], V[e], decay, step_size, beta1, beta2, eps, inv_sqrt_bc2, grad_scale);
+      reinterpret_cast<float4*>(p)[i] = make_float4(P[0], P[1], P[2], P[3]);
+      reinterpret_cast<float4*>(m)[i] = make_float4(M[0], M[1], M[2], M[3]);
+      reinterpret_cast<float4*>(v)[i] = make_float4(V[0], V[1], V[2], V[3]);
+      const uint2 sh = make_uint2(pack_bf2(P[0], P[1]), pack_bf2(P[2], P[3]));
+      if (shadow) reinterpret_cast<uint2*>(shadow)[i] = sh;
+      *reinterpret_cast<uint2*>(&tile[r][c4 * 4]) = sh;
     }
-    reinterpret_cast<float4*>(p)[i] = make_float4(P[0], P[1], P[2], P[3]);
-    reinterpret_cast<float4*>(m)[i] = make_float4(M[0], M[1], M[2], M[3]);
-    reinterpret_cast<float4*>(v)[i] = make_float4(V[0], V[1], V[2], V[3]);
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = (threadIdx.x >> 4) + 16 * q, r4 = (threadIdx.x & 15) * 4;
+      const unsigned lo = (unsigned)tile[r4][c] | ((unsigned)tile[r4 + 1][c] << 16), hi = (unsigned)tile[r4 + 2][c] | ((unsigned)tile[r4 + 3][c] << 16);
+      *reinterpret_cast<uint2*>(tr_out + mt.dst_off + (long long)(c0 + c) * mt.rows + r0 + r4) = make_uint2(lo, hi);
+    }
+    return;
+  }
+  const long long stride = (long long)(flat_blocks > 0 ? flat_blocks : (int)gridDim.x) * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const int gflag = group[i >> 6];
+    if (gflag & 0x80) continue;                                         // a tiled weight's granule
+    float4 pp = reinterpret_cast<float4*>(p)[i];
+    float P[4] = {pp.x, pp.y, pp.z, pp.w};
+    if (gflag != 2) {
+      const float lr = gflag ? lr1 : lr0, wd = gflag ? wd1 : wd0;
+      float4 gg = reinterpret_cast<const float4*>(g)[i];
+      float4 mm = reinterpret_cast<float4*>(m)[i];
+      float4 vv = reinterpret_cast<float4*>(v)[i];
+      float G[4] = {gg.x, gg.y, gg.z, gg.w}, M[4] = {mm.x, mm.y, mm.z, mm.w}, V[4] = {vv.x, vv.y, vv.z, vv.w};
+      const float decay = 1.0f - lr * wd, step_size = lr * inv_bc1;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) adamw_elem(P[k], G[k], M[k], V[k], decay, step_size, beta1, beta2, eps, inv_sqrt_bc2, grad_scale);
+      reinterpret_cast<float4*>(p)[i] = make_float4(P[0], P[1], P[2], P[3]);
+      reinterpret_cast<float4*>(m)[i] = make_float4(M[0], M[1], M[2], M[3]);
+      reinterpret_cast<float4*>(v)[i] = make_float4(V[0], V[1], V[2], V[3]);
+    }
     if (shadow) reinterpret_cast<uint2*>(shadow)[i] = make_uint2(pack_bf2(P[0], P[1]), pack_bf2(P[2], P[3]));
   }
 }
@@ -180,7 +237,25 @@ extern "C" int dig_adamw_step(float* p, const float* g, float* m, float* v, void
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
   hipLaunchKernelGGL(adamw_kernel, dim3(flat_grid(n / 4)), dim3(256), 0, stream, p, g, m, v, (bf16_t*)bf16_shadow, n / 4,
                      group_flags, lr0, wd0, lr1, wd1, beta1, beta2, eps, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)), grad_scale, finite_gate,
-                     (const float*)nullptr);
+                     (const float*)nullptr, (const AdamTrMat*)nullptr, 0, (bf16_t*)nullptr, 0);
+  return dig_check_launch();
+}
+
+// dig_adamw_step + the transposed bf16 copies of the weights listed in `mats` (device table of n_mats 32-byte records {int64 off, int64 dst_off, int32 rows, cols,
+// tile0, 0} -- see include/dig_hip.h), whose granules carry bit 7 in group_flags; n_tiles = the table's total number of 64 x 64 tiles.
+extern "C" int dig_adamw_step_tr(float* p, const float* g, float* m, float* v, void* bf16_shadow, long long n,
+                                 const unsigned char* group_flags, float lr0, float wd0, float lr1, float wd1, float beta1,
+                                 float beta2, float eps, int step, float grad_scale, const float* finite_gate, const void* mats, int n_mats,
+                                 int n_tiles, void* tr_out, hipStream_t stream) {
+  if (!p || !g || !m || !v || !group_flags || n <= 0 || (n & 255) || step < 1 || !mats || n_mats < 1 || n_tiles < 1 || !tr_out) return DIG_ERR_ARG;
+  if (!aligned16(p) || !aligned16(g) || !aligned16(m) || !aligned16(v) || (bf16_shadow && (((uintptr_t)bf16_shadow) & 7)) || (((uintptr_t)tr_out) & 7))
+    return DIG_ERR_ALIGN;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  const int fb = flat_grid(n / 4);
+  hipLaunchKernelGGL(adamw_kernel, dim3(fb + n_tiles), dim3(256), 0, stream, p, g, m, v, (bf16_t*)bf16_shadow, n / 4,
+                     group_flags, lr0, wd0, lr1, wd1, beta1, beta2, eps, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)), grad_scale, finite_gate,
+                     (const float*)nullptr, (const AdamTrMat*)mats, n_mats, (bf16_t*)tr_out, fb);
   return dig_check_launch();
 }
 
@@ -197,7 +272,8 @@ extern "C" int dig_adamw_step_dev(float* p, const float* g, float* m, float* v, 
   if (!p || !g || !m || !v || !group_flags || !scalars6 || n <= 0 || (n & 255)) return DIG_ERR_ARG;
   if (!aligned16(p) || !aligned16(g) || !aligned16(m) || !aligned16(v) || (bf16_shadow && (((uintptr_t)bf16_shadow) & 7))) return DIG_ERR_ALIGN;
   hipLaunchKernelGGL(adamw_kernel, dim3(flat_grid(n / 4)), dim3(256), 0, stream, p, g, m, v, (bf16_t*)bf16_shadow, n / 4,
-                     group_flags, 0.f, 0.f, 0.f, 0.f, beta1, beta2, eps, 1.f, 1.f, grad_scale, finite_gate, scalars6);
+                     group_flags, 0.f, 0.f, 0.f, 0.f, beta1, beta2, eps, 1.f, 1.f, grad_scale, finite_gate, scalars6, (const AdamTrMat*)nullptr, 0,
+                     (bf16_t*)nullptr, 0);
   return dig_check_launch();
 }
 

@@ -104,10 +104,14 @@ class _EncWeights:
 
 def _weights(model):
     cache = getattr(model, "_wcache", None)
-    if cache is None or cache[0] != model._views_version or model._shadow.get("online") is None or model._shadow.get("momentum") is None:
-        model.shadow("online"), model.shadow("momentum")
+    mom = getattr(model, "use_moco_target", True)
+    if cache is None or cache[0] != model._views_version or model._shadow.get("online") is None or (mom and model._shadow.get("momentum") is None):
+        model.shadow("online")
+        if mom:
+            model.shadow("momentum")
         model._w16 = None
-        cache = (model._views_version, _EncWeights(model, "encoder.", "online"), _EncWeights(model, "momentum_encoder.", "momentum"))
+        cache = (model._views_version, _EncWeights(model, "encoder.", "online"),
+                 _EncWeights(model, "momentum_encoder.", "momentum") if mom else None)
         model._wcache = cache
     return cache[1], cache[2]
 
@@ -164,12 +168,14 @@ class _Step:
         self.comm = model.comm or LOCAL
 
     # ------------------------------------------------------------------ encoder
-    def encoder_forward(self, ew, images, aug, mask_u8, save):
+    def encoder_forward(self, ew, images, aug, mask_u8, save, views=2):
+        """views = 1: the encoder over `images` only (Gen-only models with only_mim_on_ori_img: the samples of a ViT batch are independent, and
+        nothing downstream reads the augmented view's rows)."""
         M = self.m
         B, D, H, N = images.shape[0], M.D, M.H, M.N
-        R = 2 * B * N
+        R = views * B * N
         x = torch.empty((R, D), device=images.device, dtype=BF16)
-        for half, im in enumerate((images, aug)):
+        for half, im in enumerate((images, aug)[:views]):
             ops.L.call("dig_patch_embed_fwd", ops.L.ptr(im), ops.L.ptr(ew.pe_w), ops.L.ptr(ew.pe_b),
                        ops.L.ptr(mask_u8[half * B:(half + 1) * B]), ops.L.ptr(ew.mask_token), ops.L.ptr(M._pos),
                        ops.L.ptr(x[half * B * N:(half + 1) * B * N]), B, M.gh, M.gw, D, ops.L.stream())
@@ -179,18 +185,18 @@ class _Step:
         chain_ln = chain and ops.MLP_CHAIN_LN and M.F <= 2048
         nxt = None                                                      # (ln1, mean, rstd) of this block, made by the previous block's launch
         if chain_ln and ops.BLOCK_CALLS and D == H * 64:
-            return self._encoder_forward_calls(ew, x, 2 * B, save)
+            return self._encoder_forward_calls(ew, x, views * B, save, single_view=views == 1)
         for i, blk in enumerate(ew.blocks):
             ln1, mu1, rs1 = nxt if nxt is not None else ops.layernorm_fwd(x, blk["norm1.weight"], blk["norm1.bias"], M.ln_eps)
             nxt = None
-            fused_attn = ops.attn_block_supported(H, D)
+            fused_attn = ops.attn_block_supported(H, D, B if views == 1 else None)
             if fused_attn:
                 # qkv Linear -> attention -> proj Linear + residual in one launch (csrc/attn_block.hip); qkv / lse exist only where kept
                 x_mid, ctx, qkv, lse = ops.attn_block_fwd(ln1, x, blk["attn.qkv.weight"], blk["qkv_bias"], blk["attn.proj.weight"],
-                                                          blk["attn.proj.bias"], 2 * B, H, D, scale, save=save)
+                                                          blk["attn.proj.bias"], views * B, H, D, scale, save=save)
             else:
                 qkv = ops.linear_fwd(ln1, blk["attn.qkv.weight"], bias=blk["qkv_bias"], alpha=scale, alpha_cols=D)
-                ctx, lse = ops.attn_fwd(qkv, 2 * B, H, D)
+                ctx, lse = ops.attn_fwd(qkv, views * B, H, D)
             if chain_ln:
                 # norm2 -> fc1 -> GELU -> fc2 (+ residual) -> the NEXT block's norm1 in one launch: between two blocks the residual stream
                 # is written once and no LayerNorm launch remains (the first block's norm1 is the only stand-alone one); norm2 is taken on
@@ -229,7 +235,7 @@ class _Step:
             x = x_out
         return x, saved
 
-    def _encoder_forward_calls(self, ew, x, n_img, save):
+    def _encoder_forward_calls(self, ew, x, n_img, save, single_view=False):
         """The block loop of encoder_forward with ONE FFI crossing per block (dig_encoder_block_fwd: qkv GEMM -> attention -> proj GEMM +
         residual -> norm2 + MLP + residual + the next block's norm1) and two allocations per block (a bf16 buffer, an fp32 one) instead of
         four crossings and thirteen allocations.  Same kernels, same arguments, same order: bit-identical to the loop above."""
@@ -244,7 +250,7 @@ class _Step:
         saved = []
         nb_blocks = len(ew.blocks)
         key = ("fwd_call", bool(save), R, n_img)
-        fuse_attn = int(ops.attn_block_supported(H, D))
+        fuse_attn = int(ops.attn_block_supported(H, D, n_img if single_view else None))
         prev = None
         for i, blk in enumerate(ew.blocks):
             st = blk.get(key)
@@ -402,12 +408,18 @@ class _Step:
             cache[key] = extra_bytes <= (free + pooled) // 4
         return cache[key]
 
-    def mlp_weight_transposes(self, ew):
-        """K-contiguous copies of the MLP weights for the fused backward (W2^T [F, D], W1^T [D, F]; 1.2 MB each, 24 small launches):
-        they depend on nothing but this step's bf16 weight shadow, so forward() queues them on the side stream behind the momentum branch."""
-        w2t = ops.transpose_bf16_multi([b["mlp.fc2.weight"] for b in ew.blocks])      # one launch per weight shape
-        w1t = ops.transpose_bf16_multi([b["mlp.fc1.weight"] for b in ew.blocks])
-        projt = ops.transpose_bf16_multi([b["attn.proj.weight"] for b in ew.blocks])   # (the projection's data gradient inside the fused MLP backward)
+    def mlp_weight_transposes(self, ew, fresh=False):
+        """K-contiguous copies of the MLP weights for the fused backward (W2^T [F, D], W1^T [D, F]; 1.2 MB each) and of the projection weight.
+        Normally the previous step's optimizer launch has written them (dig_adamw_step_tr, MoCo_ViT.transposed_weight_table): `fresh` ->
+        no launch at all.  Otherwise (first step, after load_state_dict / .to(), under graph capture, DIG_ADAMW_FOLD=0) three launches
+        rebuild them from this step's bf16 weight shadow, into the same persistent buffers where the model has them."""
+        tr = self.m.transposed_weight_table() if hasattr(self.m, "transposed_weight_table") else None
+        if tr is not None and fresh:
+            return tr[4]
+        outs = tr[4] if tr is not None else None
+        w2t = ops.transpose_bf16_multi([b["mlp.fc2.weight"] for b in ew.blocks], [o[0] for o in outs] if outs else None)   # one launch per weight shape
+        w1t = ops.transpose_bf16_multi([b["mlp.fc1.weight"] for b in ew.blocks], [o[1] for o in outs] if outs else None)
+        projt = ops.transpose_bf16_multi([b["attn.proj.weight"] for b in ew.blocks], [o[2] for o in outs] if outs else None)
         return list(zip(w2t, w1t, projt))
 
     # ------------------------------------------------------------------ two-stream helpers (backward)
@@ -750,10 +762,23 @@ class _Step:
             mask_u8 = mask_b2n if mask_b2n.is_contiguous() else mask_b2n.contiguous()      # prepared by the engine: view-major rows already
         else:
             mask_u8 = mask_b2n.permute(1, 0, 2).reshape(2 * B, N).to(torch.uint8).contiguous()    # rows 0..B-1 = view 0 (:497)
+        if not M.use_pixel_target:
+            # Dis-only: `if not self.use_pixel_target: vis_mask_pos = None` (modeling_pretrain_moco_mim_ori.py:493-494) -- no token is replaced
+            zm = getattr(M, "_zero_mask", None)
+            if zm is None or zm.shape != (2 * B, N) or zm.device != dev:
+                zm = M._zero_mask = torch.zeros((2 * B, N), device=dev, dtype=torch.uint8)
+            mask_u8 = zm
         self.images, self.aug, self.mask_u8 = images, aug, mask_u8
         ew_on, ew_mo = _weights(M)
+        pp = M.has_pix_projector
         _mark("forward: start", dev)
-        ops.cast_f32_to_bf16(M._flat["online"], M.shadow("online"))
+        # the bf16 operand shadow of the online arena (and the transposed weight copies below): left by the previous step's optimizer launch
+        # unless something else has written the parameters since (MoCo_ViT.weights_fresh)
+        fresh = M.weights_fresh() and not torch.cuda.is_current_stream_capturing()
+        if not fresh:
+            ops.cast_f32_to_bf16(M._flat["online"], M.shadow("online"))
+        if not M.use_moco_target:
+            return self._forward_gen_only(ew_on, images, aug, mask_u8, mim_views, training, fresh)
         # ---- momentum branch (no grad) on a second HIP stream: it depends only on the pre-step online weights (fp32
         # arena, read-only here) and the inputs, so it overlaps the online forward.  EMA with the current online weights
         # comes first (:526).
@@ -763,7 +788,8 @@ class _Step:
         mode = FWD_MODE if (not dist_mode and side is not main) else "side"
 
         def online_heads(enc):
-            masked2, self.saved_pix = self.mlp_forward(enc[:B * N], "pix_projector", "online", True)
+            # (`if hasattr(self, 'pix_projector')`, :500-510: the Dis-only models pool the encoder's own rows of both views)
+            masked2, self.saved_pix = self.mlp_forward(enc[:B * N], "pix_projector", "online", True) if pp else (enc[:B * N], None)
             pooled = torch.empty((2 * B * nw, D), device=dev, dtype=BF16)
             ops.window_pool_fwd(masked2, pooled[:B * nw], B, M.gh, M.gw, nw, D)
             ops.window_pool_fwd(enc[B * N:], pooled[B * nw:], B, M.gh, M.gw, nw, D)
@@ -772,7 +798,7 @@ class _Step:
             return q
 
         def momentum_heads(enc_m):
-            masked_m, _ = self.mlp_forward(enc_m[:B * N], "pix_projector_m", "momentum", False)
+            masked_m = self.mlp_forward(enc_m[:B * N], "pix_projector_m", "momentum", False)[0] if pp else enc_m[:B * N]
             pooled_m = torch.empty((2 * B * nw, D), device=dev, dtype=BF16)
             ops.window_pool_fwd(masked_m, pooled_m[:B * nw], B, M.gh, M.gw, nw, D)
             ops.window_pool_fwd(enc_m[B * N:], pooled_m[B * nw:], B, M.gh, M.gw, nw, D)
@@ -785,33 +811,13 @@ class _Step:
             if training and ops.mlp_chain_supported(D, M.F, 2 * B * N) and (ops.MLP_CHAIN_MASK & 4):
                 # K-contiguous copies of the online MLP weights for the fused backward: two launches, in front of the momentum encoder
                 # (they read nothing but this step's bf16 weight shadow)
-                self.wT = self.mlp_weight_transposes(ew_on)
+                self.wT = self.mlp_weight_transposes(ew_on, fresh)
             enc_m, _ = self.encoder_forward(ew_mo, images, aug, mask_u8, False)
             return enc_m, (momentum_heads(enc_m) if heads else None)
 
         def decoder():
             # SimMIM decoder on the masked tokens (:560-570; the reference decodes all rows then selects): view 0 only, or both views
-            per = M._mask_count(mask_u8, B)
-            Mrows = mim_views * B * per
-            Mp = (Mrows + 63) // 64 * 64
-            idx, cnt = ops.mask_to_index(mask_u8[:mim_views * B], per)       # token rows b*N + n of enc, views stacked as the encoder stacks them
-            M._last_mask_counts, M._last_idx, M._last_images = cnt, idx[:B], images
-            # view 1's MIM target is cut from the ORIGINAL images with view 1's mask (engine_for_pretraining_moco.py:106-108 indexes
-            # `images_patch`, built from `images`, for every view), so its target indices are relative to `images`
-            # (mask_to_index zero-fills the slots of a sample with fewer masked tokens than `per`; relative to `images` those would be -B*N:
-            #  clamp, so that the target gather of a ragged mask -- reported one step late -- stays inside the image buffer)
-            M._last_idx_views = [idx[:B]] + ([(idx[B:] - B * N).clamp_min_(0)] if mim_views == 2 else [])
-            self.idx, self.Mrows, self.Mp, self.per, self.mim_views = idx, Mrows, Mp, per, mim_views
-            w16, f32 = M._w("online"), M._f32
-            gath = ops.gather_rows(self.enc, idx, Mrows, Mp)
-            h0 = ops.linear_fwd(gath, w16["pix_decoder.0.weight"])
-            h1 = ops.linear_fwd(h0, w16["pix_decoder.1.weight"])
-            h2, mu, rs = ops.layernorm_fwd(h1, f32["pix_decoder.2.weight"], f32["pix_decoder.2.bias"], M.ln_eps, gelu=True)
-            pred = torch.empty((Mp, 64), device=dev, dtype=F32)
-            C = M.dec_classes
-            ops.gemm(h2, w16["pix_decoder.4.weight"], Mp, C, M.dec_dim, out=pred, out_kind=ops.OUT_F32, bias=f32["pix_decoder.4.bias"], ldc=64)
-            self.saved_dec = (gath, h0, h1, h2, mu, rs)
-            return pred[:Mrows, :C].reshape(mim_views * B, per, C), (pred, idx, cnt) + tuple(M._last_idx_views)
+            return self._decoder_forward(mask_u8, images, mim_views), None
 
         vis_out = None
         if mode == "flip":
@@ -854,8 +860,11 @@ class _Step:
                 # online branch's first one on RCCL's in-order stream)
                 main.wait_stream(side)
                 enc_m.record_stream(main)
-                (masked2, self.saved_pix), (masked_m, _) = self.mlp_forward_pair(enc[:B * N], "pix_projector", "online", True,
-                                                                                  enc_m[:B * N], "pix_projector_m", "momentum", False)
+                if pp:
+                    (masked2, self.saved_pix), (masked_m, _) = self.mlp_forward_pair(enc[:B * N], "pix_projector", "online", True,
+                                                                                      enc_m[:B * N], "pix_projector_m", "momentum", False)
+                else:
+                    masked2, self.saved_pix, masked_m = enc[:B * N], None, enc_m[:B * N]
                 pooled = torch.empty((2 * B * nw, D), device=dev, dtype=BF16)
                 pooled_m = torch.empty((2 * B * nw, D), device=dev, dtype=BF16)
                 ops.window_pool_fwd(masked2, pooled[:B * nw], B, M.gh, M.gw, nw, D)
@@ -867,7 +876,7 @@ class _Step:
                 qs, self.saved_pred = self.mlp_forward(qs, "predictor", "online", True)
                 del enc_m, masked_m, pooled_m
         _mark("forward: both encoders + heads joined", dev)
-        M._flat["bn_count"] += 1                                            # all 14 BatchNorm layers ran once
+        M._flat["bn_count"] += 1                                            # all 14 (Dis-only: 8) BatchNorm layers ran once
         # ---- InfoNCE (:444-461): q1 vs gathered k2, q2 vs gathered k1, labels = arange + n*rank
         n = B * nw                                                          # rows of q1 / q2
         dim = M.moco_dim
@@ -894,10 +903,55 @@ class _Step:
             ops.ce_rows(logits, n * comm.rank, gs, stats[half])
             ops.sgemm(logits, kk, self.dqn[half * n:(half + 1) * n], n, dim, mk, True, 1.0 / M.T)
         contra, accs = ops.infonce_finish(stats, 2.0 * M.T / n, 100.0 / n)   # accs: q1_acc1, q1_acc5, q2_acc1, q2_acc5
-        if vis_out is None:
+        if not M.use_pixel_target:
+            vis_out = torch.empty((0, 0, M.dec_classes), device=dev, dtype=F32)     # (no 'vis_out' key for a Dis-only model: dig_forward)
+            self.mim_views = 0
+        elif vis_out is None:
             vis_out, _ = decoder()
         _mark("forward: InfoNCE + SimMIM decoder done", dev)
         return contra, accs, vis_out
+
+    def _decoder_forward(self, mask_u8, images, mim_views):
+        """pix_decoder on the masked rows of self.enc (modeling_pretrain_moco_mim_ori.py:560-570; the reference decodes all rows, then selects)."""
+        M = self.m
+        B, N, dev = images.shape[0], M.N, images.device
+        per = M._mask_count(mask_u8, B)
+        Mrows = mim_views * B * per
+        Mp = (Mrows + 63) // 64 * 64
+        idx, cnt = ops.mask_to_index(mask_u8[:mim_views * B], per)
+        M._last_mask_counts, M._last_idx, M._last_images = cnt, idx[:B], images
+        M._last_idx_views = [idx[:B]] + ([(idx[B:] - B * N).clamp_min_(0)] if mim_views == 2 else [])
+        self.idx, self.Mrows, self.Mp, self.per, self.mim_views = idx, Mrows, Mp, per, mim_views
+        w16, f32 = M._w("online"), M._f32
+        gath = ops.gather_rows(self.enc, idx, Mrows, Mp)
+        h0 = ops.linear_fwd(gath, w16["pix_decoder.0.weight"])
+        h1 = ops.linear_fwd(h0, w16["pix_decoder.1.weight"])
+        h2, mu, rs = ops.layernorm_fwd(h1, f32["pix_decoder.2.weight"], f32["pix_decoder.2.bias"], M.ln_eps, gelu=True)
+        pred = torch.empty((Mp, 64), device=dev, dtype=F32)
+        C = M.dec_classes
+        ops.gemm(h2, w16["pix_decoder.4.weight"], Mp, C, M.dec_dim, out=pred, out_kind=ops.OUT_F32, bias=f32["pix_decoder.4.bias"], ldc=64)
+        self.saved_dec = (gath, h0, h1, h2, mu, rs)
+        return pred[:Mrows, :C].reshape(mim_views * B, per, C)
+
+    def _forward_gen_only(self, ew_on, images, aug, mask_u8, mim_views, training, fresh):
+        """MoCo_ViT.forward of a Gen-only model (use_moco_target=False: pretrain_simmim_ori_*, modeling_pretrain_moco_mim_ori.py:655-681):
+        encoder -> its final LayerNorm (modeling_pretrain_vit.py:104; the moco branch is what replaces it by nn.Identity) -> pix_decoder on
+        the masked rows.  The reference runs the augmented view through the encoder as well and reads none of its rows when
+        only_mim_on_ori_img: the samples of a ViT batch are independent, so that view is not launched here (3 F per sample instead of 6)."""
+        M = self.m
+        dev = images.device
+        views = mim_views
+        self.gen_views = views
+        self.wT = None
+        if training and ops.mlp_chain_supported(M.D, M.F, views * self.B * M.N) and (ops.MLP_CHAIN_MASK & 4):
+            self.wT = self.mlp_weight_transposes(ew_on, fresh)
+        enc_raw, self.saved_enc = self.encoder_forward(ew_on, images, aug, mask_u8, True, views=views)
+        f32 = M._f32
+        self.enc, mu, rs = ops.layernorm_fwd(enc_raw, f32["encoder.norm.weight"], f32["encoder.norm.bias"], M.ln_eps)
+        self.saved_norm = (enc_raw, mu, rs)
+        vis_out = self._decoder_forward(mask_u8, images, mim_views)
+        zero = torch.zeros(5, device=dev, dtype=F32)                    # (no 'contra_loss' / accuracy keys for a Gen-only model: dig_forward)
+        return zero[0], zero[1:], vis_out
 
     # ------------------------------------------------------------------ full backward
     def backward(self, g_contra, g_vis):
@@ -909,11 +963,14 @@ class _Step:
         # contrast_start_epoch, BASELINE config 2): every gradient of that branch -- predictor, projector, pix_projector and
         # the whole augmented view -- is exactly zero in the reference, so nothing is launched for it and the encoder
         # backward runs on view 0's rows only (the gradient arena was zero-filled by optimizer.zero_grad()).
-        contrast = g_contra is not None
+        contrast = g_contra is not None and M.use_moco_target
+        if g_vis is not None and not M.use_pixel_target:
+            g_vis = None
         # the arena is known to be zero only right after optimizer.zero_grad(): a second backward() without it accumulates, as torch does
         self._assign, M._grads_fresh = bool(getattr(M, "_grads_fresh", False)), False
         _mark("backward: start (loss, MSE, autograd entry done)", dev)
         views = 2 if (contrast or (g_vis is not None and self.mim_views == 2)) else 1      # encoder rows that carry a gradient
+        # (Dis-only: no pix_projector writes view 0's rows -- both halves come from the pooling gradient, which overwrites)
         d_enc = torch.empty_like(self.enc) if contrast else torch.zeros((views * B * N, D), device=dev, dtype=BF16)
         n = B * nw
         if contrast:
@@ -926,13 +983,17 @@ class _Step:
             self._grad_ready(dev, "predictor")
             dpool = self.mlp_backward(dproj, "encoder_projection_layer", self.saved_proj)
             self._grad_ready(dev, "encoder_projection_layer")
-            dmasked2 = torch.empty((B * N, D), device=dev, dtype=BF16)
-            ops.window_pool_bwd(dpool[:n], dmasked2, B, M.gh, M.gw, nw, D, False)
-            ops.window_pool_bwd(dpool[n:], d_enc[B * N:], B, M.gh, M.gw, nw, D, False)
-            self.mlp_backward(dmasked2, "pix_projector", self.saved_pix, dx_out=d_enc[:B * N])
-            self._grad_ready(dev, "pix_projector")
-        else:
-            for name in ("predictor", "encoder_projection_layer", "pix_projector"):
+            if M.has_pix_projector:
+                dmasked2 = torch.empty((B * N, D), device=dev, dtype=BF16)
+                ops.window_pool_bwd(dpool[:n], dmasked2, B, M.gh, M.gw, nw, D, False)
+                ops.window_pool_bwd(dpool[n:], d_enc[B * N:], B, M.gh, M.gw, nw, D, False)
+                self.mlp_backward(dmasked2, "pix_projector", self.saved_pix, dx_out=d_enc[:B * N])
+                self._grad_ready(dev, "pix_projector")
+            else:
+                ops.window_pool_bwd(dpool[:n], d_enc[:B * N], B, M.gh, M.gw, nw, D, False)
+                ops.window_pool_bwd(dpool[n:], d_enc[B * N:], B, M.gh, M.gw, nw, D, False)
+        elif M.use_moco_target:
+            for name in ("predictor", "encoder_projection_layer") + (("pix_projector",) if M.has_pix_projector else ()):
                 self.comm.grad_ready(M, name)
         # ---- SimMIM decoder path
         if g_vis is not None:
@@ -950,7 +1011,16 @@ class _Step:
             self._on_side(dev, lambda: ops.linear_wgrad(dh0, gath, g32["pix_decoder.0.weight"]), dh0, gath)
             dgath = ops.linear_dgrad(dh0, w16["pix_decoder.0.weight"])
             ops.scatter_rows_add(dgath, self.idx, d_enc, Mrows)
-        self._grad_ready(dev, "pix_decoder")
+        if M.use_pixel_target:
+            self._grad_ready(dev, "pix_decoder")
+        if M.has_final_norm:
+            # Gen-only: the encoder's final LayerNorm between the blocks and the decoder (modeling_pretrain_vit.py:104)
+            if g_vis is not None:
+                enc_raw, mu, rs = self.saved_norm
+                d_enc = ops.layernorm_bwd(d_enc, enc_raw, f32["encoder.norm.weight"], f32["encoder.norm.bias"], mu, rs, None,
+                                          g32["encoder.norm.weight"], g32["encoder.norm.bias"])
+            self._grad_ready(dev, "encoder.norm")
+            self.saved_norm = None
         # ---- encoder
         ew_on, _ = _weights(M)
         _mark("backward: heads + decoder done", dev)
@@ -966,7 +1036,7 @@ class _Step:
         _mark("backward: encoder done, streams joined", dev)
         self._keep.clear()                          # (blocks go back to the caller's stream's pool: its later work is ordered behind the join)
         self._keep_marks.clear()
-        self.saved_enc = self.saved_pix = self.saved_proj = self.saved_pred = self.saved_dec = self.wT = None
+        self.saved_enc = self.saved_pix = self.saved_proj = self.saved_pred = self.saved_dec = self.saved_norm = self.wT = None
 
 
 class _DigFn(torch.autograd.Function):
@@ -1073,5 +1143,9 @@ def dig_forward(model, image, aug_image, vis_mask_pos, m, only_mim_on_ori_img=Tr
     else:
         contra, accs, vis_out = _Step(model).forward(image, aug_image, mask, m, mim_views)
     B = image.shape[0]
-    return {"contra_loss": contra, "q1_acc1": accs[0:1], "q1_acc5": accs[1:2], "q2_acc1": accs[2:3], "q2_acc5": accs[3:4],
-            "vis_out": [vis_out] if mim_views == 1 else [vis_out[:B], vis_out[B:]]}
+    out = {}
+    if model.use_moco_target:               # (the reference fills these keys only `if self.use_moco_target`, modeling_pretrain_moco_mim_ori.py:512-558)
+        out.update({"contra_loss": contra, "q1_acc1": accs[0:1], "q1_acc5": accs[1:2], "q2_acc1": accs[2:3], "q2_acc5": accs[3:4]})
+    if model.use_pixel_target:              # (:560-577)
+        out["vis_out"] = [vis_out] if mim_views == 1 else [vis_out[:B], vis_out[B:]]
+    return out

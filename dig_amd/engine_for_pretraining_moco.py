@@ -73,7 +73,7 @@ class _StepReadback:
             loss_value = host[0]
             if hv["w_contrast"] == 0.0 and not math.isfinite(host[1]):
                 loss_value = float('nan')
-            if host[7] != host[8] or int(host[7]) != self.core._per_sample_mask:
+            if self.core.use_pixel_target and (host[7] != host[8] or int(host[7]) != self.core._per_sample_mask):
                 raise RuntimeError("masks must select the same number of tokens in every sample "
                                    f"(got {int(host[7])}..{int(host[8])}, expected {self.core._per_sample_mask}; after a deliberate change "
                                    "of the mask ratio call model.reset_mask_count())")
@@ -82,7 +82,11 @@ class _StepReadback:
                 sys.exit(1)
             grad_norm = host[9] if hv["has_grad_norm"] else None
             ml = self.metric_logger
-            ml.update(loss_contrast=host[1], q1_acc1=host[3], q1_acc5=host[4], q2_acc1=host[5], q2_acc5=host[6], loss_pixel=host[2])
+            # (engine_for_pretraining_moco.py:119-144: each meter only `if '<key>' in out_dict` -- a single-objective model logs its own loss)
+            if self.core.use_moco_target:
+                ml.update(loss_contrast=host[1], q1_acc1=host[3], q1_acc5=host[4], q2_acc1=host[5], q2_acc5=host[6])
+            if self.core.use_pixel_target:
+                ml.update(loss_pixel=host[2])
             ml.update(loss=loss_value)
             ml.update(loss_scale=hv["loss_scale"])
             ml.update(lr=hv["lr"])
@@ -122,22 +126,28 @@ def _step_body(model, core, optimizer, loss_scaler, max_norm, args, normlize_tar
 
     out_dict = model(images, aug_images, bool_vis_masked_pos, moco_m, args.only_mim_on_ori_img)
     loss = 0.
-    contra_loss = out_dict['contra_loss']
-    if contrast_on:
-        loss = loss + contra_loss * w_contrast
-    # else: the reference adds 0 * contra_loss (:137), which leaves the value unchanged and back-propagates exact zeros
-    # through the whole contrastive branch; leaving the term out lets the engine skip those launches (engine_core.backward).
-    # A non-finite contra_loss would have poisoned the reference's loss (0 * inf = nan): the readback keeps that exit.
-    vis_out = out_dict['vis_out']
-    if args.only_mim_on_ori_img:
-        loss_pixel = mim_mse_loss(vis_out[0], core._last_images, core._last_idx, bool(normlize_target))
-    else:
-        # both views carry a masked-pixel loss (:138-141); every view's target comes from the ORIGINAL crops (:106-108)
-        loss_pixel = 0.
-        for i in range(args.num_view):
-            loss_pixel = loss_pixel + (1. / args.num_view) * mim_mse_loss(vis_out[i], core._last_images, core._last_idx_views[i],
-                                                                         bool(normlize_target))
-    loss = loss + loss_pixel * args.loss_weight_pixel
+    contra_loss = loss_pixel = None
+    if 'contra_loss' in out_dict:               # (:119-133: absent for a Gen-only model)
+        contra_loss = out_dict['contra_loss']
+        if contrast_on:
+            loss = loss + contra_loss * w_contrast
+        # else: the reference adds 0 * contra_loss (:137), which leaves the value unchanged and back-propagates exact zeros
+        # through the whole contrastive branch; leaving the term out lets the engine skip those launches (engine_core.backward).
+        # A non-finite contra_loss would have poisoned the reference's loss (0 * inf = nan): the readback keeps that exit.
+    if 'vis_out' in out_dict:                   # (:135-144: absent for a Dis-only model)
+        vis_out = out_dict['vis_out']
+        if args.only_mim_on_ori_img:
+            loss_pixel = mim_mse_loss(vis_out[0], core._last_images, core._last_idx, bool(normlize_target))
+        else:
+            # both views carry a masked-pixel loss (:138-141); every view's target comes from the ORIGINAL crops (:106-108)
+            loss_pixel = 0.
+            for i in range(args.num_view):
+                loss_pixel = loss_pixel + (1. / args.num_view) * mim_mse_loss(vis_out[i], core._last_images, core._last_idx_views[i],
+                                                                             bool(normlize_target))
+        loss = loss + loss_pixel * args.loss_weight_pixel
+    if not isinstance(loss, torch.Tensor):
+        # (a Dis-only model before contrast_start_epoch: the reference's loss is 0 * contra_loss -- every gradient an exact zero)
+        loss = contra_loss * 0.0
 
     optimizer.zero_grad()
     if adamw_dev_scalars is None:
@@ -150,6 +160,17 @@ def _step_body(model, core, optimizer, loss_scaler, max_norm, args, normlize_tar
     # and its per-step torch.cuda.synchronize() (:159) drain the HIP queues twice per step and leave the GPU waiting
     # on kernel launches (measured: 1.1 ms of a 28.7 ms step).  The non-finite-loss exit (:148-150) and the
     # ragged-mask check therefore fire one step late -- before anything is logged or saved for that step.
+    if contra_loss is None or loss_pixel is None:
+        # a single-objective model: the absent meters travel as NaN and are not logged (_StepReadback.resolve)
+        nan = torch.full((), float('nan'), device=loss.device)
+        accs = [out_dict[k][0] for k in ('q1_acc1', 'q1_acc5', 'q2_acc1', 'q2_acc5')] if contra_loss is not None else [nan] * 4
+        cnt = core._last_mask_counts if loss_pixel is not None else None
+        dev_vals = torch.stack([loss.detach().reshape(()).float(), nan if contra_loss is None else contra_loss.detach().reshape(()),
+                                nan if loss_pixel is None else loss_pixel.detach().reshape(())] + accs +
+                               [nan if cnt is None else cnt.min().float(), nan if cnt is None else cnt.max().float(),
+                                grad_norm.detach().reshape(()).float() if isinstance(grad_norm, torch.Tensor)
+                                else torch.full((), float('nan') if grad_norm is None else float(grad_norm), device=loss.device)])
+        return dev_vals, grad_norm is not None
     a1 = out_dict['q1_acc1']
     f32s = (loss, contra_loss, loss_pixel, a1)
     if (all(isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 for t in f32s) and loss.numel() == 1 and loss_pixel.numel() == 1

@@ -86,9 +86,11 @@ class MoCo_ViT(nn.Module):
                  encoder_type='vit', queue_size=65536, patchnet_name='regular', label_smoothing=0., use_pix_projector=True,
                  device=None, **unused):
         super().__init__()
-        if not (use_pixel_target and use_moco_target and use_pix_projector):
-            raise NotImplementedError("dig_amd implements the SimMIM+MoCo ('simmim_moco_ori') variants of the hot path")
-        if patchnet_name != 'no_patchtrans':
+        if not (use_pixel_target or use_moco_target):
+            raise ValueError("MoCo_ViT needs at least one objective (use_pixel_target / use_moco_target)")
+        if use_pixel_target and use_moco_target and not use_pix_projector:
+            raise NotImplementedError("use_pix_projector=False (no factory of the reference sets it) is not built")
+        if patchnet_name != 'no_patchtrans' and use_moco_target:
             raise NotImplementedError("only patchnet_name='no_patchtrans' (the README configuration) is implemented")
         if drop_rate or attn_drop_rate or drop_path_rate or init_values or use_learnable_pos_emb or label_smoothing:
             raise NotImplementedError("dropout / drop-path / layer-scale / learnable pos-emb / label smoothing are 0 in pre-training")
@@ -113,15 +115,21 @@ class MoCo_ViT(nn.Module):
         self.dec_dim, self.dec_classes = decoder_embed_dim, decoder_num_classes
         self.moco_dim, self.moco_mlp_dim = dim, mlp_dim
         self.ln_eps, self.bn_eps, self.bn_momentum = 1e-6, 1e-5, 0.1
-        self.use_pixel_target, self.use_moco_target = True, True
+        # which objectives the model carries (modeling_pretrain_moco_mim_ori.py:340-426): both = the `simmim_moco_ori` factories; Dis-only
+        # (`pretrain_moco_ori_*`: no mask, no pix_projector, no decoder); Gen-only (`pretrain_simmim_ori_*`: the encoder keeps its final
+        # LayerNorm -- the moco branch is what replaces it by nn.Identity, :362-363 -- no momentum networks, no heads)
+        self.use_pixel_target, self.use_moco_target = bool(use_pixel_target), bool(use_moco_target)
+        self.has_pix_projector = self.use_pixel_target and self.use_moco_target
+        self.has_final_norm = not self.use_moco_target
         self.comm = None            # set by dig_amd.parallel.DistributedDataParallel
-        self.mlps = OrderedDict([
-            ("encoder_projection_layer", _mlp_dims(3, D, mlp_dim, dim)),
-            ("momentum_projection_layer", _mlp_dims(3, D, mlp_dim, dim)),
-            ("predictor", _mlp_dims(2, dim, mlp_dim, dim)),
-            ("pix_projector", _mlp_dims(3, D, 512, D)),
-            ("pix_projector_m", _mlp_dims(3, D, 512, D)),
-        ])
+        self.mlps = OrderedDict()
+        if self.use_moco_target:
+            self.mlps["encoder_projection_layer"] = _mlp_dims(3, D, mlp_dim, dim)
+            self.mlps["momentum_projection_layer"] = _mlp_dims(3, D, mlp_dim, dim)
+            self.mlps["predictor"] = _mlp_dims(2, dim, mlp_dim, dim)
+        if self.has_pix_projector:
+            self.mlps["pix_projector"] = _mlp_dims(3, D, 512, D)
+            self.mlps["pix_projector_m"] = _mlp_dims(3, D, 512, D)
         self._build_layout()
         self._allocate(torch.device(device) if device is not None else torch.device("cpu"))
         self._init_weights()
@@ -145,6 +153,8 @@ class MoCo_ViT(nn.Module):
                   ParamSpec(b + "norm2.bias", (D,), 1, arena), ParamSpec(b + "mlp.fc1.weight", (Fh, D), 0, arena),
                   ParamSpec(b + "mlp.fc1.bias", (Fh,), 1, arena), ParamSpec(b + "mlp.fc2.weight", (D, Fh), 0, arena),
                   ParamSpec(b + "mlp.fc2.bias", (D,), 1, arena)]
+        if self.has_final_norm:                                          # modeling_pretrain_vit.py:59,104 (Gen-only)
+            s += [ParamSpec(pre + "norm.weight", (D,), 1, arena), ParamSpec(pre + "norm.bias", (D,), 1, arena)]
         return s
 
     @staticmethod
@@ -166,17 +176,24 @@ class MoCo_ViT(nn.Module):
         D, Dd = self.D, self.dec_dim
         specs = []
         specs += self._encoder_specs("encoder.", "online")
-        specs += self._encoder_specs("momentum_encoder.", "momentum")
-        specs += self._mlp_specs("encoder_projection_layer", self.mlps["encoder_projection_layer"], "online")
-        specs += self._mlp_specs("momentum_projection_layer", self.mlps["momentum_projection_layer"], "momentum")
-        specs += self._mlp_specs("predictor", self.mlps["predictor"], "online")
-        specs += self._mlp_specs("pix_projector", self.mlps["pix_projector"], "online")
-        specs += self._mlp_specs("pix_projector_m", self.mlps["pix_projector_m"], "momentum")
-        specs += [ParamSpec("pix_decoder.0.weight", (Dd, D), 0, "online"), ParamSpec("pix_decoder.1.weight", (Dd, Dd), 0, "online"),
-                  ParamSpec("pix_decoder.2.weight", (Dd,), 1, "online"), ParamSpec("pix_decoder.2.bias", (Dd,), 1, "online"),
-                  ParamSpec("pix_decoder.4.weight", (self.dec_classes, Dd), 0, "online"),
-                  ParamSpec("pix_decoder.4.bias", (self.dec_classes,), 1, "online")]
+        if self.use_moco_target:
+            specs += self._encoder_specs("momentum_encoder.", "momentum")
+            specs += self._mlp_specs("encoder_projection_layer", self.mlps["encoder_projection_layer"], "online")
+            specs += self._mlp_specs("momentum_projection_layer", self.mlps["momentum_projection_layer"], "momentum")
+            specs += self._mlp_specs("predictor", self.mlps["predictor"], "online")
+        if self.has_pix_projector:
+            specs += self._mlp_specs("pix_projector", self.mlps["pix_projector"], "online")
+            specs += self._mlp_specs("pix_projector_m", self.mlps["pix_projector_m"], "momentum")
+        if self.use_pixel_target:
+            specs += [ParamSpec("pix_decoder.0.weight", (Dd, D), 0, "online"), ParamSpec("pix_decoder.1.weight", (Dd, Dd), 0, "online"),
+                      ParamSpec("pix_decoder.2.weight", (Dd,), 1, "online"), ParamSpec("pix_decoder.2.bias", (Dd,), 1, "online"),
+                      ParamSpec("pix_decoder.4.weight", (self.dec_classes, Dd), 0, "online"),
+                      ParamSpec("pix_decoder.4.bias", (self.dec_classes,), 1, "online")]
         self.specs = OrderedDict((s.name, s) for s in specs)
+        if not self.use_pixel_target:
+            # Dis-only: the encoder runs without a mask (`vis_mask_pos = None`, :493-494), mask_token is never read, its .grad stays None
+            # and the reference's AdamW skips it altogether (custom_optim/adamw.py:78-79: no decay, no state): granule group 2 = untouched
+            self.specs["encoder.mask_token"].group = 2
 
         def place(names, arena_groups):
             off = 0
@@ -209,6 +226,8 @@ class MoCo_ViT(nn.Module):
         mom = [n for n in self.specs if self.specs[n].arena == "momentum"]
         tmp = []
         n_mom = place(mom, tmp)
+        if not self.use_moco_target:
+            self.n_ema = 0                                                  # Gen-only: no momentum arena, nothing for the EMA kernel
         assert n_mom == self.n_ema
         # the momentum arena must mirror the online one offset-for-offset
         for n in mom:
@@ -216,7 +235,9 @@ class MoCo_ViT(nn.Module):
                    .replace("pix_projector_m.", "pix_projector."))
             assert self.specs[src].offset == self.specs[n].offset, (n, src)
         # gradient-bucket boundaries (element ranges of the online arena), in backward-completion order
-        self.bucket_names = (["pix_decoder", "predictor", "encoder_projection_layer", "pix_projector"]
+        heads = [k for k, on in (("pix_decoder", self.use_pixel_target), ("predictor", self.use_moco_target),
+                                 ("encoder_projection_layer", self.use_moco_target), ("pix_projector", self.has_pix_projector)) if on]
+        self.bucket_names = (heads + (["encoder.norm"] if self.has_final_norm else [])
                              + [f"encoder.blocks.{i}" for i in reversed(range(self.depth))] + ["encoder.embed"])
 
     def bucket_range(self, key):
@@ -233,7 +254,7 @@ class MoCo_ViT(nn.Module):
     def _allocate(self, device):
         self._flat = {
             "online": torch.zeros(self.n_online, dtype=F32, device=device),
-            "momentum": torch.zeros(self.n_ema, dtype=F32, device=device),
+            "momentum": torch.zeros(max(self.n_ema, ALIGN) if not self.use_moco_target else self.n_ema, dtype=F32, device=device),
             "grad": torch.zeros(self.n_online, dtype=F32, device=device),
             "groups": torch.tensor(self._online_groups, dtype=torch.uint8, device=device),
         }
@@ -268,7 +289,8 @@ class MoCo_ViT(nn.Module):
                 c_off += d2
                 i_bn += 1
         self.encoder.pos_embed = get_sinusoid_encoding_table(self.N, self.D)     # plain attribute (not in state_dict)
-        self.momentum_encoder.pos_embed = self.encoder.pos_embed
+        if self.use_moco_target:
+            self.momentum_encoder.pos_embed = self.encoder.pos_embed
         self._rebind()
 
     def _rebind(self):
@@ -299,6 +321,7 @@ class MoCo_ViT(nn.Module):
                 if s.arena == "online":
                     self._qkv_bias_grad[key] = self._flat["grad"][s.offset:s.offset + 3 * self.D]
         self._views_version += 1
+        self._fresh = None
 
     def _apply(self, fn, recurse=True):
         self._flat = {k: fn(v) for k, v in self._flat.items()}
@@ -314,6 +337,7 @@ class MoCo_ViT(nn.Module):
                     v.copy_(state_dict[k])
                 else:
                     missing.append(k)
+        self.mark_weights_changed()
         if strict and (missing or [k for k in state_dict if k not in own]):
             raise RuntimeError(f"load_state_dict: missing {missing[:5]}, unexpected {[k for k in state_dict if k not in own][:5]}")
         return torch.nn.modules.module._IncompatibleKeys(missing, [k for k in state_dict if k not in own])
@@ -331,12 +355,15 @@ class MoCo_ViT(nn.Module):
                 if n.endswith("mask_token"):
                     v.zero_()
                 elif n.endswith("patch_embed.proj.weight"):
-                    a = math.sqrt(6.0 / float(3 * 16 + self.D))
+                    # :353-355 sits inside `if use_moco_target`: a Gen-only model keeps nn.Conv2d's own init (weight and bias U(+-1/sqrt(fan_in)))
+                    a = math.sqrt(6.0 / float(3 * 16 + self.D)) if self.use_moco_target else 1.0 / math.sqrt(48.0)
                     v.uniform_(-a, a)
+                elif n.endswith("patch_embed.proj.bias") and not self.use_moco_target:
+                    v.uniform_(-1.0 / math.sqrt(48.0), 1.0 / math.sqrt(48.0))
                 elif n.startswith("encoder."):
                     if len(s.shape) == 2:
                         nn.init.xavier_uniform_(v)
-                    elif n.endswith(("norm1.weight", "norm2.weight")):
+                    elif n.endswith(("norm1.weight", "norm2.weight", "norm.weight")):
                         v.fill_(1.0)
                     else:
                         v.zero_()
@@ -349,7 +376,8 @@ class MoCo_ViT(nn.Module):
                     v.fill_(1.0)
                 else:
                     v.zero_()
-            self._flat["momentum"].copy_(self._flat["online"][:self.n_ema])
+            if self.n_ema:
+                self._flat["momentum"].copy_(self._flat["online"][:self.n_ema])
             c_tot = self._flat["bn_stats"].numel() // 2
             self._flat["bn_stats"][c_tot:].fill_(1.0)
 
@@ -389,6 +417,60 @@ class MoCo_ViT(nn.Module):
             cache[arena] = {n: sh[s.offset:s.offset + s.numel].view(s.shape[0], -1) for n, s in self.specs.items()
                             if s.arena == arena and len(s.shape) >= 2 and not n.endswith("mask_token")}
         return cache[arena]
+
+    # ------------------------------------------------------------------ what the optimizer launch leaves for the next forward
+    # The fused AdamW launch (optim_factory.FusedAdamW.step -> dig_adamw_step_tr) writes, next to the fp32 parameters, the bf16 operand
+    # shadow of the online arena AND the K-contiguous transposed copies W^T of the weights the fused MLP backward reads (fc2, fc1, proj of
+    # every block): the forward of the next step then needs neither its cast launch nor the three transpose launches.  "Fresh" = nothing has
+    # changed the online arena since that launch: load_state_dict / .to() / _rebind() clear it, torch in-place operations on the arena or
+    # on a parameter bump the arena's version counter (checked); code that writes parameters through `.data` or raw pointers must call
+    # mark_weights_changed().
+    def transposed_weight_table(self):
+        """(device table of dig_adamw_step_tr, n_mats, n_tiles, tr_out, [(w2t, w1t, projt) views per block]) or None when a shape is not a
+        multiple of 64 (the transposes are then rebuilt by the forward, as before)."""
+        dev = self._flat["online"].device
+        cache = getattr(self, "_tr_table", None)
+        if cache is not None and cache[0] == (self._views_version, dev):
+            return cache[1]
+        recs, views, dst, tile0 = [], [], 0, 0
+        per_block = []
+        ok = dev.type == "cuda"
+        for i in range(self.depth):
+            row = []
+            for leaf in ("mlp.fc2.weight", "mlp.fc1.weight", "attn.proj.weight"):
+                sp = self.specs[f"encoder.blocks.{i}.{leaf}"]
+                r, c = sp.shape
+                ok = ok and r % 64 == 0 and c % 64 == 0 and sp.offset % ALIGN == 0
+                recs.append((sp.offset, dst, r, c, tile0))
+                row.append((dst, c, r))
+                dst += r * c
+                tile0 += (r // 64) * (c // 64)
+            per_block.append(row)
+        out = None
+        if ok:
+            import struct
+            raw = b"".join(struct.pack("<qqiiii", off, d, r, c, t0, 0) for off, d, r, c, t0 in recs)
+            table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+            tr_out = torch.empty(dst, device=dev, dtype=BF16)
+            wT = [tuple(tr_out[d:d + a * b].view(a, b) for d, a, b in row) for row in per_block]
+            flags = self._flat["groups"].clone()
+            for off, _, r, c, _ in recs:
+                flags[off // ALIGN:(off + r * c) // ALIGN] |= 0x80
+            out = (table, len(recs), tile0, tr_out, wT, flags)
+        self._tr_table = ((self._views_version, dev), out)
+        return out
+
+    def mark_weights_changed(self):
+        """The online parameters were written by something other than the fused optimizer launch: the next forward re-casts the bf16
+        shadow and rebuilds the transposed weight copies."""
+        self._fresh = None
+
+    def _set_fresh(self):
+        self._fresh = (self._views_version, self._flat["online"]._version)
+
+    def weights_fresh(self):
+        f = getattr(self, "_fresh", None)
+        return f is not None and f == (self._views_version, self._flat["online"]._version)
 
     def _side_stream(self, dev):
         """Second HIP stream for the gradient-free momentum branch (overlaps the online forward)."""
@@ -448,13 +530,13 @@ class MoCo_ViT(nn.Module):
         return dig_forward(self, image, aug_image, vis_mask_pos, m, only_mim_on_ori_img)
 
 
-def _factory(embed_dim, heads, **kwargs):
+def _factory(embed_dim, heads, pixel=True, moco=True, **kwargs):
     kwargs.pop("pretrained", None)
     init_ckpt = kwargs.pop("init_ckpt", None)
     model = MoCo_ViT(img_size=(32, 128), patch_size=4, encoder_embed_dim=embed_dim, encoder_depth=12, encoder_num_heads=heads,
                      encoder_num_classes=0, decoder_num_classes=48, decoder_embed_dim=192, decoder_depth=4, decoder_num_heads=3,
-                     mlp_ratio=4, qkv_bias=True, norm_layer=partial(nn.LayerNorm, eps=1e-6), use_pixel_target=True,
-                     use_moco_target=True, **kwargs)
+                     mlp_ratio=4, qkv_bias=True, norm_layer=partial(nn.LayerNorm, eps=1e-6), use_pixel_target=pixel,
+                     use_moco_target=moco, **kwargs)
     model.default_cfg = {'url': '', 'num_classes': 1000, 'input_size': (3, 32, 128), 'pool_size': None, 'crop_pct': 1.0,
                          'interpolation': 'bicubic', 'mean': (0.5, 0.5, 0.5), 'std': (0.5, 0.5, 0.5)}
     if init_ckpt:
@@ -478,3 +560,23 @@ def pretrain_simmim_moco_ori_vit_small_patch4_32x128(pretrained=False, **kwargs)
 def pretrain_simmim_moco_ori_vit_base_patch4_32x128(pretrained=False, **kwargs):
     """modeling_pretrain_moco_mim_ori.py:792-817 (D=512, 8 heads)."""
     return _factory(512, 8, init_ckpt=kwargs.pop("init_ckpt", None) if pretrained else None, **kwargs)
+
+
+# ---- the single-objective factories of the reference: the paper's ablation models, driven by the same train_one_epoch
+# (engine_for_pretraining_moco.py:119-144 tests `'contra_loss' in out_dict` / `'vis_out' in out_dict`)
+def _single(name, embed_dim, heads, pixel, moco, doc):
+    def fn(pretrained=False, **kwargs):
+        return _factory(embed_dim, heads, pixel=pixel, moco=moco, init_ckpt=kwargs.pop("init_ckpt", None) if pretrained else None, **kwargs)
+    fn.__name__ = fn.__qualname__ = name
+    fn.__doc__ = doc
+    fn.__module__ = __name__
+    globals()[name] = register_model(fn)
+
+
+for _size, (_d, _h) in (("tiny", (192, 3)), ("small", (384, 6)), ("base", (512, 8))):
+    _single(f"pretrain_moco_ori_vit_{_size}_patch4_32x128", _d, _h, False, True,
+            "Dis-only (use_pixel_target=False): MoCo-v3 on unmasked views, no pix_projector, no decoder "
+            "(modeling_pretrain_moco_mim_ori.py:627-653 small, :709-735 tiny, :818-843 base).")
+    _single(f"pretrain_simmim_ori_vit_{_size}_patch4_32x128", _d, _h, True, False,
+            "Gen-only (use_moco_target=False): encoder + its final LayerNorm + pix_decoder "
+            "(modeling_pretrain_moco_mim_ori.py:655-681 small, :737-763 tiny, :845-871 base).")

@@ -242,10 +242,11 @@ def transpose_bf16(src, out=None):
     return out
 
 
-def transpose_bf16_multi(srcs):
-    """[src^T for src in srcs] for equally shaped bf16 matrices, 32 per launch (dig_transpose_bf16_multi)."""
+def transpose_bf16_multi(srcs, outs=None):
+    """[src^T for src in srcs] for equally shaped bf16 matrices, 32 per launch (dig_transpose_bf16_multi); into `outs` when given."""
     rows, cols = srcs[0].shape
-    outs = [torch.empty((cols, rows), device=s_.device, dtype=BF16) for s_ in srcs]
+    if outs is None:
+        outs = [torch.empty((cols, rows), device=s_.device, dtype=BF16) for s_ in srcs]
     for i in range(0, len(srcs), 32):
         n = min(32, len(srcs) - i)
         sp = (ctypes.c_void_p * n)(*[s_.data_ptr() for s_ in srcs[i:i + n]])
@@ -694,8 +695,15 @@ def attn_fwd(qkv, n_img, heads, D, drop=None, q_rows=256):
 ATTN_BLOCK = os.environ.get("DIG_ATTN_BLOCK", "1") != "0"    # the fused attention sub-block (csrc/attn_block.hip) where the widths allow it
 
 
-def attn_block_supported(heads, D):
-    return ATTN_BLOCK and bool(L.lib().dig_attn_block_supported(int(heads), int(D)))
+# one workgroup per image: the single-view encoder of a Gen-only model at B = 128 is 128 images on 256 CUs -- the launch would leave half
+# the chip idle for its whole length, and the three launches it replaces (which tile over rows / (image, head) pairs) win.  Applied to the
+# single-view encoder only (n_img given); the two-view step keeps the fused launch at every batch size.
+ATTN_BLOCK_MIN_IMG = int(os.environ.get("DIG_ATTN_BLOCK_MIN_IMG", "160"))
+
+
+def attn_block_supported(heads, D, n_img=None):
+    return (ATTN_BLOCK and (n_img is None or n_img >= ATTN_BLOCK_MIN_IMG or n_img < 32)
+            and bool(L.lib().dig_attn_block_supported(int(heads), int(D))))
 
 
 def attn_block_fwd(ln1, x, qkv_w, qkv_b, proj_w, proj_b, n_img, heads, D, scale, save=False):
@@ -973,6 +981,14 @@ def sumsq(x, workspace, out):
 def adamw_step(p, g, m, v, shadow, group_flags, lr0, wd0, lr1, wd1, beta1, beta2, eps, step, grad_scale=1.0, finite_gate=None):
     L.call("dig_adamw_step", L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), L.ptr(shadow), cll(p.numel()), L.ptr(group_flags), cf(lr0),
            cf(wd0), cf(lr1), cf(wd1), cf(beta1), cf(beta2), cf(eps), int(step), cf(grad_scale), L.ptr(finite_gate), L.stream())
+
+
+def adamw_step_tr(p, g, m, v, shadow, group_flags, lr0, wd0, lr1, wd1, beta1, beta2, eps, step, mats, n_mats, n_tiles, tr_out, grad_scale=1.0,
+                  finite_gate=None):
+    """dig_adamw_step + the transposed bf16 copies of the weights listed in the device table `mats` (written into tr_out)."""
+    L.call("dig_adamw_step_tr", L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), L.ptr(shadow), cll(p.numel()), L.ptr(group_flags), cf(lr0),
+           cf(wd0), cf(lr1), cf(wd1), cf(beta1), cf(beta2), cf(eps), int(step), cf(grad_scale), L.ptr(finite_gate), L.ptr(mats), int(n_mats),
+           int(n_tiles), L.ptr(tr_out), L.stream())
 
 
 def adamw_step_dev(p, g, m, v, shadow, group_flags, scalars6, beta1, beta2, eps, grad_scale=1.0, finite_gate=None):

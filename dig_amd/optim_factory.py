@@ -10,7 +10,13 @@ import json
 
 import torch
 
+import os
+
 from . import ops
+
+# the optimizer launch also writes the bf16 operand shadow and the transposed weight copies the next forward needs (dig_adamw_step_tr);
+# "0": the plain launch, the forward re-casts and re-transposes every step (the round-5 plan)
+FOLD_SHADOW = os.environ.get("DIG_ADAMW_FOLD", "1") != "0"
 
 
 def get_parameter_groups(model, weight_decay=1e-5, skip_list=()):
@@ -33,7 +39,7 @@ class FusedAdamW(torch.optim.Optimizer):
         named = dict(model.named_parameters())
         # the arena's flag table was laid out with the same rule; verify instead of trusting
         for n in decay:
-            assert model.specs[n].group == 0, n
+            assert model.specs[n].group in (0, 2), n          # (2: a parameter the model never reads -- no gradient, left untouched)
         for n in no_decay:
             assert model.specs[n].group == 1, n
         groups = [
@@ -77,10 +83,25 @@ class FusedAdamW(torch.optim.Optimizer):
         if dev_scalars is not None:
             ops.adamw_step_dev(M.flat_params, M.flat_grads, self.exp_avg, self.exp_avg_sq, None, M.flat_groups, dev_scalars, b1, b2,
                                g0["eps"], grad_scale, finite_gate)
+            if hasattr(M, "mark_weights_changed"):
+                M.mark_weights_changed()
             return
         self._step += 1
+        tr = M.transposed_weight_table() if (FOLD_SHADOW and hasattr(M, "transposed_weight_table") and M.flat_params.is_cuda
+                                             and not torch.cuda.is_current_stream_capturing()) else None
+        if tr is not None:
+            # one launch: the update, the bf16 operand shadow of the whole arena and the transposed copies of the MLP / projection weights
+            # (what the next forward would otherwise rebuild with a cast launch and three transpose launches)
+            table, n_mats, n_tiles, tr_out, _, flags = tr
+            ops.adamw_step_tr(M.flat_params, M.flat_grads, self.exp_avg, self.exp_avg_sq, M.shadow("online"), flags,
+                              g0["lr"], g0["weight_decay"], g1["lr"], g1["weight_decay"], b1, b2, g0["eps"], self._step, table, n_mats, n_tiles,
+                              tr_out, grad_scale, finite_gate)
+            M._set_fresh()
+            return
         ops.adamw_step(M.flat_params, M.flat_grads, self.exp_avg, self.exp_avg_sq, None, M.flat_groups,
                        g0["lr"], g0["weight_decay"], g1["lr"], g1["weight_decay"], b1, b2, g0["eps"], self._step, grad_scale, finite_gate)
+        if hasattr(M, "mark_weights_changed"):
+            M.mark_weights_changed()
 
     # ---- checkpoint format: the reference's torch-Optimizer layout (custom_optim/optimizer.py state_dict):
     #   {'state': {i: {'step', 'exp_avg', 'exp_avg_sq'}}, 'param_groups': [{..., 'params': [i, ...]}, ...]}

@@ -98,6 +98,8 @@ def usable(core, model, optimizer, loss_scaler, max_norm):
         return False
     if max_norm is not None and max_norm > 0:
         return False
+    if not (getattr(core, "use_moco_target", True) and getattr(core, "use_pixel_target", True)):
+        return False                                  # (the single-objective models run eagerly)
     return type(optimizer) is FusedAdamW and type(loss_scaler) is NativeScalerWithGradNormCount and optimizer.model is core
 
 

@@ -266,7 +266,9 @@ int dig_colsum_masked(const void* x, const unsigned char* mask, float* out_unmas
                       int rows, int C, hipStream_t stream);   /* workspace: 2 x dig_colsum_workspace_bytes(rows, C) */
 
 /* PatchNet 'no_patchtrans' = adaptive_avg_pool2d of the gh x gw token grid to (1, nwin)
- * (modeling_pretrain_moco_mim_ori.py:189-193) and its gradient (accumulate=1 adds into dx). */
+ * (modeling_pretrain_moco_mim_ori.py:189-193) and its gradient (accumulate=1 adds into dx).  Window `w` = all gh rows x columns
+ * [floor(w gw / nwin), ceil((w + 1) gw / nwin)): equal windows when nwin divides gw (README: 4 on 32 columns), overlapping bins of
+ * 7 / 7 / 8 / 7 / 7 columns for the argparse default --num_windows 5 (run_mae_pretraining_moco.py:143); nwin <= gw. */
 int dig_window_pool_fwd(const void* x, void* out, int out_is_f32, int n_img, int gh, int gw, int nwin, int D, hipStream_t stream);
 int dig_window_pool_bwd(const void* dpool, void* dx, int n_img, int gh, int gw, int nwin, int D, int accumulate, hipStream_t stream);
 
@@ -320,7 +322,7 @@ int dig_step_meters(const float* loss, const float* contra, const float* pixel, 
  * Flat-arena optimizer (custom_optim/adamw.py:55-121 + _functional.py:115-140 as one kernel; EMA
  * modeling_pretrain_moco_mim_ori.py:428-442; grad norm utils/utils.py:507-519).
  *   dig_adamw_step: group_flags[i / 256] in {0,1} selects (lr0, wd0) or (lr1, wd1) for element i (parameters are padded
- *                   to 256 elements); step >= 1 is the Adam step count; grad_scale multiplies g (clipping / averaging);
+ *                   to 256 elements), 2 = leave the granule untouched (a parameter without a gradient); step >= 1 is the Adam step count; grad_scale multiplies g (clipping / averaging);
  *                   bf16_shadow (optional) receives the updated parameters in bf16;  finite_gate (optional): a device float --
  *                   when it is not finite (the squared gradient norm of dig_sumsq after a NaN / Inf loss) the launch changes
  *                   nothing, as torch's GradScaler skips optimizer.step() on inf / nan gradients (utils/utils.py:498-504).
@@ -330,6 +332,16 @@ int dig_step_meters(const float* loss, const float* contra, const float* pixel, 
 int dig_adamw_step(float* p, const float* g, float* m, float* v, void* bf16_shadow, long long n, const unsigned char* group_flags,
                    float lr0, float wd0, float lr1, float wd1, float beta1, float beta2, float eps, int step, float grad_scale,
                    const float* finite_gate, hipStream_t stream);
+/* dig_adamw_step that also leaves, for a list of 2-D weights, the updated values TRANSPOSED in bf16 (W^T [cols, rows], the K-contiguous
+ * operand of the fused MLP backward, dig_mlp_chain_bwd*): what three dig_transpose_bf16_multi launches per step used to rebuild from the
+ * shadow.  mats: device table of n_mats 32-byte records {int64 off (element offset of W [rows, cols] in the arena, a multiple of 256),
+ * int64 dst_off (element offset of W^T in tr_out, a multiple of 4), int32 rows, int32 cols (multiples of 64), int32 tile0 (index of the
+ * weight's first 64 x 64 tile: the running sum of rows / 64 * cols / 64), int32 0}; n_tiles = the sum over the table.  The granules of a
+ * listed weight carry bit 7 in group_flags (0x80 | group).  group_flags value 2 (either form) = a parameter that never receives a gradient:
+ * left untouched, as the reference's AdamW skips `p.grad is None` (custom_optim/adamw.py:78-79).  Same arithmetic as dig_adamw_step. */
+int dig_adamw_step_tr(float* p, const float* g, float* m, float* v, void* bf16_shadow, long long n, const unsigned char* group_flags,
+                      float lr0, float wd0, float lr1, float wd1, float beta1, float beta2, float eps, int step, float grad_scale,
+                      const float* finite_gate, const void* mats, int n_mats, int n_tiles, void* tr_out, hipStream_t stream);
 /* Same update with any number of parameter groups (layer-wise lr decay: optim_factory.py:33-100, run_class_finetuning.py:471-520):
  * group_idx holds one uint8 per 256-element granule indexing the device tables lr_tab / wd_tab; index 255 = granule without a
  * gradient, left untouched (the reference's AdamW skips p.grad is None). */

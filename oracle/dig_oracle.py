@@ -376,7 +376,7 @@ def encoder(P, pre, images, mask, cfg: DiGConfig, taps=None):
         x = block(x, P, f"{pre}blocks.{i}.", cfg, taps)
         if taps is not None:
             taps[f"{pre}blocks.{i}"] = x
-    if pre + "norm.weight" in P:                                          # x = self.norm(x), modeling_pretrain_vit.py:104 (Gen-only)
+    if not cfg.use_moco:                                                  # x = self.norm(x), modeling_pretrain_vit.py:104 (Gen-only)
         x = layer_norm(x, P[pre + "norm.weight"], P[pre + "norm.bias"], cfg.ln_eps)
     return x
 

@@ -245,6 +245,29 @@ def test_window_pool(dev):
     assert rel(dx, refdx) < 1e-2
 
 
+@pytest.mark.parametrize("nwin", [5, 3, 7, 32, 1])
+def test_window_pool_uneven_windows(dev, nwin):
+    """--num_windows 5, the reference CLI's default (run_mae_pretraining_moco.py:143): adaptive_avg_pool2d with overlapping bins, forward and
+    gradient against torch (PatchNet.forward, modeling_pretrain_moco_mim_ori.py:189-193)."""
+    from dig_amd import ops
+    Bn, D = 5, 128
+    x = torch.randn(Bn, 256, D, device=dev).bfloat16()
+    out = torch.empty(Bn * nwin, D, device=dev, dtype=torch.float32)
+    ops.window_pool_fwd(x, out, Bn, 8, 32, nwin, D)
+    xr = x.float().cpu().reshape(Bn, 8, 32, D).permute(0, 3, 1, 2).requires_grad_(True)
+    ref = F.adaptive_avg_pool2d(xr, (1, nwin))
+    assert (out.cpu() - ref.permute(0, 2, 3, 1).reshape(Bn * nwin, D)).abs().max().item() < 2e-6 * 8 * 32       # fp32 sums of the same bf16 values
+    dp = torch.randn(Bn * nwin, D, device=dev).bfloat16()
+    ref.backward(dp.float().cpu().reshape(Bn, 1, nwin, D).permute(0, 3, 1, 2))
+    refdx = xr.grad.permute(0, 2, 3, 1).reshape(Bn, 256, D)
+    for acc in (False, True):
+        dx = torch.randn(Bn, 256, D, device=dev).bfloat16()
+        dx0 = dx.clone()
+        ops.window_pool_bwd(dp, dx, Bn, 8, 32, nwin, D, acc)
+        want = (refdx + (dx0.float().cpu() if acc else 0)).bfloat16()
+        assert (dx.cpu().float() - want.float()).abs().max().item() <= 2 ** -7 * want.float().abs().max().item()     # one bf16 rounding
+
+
 def test_mask_index_gather_target_are_bit_exact(dev):
     """Integer / byte work: bit-exact against the reference's boolean indexing (engine_for_pretraining_moco.py:96-107)."""
     from dig_amd import ops
@@ -340,6 +363,52 @@ def test_adamw_ema_sumsq_colsum(dev):
     xx = torch.randn(3000, 48, device=dev).bfloat16(); cs = torch.ones(48, device=dev)
     ops.colsum(xx, cs)
     assert rel(cs, 1 + xx.float().sum(0)) < 1e-5
+
+
+def test_adamw_step_tr_equals_plain_step_plus_transposes(dev):
+    """dig_adamw_step_tr: the plain launch's p / m / v / shadow bit for bit (flat granules and the 64 x 64 tiles of the listed weights),
+    W^T of every listed weight == the transposed shadow, group 2 (a parameter without a gradient) untouched, the non-finite gate a no-op."""
+    import struct
+    from dig_amd import ops
+    mats = [(128, 192), (192, 64), (64, 64)]                      # (rows, cols) of the listed weights, with other parameters between them
+    layout, off = [], 0
+    for k, (r, c) in enumerate(mats):
+        off += 256 * (k + 1)                                      # a few 1-D parameters in front
+        layout.append((off, r, c))
+        off += r * c
+    n = off + 512
+    torch.manual_seed(5)
+    p0, g = torch.randn(n, device=dev), torch.randn(n, device=dev) * 1e-2
+    m0, v0 = torch.randn(n, device=dev) * 1e-3, torch.rand(n, device=dev) * 1e-5
+    flags = torch.zeros(n // 256, dtype=torch.uint8, device=dev)
+    flags[0] = 1
+    flags[-1] = 2                                                 # the last granule: no gradient, untouched
+    hyp = (1e-3, 0.1, 2e-3, 0.0, 0.9, 0.999, 1e-8, 3)
+    p1, m1, v1 = p0.clone(), m0.clone(), v0.clone()
+    sh1 = torch.zeros(n, device=dev, dtype=torch.bfloat16)
+    ops.adamw_step(p1, g, m1, v1, sh1, flags, *hyp, 0.5)
+    assert torch.equal(p1[-256:], p0[-256:]) and torch.equal(m1[-256:], m0[-256:]) and torch.equal(sh1[-256:], p0[-256:].bfloat16())
+    assert not torch.equal(p1[:256], p0[:256])
+    recs, dst, t0, fl = [], 0, 0, flags.clone()
+    for o, r, c in layout:
+        recs.append(struct.pack("<qqiiii", o, dst, r, c, t0, 0))
+        fl[o // 256:(o + r * c) // 256] |= 0x80
+        dst += r * c
+        t0 += (r // 64) * (c // 64)
+    table = torch.frombuffer(bytearray(b"".join(recs)), dtype=torch.uint8).to(dev)
+    p2, m2, v2 = p0.clone(), m0.clone(), v0.clone()
+    sh2 = torch.zeros(n, device=dev, dtype=torch.bfloat16)
+    tr = torch.zeros(dst, device=dev, dtype=torch.bfloat16)
+    ops.adamw_step_tr(p2, g, m2, v2, sh2, fl, *hyp, table, len(layout), t0, tr, 0.5)
+    assert torch.equal(p1, p2) and torch.equal(m1, m2) and torch.equal(v1, v2) and torch.equal(sh1, sh2)
+    d = 0
+    for o, r, c in layout:
+        assert torch.equal(tr[d:d + r * c].view(c, r), sh1[o:o + r * c].view(r, c).t())
+        d += r * c
+    gate = torch.full((1,), float("inf"), device=dev)
+    p3, tr3 = p0.clone(), torch.zeros_like(tr)
+    ops.adamw_step_tr(p3, g, m0.clone(), v0.clone(), sh2, fl, *hyp, table, len(layout), t0, tr3, 0.5, gate)
+    assert torch.equal(p3, p0) and not bool(tr3.any())
 
 
 def test_grad_reduce_batch_equals_single_launches(dev):
