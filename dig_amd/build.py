@@ -82,5 +82,53 @@ def build(force: bool = False, verbose: bool = True) -> str:
     return LIB
 
 
+# ---- the hot kernels of the pre-training step (the families on top of profiles/*_kernel_stats.csv): none may use scratch memory
+HOT_KERNELS = ("mlp_chain_kernel<1, true, false>", "mlp_chain_kernel<2, true, false>", "mlp_chain_kernel<0, true, false>",
+               "wgrad_wide_kernel<3, 7>", "attn_block_kernel<true, 2>", "attn_block_kernel<false, 2>", "attn_bwd_kernel<false>",
+               "gemm_wide_kernel<false, true, 0, 4, 3, 2, 2, false, 64, 2, false>", "gemm_pwide_kernel<4, false, false>")
+LLVM_BIN = os.environ.get("DIG_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
+
+
+def kernel_resources():
+    """[{name (demangled), scratch (private_segment_fixed_size, bytes), vgpr, sgpr, hot}] of every kernel in the built objects."""
+    import re
+    import tempfile
+    rows = []
+    objdir = os.path.join(LIBDIR, "obj")
+    with tempfile.TemporaryDirectory() as tmp:
+        for o in sorted(f for f in os.listdir(objdir) if f.endswith(".o")):
+            fat, dev = os.path.join(tmp, o + ".fat"), os.path.join(tmp, o + ".co")
+            r = subprocess.run([os.path.join(LLVM_BIN, "llvm-objcopy"), f"--dump-section=.hip_fatbin={fat}", os.path.join(objdir, o)], capture_output=True, text=True)
+            if r.returncode != 0 or not os.path.exists(fat):
+                continue                                               # (a host-only object)
+            subprocess.run([os.path.join(LLVM_BIN, "clang-offload-bundler"), "--unbundle", "--type=o", f"--input={fat}",
+                            "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={dev}"], check=True, capture_output=True)
+            notes = subprocess.run([os.path.join(LLVM_BIN, "llvm-readelf"), "--notes", dev], check=True, capture_output=True, text=True).stdout
+            for blk in notes.split("- .agpr_count")[1:]:
+                f = {k: re.search(rf"\.{k}:\s+(\S+)", blk) for k in ("name", "private_segment_fixed_size", "vgpr_count", "sgpr_count")}
+                if not all(f.values()):
+                    continue
+                mangled = f["name"].group(1)
+                try:
+                    dm = subprocess.run(["c++filt", mangled], capture_output=True, text=True).stdout.strip() or mangled
+                except OSError:
+                    dm = mangled
+                short = re.sub(r"^void ", "", dm).replace("(anonymous namespace)::", "")
+                rows.append({"name": short, "object": o, "scratch": int(f["private_segment_fixed_size"].group(1)),
+                             "vgpr": int(f["vgpr_count"].group(1)), "sgpr": int(f["sgpr_count"].group(1)),
+                             "hot": any(short.startswith(h) for h in HOT_KERNELS)})
+    return rows
+
+
+def check_scratch(rows=None, raise_on_fail=True):
+    """Every name of HOT_KERNELS exists in the library and has private_segment_fixed_size == 0.  Returns the offending rows."""
+    rows = kernel_resources() if rows is None else rows
+    missing = [h for h in HOT_KERNELS if not any(r["name"].startswith(h) for r in rows)]
+    bad = [r for r in rows if r["hot"] and r["scratch"] > 0]
+    if raise_on_fail and (bad or missing):
+        raise RuntimeError(f"hot kernels with scratch memory: {[(b['name'][:60], b['scratch']) for b in bad]}; not found: {missing}")
+    return bad + [{"name": m + " (not found)", "scratch": -1} for m in missing]
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv)

@@ -51,6 +51,9 @@
 #ifndef DIG_CHAIN_SIDE_AUX
 #define DIG_CHAIN_SIDE_AUX 2                // cache policy of the online forward's side-output stores (2 = nt)
 #endif
+#ifndef DIG_CHAIN_SDMA
+#define DIG_CHAIN_SDMA 1                  // online forward (MODE 1): the S-waves bring ALL ring pieces, the O-waves -- which issue the side-output stores -- none
+#endif
 #ifndef DIG_CHAIN_PRIO
 #define DIG_CHAIN_PRIO 0                  // 1: S-waves at s_setprio 1, 2: O-waves (static, for the whole kernel)
 #endif
@@ -113,11 +116,23 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(
 // every LDS read below is of that kind (checked in the ISA: no vmcnt(0) inside the tick loops).  LDS writes are inline asm.
 // MODE 0: forward, no side outputs (momentum branch / evaluation);  1: forward + pre-activation and GELU output (online branch:
 // what the backward reads);  2: backward (data gradient through both layers + d(pre-activation) + fc1 bias-gradient partials)
-template <int MODE, bool LN, bool DROP>
+// The third parameter is DROP for the forward forms (dropout / drop-path in the epilogue) and, for MODE 2 -- where there is no dropout: the
+// backward takes the masked gradient as its input -- PROJ: the opt-in projection phase behind norm2's backward (dig_mlp_chain_bwd_ln_proj).
+// Its own instantiation: compiled into the default backward kernel, the phase's 22 spilled registers gave the whole kernel a scratch
+// segment (private_segment_fixed_size 92) that the default path never touched but every wave had set up.
+template <int MODE, bool LN, bool DROP_OR_PROJ>
 __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainParams p) {
-  static_assert(!(DROP && MODE == 2), "dropout: forward forms only (the backward takes the masked gradient as its input)");
+  constexpr bool DROP = DROP_OR_PROJ && MODE != 2;
+  constexpr bool PROJ = DROP_OR_PROJ && MODE == 2;
+  static_assert(!PROJ || LN, "the projection phase follows norm2's backward");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr bool LNB = LN && MODE == 2;                             // backward with norm2's backward in the O-waves' epilogue
+  // VMEM operations retire in issue order on gfx950 (one vmcnt for loads and stores): a wave that waits (counted) for a ring piece it issued
+  // BEHIND its side-output stores waits for those stores' write acknowledgements too -- with every wave bringing a share of the ring, the
+  // O-waves' 8 stores of a period had to be acknowledged within two ticks (~2 us) and the launch ran at its store latency, not its MFMA
+  // rate.  SDMA: the S-waves (which never store in the loop) bring all pieces of both rings, the O-waves wait on no vmcnt in the loop
+  // and their stores drain at the memory system's pace.
+  constexpr bool SDMA = (MODE == 1) && (DIG_CHAIN_SDMA != 0);
   constexpr int LNB_RS = KD * 2 + 16;                               // LNB: row pitch of the data-gradient tile [BM][KD] bf16 at LDS offset 0
   constexpr int LNB_COLRED = BM * LNB_RS;                           //      [8 waves][3][KD] fp32 column sums
   static_assert(!LNB || LNB_COLRED + 8 * 3 * KD * 4 <= X_OFF + 2 * SLOT, "LayerNorm-backward phase: LDS map");
@@ -138,23 +153,31 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainParams p) {
 
 
   // ---- weight rings: per-thread source offsets (the swizzle lives on the source side: LDS-DMA destinations are lane-linear)
-  unsigned v1[2], v2[2], vp[2];
+  // (SDMA: an S-wave also brings the pieces of wave + 4 -- sub = 1: thread tid + 256 of the same image)
+  unsigned v1[4], v2[4], vp[2];                                     // (sized by a constant: `v1[SDMA ? 4 : 2]` made the HOST pass drop every kernel stub of this file, silently)
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
-    const int pc = it * 512 + tid;
-    const int r1 = pc >> 4, c1 = (pc & 15) ^ (r1 & 15);              // B1 slot: [64 f][128 k], 16 chunks of 16 B per row
-    v1[it] = (unsigned)((r1 * KD + 8 * c1) * 2);
-    const int r2 = pc >> 3, c2 = (pc & 7) ^ ((r2 >> 1) & 7);         // B2 slot: [128 j][64 f], 8 chunks per row
-    v2[it] = (unsigned)((r2 * F + 8 * c2) * 2);
-    vp[it] = (unsigned)(((size_t)(m0 + r2) * F + 8 * c2) * 2);       // MODE 2 pre tile: [128 tokens][64 f], same image as P
+#pragma unroll
+    for (int sub = 0; sub < (SDMA ? 2 : 1); ++sub) {
+      const int pc = it * 512 + tid + 256 * sub;
+      const int r1 = pc >> 4, c1 = (pc & 15) ^ (r1 & 15);            // B1 slot: [64 f][128 k], 16 chunks of 16 B per row
+      v1[it + 2 * sub] = (unsigned)((r1 * KD + 8 * c1) * 2);
+      const int r2 = pc >> 3, c2 = (pc & 7) ^ ((r2 >> 1) & 7);       // B2 slot: [128 j][64 f], 8 chunks per row
+      v2[it + 2 * sub] = (unsigned)((r2 * F + 8 * c2) * 2);
+      if (sub == 0) vp[it] = (unsigned)(((size_t)(m0 + r2) * F + 8 * c2) * 2);     // MODE 2 pre tile: [128 tokens][64 f], same image as P
+    }
   }
   auto issue_ring = [&](int slot, unsigned s1, unsigned s2) {
-    unsigned char* d1 = smem + W1_RING + slot * SLOT + wave * 1024;
-    unsigned char* d2 = smem + W2_RING + slot * SLOT + wave * 1024;
+    if (SDMA && wave >= 4) return;
 #pragma unroll
-    for (int it = 0; it < 2; ++it) __builtin_amdgcn_raw_ptr_buffer_load_lds(rB1, LDS_PTR(d1 + it * 8192), 16, v1[it], s1, 0, 0);
+    for (int sub = 0; sub < (SDMA ? 2 : 1); ++sub) {
+      unsigned char* d1 = smem + W1_RING + slot * SLOT + (wave + 4 * sub) * 1024;
+      unsigned char* d2 = smem + W2_RING + slot * SLOT + (wave + 4 * sub) * 1024;
 #pragma unroll
-    for (int it = 0; it < 2; ++it) __builtin_amdgcn_raw_ptr_buffer_load_lds(rB2, LDS_PTR(d2 + it * 8192), 16, v2[it], s2, 0, 0);
+      for (int it = 0; it < 2; ++it) __builtin_amdgcn_raw_ptr_buffer_load_lds(rB1, LDS_PTR(d1 + it * 8192), 16, v1[it + 2 * sub], s1, 0, 0);
+#pragma unroll
+      for (int it = 0; it < 2; ++it) __builtin_amdgcn_raw_ptr_buffer_load_lds(rB2, LDS_PTR(d2 + it * 8192), 16, v2[it + 2 * sub], s2, 0, 0);
+    }
   };
   // Barrier of tick (c, TAU): this wave's DMA pieces of the tick have landed (NW = VMEM operations it has issued behind them), its
   // own LDS traffic is complete.  The DMA for the tick after next (ring slot = position of that tick in its chunk) is then issued
@@ -164,7 +187,11 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainParams p) {
   auto tick_sync = [&](auto tau_tag, auto nw_tag, int c) {
     constexpr int TAU = decltype(tau_tag)::value;
     DIG_CHAIN_T(3)
-    wait_vm<decltype(nw_tag)::value>();
+    if constexpr (SDMA) {
+      if (wave < 4) wait_vm<8>();                                     // (an S-wave's eight pieces of the tick after this one stay in flight)
+    } else {
+      wait_vm<decltype(nw_tag)::value>();
+    }
     DIG_CHAIN_T(0)
     wait_lgkm0();
     __builtin_amdgcn_s_barrier();
@@ -188,8 +215,16 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainParams p) {
     constexpr int TAU = decltype(tau_tag)::value, K = decltype(k_tag)::value;
     constexpr int tn = (TAU + 2) % 3;
     if (DIG_CHAIN_ABL & 2) return;
+    if (SDMA) return;                                                 // (the S-waves' dma_piece8 below brings everything)
     if (K < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rB1, LDS_PTR(smem + W1_RING + tn * SLOT + wave * 1024 + K * 8192), 16, v1[K], dma_s1, 0, 0);
     else __builtin_amdgcn_raw_ptr_buffer_load_lds(rB2, LDS_PTR(smem + W2_RING + tn * SLOT + wave * 1024 + (K - 2) * 8192), 16, v2[K - 2], dma_s2, 0, 0);
+  };
+  auto dma_piece8 = [&](auto tau_tag, auto s_tag) {                   // SDMA, S-waves: piece S (0..7) of the tick = (K = S >> 1, sub = S & 1), one per k-step
+    constexpr int TAU = decltype(tau_tag)::value, S8 = decltype(s_tag)::value, K = S8 >> 1, SUB = S8 & 1;
+    constexpr int tn = (TAU + 2) % 3;
+    if (DIG_CHAIN_ABL & 2) return;
+    if (K < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rB1, LDS_PTR(smem + W1_RING + tn * SLOT + (wave + 4 * SUB) * 1024 + K * 8192), 16, v1[K + 2 * SUB], dma_s1, 0, 0);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rB2, LDS_PTR(smem + W2_RING + tn * SLOT + (wave + 4 * SUB) * 1024 + (K - 2) * 8192), 16, v2[K - 2 + 2 * SUB], dma_s2, 0, 0);
   };
   constexpr int E_ALL = MODE == 2 ? 2 : 0;                            // VMEM operations every wave issues behind the ring DMA of a tick 0
   using T0 = std::integral_constant<int, 0>;
@@ -448,7 +483,8 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainParams p) {
           pairwork(tau_tag, s_tag);
           __builtin_amdgcn_sched_barrier(0);
           if (M1 && !(DIG_CHAIN_ABL & 8)) Sc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[1], __builtin_bit_cast(bf16x8, xf[TAU * KS_PER_TICK + S]), Sc[1], 0, 0, 0);
-          if (S & 1) dma_piece(tau_tag, std::integral_constant<int, (S >> 1)>{});
+          if constexpr (SDMA) dma_piece8(tau_tag, s_tag);
+          else if (S & 1) dma_piece(tau_tag, std::integral_constant<int, (S >> 1)>{});
           if (G && !(DIG_CHAIN_ABL & 1) && MODE == 2 && TAU == 1 && S == 6) colsum_block(0);
           if (G && !(DIG_CHAIN_ABL & 1) && MODE == 2 && TAU == 2 && S == 4) colsum_block(1);
           __builtin_amdgcn_sched_barrier(0);
@@ -909,7 +945,7 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainParams p) {
       for (int w = 0; w < 8; ++w) a += cs[w * (3 * KD) + c];
       p.lnb_ws[(size_t)blockIdx.x * (3 * KD) + c] = a;
     }
-    if (p.projt) {
+    if constexpr (PROJ) {
       // ================================ the attention projection's data gradient on the rows just made =============================
       // dctx[128, KD] = dx_mid[128, KD] Wproj: the tile in LDS holds dx_mid (bf16, what the GEMM launch would read back).  Wave (tg, ch)
       // takes tokens 32 tg .. + 31 and output columns 192 ch .. + 191: its 32 x 384 slice of the tile goes to registers as MFMA
@@ -1156,7 +1192,7 @@ extern "C" int dig_mlp_chain_bwd_ln_proj(const void* dy, const void* w2t, const 
   no_layernorm(p);
   p.ln_g = ln_g; p.lnb_mean = ln_mean; p.lnb_rstd = ln_rstd; p.lnb_ws = ln_partials;
   p.projt = (const bf16_t*)projt; p.proj_out = (bf16_t*)dctx_out;
-  return launch_chain<2, true>(p, stream);
+  return projt ? launch_chain<2, true, true>(p, stream) : launch_chain<2, true>(p, stream);
 }
 
 extern "C" int dig_mlp_chain_bwd_ln(const void* dy, const void* w2t, const void* pre, const void* w1t, void* dpre_out, const void* x_mid,

@@ -107,11 +107,9 @@ class MoCo_ViT(nn.Module):
         self.N = self.gh * self.gw
         self.T = T
         self.num_windows = num_windows
-        if (img_size[1] // patch_size) % num_windows:
-            # the reference pools with adaptive_avg_pool2d, which also takes uneven windows (its argparse default of 5 on a 32-column grid);
-            # the pooling kernel here covers the README recipe (num_windows 4): equal windows only -- say so at construction
-            raise NotImplementedError(f"num_windows={num_windows} does not divide the {img_size[1] // patch_size}-column token grid: "
-                                      "dig_window_pool_fwd / _bwd pool equal windows (README: --num_windows 4)")
+        if not 1 <= num_windows <= img_size[1] // patch_size:
+            raise ValueError(f"num_windows={num_windows}: 1 .. {img_size[1] // patch_size} (the token grid's columns)")
+        # (uneven windows -- the argparse default of 5 on a 32-column grid -- pool with adaptive_avg_pool2d's overlapping bins: dig_window_pool_*)
         self.dec_dim, self.dec_classes = decoder_embed_dim, decoder_num_classes
         self.moco_dim, self.moco_mlp_dim = dim, mlp_dim
         self.ln_eps, self.bn_eps, self.bn_momentum = 1e-6, 1e-5, 0.1

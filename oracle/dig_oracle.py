@@ -384,7 +384,8 @@ def encoder(P, pre, images, mask, cfg: DiGConfig, taps=None):
 def batch_norm_train(x, gamma, beta, S, pre, cfg: DiGConfig, comm, update_buffers=True):
     """nn.BatchNorm1d in train mode; under SyncBatchNorm the statistics are over the rows of all ranks
     (run_mae_pretraining_moco.py:390).  Biased variance normalises; the running buffer gets n/(n-1)."""
-    n_local = x.shape[0]
+    x = x.float()                                                         # (a no-op in fp32; under the tests' bf16-autocast yardstick: batch_norm is an
+    n_local = x.shape[0]                                                  #  fp32 op of torch's autocast too -- E[x^2] - mean^2 from bf16 sums goes negative)
     stats = torch.cat([x.sum(0), (x * x).sum(0), x.new_tensor([float(n_local)])])
     stats = comm.all_reduce_sum(stats)
     C = x.shape[1]

@@ -58,3 +58,13 @@ def test_host_side_argument_validation_needs_no_gpu(lib):
     assert lib.dig_attn_fwd(null, null, null, 1, 6, 384, null) == -1
     lib.dig_layernorm_bwd_workspace_bytes.restype = ctypes.c_longlong
     assert lib.dig_layernorm_bwd_workspace_bytes(65536, 384) == 1024 * 3 * 384 * 4
+
+
+def test_hot_kernels_use_no_scratch():
+    """The kernels that own the step (dig_amd.build.HOT_KERNELS: the top rows of profiles/*_kernel_stats.csv) carry no scratch segment in
+    the built code objects (private_segment_fixed_size == 0: no spilled registers); tools/check_scratch.py prints the table."""
+    from dig_amd import build
+    build.build(verbose=False)
+    rows = build.kernel_resources()
+    assert len(rows) > 150 and sum(1 for r in rows if r["hot"]) >= len(build.HOT_KERNELS)
+    assert build.check_scratch(rows) == []
