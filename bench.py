@@ -28,6 +28,23 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FLOP_PER_SAMPLE = {"small": 99.6e9, "base": 171e9, "tiny": None}      # SURVEY.md §8(d), MIM+MoCo
+ENC_FWD_FLOP = {"small": 12.089e9, "base": 20.951e9, "tiny": None}     # encoder forward per 32x128 image
+# the single-objective factories (modeling_pretrain_moco_mim_ori.py:627-681, 709-763, 818-871): credited work per sample by the same rules --
+# Gen-only: encoder forward + backward of the masked view + the decoder on its 179 masked rows = 3 F + 0.129 G (BASELINE configs[1]'s credit,
+# here without the momentum networks and heads the SimMIM+MoCo model still runs for its meters); Dis-only: online forward + backward and
+# momentum forward of two views + projector / predictor / InfoNCE = 8 F + 1.39 G
+KIND_FACTORY = {"simmim_moco": "pretrain_simmim_moco_ori", "simmim": "pretrain_simmim_ori", "moco": "pretrain_moco_ori"}
+KIND_TEXT = {"simmim": "Gen-only model (use_moco_target=False): encoder + final LayerNorm + SimMIM decoder, MIM loss on the original view",
+             "moco": "Dis-only model (use_pixel_target=False): MoCo-v3 on two unmasked views, no pix_projector, no decoder"}
+
+
+def flop_per_sample(model, kind):
+    if kind == "simmim_moco":
+        return FLOP_PER_SAMPLE[model]
+    f = ENC_FWD_FLOP[model]
+    if f is None:
+        return None
+    return 3 * f + 0.129e9 if kind == "simmim" else 8 * f + 1.39e9
 WORKLOAD_TEXT = {
     "mim_moco": "BASELINE configs[2]'s step on this many GPUs: SimMIM (w=1.0) + MoCo-v3 (w=0.1)",
     "mim_only": "BASELINE configs[1]: loss_weight_contrast=0 (the contrastive forward still runs for the loss_contrast / accuracy meters; "
@@ -341,6 +358,12 @@ def cpu_baseline(model_name, budget_s=20.0):
     except OSError:
         pass
     return {"value": v128 if v128 is not None else v4, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            # the UNMODIFIED reference (engine_for_pretraining_moco.train_one_epoch + MoCo_ViT, fp32, gloo world 1,
+            # the same synthetic generator) timed where it can be imported -- the build container, not this host; reported beside the port
+            "reference_build_container": {"value": 2.24, "unit": "images/sec", "cores": 8, "batch": 128, "steps": 2, "seconds_per_step": 57.2,
+                                          "batch_4": {"value": 2.0, "seconds_per_step": 2.02, "steps": 3},
+                                          "host_cpu": "8 vCPU Intel Xeon (family 6 model 207, 2.1 GHz, AVX-512), torch 2.10.0 CPU, 8 threads",
+                                          "source": "BASELINE.md section 2 (survey-time run of the reference through oracle/ref_harness)"},
             "host_cpu": cpu_model, "host_logical_cpus": os.cpu_count(),
             "batch_128": {"value": v128, "steps": n128, "seconds": t128}, "batch_4": {"value": v4, "steps": n4, "seconds": t4},
             "thread_sweep_batch16": {str(k): round(v, 2) for k, v in sweep.items()},
@@ -376,6 +399,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=128, help="samples per GPU")
     ap.add_argument("--model", default="small", choices=["tiny", "small", "base"])
+    ap.add_argument("--model-kind", default="simmim_moco", choices=["simmim_moco", "simmim", "moco"],
+                    help="simmim_moco = the headline model (pretrain_simmim_moco_ori_*); simmim / moco = the reference's single-objective "
+                         "factories (pretrain_simmim_ori_* Gen-only, pretrain_moco_ori_* Dis-only): their own JSON line, not the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mim-only", action="store_true", help="skip the extra measurement of the other workload")
     ap.add_argument("--workload", default="mim_moco", choices=["mim_moco", "mim_only"],
@@ -410,7 +436,9 @@ def main():
     dev = torch.device("cuda", dargs.gpu)
     torch.cuda.set_device(dev)
     torch.manual_seed(0 + rank)
-    model_name = f"pretrain_simmim_moco_ori_vit_{a.model}_patch4_32x128"
+    model_name = f"{KIND_FACTORY[a.model_kind]}_vit_{a.model}_patch4_32x128"
+    if a.model_kind != "simmim_moco":
+        a.no_mim_only = True                          # (one objective: there is no "other workload" of the same model)
     model = create_model(model_name, pretrained=False, drop_path_rate=0.0, drop_block_rate=None, mlp_dim=4096, dim=256, T=0.2,
                          num_windows=4, encoder_type='vit', queue_size=65536, patchnet_name='no_patchtrans')
     model.to(dev)
@@ -606,14 +634,16 @@ def main():
     if rank != 0:
         return
     value = a.steps * B * world / dt
-    fl = FLOP_PER_SAMPLE[a.model]
+    fl = flop_per_sample(a.model, a.model_kind)
+    if a.model_kind != "simmim_moco":
+        WORKLOAD_TEXT[a.workload] = KIND_TEXT[a.model_kind]
     line = {"metric": "pretrain images/sec (32x128, 2-view, mask 0.7) ViT-S/4", "value": value, "unit": "images/sec",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{model_name}: full train_one_epoch step, {WORKLOAD_TEXT[a.workload]}; dim 256, mlp 4096, m 0.99 cos, "
                                    f"T 0.2, 4 windows, mask 0.7, 2 views, AdamW wd 0.1, {B} samples/GPU, random-init weights",
                        "global_batch": B * world, "parallelism": f"dp{world}", "loss": float(stats.get("loss", float('nan')))},
-            "step_mfma_frac": (value / world * fl / PEAK_BF16) if fl else None,
+            "step_mfma_frac": (value / world * fl / PEAK_BF16) if fl else None, "flop_per_sample": fl,
             # the whole step against the HBM roof: PMC-measured bytes of every kernel family per step (profiles/r05_pmc_traffic.json,
             # same kernel sources) / step time / 8 TB/s -- the roof that actually prices this model width
             "step_hbm_frac": (roof["step_hbm_bytes"] / (dt / a.steps) / PEAK_HBM) if roof and roof.get("step_hbm_bytes") and B == 128 and a.model == "small" and a.workload == "mim_moco" else None,

@@ -52,7 +52,11 @@
 #define DIG_CHAIN_SIDE_AUX 2                // cache policy of the online forward's side-output stores (2 = nt)
 #endif
 #ifndef DIG_CHAIN_SDMA
-#define DIG_CHAIN_SDMA 1                  // online forward (MODE 1): the S-waves bring ALL ring pieces, the O-waves -- which issue the side-output stores -- none
+#define DIG_CHAIN_SDMA 0                  // lab (round 6): 1 = online forward (MODE 1) with the S-waves bringing ALL ring pieces and the O-waves -- which issue the
+                                          // side-output stores -- none.  Measured (tools/experiments/r06_sdma_ab.sh, profiles/r06_chain_sdma_lab.txt): 209.0 us
+                                          // against 201.9 (bare form), 231.7 against 223.7 (product form) -- the O-waves' counted waits were never the cost
+                                          // (11 k of 172 k cycles): the side outputs cost what they add to BOTH roles' work (O: 8 LDS reads + 8 KiB-stores per
+                                          // period on a 64 B/clk path shared by the CU; S: the second tile's packs and LDS writes) under one barrier per tick
 #endif
 #ifndef DIG_CHAIN_PRIO
 #define DIG_CHAIN_PRIO 0                  // 1: S-waves at s_setprio 1, 2: O-waves (static, for the whole kernel)
@@ -127,11 +131,9 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainParams p) {
   static_assert(!PROJ || LN, "the projection phase follows norm2's backward");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr bool LNB = LN && MODE == 2;                             // backward with norm2's backward in the O-waves' epilogue
-  // VMEM operations retire in issue order on gfx950 (one vmcnt for loads and stores): a wave that waits (counted) for a ring piece it issued
-  // BEHIND its side-output stores waits for those stores' write acknowledgements too -- with every wave bringing a share of the ring, the
-  // O-waves' 8 stores of a period had to be acknowledged within two ticks (~2 us) and the launch ran at its store latency, not its MFMA
-  // rate.  SDMA: the S-waves (which never store in the loop) bring all pieces of both rings, the O-waves wait on no vmcnt in the loop
-  // and their stores drain at the memory system's pace.
+  // Lab switch (off): VMEM operations retire in issue order on gfx950 (one vmcnt for loads and stores), so a wave that waits (counted) for a ring
+  // piece it issued BEHIND its side-output stores also waits for those stores' acknowledgements.  SDMA lets the S-waves (which never store in
+  // the loop) bring all pieces of both rings; the O-waves then wait on no vmcnt in the loop.  Measured: no gain (see DIG_CHAIN_SDMA above).
   constexpr bool SDMA = (MODE == 1) && (DIG_CHAIN_SDMA != 0);
   constexpr int LNB_RS = KD * 2 + 16;                               // LNB: row pitch of the data-gradient tile [BM][KD] bf16 at LDS offset 0
   constexpr int LNB_COLRED = BM * LNB_RS;                           //      [8 waves][3][KD] fp32 column sums

@@ -950,8 +950,8 @@ class _Step:
         self.enc, mu, rs = ops.layernorm_fwd(enc_raw, f32["encoder.norm.weight"], f32["encoder.norm.bias"], M.ln_eps)
         self.saved_norm = (enc_raw, mu, rs)
         vis_out = self._decoder_forward(mask_u8, images, mim_views)
-        zero = torch.zeros(5, device=dev, dtype=F32)                    # (no 'contra_loss' / accuracy keys for a Gen-only model: dig_forward)
-        return zero[0], zero[1:], vis_out
+        # (no 'contra_loss' / accuracy keys for a Gen-only model: dig_forward drops these two; an operator's outputs must not alias each other)
+        return torch.zeros((), device=dev, dtype=F32), torch.zeros(4, device=dev, dtype=F32), vis_out
 
     # ------------------------------------------------------------------ full backward
     def backward(self, g_contra, g_vis):
