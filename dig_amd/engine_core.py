@@ -168,9 +168,22 @@ class _Step:
         self.comm = model.comm or LOCAL
 
     # ------------------------------------------------------------------ encoder
-    def encoder_forward(self, ew, images, aug, mask_u8, save, views=2):
+    def _path_specs(self, plan, site_off):
+        """[(attention-branch DropSpec, MLP-branch DropSpec) or None per block] for stochastic depth under `plan` (dropout.DropPlan)."""
+        from . import dropout as DR
+        M = self.m
+        out = []
+        for i, p in enumerate(M.dpr):
+            if not p:
+                out.append(None)
+                continue
+            out.append((plan.spec(0, 0.0, path_site=DR.enc_site(i + site_off, 2), path_p=p, rows_per_sample=M.N),
+                        plan.spec(0, 0.0, path_site=DR.enc_site(i + site_off, 4), path_p=p, rows_per_sample=M.N)))
+        return out
+
+    def encoder_forward(self, ew, images, aug, mask_u8, save, views=2, path=None):
         """views = 1: the encoder over `images` only (Gen-only models with only_mim_on_ori_img: the samples of a ViT batch are independent, and
-        nothing downstream reads the augmented view's rows)."""
+        nothing downstream reads the augmented view's rows).  path: per-block stochastic-depth specs (_path_specs) or None."""
         M = self.m
         B, D, H, N = images.shape[0], M.D, M.H, M.N
         R = views * B * N
@@ -184,12 +197,13 @@ class _Step:
         chain = ops.mlp_chain_supported(D, M.F, R) and bool(ops.MLP_CHAIN_MASK & (2 if save else 1))
         chain_ln = chain and ops.MLP_CHAIN_LN and M.F <= 2048
         nxt = None                                                      # (ln1, mean, rstd) of this block, made by the previous block's launch
-        if chain_ln and ops.BLOCK_CALLS and D == H * 64:
+        if chain_ln and ops.BLOCK_CALLS and D == H * 64 and path is None:
             return self._encoder_forward_calls(ew, x, views * B, save, single_view=views == 1)
         for i, blk in enumerate(ew.blocks):
             ln1, mu1, rs1 = nxt if nxt is not None else ops.layernorm_fwd(x, blk["norm1.weight"], blk["norm1.bias"], M.ln_eps)
             nxt = None
-            fused_attn = ops.attn_block_supported(H, D, B if views == 1 else None)
+            ds = path[i] if path is not None else None                 # x + drop_path(branch): per-sample keep / scale in the producing epilogue
+            fused_attn = ops.attn_block_supported(H, D, B if views == 1 else None) and ds is None
             if fused_attn:
                 # qkv Linear -> attention -> proj Linear + residual in one launch (csrc/attn_block.hip); qkv / lse exist only where kept
                 x_mid, ctx, qkv, lse = ops.attn_block_fwd(ln1, x, blk["attn.qkv.weight"], blk["qkv_bias"], blk["attn.proj.weight"],
@@ -203,10 +217,10 @@ class _Step:
                 # the way into the MLP launch
                 nb = ew.blocks[i + 1] if i + 1 < len(ew.blocks) else None
                 if not fused_attn:
-                    x_mid = ops.linear_fwd(ctx, blk["attn.proj.weight"], bias=blk["attn.proj.bias"], resid=x)
+                    x_mid = ops.linear_fwd(ctx, blk["attn.proj.weight"], bias=blk["attn.proj.bias"], resid=x, drop=ds[0] if ds else None)
                 r = ops.mlp_chain_fwd_ln(x_mid, blk["norm2.weight"], blk["norm2.bias"], M.ln_eps, blk["mlp.fc1.weight"], blk["mlp.fc1.bias"],
                                          blk["mlp.fc2.weight"], blk["mlp.fc2.bias"], nb["norm1.weight"] if nb else None,
-                                         nb["norm1.bias"] if nb else None, save=save)
+                                         nb["norm1.bias"] if nb else None, save=save, drop=ds[1] if ds else None)
                 ln2, mu2, rs2 = r["ln"], r["ln_mean"], r["ln_rstd"]
                 if save:
                     saved.append((x, ln1, mu1, rs1, qkv, ctx, lse, x_mid, ln2, mu2, rs2, r["pre"], r["act"]))
@@ -215,9 +229,9 @@ class _Step:
                 x = r["out"]
                 continue
             if not fused_attn:
-                x_mid = ops.linear_fwd(ctx, blk["attn.proj.weight"], bias=blk["attn.proj.bias"], resid=x)
+                x_mid = ops.linear_fwd(ctx, blk["attn.proj.weight"], bias=blk["attn.proj.bias"], resid=x, drop=ds[0] if ds else None)
             ln2, mu2, rs2 = ops.layernorm_fwd(x_mid, blk["norm2.weight"], blk["norm2.bias"], M.ln_eps)
-            if chain:
+            if chain and ds is None:
                 # fc1 -> GELU -> fc2 (+ residual) in one launch: the [R, F] hidden tensor is never a GEMM operand in HBM; the online
                 # branch still writes the pre-activation and the GELU output (the backward's inputs), the momentum branch nothing
                 if save:
@@ -229,7 +243,7 @@ class _Step:
             else:
                 pre = torch.empty((R, M.F), device=x.device, dtype=BF16) if save else None
                 act = ops.linear_fwd(ln2, blk["mlp.fc1.weight"], bias=blk["mlp.fc1.bias"], act=1, pre=pre)
-                x_out = ops.linear_fwd(act, blk["mlp.fc2.weight"], bias=blk["mlp.fc2.bias"], resid=x_mid)
+                x_out = ops.linear_fwd(act, blk["mlp.fc2.weight"], bias=blk["mlp.fc2.bias"], resid=x_mid, drop=ds[1] if ds else None)
             if save:
                 saved.append((x, ln1, mu1, rs1, qkv, ctx, lse, x_mid, ln2, mu2, rs2, pre, act))
             x = x_out
@@ -504,8 +518,9 @@ class _Step:
         Rg = (B * N) if views == 1 else (2 * B * N)
         grouped = (ops.WGRAD_GROUP and WGRAD_GROUPING != "off" and
                    all(ops.wgrad_group_route(o, i_, Rg) is not None for o, i_ in ((M.F, D), (D, M.F), (3 * D, D), (D, D))))
+        path = getattr(self, "path_on", None)
         if (grouped and chain_any and ops.BLOCK_CALLS and WGRAD_INLINE and WGRAD_GROUPING == "block" and CHAIN_BWD_EVERY == 1 and FUSED_QV_BIAS_SUMS
-                and not BATCH_REDUCE and PHASE_MARKS is None and all(isinstance(s_, _BlockSaved) for s_ in saved) and dx.is_contiguous()):
+                and path is None and not BATCH_REDUCE and PHASE_MARKS is None and all(isinstance(s_, _BlockSaved) for s_ in saved) and dx.is_contiguous()):
             plan = ops.wgrad_block_plan(dev, Rg, D, M.F)
             if plan is not None:
                 dx = self._encoder_backward_calls(ew, saved, dx, wT, plan, B if views == 1 else 2 * B, Rg)
@@ -551,15 +566,25 @@ class _Step:
                     if not grp.add(dy_, x_, dw_):                    # (never inside an assert: python -O would drop the weight gradient)
                         raise RuntimeError("grouped weight gradient: a problem of this block does not fit the group's plan")
                     held.extend((dy_, x_))
-                wg(dx, act, g["mlp.fc2.weight"])
+            # stochastic depth: a dropped branch back-propagates the residual gradient under the same per-sample mask (dz); its bias gradient is
+            # the column sum of the MASKED gradient, so the LayerNorm kernel's fused residual column sum is switched off for it
+            ds = path[i] if path is not None else None
+            dz = ops.dropout_apply(dx, ds[1]) if ds else dx
+            if ds:
+                on_side(lambda dz=dz: ops.colsum(dz, g["mlp.fc2.bias"]), dz)
+            if grp:
+                wg(dz, act, g["mlp.fc2.weight"])
             else:
-                on_side(lambda: wg(dx, act, g["mlp.fc2.weight"]), dx, act)
+                on_side(lambda dz=dz: wg(dz, act, g["mlp.fc2.weight"]), dz, act)
             if chain:
                 # data gradient through fc2, GELU' and fc1 in one launch (d(pre-activation) leaves it as a side output for the fc1
                 # weight gradient, with its column sums = the fc1 bias gradient)
                 w2t, w1t, projt = wT[i]
                 dctx = None
-                if ops.MLP_CHAIN_LNB and red is None and ops.MLP_CHAIN_PROJ:
+                if ds:
+                    dln2, dact, bparts = ops.mlp_chain_bwd(dz, w2t, pre, w1t)
+                    lnp = None
+                elif ops.MLP_CHAIN_LNB and red is None and ops.MLP_CHAIN_PROJ:
                     dx_mid, dact, bparts, lnp, dctx = ops.mlp_chain_bwd_ln(dx, w2t, pre, w1t, x_mid, blk["norm2.weight"], mu2, rs2, projt=projt)
                     dln2 = dx_mid
                 elif ops.MLP_CHAIN_LNB and red is None:
@@ -572,7 +597,7 @@ class _Step:
                     lnp = None
                 _mark("blk: fused MLP backward", dev)
             else:
-                dact, bparts = ops.linear_dgrad(dx, blk["mlp.fc2.weight"], gelu_pre=pre, colsum=True)   # d(pre-activation): GELU' and
+                dact, bparts = ops.linear_dgrad(dz, blk["mlp.fc2.weight"], gelu_pre=pre, colsum=True)   # d(pre-activation): GELU' and
                 dln2 = None                                                                              # the fc1 bias sums fused
             if grp:
                 wg(dact, ln2, g["mlp.fc1.weight"])
@@ -587,19 +612,22 @@ class _Step:
                 side_later(lambda lnp=lnp, g=g: ops.layernorm_finalize_parts(lnp, g["norm2.weight"], g["norm2.bias"], g["mlp.fc2.bias"]), lnp)
             else:
                 dx_mid, fin2, ws2 = ops.layernorm_bwd(dln2, x_mid, blk["norm2.weight"], blk["norm2.bias"], mu2, rs2, dx, g["norm2.weight"],
-                                                      g["norm2.bias"], out=dln2, dres_colsum=g["mlp.fc2.bias"], defer=True)
+                                                      g["norm2.bias"], out=dln2, dres_colsum=None if ds else g["mlp.fc2.bias"], defer=True)
                 if red:                                                       # norm2 grads + colsum(dx) = fc2 bias grad: off the chain
-                    red.layernorm_finalize(ws2, x_mid.shape[0], D, g["norm2.weight"], g["norm2.bias"], g["mlp.fc2.bias"])
+                    red.layernorm_finalize(ws2, x_mid.shape[0], D, g["norm2.weight"], g["norm2.bias"], None if ds else g["mlp.fc2.bias"])
                 else:
                     side_later(fin2, ws2)
             # x_mid = x + proj(attn(ln1))
+            dzp = ops.dropout_apply(dx_mid, ds[0]) if ds else dx_mid
+            if ds:
+                on_side(lambda dzp=dzp: ops.colsum(dzp, g["attn.proj.bias"]), dzp)
             if grp:
-                wg(dx_mid, ctx, g["attn.proj.weight"])
+                wg(dzp, ctx, g["attn.proj.weight"])
             else:
-                on_side(lambda: wg(dx_mid, ctx, g["attn.proj.weight"]), dx_mid, ctx)
+                on_side(lambda dzp=dzp: wg(dzp, ctx, g["attn.proj.weight"]), dzp, ctx)
             _mark("blk: LayerNorm backward (norm2)", dev)
             if not chain or dctx is None:
-                dctx = ops.linear_dgrad(dx_mid, blk["attn.proj.weight"])
+                dctx = ops.linear_dgrad(dzp, blk["attn.proj.weight"])
             _mark("blk: proj data gradient", dev)
             gb = g["qkv_bias"]
             if FUSED_QV_BIAS_SUMS:
@@ -628,17 +656,17 @@ class _Step:
             dln1 = ops.linear_dgrad(dqkv, blk["attn.qkv.weight"], out=dctx)
             _mark("blk: qkv data gradient", dev)
             dx, fin1, ws1 = ops.layernorm_bwd(dln1, x, blk["norm1.weight"], blk["norm1.bias"], mu1, rs1, dx_mid, g["norm1.weight"],
-                                              g["norm1.bias"], out=dln1, dres_colsum=g["attn.proj.bias"], defer=True)
+                                              g["norm1.bias"], out=dln1, dres_colsum=None if ds else g["attn.proj.bias"], defer=True)
             _mark("blk: LayerNorm backward (norm1)", dev)
             if red:                                                           # norm1 grads + colsum(dx_mid) = proj bias grad
-                red.layernorm_finalize(ws1, x.shape[0], D, g["norm1.weight"], g["norm1.bias"], g["attn.proj.bias"])
+                red.layernorm_finalize(ws1, x.shape[0], D, g["norm1.weight"], g["norm1.bias"], None if ds else g["attn.proj.bias"])
                 side_later(red.flush, *red.tensors())
             else:
                 side_later(fin1, ws1)
             if late:
                 fns = list(late)
                 on_side(lambda: [f() for f in fns], *late_t)
-            del dact, pre, act, dln2, dqkv, dctx, held, late, late_t
+            del dact, pre, act, dln2, dqkv, dctx, held, late, late_t, dz, dzp
             self._mark_kept(dev)
             self._release_kept(dev)
             # this block's gradients are final once BOTH streams pass this point: the bucket's all-reduce is issued from the
@@ -777,6 +805,13 @@ class _Step:
         fresh = M.weights_fresh() and not torch.cuda.is_current_stream_capturing()
         if not fresh:
             ops.cast_f32_to_bf16(M._flat["online"], M.shadow("online"))
+        # stochastic depth (--drop_path): this step's keys; the online encoder's specs are kept for the backward
+        self.path_on = self.path_mo = None
+        if M.drop_path_rate > 0 and M.training:
+            from . import dropout as DR
+            plan = DR.DropPlan(M.drop_seed, M.drop_step)
+            M.drop_step += 1
+            self.path_on, self.path_mo = self._path_specs(plan, 0), self._path_specs(plan, 64)
         if not M.use_moco_target:
             return self._forward_gen_only(ew_on, images, aug, mask_u8, mim_views, training, fresh)
         # ---- momentum branch (no grad) on a second HIP stream: it depends only on the pre-step online weights (fp32
@@ -812,7 +847,7 @@ class _Step:
                 # K-contiguous copies of the online MLP weights for the fused backward: two launches, in front of the momentum encoder
                 # (they read nothing but this step's bf16 weight shadow)
                 self.wT = self.mlp_weight_transposes(ew_on, fresh)
-            enc_m, _ = self.encoder_forward(ew_mo, images, aug, mask_u8, False)
+            enc_m, _ = self.encoder_forward(ew_mo, images, aug, mask_u8, False, path=self.path_mo)
             return enc_m, (momentum_heads(enc_m) if heads else None)
 
         def decoder():
@@ -831,7 +866,7 @@ class _Step:
             hi_st = M._side_stream(dev)
             hi_st.wait_stream(main)
             with torch.cuda.stream(hi_st):
-                enc, self.saved_enc = self.encoder_forward(ew_on, images, aug, mask_u8, True)
+                enc, self.saved_enc = self.encoder_forward(ew_on, images, aug, mask_u8, True, path=self.path_on)
                 self.enc = enc
                 qs = online_heads(enc)
             # (Measured and not kept, round 4: the SimMIM decoder right behind the online heads instead of after the join: 21.06 vs 21.07 ms.)
@@ -846,7 +881,7 @@ class _Step:
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 enc_m, ks = momentum_branch(heads=not dist_mode)
-            enc, self.saved_enc = self.encoder_forward(ew_on, images, aug, mask_u8, True)
+            enc, self.saved_enc = self.encoder_forward(ew_on, images, aug, mask_u8, True, path=self.path_on)
             self.enc = enc
             if not dist_mode:
                 qs = online_heads(enc)
@@ -945,7 +980,7 @@ class _Step:
         self.wT = None
         if training and ops.mlp_chain_supported(M.D, M.F, views * self.B * M.N) and (ops.MLP_CHAIN_MASK & 4):
             self.wT = self.mlp_weight_transposes(ew_on, fresh)
-        enc_raw, self.saved_enc = self.encoder_forward(ew_on, images, aug, mask_u8, True, views=views)
+        enc_raw, self.saved_enc = self.encoder_forward(ew_on, images, aug, mask_u8, True, views=views, path=self.path_on)
         f32 = M._f32
         self.enc, mu, rs = ops.layernorm_fwd(enc_raw, f32["encoder.norm.weight"], f32["encoder.norm.bias"], M.ln_eps)
         self.saved_norm = (enc_raw, mu, rs)

@@ -92,8 +92,9 @@ class MoCo_ViT(nn.Module):
             raise NotImplementedError("use_pix_projector=False (no factory of the reference sets it) is not built")
         if patchnet_name != 'no_patchtrans' and use_moco_target:
             raise NotImplementedError("only patchnet_name='no_patchtrans' (the README configuration) is implemented")
-        if drop_rate or attn_drop_rate or drop_path_rate or init_values or use_learnable_pos_emb or label_smoothing:
-            raise NotImplementedError("dropout / drop-path / layer-scale / learnable pos-emb / label smoothing are 0 in pre-training")
+        if drop_rate or attn_drop_rate or init_values or use_learnable_pos_emb or label_smoothing:
+            raise NotImplementedError("dropout / layer-scale / learnable pos-emb / label smoothing are 0 in pre-training (no flag of "
+                                      "run_mae_pretraining_moco.py sets them)")
         if not qkv_bias or patch_size != 4 or in_chans != 3:
             raise NotImplementedError("qkv_bias=True, patch 4, RGB only")
         D, H = encoder_embed_dim, encoder_num_heads
@@ -102,6 +103,13 @@ class MoCo_ViT(nn.Module):
         if tuple(img_size) != (32, 128):
             raise NotImplementedError("attention kernel is specialised for 8x32 = 256 tokens (32x128 crops)")
         self.D, self.H, self.depth = D, H, encoder_depth
+        # --drop_path (run_mae_pretraining_moco.py:87,283): stochastic depth, rate linspace(0, rate, depth)[i] on both branches of block i of
+        # BOTH encoders (modeling_pretrain_vit.py:50-56; the momentum encoder runs in train mode too).  Masks: keyed counter hash per (step,
+        # site) as in the fine-tune step (dig_amd/dropout.py); drop_seed / drop_step travel in checkpoints (utils.save_model).
+        self.drop_path_rate = float(drop_path_rate)
+        self.dpr = [x.item() for x in torch.linspace(0, self.drop_path_rate, encoder_depth)]
+        self.drop_seed = torch.initial_seed()
+        self.drop_step = 0
         self.F = int(D * mlp_ratio)
         self.gh, self.gw = img_size[0] // patch_size, img_size[1] // patch_size
         self.N = self.gh * self.gw

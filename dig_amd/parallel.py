@@ -66,6 +66,9 @@ class DistributedDataParallel(torch.nn.Module):
         super().__init__()
         self.module = module
         module.comm = DistComm(process_group)
+        if getattr(module, "drop_path_rate", 0.0):
+            # stochastic-depth mask keys: every rank draws its own (the reference seeds torch with seed + rank, run_mae_pretraining_moco.py:313)
+            module.drop_seed = (int(module.drop_seed) + 0x9E3779B97F4A7C15 * module.comm.rank) & ((1 << 64) - 1)
         if broadcast:
             for k in ("online", "momentum", "bn_stats", "bn_count"):
                 dist.broadcast(module._flat[k], src=0, group=process_group)

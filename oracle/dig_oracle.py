@@ -352,18 +352,26 @@ def attention(x, P, pre, cfg: DiGConfig, taps=None):
     return F.linear(o, P[pre + "proj.weight"], P[pre + "proj.bias"])
 
 
-def block(x, P, pre, cfg: DiGConfig, taps=None):
-    """Block.forward with init_values=0 (no layer scale), drop_path=0: modeling_finetune.py:150-158."""
-    x = x + attention(layer_norm(x, P[pre + "norm1.weight"], P[pre + "norm1.bias"], cfg.ln_eps), P, pre + "attn.", cfg, taps)
+MOMENTUM_SITE_OFFSET = 64        # drop-path sites of the momentum encoder's block i: those of block i + 64 (its own, independent draws)
+
+
+def block(x, P, pre, cfg: DiGConfig, taps=None, path=None):
+    """Block.forward with init_values=0 (no layer scale): modeling_finetune.py:150-158.  path: None (drop_path = 0, the README recipe) or
+    (attention-branch mask fn, MLP-branch mask fn) -- `x + self.drop_path(...)` with the per-sample keep / scale of timm's drop_path."""
+    pa, pm = path if path is not None else ((lambda t: t), (lambda t: t))
+    x = x + pa(attention(layer_norm(x, P[pre + "norm1.weight"], P[pre + "norm1.bias"], cfg.ln_eps), P, pre + "attn.", cfg, taps))
     h = F.linear(layer_norm(x, P[pre + "norm2.weight"], P[pre + "norm2.bias"], cfg.ln_eps),
                  P[pre + "mlp.fc1.weight"], P[pre + "mlp.fc1.bias"])
     h = F.gelu(h)                                                         # nn.GELU() exact erf, :43-60
-    return x + F.linear(h, P[pre + "mlp.fc2.weight"], P[pre + "mlp.fc2.bias"])
+    return x + pm(F.linear(h, P[pre + "mlp.fc2.weight"], P[pre + "mlp.fc2.bias"]))
 
 
-def encoder(P, pre, images, mask, cfg: DiGConfig, taps=None):
+def encoder(P, pre, images, mask, cfg: DiGConfig, taps=None, drop=None):
     """PretrainVisionTransformerEncoder.forward_features, modeling_pretrain_vit.py:89-106 (norm/head = Identity,
-    modeling_pretrain_moco_mim_ori.py:362-363).  mask: bool [Bn, N] (True = replaced by mask_token)."""
+    modeling_pretrain_moco_mim_ori.py:362-363).  mask: bool [Bn, N] (True = replaced by mask_token).
+    drop: None, or a finetune_oracle.DropOracle (--drop_path > 0, run_mae_pretraining_moco.py:87: stochastic depth with rate
+    linspace(0, rate, depth)[i] on both branches of block i, modeling_pretrain_vit.py:50-56; keyed masks as the device draws them --
+    the momentum encoder, which the reference also runs in train mode, draws its own under the sites of block i + 64)."""
     w = P[pre + "patch_embed.proj.weight"]
     x = patchify_cpp(images, cfg.patch) @ w.reshape(w.shape[0], -1).t() + P[pre + "patch_embed.proj.bias"]
     if mask is not None:
@@ -373,7 +381,12 @@ def encoder(P, pre, images, mask, cfg: DiGConfig, taps=None):
     if taps is not None:
         taps[pre + "embed"] = x
     for i in range(cfg.depth):
-        x = block(x, P, f"{pre}blocks.{i}.", cfg, taps)
+        path = None
+        if drop is not None and drop.dpr[i]:
+            import finetune_oracle as FO
+            j = i + (MOMENTUM_SITE_OFFSET if pre.startswith("momentum_") else 0)
+            path = (lambda t, j=j, i=i: drop.path(FO.enc_site(j, 2), t, drop.dpr[i]), lambda t, j=j, i=i: drop.path(FO.enc_site(j, 4), t, drop.dpr[i]))
+        x = block(x, P, f"{pre}blocks.{i}.", cfg, taps, path)
         if taps is not None:
             taps[f"{pre}blocks.{i}"] = x
     if not cfg.use_moco:                                                  # x = self.norm(x), modeling_pretrain_vit.py:104 (Gen-only)
@@ -460,7 +473,7 @@ def ema_update(P, m: float):
 
 
 def model_forward(P, S, images, aug_images, mask, m: float, cfg: DiGConfig, comm=None,
-                  only_mim_on_ori_img: bool = True, taps=None, do_ema: bool = True):
+                  only_mim_on_ori_img: bool = True, taps=None, do_ema: bool = True, drop=None):
     """MoCo_ViT.forward, modeling_pretrain_moco_mim_ori.py:488-577.  mask: bool [B, num_view, N] (ignored by the Dis-only models:
     `if not self.use_pixel_target: vis_mask_pos = None`, :493-494)."""
     comm = comm or LocalComm()
@@ -470,7 +483,7 @@ def model_forward(P, S, images, aug_images, mask, m: float, cfg: DiGConfig, comm
     allim = torch.cat([images, aug_images], 0)
     num_view = mask.shape[1]
     mflat = mask.permute(1, 0, 2).reshape(-1, N) if cfg.use_pixel else None     # rows 0..B-1 = view 0 (:497)
-    enc = encoder(P, "encoder.", allim, mflat, cfg, taps)
+    enc = encoder(P, "encoder.", allim, mflat, cfg, taps, drop)
     has_pp = "pix_projector." in specs                                    # hasattr(self, 'pix_projector'), :500
     out = {}
     if cfg.use_moco:
@@ -487,7 +500,7 @@ def model_forward(P, S, images, aug_images, mask, m: float, cfg: DiGConfig, comm
         with torch.no_grad():
             if do_ema:
                 ema_update(P, m)
-            enc_m = encoder(P, "momentum_encoder.", allim, mflat, cfg)
+            enc_m = encoder(P, "momentum_encoder.", allim, mflat, cfg, drop=drop)
             if has_pp:
                 masked_m = bn_mlp(enc_m[:B].reshape(B * N, D), P, S, "pix_projector_m.", specs["pix_projector_m."], cfg, comm)
                 feat_m = torch.cat([masked_m.reshape(B, N, D), enc_m[B:]], 0)
@@ -624,6 +637,8 @@ class StepHyper:
     eps: float = 1e-8
     only_mim_on_ori_img: bool = True
     clip_grad: Optional[float] = None
+    drop_path: float = 0.0            # --drop_path (run_mae_pretraining_moco.py:87); masks keyed by (drop_seed, step): finetune_oracle.DropOracle
+    drop_seed: int = 0
 
 
 class OracleTrainer:
@@ -647,8 +662,12 @@ class OracleTrainer:
         for n in train:
             self.P[n].requires_grad_(True)
             self.P[n].grad = None
+        drop = None
+        if hp.drop_path:
+            import finetune_oracle as FO
+            drop = FO.DropOracle(hp.drop_seed, self.step_count, drop_path=hp.drop_path, depth=cfg.depth)
         out = model_forward(self.P, self.S, images, aug_images, mask, hp.moco_m, cfg, self.comm,
-                            hp.only_mim_on_ori_img, taps)
+                            hp.only_mim_on_ori_img, taps, drop=drop)
         nv = 1 if hp.only_mim_on_ori_img else mask_f.shape[1]
         # engine_for_pretraining_moco.py:119-144: each term only `if '<key>' in out_dict` (the single-objective models leave one out)
         loss = 0.0

@@ -33,10 +33,10 @@ def sample_index(numel: int, k: int = 8):
     return (np.arange(k, dtype=np.int64) * 2654435761 + 12345) % numel
 
 
-def build_ref_model(cfg: O.DiGConfig):
+def build_ref_model(cfg: O.DiGConfig, drop_path: float = 0.0):
     import torch.nn as nn
     import modeling_pretrain_moco_mim_ori as M
-    return M.MoCo_ViT(img_size=(cfg.img_h, cfg.img_w), patch_size=cfg.patch, encoder_embed_dim=cfg.embed_dim,
+    return M.MoCo_ViT(drop_path_rate=drop_path, img_size=(cfg.img_h, cfg.img_w), patch_size=cfg.patch, encoder_embed_dim=cfg.embed_dim,
                       encoder_depth=cfg.depth, encoder_num_heads=cfg.heads, encoder_num_classes=0,
                       decoder_num_classes=cfg.dec_classes, decoder_embed_dim=cfg.dec_dim, decoder_depth=4,
                       decoder_num_heads=3, mlp_ratio=cfg.mlp_ratio, qkv_bias=True,
@@ -82,12 +82,42 @@ class ScalerCPU:
         return d
 
 
+def patch_drop_paths(model, holder):
+    """--drop_path > 0: every DropPath INSTANCE of the unmodified model (encoder.blocks.i.drop_path and momentum_encoder.blocks.i.drop_path,
+    each called twice per forward: attention branch, then MLP branch -- modeling_finetune.py:156-158) gets its forward replaced by the keyed
+    per-sample mask of its site, as the device and the oracle draw it (torch's own generator stream cannot be reproduced outside torch)."""
+    import modeling_finetune as MF
+    import finetune_oracle as FO
+    counts, done = {}, []
+    for name, m in model.named_modules():
+        if not isinstance(m, MF.DropPath):
+            continue
+        parts = name.split(".")
+        assert parts[0] in ("encoder", "momentum_encoder") and parts[1] == "blocks" and parts[3] == "drop_path", name
+        i = int(parts[2])
+        j = i + (O.MOMENTUM_SITE_OFFSET if parts[0] == "momentum_encoder" else 0)
+
+        def f(x, name=name, i=i, j=j):
+            n = counts.get(name, 0)
+            counts[name] = n + 1
+            dr = holder["dr"]
+            return dr.path(FO.enc_site(j, 2 if n % 2 == 0 else 4), x, dr.dpr[i])
+        m.forward = f
+        done.append(name)
+    return done
+
+
 def run_reference_steps(cfg, seed, B, n_steps, hp, world=1, rank=0, sync_bn=False):
     """Drive the unmodified engine for n_steps one-batch 'epochs-worth' loaders; capture per-step values."""
     ref_utils = refenv.setup(rank=rank, world_size=world)
     import engine_for_pretraining_moco as E
     import optim_factory
-    model = build_ref_model(cfg)
+    model = build_ref_model(cfg, hp.drop_path)
+    drop_holder = {}
+    if hp.drop_path:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        patched = patch_drop_paths(model, drop_holder)
+        assert len(patched) == (2 if cfg.use_moco else 1) * (cfg.depth - 1), patched      # (block 0's rate is 0: nn.Identity, modeling_finetune.py:137)
     P, S = O.det_state(cfg, seed)
     sd = model.state_dict()
     for k, v in P.items():
@@ -143,6 +173,9 @@ def run_reference_steps(cfg, seed, B, n_steps, hp, world=1, rank=0, sync_bn=Fals
     for s in range(n_steps):
         im, au, mk = O.synthetic_batch(B, cfg, seed * 1000 + 17 * s + rank)
         loader = [([im, au, mk], torch.ones(1), torch.ones(1))]
+        if hp.drop_path:
+            import finetune_oracle as FO
+            drop_holder["dr"] = FO.DropOracle(hp.drop_seed, s, drop_path=hp.drop_path, depth=cfg.depth)
         stats = E.train_one_epoch(run_model, None, None, loader, None, opt, torch.device('cpu'), s, scaler, hp.clip_grad,
                                   patch_size=cfg.patch, normlize_target=False, start_steps=s,
                                   lr_schedule_values=lr_sched, wd_schedule_values=wd_sched, args=args)
@@ -412,5 +445,7 @@ if __name__ == "__main__":
         if a.only in ("", "nw5"):                   # the argparse default --num_windows 5: uneven adaptive_avg_pool2d windows on 32 columns
             import dataclasses
             gen_single("tiny_w1_nw5", dataclasses.replace(tiny, num_windows=5), 27, 4, 1, hp)
+        if a.only in ("", "dp"):                    # --drop_path 0.3 (run_mae_pretraining_moco.py:87): stochastic depth in both encoders under keyed masks
+            gen_single("tiny_w1_dp", O.DiGConfig(**dict(O.TINY, depth=3)), 29, 8, 2, O.StepHyper(lr=1e-3, drop_path=0.3, drop_seed=1234))
         if a.only in ("", "mim2"):                  # only_mim_on_ori_img=False: both views masked, MIM loss on both (engine :100-111,138-141)
             gen_single("tiny_w1_mim2", tiny, 9, 4, 1, O.StepHyper(lr=1e-3, only_mim_on_ori_img=False))

@@ -136,11 +136,13 @@ def _fixture_step0(name):
     cfg = O.DiGConfig(**{k: (int(v) if k in ints else v) for k, v in kw.items()})
     hpk = {k: v for k, v in zip(g["hp_keys"].tolist(), g["hp_vals"].tolist())}
     hpk["only_mim_on_ori_img"] = bool(hpk.get("only_mim_on_ori_img", 1.0))
+    if "drop_seed" in hpk:
+        hpk["drop_seed"] = int(hpk["drop_seed"])
     return g, cfg, O.StepHyper(**hpk), int(g["seed"]), int(g["B"])
 
 
 @pytest.mark.parametrize("name", ["tiny_w1", "vit_small_b4_w1", "vit_base_b2_w1", "tiny_w1_c0", "tiny_w1_mim2", "tiny_w1_nw5", "tiny_dis_w1",
-                                  "tiny_gen_w1", "tiny_gen_w1_mim2"])
+                                  "tiny_gen_w1", "tiny_gen_w1_mim2", "tiny_w1_dp"])
 def test_step_vs_reference_golden_fixture(name):
     """Fixtures come from the UNMODIFIED reference engine (tests/golden, oracle/ref_harness/gen_golden.py).
     vit_small_b4_w1 is BASELINE.json configs[0] (the reference's own CPU-runnable case), vit_base_b2_w1 the model of
@@ -148,7 +150,7 @@ def test_step_vs_reference_golden_fixture(name):
     only_mim_on_ori_img=False variant (both views masked, a masked-pixel loss on each, view 1's target cut from the original crops)."""
     g, cfg, hp, seed, B = _fixture_step0(name)
     im, au, mk = O.synthetic_batch(B, cfg, seed * 1000)
-    model = build_model(cfg, *O.det_state(cfg, seed))
+    model = build_model(cfg, *O.det_state(cfg, seed), hp=hp)          # (tiny_w1_dp: --drop_path 0.3 under the fixture's mask keys)
     cap = {}
     def grab(mod, inp, out):                                              # (a forward hook must return None, or it replaces the output)
         assert ("vis_out" in out) == cfg.use_pixel and ("contra_loss" in out) == cfg.use_moco      # the reference's out_dict keys
@@ -881,10 +883,12 @@ def test_optimizer_launch_leaves_shadow_and_transposes_for_the_next_forward():
     rebuilds both every step; a parameter written behind the optimizer's back (a torch in-place operation on the arena, load_state_dict)
     is seen and the copies are rebuilt."""
     from dig_amd import ops, optim_factory
-    cfg = O.DiGConfig(**O.TINY)
+    # (ViT-S width, two blocks: the fused MLP backward -- the reader of the transposed copies -- exists for D = 384 only)
+    cfg = dataclasses.replace(O.make_config("pretrain_simmim_moco_ori_vit_small_patch4_32x128"), depth=2)
     seed, B = 41, 4
     hp = O.StepHyper(lr=1e-3)
     batches = [O.synthetic_batch(B, cfg, 300 + s) for s in range(4)]
+    assert ops.mlp_chain_supported(cfg.embed_dim, cfg.hidden, 2 * B * 256)
 
     def run(fold, poke):
         old = optim_factory.FOLD_SHADOW
@@ -892,7 +896,7 @@ def test_optimizer_launch_leaves_shadow_and_transposes_for_the_next_forward():
         counts = {"cast": 0, "tr": 0}
         oc, ot = ops.cast_f32_to_bf16, ops.transpose_bf16_multi
         try:
-            model = build_model(cfg, *O.det_state(cfg, seed))
+            model = build_model(cfg, *O.init_state(cfg, seed))
             big = model.flat_params.numel()
 
             def cast(x, y):

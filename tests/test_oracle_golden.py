@@ -32,6 +32,8 @@ def cfg_from(g):
 def hp_from(g):
     kw = {k: v for k, v in zip(g["hp_keys"].tolist(), g["hp_vals"].tolist())}
     kw["only_mim_on_ori_img"] = bool(kw.get("only_mim_on_ori_img", 1.0))
+    if "drop_seed" in kw:
+        kw["drop_seed"] = int(kw["drop_seed"])
     return O.StepHyper(**kw)
 
 
@@ -144,6 +146,21 @@ def test_uneven_windows_step_matches_reference(golden_dir):
     g = load(golden_dir, "tiny_w1_nw5")
     assert cfg_from(g).num_windows == 5
     check_step0(g)
+
+
+def test_drop_path_step_matches_reference(golden_dir):
+    """--drop_path 0.3 (run_mae_pretraining_moco.py:87): stochastic depth on both branches of blocks 1.. of BOTH encoders, the unmodified
+    reference run with every DropPath instance drawing the keyed per-sample masks the device and the oracle draw (gen_golden.patch_drop_paths)."""
+    g = load(golden_dir, "tiny_w1_dp")
+    hp = hp_from(g)
+    assert hp.drop_path == pytest.approx(0.3) and cfg_from(g).depth == 3
+    check_step0(g, rtol=2e-3)                       # (fp32 summation order with a third of the batch's branches zeroed: one of 8 x 356 sampled elements sits at 1e-3 relative)
+    # the masks bite: the same step without them is a different step
+    cfg, seed, B = cfg_from(g), int(g["seed"]), int(g["B"])
+    im, au, mk = O.synthetic_batch(B, cfg, seed * 1000)
+    hp0 = dataclasses.replace(hp, moco_m=float(g["s0/stat/moco_m"]), drop_path=0.0)
+    m0, _, _, _ = O.OracleTrainer(cfg, *O.det_state(cfg, seed)).loss_and_grads(im, au, mk, hp0)
+    assert abs(m0["loss"] - float(g["s0/stat/loss"])) > 1e-3 * abs(m0["loss"])
 
 
 def test_clip_grad_two_steps_match_reference(golden_dir):
