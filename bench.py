@@ -52,7 +52,7 @@ WORKLOAD_TEXT = {
 }
 PEAK_BF16 = 2.5e15
 PEAK_HBM = 8.0e12                                                      # /opt/skills/guides/MI355X_MICROARCH.md
-PMC_FILE = "r05_pmc_traffic.json"                                      # rocprofv3 --pmc passes of this command (tools/collect_profiles.sh), stamped
+PMC_FILE = "r06_pmc_traffic.json"                                      # rocprofv3 --pmc passes of this command (tools/collect_profiles.sh), stamped
 #                                                                        with the hash of the kernel SOURCES they were measured on
 
 

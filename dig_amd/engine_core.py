@@ -822,21 +822,32 @@ class _Step:
         dist_mode = comm.world > 1 or getattr(comm, "world_override", False)
         mode = FWD_MODE if (not dist_mode and side is not main) else "side"
 
+        regular = M.patchnet == 'regular'
+
+        def extract(masked, enc_rows, pre, arena, save):
+            """patch_extractor (PatchNet.forward, :189-205): the pooled windows of [masked view | augmented view]; with --patchnet_name regular
+            they then attend over all tokens of their image (dig_amd/patchnet.py)."""
+            pooled = torch.empty((2 * B * nw, D), device=dev, dtype=BF16)
+            ops.window_pool_fwd(masked, pooled[:B * nw], B, M.gh, M.gw, nw, D)
+            ops.window_pool_fwd(enc_rows[B * N:], pooled[B * nw:], B, M.gh, M.gw, nw, D)
+            if not regular:
+                return pooled, None
+            from . import patchnet
+            # (the image tokens of both views as one [2 B N, D] matrix: without a pix_projector that is the encoder output itself)
+            feat = torch.cat([masked, enc_rows[B * N:]]) if masked.data_ptr() != enc_rows.data_ptr() else enc_rows
+            return patchnet.forward(self, feat, pooled, pre, arena, 2 * B, save)
+
         def online_heads(enc):
             # (`if hasattr(self, 'pix_projector')`, :500-510: the Dis-only models pool the encoder's own rows of both views)
             masked2, self.saved_pix = self.mlp_forward(enc[:B * N], "pix_projector", "online", True) if pp else (enc[:B * N], None)
-            pooled = torch.empty((2 * B * nw, D), device=dev, dtype=BF16)
-            ops.window_pool_fwd(masked2, pooled[:B * nw], B, M.gh, M.gw, nw, D)
-            ops.window_pool_fwd(enc[B * N:], pooled[B * nw:], B, M.gh, M.gw, nw, D)
+            pooled, self.saved_pnet = extract(masked2, enc, "patch_extractor", "online", True)
             q, self.saved_proj = self.mlp_forward(pooled, "encoder_projection_layer", "online", True)
             q, self.saved_pred = self.mlp_forward(q, "predictor", "online", True)
             return q
 
         def momentum_heads(enc_m):
             masked_m = self.mlp_forward(enc_m[:B * N], "pix_projector_m", "momentum", False)[0] if pp else enc_m[:B * N]
-            pooled_m = torch.empty((2 * B * nw, D), device=dev, dtype=BF16)
-            ops.window_pool_fwd(masked_m, pooled_m[:B * nw], B, M.gh, M.gw, nw, D)
-            ops.window_pool_fwd(enc_m[B * N:], pooled_m[B * nw:], B, M.gh, M.gw, nw, D)
+            pooled_m, _ = extract(masked_m, enc_m, "momentum_patch_extractor", "momentum", False)
             k, _ = self.mlp_forward(pooled_m, "momentum_projection_layer", "momentum", False)
             return k
 
@@ -900,12 +911,8 @@ class _Step:
                                                                                       enc_m[:B * N], "pix_projector_m", "momentum", False)
                 else:
                     masked2, self.saved_pix, masked_m = enc[:B * N], None, enc_m[:B * N]
-                pooled = torch.empty((2 * B * nw, D), device=dev, dtype=BF16)
-                pooled_m = torch.empty((2 * B * nw, D), device=dev, dtype=BF16)
-                ops.window_pool_fwd(masked2, pooled[:B * nw], B, M.gh, M.gw, nw, D)
-                ops.window_pool_fwd(enc[B * N:], pooled[B * nw:], B, M.gh, M.gw, nw, D)
-                ops.window_pool_fwd(masked_m, pooled_m[:B * nw], B, M.gh, M.gw, nw, D)
-                ops.window_pool_fwd(enc_m[B * N:], pooled_m[B * nw:], B, M.gh, M.gw, nw, D)
+                pooled, self.saved_pnet = extract(masked2, enc, "patch_extractor", "online", True)
+                pooled_m, _ = extract(masked_m, enc_m, "momentum_patch_extractor", "momentum", False)
                 (qs, self.saved_proj), (ks, _) = self.mlp_forward_pair(pooled, "encoder_projection_layer", "online", True,
                                                                         pooled_m, "momentum_projection_layer", "momentum", False)
                 qs, self.saved_pred = self.mlp_forward(qs, "predictor", "online", True)
@@ -1018,17 +1025,27 @@ class _Step:
             self._grad_ready(dev, "predictor")
             dpool = self.mlp_backward(dproj, "encoder_projection_layer", self.saved_proj)
             self._grad_ready(dev, "encoder_projection_layer")
+            acc = False
+            if M.patchnet == 'regular':
+                # the patch transformer's backward: d(pooled windows) and the gradient w.r.t. the image tokens through both blocks' keys /
+                # values -- [masked view | augmented view] rows, written where the pooling gradient is then ADDED
+                from . import patchnet
+                dpool, dfeat = patchnet.backward(self, dpool, "patch_extractor", self.saved_pnet, 2 * B)
+                self._grad_ready(dev, "patch_extractor")
+                d_enc, acc = dfeat, True
             if M.has_pix_projector:
-                dmasked2 = torch.empty((B * N, D), device=dev, dtype=BF16)
-                ops.window_pool_bwd(dpool[:n], dmasked2, B, M.gh, M.gw, nw, D, False)
-                ops.window_pool_bwd(dpool[n:], d_enc[B * N:], B, M.gh, M.gw, nw, D, False)
+                dmasked2 = d_enc[:B * N] if acc else torch.empty((B * N, D), device=dev, dtype=BF16)
+                ops.window_pool_bwd(dpool[:n], dmasked2, B, M.gh, M.gw, nw, D, acc)
+                ops.window_pool_bwd(dpool[n:], d_enc[B * N:], B, M.gh, M.gw, nw, D, acc)
+                # (regular: the incoming gradient lives in d_enc's own first half; the stack's last data gradient overwrites it when it is done with it)
                 self.mlp_backward(dmasked2, "pix_projector", self.saved_pix, dx_out=d_enc[:B * N])
                 self._grad_ready(dev, "pix_projector")
             else:
-                ops.window_pool_bwd(dpool[:n], d_enc[:B * N], B, M.gh, M.gw, nw, D, False)
-                ops.window_pool_bwd(dpool[n:], d_enc[B * N:], B, M.gh, M.gw, nw, D, False)
+                ops.window_pool_bwd(dpool[:n], d_enc[:B * N], B, M.gh, M.gw, nw, D, acc)
+                ops.window_pool_bwd(dpool[n:], d_enc[B * N:], B, M.gh, M.gw, nw, D, acc)
         elif M.use_moco_target:
-            for name in ("predictor", "encoder_projection_layer") + (("pix_projector",) if M.has_pix_projector else ()):
+            for name in (("predictor", "encoder_projection_layer") + (("patch_extractor",) if M.patchnet == 'regular' else ())
+                         + (("pix_projector",) if M.has_pix_projector else ())):
                 self.comm.grad_ready(M, name)
         # ---- SimMIM decoder path
         if g_vis is not None:
@@ -1071,7 +1088,7 @@ class _Step:
         _mark("backward: encoder done, streams joined", dev)
         self._keep.clear()                          # (blocks go back to the caller's stream's pool: its later work is ordered behind the join)
         self._keep_marks.clear()
-        self.saved_enc = self.saved_pix = self.saved_proj = self.saved_pred = self.saved_dec = self.saved_norm = self.wT = None
+        self.saved_enc = self.saved_pix = self.saved_proj = self.saved_pred = self.saved_dec = self.saved_norm = self.saved_pnet = self.wT = None
 
 
 class _DigFn(torch.autograd.Function):

@@ -90,8 +90,10 @@ class MoCo_ViT(nn.Module):
             raise ValueError("MoCo_ViT needs at least one objective (use_pixel_target / use_moco_target)")
         if use_pixel_target and use_moco_target and not use_pix_projector:
             raise NotImplementedError("use_pix_projector=False (no factory of the reference sets it) is not built")
-        if patchnet_name != 'no_patchtrans' and use_moco_target:
-            raise NotImplementedError("only patchnet_name='no_patchtrans' (the README configuration) is implemented")
+        if patchnet_name not in ('no_patchtrans', 'regular') and use_moco_target:
+            # ('conv' = ConvPatchNet, modeling_pretrain_moco_mim_ori.py:207-260: a 3x3-convolution / BatchNorm2d / max-pool stack -- no kernel of
+            #  this library is a convolution; the README recipe is 'no_patchtrans', the argparse default 'regular')
+            raise NotImplementedError(f"patchnet_name={patchnet_name!r}: 'no_patchtrans' (README) and 'regular' (the CLI default) are implemented")
         if drop_rate or attn_drop_rate or init_values or use_learnable_pos_emb or label_smoothing:
             raise NotImplementedError("dropout / layer-scale / learnable pos-emb / label smoothing are 0 in pre-training (no flag of "
                                       "run_mae_pretraining_moco.py sets them)")
@@ -125,6 +127,8 @@ class MoCo_ViT(nn.Module):
         # (`pretrain_moco_ori_*`: no mask, no pix_projector, no decoder); Gen-only (`pretrain_simmim_ori_*`: the encoder keeps its final
         # LayerNorm -- the moco branch is what replaces it by nn.Identity, :362-363 -- no momentum networks, no heads)
         self.use_pixel_target, self.use_moco_target = bool(use_pixel_target), bool(use_moco_target)
+        self.patchnet = patchnet_name if use_moco_target else 'no_patchtrans'
+        self.patchnet_depth = 2                                          # `depth=2` where MoCo_ViT builds its patch_extractor (:383-396)
         self.has_pix_projector = self.use_pixel_target and self.use_moco_target
         self.has_final_norm = not self.use_moco_target
         self.comm = None            # set by dig_amd.parallel.DistributedDataParallel
@@ -163,6 +167,21 @@ class MoCo_ViT(nn.Module):
             s += [ParamSpec(pre + "norm.weight", (D,), 1, arena), ParamSpec(pre + "norm.bias", (D,), 1, arena)]
         return s
 
+    def _patchnet_specs(self, pre, arena):
+        """PatchNet(use_patch_transformer=True): modeling_pretrain_moco_mim_ori.py:144-154 (blocks of :88-135, q / k / v without bias)."""
+        D, Fh = self.D, self.F
+        s = []
+        for i in range(self.patchnet_depth):
+            b = f"{pre}.blocks.{i}."
+            s += [ParamSpec(b + "norm1.weight", (D,), 1, arena), ParamSpec(b + "norm1.bias", (D,), 1, arena),
+                  ParamSpec(b + "attn.linear_q.weight", (D, D), 0, arena), ParamSpec(b + "attn.linear_k.weight", (D, D), 0, arena),
+                  ParamSpec(b + "attn.linear_v.weight", (D, D), 0, arena), ParamSpec(b + "attn.proj.weight", (D, D), 0, arena),
+                  ParamSpec(b + "attn.proj.bias", (D,), 1, arena), ParamSpec(b + "norm2.weight", (D,), 1, arena),
+                  ParamSpec(b + "norm2.bias", (D,), 1, arena), ParamSpec(b + "mlp.fc1.weight", (Fh, D), 0, arena),
+                  ParamSpec(b + "mlp.fc1.bias", (Fh,), 1, arena), ParamSpec(b + "mlp.fc2.weight", (D, Fh), 0, arena),
+                  ParamSpec(b + "mlp.fc2.bias", (D,), 1, arena)]
+        return s + [ParamSpec(pre + ".norm.weight", (D,), 1, arena), ParamSpec(pre + ".norm.bias", (D,), 1, arena)]
+
     @staticmethod
     def _mlp_specs(pre, dims, arena):
         s, n = [], len(dims)
@@ -187,6 +206,9 @@ class MoCo_ViT(nn.Module):
             specs += self._mlp_specs("encoder_projection_layer", self.mlps["encoder_projection_layer"], "online")
             specs += self._mlp_specs("momentum_projection_layer", self.mlps["momentum_projection_layer"], "momentum")
             specs += self._mlp_specs("predictor", self.mlps["predictor"], "online")
+            if self.patchnet == 'regular':
+                specs += self._patchnet_specs("patch_extractor", "online")
+                specs += self._patchnet_specs("momentum_patch_extractor", "momentum")
         if self.has_pix_projector:
             specs += self._mlp_specs("pix_projector", self.mlps["pix_projector"], "online")
             specs += self._mlp_specs("pix_projector_m", self.mlps["pix_projector_m"], "momentum")
@@ -218,7 +240,7 @@ class MoCo_ViT(nn.Module):
                 off += padded
             return off
 
-        ema_src = [n for n in self.specs if n.startswith(("encoder.", "encoder_projection_layer.", "pix_projector."))]
+        ema_src = [n for n in self.specs if n.startswith(("encoder.", "encoder_projection_layer.", "patch_extractor.", "pix_projector."))]
         rest = [n for n in self.specs if n.startswith(("predictor.", "pix_decoder."))]
         self._online_groups = []
         self.n_ema = place(ema_src, self._online_groups)                    # elements covered by the EMA
@@ -238,11 +260,12 @@ class MoCo_ViT(nn.Module):
         # the momentum arena must mirror the online one offset-for-offset
         for n in mom:
             src = (n.replace("momentum_encoder.", "encoder.").replace("momentum_projection_layer.", "encoder_projection_layer.")
-                   .replace("pix_projector_m.", "pix_projector."))
+                   .replace("momentum_patch_extractor.", "patch_extractor.").replace("pix_projector_m.", "pix_projector."))
             assert self.specs[src].offset == self.specs[n].offset, (n, src)
         # gradient-bucket boundaries (element ranges of the online arena), in backward-completion order
         heads = [k for k, on in (("pix_decoder", self.use_pixel_target), ("predictor", self.use_moco_target),
-                                 ("encoder_projection_layer", self.use_moco_target), ("pix_projector", self.has_pix_projector)) if on]
+                                 ("encoder_projection_layer", self.use_moco_target), ("patch_extractor", self.patchnet == 'regular'),
+                                 ("pix_projector", self.has_pix_projector)) if on]
         self.bucket_names = (heads + (["encoder.norm"] if self.has_final_norm else [])
                              + [f"encoder.blocks.{i}" for i in reversed(range(self.depth))] + ["encoder.embed"])
 
@@ -366,7 +389,7 @@ class MoCo_ViT(nn.Module):
                     v.uniform_(-a, a)
                 elif n.endswith("patch_embed.proj.bias") and not self.use_moco_target:
                     v.uniform_(-1.0 / math.sqrt(48.0), 1.0 / math.sqrt(48.0))
-                elif n.startswith("encoder."):
+                elif n.startswith(("encoder.", "patch_extractor.")):    # (PatchNet._init_weights, :159-166: the encoder's rule)
                     if len(s.shape) == 2:
                         nn.init.xavier_uniform_(v)
                     elif n.endswith(("norm1.weight", "norm2.weight", "norm.weight")):

@@ -53,6 +53,11 @@ class DiGConfig:
     #   no mask, no pix_projector, no decoder), "simmim" = Gen-only (pretrain_simmim_ori_*, :655-681,737-763,845-871: the encoder keeps its
     #   final LayerNorm, no momentum networks, no heads; the patch embedding keeps nn.Conv2d's default init)
     kind: str = "simmim_moco"
+    # --patchnet_name (run_mae_pretraining_moco.py:145): "no_patchtrans" (README) = the pooled windows themselves; "regular" (the argparse
+    # default) = PatchNet with its 2-block patch transformer: the pooled windows attend over all 256 tokens (modeling_pretrain_moco_mim_ori.py:137-205)
+    patchnet: str = "no_patchtrans"
+    patchnet_depth: int = 2
+    patchnet_eps: float = 1e-5        # PatchNet's own norm_layer default: nn.LayerNorm (eps 1e-5), not the encoder's 1e-6
 
     @property
     def use_moco(self) -> bool:
@@ -128,6 +133,23 @@ def _encoder_param_shapes(cfg: DiGConfig, pre: str) -> "OrderedDict[str, tuple]"
     return o
 
 
+def _patchnet_param_shapes(cfg: DiGConfig, pre: str) -> "OrderedDict[str, tuple]":
+    """PatchNet(use_patch_transformer=True): `depth` cross-attention Blocks (modeling_pretrain_moco_mim_ori.py:21-135: separate q / k / v
+    Linear layers without bias -- qkv_bias defaults to False there) and a final LayerNorm."""
+    D, Fh = cfg.embed_dim, cfg.hidden
+    o = OrderedDict()
+    for i in range(cfg.patchnet_depth):
+        b = f"{pre}blocks.{i}."
+        o[b + "norm1.weight"] = (D,); o[b + "norm1.bias"] = (D,)
+        o[b + "attn.linear_q.weight"] = (D, D); o[b + "attn.linear_k.weight"] = (D, D); o[b + "attn.linear_v.weight"] = (D, D)
+        o[b + "attn.proj.weight"] = (D, D); o[b + "attn.proj.bias"] = (D,)
+        o[b + "norm2.weight"] = (D,); o[b + "norm2.bias"] = (D,)
+        o[b + "mlp.fc1.weight"] = (Fh, D); o[b + "mlp.fc1.bias"] = (Fh,)
+        o[b + "mlp.fc2.weight"] = (D, Fh); o[b + "mlp.fc2.bias"] = (D,)
+    o[pre + "norm.weight"] = (D,); o[pre + "norm.bias"] = (D,)
+    return o
+
+
 def _mlp_dims(n_layers: int, din: int, dmid: int, dout: int) -> List[Tuple[int, int]]:
     """_build_mlp, modeling_pretrain_moco_mim_ori.py:463-482."""
     return [(din if l == 0 else dmid, dout if l == n_layers - 1 else dmid) for l in range(n_layers)]
@@ -175,6 +197,9 @@ def param_shapes(cfg: DiGConfig) -> "OrderedDict[str, tuple]":
         o.update(_encoder_param_shapes(cfg, "momentum_encoder."))
     for pre, dims in mlp_specs(cfg).items():
         o.update(_mlp_param_shapes(pre, dims))
+        if pre == "predictor." and cfg.patchnet == "regular":            # registration order of MoCo_ViT.__init__ (:366-394)
+            o.update(_patchnet_param_shapes(cfg, "patch_extractor."))
+            o.update(_patchnet_param_shapes(cfg, "momentum_patch_extractor."))
     if cfg.use_pixel:
         Dd = cfg.dec_dim                                                  # pix_decoder, :422-426
         o["pix_decoder.0.weight"] = (Dd, cfg.embed_dim)
@@ -193,9 +218,10 @@ def buffer_shapes(cfg: DiGConfig) -> "OrderedDict[str, tuple]":
     return o
 
 
-MOMENTUM_PREFIXES = ("momentum_encoder.", "momentum_projection_layer.", "pix_projector_m.")
+MOMENTUM_PREFIXES = ("momentum_encoder.", "momentum_projection_layer.", "pix_projector_m.", "momentum_patch_extractor.")
 EMA_PAIRS = (("encoder.", "momentum_encoder."),                         # _update_momentum_encoder, :428-442
              ("encoder_projection_layer.", "momentum_projection_layer."),
+             ("patch_extractor.", "momentum_patch_extractor."),
              ("pix_projector.", "pix_projector_m."))
 
 
@@ -236,7 +262,7 @@ def init_state(cfg: DiGConfig, seed: int = 0, dtype=torch.float32):
                 t = uni(shp, 1.0 / math.sqrt(cfg.in_chans * cfg.patch * cfg.patch))
         elif name.endswith("patch_embed.proj.bias") and not cfg.use_moco:
             t = uni(shp, 1.0 / math.sqrt(cfg.in_chans * cfg.patch * cfg.patch))
-        elif name.startswith("encoder."):
+        elif name.startswith(("encoder.", "patch_extractor.")):           # (PatchNet._init_weights, :159-166: the same rule)
             if len(shp) == 2:
                 t = uni(shp, math.sqrt(6.0 / (shp[0] + shp[1])))           # xavier_uniform_
             elif name.endswith(("norm1.weight", "norm2.weight", "norm.weight")):
@@ -445,6 +471,31 @@ def window_pool(x, cfg: DiGConfig):
     return x.reshape(Bn, gh, cfg.num_windows, gw // cfg.num_windows, C).mean(dim=(1, 3))
 
 
+def patch_extractor(x, P, pre, cfg: DiGConfig):
+    """PatchNet.forward (modeling_pretrain_moco_mim_ori.py:189-205): the pooled windows; with the patch transformer ("regular") each of them
+    then attends over all tokens of its image through `depth` Blocks (:88-135) -- every Block normalises queries AND keys / values with its
+    own norm1, adds the attention output to the NORMALISED queries (`x = self.norm1(x) ... x = x + attn_x`, :107-121), then the MLP; a final
+    LayerNorm.  x: [Bn, N, C] -> [Bn, num_windows, C]."""
+    pooled = window_pool(x, cfg)
+    if cfg.patchnet != "regular":
+        return pooled
+    Bn, N, C = x.shape
+    H, dh, eps = cfg.heads, cfg.head_dim, cfg.patchnet_eps
+    y = pooled
+    for i in range(cfg.patchnet_depth):
+        b = f"{pre}blocks.{i}."
+        yn = layer_norm(y, P[b + "norm1.weight"], P[b + "norm1.bias"], eps)
+        kn = layer_norm(x, P[b + "norm1.weight"], P[b + "norm1.bias"], eps)
+        q = F.linear(yn, P[b + "attn.linear_q.weight"]).reshape(Bn, -1, H, dh).permute(0, 2, 1, 3) * (dh ** -0.5)
+        k = F.linear(kn, P[b + "attn.linear_k.weight"]).reshape(Bn, N, H, dh).permute(0, 2, 3, 1)
+        v = F.linear(kn, P[b + "attn.linear_v.weight"]).reshape(Bn, N, H, dh).permute(0, 2, 1, 3)
+        a = ((q @ k).softmax(dim=-1) @ v).transpose(1, 2).reshape(Bn, -1, C)
+        y = yn + F.linear(a, P[b + "attn.proj.weight"], P[b + "attn.proj.bias"])
+        h = F.gelu(F.linear(layer_norm(y, P[b + "norm2.weight"], P[b + "norm2.bias"], eps), P[b + "mlp.fc1.weight"], P[b + "mlp.fc1.bias"]))
+        y = y + F.linear(h, P[b + "mlp.fc2.weight"], P[b + "mlp.fc2.bias"])
+    return layer_norm(y, P[pre + "norm.weight"], P[pre + "norm.bias"], eps)
+
+
 def info_nce(q, k, T, comm):
     """contrastive_loss + accuracy + label_smooth_loss(smoothing=0): :444-461, :593-625."""
     q = F.normalize(q, dim=1)
@@ -492,7 +543,7 @@ def model_forward(P, S, images, aug_images, mask, m: float, cfg: DiGConfig, comm
             feat = torch.cat([masked.reshape(B, N, D), enc[B:]], 0)
         else:
             feat = enc
-        pooled = window_pool(feat, cfg).reshape(2 * B * cfg.num_windows, D)
+        pooled = patch_extractor(feat, P, "patch_extractor.", cfg).reshape(2 * B * cfg.num_windows, D)
         qs = bn_mlp(pooled, P, S, "encoder_projection_layer.", specs["encoder_projection_layer."], cfg, comm, taps)
         qs = bn_mlp(qs, P, S, "predictor.", specs["predictor."], cfg, comm, taps)
         half = B * cfg.num_windows
@@ -506,7 +557,7 @@ def model_forward(P, S, images, aug_images, mask, m: float, cfg: DiGConfig, comm
                 feat_m = torch.cat([masked_m.reshape(B, N, D), enc_m[B:]], 0)
             else:
                 feat_m = enc_m
-            pooled_m = window_pool(feat_m, cfg).reshape(2 * B * cfg.num_windows, D)
+            pooled_m = patch_extractor(feat_m, P, "momentum_patch_extractor.", cfg).reshape(2 * B * cfg.num_windows, D)
             ks = bn_mlp(pooled_m, P, S, "momentum_projection_layer.", specs["momentum_projection_layer."], cfg, comm)
             k1, k2 = ks[:half], ks[half:]
         l1, a11, a15 = info_nce(q1, k2, cfg.T, comm)

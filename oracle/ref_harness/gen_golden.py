@@ -42,7 +42,7 @@ def build_ref_model(cfg: O.DiGConfig, drop_path: float = 0.0):
                       decoder_num_heads=3, mlp_ratio=cfg.mlp_ratio, qkv_bias=True,
                       norm_layer=partial(nn.LayerNorm, eps=1e-6), use_pixel_target=cfg.use_pixel, use_moco_target=cfg.use_moco,
                       mlp_dim=cfg.moco_mlp_dim, dim=cfg.moco_dim, T=cfg.T, num_windows=cfg.num_windows,
-                      patchnet_name='no_patchtrans')
+                      patchnet_name=cfg.patchnet)
 
 
 def ref_args(hp: O.StepHyper, epochs=10):
@@ -276,6 +276,7 @@ def pack(ref_steps, cfg, seed, B, hp, extra=None):
     d = {"seed": np.int64(seed), "B": np.int64(B), "n_steps": np.int64(len(ref_steps)),
          "cfg_keys": np.array([k for k, v in vars(cfg).items() if not isinstance(v, str)]),
          "cfg_vals": np.array([float(v) for v in vars(cfg).values() if not isinstance(v, str)]), "cfg_kind": np.array(cfg.kind),
+         "cfg_patchnet": np.array(cfg.patchnet),
          "hp_keys": np.array([k for k, v in vars(hp).items() if isinstance(v, (int, float)) and v is not None]),
          "hp_vals": np.array([float(v) for k, v in vars(hp).items() if isinstance(v, (int, float)) and v is not None])}
     for s, r in enumerate(ref_steps):
@@ -445,6 +446,9 @@ if __name__ == "__main__":
         if a.only in ("", "nw5"):                   # the argparse default --num_windows 5: uneven adaptive_avg_pool2d windows on 32 columns
             import dataclasses
             gen_single("tiny_w1_nw5", dataclasses.replace(tiny, num_windows=5), 27, 4, 1, hp)
+        if a.only in ("", "regular"):               # the reference CLI's defaults: --patchnet_name regular with --num_windows 5 (run_mae_pretraining_moco.py:143-145)
+            import dataclasses
+            gen_single("tiny_w1_regular", dataclasses.replace(tiny, patchnet="regular", num_windows=5), 35, 4, 2, hp)
         if a.only in ("", "dp"):                    # --drop_path 0.3 (run_mae_pretraining_moco.py:87): stochastic depth in both encoders under keyed masks
             gen_single("tiny_w1_dp", O.DiGConfig(**dict(O.TINY, depth=3)), 29, 8, 2, O.StepHyper(lr=1e-3, drop_path=0.3, drop_seed=1234))
         if a.only in ("", "mim2"):                  # only_mim_on_ori_img=False: both views masked, MIM loss on both (engine :100-111,138-141)

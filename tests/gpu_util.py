@@ -23,7 +23,7 @@ def build_model(cfg, P=None, S=None, device="cuda:0", hp=None):
     from dig_amd.modeling_pretrain_moco_mim_ori import MoCo_ViT
     m = MoCo_ViT(encoder_embed_dim=cfg.embed_dim, encoder_depth=cfg.depth, encoder_num_heads=cfg.heads,
                  decoder_embed_dim=cfg.dec_dim, mlp_dim=cfg.moco_mlp_dim, dim=cfg.moco_dim, T=cfg.T, num_windows=cfg.num_windows,
-                 use_pixel_target=cfg.use_pixel, use_moco_target=cfg.use_moco, patchnet_name='no_patchtrans',
+                 use_pixel_target=cfg.use_pixel, use_moco_target=cfg.use_moco, patchnet_name=getattr(cfg, "patchnet", "no_patchtrans"),
                  drop_path_rate=float(getattr(hp, "drop_path", 0.0) or 0.0))
     if hp is not None and getattr(hp, "drop_path", 0.0):
         m.drop_seed = int(hp.drop_seed)

@@ -130,9 +130,11 @@ def _fixture_step0(name):
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
     kw = {k: v for k, v in zip(g["cfg_keys"].tolist(), g["cfg_vals"].tolist())}
     ints = {"img_h", "img_w", "patch", "in_chans", "embed_dim", "depth", "heads", "dec_dim", "dec_classes", "moco_dim",
-            "moco_mlp_dim", "pix_mlp_dim", "num_windows"}
+            "moco_mlp_dim", "pix_mlp_dim", "num_windows", "patchnet_depth"}
     if "cfg_kind" in g:
         kw["kind"] = str(g["cfg_kind"])
+    if "cfg_patchnet" in g:
+        kw["patchnet"] = str(g["cfg_patchnet"])
     cfg = O.DiGConfig(**{k: (int(v) if k in ints else v) for k, v in kw.items()})
     hpk = {k: v for k, v in zip(g["hp_keys"].tolist(), g["hp_vals"].tolist())}
     hpk["only_mim_on_ori_img"] = bool(hpk.get("only_mim_on_ori_img", 1.0))
@@ -142,7 +144,7 @@ def _fixture_step0(name):
 
 
 @pytest.mark.parametrize("name", ["tiny_w1", "vit_small_b4_w1", "vit_base_b2_w1", "tiny_w1_c0", "tiny_w1_mim2", "tiny_w1_nw5", "tiny_dis_w1",
-                                  "tiny_gen_w1", "tiny_gen_w1_mim2", "tiny_w1_dp"])
+                                  "tiny_gen_w1", "tiny_gen_w1_mim2", "tiny_w1_dp", "tiny_w1_regular"])
 def test_step_vs_reference_golden_fixture(name):
     """Fixtures come from the UNMODIFIED reference engine (tests/golden, oracle/ref_harness/gen_golden.py).
     vit_small_b4_w1 is BASELINE.json configs[0] (the reference's own CPU-runnable case), vit_base_b2_w1 the model of

@@ -23,9 +23,11 @@ def load(golden_dir, name):
 def cfg_from(g):
     kw = {k: v for k, v in zip(g["cfg_keys"].tolist(), g["cfg_vals"].tolist())}
     ints = {"img_h", "img_w", "patch", "in_chans", "embed_dim", "depth", "heads", "dec_dim", "dec_classes",
-            "moco_dim", "moco_mlp_dim", "pix_mlp_dim", "num_windows"}
+            "moco_dim", "moco_mlp_dim", "pix_mlp_dim", "num_windows", "patchnet_depth"}
     if "cfg_kind" in g:                                                   # fixtures of the single-objective models
         kw["kind"] = str(g["cfg_kind"])
+    if "cfg_patchnet" in g:
+        kw["patchnet"] = str(g["cfg_patchnet"])
     return O.DiGConfig(**{k: (int(v) if k in ints else v) for k, v in kw.items()})
 
 
@@ -145,6 +147,17 @@ def test_uneven_windows_step_matches_reference(golden_dir):
     """--num_windows 5, the reference CLI's default (run_mae_pretraining_moco.py:143): adaptive_avg_pool2d bins of 7 / 7 / 8 / 7 / 7 columns."""
     g = load(golden_dir, "tiny_w1_nw5")
     assert cfg_from(g).num_windows == 5
+    check_step0(g)
+
+
+def test_regular_patchnet_step_matches_reference(golden_dir):
+    """The reference CLI's defaults --patchnet_name regular --num_windows 5 (run_mae_pretraining_moco.py:143-145): PatchNet with its two
+    cross-attention blocks (modeling_pretrain_moco_mim_ori.py:137-205, :21-135) in both the online and the EMA'd momentum branch."""
+    g = load(golden_dir, "tiny_w1_regular")
+    cfg = cfg_from(g)
+    pn = g["s0/param_names"].tolist()
+    assert cfg.patchnet == "regular" and cfg.num_windows == 5
+    assert "patch_extractor.blocks.1.attn.linear_k.weight" in pn and "momentum_patch_extractor.norm.bias" in pn
     check_step0(g)
 
 
