@@ -13,10 +13,9 @@ backward's residual input and handed back to the caller, which adds the pooling 
 import torch
 
 from . import ops
-from ._lib import cf
 
 BF16, F32 = torch.bfloat16, torch.float32
-L = ops.L
+L, cf = ops.L, ops.cf
 EPS = 1e-5
 
 

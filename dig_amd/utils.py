@@ -322,7 +322,10 @@ def save_model(args, epoch, model, model_without_ddp, optimizer, loss_scaler, mo
     ck = {'model': {k: v.detach().cpu() for k, v in model_without_ddp.state_dict().items()},
           'optimizer': _to_cpu(optimizer.state_dict()),
           'epoch': epoch, 'scaler': loss_scaler.state_dict(), 'args': vars(args) if hasattr(args, "__dict__") else args}
-    if hasattr(model_without_ddp, "drop_step"):        # dropout mask keys of the fine-tune model (an extra top-level key: the
+    # dropout / stochastic-depth mask keys (an extra top-level key: the reference ignores it).  The pre-training model carries them only under
+    # --drop_path > 0: with the README recipe its checkpoint has exactly the reference's five keys
+    if hasattr(model_without_ddp, "drop_step") and not (hasattr(model_without_ddp, "dpr") and not getattr(model_without_ddp, "drop_path_rate", 0.0)
+                                                       and hasattr(model_without_ddp, "use_moco_target")):
         ck['dig_amd'] = {'drop_seed': int(model_without_ddp.drop_seed), 'drop_step': int(model_without_ddp.drop_step)}   # reference ignores it)
     torch.save(ck, path)
 
