@@ -181,11 +181,19 @@ def test_step_vs_reference_golden_fixture(name):
     torch.set_num_threads(max(8, min(32, os.cpu_count() or 8)))
     with torch.autocast("cpu", dtype=torch.bfloat16):
         _, bf_g, _, _ = O.OracleTrainer(cfg, *O.det_state(cfg, seed)).loss_and_grads(im, au, mk, hp0)
+    # tiny models: the yardstick's DIRECTION error widens the norm band, as in test_both_views_mim_vs_oracle (a vector that bf16 turns by
+    # 1 - cos = 2.5 % -- every tensor behind the 40-row BatchNorms of the patch transformer's fixture -- cannot have its norm pinned to 3 %);
+    # the fixture holds norms and samples only, so the directions come from the fp32 oracle (itself pinned to this fixture on the CPU side)
+    ref_g = None
+    if cfg.embed_dim <= 128:
+        _, ref_g, _, _ = O.OracleTrainer(cfg, *O.det_state(cfg, seed)).loss_and_grads(im, au, mk, hp0)
+    cosf = torch.nn.functional.cosine_similarity
     for i, n in enumerate(names):
         if norms[i] > 1e-3 * tot:                                        # tensors that carry the gradient
             q_hip, q_bf = grads[n].norm().item() / norms[i], bf_g[n].float().norm().item() / norms[i]
+            turn = (1 - cosf(bf_g[n].float().reshape(1, -1), ref_g[n].reshape(1, -1)).item()) if ref_g is not None else 0.0
             # (+ an absolute floor of 1e-4 of the whole gradient's norm: see test_both_views_mim_vs_oracle)
-            assert abs(q_hip - 1) <= 2 * abs(q_bf - 1) + 3e-2 + 1e-4 * tot / norms[i], (n, q_hip, q_bf, norms[i] / tot)
+            assert abs(q_hip - 1) <= 2 * abs(q_bf - 1) + 3e-2 + turn + 1e-4 * tot / norms[i], (n, q_hip, q_bf, turn, norms[i] / tot)
     # mask gather order is bit-exact => vis_out rows line up with the reference's: compare the full [B, 179, 48] tensor, captured
     # from the step's own forward (before the optimizer touched the weights)
     if cfg.use_pixel:
