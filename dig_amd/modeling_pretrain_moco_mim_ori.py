@@ -269,6 +269,24 @@ class MoCo_ViT(nn.Module):
         self.bucket_names = (heads + (["encoder.norm"] if self.has_final_norm else [])
                              + [f"encoder.blocks.{i}" for i in reversed(range(self.depth))] + ["encoder.embed"])
 
+    def bucket_groups(self):
+        """Gradient buckets that travel in ONE all-reduce: neighbours in the arena whose gradients become final within a few launches of each
+        other (xGMI is point-to-point: fewer, larger messages -- the patch embedding's 78 KB and the decoder's 0.5 MB are latency, not
+        bandwidth).  {key: tuple of the keys of its group}; a group's range is contiguous (checked)."""
+        cache = getattr(self, "_bucket_groups", None)
+        if cache is None:
+            names = set(self.bucket_names)
+            groups = [g for g in (("predictor", "pix_decoder"), ("encoder_projection_layer", "patch_extractor", "pix_projector"),
+                                  ("encoder.embed", "encoder.blocks.0")) if sum(k in names for k in g) >= 2]
+            cache = {}
+            for g in groups:
+                g = tuple(k for k in g if k in names)
+                rng = sorted(self.bucket_range(k) for k in g)
+                if all(a[1] == b[0] for a, b in zip(rng, rng[1:])):      # (contiguous in the arena: always, by the layout of _build_layout)
+                    cache.update({k: g for k in g})
+            self._bucket_groups = cache
+        return cache
+
     def bucket_range(self, key):
         """[begin, end) element range of the online arena that holds the parameters of one backward stage."""
         if key == "encoder.embed":

@@ -22,6 +22,7 @@ class DistComm:
         self.world = dist.get_world_size(process_group)
         self.rank = dist.get_rank(process_group)
         self._pending = []
+        self._ready = set()                  # buckets of a group (grad_ready) that are final and wait for their neighbours
         self.log = None                      # a list: every collective issued is recorded as (op, numel) -- the order on the communicator
         #                                       must be the same on every rank or the first multi-GPU step dead-locks (tests/golden/collective_order_tiny.json)
 
@@ -44,8 +45,19 @@ class DistComm:
         return out
 
     def grad_ready(self, model, key):
-        """Called by the backward as soon as every gradient in bucket `key` is final."""
-        lo, hi = model.bucket_range(key)
+        """Called by the backward as soon as every gradient in bucket `key` is final.  Buckets of one group (MoCo_ViT.bucket_groups: small
+        neighbours in the arena) go out together, when the last of them is final: 14 gradient messages per step instead of 17."""
+        group = model.bucket_groups().get(key) if hasattr(model, "bucket_groups") else None
+        if group is not None:
+            self._ready.add(key)
+            if not all(k in self._ready for k in group):
+                return
+            self._ready.difference_update(group)
+            rng = [model.bucket_range(k) for k in group]
+            lo, hi = min(r[0] for r in rng), max(r[1] for r in rng)
+            key = "+".join(group)
+        else:
+            lo, hi = model.bucket_range(key)
         g = model.flat_grads[lo:hi]
         self._note("all_reduce_async:" + key, g)
         self._pending.append((dist.all_reduce(g, group=self.group, async_op=True), g))
@@ -54,6 +66,8 @@ class DistComm:
         """Wait for the outstanding bucket all-reduces.  The 1/world averaging costs nothing: NativeScalerWithGradNormCount seeds the
         backward with loss / world, so every rank's gradients arrive pre-divided and the SUM all-reduce is the mean (a power-of-two
         scale commutes with every rounding on the way: bit-identical to scaling the 174 MB arena afterwards, minus that pass)."""
+        if self._ready:
+            raise RuntimeError(f"gradient buckets {sorted(self._ready)} were final but their group never completed: a backward stage did not report")
         for work, _ in self._pending:
             work.wait()
         self._pending = []

@@ -87,9 +87,15 @@ def _comm_worker(rank, world, port, q):
         gen = torch.Generator().manual_seed(7 + rank)
         m.flat_grads.copy_(torch.randn(m.flat_grads.shape, generator=gen))
         mine = m.flat_grads.clone()
+        m.comm.log = []
         for key in m.bucket_names:
             m.comm.grad_ready(m, key)
         m.comm.finish_grad_sync(m)
+        # small neighbours travel together (MoCo_ViT.bucket_groups): depth + 5 buckets in depth + 2 messages, every element exactly once
+        sent = [op for op, _ in m.comm.log]
+        m.comm.log = None
+        assert len(sent) == cfg.depth + 2 and sum(n for _, n in zip(sent, [0] * len(sent))) == 0
+        assert "all_reduce_async:predictor+pix_decoder" in sent and "all_reduce_async:encoder.embed+encoder.blocks.0" in sent
         tot = mine.clone()
         dist.all_reduce(tot)
         torch.testing.assert_close(m.flat_grads, tot, rtol=1e-6, atol=1e-7)
