@@ -314,6 +314,7 @@ class _Step:
         probs = ((ops._WgProb * 4)(), (ops._WgProb * 4)())
         wmap_ptr = plan["wmap"].data_ptr()
         tile = ops.dgrad_tile_code(R, D) or ops.GEMM_BK_BWD
+        tile_direct = ops.dgrad_direct_tile_code(R, D)
         key = ("bwd_call", R, n_img)
         dy_ptr, dy_owner = dx.data_ptr(), dx
         prev_block, n_launch, slabs_prev = None, 0, None
@@ -339,9 +340,11 @@ class _Step:
                     g_fc2_b=g["mlp.fc2.bias"].data_ptr(),
                     wg_fn=plan["fn"], wg_wa=plan["wa"], wg_splits=plan["splits"], wg_n_wg=plan["n_wg"], wg_fold_splits=plan["splits"],
                     wg_trans=(ctypes.c_int * 4)(*plan["trans"]))
-            w2t, w1t, projt = wT[i]
+            w2t, w1t, projt, qkvt = wT[i]
             st.w2t, st.w1t = w2t.data_ptr(), w1t.data_ptr()
             st.projt = projt.data_ptr() if (ops.MLP_CHAIN_LNB and ops.MLP_CHAIN_PROJ) else None
+            st.tile_direct = tile_direct                              # (a switch: read on every call)
+            st.proj_wt, st.qkv_wt = (projt.data_ptr(), qkvt.data_ptr()) if tile_direct else (None, None)
             st.x, st.ln1, st.mu1, st.rs1 = sv.inp_ptr
             for k in ("qkv", "ctx", "lse", "x_mid", "ln2", "mu2", "rs2", "pre", "act"):
                 setattr(st, k, sv.ptr(k))
@@ -434,7 +437,8 @@ class _Step:
         w2t = ops.transpose_bf16_multi([b["mlp.fc2.weight"] for b in ew.blocks], [o[0] for o in outs] if outs else None)   # one launch per weight shape
         w1t = ops.transpose_bf16_multi([b["mlp.fc1.weight"] for b in ew.blocks], [o[1] for o in outs] if outs else None)
         projt = ops.transpose_bf16_multi([b["attn.proj.weight"] for b in ew.blocks], [o[2] for o in outs] if outs else None)
-        return list(zip(w2t, w1t, projt))
+        qkvt = ops.transpose_bf16_multi([b["attn.qkv.weight"] for b in ew.blocks], [o[3] for o in outs] if outs else None)   # (direct-form qkv data gradient)
+        return list(zip(w2t, w1t, projt, qkvt))
 
     # ------------------------------------------------------------------ two-stream helpers (backward)
     def _streams(self, dev):
@@ -579,7 +583,7 @@ class _Step:
             if chain:
                 # data gradient through fc2, GELU' and fc1 in one launch (d(pre-activation) leaves it as a side output for the fc1
                 # weight gradient, with its column sums = the fc1 bias gradient)
-                w2t, w1t, projt = wT[i]
+                w2t, w1t, projt, qkvt = wT[i]
                 dctx = None
                 if ds:
                     dln2, dact, bparts = ops.mlp_chain_bwd(dz, w2t, pre, w1t)
@@ -626,8 +630,10 @@ class _Step:
             else:
                 on_side(lambda dzp=dzp: wg(dzp, ctx, g["attn.proj.weight"]), dzp, ctx)
             _mark("blk: LayerNorm backward (norm2)", dev)
+            td = ops.dgrad_direct_tile_code(dzp.shape[0], D) if (chain_any and wT is not None) else 0
             if not chain or dctx is None:
-                dctx = ops.linear_dgrad(dzp, blk["attn.proj.weight"])
+                # (direct form on proj.weight^T where the tile plan has one: both operands K-contiguous, bit-identical to the transpose-read form)
+                dctx = (ops.gemm(dzp, wT[i][2], dzp.shape[0], D, D, bk=td) if td else ops.linear_dgrad(dzp, blk["attn.proj.weight"]))
             _mark("blk: proj data gradient", dev)
             gb = g["qkv_bias"]
             if FUSED_QV_BIAS_SUMS:
@@ -653,7 +659,7 @@ class _Step:
                 else:
                     on_side(lambda: (wg(dqkv, ln1, g["attn.qkv.weight"]),
                                      ops.colsum(dqkv, gb[:D], cols=D), ops.colsum(dqkv[:, 2 * D:], gb[2 * D:], cols=D)), dqkv, ln1)
-            dln1 = ops.linear_dgrad(dqkv, blk["attn.qkv.weight"], out=dctx)
+            dln1 = (ops.gemm(dqkv, wT[i][3], dqkv.shape[0], D, 3 * D, out=dctx, bk=td) if td else ops.linear_dgrad(dqkv, blk["attn.qkv.weight"], out=dctx))
             _mark("blk: qkv data gradient", dev)
             dx, fin1, ws1 = ops.layernorm_bwd(dln1, x, blk["norm1.weight"], blk["norm1.bias"], mu1, rs1, dx_mid, g["norm1.weight"],
                                               g["norm1.bias"], out=dln1, dres_colsum=None if ds else g["attn.proj.bias"], defer=True)

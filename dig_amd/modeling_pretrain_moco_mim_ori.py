@@ -473,7 +473,7 @@ class MoCo_ViT(nn.Module):
     # on a parameter bump the arena's version counter (checked); code that writes parameters through `.data` or raw pointers must call
     # mark_weights_changed().
     def transposed_weight_table(self):
-        """(device table of dig_adamw_step_tr, n_mats, n_tiles, tr_out, [(w2t, w1t, projt) views per block]) or None when a shape is not a
+        """(device table of dig_adamw_step_tr, n_mats, n_tiles, tr_out, [(w2t, w1t, projt, qkvt) views per block]) or None when a shape is not a
         multiple of 64 (the transposes are then rebuilt by the forward, as before)."""
         dev = self._flat["online"].device
         cache = getattr(self, "_tr_table", None)
@@ -484,7 +484,7 @@ class MoCo_ViT(nn.Module):
         ok = dev.type == "cuda"
         for i in range(self.depth):
             row = []
-            for leaf in ("mlp.fc2.weight", "mlp.fc1.weight", "attn.proj.weight"):
+            for leaf in ("mlp.fc2.weight", "mlp.fc1.weight", "attn.proj.weight", "attn.qkv.weight"):
                 sp = self.specs[f"encoder.blocks.{i}.{leaf}"]
                 r, c = sp.shape
                 ok = ok and r % 64 == 0 and c % 64 == 0 and sp.offset % ALIGN == 0

@@ -284,6 +284,15 @@ def linear_dgrad(dy, w, out=None, gelu_pre=None, colsum=False, drop=None):
     return gemm(dy, w, rows, J, w.shape[0], tb=True, out=out, bk=dgrad_tile_code(rows, J, drop))
 
 
+DGRAD_DIRECT = os.environ.get("DIG_DGRAD_DIRECT", "1") != "0"     # the proj / qkv data gradients as direct-form GEMMs on the transposed weight copies
+
+
+def dgrad_direct_tile_code(rows, J):
+    """DIG_GEMM_TILE_* of a data-gradient GEMM in its DIRECT form dx[rows, J] = dy wt^T on the K-contiguous copy wt = w^T [J, K], or 0: keep
+    the transpose-read form.  Measured for the 384-wide gradients of ViT-S on the 256 x 192 persistent tiles (tools/gpu_dgrad_form_probe.py)."""
+    return 264 if (DGRAD_DIRECT and rows >= 8192 and J % 192 == 0 and J % 256 != 0) else 0
+
+
 def dgrad_tile_code(rows, J, drop=None):
     """DIG_GEMM_TILE_* of a data-gradient GEMM dx[rows, J] = dy w."""
     if rows <= 2048:
@@ -559,8 +568,8 @@ class BlockFwd(ctypes.Structure):
 
 class BlockBwd(ctypes.Structure):
     """include/dig_block_types.h `dig_block_bwd_t`."""
-    _fields_ = ([(k, _I) for k in ("n_img", "heads", "D", "F", "rows", "tile_dgrad")] + [("scale", _F)] +
-                [(k, _VP) for k in ("qkv_w", "proj_w", "w2t", "w1t", "projt", "n1_g", "n1_b", "n2_g", "n2_b",
+    _fields_ = ([(k, _I) for k in ("n_img", "heads", "D", "F", "rows", "tile_dgrad", "tile_direct")] + [("scale", _F)] +
+                [(k, _VP) for k in ("qkv_w", "proj_w", "w2t", "w1t", "projt", "proj_wt", "qkv_wt", "n1_g", "n1_b", "n2_g", "n2_b",
                                     "g_n1_g", "g_n1_b", "g_qkv_w", "g_q_b", "g_v_b", "g_proj_w", "g_proj_b", "g_n2_g", "g_n2_b", "g_fc1_w", "g_fc1_b",
                                     "g_fc2_w", "g_fc2_b",
                                     "x", "ln1", "mu1", "rs1", "qkv", "ctx", "lse", "x_mid", "ln2", "mu2", "rs2", "pre", "act", "dy",

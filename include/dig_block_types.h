@@ -35,11 +35,17 @@ typedef struct dig_block_fwd {
 typedef struct dig_block_bwd {
   int n_img, heads, D, F, rows;
   int tile_dgrad;                      /* DIG_GEMM_TILE_* of the two data-gradient GEMMs (proj, qkv) */
+  int tile_direct;                     /* DIG_GEMM_TILE_* of their DIRECT form on the K-contiguous weight copies proj_wt / qkv_wt (0: not used) */
   float scale;
   /* parameters; w2t = fc2.weight^T [F, D], w1t = fc1.weight^T [D, F] (dig_transpose_bf16) */
   const void* qkv_w; const void* proj_w; const void* w2t; const void* w1t;
   const void* projt;                   /* proj.weight^T [D, D] (dig_transpose_bf16), or NULL: with fuse_ln2, non-NULL puts the projection's data gradient
                                           into the fused MLP backward launch as well (dig_mlp_chain_bwd_ln_proj) instead of its own GEMM launch */
+  /* K-contiguous copies proj.weight^T [D, D] and qkv.weight^T [D, 3D] (dig_adamw_step_tr leaves them; dig_transpose_bf16 otherwise), or
+   * NULL: with tile_direct != 0 the two data gradients dctx = dx_mid Wproj and dln1 = dqkv Wqkv run as direct-form GEMMs on them (both
+   * operands read along K: the 256 x 192 persistent tiles of the forward) instead of the transpose-read form on the [out, in] weights --
+   * bit-identical results, 57.9 against 69.0 us (qkv) and 28.5 against 31.9 us (proj) per launch at 65 536 rows (tools/gpu_dgrad_form_probe.py) */
+  const void* proj_wt; const void* qkv_wt;
   const float* n1_g; const float* n1_b; const float* n2_g; const float* n2_b;
   /* fp32 gradients, accumulated into (contiguous [out, in] matrices); g_q_b / g_v_b = the q and v thirds of the qkv bias gradient */
   float* g_n1_g; float* g_n1_b; float* g_qkv_w; float* g_q_b; float* g_v_b; float* g_proj_w; float* g_proj_b;

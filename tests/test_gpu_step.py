@@ -890,7 +890,7 @@ def test_vit_base_b16_every_tensor_gradient_vs_oracle():
 
 def test_optimizer_launch_leaves_shadow_and_transposes_for_the_next_forward():
     """dig_adamw_step_tr (the default: optim_factory.FOLD_SHADOW) writes the bf16 operand shadow and the transposed MLP / projection
-    weights, and the next forward launches neither its cast nor its three transposes: four steps are bit-identical to the plan that
+    weights, and the next forward launches neither its cast nor its four transposes: four steps are bit-identical to the plan that
     rebuilds both every step; a parameter written behind the optimizer's back (a torch in-place operation on the arena, load_state_dict)
     is seen and the copies are rebuilt."""
     from dig_amd import ops, optim_factory
@@ -934,9 +934,9 @@ def test_optimizer_launch_leaves_shadow_and_transposes_for_the_next_forward():
         l1, p1, c1 = run(True, poke)
         l0, p0, c0 = run(False, poke)
         assert l1 == l0 and torch.equal(p1, p0), poke
-        assert c0 == {"cast": 4, "tr": 12}
+        assert c0 == {"cast": 4, "tr": 16}                               # (four weight kinds: fc2, fc1, proj, qkv)
         # folded: the first forward (and the one behind a foreign write) rebuilds, the others launch nothing
-        assert c1 == ({"cast": 1, "tr": 3} if poke is None else {"cast": 2, "tr": 6}), (poke, c1)
+        assert c1 == ({"cast": 1, "tr": 4} if poke is None else {"cast": 2, "tr": 8}), (poke, c1)
 
 
 @pytest.mark.parametrize("switch", ["wgrad_off", "wgrad_pair", "wgrad_wa1", "wgrad_side_stream", "chain_mask3", "dgrad_128", "fwd_side", "fwd_serial",
