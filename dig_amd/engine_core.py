@@ -511,7 +511,7 @@ class _Step:
         wT = getattr(self, "wT", None)
         if chain and wT is None:
             wT = self.mlp_weight_transposes(ew)
-        elif chain:
+        elif wT is not None:
             for pair_ in wT:                                            # made on the side stream in forward(), read here on the main one
                 for t in pair_:
                     t.record_stream(main)
@@ -611,7 +611,9 @@ class _Step:
             else:
                 on_side(lambda: (wg(dact, ln2, g["mlp.fc1.weight"]), csum(bparts, g["mlp.fc1.bias"])), dact, ln2, bparts)   # (0.3 ms/step vs a 201 MB pass)
             if dln2 is None:
-                dln2 = ops.linear_dgrad(dact, blk["mlp.fc1.weight"])
+                dln2 = ops.dgrad_direct(dact, wT[i][1]) if wT is not None else None        # (direct form on fc1.weight^T where it pays)
+                if dln2 is None:
+                    dln2 = ops.linear_dgrad(dact, blk["mlp.fc1.weight"])
             if chain and lnp is not None:
                 side_later(lambda lnp=lnp, g=g: ops.layernorm_finalize_parts(lnp, g["norm2.weight"], g["norm2.bias"], g["mlp.fc2.bias"]), lnp)
             else:
@@ -630,10 +632,11 @@ class _Step:
             else:
                 on_side(lambda dzp=dzp: wg(dzp, ctx, g["attn.proj.weight"]), dzp, ctx)
             _mark("blk: LayerNorm backward (norm2)", dev)
-            td = ops.dgrad_direct_tile_code(dzp.shape[0], D) if (chain_any and wT is not None) else 0
             if not chain or dctx is None:
-                # (direct form on proj.weight^T where the tile plan has one: both operands K-contiguous, bit-identical to the transpose-read form)
-                dctx = (ops.gemm(dzp, wT[i][2], dzp.shape[0], D, D, bk=td) if td else ops.linear_dgrad(dzp, blk["attn.proj.weight"]))
+                # (direct form on proj.weight^T where it pays: both operands K-contiguous, bit-identical to the transpose-read form)
+                dctx = ops.dgrad_direct(dzp, wT[i][2]) if wT is not None else None
+                if dctx is None:
+                    dctx = ops.linear_dgrad(dzp, blk["attn.proj.weight"])
             _mark("blk: proj data gradient", dev)
             gb = g["qkv_bias"]
             if FUSED_QV_BIAS_SUMS:
@@ -659,7 +662,9 @@ class _Step:
                 else:
                     on_side(lambda: (wg(dqkv, ln1, g["attn.qkv.weight"]),
                                      ops.colsum(dqkv, gb[:D], cols=D), ops.colsum(dqkv[:, 2 * D:], gb[2 * D:], cols=D)), dqkv, ln1)
-            dln1 = (ops.gemm(dqkv, wT[i][3], dqkv.shape[0], D, 3 * D, out=dctx, bk=td) if td else ops.linear_dgrad(dqkv, blk["attn.qkv.weight"], out=dctx))
+            dln1 = ops.dgrad_direct(dqkv, wT[i][3], out=dctx) if wT is not None else None
+            if dln1 is None:
+                dln1 = ops.linear_dgrad(dqkv, blk["attn.qkv.weight"], out=dctx)
             _mark("blk: qkv data gradient", dev)
             dx, fin1, ws1 = ops.layernorm_bwd(dln1, x, blk["norm1.weight"], blk["norm1.bias"], mu1, rs1, dx_mid, g["norm1.weight"],
                                               g["norm1.bias"], out=dln1, dres_colsum=None if ds else g["attn.proj.bias"], defer=True)
@@ -860,9 +865,10 @@ class _Step:
         def momentum_branch(heads=True):
             ops.ema_update(M._flat["momentum"], M._flat["online"], M.shadow("momentum"), M.n_ema, m)
             self.wT = None
-            if training and ops.mlp_chain_supported(D, M.F, 2 * B * N) and (ops.MLP_CHAIN_MASK & 4):
-                # K-contiguous copies of the online MLP weights for the fused backward: two launches, in front of the momentum encoder
-                # (they read nothing but this step's bf16 weight shadow)
+            if training and ((ops.mlp_chain_supported(D, M.F, 2 * B * N) and (ops.MLP_CHAIN_MASK & 4)) or
+                             (ops.DGRAD_DIRECT and 2 * B * N >= 8192)):
+                # K-contiguous copies of the online weights for the backward (the fused MLP backward's operands; the direct-form data
+                # gradients): left by the optimizer launch, or rebuilt here in front of the momentum encoder from this step's shadow
                 self.wT = self.mlp_weight_transposes(ew_on, fresh)
             enc_m, _ = self.encoder_forward(ew_mo, images, aug, mask_u8, False, path=self.path_mo)
             return enc_m, (momentum_heads(enc_m) if heads else None)
@@ -991,7 +997,8 @@ class _Step:
         views = mim_views
         self.gen_views = views
         self.wT = None
-        if training and ops.mlp_chain_supported(M.D, M.F, views * self.B * M.N) and (ops.MLP_CHAIN_MASK & 4):
+        if training and ((ops.mlp_chain_supported(M.D, M.F, views * self.B * M.N) and (ops.MLP_CHAIN_MASK & 4)) or
+                         (ops.DGRAD_DIRECT and views * self.B * M.N >= 8192)):
             self.wT = self.mlp_weight_transposes(ew_on, fresh)
         enc_raw, self.saved_enc = self.encoder_forward(ew_on, images, aug, mask_u8, True, views=views, path=self.path_on)
         f32 = M._f32

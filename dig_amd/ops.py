@@ -293,6 +293,22 @@ def dgrad_direct_tile_code(rows, J):
     return 264 if (DGRAD_DIRECT and rows >= 8192 and J % 192 == 0 and J % 256 != 0) else 0
 
 
+def dgrad_direct(dy, wt, out=None):
+    """dx[rows, J] = dy[rows, K] wt[J, K]^T with wt = w^T, the K-contiguous copy of a Linear weight w [K out, J in] (what dig_adamw_step_tr
+    leaves): the data gradient as a direct-form GEMM -- bit-identical to linear_dgrad(dy, w), faster on the tall shapes of the encoder
+    (tools/gpu_dgrad_form_probe.py: 384-wide 28.5 / 57.9 us against 31.9 / 69.0; 512-wide 83.8 / 197 / 258 us against 99 / 230 / 301).
+    Returns None where the transpose-read form stays (small row counts, DIG_DGRAD_DIRECT=0)."""
+    rows, K = dy.shape
+    J = wt.shape[0]
+    if not DGRAD_DIRECT or rows < 8192:
+        return None
+    if J % 192 == 0 and J % 256 != 0:
+        return gemm(dy, wt, rows, J, K, out=out, bk=264)
+    if J % 256 == 0:
+        return gemm(dy, wt, rows, J, K, out=out, bk=244) if K >= 1024 else linear_fwd(dy, wt, out=out)
+    return None
+
+
 def dgrad_tile_code(rows, J, drop=None):
     """DIG_GEMM_TILE_* of a data-gradient GEMM dx[rows, J] = dy w."""
     if rows <= 2048:
