@@ -402,6 +402,10 @@ def main():
     ap.add_argument("--model-kind", default="simmim_moco", choices=["simmim_moco", "simmim", "moco"],
                     help="simmim_moco = the headline model (pretrain_simmim_moco_ori_*); simmim / moco = the reference's single-objective "
                          "factories (pretrain_simmim_ori_* Gen-only, pretrain_moco_ori_* Dis-only): their own JSON line, not the headline")
+    ap.add_argument("--num-windows", type=int, default=4, help="README: 4; the reference's argparse default is 5 (uneven pooling windows)")
+    ap.add_argument("--patchnet-name", default="no_patchtrans", choices=["no_patchtrans", "regular"],
+                    help="README: no_patchtrans; the reference's argparse default is regular (PatchNet with its 2-block patch transformer)")
+    ap.add_argument("--drop-path", type=float, default=0.0, help="stochastic depth rate (--drop_path of the reference driver; README: 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mim-only", action="store_true", help="skip the extra measurement of the other workload")
     ap.add_argument("--workload", default="mim_moco", choices=["mim_moco", "mim_only"],
@@ -439,8 +443,11 @@ def main():
     model_name = f"{KIND_FACTORY[a.model_kind]}_vit_{a.model}_patch4_32x128"
     if a.model_kind != "simmim_moco":
         a.no_mim_only = True                          # (one objective: there is no "other workload" of the same model)
-    model = create_model(model_name, pretrained=False, drop_path_rate=0.0, drop_block_rate=None, mlp_dim=4096, dim=256, T=0.2,
-                         num_windows=4, encoder_type='vit', queue_size=65536, patchnet_name='no_patchtrans')
+    model = create_model(model_name, pretrained=False, drop_path_rate=a.drop_path, drop_block_rate=None, mlp_dim=4096, dim=256, T=0.2,
+                         num_windows=a.num_windows, encoder_type='vit', queue_size=65536, patchnet_name=a.patchnet_name)
+    readme = a.num_windows == 4 and a.patchnet_name == "no_patchtrans" and a.drop_path == 0.0
+    if not readme:
+        a.no_cpu_baseline = True                      # (the CPU port is timed on the README recipe)
     model.to(dev)
     force_dist = world > 1 or (os.environ.get("DIG_FORCE_DIST") == "1" and torch.distributed.is_initialized())
     run_model = DistributedDataParallel(model) if force_dist else model
@@ -641,7 +648,8 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{model_name}: full train_one_epoch step, {WORKLOAD_TEXT[a.workload]}; dim 256, mlp 4096, m 0.99 cos, "
-                                   f"T 0.2, 4 windows, mask 0.7, 2 views, AdamW wd 0.1, {B} samples/GPU, random-init weights",
+                                   f"T 0.2, {a.num_windows} windows ({a.patchnet_name}), drop_path {a.drop_path}, mask 0.7, 2 views, AdamW wd 0.1, {B} samples/GPU, "
+                                   "random-init weights",
                        "global_batch": B * world, "parallelism": f"dp{world}", "loss": float(stats.get("loss", float('nan')))},
             "step_mfma_frac": (value / world * fl / PEAK_BF16) if fl else None, "flop_per_sample": fl,
             # the whole step against the HBM roof: PMC-measured bytes of every kernel family per step (profiles/r05_pmc_traffic.json,
