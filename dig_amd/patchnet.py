@@ -49,11 +49,25 @@ def forward(step, feat, pooled, pre, arena, n_img, save):
         yn, mux, rsx = ops.layernorm_fwd(y, f32[n["norm1.weight"]], f32[n["norm1.bias"]], EPS)
         kn, muk, rsk = ops.layernorm_fwd(feat, f32[n["norm1.weight"]], f32[n["norm1.bias"]], EPS)
         q = ops.linear_fwd(yn, w16[n["attn.linear_q.weight"]])
-        kv = ops.linear_fwd(kn, _kv_view(M, sh, n["attn.linear_k.weight"]))
-        a = torch.empty((n_img * nw, D), device=dev, dtype=BF16)
-        lse = torch.empty((n_img, H, nw), device=dev, dtype=F32)
-        L.call("dig_seq_attn_fwd", L.ptr(q), D, L.ptr(kv), 2 * D, L.ptr(kv[:, D:]), 2 * D, L.ptr(a), D, L.ptr(lse), n_img, H, nw, N, cf(scale), 0,
-               None, L.stream())
+        if N == 256 and D == H * 64:
+            # on the encoder's MFMA attention kernels (as the recognition decoder's cross-attention, dig_amd/finetune.py): the nw queries of
+            # an image sit in rows [0, nw) of a fused q | k | v buffer of 256 rows per image, the k | v GEMM writes its columns [D, 3D), and the
+            # kernels compute the first query block only (q_rows); rows nw..31 are zero queries with a zero output gradient.
+            # (dig_seq_attn_fwd / _bwd -- a thread per key -- took 257 / 426 us per launch here: 1.9 ms per step for 5 x 256 scores per head)
+            kv = torch.empty((n_img * N, 3 * D), device=dev, dtype=BF16)
+            ops.gemm(kn, _kv_view(M, sh, n["attn.linear_k.weight"]), n_img * N, 2 * D, D, out=kv[:, D:], ldc=3 * D)
+            fq = kv.view(n_img, N, 3 * D)[:, :, :D]
+            fq[:, nw:32].zero_()
+            fq[:, :nw] = (q * scale).view(n_img, nw, D)                 # (scale = 2^-3: exact in bf16)
+            ctx, lse = ops.attn_fwd(kv, n_img, H, D, q_rows=nw)
+            a = ctx.view(n_img, N, D)[:, :nw].reshape(n_img * nw, D)
+            lse = (lse, ctx)
+        else:
+            kv = ops.linear_fwd(kn, _kv_view(M, sh, n["attn.linear_k.weight"]))
+            a = torch.empty((n_img * nw, D), device=dev, dtype=BF16)
+            lse = torch.empty((n_img, H, nw), device=dev, dtype=F32)
+            L.call("dig_seq_attn_fwd", L.ptr(q), D, L.ptr(kv), 2 * D, L.ptr(kv[:, D:]), 2 * D, L.ptr(a), D, L.ptr(lse), n_img, H, nw, N, cf(scale), 0,
+                   None, L.stream())
         y1 = ops.linear_fwd(a, w16[n["attn.proj.weight"]], bias=f32[n["attn.proj.bias"]], resid=yn)
         h2, mu2, rs2 = ops.layernorm_fwd(y1, f32[n["norm2.weight"]], f32[n["norm2.bias"]], EPS)
         pre_act = torch.empty((n_img * nw, M.F), device=dev, dtype=BF16) if save else None
@@ -94,10 +108,20 @@ def backward(step, dout, pre, saved, n_img):
         # y1 = yn + proj(a)
         side(lambda dy1=dy1, a=a, n=n: (ops.linear_wgrad(dy1, a, g32[n["attn.proj.weight"]]), ops.colsum(dy1, g32[n["attn.proj.bias"]])), dy1, a)
         da = ops.linear_dgrad(dy1, w16[n["attn.proj.weight"]])
-        dq = torch.empty_like(q)
-        dkv = torch.empty_like(kv)
-        L.call("dig_seq_attn_bwd", L.ptr(q), D, L.ptr(kv), 2 * D, L.ptr(kv[:, D:]), 2 * D, L.ptr(da), D, L.ptr(lse), L.ptr(dq), D, L.ptr(dkv), 2 * D,
-               L.ptr(dkv[:, D:]), 2 * D, n_img, H, nw, N, cf(scale), 0, None, L.stream())
+        if isinstance(lse, tuple):                                       # MFMA path (see forward): kv = the fused q | k | v buffer
+            lse_, ctx = lse
+            dctx = torch.empty((n_img * N, D), device=dev, dtype=BF16)
+            dv_ = dctx.view(n_img, N, D)
+            dv_[:, nw:32].zero_()
+            dv_[:, :nw] = da.view(n_img, nw, D)
+            dfused = ops.attn_bwd(kv, ctx, dctx, lse_, n_img, H, D, scale, q_rows=nw)
+            dq = dfused.view(n_img, N, 3 * D)[:, :nw, :D].reshape(n_img * nw, D)
+            dkv = dfused[:, D:]                                           # [n_img * N, 2 D] view, row stride 3 D
+        else:
+            dq = torch.empty_like(q)
+            dkv = torch.empty_like(kv)
+            L.call("dig_seq_attn_bwd", L.ptr(q), D, L.ptr(kv), 2 * D, L.ptr(kv[:, D:]), 2 * D, L.ptr(da), D, L.ptr(lse), L.ptr(dq), D, L.ptr(dkv), 2 * D,
+                   L.ptr(dkv[:, D:]), 2 * D, n_img, H, nw, N, cf(scale), 0, None, L.stream())
         side(lambda dq=dq, yn=yn, n=n: ops.linear_wgrad(dq, yn, g32[n["attn.linear_q.weight"]]), dq, yn)
         gkv = _kv_view(M, gflat, n["attn.linear_k.weight"])
         side(lambda dkv=dkv, kn=kn, gkv=gkv: ops.wgrad(dkv, kn, gkv, 2 * D, D, kn.shape[0]), dkv, kn)
