@@ -193,7 +193,10 @@ def test_step_vs_reference_golden_fixture(name):
             q_hip, q_bf = grads[n].norm().item() / norms[i], bf_g[n].float().norm().item() / norms[i]
             turn = (1 - cosf(bf_g[n].float().reshape(1, -1), ref_g[n].reshape(1, -1)).item()) if ref_g is not None else 0.0
             # (+ an absolute floor of 1e-4 of the whole gradient's norm: see test_both_views_mim_vs_oracle)
-            assert abs(q_hip - 1) <= 2 * abs(q_bf - 1) + 3e-2 + turn + 1e-4 * tot / norms[i], (n, q_hip, q_bf, turn, norms[i] / tot)
+            # (2 x turn: the device's rounding noise is as large as the yardstick's and independent of it; the patch transformer's fixture at
+            #  B = 4 has every tensor behind two 40-row BatchNorm stacks turned by 2.5 % -- tools/gpu_patchnet_probe.py shows the yardstick
+            #  itself 3-4 % long on the same tensors at B = 16, and test_patch_transformer_forward_backward_vs_oracle pins the module alone to 3 %)
+            assert abs(q_hip - 1) <= 2 * abs(q_bf - 1) + 3e-2 + 2 * turn + 1e-4 * tot / norms[i], (n, q_hip, q_bf, turn, norms[i] / tot)
     # mask gather order is bit-exact => vis_out rows line up with the reference's: compare the full [B, 179, 48] tensor, captured
     # from the step's own forward (before the optimizer touched the weights)
     if cfg.use_pixel:
@@ -266,6 +269,50 @@ def test_single_objective_two_steps_vs_oracle(kind):
     for k in keys:
         assert close(st1[k], ref1[k], rtol=3e-2, atol=3e-3), (1, k, st1[k], ref1[k])
     assert opt._step == 2
+
+
+@pytest.mark.parametrize("n_img,nw", [(16, 5), (8, 4)])
+def test_patch_transformer_forward_backward_vs_oracle(n_img, nw):
+    """dig_amd/patchnet.py (PatchNet with its patch transformer, --patchnet_name regular) in isolation: output, every parameter gradient and
+    the gradients w.r.t. the image tokens and the pooled windows against fp32 autograd through oracle.patch_extractor on the same bf16
+    inputs -- the attention on the encoder's MFMA kernels with q_rows = num_windows."""
+    from dig_amd import engine_core, patchnet, ops
+    cfg = dataclasses.replace(O.DiGConfig(**O.TINY), patchnet="regular", num_windows=nw)
+    P, S = O.det_state(cfg, 51)
+    model = build_model(cfg, P, S)
+    dev = torch.device("cuda:0")
+    D, N = cfg.embed_dim, 256
+    torch.manual_seed(3)
+    feat = torch.randn(n_img * N, D, device=dev).bfloat16()
+    dout = (torch.randn(n_img * nw, D, device=dev) * 0.1).bfloat16()
+    ops.cast_f32_to_bf16(model._flat["online"], model.shadow("online"))
+    model.flat_grads.zero_()
+    step = engine_core._Step(model)
+    pooled = torch.empty((n_img * nw, D), device=dev, dtype=torch.bfloat16)
+    ops.window_pool_fwd(feat, pooled, n_img, model.gh, model.gw, nw, D)
+    out, saved = patchnet.forward(step, feat, pooled, "patch_extractor", "online", n_img, True)
+    dpooled, dfeat = patchnet.backward(step, dout, "patch_extractor", saved, n_img)
+    torch.cuda.synchronize()
+    # fp32 reference: the oracle's patch_extractor (pinned to the reference by tiny_w1_regular) with the pooling cut out of the graph
+    Pf = {k: v.clone().requires_grad_(k.startswith("patch_extractor.")) for k, v in P.items()}
+    xf = feat.float().cpu().view(n_img, N, D).requires_grad_(True)
+    pf = pooled.float().cpu().view(n_img, nw, D).requires_grad_(True)
+    import unittest.mock as um
+    with um.patch.object(O, "window_pool", lambda x, c: pf):
+        ref = O.patch_extractor(xf, Pf, "patch_extractor.", cfg)
+    ref.backward(dout.float().cpu().view(n_img, nw, D))
+
+    def close_(a, b, tol, name):
+        a, b = a.detach().float().cpu().reshape(-1), b.detach().float().reshape(-1)
+        err = ((a - b).norm() / b.norm()).item()
+        assert err < tol, (name, err, (a.norm() / b.norm()).item())
+    close_(out, ref, 2e-2, "out")
+    close_(dpooled, pf.grad, 3e-2, "d pooled")
+    close_(dfeat, xf.grad, 3e-2, "d tokens")
+    for n_, sp in model.specs.items():
+        if n_.startswith("patch_extractor."):
+            g = model.flat_grads[sp.offset:sp.offset + sp.numel]
+            close_(g, Pf[n_].grad, 3e-2, n_)
 
 
 def test_gen_only_skips_the_unread_view():
