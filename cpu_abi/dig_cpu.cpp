@@ -540,6 +540,80 @@ int dig_bn_update_running(const float* sums, float n_total, float momentum, floa
   return DIG_OK;
 }
 
+int dig_bn_fused_supported(int rows, int C) { return rows >= 2 && rows <= 4096 && C >= 256 && (C % 32) == 0; }
+
+int dig_bn_fwd_fused(const void* x_, float eps, const float* gamma, const float* beta, int relu, void* y_, float* mean_out, float* rstd_out,
+                     float momentum, float* running_mean, float* running_var, int rows, int C, hipStream_t) {
+  if (!x_ || !y_ || !mean_out || !rstd_out || (gamma == nullptr) != (beta == nullptr) || (running_mean == nullptr) != (running_var == nullptr))
+    return DIG_ERR_ARG;
+  if (!dig_bn_fused_supported(rows, C)) return DIG_ERR_UNSUPPORTED;
+  const bf16_t* x = (const bf16_t*)x_;
+  bf16_t* y = (bf16_t*)y_;
+  const float n = (float)rows, inv_n = 1.0f / n;
+#pragma omp parallel for
+  for (int c = 0; c < C; ++c) {
+    float lane1[64], lane2[64];                                        // the device's row lanes: rows l, l + 64, ... summed per lane, lanes in order
+    for (int l = 0; l < 64; ++l) {
+      float a = 0.f, b = 0.f;
+      for (int r = l; r < rows; r += 64) { const float v = bf2f(x[(size_t)r * C + c]); a += v; b += v * v; }
+      lane1[l] = a; lane2[l] = b;
+    }
+    float s1 = 0.f, s2 = 0.f;
+    for (int l = 0; l < 64; ++l) { s1 += lane1[l]; s2 += lane2[l]; }
+    const float mu = s1 * inv_n, var = std::max(s2 * inv_n - mu * mu, 0.f), rs = 1.0f / std::sqrt(var + eps);
+    mean_out[c] = mu; rstd_out[c] = rs;
+    if (running_mean) {
+      const float mr = s1 / n, vr = std::max(s2 / n - mr * mr, 0.f);
+      running_mean[c] = running_mean[c] * (1.f - momentum) + mr * momentum;
+      running_var[c] = running_var[c] * (1.f - momentum) + vr * (n / (n - 1.f)) * momentum;
+    }
+    for (int r = 0; r < rows; ++r) {
+      float o = (bf2f(x[(size_t)r * C + c]) - mu) * rs;
+      if (gamma) o = o * gamma[c] + beta[c];
+      if (relu) o = std::max(o, 0.f);
+      y[(size_t)r * C + c] = f2bf(o);
+    }
+  }
+  return DIG_OK;
+}
+
+int dig_bn_bwd_fused(const void* dy_, const void* x_, const float* mean, const float* rstd, const float* gamma, const float* beta, int relu,
+                     float* dbeta_acc, float* dgamma_acc, void* dx_, int rows, int C, hipStream_t) {
+  if (!dy_ || !x_ || !mean || !rstd || !dx_ || (gamma == nullptr) != (beta == nullptr) || (dbeta_acc == nullptr) != (dgamma_acc == nullptr))
+    return DIG_ERR_ARG;
+  if (!dig_bn_fused_supported(rows, C)) return DIG_ERR_UNSUPPORTED;
+  const bf16_t* dy = (const bf16_t*)dy_;
+  const bf16_t* x = (const bf16_t*)x_;
+  bf16_t* dx = (bf16_t*)dx_;
+  const float inv_n = 1.0f / (float)rows;
+#pragma omp parallel for
+  for (int c = 0; c < C; ++c) {
+    const float g0 = gamma ? gamma[c] : 1.f, b0 = gamma ? beta[c] : 0.f;
+    float lane1[64], lane2[64];
+    for (int l = 0; l < 64; ++l) {
+      float a = 0.f, b = 0.f;
+      for (int r = l; r < rows; r += 64) {
+        const float xh = (bf2f(x[(size_t)r * C + c]) - mean[c]) * rstd[c];
+        float d = bf2f(dy[(size_t)r * C + c]);
+        if (relu && !(g0 * xh + b0 > 0.f)) d = 0.f;
+        a += d; b += d * xh;
+      }
+      lane1[l] = a; lane2[l] = b;
+    }
+    float s1 = 0.f, s2 = 0.f;
+    for (int l = 0; l < 64; ++l) { s1 += lane1[l]; s2 += lane2[l]; }
+    if (dbeta_acc) { dbeta_acc[c] += s1; dgamma_acc[c] += s2; }
+    s1 *= inv_n; s2 *= inv_n;
+    for (int r = 0; r < rows; ++r) {
+      const float xh = (bf2f(x[(size_t)r * C + c]) - mean[c]) * rstd[c];
+      float g = bf2f(dy[(size_t)r * C + c]);
+      if (relu && !(g0 * xh + b0 > 0.f)) g = 0.f;
+      dx[(size_t)r * C + c] = f2bf(g0 * rstd[c] * (g - s1 - xh * s2));
+    }
+  }
+  return DIG_OK;
+}
+
 int dig_bn_fwd_apply_running(const void* x, const float* sums, float n_total, float eps, const float* gamma, const float* beta, int relu, void* y,
                              float* mean_out, float* rstd_out, float momentum, float* running_mean, float* running_var, int rows, int C,
                              hipStream_t st) {

@@ -369,6 +369,116 @@ __global__ void bn_running_kernel(const float* __restrict__ sums, float n, float
   rv[c] = rv[c] * (1.f - momentum) + var * (n / (n - 1.f)) * momentum;
 }
 
+
+// ---------------- BatchNorm of a FEW-ROW layer in one launch (single rank: no cross-rank reduction sits between statistics and apply) ---------
+// The BN-MLP heads' 4096 / 256-wide layers see 8 B = 1 024 pooled rows: three launches per layer (column statistics in row strips, their
+// fold, apply) of 10-25 us each for 16 MB of traffic.  Here a workgroup owns a slab of 32 columns for ALL rows: thread (rl, cq) = 64 row
+// lanes x 4 column groups of 8 walks rows rl, rl + 64, ... twice -- sums (folded over the row lanes through LDS in lane order: fixed order,
+// bit-reproducible), then the apply on the second, L2-hot read of its 64 KiB slab.  Same expressions as the three-launch path; the
+// summation ORDER over rows differs (row lanes instead of strips), so the two paths agree to fp32 round-off, not bit for bit.
+constexpr int BNF_COLS = 32, BNF_LANES = 64;
+
+// MODE 0 forward: y = [relu](gamma xhat + beta), mean / rstd out, running statistics;  MODE 1 backward: dx, += dbeta / dgamma
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_fused_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, const float* __restrict__ mean_in,
+                                                       const float* __restrict__ rstd_in, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, int relu, float eps, bf16_t* __restrict__ out,
+                                                       float* __restrict__ mean_out, float* __restrict__ rstd_out, float momentum,
+                                                       float* __restrict__ run_mean, float* __restrict__ run_var, float* __restrict__ dbeta_acc,
+                                                       float* __restrict__ dgamma_acc, int rows, int C) {
+  __shared__ float red[BNF_LANES][4][17];
+  __shared__ float tot[4][16];
+  const int tid = threadIdx.x, cq = tid & 3, rl = tid >> 2;
+  const int c = blockIdx.x * BNF_COLS + cq * 8;
+  float mu[8], rs[8], gm[8], bt[8], a[8], b[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { a[k] = b[k] = 0.f; gm[k] = 1.f; bt[k] = 0.f; mu[k] = 0.f; rs[k] = 1.f; }
+  if (gamma) { load8f(gamma + c, gm); load8f(beta + c, bt); }
+  if (MODE == 1) { load8f(mean_in + c, mu); load8f(rstd_in + c, rs); }
+  for (int r = rl; r < rows; r += BNF_LANES) {
+    float xv[8];
+    load_row<8>(x + (size_t)r * C + c, xv);
+    if (MODE == 0) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { a[k] += xv[k]; b[k] += xv[k] * xv[k]; }
+    } else {
+      float dv[8];
+      load_row<8>(dy + (size_t)r * C + c, dv);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float xh = (xv[k] - mu[k]) * rs[k];
+        float d = dv[k];
+        if (relu && !(gm[k] * xh + bt[k] > 0.f)) d = 0.f;
+        a[k] += d; b[k] += d * xh;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { red[rl][cq][k] = a[k]; red[rl][cq][8 + k] = b[k]; }
+  __syncthreads();
+  if (tid < 64) {                                                     // 4 column groups x 16 sums: one thread each, row lanes in order
+    const int q = tid >> 4, e = tid & 15;
+    float t = 0.f;
+    for (int l = 0; l < BNF_LANES; ++l) t += red[l][q][e];
+    tot[q][e] = t;
+  }
+  __syncthreads();
+  float s1[8], s2[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { s1[k] = tot[cq][k]; s2[k] = tot[cq][8 + k]; }
+  if (MODE == 0) {
+    const float n_total = (float)rows, inv_n = 1.0f / n_total;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      mu[k] = s1[k] * inv_n;
+      const float var = fmaxf(s2[k] * inv_n - mu[k] * mu[k], 0.f);
+      rs[k] = rsqrtf(var + eps);
+      if (rl == 0) {
+        mean_out[c + k] = mu[k]; rstd_out[c + k] = rs[k];
+        if (run_mean) {                                                // bn_running_kernel's own expressions
+          const float mr = s1[k] / n_total;
+          const float vr = fmaxf(s2[k] / n_total - mr * mr, 0.f);
+          run_mean[c + k] = run_mean[c + k] * (1.f - momentum) + mr * momentum;
+          run_var[c + k] = run_var[c + k] * (1.f - momentum) + vr * (n_total / (n_total - 1.f)) * momentum;
+        }
+      }
+    }
+    for (int r = rl; r < rows; r += BNF_LANES) {
+      float v[8];
+      load_row<8>(x + (size_t)r * C + c, v);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        float o = (v[k] - mu[k]) * rs[k];
+        if (gamma) o = o * gm[k] + bt[k];
+        if (relu) o = fmaxf(o, 0.f);
+        v[k] = o;
+      }
+      store_row<8>(out + (size_t)r * C + c, v);
+    }
+  } else {
+    if (rl == 0 && dbeta_acc) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { dbeta_acc[c + k] += s1[k]; dgamma_acc[c + k] += s2[k]; }
+    }
+    const float inv_n = 1.0f / (float)rows;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { s1[k] *= inv_n; s2[k] *= inv_n; }
+    for (int r = rl; r < rows; r += BNF_LANES) {
+      float v[8], d[8];
+      load_row<8>(x + (size_t)r * C + c, v);
+      load_row<8>(dy + (size_t)r * C + c, d);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float xh = (v[k] - mu[k]) * rs[k];
+        float g = d[k];
+        if (relu && !(gm[k] * xh + bt[k] > 0.f)) g = 0.f;
+        v[k] = gm[k] * rs[k] * (g - s1[k] - xh * s2[k]);
+      }
+      store_row<8>(out + (size_t)r * C + c, v);
+    }
+  }
+}
+
 inline int ln_grid(int rows) { return std::max(1, std::min(2048, (rows + 3) / 4)); }
 
 }  // namespace
@@ -528,6 +638,34 @@ extern "C" int dig_bn_bwd_apply(const void* dy, const void* x, const float* mean
   const int grid = bn_apply_grid(total8, C);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)x, mean, rstd,
                      gamma, beta, relu, sums, 1.0f / n_total, (bf16_t*)dx, total8, C);
+  return dig_check_launch();
+}
+
+
+// Few-row BatchNorm layers in ONE launch each (single rank only: with a process group the cross-rank reduction of the statistics sits between
+// dig_bn_stats and dig_bn_fwd_apply).  rows <= 4096, C a multiple of 32, at least 32 column slabs.
+extern "C" int dig_bn_fused_supported(int rows, int C) { return rows >= 2 && rows <= 4096 && C >= 256 && (C % BNF_COLS) == 0; }
+
+extern "C" int dig_bn_fwd_fused(const void* x, float eps, const float* gamma, const float* beta, int relu, void* y, float* mean_out,
+                                float* rstd_out, float momentum, float* running_mean, float* running_var, int rows, int C, hipStream_t stream) {
+  if (!x || !y || !mean_out || !rstd_out || (gamma == nullptr) != (beta == nullptr) || (running_mean == nullptr) != (running_var == nullptr))
+    return DIG_ERR_ARG;
+  if (!dig_bn_fused_supported(rows, C)) return DIG_ERR_UNSUPPORTED;
+  if (!aligned16(x) || !aligned16(y)) return DIG_ERR_ALIGN;
+  hipLaunchKernelGGL(bn_fused_kernel<0>, dim3(C / BNF_COLS), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)nullptr, (const float*)nullptr,
+                     (const float*)nullptr, gamma, beta, relu, eps, (bf16_t*)y, mean_out, rstd_out, momentum, running_mean, running_var,
+                     (float*)nullptr, (float*)nullptr, rows, C);
+  return dig_check_launch();
+}
+
+extern "C" int dig_bn_bwd_fused(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                int relu, float* dbeta_acc, float* dgamma_acc, void* dx, int rows, int C, hipStream_t stream) {
+  if (!dy || !x || !mean || !rstd || !dx || (gamma == nullptr) != (beta == nullptr) || (dbeta_acc == nullptr) != (dgamma_acc == nullptr))
+    return DIG_ERR_ARG;
+  if (!dig_bn_fused_supported(rows, C)) return DIG_ERR_UNSUPPORTED;
+  if (!aligned16(x) || !aligned16(dy) || !aligned16(dx)) return DIG_ERR_ALIGN;
+  hipLaunchKernelGGL(bn_fused_kernel<1>, dim3(C / BNF_COLS), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)dy, mean, rstd, gamma, beta,
+                     relu, 0.f, (bf16_t*)dx, (float*)nullptr, (float*)nullptr, 0.f, (float*)nullptr, (float*)nullptr, dbeta_acc, dgamma_acc, rows, C);
   return dig_check_launch();
 }
 

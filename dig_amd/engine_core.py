@@ -715,13 +715,17 @@ class _Step:
         for l, (d1, d2) in enumerate(dims):
             last = l == len(dims) - 1
             h = ops.linear_fwd(x, w16[f"{pre}.{3 * l}.weight"])
-            sums = torch.empty((2, d2), device=x.device, dtype=F32)
-            ops.bn_stats(h, sums)
-            self.comm.all_reduce_(sums)
             gamma = None if last else f32[f"{pre}.{3 * l + 1}.weight"]
             beta = None if last else f32[f"{pre}.{3 * l + 1}.bias"]
             rm, rv, i_bn = M._bn_views[f"{pre}.{3 * l + 1}"]
-            y, mean, rstd = ops.bn_fwd_apply(h, sums, n_total, M.bn_eps, gamma, beta, relu=not last, running=(rm, rv, M.bn_momentum))
+            if self.comm is LOCAL and ops.bn_fused_supported(n_local, d2):
+                # a single rank: nothing sits between statistics and apply -- a few-row layer (the heads on 8 B pooled rows) is one launch
+                y, mean, rstd = ops.bn_fwd_fused(h, M.bn_eps, gamma, beta, relu=not last, running=(rm, rv, M.bn_momentum))
+            else:
+                sums = torch.empty((2, d2), device=x.device, dtype=F32)
+                ops.bn_stats(h, sums)
+                self.comm.all_reduce_(sums)
+                y, mean, rstd = ops.bn_fwd_apply(h, sums, n_total, M.bn_eps, gamma, beta, relu=not last, running=(rm, rv, M.bn_momentum))
             self._bn_touched.append(i_bn)
             if save:
                 saved.append((x, h, mean, rstd))
@@ -770,12 +774,16 @@ class _Step:
             x, h, mean, rstd = saved[l]
             gamma = None if last else f32[f"{pre}.{3 * l + 1}.weight"]
             beta = None if last else f32[f"{pre}.{3 * l + 1}.bias"]
-            sums = torch.empty((2, d2), device=dy.device, dtype=F32)
-            # (the LOCAL sums are the affine gradients: accumulated by the statistics launch itself)
-            ops.bn_bwd_stats(dy, h, mean, rstd, gamma, beta, not last, sums, None if last else g32[f"{pre}.{3 * l + 1}.bias"],
-                             None if last else g32[f"{pre}.{3 * l + 1}.weight"])
-            self.comm.all_reduce_(sums)
-            dh = ops.bn_bwd_apply(dy, h, mean, rstd, gamma, beta, not last, sums, n_total)
+            if self.comm is LOCAL and ops.bn_fused_supported(h.shape[0], d2):
+                dh = ops.bn_bwd_fused(dy, h, mean, rstd, gamma, beta, not last, None if last else g32[f"{pre}.{3 * l + 1}.bias"],
+                                      None if last else g32[f"{pre}.{3 * l + 1}.weight"])
+            else:
+                sums = torch.empty((2, d2), device=dy.device, dtype=F32)
+                # (the LOCAL sums are the affine gradients: accumulated by the statistics launch itself)
+                ops.bn_bwd_stats(dy, h, mean, rstd, gamma, beta, not last, sums, None if last else g32[f"{pre}.{3 * l + 1}.bias"],
+                                 None if last else g32[f"{pre}.{3 * l + 1}.weight"])
+                self.comm.all_reduce_(sums)
+                dh = ops.bn_bwd_apply(dy, h, mean, rstd, gamma, beta, not last, sums, n_total)
             # (every head weight is used once per forward: right after zero_grad() its gradient can be written instead of added)
             asg = getattr(self, "_assign", False)
             self._on_side(dy.device, lambda: ops.linear_wgrad(dh, x, g32[f"{pre}.{3 * l}.weight"], assign=asg), dh, x)

@@ -884,6 +884,34 @@ def bn_fwd_apply(x, sums, n_total, eps, gamma, beta, relu, running=None):
     return y, mean, rstd
 
 
+BN_FUSED = os.environ.get("DIG_BN_FUSED", "1") != "0"      # few-row BatchNorm layers of a single rank in one launch each (csrc/norm.hip)
+
+
+def bn_fused_supported(rows, C):
+    return BN_FUSED and bool(L.lib().dig_bn_fused_supported(int(rows), int(C)))
+
+
+def bn_fwd_fused(x, eps, gamma, beta, relu, running=None):
+    """BatchNorm (train mode, statistics over these rows) of a few-row layer in ONE launch: (y, mean, rstd); running = (running_mean,
+    running_var, momentum) is updated by the same launch."""
+    rows, C = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(C, device=x.device, dtype=F32)
+    rstd = torch.empty(C, device=x.device, dtype=F32)
+    rm, rv, mom = running if running is not None else (None, None, 0.0)
+    L.call("dig_bn_fwd_fused", L.ptr(x), cf(eps), L.ptr(gamma), L.ptr(beta), int(relu), L.ptr(y), L.ptr(mean), L.ptr(rstd), cf(mom), L.ptr(rm),
+           L.ptr(rv), rows, C, L.stream())
+    return y, mean, rstd
+
+
+def bn_bwd_fused(dy, x, mean, rstd, gamma, beta, relu, dbeta=None, dgamma=None):
+    """Its gradient in ONE launch: dx; dbeta / dgamma (both or neither) += the layer's affine gradients."""
+    dx = torch.empty_like(x)
+    L.call("dig_bn_bwd_fused", L.ptr(dy), L.ptr(x), L.ptr(mean), L.ptr(rstd), L.ptr(gamma), L.ptr(beta), int(relu), L.ptr(dbeta), L.ptr(dgamma),
+           L.ptr(dx), x.shape[0], x.shape[1], L.stream())
+    return dx
+
+
 def bn_update_running(sums, n_total, momentum, rm, rv):
     L.call("dig_bn_update_running", L.ptr(sums), cf(n_total), cf(momentum), L.ptr(rm), L.ptr(rv), rm.numel(), L.stream())
 

@@ -246,6 +246,17 @@ int dig_bn_bwd_stats(const void* dy, const void* x, const float* mean, const flo
  * dbeta_acc[c] += sums[0][c], dgamma_acc[c] += sums[1][c]  (both or neither; the two axpy launches per layer of the backward) */
 int dig_bn_bwd_stats_acc(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
                          int relu, float* sums, float* dbeta_acc, float* dgamma_acc, float* workspace, int rows, int C, hipStream_t stream);
+/* Few-row BatchNorm layers (the BN-MLP heads on 8 B pooled rows) in ONE launch each, for a SINGLE rank -- with a process group the cross-rank
+ * reduction of the statistics sits between dig_bn_stats and dig_bn_fwd_apply, and those stay.  Same expressions as the three-launch path
+ * (statistics over these rows, biased variance, running statistics with n / (n - 1)); the summation order over rows differs, so the two
+ * paths agree to fp32 round-off.  dig_bn_fused_supported: 2 <= rows <= 4096, C a multiple of 32 and >= 256.
+ * dig_bn_bwd_fused: dx = gamma rstd (g - mean_r(g) - xhat mean_r(g xhat)), g = dy under the ReLU mask; dbeta_acc / dgamma_acc (both or
+ * neither) += sum g, sum g xhat. */
+int dig_bn_fused_supported(int rows, int C);
+int dig_bn_fwd_fused(const void* x, float eps, const float* gamma, const float* beta, int relu, void* y, float* mean_out, float* rstd_out,
+                     float momentum, float* running_mean, float* running_var, int rows, int C, hipStream_t stream);
+int dig_bn_bwd_fused(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta, int relu,
+                     float* dbeta_acc, float* dgamma_acc, void* dx, int rows, int C, hipStream_t stream);
 int dig_bn_bwd_apply(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
                      int relu, const float* sums, float n_total, void* dx, int rows, int C, hipStream_t stream);
 

@@ -208,6 +208,41 @@ def test_batchnorm(dev, rows, C, affine, relu):
     assert torch.equal(s3, s2) and torch.equal(db, 0.5 + s2[0]) and torch.equal(dg, -0.25 + s2[1])
 
 
+@pytest.mark.parametrize("rows,C,affine,relu", [(1024, 4096, True, True), (1024, 256, False, False), (2048, 512, True, True), (40, 256, True, False),
+                                                (333, 288, True, True)])
+def test_batchnorm_fused_few_rows(dev, rows, C, affine, relu):
+    """dig_bn_fwd_fused / dig_bn_bwd_fused (a few-row BatchNorm layer of a single rank in ONE launch each) against the three-launch path of
+    the same library -- the same expressions, another summation order over rows: statistics to fp32 round-off, outputs within one bf16
+    rounding -- and against torch."""
+    from dig_amd import ops
+    assert ops.bn_fused_supported(rows, C) and not ops.bn_fused_supported(32768, 512) and not ops.bn_fused_supported(1024, 64)
+    x = (torch.randn(rows, C, device=dev) * 2 + 0.5).bfloat16()
+    gamma = (torch.randn(C, device=dev) * 0.2 + 1) if affine else None
+    beta = (torch.randn(C, device=dev) * 0.1) if affine else None
+    sums = torch.empty(2, C, device=dev)
+    ops.bn_stats(x, sums)
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    y, mean, rstd = ops.bn_fwd_apply(x, sums, float(rows), 1e-5, gamma, beta, relu, running=(rm, rv, 0.1))
+    rm2, rv2 = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    y2, mean2, rstd2 = ops.bn_fwd_fused(x, 1e-5, gamma, beta, relu, running=(rm2, rv2, 0.1))
+    assert rel(mean2, mean) < 1e-5 and rel(rstd2, rstd) < 1e-5 and rel(rm2, rm) < 1e-5 and rel(rv2, rv) < 1e-5
+    assert (y2.float() - y.float()).abs().max().item() <= 2 ** -7 * y.float().abs().max().item() and rel(y2, y) < 1e-3
+    dy = torch.randn(rows, C, device=dev).bfloat16()
+    s2, db, dg = torch.empty(2, C, device=dev), torch.full((C,), 0.5, device=dev), torch.full((C,), -0.25, device=dev)
+    ops.bn_bwd_stats(dy, x, mean, rstd, gamma, beta, relu, s2, db, dg)
+    dx = ops.bn_bwd_apply(dy, x, mean, rstd, gamma, beta, relu, s2, float(rows))
+    db2, dg2 = torch.full((C,), 0.5, device=dev), torch.full((C,), -0.25, device=dev)
+    dx2 = ops.bn_bwd_fused(dy, x, mean, rstd, gamma, beta, relu, db2, dg2)
+    assert rel(db2, db) < 1e-5 and rel(dg2, dg) < 1e-5 and rel(dx2, dx) < 2e-3
+    dx3 = ops.bn_bwd_fused(dy, x, mean, rstd, gamma, beta, relu)            # (the last layer of a stack: no affine gradients)
+    assert torch.equal(dx3, dx2)
+    xf = x.float().requires_grad_(True)
+    ref = F.batch_norm(xf, torch.zeros(C, device=dev), torch.ones(C, device=dev), gamma, beta, True, 0.1, 1e-5)
+    ref = F.relu(ref) if relu else ref
+    ref.backward(dy.float())
+    assert rel(y2, ref) < 1e-2 and rel(dx2, xf.grad) < 1.5e-2
+
+
 @pytest.mark.parametrize("Bn,D", [(6, 384), (3, 128)])
 def test_patch_embed(dev, Bn, D):
     from dig_amd import ops

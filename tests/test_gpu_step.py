@@ -695,7 +695,12 @@ def test_rccl_path_world1_matches_local_path(which):
     hp = O.StepHyper(lr=1e-3)
     im, au, mk = O.synthetic_batch(B, cfg, 900)
     base = build_model(cfg, *state())
-    (s0,), _ = run_engine_steps(base, [(im, au, mk)], hp)
+    from dig_amd import ops
+    fused_bn, ops.BN_FUSED = ops.BN_FUSED, False      # (the single-process plan folds a few-row BatchNorm layer into one launch: another summation
+    try:                                              #  order over rows than the statistics / all-reduce / apply launches of the process-group path)
+        (s0,), _ = run_engine_steps(base, [(im, au, mk)], hp)
+    finally:
+        ops.BN_FUSED = fused_bn
     g0 = base.flat_grads.clone()
     created = False
     if not dist.is_initialized():
@@ -988,7 +993,8 @@ def test_optimizer_launch_leaves_shadow_and_transposes_for_the_next_forward():
 
 @pytest.mark.parametrize("switch", ["wgrad_off", "wgrad_pair", "wgrad_wa1", "wgrad_side_stream", "chain_mask3", "dgrad_128", "fwd_side", "fwd_serial",
                                     "chain_no_ln", "bwd_single", "chain_bwd_every2", "per_entry_point", "autograd_function", "attn_three_launches",
-                                    "attn_bwd_single_pass", "wgrad_inline", "ln2_bwd_own_launch", "proj_dgrad_in_chain"])
+                                    "attn_bwd_single_pass", "wgrad_inline", "ln2_bwd_own_launch", "proj_dgrad_in_chain", "bn_three_launches",
+                                    "dgrad_transpose_read", "adamw_plain"])
 def test_engine_switches_agree_with_the_default_path(switch):
     """Every non-default execution plan of the step (environment switches of dig_amd/ops.py and engine_core.py: launch groupings, tile
     codes, stream plans, fusion masks) against the default plan on one ViT-S step from the same state and batch: the losses agree, and
@@ -1028,10 +1034,20 @@ def test_engine_switches_agree_with_the_default_path(switch):
         "ln2_bwd_own_launch": [(ops, "MLP_CHAIN_LNB", False)],
         # the projection's data gradient behind norm2's backward in dig_mlp_chain_bwd_ln_proj instead of its own GEMM launch (opt-in plan)
         "proj_dgrad_in_chain": [(ops, "MLP_CHAIN_PROJ", True)],
+        # the heads' few-row BatchNorm layers as statistics / apply launches (the plan under a process group) instead of one fused launch
+        # each: another summation order of the column statistics
+        "bn_three_launches": [(ops, "BN_FUSED", False)],
+        # the proj / qkv data gradients in their transpose-read form on the [out, in] weights instead of the direct form on the transposed copies:
+        # bit-identical; and the plain optimizer launch (cast + transposes rebuilt by the forward): one step from a loaded state is the same step
+        "dgrad_transpose_read": [(ops, "DGRAD_DIRECT", False)],
+        "adamw_plain": [],
         "wgrad_inline": [(engine_core, "WGRAD_DEFER", "0")],              # the grouped launch of a block inside its data-gradient chain (the plan under a
                                                                           # process group) instead of all twelve behind the last data gradient: same sums
     }
     tight = switch in ("wgrad_off", "wgrad_pair", "wgrad_wa1", "wgrad_side_stream", "fwd_side", "fwd_serial", "bwd_single", "wgrad_inline")
+    if switch == "adamw_plain":
+        from dig_amd import optim_factory
+        plans[switch] = [(optim_factory, "FOLD_SHADOW", False)]
     saved = [(m, k, getattr(m, k)) for m, k, _ in plans[switch]]
     prev_mode = ops.attn_bwd_mode(True) if switch == "attn_bwd_single_pass" else None
     try:
@@ -1050,6 +1066,11 @@ def test_engine_switches_agree_with_the_default_path(switch):
         assert engine_core.STEP_OPS and torch.ops.dig.pretrain_step_fwd is not None and not engine_core._LIVE_STEPS
         assert stats["grad_norm"] == ref_stats["grad_norm"] and torch.equal(g, ref_g)
         return
+    if switch in ("dgrad_transpose_read", "adamw_plain"):
+        # same products, same K order per output element / the same step from a loaded state: bit for bit
+        assert all(stats[k] == ref_stats[k] for k in ("loss", "loss_pixel", "loss_contrast", "grad_norm")), (stats, ref_stats)
+        assert torch.equal(g, ref_g)
+        return
     if switch == "per_entry_point":
         # gradients may be WRITTEN instead of added only right after zero_grad(): the flag is consumed by the backward
         m_ = build_model(cfg, {k: v.clone() for k, v in P.items()}, {k: v.clone() for k, v in S.items()})
@@ -1066,7 +1087,7 @@ def test_engine_switches_agree_with_the_default_path(switch):
     for k in ("loss", "loss_pixel", "loss_contrast", "grad_norm"):
         assert abs(stats[k] - ref_stats[k]) <= (1e-5 if tight else 2e-2) * abs(ref_stats[k]) + 1e-6, (k, stats[k], ref_stats[k])      # (2e-2: this file's bf16 band)
     tol = 1e-5 if tight else 2e-2
-    fwd_plan = switch in ("chain_no_ln", "attn_three_launches")
+    fwd_plan = switch in ("chain_no_ln", "attn_three_launches", "bn_three_launches")     # (bn: a last-bit change of the heads' statistics re-rounds what follows)
     for name, sp in specs.items():
         a, b = g[sp.offset:sp.offset + sp.numel], ref_g[sp.offset:sp.offset + sp.numel]
         if float(b.norm()) == 0.0:
