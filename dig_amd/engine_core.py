@@ -431,13 +431,20 @@ class _Step:
         no launch at all.  Otherwise (first step, after load_state_dict / .to(), under graph capture, DIG_ADAMW_FOLD=0) three launches
         rebuild them from this step's bf16 weight shadow, into the same persistent buffers where the model has them."""
         tr = self.m.transposed_weight_table() if hasattr(self.m, "transposed_weight_table") else None
+        self.head_wT = {}
         if tr is not None and fresh:
+            self.head_wT = tr[6]
             return tr[4]
         outs = tr[4] if tr is not None else None
         w2t = ops.transpose_bf16_multi([b["mlp.fc2.weight"] for b in ew.blocks], [o[0] for o in outs] if outs else None)   # one launch per weight shape
         w1t = ops.transpose_bf16_multi([b["mlp.fc1.weight"] for b in ew.blocks], [o[1] for o in outs] if outs else None)
         projt = ops.transpose_bf16_multi([b["attn.proj.weight"] for b in ew.blocks], [o[2] for o in outs] if outs else None)
         qkvt = ops.transpose_bf16_multi([b["attn.qkv.weight"] for b in ew.blocks], [o[3] for o in outs] if outs else None)   # (direct-form qkv data gradient)
+        if tr is not None:                                              # (the heads' copies: one small launch each, only behind a foreign write)
+            w16 = self.m._w("online")
+            for name, dst in tr[6].items():
+                ops.transpose_bf16(w16[name], dst)
+            self.head_wT = tr[6]
         return list(zip(w2t, w1t, projt, qkvt))
 
     # ------------------------------------------------------------------ two-stream helpers (backward)
@@ -788,7 +795,12 @@ class _Step:
             asg = getattr(self, "_assign", False)
             self._on_side(dy.device, lambda: ops.linear_wgrad(dh, x, g32[f"{pre}.{3 * l}.weight"], assign=asg), dh, x)
             if l > 0 or need_dx:
-                dy = ops.linear_dgrad(dh, w16[f"{pre}.{3 * l}.weight"], out=dx_out if l == 0 else None)
+                wt = getattr(self, "head_wT", {}).get(f"{pre}.{3 * l}.weight") if ops.HEAD_DGRAD_DIRECT else None
+                if wt is not None:
+                    # direct form on the K-contiguous copy the optimizer launch left (the forward's tile plan for this shape)
+                    dy = ops.linear_fwd(dh, wt, out=dx_out if l == 0 else None)
+                else:
+                    dy = ops.linear_dgrad(dh, w16[f"{pre}.{3 * l}.weight"], out=dx_out if l == 0 else None)
         return dy
 
     # ------------------------------------------------------------------ full forward

@@ -482,17 +482,28 @@ class MoCo_ViT(nn.Module):
         recs, views, dst, tile0 = [], [], 0, 0
         per_block = []
         ok = dev.type == "cuda"
+
+        def add(name):
+            nonlocal dst, tile0, ok
+            sp = self.specs[name]
+            r, c = sp.shape
+            ok = ok and r % 64 == 0 and c % 64 == 0 and sp.offset % ALIGN == 0
+            recs.append((sp.offset, dst, r, c, tile0))
+            ent = (dst, c, r)
+            dst += r * c
+            tile0 += (r // 64) * (c // 64)
+            return ent
         for i in range(self.depth):
-            row = []
-            for leaf in ("mlp.fc2.weight", "mlp.fc1.weight", "attn.proj.weight", "attn.qkv.weight"):
-                sp = self.specs[f"encoder.blocks.{i}.{leaf}"]
-                r, c = sp.shape
-                ok = ok and r % 64 == 0 and c % 64 == 0 and sp.offset % ALIGN == 0
-                recs.append((sp.offset, dst, r, c, tile0))
-                row.append((dst, c, r))
-                dst += r * c
-                tile0 += (r // 64) * (c // 64)
-            per_block.append(row)
+            per_block.append([add(f"encoder.blocks.{i}.{leaf}") for leaf in ("mlp.fc2.weight", "mlp.fc1.weight", "attn.proj.weight", "attn.qkv.weight")])
+        # the BN-MLP heads' Linear weights too (their data gradients in direct form: the 4096 x 4096 projector layer 105 -> 64 us); a head
+        # whose widths are not multiples of 64 (test models) simply stays on the transpose-read form
+        head_ents = {}
+        for pre in ("predictor", "encoder_projection_layer", "pix_projector"):
+            for l in range(len(self.mlps.get(pre, ()))):
+                name = f"{pre}.{3 * l}.weight"
+                r, c = self.specs[name].shape
+                if r % 64 == 0 and c % 64 == 0:
+                    head_ents[name] = add(name)
         out = None
         if ok:
             import struct
@@ -503,7 +514,8 @@ class MoCo_ViT(nn.Module):
             flags = self._flat["groups"].clone()
             for off, _, r, c, _ in recs:
                 flags[off // ALIGN:(off + r * c) // ALIGN] |= 0x80
-            out = (table, len(recs), tile0, tr_out, wT, flags)
+            heads = {n_: tr_out[d:d + a * b].view(a, b) for n_, (d, a, b) in head_ents.items()}
+            out = (table, len(recs), tile0, tr_out, wT, flags, heads)
         self._tr_table = ((self._views_version, dev), out)
         return out
 

@@ -285,6 +285,8 @@ def linear_dgrad(dy, w, out=None, gelu_pre=None, colsum=False, drop=None):
 
 
 DGRAD_DIRECT = os.environ.get("DIG_DGRAD_DIRECT", "1") != "0"     # the proj / qkv data gradients as direct-form GEMMs on the transposed weight copies
+HEAD_DGRAD_DIRECT = os.environ.get("DIG_HEAD_DGRAD_DIRECT", "1") != "0"   # ... and those of the BN-MLP heads (the forward's tile plan per shape: for the
+#                                                                           long-K layers that is the R-sliced form, so not bit-identical to the dgrad launch)
 
 
 def dgrad_direct_tile_code(rows, J):

@@ -92,7 +92,7 @@ class FusedAdamW(torch.optim.Optimizer):
         if tr is not None:
             # one launch: the update, the bf16 operand shadow of the whole arena and the transposed copies of the MLP / projection weights
             # (what the next forward would otherwise rebuild with a cast launch and three transpose launches)
-            table, n_mats, n_tiles, tr_out, _, flags = tr
+            table, n_mats, n_tiles, tr_out, _, flags = tr[:6]
             ops.adamw_step_tr(M.flat_params, M.flat_grads, self.exp_avg, self.exp_avg_sq, M.shadow("online"), flags,
                               g0["lr"], g0["weight_decay"], g1["lr"], g1["weight_decay"], b1, b2, g0["eps"], self._step, table, n_mats, n_tiles,
                               tr_out, grad_scale, finite_gate)

@@ -994,7 +994,7 @@ def test_optimizer_launch_leaves_shadow_and_transposes_for_the_next_forward():
 @pytest.mark.parametrize("switch", ["wgrad_off", "wgrad_pair", "wgrad_wa1", "wgrad_side_stream", "chain_mask3", "dgrad_128", "fwd_side", "fwd_serial",
                                     "chain_no_ln", "bwd_single", "chain_bwd_every2", "per_entry_point", "autograd_function", "attn_three_launches",
                                     "attn_bwd_single_pass", "wgrad_inline", "ln2_bwd_own_launch", "proj_dgrad_in_chain", "bn_three_launches",
-                                    "dgrad_transpose_read", "adamw_plain"])
+                                    "dgrad_transpose_read", "adamw_plain", "head_dgrad_transpose_read"])
 def test_engine_switches_agree_with_the_default_path(switch):
     """Every non-default execution plan of the step (environment switches of dig_amd/ops.py and engine_core.py: launch groupings, tile
     codes, stream plans, fusion masks) against the default plan on one ViT-S step from the same state and batch: the losses agree, and
@@ -1041,6 +1041,7 @@ def test_engine_switches_agree_with_the_default_path(switch):
         # bit-identical; and the plain optimizer launch (cast + transposes rebuilt by the forward): one step from a loaded state is the same step
         "dgrad_transpose_read": [(ops, "DGRAD_DIRECT", False)],
         "adamw_plain": [],
+        "head_dgrad_transpose_read": [(ops, "HEAD_DGRAD_DIRECT", False)],  # the heads' data gradients on the [out, in] weights: another K split of the 4096-deep layers
         "wgrad_inline": [(engine_core, "WGRAD_DEFER", "0")],              # the grouped launch of a block inside its data-gradient chain (the plan under a
                                                                           # process group) instead of all twelve behind the last data gradient: same sums
     }
