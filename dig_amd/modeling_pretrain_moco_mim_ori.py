@@ -495,10 +495,10 @@ class MoCo_ViT(nn.Module):
             return ent
         for i in range(self.depth):
             per_block.append([add(f"encoder.blocks.{i}.{leaf}") for leaf in ("mlp.fc2.weight", "mlp.fc1.weight", "attn.proj.weight", "attn.qkv.weight")])
-        # the BN-MLP heads' Linear weights too (their data gradients in direct form: the 4096 x 4096 projector layer 105 -> 64 us); a head
-        # whose widths are not multiples of 64 (test models) simply stays on the transpose-read form
+        # opt-in (DIG_HEAD_DGRAD_DIRECT=1: no gain in the step): the BN-MLP heads' Linear weights too (their data gradients in direct form); a
+        # head whose widths are not multiples of 64 (test models) stays on the transpose-read form
         head_ents = {}
-        for pre in ("predictor", "encoder_projection_layer", "pix_projector"):
+        for pre in (("predictor", "encoder_projection_layer", "pix_projector") if ops.HEAD_DGRAD_DIRECT else ()):
             for l in range(len(self.mlps.get(pre, ()))):
                 name = f"{pre}.{3 * l}.weight"
                 r, c = self.specs[name].shape

@@ -285,8 +285,9 @@ def linear_dgrad(dy, w, out=None, gelu_pre=None, colsum=False, drop=None):
 
 
 DGRAD_DIRECT = os.environ.get("DIG_DGRAD_DIRECT", "1") != "0"     # the proj / qkv data gradients as direct-form GEMMs on the transposed weight copies
-HEAD_DGRAD_DIRECT = os.environ.get("DIG_HEAD_DGRAD_DIRECT", "1") != "0"   # ... and those of the BN-MLP heads (the forward's tile plan per shape: for the
-#                                                                           long-K layers that is the R-sliced form, so not bit-identical to the dgrad launch)
+HEAD_DGRAD_DIRECT = os.environ.get("DIG_HEAD_DGRAD_DIRECT", "0") == "1"   # ... and those of the BN-MLP heads: opt-in.  Measured in the step, two A/B pairs
+#                                                                           on one box: 19.18 / 19.20 against 19.17 / 19.19 ms -- the 4096 x 4096 layer's
+#                                                                           105 -> 64 us is eaten by the 17 M more elements the optimizer launch turns
 
 
 def dgrad_direct_tile_code(rows, J):
