@@ -86,6 +86,8 @@ class DistributedDataParallel(torch.nn.Module):
         if broadcast:
             for k in ("online", "momentum", "bn_stats", "bn_count"):
                 dist.broadcast(module._flat[k], src=0, group=process_group)
+            if hasattr(module, "mark_weights_changed"):
+                module.mark_weights_changed()            # (the arena was just rewritten behind the optimizer's back: bf16 shadow and transposed copies are stale)
 
     def forward(self, *args, **kwargs):
         return self.module(*args, **kwargs)
