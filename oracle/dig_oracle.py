@@ -55,6 +55,8 @@ class DiGConfig:
     kind: str = "simmim_moco"
     # --patchnet_name (run_mae_pretraining_moco.py:145): "no_patchtrans" (README) = the pooled windows themselves; "regular" (the argparse
     # default) = PatchNet with its 2-block patch transformer: the pooled windows attend over all 256 tokens (modeling_pretrain_moco_mim_ori.py:137-205)
+    # "conv" = ConvPatchNet (:207-260): four 3x3-convolution / BatchNorm2d / ReLU blocks with three 2x2 max-pools on the 8 x 32 token grid,
+    # adaptive_avg_pool2d to (1, num_windows), then Linear-BN-ReLU-Linear-BN(affine=False): ONE patch per image
     patchnet: str = "no_patchtrans"
     patchnet_depth: int = 2
     patchnet_eps: float = 1e-5        # PatchNet's own norm_layer default: nn.LayerNorm (eps 1e-5), not the encoder's 1e-6
@@ -66,6 +68,17 @@ class DiGConfig:
     @property
     def use_pixel(self) -> bool:
         return self.kind in ("simmim_moco", "simmim")
+
+    @property
+    def n_patch(self) -> int:
+        """Rows per image the patch extractor hands to the projector (ConvPatchNet.forward ends in `.unsqueeze(1)`, :257)."""
+        return 1 if self.patchnet == "conv" else self.num_windows
+
+    @property
+    def conv_channels(self) -> Tuple[int, ...]:
+        """ConvPatchNet's conv3x3_block widths (:217-225)."""
+        D = self.embed_dim
+        return (D, D, int(D * 1.5), D * 2, D * 2)
 
     @property
     def grid(self) -> Tuple[int, int]:
@@ -150,6 +163,39 @@ def _patchnet_param_shapes(cfg: DiGConfig, pre: str) -> "OrderedDict[str, tuple]
     return o
 
 
+CONV_IDX = (0, 2, 4, 6)                  # positions of the conv3x3_blocks in ConvPatchNet.conv_layers (max-pools sit at 1, 3, 5)
+
+
+def _convnet_param_shapes(cfg: DiGConfig, pre: str) -> "OrderedDict[str, tuple]":
+    """ConvPatchNet (modeling_pretrain_moco_mim_ori.py:207-260): conv_layers.{0,2,4,6} = Sequential(Conv2d 3x3 pad 1 (bias), BatchNorm2d, ReLU);
+    patches2global = Linear(2 D nw -> D), BatchNorm1d, ReLU, Linear(D -> D), BatchNorm1d(affine=False)."""
+    c = cfg.conv_channels
+    o = OrderedDict()
+    for j, i in enumerate(CONV_IDX):
+        o[f"{pre}conv_layers.{i}.0.weight"] = (c[j + 1], c[j], 3, 3); o[f"{pre}conv_layers.{i}.0.bias"] = (c[j + 1],)
+        o[f"{pre}conv_layers.{i}.1.weight"] = (c[j + 1],); o[f"{pre}conv_layers.{i}.1.bias"] = (c[j + 1],)
+    D = cfg.embed_dim
+    o[pre + "patches2global.0.weight"] = (D, c[4] * cfg.num_windows); o[pre + "patches2global.0.bias"] = (D,)
+    o[pre + "patches2global.1.weight"] = (D,); o[pre + "patches2global.1.bias"] = (D,)
+    o[pre + "patches2global.3.weight"] = (D, D); o[pre + "patches2global.3.bias"] = (D,)
+    return o
+
+
+def _convnet_buffer_shapes(cfg: DiGConfig, pre: str) -> "OrderedDict[str, tuple]":
+    c = cfg.conv_channels
+    o = OrderedDict()
+    for key, C in [(f"conv_layers.{i}.1", c[j + 1]) for j, i in enumerate(CONV_IDX)] + [("patches2global.1", cfg.embed_dim), ("patches2global.4", cfg.embed_dim)]:
+        o[f"{pre}{key}.running_mean"] = (C,); o[f"{pre}{key}.running_var"] = (C,); o[f"{pre}{key}.num_batches_tracked"] = ()
+    return o
+
+
+def bn_cancelled_bias(name: str, cfg: DiGConfig) -> bool:
+    """A bias whose layer feeds a BatchNorm directly (ConvPatchNet's conv and Linear biases): the normalisation subtracts it again, its true
+    gradient is exactly zero and what any implementation holds there is round-off of its own summation order."""
+    return (cfg.patchnet == "conv" and name.startswith("patch_extractor.")
+            and name.endswith((".0.bias", "patches2global.3.bias")) and not name.endswith(".1.bias"))
+
+
 def _mlp_dims(n_layers: int, din: int, dmid: int, dout: int) -> List[Tuple[int, int]]:
     """_build_mlp, modeling_pretrain_moco_mim_ori.py:463-482."""
     return [(din if l == 0 else dmid, dout if l == n_layers - 1 else dmid) for l in range(n_layers)]
@@ -200,6 +246,9 @@ def param_shapes(cfg: DiGConfig) -> "OrderedDict[str, tuple]":
         if pre == "predictor." and cfg.patchnet == "regular":            # registration order of MoCo_ViT.__init__ (:366-394)
             o.update(_patchnet_param_shapes(cfg, "patch_extractor."))
             o.update(_patchnet_param_shapes(cfg, "momentum_patch_extractor."))
+        if pre == "predictor." and cfg.patchnet == "conv":
+            o.update(_convnet_param_shapes(cfg, "patch_extractor."))
+            o.update(_convnet_param_shapes(cfg, "momentum_patch_extractor."))
     if cfg.use_pixel:
         Dd = cfg.dec_dim                                                  # pix_decoder, :422-426
         o["pix_decoder.0.weight"] = (Dd, cfg.embed_dim)
@@ -215,6 +264,9 @@ def buffer_shapes(cfg: DiGConfig) -> "OrderedDict[str, tuple]":
     o = OrderedDict()
     for pre, dims in mlp_specs(cfg).items():
         o.update(_mlp_buffer_shapes(pre, dims))
+        if pre == "predictor." and cfg.patchnet == "conv":
+            o.update(_convnet_buffer_shapes(cfg, "patch_extractor."))
+            o.update(_convnet_buffer_shapes(cfg, "momentum_patch_extractor."))
     return o
 
 
@@ -262,6 +314,18 @@ def init_state(cfg: DiGConfig, seed: int = 0, dtype=torch.float32):
                 t = uni(shp, 1.0 / math.sqrt(cfg.in_chans * cfg.patch * cfg.patch))
         elif name.endswith("patch_embed.proj.bias") and not cfg.use_moco:
             t = uni(shp, 1.0 / math.sqrt(cfg.in_chans * cfg.patch * cfg.patch))
+        elif name.startswith("patch_extractor.") and cfg.patchnet == "conv":
+            # ConvPatchNet has no _init_weights: nn.Conv2d / nn.Linear defaults U(+-1/sqrt(fan_in)) for weight and bias, BatchNorm 1 / 0
+            fan = shp[1] * 9 if len(shp) == 4 else shp[1] if len(shp) == 2 else None
+            if fan is not None:
+                t = uni(shp, 1.0 / math.sqrt(fan))
+            elif name.endswith(".0.bias") or name.endswith(".3.bias"):
+                w = param_shapes(cfg)[name[:-4] + "weight"]
+                t = uni(shp, 1.0 / math.sqrt(w[1] * (9 if len(w) == 4 else 1)))
+            elif name.endswith(".weight"):
+                t = torch.ones(shp, dtype=dtype)
+            else:
+                t = torch.zeros(shp, dtype=dtype)
         elif name.startswith(("encoder.", "patch_extractor.")):           # (PatchNet._init_weights, :159-166: the same rule)
             if len(shp) == 2:
                 t = uni(shp, math.sqrt(6.0 / (shp[0] + shp[1])))           # xavier_uniform_
@@ -471,11 +535,38 @@ def window_pool(x, cfg: DiGConfig):
     return x.reshape(Bn, gh, cfg.num_windows, gw // cfg.num_windows, C).mean(dim=(1, 3))
 
 
-def patch_extractor(x, P, pre, cfg: DiGConfig):
+def conv_patch_extractor(x, P, S, pre, cfg: DiGConfig, comm):
+    """ConvPatchNet.forward (modeling_pretrain_moco_mim_ori.py:250-258): the token grid as a [C, 8, 32] map through conv3x3 / BatchNorm2d / ReLU
+    (x 4) with 2x2 max-pools between them (8x32 -> 4x16 -> 2x8 -> 1x4), adaptive_avg_pool2d to (1, num_windows), flattened window-major, then
+    patches2global.  BatchNorm2d in train mode = per-channel statistics over (batch, y, x): batch_norm_train on the [B H W, C] rows (under
+    SyncBatchNorm over all ranks, run_mae_pretraining_moco.py:390).  x: [Bn, N, C] -> [Bn, 1, C]."""
+    Bn, N, C = x.shape
+    gh, gw = cfg.grid
+    h = x.reshape(Bn, gh, gw, C).permute(0, 3, 1, 2)
+    for j, i in enumerate(CONV_IDX):
+        b = f"{pre}conv_layers.{i}."
+        h = F.conv2d(h, P[b + "0.weight"], P[b + "0.bias"], stride=1, padding=1)
+        _, c_, hh, ww = h.shape
+        r = batch_norm_train(h.permute(0, 2, 3, 1).reshape(-1, c_), P[b + "1.weight"], P[b + "1.bias"], S, b + "1.", cfg, comm)
+        h = F.relu(r).reshape(Bn, hh, ww, c_).permute(0, 3, 1, 2)
+        if j < 3:
+            h = F.max_pool2d(h, kernel_size=2, stride=2)
+    h = F.adaptive_avg_pool2d(h, (1, cfg.num_windows)).permute(0, 2, 3, 1).reshape(Bn, -1)
+    g = f"{pre}patches2global."
+    z = F.linear(h, P[g + "0.weight"], P[g + "0.bias"])
+    z = F.relu(batch_norm_train(z, P[g + "1.weight"], P[g + "1.bias"], S, g + "1.", cfg, comm))
+    z = F.linear(z, P[g + "3.weight"], P[g + "3.bias"])
+    z = batch_norm_train(z, None, None, S, g + "4.", cfg, comm)
+    return z.unsqueeze(1)
+
+
+def patch_extractor(x, P, pre, cfg: DiGConfig, S=None, comm=None):
     """PatchNet.forward (modeling_pretrain_moco_mim_ori.py:189-205): the pooled windows; with the patch transformer ("regular") each of them
     then attends over all tokens of its image through `depth` Blocks (:88-135) -- every Block normalises queries AND keys / values with its
     own norm1, adds the attention output to the NORMALISED queries (`x = self.norm1(x) ... x = x + attn_x`, :107-121), then the MLP; a final
     LayerNorm.  x: [Bn, N, C] -> [Bn, num_windows, C]."""
+    if cfg.patchnet == "conv":
+        return conv_patch_extractor(x, P, S, pre, cfg, comm or LocalComm())
     pooled = window_pool(x, cfg)
     if cfg.patchnet != "regular":
         return pooled
@@ -543,10 +634,10 @@ def model_forward(P, S, images, aug_images, mask, m: float, cfg: DiGConfig, comm
             feat = torch.cat([masked.reshape(B, N, D), enc[B:]], 0)
         else:
             feat = enc
-        pooled = patch_extractor(feat, P, "patch_extractor.", cfg).reshape(2 * B * cfg.num_windows, D)
+        pooled = patch_extractor(feat, P, "patch_extractor.", cfg, S, comm).reshape(2 * B * cfg.n_patch, D)
         qs = bn_mlp(pooled, P, S, "encoder_projection_layer.", specs["encoder_projection_layer."], cfg, comm, taps)
         qs = bn_mlp(qs, P, S, "predictor.", specs["predictor."], cfg, comm, taps)
-        half = B * cfg.num_windows
+        half = B * cfg.n_patch
         q1, q2 = qs[:half], qs[half:]
         with torch.no_grad():
             if do_ema:
@@ -557,7 +648,7 @@ def model_forward(P, S, images, aug_images, mask, m: float, cfg: DiGConfig, comm
                 feat_m = torch.cat([masked_m.reshape(B, N, D), enc_m[B:]], 0)
             else:
                 feat_m = enc_m
-            pooled_m = patch_extractor(feat_m, P, "momentum_patch_extractor.", cfg).reshape(2 * B * cfg.num_windows, D)
+            pooled_m = patch_extractor(feat_m, P, "momentum_patch_extractor.", cfg, S, comm).reshape(2 * B * cfg.n_patch, D)
             ks = bn_mlp(pooled_m, P, S, "momentum_projection_layer.", specs["momentum_projection_layer."], cfg, comm)
             k1, k2 = ks[:half], ks[half:]
         l1, a11, a15 = info_nce(q1, k2, cfg.T, comm)

@@ -246,7 +246,12 @@ def check_adamw_formula(ref_step0, cfg, seed, hp, m0):
     print(f"AdamW + EMA restatement == reference given reference grads; worst abs err {worst:.2e}")
 
 
-def compare(ref_steps, ora_steps, rtol=2e-4, atol=2e-5, tag="", lr=1e-3):
+def compare(ref_steps, ora_steps, rtol=2e-4, atol=2e-5, tag="", lr=1e-3, nonsmooth=None):
+    """nonsmooth (ConvPatchNet: cfg): the loss is piecewise smooth in the weights with ~10^6 kinks per step (2x2 max-pool arg-maxima and ReLU
+    signs over [2 B, 8 x 32 .. 1 x 4] maps) -- a 1e-7 round-off difference upstream (this file's BatchNorm sums vs torch's native kernel) flips a
+    few of them, and each flip moves single gradient elements by their full size: the reference in fp32 differs from ITSELF in fp64 by 5e-2 of
+    the maximum there (check_conv_module prints it).  Gradients are then compared in the L2 norm per tensor (<= 1e-2), everything else as
+    before; the module itself is pinned tightly on identical inputs by check_conv_module."""
     worst = 0.0
     for s, (r, o) in enumerate(zip(ref_steps, ora_steps)):
         logged = ("loss", "loss_pixel", "loss_contrast", "q1_acc1", "q1_acc5", "q2_acc1", "q2_acc5")
@@ -268,6 +273,13 @@ def compare(ref_steps, ora_steps, rtol=2e-4, atol=2e-5, tag="", lr=1e-3):
                 if err / (ref + 1e-12) > worst:
                     worst, worst_at = err / (ref + 1e-12), (s, grp, k, err, ref)
                 slack = 2.5 * lr if grp == "params" else 0.0   # Adam step is sign-like where |g|~eps
+                if nonsmooth is not None and grp == "grads":
+                    if O.bn_cancelled_bias(k, nonsmooth):         # a bias in front of a BatchNorm: its true gradient is zero, both sides hold round-off
+                        assert a.norm().item() <= 1e-6 and b.norm().item() <= 1e-6, (tag, s, k, a.norm().item(), b.norm().item())
+                        continue
+                    l2 = (a - b).norm().item() / (a.norm().item() + 1e-30)
+                    assert l2 <= 1e-2, (tag, s, grp, k, l2)
+                    continue
                 assert err <= atol + rtol * ref + slack, (tag, s, grp, k, err, ref)
     print(f"[{tag}] oracle == reference over {len(ref_steps)} steps; worst rel-to-max err {worst:.2e} at {worst_at}")
 
@@ -311,10 +323,58 @@ def pack(ref_steps, cfg, seed, B, hp, extra=None):
     return d
 
 
+def check_conv_module(cfg, seed, x0, go):
+    """ConvPatchNet alone on the input / output gradient captured in the reference's step (identical bits on both sides): the oracle's
+    restatement against the reference module, both fp32 -- and, for the record, the reference module against itself in fp64."""
+    import modeling_pretrain_moco_mim_ori as M
+    P, S = O.det_state(cfg, seed)
+    res = {}
+    with torch.enable_grad():
+        for tg, dt in (("ref32", torch.float32), ("ref64", torch.float64)):
+            net = M.ConvPatchNet(embed_dim=cfg.embed_dim, num_windows=cfg.num_windows, patch_shape=cfg.grid).to(dt)
+            missing = net.load_state_dict({k[len("patch_extractor."):]: v.to(dt) for k, v in P.items() if k.startswith("patch_extractor.")}, strict=False)
+            assert not missing.unexpected_keys and all(k.rsplit(".", 1)[-1].startswith(("running_", "num_batches")) for k in missing.missing_keys), missing
+            net.train()
+            x = x0.detach().clone().to(dt).requires_grad_()
+            y = net(x)
+            (y * go.to(dt)).sum().backward()
+            res[tg] = [y.detach().double(), x.grad.double()] + [p.grad.double() for n, p in net.named_parameters() if n.endswith("weight")]
+        Pd = {k: v.clone().requires_grad_() for k, v in P.items() if k.startswith("patch_extractor.")}
+        x = x0.detach().clone().requires_grad_()
+        y = O.conv_patch_extractor(x, Pd, {k: v.clone() for k, v in S.items()}, "patch_extractor.", cfg, O.LocalComm())
+        (y * go).sum().backward()
+        res["ora32"] = [y.detach().double(), x.grad.double()] + [g.grad.double() for n, g in Pd.items() if n.endswith("weight")]
+    rel = lambda a, b: ((a - b).abs().max() / b.abs().max()).item()          # noqa: E731
+    tight = max(rel(a, b) for a, b in zip(res["ora32"], res["ref32"]))
+    loose = max(rel(a, b) for a, b in zip(res["ref32"], res["ref64"]))
+    assert tight <= 2e-5, tight
+    print(f"ConvPatchNet: oracle == reference module on the step's own input, worst rel-to-max err {tight:.2e} over output, d input and "
+          f"{len(res['ref32']) - 2} weight gradients (the reference in fp32 vs itself in fp64: {loose:.2e})")
+
+
 def gen_single(tag, cfg, seed, B, n_steps, hp):
-    ref_steps = run_reference_steps(cfg, seed, B, n_steps, hp)
+    global build_ref_model
+    cap, orig = {}, build_ref_model
+    if cfg.patchnet == "conv":
+        def build_ref_model(c, dp=0.0):
+            m = orig(c, dp)
+
+            def grab_in(mod, inp):
+                cap.setdefault("x", inp[0].detach().clone())
+
+            def grab_go(mod, gi, go):
+                cap.setdefault("go", go[0].detach().clone())
+            m.patch_extractor.register_forward_pre_hook(grab_in)
+            m.patch_extractor.register_full_backward_hook(grab_go)
+            return m
+    try:
+        ref_steps = run_reference_steps(cfg, seed, B, n_steps, hp)
+    finally:
+        build_ref_model = orig
     ora_steps = run_oracle_steps(cfg, seed, B, n_steps, hp, teacher=ref_steps)
-    compare(ref_steps, ora_steps, tag=tag, lr=hp.lr)
+    if cfg.patchnet == "conv":
+        check_conv_module(cfg, seed, cap["x"], cap["go"])
+    compare(ref_steps, ora_steps, tag=tag, lr=hp.lr, nonsmooth=cfg if cfg.patchnet == "conv" else None)
     check_adamw_formula(ref_steps[0], cfg, seed, hp, O.adjust_moco_momentum(0.0, 10, hp.moco_m))
     os.makedirs(GOLD, exist_ok=True)
     np.savez_compressed(os.path.join(GOLD, f"{tag}.npz"), **pack(ref_steps, cfg, seed, B, hp))
@@ -449,6 +509,9 @@ if __name__ == "__main__":
         if a.only in ("", "regular"):               # the reference CLI's defaults: --patchnet_name regular with --num_windows 5 (run_mae_pretraining_moco.py:143-145)
             import dataclasses
             gen_single("tiny_w1_regular", dataclasses.replace(tiny, patchnet="regular", num_windows=5), 35, 4, 2, hp)
+        if a.only in ("", "conv"):                  # --patchnet_name conv (ConvPatchNet, :207-260): conv3x3 / BatchNorm2d / max-pool stack, one patch per image
+            import dataclasses
+            gen_single("tiny_w1_conv", dataclasses.replace(tiny, patchnet="conv", num_windows=5), 41, 8, 2, hp)
         if a.only in ("", "dp"):                    # --drop_path 0.3 (run_mae_pretraining_moco.py:87): stochastic depth in both encoders under keyed masks
             gen_single("tiny_w1_dp", O.DiGConfig(**dict(O.TINY, depth=3)), 29, 8, 2, O.StepHyper(lr=1e-3, drop_path=0.3, drop_seed=1234))
         if a.only in ("", "mim2"):                  # only_mim_on_ori_img=False: both views masked, MIM loss on both (engine :100-111,138-141)

@@ -161,6 +161,25 @@ def test_regular_patchnet_step_matches_reference(golden_dir):
     check_step0(g)
 
 
+def test_conv_patchnet_step_matches_reference(golden_dir):
+    """--patchnet_name conv (ConvPatchNet, modeling_pretrain_moco_mim_ori.py:207-260): conv3x3 / BatchNorm2d / ReLU x 4 with three max-pools, one
+    patch per image.  Losses, activations, buffers as everywhere; gradients in the per-tensor norm at 1e-2 without element samples -- arg-max
+    and ReLU kinks make single elements jump under 1e-7 round-off differences (the reference in fp32 vs itself in fp64: 5e-2 of the maximum;
+    oracle/ref_harness/gen_golden.py::compare), and the module alone is pinned at 5e-6 on identical inputs while the fixture is generated
+    (check_conv_module)."""
+    g = load(golden_dir, "tiny_w1_conv")
+    cfg = cfg_from(g)
+    pn = g["s0/param_names"].tolist()
+    assert cfg.patchnet == "conv" and cfg.n_patch == 1 and cfg.conv_channels == (128, 128, 192, 256, 256)
+    assert "patch_extractor.conv_layers.4.0.weight" in pn and "momentum_patch_extractor.patches2global.3.bias" in pn
+    assert "patch_extractor.conv_layers.6.1.running_var" in g["s0/buf_names"].tolist()
+    check_step0(g, rtol=1e-2, samples=False)
+    names, norms = g["s0/grad_names"].tolist(), g["s0/grad_norms"]
+    for n, v in zip(names, norms):
+        if O.bn_cancelled_bias(n, cfg):
+            assert v <= 1e-6, (n, v)                                      # a bias in front of a BatchNorm: zero gradient, round-off in the reference too
+
+
 def test_drop_path_step_matches_reference(golden_dir):
     """--drop_path 0.3 (run_mae_pretraining_moco.py:87): stochastic depth on both branches of blocks 1.. of BOTH encoders, the unmodified
     reference run with every DropPath instance drawing the keyed per-sample masks the device and the oracle draw (gen_golden.patch_drop_paths)."""
