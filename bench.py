@@ -403,7 +403,7 @@ def main():
                     help="simmim_moco = the headline model (pretrain_simmim_moco_ori_*); simmim / moco = the reference's single-objective "
                          "factories (pretrain_simmim_ori_* Gen-only, pretrain_moco_ori_* Dis-only): their own JSON line, not the headline")
     ap.add_argument("--num-windows", type=int, default=4, help="README: 4; the reference's argparse default is 5 (uneven pooling windows)")
-    ap.add_argument("--patchnet-name", default="no_patchtrans", choices=["no_patchtrans", "regular"],
+    ap.add_argument("--patchnet-name", default="no_patchtrans", choices=["no_patchtrans", "regular", "conv"],
                     help="README: no_patchtrans; the reference's argparse default is regular (PatchNet with its 2-block patch transformer)")
     ap.add_argument("--drop-path", type=float, default=0.0, help="stochastic depth rate (--drop_path of the reference driver; README: 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -117,19 +117,24 @@ int dig_gemm_bf16_dropout(const void* A_, const void* B_, void* C_, int I, int J
   bf16_t* pre = (bf16_t*)pre_;
   const int arows = a_rows > 0 ? a_rows : (trans_a ? R : I);
   const int brows = b_rows > 0 ? b_rows : (trans_b ? R : J);
-  // operands as dense fp32 [I][R] / [J][R] (rows past a_rows / b_rows read as zero)
+  // operands as dense fp32 [I][R] / [J][R] (rows past a_rows / b_rows read as zero -- and, as through the HIP build's buffer descriptors of
+  // a_rows x lda / b_rows x ldb elements, anything past the operand's last element: a direct operand whose reduction runs past its row pitch
+  // (ConvPatchNet's 2592-column weight rows under a 2624-column zero-padded im2col matrix) wraps into the next row and ends in zeros)
+  const size_t a_elems = (size_t)arows * lda, b_elems = (size_t)brows * ldb;
   std::vector<float> a((size_t)I * R), b((size_t)J * R);
 #pragma omp parallel for
   for (int i = 0; i < I; ++i)
     for (int r = 0; r < R; ++r) {
       const int row = trans_a ? r : i;
-      a[(size_t)i * R + r] = row < arows ? bf2f(trans_a ? A[(size_t)r * lda + i] : A[(size_t)i * lda + r]) : 0.f;
+      const size_t at = trans_a ? (size_t)r * lda + i : (size_t)i * lda + r;
+      a[(size_t)i * R + r] = (row < arows && at < a_elems) ? bf2f(A[at]) : 0.f;
     }
 #pragma omp parallel for
   for (int j = 0; j < J; ++j)
     for (int r = 0; r < R; ++r) {
       const int row = trans_b ? r : j;
-      b[(size_t)j * R + r] = row < brows ? bf2f(trans_b ? B[(size_t)r * ldb + j] : B[(size_t)j * ldb + r]) : 0.f;
+      const size_t at = trans_b ? (size_t)r * ldb + j : (size_t)j * ldb + r;
+      b[(size_t)j * R + r] = (row < brows && at < b_elems) ? bf2f(B[at]) : 0.f;
     }
   if (out_kind == 2) {
     float* C = (float*)C_;
@@ -770,7 +775,7 @@ static inline void pool_window(int win, int gw, int nwin, int& c_lo, int& wlen) 
 }
 
 int dig_window_pool_fwd(const void* x_, void* out, int out_is_f32, int n_img, int gh, int gw, int nwin, int D, hipStream_t) {
-  if (!x_ || !out || n_img <= 0 || nwin <= 0 || nwin > gw || (D & 1)) return DIG_ERR_ARG;
+  if (!x_ || !out || n_img <= 0 || nwin <= 0 || gh <= 0 || gw <= 0 || (D & 1)) return DIG_ERR_ARG;
   const bf16_t* x = (const bf16_t*)x_;
 #pragma omp parallel for
   for (int idx = 0; idx < n_img * nwin; ++idx) {
@@ -790,7 +795,7 @@ int dig_window_pool_fwd(const void* x_, void* out, int out_is_f32, int n_img, in
 }
 
 int dig_window_pool_bwd(const void* dpool_, void* dx_, int n_img, int gh, int gw, int nwin, int D, int accumulate, hipStream_t) {
-  if (!dpool_ || !dx_ || n_img <= 0 || nwin <= 0 || nwin > gw || (D & 1)) return DIG_ERR_ARG;
+  if (!dpool_ || !dx_ || n_img <= 0 || nwin <= 0 || gh <= 0 || gw <= 0 || (D & 1)) return DIG_ERR_ARG;
   const bf16_t* dpool = (const bf16_t*)dpool_;
   bf16_t* dx = (bf16_t*)dx_;
   const int ntok = gh * gw;
@@ -799,7 +804,7 @@ int dig_window_pool_bwd(const void* dpool_, void* dx_, int n_img, int gh, int gw
     const int img = t / ntok, n = t % ntok, col = n % gw, w0 = (col * nwin) / gw;
     for (int d = 0; d < D; ++d) {
       float a = 0.f;
-      for (int win = std::max(0, w0 - 1); win <= std::min(nwin - 1, w0 + 1); ++win) {
+      for (int win = std::max(0, w0 - 1); win <= std::min(nwin - 1, ((col + 1) * nwin + gw - 1) / gw - 1); ++win) {
         int c_lo, wlen;
         pool_window(win, gw, nwin, c_lo, wlen);
         if (col < c_lo || col >= c_lo + wlen) continue;
@@ -808,6 +813,78 @@ int dig_window_pool_bwd(const void* dpool_, void* dx_, int n_img, int gh, int gw
       if (accumulate) a += bf2f(dx[(size_t)t * D + d]);
       dx[(size_t)t * D + d] = f2bf(a);
     }
+  }
+  return DIG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------ ConvPatchNet data movement
+int dig_im2col3x3(const void* x_, void* col_, int n_img, int H, int W, int C, int ldc, hipStream_t) {
+  if (!x_ || !col_ || n_img <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7) || ldc < 9 * C || (ldc & 7)) return DIG_ERR_ARG;
+  const bf16_t* x = (const bf16_t*)x_;
+  bf16_t* col = (bf16_t*)col_;
+  const long rows = (long)n_img * H * W;
+#pragma omp parallel for
+  for (long r = 0; r < rows; ++r) {
+    const int xx = (int)(r % W), yy = (int)((r / W) % H);
+    bf16_t* o = col + (size_t)r * ldc;
+    for (int t = 0; t < 9; ++t) {
+      const int y2 = yy + t / 3 - 1, x2 = xx + t % 3 - 1;
+      const bool in = y2 >= 0 && y2 < H && x2 >= 0 && x2 < W;
+      const bf16_t* s = x + ((long)r + (long)(t / 3 - 1) * W + (t % 3 - 1)) * (long)C;
+      for (int c = 0; c < C; ++c) o[c * 9 + t] = in ? s[c] : (bf16_t)0;
+    }
+    for (int c = 9 * C; c < ldc; ++c) o[c] = 0;
+  }
+  return DIG_OK;
+}
+
+int dig_conv3x3_weight_flip(const void* w_, void* wt_, int c_out, int c_in, hipStream_t) {
+  if (!w_ || !wt_ || c_out <= 0 || c_in <= 0) return DIG_ERR_ARG;
+  const bf16_t* w = (const bf16_t*)w_;
+  bf16_t* wt = (bf16_t*)wt_;
+  for (int co = 0; co < c_out; ++co)
+    for (int ci = 0; ci < c_in; ++ci)
+      for (int t = 0; t < 9; ++t) wt[((size_t)ci * c_out + co) * 9 + t] = w[((size_t)co * c_in + ci) * 9 + 8 - t];
+  return DIG_OK;
+}
+
+int dig_maxpool2x2_fwd(const void* x_, void* y_, unsigned char* idx, int n_img, int H, int W, int C, hipStream_t) {
+  if (!x_ || !y_ || !idx || n_img <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || C <= 0 || (C & 7)) return DIG_ERR_ARG;
+  const bf16_t* x = (const bf16_t*)x_;
+  bf16_t* y = (bf16_t*)y_;
+  const int Ho = H / 2, Wo = W / 2;
+#pragma omp parallel for
+  for (long ro = 0; ro < (long)n_img * Ho * Wo; ++ro) {
+    const int xo = (int)(ro % Wo), yo = (int)((ro / Wo) % Ho);
+    const long b = ro / ((long)Wo * Ho);
+    const bf16_t* p = x + ((b * H + 2 * yo) * W + 2 * xo) * (size_t)C;
+    for (int c = 0; c < C; ++c) {
+      bf16_t m = p[c];
+      unsigned char am = 0;
+      for (int t = 1; t < 4; ++t) {
+        const bf16_t v = p[((size_t)(t >> 1) * W + (t & 1)) * C + c];
+        const float fv = bf2f(v), fm = bf2f(m);
+        if (fv > fm || fv != fv) { m = v; am = (unsigned char)t; }
+      }
+      y[(size_t)ro * C + c] = m;
+      idx[(size_t)ro * C + c] = am;
+    }
+  }
+  return DIG_OK;
+}
+
+int dig_maxpool2x2_bwd(const void* dy_, const unsigned char* idx, void* dx_, int n_img, int H, int W, int C, hipStream_t) {
+  if (!dy_ || !dx_ || !idx || n_img <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || C <= 0 || (C & 7)) return DIG_ERR_ARG;
+  const bf16_t* dy = (const bf16_t*)dy_;
+  bf16_t* dx = (bf16_t*)dx_;
+  const int Ho = H / 2, Wo = W / 2;
+#pragma omp parallel for
+  for (long ro = 0; ro < (long)n_img * Ho * Wo; ++ro) {
+    const int xo = (int)(ro % Wo), yo = (int)((ro / Wo) % Ho);
+    const long b = ro / ((long)Wo * Ho);
+    bf16_t* p = dx + ((b * H + 2 * yo) * W + 2 * xo) * (size_t)C;
+    for (int c = 0; c < C; ++c)
+      for (int t = 0; t < 4; ++t) p[((size_t)(t >> 1) * W + (t & 1)) * C + c] = idx[(size_t)ro * C + c] == t ? dy[(size_t)ro * C + c] : (bf16_t)0;
   }
   return DIG_OK;
 }

@@ -190,6 +190,9 @@ __device__ __forceinline__ void pool_window(int win, int gw, int nwin, int& c_lo
   c_lo = (win * gw) / nwin;
   wlen = ((win + 1) * gw + nwin - 1) / nwin - c_lo;
 }
+// Last window whose bin holds column `col` (the first is floor(col nwin / gw)): at most the next one when nwin <= gw; with MORE windows than
+// columns (ConvPatchNet pools its 1 x 4 map to (1, num_windows), :254) a column feeds ceil(nwin / gw) + 1 of them.
+__device__ __forceinline__ int pool_last_window(int col, int gw, int nwin) { return ((col + 1) * nwin + gw - 1) / gw - 1; }
 
 // x [n_img, gh*gw, D] bf16 -> out [n_img*nwin, D] (fp32 or bf16): mean over all gh rows and the window's columns
 template <typename OutT>
@@ -291,7 +294,7 @@ __global__ __launch_bounds__(256) void window_pool_bwd16_kernel(const bf16_t* __
     float v[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) v[k] = 0.f;
-    for (int win = max(0, w0 - 1); win <= min(nwin - 1, w0 + 1); ++win) {
+    for (int win = max(0, w0 - 1); win <= min(nwin - 1, pool_last_window(col, gw, nwin)); ++win) {
       int c_lo, wlen;
       pool_window(win, gw, nwin, c_lo, wlen);
       if (col < c_lo || col >= c_lo + wlen) continue;
@@ -321,7 +324,7 @@ __global__ void window_pool_bwd_kernel(const bf16_t* __restrict__ dpool, bf16_t*
   const int col = n % gw, w0 = (col * nwin) / gw;
   for (int d2 = threadIdx.x; d2 < D / 2; d2 += blockDim.x) {
     float a0 = 0.f, a1 = 0.f;
-    for (int win = max(0, w0 - 1); win <= min(nwin - 1, w0 + 1); ++win) {
+    for (int win = max(0, w0 - 1); win <= min(nwin - 1, pool_last_window(col, gw, nwin)); ++win) {
       int c_lo, wlen;
       pool_window(win, gw, nwin, c_lo, wlen);
       if (col < c_lo || col >= c_lo + wlen) continue;
@@ -685,7 +688,7 @@ extern "C" int dig_patch_embed_bwd(const void* dy, const float* img, const unsig
 
 extern "C" int dig_window_pool_fwd(const void* x, void* out, int out_is_f32, int n_img, int gh, int gw, int nwin, int D,
                                    hipStream_t stream) {
-  if (!x || !out || n_img <= 0 || nwin <= 0 || nwin > gw || (D & 1)) return DIG_ERR_ARG;
+  if (!x || !out || n_img <= 0 || nwin <= 0 || gh <= 0 || gw <= 0 || (D & 1)) return DIG_ERR_ARG;
   if ((D & 7) == 0 && D / 8 <= 256 && aligned16(x) && aligned16(out)) {
     if (out_is_f32)
       hipLaunchKernelGGL(window_pool_fwd16_kernel<float>, dim3(n_img * nwin), dim3(256), 0, stream, (const bf16_t*)x, (float*)out, n_img, gh, gw, nwin, D);
@@ -704,7 +707,7 @@ extern "C" int dig_window_pool_fwd(const void* x, void* out, int out_is_f32, int
 
 extern "C" int dig_window_pool_bwd(const void* dpool, void* dx, int n_img, int gh, int gw, int nwin, int D, int accumulate,
                                    hipStream_t stream) {
-  if (!dpool || !dx || n_img <= 0 || nwin <= 0 || nwin > gw || (D & 1)) return DIG_ERR_ARG;
+  if (!dpool || !dx || n_img <= 0 || nwin <= 0 || gh <= 0 || gw <= 0 || (D & 1)) return DIG_ERR_ARG;
   if ((D & 7) == 0 && aligned16(dpool) && aligned16(dx)) {
     const size_t total = (size_t)n_img * gh * gw * (D / 8);
     hipLaunchKernelGGL(window_pool_bwd16_kernel, dim3((unsigned)std::min<size_t>(2048, (total + 255) / 256)), dim3(256), 0, stream,

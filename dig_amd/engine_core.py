@@ -858,6 +858,11 @@ class _Step:
         def extract(masked, enc_rows, pre, arena, save):
             """patch_extractor (PatchNet.forward, :189-205): the pooled windows of [masked view | augmented view]; with --patchnet_name regular
             they then attend over all tokens of their image (dig_amd/patchnet.py)."""
+            if M.patchnet == 'conv':
+                # ConvPatchNet (:207-260): no window pooling in front -- the token maps of both views through the convolution stack, one row per image
+                from . import convpatchnet
+                feat = torch.cat([masked, enc_rows[B * N:]]) if masked.data_ptr() != enc_rows.data_ptr() else enc_rows
+                return convpatchnet.forward(self, feat, pre, arena, 2 * B, save)
             pooled = torch.empty((2 * B * nw, D), device=dev, dtype=BF16)
             ops.window_pool_fwd(masked, pooled[:B * nw], B, M.gh, M.gw, nw, D)
             ops.window_pool_fwd(enc_rows[B * N:], pooled[B * nw:], B, M.gh, M.gw, nw, D)
@@ -952,7 +957,7 @@ class _Step:
         _mark("forward: both encoders + heads joined", dev)
         M._flat["bn_count"] += 1                                            # all 14 (Dis-only: 8) BatchNorm layers ran once
         # ---- InfoNCE (:444-461): q1 vs gathered k2, q2 vs gathered k1, labels = arange + n*rank
-        n = B * nw                                                          # rows of q1 / q2
+        n = B * M.n_patch                                                   # rows of q1 / q2
         dim = M.moco_dim
         qf = torch.empty((2 * n, dim), device=dev, dtype=F32)
         kf = torch.empty((2 * n, dim), device=dev, dtype=F32)
@@ -1047,7 +1052,7 @@ class _Step:
         views = 2 if (contrast or (g_vis is not None and self.mim_views == 2)) else 1      # encoder rows that carry a gradient
         # (Dis-only: no pix_projector writes view 0's rows -- both halves come from the pooling gradient, which overwrites)
         d_enc = torch.empty_like(self.enc) if contrast else torch.zeros((views * B * N, D), device=dev, dtype=BF16)
-        n = B * nw
+        n = B * M.n_patch
         if contrast:
             dqn = self.dqn
             ops.scale_by_device_scalar(dqn, g_contra.reshape(1).float())
@@ -1066,7 +1071,15 @@ class _Step:
                 dpool, dfeat = patchnet.backward(self, dpool, "patch_extractor", self.saved_pnet, 2 * B)
                 self._grad_ready(dev, "patch_extractor")
                 d_enc, acc = dfeat, True
-            if M.has_pix_projector:
+            if M.patchnet == 'conv':
+                # ConvPatchNet's backward hands the gradient w.r.t. the token maps of [masked view | augmented view] straight back
+                from . import convpatchnet
+                d_enc = convpatchnet.backward(self, dpool, "patch_extractor", self.saved_pnet, 2 * B)
+                self._grad_ready(dev, "patch_extractor")
+                if M.has_pix_projector:
+                    self.mlp_backward(d_enc[:B * N], "pix_projector", self.saved_pix, dx_out=d_enc[:B * N])
+                    self._grad_ready(dev, "pix_projector")
+            elif M.has_pix_projector:
                 dmasked2 = d_enc[:B * N] if acc else torch.empty((B * N, D), device=dev, dtype=BF16)
                 ops.window_pool_bwd(dpool[:n], dmasked2, B, M.gh, M.gw, nw, D, acc)
                 ops.window_pool_bwd(dpool[n:], d_enc[B * N:], B, M.gh, M.gw, nw, D, acc)
@@ -1077,7 +1090,7 @@ class _Step:
                 ops.window_pool_bwd(dpool[:n], d_enc[:B * N], B, M.gh, M.gw, nw, D, acc)
                 ops.window_pool_bwd(dpool[n:], d_enc[B * N:], B, M.gh, M.gw, nw, D, acc)
         elif M.use_moco_target:
-            for name in (("predictor", "encoder_projection_layer") + (("patch_extractor",) if M.patchnet == 'regular' else ())
+            for name in (("predictor", "encoder_projection_layer") + (("patch_extractor",) if M.patchnet != 'no_patchtrans' else ())
                          + (("pix_projector",) if M.has_pix_projector else ())):
                 self.comm.grad_ready(M, name)
         # ---- SimMIM decoder path

@@ -90,10 +90,8 @@ class MoCo_ViT(nn.Module):
             raise ValueError("MoCo_ViT needs at least one objective (use_pixel_target / use_moco_target)")
         if use_pixel_target and use_moco_target and not use_pix_projector:
             raise NotImplementedError("use_pix_projector=False (no factory of the reference sets it) is not built")
-        if patchnet_name not in ('no_patchtrans', 'regular') and use_moco_target:
-            # ('conv' = ConvPatchNet, modeling_pretrain_moco_mim_ori.py:207-260: a 3x3-convolution / BatchNorm2d / max-pool stack -- no kernel of
-            #  this library is a convolution; the README recipe is 'no_patchtrans', the argparse default 'regular')
-            raise NotImplementedError(f"patchnet_name={patchnet_name!r}: 'no_patchtrans' (README) and 'regular' (the CLI default) are implemented")
+        if patchnet_name not in ('no_patchtrans', 'regular', 'conv') and use_moco_target:
+            raise NotImplementedError(f"patchnet_name={patchnet_name!r}: 'regular', 'no_patchtrans' or 'conv' (modeling_pretrain_moco_mim_ori.py:371-382)")
         if drop_rate or attn_drop_rate or init_values or use_learnable_pos_emb or label_smoothing:
             raise NotImplementedError("dropout / layer-scale / learnable pos-emb / label smoothing are 0 in pre-training (no flag of "
                                       "run_mae_pretraining_moco.py sets them)")
@@ -129,6 +127,8 @@ class MoCo_ViT(nn.Module):
         self.use_pixel_target, self.use_moco_target = bool(use_pixel_target), bool(use_moco_target)
         self.patchnet = patchnet_name if use_moco_target else 'no_patchtrans'
         self.patchnet_depth = 2                                          # `depth=2` where MoCo_ViT builds its patch_extractor (:383-396)
+        # rows per image the patch extractor hands to the projector: the pooled windows, or ConvPatchNet's single row (`.unsqueeze(1)`, :257)
+        self.n_patch = 1 if self.patchnet == 'conv' else num_windows
         self.has_pix_projector = self.use_pixel_target and self.use_moco_target
         self.has_final_norm = not self.use_moco_target
         self.comm = None            # set by dig_amd.parallel.DistributedDataParallel
@@ -182,6 +182,32 @@ class MoCo_ViT(nn.Module):
                   ParamSpec(b + "mlp.fc2.bias", (D,), 1, arena)]
         return s + [ParamSpec(pre + ".norm.weight", (D,), 1, arena), ParamSpec(pre + ".norm.bias", (D,), 1, arena)]
 
+    def _convnet_specs(self, pre, arena):
+        """ConvPatchNet: modeling_pretrain_moco_mim_ori.py:216-232 (conv_layers.{0,2,4,6} = Conv2d 3x3 with bias + BatchNorm2d; patches2global =
+        Linear, BatchNorm1d, ReLU, Linear, BatchNorm1d(affine=False))."""
+        from .convpatchnet import CONV_IDX, channels
+        c, D = channels(self.D), self.D
+        s = []
+        for j, i in enumerate(CONV_IDX):
+            b = f"{pre}.conv_layers.{i}."
+            s += [ParamSpec(b + "0.weight", (c[j + 1], c[j], 3, 3), 0, arena), ParamSpec(b + "0.bias", (c[j + 1],), 1, arena),
+                  ParamSpec(b + "1.weight", (c[j + 1],), 1, arena), ParamSpec(b + "1.bias", (c[j + 1],), 1, arena)]
+        g = pre + ".patches2global."
+        return s + [ParamSpec(g + "0.weight", (D, c[4] * self.num_windows), 0, arena), ParamSpec(g + "0.bias", (D,), 1, arena),
+                    ParamSpec(g + "1.weight", (D,), 1, arena), ParamSpec(g + "1.bias", (D,), 1, arena),
+                    ParamSpec(g + "3.weight", (D, D), 0, arena), ParamSpec(g + "3.bias", (D,), 1, arena)]
+
+    def _bn_layers(self):
+        """(state_dict prefix, channels) of every BatchNorm layer, in the reference's registration order: the BN-MLP heads, then ConvPatchNet's."""
+        out = [(f"{pre}.{3 * l + 1}", d2) for pre, dims in self.mlps.items() for l, (_, d2) in enumerate(dims)]
+        if self.patchnet == 'conv':
+            from .convpatchnet import CONV_IDX, channels
+            c = channels(self.D)
+            for pre in ("patch_extractor", "momentum_patch_extractor"):
+                out += [(f"{pre}.conv_layers.{i}.1", c[j + 1]) for j, i in enumerate(CONV_IDX)]
+                out += [(f"{pre}.patches2global.1", self.D), (f"{pre}.patches2global.4", self.D)]
+        return out
+
     @staticmethod
     def _mlp_specs(pre, dims, arena):
         s, n = [], len(dims)
@@ -209,6 +235,9 @@ class MoCo_ViT(nn.Module):
             if self.patchnet == 'regular':
                 specs += self._patchnet_specs("patch_extractor", "online")
                 specs += self._patchnet_specs("momentum_patch_extractor", "momentum")
+            elif self.patchnet == 'conv':
+                specs += self._convnet_specs("patch_extractor", "online")
+                specs += self._convnet_specs("momentum_patch_extractor", "momentum")
         if self.has_pix_projector:
             specs += self._mlp_specs("pix_projector", self.mlps["pix_projector"], "online")
             specs += self._mlp_specs("pix_projector_m", self.mlps["pix_projector_m"], "momentum")
@@ -264,7 +293,7 @@ class MoCo_ViT(nn.Module):
             assert self.specs[src].offset == self.specs[n].offset, (n, src)
         # gradient-bucket boundaries (element ranges of the online arena), in backward-completion order
         heads = [k for k, on in (("pix_decoder", self.use_pixel_target), ("predictor", self.use_moco_target),
-                                 ("encoder_projection_layer", self.use_moco_target), ("patch_extractor", self.patchnet == 'regular'),
+                                 ("encoder_projection_layer", self.use_moco_target), ("patch_extractor", self.patchnet != 'no_patchtrans'),
                                  ("pix_projector", self.has_pix_projector)) if on]
         self.bucket_names = (heads + (["encoder.norm"] if self.has_final_norm else [])
                              + [f"encoder.blocks.{i}" for i in reversed(range(self.depth))] + ["encoder.embed"])
@@ -305,8 +334,8 @@ class MoCo_ViT(nn.Module):
             "grad": torch.zeros(self.n_online, dtype=F32, device=device),
             "groups": torch.tensor(self._online_groups, dtype=torch.uint8, device=device),
         }
-        n_bn = sum(len(d) for d in self.mlps.values())
-        c_tot = sum(d2 for dims in self.mlps.values() for _, d2 in dims)
+        n_bn = len(self._bn_layers())
+        c_tot = sum(C for _, C in self._bn_layers())
         self._flat["bn_stats"] = torch.zeros(2 * c_tot, dtype=F32, device=device)      # running_mean | running_var
         self._flat["bn_count"] = torch.zeros(n_bn, dtype=torch.int64, device=device)
         self._shadow = {}
@@ -326,15 +355,14 @@ class MoCo_ViT(nn.Module):
         self._buffer_slots = []
         c_off, i_bn = 0, 0
         c_tot = self._flat["bn_stats"].numel() // 2
-        for pre, dims in self.mlps.items():
-            for l, (_, d2) in enumerate(dims):
-                mod, _ = _node_for(self, f"{pre}.{3 * l + 1}.x")
-                self._buffer_slots.append((f"{pre}.{3 * l + 1}", c_off, d2, i_bn))
-                mod.register_buffer("running_mean", None)
-                mod.register_buffer("running_var", None)
-                mod.register_buffer("num_batches_tracked", None)
-                c_off += d2
-                i_bn += 1
+        for key, d2 in self._bn_layers():
+            mod, _ = _node_for(self, key + ".x")
+            self._buffer_slots.append((key, c_off, d2, i_bn))
+            mod.register_buffer("running_mean", None)
+            mod.register_buffer("running_var", None)
+            mod.register_buffer("num_batches_tracked", None)
+            c_off += d2
+            i_bn += 1
         self.encoder.pos_embed = get_sinusoid_encoding_table(self.N, self.D)     # plain attribute (not in state_dict)
         if self.use_moco_target:
             self.momentum_encoder.pos_embed = self.encoder.pos_embed
@@ -407,6 +435,19 @@ class MoCo_ViT(nn.Module):
                     v.uniform_(-a, a)
                 elif n.endswith("patch_embed.proj.bias") and not self.use_moco_target:
                     v.uniform_(-1.0 / math.sqrt(48.0), 1.0 / math.sqrt(48.0))
+                elif n.startswith("patch_extractor.") and self.patchnet == 'conv':
+                    # ConvPatchNet has no _init_weights: nn.Conv2d / nn.Linear defaults (weight and bias U(+-1/sqrt(fan_in))), BatchNorm 1 / 0
+                    if len(s.shape) >= 2:
+                        b = 1.0 / math.sqrt(s.numel // s.shape[0])
+                        v.uniform_(-b, b)
+                    elif n.endswith((".0.bias", ".3.bias")):
+                        ws = self.specs[n[:-4] + "weight"]
+                        b = 1.0 / math.sqrt(ws.numel // ws.shape[0])
+                        v.uniform_(-b, b)
+                    elif n.endswith(".weight"):
+                        v.fill_(1.0)
+                    else:
+                        v.zero_()
                 elif n.startswith(("encoder.", "patch_extractor.")):    # (PatchNet._init_weights, :159-166: the encoder's rule)
                     if len(s.shape) == 2:
                         nn.init.xavier_uniform_(v)

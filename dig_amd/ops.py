@@ -798,6 +798,36 @@ def window_pool_bwd(dpool, dx, n_img, gh, gw, nwin, D, accumulate):
     L.call("dig_window_pool_bwd", L.ptr(dpool), L.ptr(dx), n_img, gh, gw, nwin, D, int(accumulate), L.stream())
 
 
+# ---- ConvPatchNet data movement (csrc/conv_patch.hip): NHWC bf16 maps [n_img * H * W, C]
+def im2col3x3(x, n_img, H, W, C):
+    """[n_img H W, ldc] matrix of a 3x3 / pad 1 convolution over x, columns c * 9 + ky * 3 + kx (conv.weight.view(C_out, -1)'s order), the row
+    pitch rounded up to the GEMM's 64-element reduction granule (pad columns zero)."""
+    ldc = _round_up(9 * C, 64)
+    col = torch.empty((n_img * H * W, ldc), device=x.device, dtype=BF16)
+    L.call("dig_im2col3x3", L.ptr(x), L.ptr(col), n_img, H, W, C, ldc, L.stream())
+    return col
+
+
+def conv3x3_weight_flip(w, c_out, c_in):
+    """[c_in, c_out * 9] bf16: the taps of w [c_out, c_in * 9] flipped and transposed (the data gradient's convolution weights)."""
+    wt = torch.empty((c_in, c_out * 9), device=w.device, dtype=BF16)
+    L.call("dig_conv3x3_weight_flip", L.ptr(w), L.ptr(wt), c_out, c_in, L.stream())
+    return wt
+
+
+def maxpool2x2_fwd(x, n_img, H, W, C):
+    y = torch.empty((n_img * (H // 2) * (W // 2), C), device=x.device, dtype=BF16)
+    idx = torch.empty((n_img * (H // 2) * (W // 2), C), device=x.device, dtype=torch.uint8)
+    L.call("dig_maxpool2x2_fwd", L.ptr(x), L.ptr(y), L.ptr(idx), n_img, H, W, C, L.stream())
+    return y, idx
+
+
+def maxpool2x2_bwd(dy, idx, n_img, H, W, C):
+    dx = torch.empty((n_img * H * W, C), device=dy.device, dtype=BF16)
+    L.call("dig_maxpool2x2_bwd", L.ptr(dy), L.ptr(idx), L.ptr(dx), n_img, H, W, C, L.stream())
+    return dx
+
+
 _MASK_KINDS = {torch.bool: 0, torch.uint8: 0, torch.float32: 1, torch.float64: 2, torch.int32: 3, torch.int64: 4}
 
 

@@ -279,9 +279,26 @@ int dig_colsum_masked(const void* x, const unsigned char* mask, float* out_unmas
 /* PatchNet 'no_patchtrans' = adaptive_avg_pool2d of the gh x gw token grid to (1, nwin)
  * (modeling_pretrain_moco_mim_ori.py:189-193) and its gradient (accumulate=1 adds into dx).  Window `w` = all gh rows x columns
  * [floor(w gw / nwin), ceil((w + 1) gw / nwin)): equal windows when nwin divides gw (README: 4 on 32 columns), overlapping bins of
- * 7 / 7 / 8 / 7 / 7 columns for the argparse default --num_windows 5 (run_mae_pretraining_moco.py:143); nwin <= gw. */
+ * 7 / 7 / 8 / 7 / 7 columns for the argparse default --num_windows 5 (run_mae_pretraining_moco.py:143).  nwin > gw is allowed (ConvPatchNet pools
+ * its 1 x 4 map to (1, num_windows), :254: a column then feeds several windows). */
 int dig_window_pool_fwd(const void* x, void* out, int out_is_f32, int n_img, int gh, int gw, int nwin, int D, hipStream_t stream);
 int dig_window_pool_bwd(const void* dpool, void* dx, int n_img, int gh, int gw, int nwin, int D, int accumulate, hipStream_t stream);
+
+/* ConvPatchNet (`--patchnet_name conv`, modeling_pretrain_moco_mim_ori.py:207-260) on NHWC bf16 maps [n_img, H, W, C] (the encoder's token
+ * matrix [n_img, 8 * 32, C] is the map of :251-253).  Its conv3x3_blocks (:239-248: nn.Conv2d(k 3, stride 1, pad 1) -> BatchNorm2d -> ReLU) run as
+ * dig_gemm_bf16 over the im2col matrix in the reference's own weight layout, BatchNorm2d as dig_bn_* over the [n_img H W, C] rows:
+ *   dig_im2col3x3:  col[(b, y, x), c * 9 + ky * 3 + kx] = map[b, y + ky - 1, x + kx - 1, c] (zero outside the map) -- the column order of
+ *                   conv.weight.view(C_out, C_in * 9), so conv = col @ W^T (+ bias) and dW = dy^T @ col on the arena's own views.  ldc >= 9 C
+ *                   (multiple of 8; a multiple of 64 for the GEMM's reduction granule): columns [9 C, ldc) are zero-filled.  C % 8 == 0.
+ *   dig_conv3x3_weight_flip:  wt[c_in, c_out * 9 + t] = w[c_out, c_in * 9 + 8 - t]: the convolution's data gradient is the convolution of dy with
+ *                   the flipped, transposed taps -- dx = im2col(dy) @ wt^T (what aten's conv backward-input computes).
+ *   dig_maxpool2x2_fwd / _bwd:  nn.MaxPool2d(kernel_size=2, stride=2) (:219-223) and its gradient.  idx [n_img, H/2, W/2, C] bytes: the position
+ *                   0..3 = (0,0), (0,1), (1,0), (1,1) of the maximum; the first one wins a tie (aten: `val > maxval` scan), NaN propagates.
+ *                   The backward writes every dx element (the gradient at the arg-max, zero elsewhere).  H, W even, C % 8 == 0. */
+int dig_im2col3x3(const void* x, void* col, int n_img, int H, int W, int C, int ldc, hipStream_t stream);
+int dig_conv3x3_weight_flip(const void* w, void* wt, int c_out, int c_in, hipStream_t stream);
+int dig_maxpool2x2_fwd(const void* x, void* y, unsigned char* idx, int n_img, int H, int W, int C, hipStream_t stream);
+int dig_maxpool2x2_bwd(const void* dy, const unsigned char* idx, void* dx, int n_img, int H, int W, int C, hipStream_t stream);
 
 /* The loader's mask [B, V, N] (elem_kind 0: 1-byte bool / uint8, 1: fp32, 2: fp64, 3: int32, 4: int64; non-zero = masked) as the view-major
  * uint8 rows [V * B, N] the encoder reads, views >= keep_views zeroed (only_mim_on_ori_img: keep_views = 1) -- the bool cast, fill, permute

@@ -303,6 +303,159 @@ def test_window_pool_uneven_windows(dev, nwin):
         assert (dx.cpu().float() - want.float()).abs().max().item() <= 2 ** -7 * want.float().abs().max().item()     # one bf16 rounding
 
 
+@pytest.mark.parametrize("nwin", [4, 5, 7, 32])
+def test_window_pool_more_windows_than_columns(dev, nwin):
+    """ConvPatchNet pools its 1 x 4 map to (1, num_windows) (modeling_pretrain_moco_mim_ori.py:254): with 5 (the CLI default) .. 32 windows on 4
+    columns a column feeds several windows -- forward and gradient against torch."""
+    from dig_amd import ops
+    Bn, D = 3, 256
+    x = torch.randn(Bn, 4, D, device=dev).bfloat16()
+    out = torch.empty(Bn * nwin, D, device=dev, dtype=torch.bfloat16)
+    ops.window_pool_fwd(x, out, Bn, 1, 4, nwin, D)
+    xr = x.float().cpu().reshape(Bn, 1, 4, D).permute(0, 3, 1, 2).requires_grad_(True)
+    ref = F.adaptive_avg_pool2d(xr, (1, nwin))
+    assert torch.equal(out.cpu(), ref.permute(0, 2, 3, 1).reshape(Bn * nwin, D).bfloat16())
+    dp = torch.randn(Bn * nwin, D, device=dev).bfloat16()
+    ref.backward(dp.float().cpu().reshape(Bn, 1, nwin, D).permute(0, 3, 1, 2))
+    dx = torch.empty(Bn, 4, D, device=dev, dtype=torch.bfloat16)
+    ops.window_pool_bwd(dp, dx, Bn, 1, 4, nwin, D, False)
+    want = xr.grad.permute(0, 2, 3, 1).reshape(Bn, 4, D)
+    assert (dx.cpu().float() - want).abs().max().item() <= 2 ** -7 * want.abs().max().item()
+
+
+@pytest.mark.parametrize("n_img,H,W,C", [(3, 8, 32, 64), (2, 4, 16, 96), (5, 2, 8, 288), (4, 1, 4, 128)])
+def test_im2col_and_weight_flip_are_bit_exact(dev, n_img, H, W, C):
+    """Byte work of the convolution-as-GEMM (csrc/conv_patch.hip): the im2col matrix against F.unfold (the column order of conv.weight.view(C_out,
+    -1)), its zero pad columns, and the flipped / transposed taps of the data gradient."""
+    from dig_amd import ops
+    x = torch.randn(n_img * H * W, C, device=dev).bfloat16()
+    col = ops.im2col3x3(x, n_img, H, W, C)
+    assert col.shape == (n_img * H * W, -(-9 * C // 64) * 64)
+    ref = F.unfold(x.cpu().float().reshape(n_img, H, W, C).permute(0, 3, 1, 2), 3, padding=1).transpose(1, 2).reshape(n_img * H * W, 9 * C)
+    assert torch.equal(col[:, :9 * C].cpu().float(), ref)
+    assert not col[:, 9 * C:].any()
+    co = 40
+    w = torch.randn(co, C * 9, device=dev).bfloat16()
+    wt = ops.conv3x3_weight_flip(w, co, C)
+    want = w.cpu().reshape(co, C, 9).flip(2).permute(1, 0, 2).reshape(C, co * 9)
+    assert torch.equal(wt.cpu(), want)
+
+
+@pytest.mark.parametrize("n_img,H,W,C", [(3, 8, 32, 64), (2, 4, 16, 96), (5, 2, 8, 288)])
+def test_maxpool2x2_matches_torch_including_ties(dev, n_img, H, W, C):
+    """nn.MaxPool2d(2, 2) (modeling_pretrain_moco_mim_ori.py:219-223) after a ReLU: values, arg-max bytes (first maximum wins: whole windows of
+    zeros are common) and the gradient routing, bit-exact against torch."""
+    from dig_amd import ops
+    x = torch.relu(torch.randn(n_img * H * W, C, device=dev)).bfloat16()
+    x[::3] = torch.round(x[::3].float() * 2).bfloat16() / 2                   # coarse values: ties between positive entries too
+    y, idx = ops.maxpool2x2_fwd(x, n_img, H, W, C)
+    xr = x.cpu().float().reshape(n_img, H, W, C).permute(0, 3, 1, 2).requires_grad_(True)
+    yr, ir = F.max_pool2d(xr, 2, 2, return_indices=True)
+    assert torch.equal(y.cpu().float(), yr.permute(0, 2, 3, 1).reshape(-1, C))
+    ir = ir.permute(0, 2, 3, 1)                                              # flat index h * W + w of the plane
+    hh, ww = ir // W, ir % W
+    pos = ((hh % 2) * 2 + (ww % 2)).reshape(-1, C).to(torch.uint8)
+    assert torch.equal(idx.cpu(), pos)
+    dy = torch.randn(n_img * (H // 2) * (W // 2), C, device=dev).bfloat16()
+    dx = ops.maxpool2x2_bwd(dy, idx, n_img, H, W, C)
+    yr.backward(dy.cpu().float().reshape(n_img, H // 2, W // 2, C).permute(0, 3, 1, 2))
+    assert torch.equal(dx.cpu().float(), xr.grad.permute(0, 2, 3, 1).reshape(-1, C))
+
+
+@pytest.mark.parametrize("n_img,H,W,ci,co", [(4, 8, 32, 128, 128), (4, 4, 16, 128, 192), (6, 2, 8, 288, 384), (8, 1, 4, 256, 256)])
+def test_conv3x3_as_gemm_forward_dgrad_wgrad(dev, n_img, H, W, ci, co):
+    """conv3x3_block's convolution (modeling_pretrain_moco_mim_ori.py:239-248) on the GEMM kernels: forward = im2col @ W^T + bias, data gradient =
+    im2col(dy) @ flip(W)^T, weight gradient = dy^T @ im2col -- against F.conv2d and autograd in fp32 on the same bf16 values (incl. the
+    288-channel map of ViT-Tiny whose 2592 columns are padded to 2624)."""
+    from dig_amd import ops
+    cpu_limit(dev, n_img * H * W * 9 * ci * co * 3.0)
+    rows = n_img * H * W
+    x = torch.randn(rows, ci, device=dev).bfloat16()
+    w = (torch.randn(co, ci * 9, device=dev) / (3 * ci ** 0.5)).bfloat16()
+    b = torch.randn(co, device=dev)
+    col = ops.im2col3x3(x, n_img, H, W, ci)
+    y = ops.gemm(col, w, rows, co, col.shape[1], bias=b)
+    xr = x.cpu().float().reshape(n_img, H, W, ci).permute(0, 3, 1, 2).requires_grad_(True)
+    wr = w.cpu().float().reshape(co, ci, 3, 3).requires_grad_(True)
+    yr = F.conv2d(xr, wr, b.cpu(), padding=1)
+    assert rel(y.cpu(), yr.permute(0, 2, 3, 1).reshape(rows, co)) < 1e-2
+    dy = torch.randn(rows, co, device=dev).bfloat16()
+    yr.backward(dy.cpu().float().reshape(n_img, H, W, co).permute(0, 3, 1, 2))
+    cold = ops.im2col3x3(dy, n_img, H, W, co)
+    dx = ops.gemm(cold, ops.conv3x3_weight_flip(w, co, ci), rows, ci, cold.shape[1])
+    assert rel(dx.cpu(), xr.grad.permute(0, 2, 3, 1).reshape(rows, ci)) < 1e-2
+    dw = torch.zeros(co, ci * 9, device=dev)
+    ops.wgrad(dy, col, dw, co, ci * 9, rows)
+    assert rel(dw.cpu(), wr.grad.reshape(co, ci * 9)) < 1e-2
+
+
+def test_conv_patchnet_module_vs_oracle(dev):
+    """dig_amd/convpatchnet.py (ConvPatchNet, --patchnet_name conv) in isolation: output, the gradient w.r.t. the image tokens and every
+    parameter gradient against fp32 autograd through oracle.conv_patch_extractor (pinned to the reference by tests/golden/tiny_w1_conv.npz) on
+    the same bf16 inputs and weights.  The map is piecewise linear with a kink per ReLU sign and per max-pool arg-max: bf16 rounding flips
+    some, each flip moves its own gradient elements by their full size -- the yardstick is the oracle itself under CPU bf16 autocast (the
+    device may be twice as far from fp32 as that run is, + 3 %).  Running statistics and batch counters: against the oracle's buffers."""
+    import dataclasses
+    import dig_oracle as O
+    from gpu_util import build_model
+    from dig_amd import engine_core, convpatchnet, ops
+    cfg = dataclasses.replace(O.DiGConfig(**O.TINY), patchnet="conv", num_windows=5)
+    n_img, N, D = 48, 256, cfg.embed_dim
+    P, S = O.det_state(cfg, 61)
+    model = build_model(cfg, P, S, device=str(dev))
+    torch.manual_seed(5)
+    feat = torch.randn(n_img * N, D).bfloat16().to(dev)
+    dout = (torch.randn(n_img, D) * 0.1).bfloat16().to(dev)
+    ops.cast_f32_to_bf16(model._flat["online"], model.shadow("online"))
+    model.flat_grads.zero_()
+    if dev.type == "cuda":
+        step = engine_core._Step(model)
+    else:
+        class step:                                                      # the CPU build: one "stream"
+            m, comm = model, engine_core.LOCAL
+
+            @staticmethod
+            def _on_side(dev_, fn, *t):
+                fn()
+    step._bn_touched = []
+    out, saved = convpatchnet.forward(step, feat, "patch_extractor", "online", n_img, True)
+    dfeat = convpatchnet.backward(step, dout, "patch_extractor", saved, n_img)
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+    assert out.shape == (n_img, D) and dfeat.shape == (n_img * N, D) and len(step._bn_touched) == 6
+
+    def run(autocast):
+        # the weights as the kernels read them (bf16 shadow values), in fp32
+        Pf = {k: (v.bfloat16().float() if v.dim() >= 2 else v.clone()).requires_grad_(True) for k, v in P.items() if k.startswith("patch_extractor.")}
+        Sf = {k: v.clone() for k, v in S.items()}
+        xf = feat.float().cpu().view(n_img, N, D).requires_grad_(True)
+        with torch.autocast("cpu", dtype=torch.bfloat16, enabled=autocast):
+            y = O.conv_patch_extractor(xf, Pf, Sf, "patch_extractor.", cfg, O.LocalComm())
+        y.float().backward(dout.float().cpu().view(n_img, 1, D))
+        return y.detach().float().reshape(n_img, D), xf.grad.reshape(n_img * N, D), {k: v.grad for k, v in Pf.items()}, Sf
+    y32, dx32, g32, S32 = run(False)
+    y16, dx16, g16, _ = run(True)
+
+    def far(a, b):
+        return ((a.detach().float().cpu().reshape(-1) - b.float().reshape(-1)).norm() / b.float().norm()).item()
+    checks = [("out", out, y32, y16), ("d tokens", dfeat, dx32, dx16)]
+    for n_, sp in model.specs.items():
+        if n_.startswith("patch_extractor.") and not O.bn_cancelled_bias(n_, cfg):
+            checks.append((n_, model.flat_grads[sp.offset:sp.offset + sp.numel], g32[n_], g16[n_]))
+    bad = [(n_, far(a, r), far(y, r)) for n_, a, r, y in checks if far(a, r) > 2 * far(y, r) + 3e-2]
+    assert not bad, bad
+    for n_, sp in model.specs.items():                                   # biases in front of a BatchNorm: zero gradient, round-off on every side
+        if n_.startswith("patch_extractor.") and O.bn_cancelled_bias(n_, cfg):
+            w = n_[:-4] + "weight"
+            assert model._g32[n_].norm().item() <= 2e-2 * model._g32[w].norm().item() + 1e-6, n_
+    sd = model.state_dict()
+    for k in S32:
+        if k.startswith("patch_extractor."):
+            if k.endswith("num_batches_tracked"):
+                continue                                                  # (counted once per step by the engine: dig_amd/engine_core.py)
+            assert far(sd[k], S32[k]) < 2e-2, k
+
+
 def test_mask_index_gather_target_are_bit_exact(dev):
     """Integer / byte work: bit-exact against the reference's boolean indexing (engine_for_pretraining_moco.py:96-107)."""
     from dig_amd import ops

@@ -144,7 +144,7 @@ def _fixture_step0(name):
 
 
 @pytest.mark.parametrize("name", ["tiny_w1", "vit_small_b4_w1", "vit_base_b2_w1", "tiny_w1_c0", "tiny_w1_mim2", "tiny_w1_nw5", "tiny_dis_w1",
-                                  "tiny_gen_w1", "tiny_gen_w1_mim2", "tiny_w1_dp", "tiny_w1_regular"])
+                                  "tiny_gen_w1", "tiny_gen_w1_mim2", "tiny_w1_dp", "tiny_w1_regular", "tiny_w1_conv"])
 def test_step_vs_reference_golden_fixture(name):
     """Fixtures come from the UNMODIFIED reference engine (tests/golden, oracle/ref_harness/gen_golden.py).
     vit_small_b4_w1 is BASELINE.json configs[0] (the reference's own CPU-runnable case), vit_base_b2_w1 the model of
@@ -171,7 +171,8 @@ def test_step_vs_reference_golden_fixture(name):
             assert close(stats[k], float(g[f"s0/stat/{k}"])), (k, stats[k], float(g[f"s0/stat/{k}"]))
     for k in ("q1_acc1", "q1_acc5", "q2_acc1", "q2_acc5"):
         if k in stats:
-            assert abs(stats[k] - float(g[f"s0/stat/{k}"])) <= 100.0 / (cfg.num_windows * B) + 1e-6
+            # (one rank flip among the B * n_patch rows of a view; ConvPatchNet's fixture has 8 rows per view: two)
+            assert abs(stats[k] - float(g[f"s0/stat/{k}"])) <= (2 if cfg.patchnet == "conv" else 1) * 100.0 / (cfg.n_patch * B) + 1e-6
     grads = {n: p.grad.detach().float().cpu() for n, p in model.named_parameters() if p.requires_grad}
     names, norms = g["s0/grad_names"].tolist(), g["s0/grad_norms"]
     tot = float(np.sqrt((norms ** 2).sum()))

@@ -159,10 +159,11 @@ def test_no_cpu_fallback():
 
 
 def test_unsupported_variants_fail_loudly():
-    """What is NOT built raises at construction (never a silent fallback): the convolutional patch extractor, dropout rates no flag of the
+    """What is NOT built raises at construction (never a silent fallback): a patch extractor the reference does not know either
+    (modeling_pretrain_moco_mim_ori.py:371-382 raises for anything but regular / no_patchtrans / conv), dropout rates no flag of the
     pre-training driver sets, an objective-less model."""
     with pytest.raises(NotImplementedError):
-        MoCo_ViT(use_pixel_target=True, patchnet_name='conv')
+        MoCo_ViT(use_pixel_target=True, patchnet_name='deformable')
     with pytest.raises(NotImplementedError):
         MoCo_ViT(use_pixel_target=True, patchnet_name='no_patchtrans', drop_rate=0.1)
     with pytest.raises(ValueError):
@@ -173,16 +174,19 @@ def test_unsupported_variants_fail_loudly():
 
 def test_every_reference_factory_and_cli_default_constructs():
     """All nine factories of modeling_pretrain_moco_mim_ori.py (:627-871) with the reference driver's ARGPARSE defaults
-    (run_mae_pretraining_moco.py:87,143-145: --num_windows 5, --patchnet_name regular, --drop_path 0) and with the README flags: parameter
-    names and order are the reference's (oracle.param_shapes, pinned by the fixtures written from the unmodified reference)."""
+    (run_mae_pretraining_moco.py:87,143-145: --num_windows 5, --patchnet_name regular, --drop_path 0), with the README flags and with the third
+    value --patchnet_name takes (conv): parameter AND buffer names and order are the reference's (oracle.param_shapes / buffer_shapes, pinned by
+    the fixtures written from the unmodified reference)."""
     import dataclasses
     for fam, kind in (("pretrain_simmim_moco_ori", "simmim_moco"), ("pretrain_moco_ori", "moco"), ("pretrain_simmim_ori", "simmim")):
         for size in ("tiny", "small", "base"):
             name = f"{fam}_vit_{size}_patch4_32x128"
-            for nw, pn in ((5, "regular"), (4, "no_patchtrans")):
+            for nw, pn in ((5, "regular"), (4, "no_patchtrans"), (5, "conv")):
                 m = create_model(name, **dict(KW, num_windows=nw, patchnet_name=pn))
                 cfg = dataclasses.replace(O.make_config(name), num_windows=nw, patchnet=pn if kind != "simmim" else "no_patchtrans")
                 assert [k for k, _ in m.named_parameters()] == list(O.param_shapes(cfg).keys()), (name, pn)
+                assert {k: tuple(v.shape) for k, v in m.named_parameters()} == {k: tuple(v) for k, v in O.param_shapes(cfg).items()}, (name, pn)
+                assert sorted(k for k, _ in m.named_buffers()) == sorted(O.buffer_shapes(cfg).keys()), (name, pn)
                 assert m.use_moco_target == cfg.use_moco and m.use_pixel_target == cfg.use_pixel
 
 
