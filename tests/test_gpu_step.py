@@ -677,7 +677,7 @@ def test_vit_base_b256_full_size_properties():
     assert more[-1]["loss_pixel"] < s1["loss_pixel"]
 
 
-@pytest.mark.parametrize("which", ["tiny", "vit_small"])
+@pytest.mark.parametrize("which", ["tiny", "vit_small", "tiny_conv"])
 def test_rccl_path_world1_matches_local_path(which):
     """The data-parallel wrapper on a one-rank 'nccl' (= RCCL) group: every collective of the N>1 path is issued
     (BN-statistics all-reduce, key all-gather, 17 gradient-bucket all-reduces, 1/world averaging) and the step must equal
@@ -688,6 +688,10 @@ def test_rccl_path_world1_matches_local_path(which):
     seed = 21
     if which == "tiny":
         cfg, B = O.DiGConfig(**O.TINY), 4
+        P0, S0 = O.det_state(cfg, seed)
+    elif which == "tiny_conv":
+        # ConvPatchNet: six more BatchNorm layers per extractor whose statistics cross the ranks (SyncBatchNorm converts BatchNorm2d too)
+        cfg, B = dataclasses.replace(O.DiGConfig(**O.TINY), patchnet="conv", num_windows=5), 8
         P0, S0 = O.det_state(cfg, seed)
     else:
         cfg, B = O.make_config("pretrain_simmim_moco_ori_vit_small_patch4_32x128"), 8
@@ -738,9 +742,14 @@ def test_rccl_path_world1_matches_local_path(which):
         train_one_epoch(ddp, None, None, [([im, au, mk], torch.ones(1), torch.ones(1))], None, opt, torch.device("cuda:0"), 1,
                         NativeScalerWithGradNormCount(), None, patch_size=4, normlize_target=False, start_steps=1,
                         lr_schedule_values=np.full(3, hp.lr), wd_schedule_values=np.full(3, hp.weight_decay), args=args)
-        want = json.load(open(os.path.join(os.path.dirname(__file__), "golden", f"collective_order_{which}.json")))
         got = [[op, n] for op, n in m.comm.log]
         m.comm.log = None
+        if which == "tiny_conv":
+            # 8 + 8 of the heads, 6 + 6 of the two extractors' forward, 6 of the online extractor's backward; its gradients travel with the projector's
+            assert sum(1 for op, _ in got if op == "all_reduce") == 34 and sum(1 for op, _ in got if op == "all_gather") == 1
+            assert sum(1 for op, _ in got if op.startswith("all_reduce_async:")) == cfg.depth + 2
+            return
+        want = json.load(open(os.path.join(os.path.dirname(__file__), "golden", f"collective_order_{which}.json")))
         assert got == want["step"], (got[:6], want["step"][:6])
         # depth + 5 gradient buckets in depth + 2 messages (14 for the 12-block models: small neighbours travel together, MoCo_ViT.bucket_groups),
         # one fused key gather, 8 + 8 BatchNorm-statistics messages
