@@ -22,9 +22,16 @@ def close(a, b, rtol=2e-2, atol=1e-3):
     return abs(a - b) <= rtol * abs(b) + atol
 
 
-def test_tiny_step_vs_oracle_with_bf16_yardstick():
+@pytest.mark.parametrize("variant", ["tiny", "vit_tiny_widths_conv"])
+def test_tiny_step_vs_oracle_with_bf16_yardstick(variant):
+    """vit_tiny_widths_conv: ConvPatchNet at ViT-Tiny's widths (192 -> 192 -> 288 -> 384 -> 384, 3 heads) -- the 288-channel map's im2col matrix
+    has 2592 columns, padded to the GEMM's 64-element reduction granule (2624), in the forward and in the data gradient."""
     cfg = O.DiGConfig(**O.TINY)
     seed, B = 3, 4
+    if variant == "vit_tiny_widths_conv":
+        cfg = dataclasses.replace(O.make_config("pretrain_simmim_moco_ori_vit_tiny_patch4_32x128"), depth=2, patchnet="conv", num_windows=5,
+                                  moco_mlp_dim=512)
+        B = 16
     hp = O.StepHyper(lr=1e-3)
     im, au, mk = O.synthetic_batch(B, cfg, seed * 1000)
     model = build_model(cfg, *O.det_state(cfg, seed))
@@ -37,7 +44,7 @@ def test_tiny_step_vs_oracle_with_bf16_yardstick():
     for k in ("loss", "loss_pixel", "loss_contrast", "grad_norm"):
         assert close(stats[k], ref_m[k]), (k, stats[k], ref_m[k])
     for k in ("q1_acc1", "q1_acc5", "q2_acc1", "q2_acc5"):
-        assert abs(stats[k] - ref_m[k]) <= 100.0 / (4 * B) + 1e-6, (k, stats[k], ref_m[k])
+        assert abs(stats[k] - ref_m[k]) <= (2 if cfg.patchnet == "conv" else 1) * 100.0 / (cfg.n_patch * B) + 1e-6, (k, stats[k], ref_m[k])
     cos = torch.nn.functional.cosine_similarity
     bad = []
     for n, g in grads.items():
