@@ -22,7 +22,7 @@ def close(a, b, rtol=2e-2, atol=1e-3):
     return abs(a - b) <= rtol * abs(b) + atol
 
 
-@pytest.mark.parametrize("variant", ["tiny", "vit_tiny_widths_conv"])
+@pytest.mark.parametrize("variant", ["tiny", "vit_tiny_widths_conv", "dis_only_conv"])
 def test_tiny_step_vs_oracle_with_bf16_yardstick(variant):
     """vit_tiny_widths_conv: ConvPatchNet at ViT-Tiny's widths (192 -> 192 -> 288 -> 384 -> 384, 3 heads) -- the 288-channel map's im2col matrix
     has 2592 columns, padded to the GEMM's 64-element reduction granule (2624), in the forward and in the data gradient."""
@@ -32,6 +32,10 @@ def test_tiny_step_vs_oracle_with_bf16_yardstick(variant):
         cfg = dataclasses.replace(O.make_config("pretrain_simmim_moco_ori_vit_tiny_patch4_32x128"), depth=2, patchnet="conv", num_windows=5,
                                   moco_mlp_dim=512)
         B = 16
+    elif variant == "dis_only_conv":
+        # pretrain_moco_ori_* with --patchnet_name conv: no pix_projector -- the extractor reads the encoder's own rows of both views and its
+        # backward hands their gradient straight to the encoder
+        cfg, B = dataclasses.replace(cfg, kind="moco", patchnet="conv", num_windows=5), 16
     hp = O.StepHyper(lr=1e-3)
     im, au, mk = O.synthetic_batch(B, cfg, seed * 1000)
     model = build_model(cfg, *O.det_state(cfg, seed))
@@ -42,7 +46,8 @@ def test_tiny_step_vs_oracle_with_bf16_yardstick(variant):
     with torch.autocast("cpu", dtype=torch.bfloat16):
         _, bf_g, _, _ = O.OracleTrainer(cfg, *O.det_state(cfg, seed)).loss_and_grads(im, au, mk, hp0)
     for k in ("loss", "loss_pixel", "loss_contrast", "grad_norm"):
-        assert close(stats[k], ref_m[k]), (k, stats[k], ref_m[k])
+        if k in stats or k in ref_m:
+            assert close(stats[k], ref_m[k]), (k, stats[k], ref_m[k])
     for k in ("q1_acc1", "q1_acc5", "q2_acc1", "q2_acc5"):
         assert abs(stats[k] - ref_m[k]) <= (2 if cfg.patchnet == "conv" else 1) * 100.0 / (cfg.n_patch * B) + 1e-6, (k, stats[k], ref_m[k])
     cos = torch.nn.functional.cosine_similarity
@@ -53,7 +58,9 @@ def test_tiny_step_vs_oracle_with_bf16_yardstick(variant):
             continue
         c_hip, c_bf = cos(g.reshape(1, -1), r).item(), cos(bf_g[n].float().reshape(1, -1), r).item()
         q_hip, q_bf = (g.norm() / r.norm()).item(), (bf_g[n].float().norm() / r.norm()).item()
-        if (1 - c_hip) > 2 * (1 - c_bf) + 5e-3 or abs(q_hip - 1) > 2 * abs(q_bf - 1) + 3e-2:
+        # (norm band + 2 x the yardstick's own turn, as in test_step_vs_reference_golden_fixture: independent noise adds to the norm in
+        #  quadrature -- a ConvPatchNet gradient that bf16 turns by 1 - cos = 5 % is 10 % longer than the fp32 one on either side)
+        if (1 - c_hip) > 2 * (1 - c_bf) + 5e-3 or abs(q_hip - 1) > 2 * abs(q_bf - 1) + 3e-2 + 2 * (1 - c_bf):
             bad.append((n, c_hip, c_bf, q_hip, q_bf))
     assert not bad, bad
     # EMA'd momentum parameters (fp32 path) match tightly
