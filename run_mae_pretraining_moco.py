@@ -15,8 +15,8 @@ per epoch in `log.txt` (:437-446).
 
 What is different, on purpose: the input pipeline.  The reference decodes LMDB crops and runs imgaug in dataloader workers
 (dataset/dataset_image.py -- lmdb, cv2 and imgaug are not part of this image and are out of scope).  Here the data
-source is either `--synthetic N` (N samples of U(-1,1) crops per epoch: the benchmark's data) or a directory tree of image files under
-`--image_alone_path` (decoded with Pillow to uint8 crops; resize + normalisation + mask drawing happen on the MI355X,
+source is either `--synthetic N` / `--data_path synthetic` (N samples of U(-1,1) crops per epoch: the benchmark's data) or a directory tree
+of image files under `--image_alone_path` / `--data_path` (decoded with Pillow to uint8 crops; resize + normalisation + mask drawing happen on the MI355X,
 dig_amd/datasets.py).  The augmented view is produced by `--aug_module pkg.fn` (a callable `fn(list_of_uint8_crops) -> list_of_uint8_crops`
 run on the host) -- without it the second view is the crop itself.
 """
@@ -94,7 +94,42 @@ def get_args(argv=None):
     a("--no_auto_resume", action="store_false", dest="auto_resume")
     a("--start_epoch", type=int, default=0)
     a("--dist_url", type=str, default="env://")
-    return p.parse_args(argv)
+    a("--data_path", nargs="+", type=str, default="",
+      help="`synthetic` (with --synthetic N, default 100 global batches per epoch), or directory tree(s) of image files like --image_alone_path; "
+           "an LMDB directory is the reference's dataset/ reader's business (INTEGRATION.md, 'Input transform')")
+    a("--num_samples", type=float, default=float("inf"), help="cap on the samples of --data_path taken per epoch")
+    a("--aloneimage_num_samples", type=float, default=float("inf"), help="cap on the samples of --image_alone_path taken per epoch")
+    a("--use_ema", action="store_true", default=False, help="(the reference's teacher-student mode: not built, raises)")
+    # Every other flag of the reference's get_args (run_mae_pretraining_moco.py:30-277), so that its launch scripts run unchanged: the
+    # pre-training path of the reference never reads them (leftovers of other experiments: `grep args.<name>` over its driver, engine,
+    # optimizer factory, datasets and utils finds nothing), or they configure what has no counterpart here (dataloader pinning, SGD momentum,
+    # ModelArts paths, the launcher's rank arguments -- ranks come from the launcher's environment).  Parsed, reported once, not used.
+    for name in REFERENCE_ONLY_SWITCHES:
+        a(name, action="store_true", default=False, help=argparse.SUPPRESS)
+    a("--no_pin_mem", action="store_false", dest="pin_mem", help=argparse.SUPPRESS)
+    for name in REFERENCE_ONLY_VALUES:
+        a(name, type=str, default=None, help=argparse.SUPPRESS)
+    args = p.parse_args(argv)
+    given = [n for n in REFERENCE_ONLY_SWITCHES if getattr(args, n[2:])] + [n for n in REFERENCE_ONLY_VALUES if getattr(args, n[2:]) is not None]
+    if given:
+        print("flags of the reference that its pre-training path does not read either (accepted, not used): " + " ".join(given))
+    if args.use_ema:
+        raise SystemExit("--use_ema (teacher-student mode, run_mae_pretraining_moco.py:326-338) is not built")
+    return args
+
+
+REFERENCE_ONLY_SWITCHES = ("--alternately_epoch_training", "--alternately_training", "--dist_on_itp", "--first_train_mim", "--fix_mask_token",
+                           "--imagenet_default_mean_and_std", "--mix_train_with_aloneimage", "--mix_train_with_ctx", "--only_real_data_for_pretrain",
+                           "--pin_mem", "--use_abi_aug", "--use_color_aug", "--use_corner_mask", "--use_hard_sample", "--use_image_slice",
+                           "--use_loss_weight", "--use_mem_in_decoder", "--use_mim", "--use_moco", "--use_multiscale_mask", "--use_patch_transformer")
+REFERENCE_ONLY_VALUES = ("--attn_map_type", "--aug_ratio", "--cluster_update_interval", "--color_jitter", "--contrast_temperature", "--corner_prob",
+                         "--corner_ratio", "--corrupt_ops_ratios", "--ctx_max_len", "--ctx_min_len", "--ctx_nb_classes", "--ctx_num_samples", "--ctx_path",
+                         "--distill_start_epoch", "--image_to_ctx_ratio", "--input_size", "--local_rank", "--loss_feat_beta", "--loss_feat_type",
+                         "--loss_weight_consist", "--loss_weight_distill", "--loss_weight_feat_align", "--loss_weight_pos", "--loss_weight_semgroup",
+                         "--loss_win_size", "--mask_ratios", "--mask_scales", "--momentum", "--momentum_teacher", "--momentum_teacher_end",
+                         "--num_distribution", "--num_mem_slots", "--num_relation_heads", "--num_target_layers", "--recon_patch_scales", "--relation_T",
+                         "--relation_window_size", "--soft_label_type", "--text_loss_weight", "--text_mask_ratio", "--train_interpolation", "--train_url",
+                         "--vis_loss_weight", "--voc_type", "--warmup_lr", "--world_size")
 
 
 class SyntheticCrops:
@@ -121,10 +156,12 @@ class ImageFolderCrops:
     uint8 crop (bicubic resize to 32 x 128, normalisation, masks) on the device."""
     EXT = (".png", ".jpg", ".jpeg", ".bmp", ".tif", ".tiff", ".webp")
 
-    def __init__(self, roots, batch, rank, world, transform, aug, workers):
+    def __init__(self, roots, batch, rank, world, transform, aug, workers, cap=float("inf")):
         self.files = sorted(os.path.join(d, f) for r in roots for d, _, fs in os.walk(r) for f in fs if f.lower().endswith(self.EXT))
         if not self.files:
             raise SystemExit(f"no image files under {roots}")
+        if cap < len(self.files):                                        # --num_samples / --aloneimage_num_samples: the first N, as the
+            self.files = self.files[:int(cap)]                           # reference's datasets do (dataset/dataset_image.py: min(nSamples, num_samples))
         self.batch, self.rank, self.world, self.transform, self.aug, self.workers = batch, rank, world, transform, aug, max(1, workers)
         self.epoch = 0
         self.steps = len(self.files) // batch // world
@@ -187,6 +224,19 @@ def main(args):
     print("number of params: {} M".format(n_parameters / 1e6))
 
     world, rank = utils.get_world_size(), utils.get_rank()
+    data_path = [args.data_path] if isinstance(args.data_path, str) else list(args.data_path)
+    data_path = [d for d in data_path if d]
+    if data_path == ["synthetic"] and args.synthetic <= 0:
+        args.synthetic = 100 * args.batch_size * world
+    elif data_path and data_path != ["synthetic"]:
+        for d in data_path:
+            if os.path.isfile(os.path.join(d, "data.mdb")):
+                raise SystemExit(f"--data_path {d}: an LMDB environment.  The LMDB reader (dataset/dataset_image.py: lmdb + cv2 + imgaug) stays with "
+                                 "the reference; feed its uint8 crops to dig_amd.datasets.GpuBatchTransform (INTEGRATION.md, 'Input transform'), or "
+                                 "point --data_path / --image_alone_path at a directory tree of image files")
+        # (the reference mixes --data_path and --image_alone_path datasets when both are given: one list of directory trees here)
+        alone = args.image_alone_path if isinstance(args.image_alone_path, (list, tuple)) else ([args.image_alone_path] if args.image_alone_path else [])
+        args.image_alone_path = data_path + list(alone)
     if args.synthetic > 0:
         gen = RandomMaskingGenerator(args.window_size, args.mask_ratio, num_view=args.num_view, seed=seed, device=device)
         loader = SyntheticCrops(args.synthetic // world, args.batch_size, device, seed, gen)
@@ -196,7 +246,8 @@ def main(args):
             mod, fn = args.aug_module.rsplit(".", 1)
             aug = getattr(importlib.import_module(mod), fn)
         roots = args.image_alone_path if isinstance(args.image_alone_path, (list, tuple)) else [args.image_alone_path]
-        loader = ImageFolderCrops(roots, args.batch_size, rank, world, GpuBatchTransform(args, seed=seed, device=device), aug, args.num_workers)
+        loader = ImageFolderCrops(roots, args.batch_size, rank, world, GpuBatchTransform(args, seed=seed, device=device), aug, args.num_workers,
+                                  cap=min(args.num_samples, args.aloneimage_num_samples))
     steps_per_epoch = len(loader)
     if steps_per_epoch == 0:
         raise SystemExit("fewer samples than one global batch")

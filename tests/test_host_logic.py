@@ -307,6 +307,63 @@ def test_pretrain_driver_parses_the_readme_command_and_shards_image_folders(tmp_
         assert all(len(b) == 4 for b in e0) and e0 != e1
         seen.append({sh for b in e0 for sh in b})
     assert not (seen[0] & seen[1])                                          # every crop has a distinct shape here: shards are disjoint
+    # --num_samples / --aloneimage_num_samples: the first N samples, as the reference's datasets cap theirs
+    assert len(drv.ImageFolderCrops([str(tmp_path)], 4, 0, 1, tf, None, 2, cap=9).files) == 9
+
+
+def test_pretrain_driver_accepts_every_flag_of_the_reference(capsys):
+    """Every flag name of the reference's get_args (run_mae_pretraining_moco.py:30-277; names only -- a list of interface facts) parses here: the
+    ones its pre-training path never reads are accepted and reported, --use_ema (teacher-student mode) and an LMDB --data_path say what they
+    are and stop."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("dig_driver2", os.path.join(root, "run_mae_pretraining_moco.py"))
+    drv = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(drv)
+    p = argparse_names(drv)
+    for n in REFERENCE_FLAGS.split():
+        assert n in p, n
+    a = drv.get_args("--data_path synthetic --batch_size 8 --voc_type ALLCASES_SYMBOLS --pin_mem --use_abi_aug --mask_scales 1 --world_size 8 "
+                     "--local_rank 0 --momentum 0.9 --train_url X --imagenet_default_mean_and_std".split())
+    assert a.data_path == ["synthetic"] and a.batch_size == 8
+    out = capsys.readouterr().out
+    assert "--voc_type" in out and "--use_abi_aug" in out and "accepted, not used" in out
+    with pytest.raises(SystemExit):
+        drv.get_args(["--use_ema"])
+    with pytest.raises(SystemExit):
+        drv.get_args(["--no_such_flag", "1"])
+
+
+def argparse_names(drv):
+    import argparse
+    names = set()
+    orig = argparse.ArgumentParser.add_argument
+
+    def rec(self, *a, **k):
+        names.update(x for x in a if isinstance(x, str) and x.startswith("--"))
+        return orig(self, *a, **k)
+    argparse.ArgumentParser.add_argument = rec
+    try:
+        drv.get_args([])
+    finally:
+        argparse.ArgumentParser.add_argument = orig
+    return names
+
+
+REFERENCE_FLAGS = """--aloneimage_num_samples --alternately_epoch_training --alternately_training --attn_map_type --aug_ratio --auto_resume --batch_size
+--clip_grad --cluster_update_interval --color_jitter --contrast_start_epoch --contrast_temperature --contrast_warmup_steps --corner_prob --corner_ratio
+--corrupt_ops_ratios --ctx_max_len --ctx_min_len --ctx_nb_classes --ctx_num_samples --ctx_path --data_path --device --dist_on_itp --dist_url
+--distill_start_epoch --drop_path --encoder_type --epochs --eval_freq --first_train_mim --fix_mask_token --image_alone_path --image_to_ctx_ratio
+--imagenet_default_mean_and_std --input_h --input_size --input_w --local_rank --log_dir --loss_feat_beta --loss_feat_type --loss_weight_consist
+--loss_weight_contrast --loss_weight_distill --loss_weight_feat_align --loss_weight_pixel --loss_weight_pos --loss_weight_semgroup --loss_win_size --lr
+--mask_ratio --mask_ratios --mask_scales --max_len --min_lr --mix_train_with_aloneimage --mix_train_with_ctx --moco_dim --moco_m --moco_m_cos
+--moco_mlp_dim --moco_t --model --momentum --momentum_teacher --momentum_teacher_end --no_auto_resume --no_pin_mem --normlize_target --num_distribution
+--num_mem_slots --num_relation_heads --num_samples --num_target_layers --num_view --num_windows --num_workers --only_mim_on_ori_img
+--only_real_data_for_pretrain --opt --opt_betas --opt_eps --output_dir --patchnet_name --pin_mem --queue_size --recon_patch_scales --relation_T
+--relation_window_size --resume --save_ckpt_freq --seed --soft_label_type --start_epoch --text_loss_weight --text_mask_ratio --train_interpolation
+--train_url --use_abi_aug --use_color_aug --use_corner_mask --use_ema --use_hard_sample --use_image_slice --use_loss_weight --use_mem_in_decoder --use_mim
+--use_moco --use_moco_m_cos --use_multiscale_mask --use_patch_transformer --vis_loss_weight --voc_type --warmup_epochs --warmup_lr --warmup_steps
+--weight_decay --weight_decay_end --world_size"""
 
 
 def test_tensorboard_logger_surface(tmp_path):
