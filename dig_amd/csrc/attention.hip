@@ -19,6 +19,7 @@
 // the transpose read).
 #include "common.h"
 #include <atomic>
+#include <cstdlib>
 
 // phase time stamps for tools/experiments/attn_bwd_lab.hip (empty in the product build)
 #ifndef DIG_ATTN_SP_LAB
@@ -29,6 +30,28 @@
 #endif
 #ifndef DIG_ATTN_TS
 #define DIG_ATTN_TS(i)
+#endif
+#ifndef DIG_ATTN_B_PIPE
+#define DIG_ATTN_B_PIPE 0                    // backward phase B: 1 = the tile's element arithmetic issued between its own MFMAs (see the loop)
+#endif
+#ifndef DIG_ATTN_BWD_STORE
+#define DIG_ATTN_BWD_STORE 3                 // backward, how dq / dk / dv leave: 0 = 16-byte row stores, 1 = the same, non-temporal, 3 = full 128-byte lines
+#endif                                       // through 2 KiB of LDS per wave, non-temporal (environment DIG_ATTN_BWD_STORE overrides: A/B in the step)
+#ifndef DIG_ATTN_LIFT
+#define DIG_ATTN_LIFT 3                      // backward restage: bit 0 both query blocks' Q / dO fragments from LDS, bit 1 odd K / V blocks from registers
+#endif
+#ifndef DIG_ATTN_B_ABL
+#define DIG_ATTN_B_ABL 0                     // lab ablations of phase B (results wrong): 1 no element arithmetic, 2 no transposed fragment reads, 4 no seed
+#endif                                       // reads, 8 no S / dP MFMAs, 16 no dV / dK MFMAs, 32 no direct fragment reads, 64 no phase A loop, 128 no result stores, 256 O rows all from one address
+#ifndef DIG_ATTN_A_PIPE
+#define DIG_ATTN_A_PIPE 0
+#endif
+#ifndef DIG_ATTN_SGB_V1
+#define DIG_ATTN_SGB_V1 14                   // VALU instructions scheduled behind each of the four dP^T MFMAs (exp, pack P) ...
+#define DIG_ATTN_SGB_V2 8                    // ... and behind each dV^T MFMA (P (dP - delta), pack dS)
+#endif
+#ifndef DIG_ATTN_SGB
+#define DIG_ATTN_SGB 1                       // lab: 0 = the pipelined loops without sched_group_barrier directives (the compiler's own order)
 #endif
 
 #include "attn_tiles.h"
@@ -185,12 +208,15 @@ __device__ __forceinline__ void wave_colsum(const f32x16 (&acc)[2], float* out, 
 // (image, head) overlap the MFMA phases of another -- the 8-wave / 128 KiB form ran one workgroup per CU with nothing to
 // overlap its serial phases (tools/experiments/attn_bwd_lab.hip: phase timeline and ablations).
 // ------------------------------------------------------------------------------------------------
-template <bool DROP>
+constexpr int BWD_STG_OFF = 2 * TILE + 2 * N_TOK * 4 + 8 * 128 * 4;
+constexpr int BWD_LDS = BWD_STG_OFF + 4 * 2048;                            // 78 KiB: two workgroups per CU
+template <bool DROP, int STORE>
 __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ ctx,
                                                            const bf16_t* __restrict__ dctx, const float* __restrict__ lse,
                                                            bf16_t* __restrict__ dqkv, int D, int H, float scale,
                                                            unsigned qkv_bytes, unsigned ctx_bytes, float* __restrict__ qsum, float* __restrict__ vsum,
                                                            dig_dropout_t drop, int nqb) {
+  constexpr int store_mode = STORE;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* T0 = smem;                                              // Q, then K
   unsigned char* T1 = smem + TILE;                                       // dO, then V
@@ -213,7 +239,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const bf16_t* __restri
   bf16x8 orow[8];
 #pragma unroll
   for (int ps = 0; ps < 8; ++ps)
-    orow[ps] = *reinterpret_cast<const bf16x8*>(ctx + (tok0 + ps * 32 + (tid >> 3)) * D + h * DH + (tid & 7) * 8);
+    orow[ps] = *reinterpret_cast<const bf16x8*>(ctx + ((DIG_ATTN_B_ABL & 256) ? 0 : (tok0 + ps * 32 + (tid >> 3)) * D + h * DH + (tid & 7) * 8));
   stage_tile<256>(T0, rs, base, ld, tid, wave);                                         // Q
   stage_tile<256>(T1, rg, (unsigned)((tok0 * D + h * DH) * 2), D, tid, wave);           // dO
   // K / V fragments of a key block, straight from global
@@ -290,10 +316,84 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const bf16_t* __restri
       }
     };
     seed(0);
+    if constexpr (!DROP && DIG_ATTN_B_PIPE) {
+      // One wave has nobody to hide behind while its partner on the SIMD waits for memory (two waves per SIMD, a third of a wave's life is
+      // staging): the tile's serial chain  fragment reads -> 8 MFMAs -> 32 exp / mul + 16 converts -> 8 MFMAs  is re-ordered so that the matrix
+      // pipe always has an instruction of THIS wave to run:  S^T (4 MFMAs) | dP^T (4) beside exp(S - lse) and the pack of P | dV^T (4, needs P
+      // only) beside P (dP - delta) and the pack of dS | dK^T (4) beside the next tile's fragment and seed reads.  Same arithmetic per
+      // element, same summation order in every accumulator: bit-identical to the fenced form.
+      for (int qt = 0; qt < nqb; ++qt) {
+        __builtin_amdgcn_sched_barrier(0);
+        bf16x8 gtr[2][2], qtr[2][2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            gtr[u][dt] = frag_tr_o(T1 + qt * 4096 + u * 2048, fo, dt);
+            qtr[u][dt] = frag_tr_o(T0 + qt * 4096 + u * 2048, fo, dt);
+          }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr[s], kf[s], st, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        // dP^T | exp(S - lse), pack P
+#pragma unroll
+        for (int s = 0; s < 4; ++s) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gfr[s], vf[s], dp, 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) st[e] = __expf(st[e]);
+        bf16x8 pf[2], ds[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) pf[u] = pack8(st, u);
+#if DIG_ATTN_SGB
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, DIG_ATTN_SGB_V1, 0);
+        }
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        // dV^T | P (dP - delta), pack dS
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gtr[u][dt], pf[u], dv[dt], 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dp[e] = st[e] * dp[e];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) ds[u] = pack8(dp, u);
+#if DIG_ATTN_SGB
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, DIG_ATTN_SGB_V2, 0);
+        }
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        // dK^T | the next tile's operand fragments and seeds
+        const int qtn = (qt + 1) & 7;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          qfr[s] = frag_direct_o(T0 + qtn * 4096, fo, s);
+          gfr[s] = frag_direct_o(T1 + qtn * 4096, fo, s);
+        }
+        seed(qtn);
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtr[u][dt], ds[u], dk[dt], 0, 0, 0);
+#if DIG_ATTN_SGB
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        }
+#endif
+      }
+    } else
     for (int qt = 0; qt < nqb; ++qt) {
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
+        if (DIG_ATTN_B_ABL & 8) break;
         st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr[s], kf[s], st, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gfr[s], vf[s], dp, 0, 0, 0);
       }
@@ -303,12 +403,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const bf16_t* __restri
       for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
+          if (DIG_ATTN_B_ABL & 2) { gtr[u][dt] = kf[u * 2 + dt]; qtr[u][dt] = vf[u * 2 + dt]; continue; }
           gtr[u][dt] = frag_tr_o(T1 + qt * 4096 + u * 2048, fo, dt);
           qtr[u][dt] = frag_tr_o(T0 + qt * 4096 + u * 2048, fo, dt);
         }
       const int qtn = (qt + 1) & 7;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
+        if (DIG_ATTN_B_ABL & 32) break;
         qfr[s] = frag_direct_o(T0 + qtn * 4096, fo, s);
         gfr[s] = frag_direct_o(T1 + qtn * 4096, fo, s);
       }
@@ -317,6 +419,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const bf16_t* __restri
       if (!DROP) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
+          if (DIG_ATTN_B_ABL & 1) break;
           const float p = __expf(st[e]);
           st[e] = p;
           dp[e] = p * dp[e];
@@ -339,11 +442,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const bf16_t* __restri
 #pragma unroll
       for (int u = 0; u < 2; ++u) { pf[u] = pack8(st, u); ds[u] = pack8(dp, u); }
       __builtin_amdgcn_sched_barrier(0);
-      seed(qtn);                                                           // next tile's seeds land while the output MFMAs run
+      if (!(DIG_ATTN_B_ABL & 4)) seed(qtn);                                // next tile's seeds land while the output MFMAs run
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
+          if (DIG_ATTN_B_ABL & 16) { dv[dt][u] += __builtin_bit_cast(float, (int)gtr[u][dt][0] ^ (int)pf[u][1]); dk[dt][u] += __builtin_bit_cast(float, (int)qtr[u][dt][0] ^ (int)ds[u][1]); continue; }
           dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gtr[u][dt], pf[u], dv[dt], 0, 0, 0);
           dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtr[u][dt], ds[u], dk[dt], 0, 0, 0);
         }
@@ -351,16 +455,30 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const bf16_t* __restri
     if (ps == 0) { DIG_ATTN_TS(7) }
     if (ps == 0) load_kv(kb + 1);                                         // the next block's rows fly while this block's result is stored
     bf16_t* okp = dqkv + (tok0 + key) * ld + D + h * DH;
-    store_rows(okp, dk, hi);
-    store_rows(okp + D, dv, hi);
+    if (!(DIG_ATTN_B_ABL & 128)) {
+      if (store_mode == 3) {
+        bf16_t* blk = dqkv + (tok0 + k0) * ld + D + h * DH;
+        store_rows_lines<true>(blk, ld, dk, smem + BWD_STG_OFF + wave * 2048, lane);
+        store_rows_lines<true>(blk + D, ld, dv, smem + BWD_STG_OFF + wave * 2048, lane);
+      } else if (store_mode == 1) {
+        store_rows<true>(okp, dk, hi);
+        store_rows<true>(okp + D, dv, hi);
+      } else {
+        store_rows(okp, dk, hi);
+        store_rows(okp + D, dv, hi);
+      }
+    } else if (dk[0][0] == 1.2345f && dv[1][3] == 5.4321f) okp[0] = 1;
     if (vsum) wave_colsum(dv, csum_s + kb * 128 + 64, lane);
   }
   DIG_ATTN_TS(4)
 
   // ---------------- restage: K -> T0, V -> T1 (every wave is done with Q, dO) ----------------
-  // Q / dO fragments of this wave's first query block are lifted out of LDS before it is overwritten; the second block's come
-  // from global memory (L2-warm) while the first block's result is stored
-  bf16x8 qf[4], gf[4];
+  // What is already on the chip is not fetched again (the kernel runs at the fabric's byte rate: 95 us of its 133 are loads + stores with every
+  // MFMA removed): the Q / dO fragments of BOTH query blocks of this wave are lifted out of LDS before it is overwritten (DIG_ATTN_LIFT bit 0;
+  // without it the second block's come from global memory while the first block's result is stored), and the K / V rows of the wave's
+  // second key block, still in its registers as phase B's fragments, are written into the tiles by the wave itself (bit 1): the LDS-DMA brings
+  // only the even 32-row blocks.  256 -> 192 KiB read per (image, head).
+  bf16x8 qf[4], gf[4], qf2[4], gf2[4];
   if (wave * 2 < nqb) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -368,7 +486,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const bf16_t* __restri
       gf[s] = frag_direct_o(T1 + wave * 8192, fo, s);
     }
   }
+  if ((DIG_ATTN_LIFT & 1) && wave * 2 + 1 < nqb) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      qf2[s] = frag_direct_o(T0 + wave * 8192 + 4096, fo, s);
+      gf2[s] = frag_direct_o(T1 + wave * 8192 + 4096, fo, s);
+    }
+  }
   auto load_qg = [&](int qb) {
+    if (DIG_ATTN_LIFT & 1) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) { qf[s] = qf2[s]; gf[s] = gf2[s]; }
+      return;
+    }
     const int q = qb * 32 + (lane & 31);
     const bf16_t* qp = qkv + (tok0 + q) * ld + h * DH + hi * 8;
     const bf16_t* gp = dctx + (tok0 + q) * D + h * DH + hi * 8;
@@ -381,8 +511,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const bf16_t* __restri
     }
   };
   __syncthreads();
-  stage_tile<256>(T0, rs, base + (unsigned)(D * 2), ld, tid, wave);      // K
-  stage_tile<256>(T1, rs, base + (unsigned)(2 * D * 2), ld, tid, wave);  // V
+  if (DIG_ATTN_LIFT & 2) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {                                          // kf / vf hold key block 2 wave + 1 (rows 32 (2 wave + 1) + (lane & 31), chunk 2 s + hi)
+      *reinterpret_cast<bf16x8*>(T0 + wave * 8192 + 4096 + fo.d[s]) = kf[s];     // (in front of the DMA: behind it the compiler would wait for vmcnt(0) first)
+      *reinterpret_cast<bf16x8*>(T1 + wave * 8192 + 4096 + fo.d[s]) = vf[s];
+    }
+    stage_tile<256, 2>(T0, rs, base + (unsigned)(D * 2), ld, tid, wave);      // K, even 32-row blocks
+    stage_tile<256, 2>(T1, rs, base + (unsigned)(2 * D * 2), ld, tid, wave);  // V
+  } else {
+    stage_tile<256>(T0, rs, base + (unsigned)(D * 2), ld, tid, wave);      // K
+    stage_tile<256>(T1, rs, base + (unsigned)(2 * D * 2), ld, tid, wave);  // V
+  }
   __syncthreads();
   DIG_ATTN_TS(5)
 
@@ -408,10 +548,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const bf16_t* __restri
       vfr[s] = frag_direct_o(T1, fo, s);
     }
 #pragma unroll 2
-    for (int kt = 0; kt < 8; ++kt) {
+    for (int kt = 0; kt < ((DIG_ATTN_B_ABL & 64) ? 0 : 8); ++kt) {
+      // as in phase B the accumulators start from -lse[q] and -delta[q] (here one constant per lane: a lane owns a query), so the MFMAs
+      // deliver S - lse and dP - delta and the element arithmetic is mul, exp, mul.  Dropout needs dP * mask - delta: seeded with 0 there.
       f32x16 st, dp;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) { st[e] = 0.f; dp[e] = 0.f; }
+      for (int e = 0; e < 16; ++e) { st[e] = DROP ? 0.f : my_lse; dp[e] = DROP ? 0.f : my_del; }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
@@ -433,12 +575,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const bf16_t* __restri
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        float g = dp[e];
         if (DROP) {                                                        // dP = mask * (dO V^T) / (1 - p)
+          float g = dp[e];
           const unsigned key = kt * 32 + 8 * (e >> 2) + 4 * hi + (e & 3);
           g = dig_drop_keep(drop.k0, drop.k1, ((unsigned)q << 16) | key, blockIdx.x, drop.thr) ? g * drop.scale : 0.f;
+          st[e] = __expf(st[e] + my_lse) * (g + my_del);                   // dS^T (my_lse = -lse, my_del = -delta)
+        } else {
+          st[e] = __expf(st[e]) * dp[e];
         }
-        st[e] = __expf(st[e] + my_lse) * (g + my_del);                     // dS^T (my_lse = -lse, my_del = -delta)
       }
       const bf16x8 ds0 = pack8(st, 0), ds1 = pack8(st, 1);
 #pragma unroll
@@ -451,19 +595,26 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const bf16_t* __restri
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int e = 0; e < 16; ++e) dq[dt][e] *= scale;
-    store_rows(dqkv + (tok0 + q) * ld + h * DH, dq, hi);
+    if (!(DIG_ATTN_B_ABL & 128)) {
+      if (store_mode == 3) store_rows_lines<true>(dqkv + (tok0 + q0) * ld + h * DH, ld, dq, smem + BWD_STG_OFF + wave * 2048, lane);
+      else if (store_mode == 1) store_rows<true>(dqkv + (tok0 + q) * ld + h * DH, dq, hi);
+      else store_rows(dqkv + (tok0 + q) * ld + h * DH, dq, hi);
+    }
+    else if (dq[0][0] == 1.2345f && dq[1][3] == 5.4321f) dqkv[0] = 1;
     if (qsum) wave_colsum(dq, csum_s + qb * 128, lane);
   }
   DIG_ATTN_TS(6)
   // fused q_bias / v_bias gradients: this (image, head)'s column sums of dQ and dV, one partial row per image
   if (qsum) {
     __syncthreads();
-    if (tid < 128) {
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));                 // re-derived here: kept alive from the prologue the index cost the kernel a spilled register
+    if (t < 128) {
       float a = 0.f;
 #pragma unroll
-      for (int w = 0; w < 8; ++w) a += csum_s[w * 128 + tid];
-      float* dst = tid < 64 ? qsum : vsum;
-      dst[(size_t)img * D + h * DH + (tid & 63)] = a;
+      for (int w = 0; w < 8; ++w) a += csum_s[w * 128 + t];
+      float* dst = t < 64 ? qsum : vsum;
+      dst[(size_t)img * D + h * DH + (t & 63)] = a;
     }
   }
 }
@@ -745,20 +896,29 @@ extern "C" int dig_attn_bwd_dropout(const void* qkv, const void* ctx, const void
                  (const bf16_t*)dctx, lse, (bf16_t*)dqkv, embed_dim, heads, scale, (unsigned)qb, (unsigned)(qb / 3), q_colsum, v_colsum);
     return dig_check_launch();
   }
-  const int lds = 2 * TILE + 2 * N_TOK * 4 + (q_colsum ? 8 * 128 * 4 : 0);
+  const int lds = BWD_LDS;
+  static const int store_mode = [] {
+    const char* e = getenv("DIG_ATTN_BWD_STORE");
+    const int m = e ? atoi(e) : DIG_ATTN_BWD_STORE;
+    return (m == 0 || m == 1 || m == 3) ? m : DIG_ATTN_BWD_STORE;
+  }();
   static bool attr[DIG_MAX_DEVICES] = {};
   if (!attr[dev]) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TILE + 2 * N_TOK * 4 + 8 * 128 * 4);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TILE + 2 * N_TOK * 4 + 8 * 128 * 4);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<true, DIG_ATTN_BWD_STORE>), hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS);
     attr[dev] = true;
   }
   if (drop && drop->thr)
-    dig_launch(attn_bwd_kernel<true>, dim3(n_img * heads), dim3(256), (unsigned)lds, stream, (const bf16_t*)qkv, (const bf16_t*)ctx,
+    dig_launch(attn_bwd_kernel<true, DIG_ATTN_BWD_STORE>, dim3(n_img * heads), dim3(256), (unsigned)lds, stream, (const bf16_t*)qkv, (const bf16_t*)ctx,
                (const bf16_t*)dctx, lse, (bf16_t*)dqkv, embed_dim, heads, scale, (unsigned)qb, (unsigned)(qb / 3), q_colsum, v_colsum, *drop, nqb);
-  else
-    dig_launch(attn_bwd_kernel<false>, dim3(n_img * heads), dim3(256), (unsigned)lds, stream, (const bf16_t*)qkv, (const bf16_t*)ctx,
+  else {
+    auto* k = store_mode == 3 ? attn_bwd_kernel<false, 3> : (store_mode == 1 ? attn_bwd_kernel<false, 1> : attn_bwd_kernel<false, 0>);
+    dig_launch(k, dim3(n_img * heads), dim3(256), (unsigned)lds, stream, (const bf16_t*)qkv, (const bf16_t*)ctx,
                (const bf16_t*)dctx, lse, (bf16_t*)dqkv, embed_dim, heads, scale, (unsigned)qb, (unsigned)(qb / 3), q_colsum, v_colsum,
                dig_dropout_t{}, nqb);
+  }
   return dig_check_launch();
 }
 

@@ -14,11 +14,12 @@ __device__ __forceinline__ int u_addr(int row, int col) { return row * 128 + (((
 
 // Stage a [256 x 64] bf16 tile (row stride ld elements, starting at element offset base) into LDS layout U.
 // 2048 16-B pieces; NT threads.
-template <int NT>
+// STEP = 2 (NT = 256: one iteration = one 32-row block): only the even 32-row blocks
+template <int NT, int STEP = 1>
 __device__ __forceinline__ void stage_tile(unsigned char* lds, __amdgpu_buffer_rsrc_t rs, unsigned base_bytes, int ld,
                                            int tid, int wave) {
 #pragma unroll
-  for (int it = 0; it < 2048 / NT; ++it) {
+  for (int it = 0; it < 2048 / NT; it += STEP) {
     const int piece = it * NT + tid;
     const int row = piece >> 3, pc = piece & 7;
     const int c = pc ^ swz(row);
@@ -94,6 +95,7 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& a, int u) {
 // Store one lane-row of a 32 x 64 result held as two 32x32 MFMA accumulators (lane = row, registers = 4-column groups
 // interleaved between the two lane halves).  v_permlane32_swap trades column groups between lane l and l+32 so that each
 // lane owns 16 contiguous columns per accumulator: 4 x 16-byte stores per row instead of 8 x 8-byte ones.
+template <bool NT = false>
 __device__ __forceinline__ void store_rows(bf16_t* row, const f32x16 (&acc)[2], int hi) {
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt) {
@@ -111,8 +113,49 @@ __device__ __forceinline__ void store_rows(bf16_t* row, const f32x16 (&acc)[2], 
       P[1][k] = r1[0]; P[3][k] = r1[1];
     }
     bf16_t* o = row + dt * 32 + hi * 16;
-    *reinterpret_cast<uint4*>(o) = make_uint4(P[0][0], P[0][1], P[2][0], P[2][1]);
-    *reinterpret_cast<uint4*>(o + 8) = make_uint4(P[1][0], P[1][1], P[3][0], P[3][1]);
+    const dig_u32x4 w0 = {P[0][0], P[0][1], P[2][0], P[2][1]}, w1 = {P[1][0], P[1][1], P[3][0], P[3][1]};
+    if (NT) {                                                            // results nobody re-reads through this L2 soon: no write-allocate
+      __builtin_nontemporal_store(w0, reinterpret_cast<dig_u32x4*>(o));
+      __builtin_nontemporal_store(w1, reinterpret_cast<dig_u32x4*>(o + 8));
+    } else {
+      *reinterpret_cast<dig_u32x4*>(o) = w0;
+      *reinterpret_cast<dig_u32x4*>(o + 8) = w1;
+    }
+  }
+}
+
+// The same 32 x 64 result leaving in FULL 128-byte lines: store_rows writes 32 bytes of 32 different rows per instruction (a lane pair per row) --
+// 32 partial-line write requests where 8 full lines would do -- and the attention backward's 151 MB of results cost it a third of its time that
+// way (lab: 133 us with the row stores, 99 us with no stores at all, 45 us for all its loads).  The block goes through 2 KiB of wave-private LDS,
+// 16 rows at a time (64-bit pieces at 16-byte position (4 dt + g) ^ (row & 7): conflict-free both ways), and is read back 8 adjacent lanes per
+// row: one store instruction = 8 rows x 128 contiguous bytes.  `blk` = &T[the wave's first row][first column], ld in elements.
+template <bool NT = false>
+__device__ __forceinline__ void store_rows_lines(bf16_t* blk, int ld, const f32x16 (&acc)[2], unsigned char* stg, int lane) {
+  asm volatile("" : "+v"(lane));            // the addresses below are derived HERE from a copy the optimiser cannot see through: hoisted out of the
+                                            // caller's loops they stay alive across its MFMA phases (a spilled register in the attention backward)
+  const int rr = lane & 31, hi = lane >> 5;
+  const int wr = (rr & 15) * 128 + hi * 8, ws = rr & 7;
+  const int r8 = lane >> 3, c = lane & 7;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    if ((rr >> 4) == pass) {
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<uint2*>(stg + wr + (((4 * dt + g) ^ ws) << 4)) =
+              make_uint2(pack_bf2(acc[dt][g * 4], acc[dt][g * 4 + 1]), pack_bf2(acc[dt][g * 4 + 2], acc[dt][g * 4 + 3]));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    const dig_u32x4 v0 = *reinterpret_cast<const dig_u32x4*>(stg + r8 * 128 + ((c ^ (r8 & 7)) << 4));
+    const dig_u32x4 v1 = *reinterpret_cast<const dig_u32x4*>(stg + (8 + r8) * 128 + ((c ^ (r8 & 7)) << 4));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    dig_u32x4* d0 = reinterpret_cast<dig_u32x4*>(blk + (size_t)(16 * pass + r8) * ld + c * 8);
+    dig_u32x4* d1 = reinterpret_cast<dig_u32x4*>(blk + (size_t)(16 * pass + 8 + r8) * ld + c * 8);
+    if (NT) { __builtin_nontemporal_store(v0, d0); __builtin_nontemporal_store(v1, d1); }
+    else { *d0 = v0; *d1 = v1; }
   }
 }
 

@@ -50,30 +50,46 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
                                                      const float* __restrict__ beta, bf16_t* __restrict__ y,
                                                      float* __restrict__ mean, float* __restrict__ rstd, int rows, float eps) {
   constexpr int D = EPL * 64;
+  // rows per wave per iteration: all U row loads are issued before the first reduction (a wave with one 1-KiB row in flight and two
+  // dependent 6-step wave reductions behind it keeps 32 KiB per CU in flight -- half of what the HBM latency x bandwidth product asks for);
+  // each row's arithmetic and summation order are those of the one-row form (bit-identical results)
+  constexpr int U = GELU ? 2 : 4;
   const int lane = threadIdx.x & 63;
   const int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int nw = (gridDim.x * blockDim.x) >> 6;
   float g[EPL], b[EPL];
 #pragma unroll
   for (int k = 0; k < EPL; ++k) { g[k] = gamma[lane * EPL + k]; b[k] = beta[lane * EPL + k]; }
-  for (int r = w; r < rows; r += nw) {
-    float v[EPL];
-    load_row<EPL>(x + (size_t)r * D + lane * EPL, v);
-    float s = 0.f;
+  for (int r0 = w * U; r0 < rows; r0 += nw * U) {
+    float v[U][EPL];
 #pragma unroll
-    for (int k = 0; k < EPL; ++k) s += v[k];
-    const float mu = wave_sum(s) * (1.0f / D);
-    float q = 0.f;
+    for (int u = 0; u < U; ++u) load_row<EPL>(x + (size_t)min(r0 + u, rows - 1) * D + lane * EPL, v[u]);
+    float mu[U], rs[U];
 #pragma unroll
-    for (int k = 0; k < EPL; ++k) { v[k] -= mu; q += v[k] * v[k]; }
-    const float rs = rsqrtf(wave_sum(q) * (1.0f / D) + eps);
+    for (int u = 0; u < U; ++u) {
+      float s = 0.f;
 #pragma unroll
-    for (int k = 0; k < EPL; ++k) {
-      v[k] = v[k] * rs * g[k] + b[k];
-      if (GELU) v[k] = gelu_f(v[k]);
+      for (int k = 0; k < EPL; ++k) s += v[u][k];
+      mu[u] = wave_sum(s) * (1.0f / D);
     }
-    store_row<EPL>(y + (size_t)r * D + lane * EPL, v);
-    if (lane == 0) { mean[r] = mu; rstd[r] = rs; }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float q = 0.f;
+#pragma unroll
+      for (int k = 0; k < EPL; ++k) { v[u][k] -= mu[u]; q += v[u][k] * v[u][k]; }
+      rs[u] = rsqrtf(wave_sum(q) * (1.0f / D) + eps);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (r0 + u >= rows) break;
+#pragma unroll
+      for (int k = 0; k < EPL; ++k) {
+        v[u][k] = v[u][k] * rs[u] * g[k] + b[k];
+        if (GELU) v[u][k] = gelu_f(v[u][k]);
+      }
+      store_row<EPL>(y + (size_t)(r0 + u) * D + lane * EPL, v[u]);
+      if (lane == 0) { mean[r0 + u] = mu[u]; rstd[r0 + u] = rs[u]; }
+    }
   }
 }
 
@@ -480,6 +496,7 @@ __global__ __launch_bounds__(256) void bn_fused_kernel(const bf16_t* __restrict_
 }
 
 inline int ln_grid(int rows) { return std::max(1, std::min(2048, (rows + 3) / 4)); }
+inline int ln_fwd_grid(int rows, bool gelu) { const int per = 4 * (gelu ? 2 : 4); return std::max(1, std::min(2048, (rows + per - 1) / per)); }
 
 }  // namespace
 
@@ -498,7 +515,7 @@ extern "C" int dig_layernorm_fwd(const void* x, const float* gamma, const float*
                                  int rows, int D, float eps, int fuse_gelu, hipStream_t stream) {
   if (!x || !gamma || !beta || !y || !mean || !rstd || rows <= 0) return DIG_ERR_ARG;
   if (!aligned16(x) || !aligned16(y)) return DIG_ERR_ALIGN;
-  const int grid = ln_grid(rows);
+  const int grid = ln_fwd_grid(rows, fuse_gelu != 0);
   if (fuse_gelu) { LN_DISPATCH(D, true, ln_fwd_kernel, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, rows, eps) }
   else { LN_DISPATCH(D, false, ln_fwd_kernel, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, rows, eps) }
   return dig_check_launch();

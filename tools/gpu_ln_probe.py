@@ -1,9 +1,11 @@
-"""LayerNorm forward / backward alone at the step's shape (65 536 x 384 bf16): microseconds and achieved HBM rate."""
+"""LayerNorm forward / backward alone at the step's shape (65 536 x 384 bf16; `python tools/gpu_ln_probe.py R D` for another, e.g. 131072 512 =
+ViT-Base at B = 256): microseconds and achieved HBM rate."""
 import sys, torch
 sys.path.insert(0, ".")
 from dig_amd import ops
 dev = torch.device("cuda:0")
-R, D = 65536, 384
+R, D = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (65536, 384)
+print(f"rows {R} width {D}")
 x = torch.randn(R, D, device=dev).bfloat16(); dy = torch.randn(R, D, device=dev).bfloat16(); dres = torch.randn(R, D, device=dev).bfloat16()
 g, b = torch.randn(D, device=dev), torch.randn(D, device=dev)
 dg, db, dc = torch.zeros(D, device=dev), torch.zeros(D, device=dev), torch.zeros(D, device=dev)
