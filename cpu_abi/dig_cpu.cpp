@@ -281,6 +281,7 @@ int dig_attn_fwd(const void* qkv, void* ctx, float* lse, int n_img, int heads, i
 
 // (one backward form in this build: the switch of the HIP build is accepted and ignored)
 int dig_attn_bwd_mode(int) { return 0; }
+int dig_attn_bwd_store(int) { return 0; }   // (one store form in the CPU build)
 
 // the attention sub-block in one call (HIP: csrc/attn_block.hip): here the same three steps, one after the other.  qkv / lse null: the
 // momentum branch keeps nothing (the q | k | v rows then live in a temporary)

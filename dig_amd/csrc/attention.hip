@@ -19,7 +19,6 @@
 // the transpose read).
 #include "common.h"
 #include <atomic>
-#include <cstdlib>
 
 // phase time stamps for tools/experiments/attn_bwd_lab.hip (empty in the product build)
 #ifndef DIG_ATTN_SP_LAB
@@ -36,7 +35,7 @@
 #endif
 #ifndef DIG_ATTN_BWD_STORE
 #define DIG_ATTN_BWD_STORE 3                 // backward, how dq / dk / dv leave: 0 = 16-byte row stores, 1 = the same, non-temporal, 3 = full 128-byte lines
-#endif                                       // through 2 KiB of LDS per wave, non-temporal (environment DIG_ATTN_BWD_STORE overrides: A/B in the step)
+#endif                                       // through 2 KiB of LDS per wave, non-temporal (dig_attn_bwd_store() / environment DIG_ATTN_BWD_STORE: A/B in the step)
 #ifndef DIG_ATTN_LIFT
 #define DIG_ATTN_LIFT 3                      // backward restage: bit 0 both query blocks' Q / dO fragments from LDS, bit 1 odd K / V blocks from registers
 #endif
@@ -835,6 +834,12 @@ __global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const bf16_t* __restri
 // which backward kernel dig_attn_bwd launches for full self-attention without dropout: 1 = single pass (attn_bwd_sp_kernel), 0 = two phases
 // (read by dig_attn_bwd on autograd's thread while a caller's thread may set it: an atomic, read once per launch)
 static std::atomic<int> g_attn_bwd_single_pass{DIG_ATTN_BWD_SP_DEFAULT};
+// how the two-phase kernel's results leave (DIG_ATTN_BWD_STORE above); process-wide, read once per launch
+static std::atomic<int> g_attn_bwd_store{DIG_ATTN_BWD_STORE};
+extern "C" int dig_attn_bwd_store(int mode) {
+  if (mode == 0 || mode == 1 || mode == 3) return g_attn_bwd_store.exchange(mode, std::memory_order_relaxed);
+  return g_attn_bwd_store.load(std::memory_order_relaxed);
+}
 extern "C" int dig_attn_bwd_mode(int single_pass) {
   if (single_pass == 0 || single_pass == 1) return g_attn_bwd_single_pass.exchange(single_pass, std::memory_order_relaxed);
   return g_attn_bwd_single_pass.load(std::memory_order_relaxed);
@@ -897,11 +902,7 @@ extern "C" int dig_attn_bwd_dropout(const void* qkv, const void* ctx, const void
     return dig_check_launch();
   }
   const int lds = BWD_LDS;
-  static const int store_mode = [] {
-    const char* e = getenv("DIG_ATTN_BWD_STORE");
-    const int m = e ? atoi(e) : DIG_ATTN_BWD_STORE;
-    return (m == 0 || m == 1 || m == 3) ? m : DIG_ATTN_BWD_STORE;
-  }();
+  const int store_mode = g_attn_bwd_store.load(std::memory_order_relaxed);
   static bool attr[DIG_MAX_DEVICES] = {};
   if (!attr[dev]) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS);

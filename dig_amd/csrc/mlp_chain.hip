@@ -51,6 +51,9 @@
 #ifndef DIG_CHAIN_SIDE_AUX
 #define DIG_CHAIN_SIDE_AUX 2                // cache policy of the online forward's side-output stores (2 = nt)
 #endif
+#ifndef DIG_CHAIN_BWD_AUX
+#define DIG_CHAIN_BWD_AUX 0                 // cache policy of the backward's d(pre-activation) stores (2 = nt measured: no difference in the step, 19.14 vs 19.14 ms)
+#endif
 #ifndef DIG_CHAIN_SDMA
 #define DIG_CHAIN_SDMA 0                  // lab (round 6): 1 = online forward (MODE 1) with the S-waves bringing ALL ring pieces and the O-waves -- which issue the
                                           // side-output stores -- none.  Measured (tools/experiments/r06_sdma_ab.sh, profiles/r06_chain_sdma_lab.txt): 209.0 us
@@ -663,7 +666,7 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainParams p) {
             const dig_u32x4 a = *reinterpret_cast<const dig_u32x4*>(pt + row * 128 + cp * 16);
             // (forward: the GELU output and the pre-activation are read again only by the backward -- non-temporal stores, aux = 2: the 400 MB of a
             //  launch do not go through write-allocated L2 lines)
-            __builtin_amdgcn_raw_buffer_store_b128(a, rS0, go, 0, MODE == 1 ? DIG_CHAIN_SIDE_AUX : 0);
+            __builtin_amdgcn_raw_buffer_store_b128(a, rS0, go, 0, MODE == 1 ? DIG_CHAIN_SIDE_AUX : DIG_CHAIN_BWD_AUX);
             if (MODE == 1) {
               const dig_u32x4 b = *reinterpret_cast<const dig_u32x4*>(pt + (X_OFF - P_OFF) + row * 128 + cp * 16);
               __builtin_amdgcn_raw_buffer_store_b128(b, rSide1, go, 0, DIG_CHAIN_SIDE_AUX);

@@ -755,6 +755,18 @@ if os.environ.get("DIG_ATTN_BWD_SP") in ("0", "1"):
     attn_bwd_mode(os.environ["DIG_ATTN_BWD_SP"] == "1")
 
 
+def attn_bwd_store(mode=None):
+    """Select (0 / 1 / 3) or query (None) how the two-phase attention backward writes dqkv: 16-byte row stores, the same non-temporal, or full
+    128-byte lines through LDS, non-temporal (the default).  Bit-identical results.  Returns the previous setting."""
+    if mode is not None and mode not in (0, 1, 3):
+        raise ValueError(f"attn_bwd_store: mode {mode!r} (one of 0, 1, 3)")
+    return int(L.lib().dig_attn_bwd_store(-1 if mode is None else int(mode)))
+
+
+if os.environ.get("DIG_ATTN_BWD_STORE") is not None:
+    attn_bwd_store(int(os.environ["DIG_ATTN_BWD_STORE"]))
+
+
 def attn_bwd(qkv, ctx, dctx, lse, n_img, heads, D, scale, bias_sums=False, drop=None, q_rows=256):
     """dqkv (dq pre-multiplied by `scale`).  bias_sums=True also returns the per-image column sums of the dq and dv parts
     ([n_img, D] fp32 each): the q_bias / v_bias gradient partials for colsum_partials()."""

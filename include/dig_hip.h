@@ -177,6 +177,11 @@ int dig_attn_bwd(const void* qkv, const void* ctx, const void* dctx, const float
  * order), 0 = the two-phase kernel (two 4-wave workgroups per CU, seven products).  Same results up to fp32 summation order; both are
  * bit-reproducible run to run.  Returns the previous setting; any other argument only queries.  Process-wide. */
 int dig_attn_bwd_mode(int single_pass);
+/* How the two-phase kernel's results (dq | dk | dv rows of dqkv) leave: 0 = 16-byte row stores (a lane pair per row: 32 partial-line write
+ * requests per instruction), 1 = the same stores, non-temporal, 3 = full 128-byte lines through 2 KiB of LDS per wave, non-temporal (default:
+ * 143.5 -> 133.7 us per launch alone, 19.05 -> 19.00 ms in the step).  Bit-identical results.  Returns the previous setting; any other argument
+ * only queries.  Process-wide. */
+int dig_attn_bwd_store(int mode);
 
 /* The attention sub-block of an encoder block in ONE launch (csrc/attn_block.hip; D = 384, 6 heads of 64, 256 tokens per image):
  *     x_mid = x + proj(softmax(q k^T) v) + proj_b,   (q | k | v) = ln1 qkv_w^T + qkv_b, q scaled by `scale`

@@ -146,6 +146,15 @@ def _attention_fwd_bwd(dev, Bn, H, scale, spike):
     dqkv2, qs, vs = ops.attn_bwd(qkv, ctx, dctx, lse, Bn, H, D, scale, bias_sums=True)      # fused q_bias / v_bias gradients
     assert torch.equal(dqkv2, dqkv)
     assert torch.equal(ops.attn_bwd(qkv, ctx, dctx, lse, Bn, H, D, scale), dqkv)            # bit-reproducible run to run
+    if dev.type != "cpu":                                                                   # the three store forms of the two-phase kernel: the same bits
+        prev = ops.attn_bwd_store()
+        try:
+            for mode in (0, 1, 3):
+                ops.attn_bwd_store(mode)
+                d3, q3, v3 = ops.attn_bwd(qkv, ctx, dctx, lse, Bn, H, D, scale, bias_sums=True)
+                assert torch.equal(d3, dqkv) and torch.equal(q3, qs) and torch.equal(v3, vs), mode
+        finally:
+            ops.attn_bwd_store(prev)
     bq, bv = torch.randn(D, device=dev), torch.randn(D, device=dev)
     bq0, bv0 = bq.clone(), bv.clone()
     ops.colsum_partials(qs, bq); ops.colsum_partials(vs, bv)
