@@ -184,6 +184,17 @@ class GemmProbe:
             # dP, dV, dK, dQ (5); bytes: qkv (+ ctx, dctx, lse) in, ctx / dqkv out
             return ("attn_bwd" if bwd else "attn_fwd", (10.0 if bwd else 4.0) * R * 256 * D, 2.0 * R * D * (9 if bwd else 4))
         sv["attn_fwd"], sv["attn_bwd"] = ops.attn_fwd, ops.attn_bwd
+        sv["attn_bwd_proj"] = ops.attn_bwd_proj
+
+        def attn_proj_rec(R, D):
+            # the attention backward with the projection's data gradient in the launch: + 2 R D D FLOP; dy in instead of d(ctx) in, + the weight
+            f, b = attn_rec(True, R, D)[1:]
+            return ("attn_bwd_proj", f + 2.0 * R * D * D, b + 2.0 * D * D)
+
+        def timed_attn_bwd_proj(qkv, ctx, dy, projt, lse, n_img, heads, D, scale, bias_sums=False):
+            self.rec.append(attn_proj_rec(qkv.shape[0], D))
+            return sv["attn_bwd_proj"](qkv, ctx, dy, projt, lse, n_img, heads, D, scale, bias_sums=bias_sums)
+        ops.attn_bwd_proj = timed_attn_bwd_proj
 
         def timed_attn_fwd(qkv, n_img, heads, D, drop=None, q_rows=256):
             self.rec.append(attn_rec(False, qkv.shape[0], D))
@@ -244,9 +255,10 @@ class GemmProbe:
                 proj_in = bool(b.fuse_ln2 and b.projt)                        # ... and the projection's data gradient: its FLOP, dctx out, the weight
                 self.rec.append(("mlp_chain_bwd", 4.0 * R * D * Fh + 2.0 * R * D * D * proj_in,
                                  2.0 * R * D * ((3 if b.fuse_ln2 else 2) + proj_in) + 2.0 * R * Fh * 2 + 2.0 * 2 * D * Fh + 2.0 * D * D * proj_in))
-                if not proj_in:
+                proj_attn = bool(not proj_in and b.attn_proj and b.proj_wt and ops.attn_bwd_proj_supported(D))   # (csrc/encoder_block.inc)
+                if not proj_in and not proj_attn:
                     self.rec.append(gemm_rec("dgrad", b.tile_dgrad, R, D, D))
-                self.rec.append(attn_rec(True, R, D))
+                self.rec.append(attn_proj_rec(R, D) if proj_attn else attn_rec(True, R, D))
                 shapes = ((D, Fh), (Fh, D), (D, D), (3 * D, D))
                 if not b.wg_defer:                                            # (deferred plan: the grouped launch is issued by the caller, booked below)
                     self.rec.append(("wgrad_group", sum(2.0 * R * o * i for o, i in shapes), sum(2.0 * R * (o + i) + 8.0 * o * i for o, i in shapes)))
@@ -269,6 +281,7 @@ class GemmProbe:
         ops.WgradGroup.launch = sv["wg_launch"]
         ops.attn_block_fwd = sv["attn_block"]
         ops.attn_fwd, ops.attn_bwd = sv["attn_fwd"], sv["attn_bwd"]
+        ops.attn_bwd_proj = sv["attn_bwd_proj"]
         ops.L.call = sv["call"]
         torch.cuda.synchronize()
         cap = len(self.rec) + 64
@@ -298,6 +311,8 @@ KERNEL_TEXT = {
     "mlp_chain_momentum": "dig_mlp_chain_fwd_ln, momentum form (mlp_chain_kernel<0, true>: norm2 -> fc1 -> GELU -> fc2 + residual -> next norm1 in one launch, no side outputs)",
     "mlp_chain_bwd": "dig_mlp_chain_bwd_ln (mlp_chain_kernel<2>: the MLP's two data gradients x GELU' and norm2's backward in one launch)",
     "attn_bwd": "dig_attn_bwd (attn_bwd_kernel: dq, dk, dv of the softmax attention given d(ctx), one workgroup per (image, head), + the q / v bias sums)",
+    "attn_bwd_proj": "dig_attn_bwd_proj (attn_bwd_kernel<.., PROJ>: the same launch with the projection's data gradient in front -- d(ctx) = dx_mid Wproj computed per "
+                     "workgroup, never written)",
     "attn_fwd": "dig_attn_fwd (attn_fwd_kernel: softmax(q k^T) v, one workgroup per (image, head))",
     "attn_block_online": "dig_attn_block_fwd, online form (attn_block_kernel<true>: qkv Linear -> softmax(q k^T) v -> proj Linear + residual in one launch, one "
                          "workgroup per image; writes qkv, ctx, lse for the backward)",

@@ -380,6 +380,31 @@ int dig_attn_bwd(const void* qkv, const void* ctx, const void* dctx, const float
   return dig_attn_bwd_dropout(qkv, ctx, dctx, lse, dqkv, n_img, heads, embed_dim, scale, q_colsum, v_colsum, nullptr, N_TOK, stream);
 }
 
+// the projection's data gradient in front of the backward: d(ctx) = bf16(dy Wproj) with fp32 accumulation, then the plain backward
+int dig_attn_bwd_proj(const void* qkv, const void* ctx, const void* dy_, const void* projt_, const float* lse, void* dqkv, int n_img, int heads,
+                      int embed_dim, float scale, float* q_colsum, float* v_colsum, hipStream_t stream) {
+  if (!qkv || !ctx || !dy_ || !projt_ || !lse || !dqkv || n_img <= 0 || heads <= 0) return DIG_ERR_ARG;
+  if (embed_dim != heads * 64 || (embed_dim & 127) || embed_dim > 512) return DIG_ERR_UNSUPPORTED;
+  const int D = embed_dim;
+  const long R = (long)n_img * N_TOK;
+  const uint16_t* dy = (const uint16_t*)dy_;
+  const uint16_t* wt = (const uint16_t*)projt_;                       // [in i][out o]
+  std::vector<float> w((size_t)D * D);
+  for (size_t k = 0; k < w.size(); ++k) w[k] = bf2f(wt[k]);
+  std::vector<uint16_t> dctx((size_t)R * D);
+#pragma omp parallel for
+  for (long r = 0; r < R; ++r) {
+    std::vector<float> row(D);
+    for (int o = 0; o < D; ++o) row[o] = bf2f(dy[r * D + o]);
+    for (int i = 0; i < D; ++i) {
+      float a = 0.f;
+      for (int o = 0; o < D; ++o) a += row[o] * w[(size_t)i * D + o];
+      dctx[r * D + i] = f2bf(a);
+    }
+  }
+  return dig_attn_bwd(qkv, ctx, dctx.data(), lse, dqkv, n_img, heads, embed_dim, scale, q_colsum, v_colsum, stream);
+}
+
 // ------------------------------------------------------------------------------------------------------------------ LayerNorm
 static bool ln_dim_ok(int D) { return D == 64 || D == 128 || D == 192 || D == 256 || D == 384 || D == 512; }
 

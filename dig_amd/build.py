@@ -84,7 +84,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 # ---- the hot kernels of the pre-training step (the families on top of profiles/*_kernel_stats.csv): none may use scratch memory
 HOT_KERNELS = ("mlp_chain_kernel<1, true, false>", "mlp_chain_kernel<2, true, false>", "mlp_chain_kernel<0, true, false>",
-               "wgrad_wide_kernel<3, 7>", "attn_block_kernel<true, 2>", "attn_block_kernel<false, 2>", "attn_bwd_kernel<false, 3>", "attn_bwd_kernel<false, 0>",
+               "wgrad_wide_kernel<3, 7>", "attn_block_kernel<true, 2>", "attn_block_kernel<false, 2>", "attn_bwd_kernel<false, 3, false>", "attn_bwd_kernel<false, 3, true>",
                "gemm_wide_kernel<false, true, 0, 4, 3, 2, 2, false, 64, 2, false>", "gemm_pwide_kernel<4, false, false>")
 LLVM_BIN = os.environ.get("DIG_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
 

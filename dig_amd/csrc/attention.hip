@@ -209,12 +209,19 @@ __device__ __forceinline__ void wave_colsum(const f32x16 (&acc)[2], float* out, 
 // ------------------------------------------------------------------------------------------------
 constexpr int BWD_STG_OFF = 2 * TILE + 2 * N_TOK * 4 + 8 * 128 * 4;
 constexpr int BWD_LDS = BWD_STG_OFF + 4 * 2048;                            // 78 KiB: two workgroups per CU
-template <bool DROP, int STORE>
+// PROJ (dig_attn_bwd_proj): `dctx` holds dy, the gradient of the projection's OUTPUT rows [R, D], and `projt` = Wproj^T [D in][D out]; the
+// workgroup computes its own d(ctx) tile  dO[256 q, 64 d] = dy[256, D] Wproj[:, 64 h ..]  before anything else -- 96 (D = 384) MFMAs per wave,
+// Wproj^T's 64 rows of this head through LDS (D / 64 sub-tiles [64 i][64 o] in layout U over T0 | T1), the dy rows as B fragments straight
+// from global memory -- rounds it to bf16 as the projection's data-gradient GEMM does and parks it in T1 where the staging of d(ctx) would
+// have put it.  d(ctx) never exists in HBM and the GEMM launch is gone.  The six heads of an image read the same dy rows: the block index is
+// re-mapped so that they sit on ONE XCD (block b runs on XCD b mod 8) and share them through its L2.
+template <bool DROP, int STORE, bool PROJ = false>
 __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ ctx,
                                                            const bf16_t* __restrict__ dctx, const float* __restrict__ lse,
                                                            bf16_t* __restrict__ dqkv, int D, int H, float scale,
                                                            unsigned qkv_bytes, unsigned ctx_bytes, float* __restrict__ qsum, float* __restrict__ vsum,
-                                                           dig_dropout_t drop, int nqb) {
+                                                           dig_dropout_t drop, int nqb, const bf16_t* __restrict__ projt) {
+  static_assert(!PROJ || (DIG_ATTN_LIFT & 1), "the fused projection gradient leaves no d(ctx) rows to re-read");
   constexpr int store_mode = STORE;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* T0 = smem;                                              // Q, then K
@@ -224,7 +231,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const bf16_t* __restri
   float* csum_s = del_s + N_TOK;                                         // [8 blocks][2][64]: column sums of dQ and dV (qsum only)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int img = blockIdx.x / H, h = blockIdx.x - img * H;
+  int bid = blockIdx.x;
+  if (PROJ && (gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);    // consecutive (image, head) pairs on one XCD
+  const int img = bid / H, h = bid - img * H;
   const int ld = 3 * D;
   const size_t tok0 = (size_t)img * N_TOK;
   const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)qkv, 0, qkv_bytes, 0x00020000);
@@ -236,11 +245,73 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const bf16_t* __restri
   // O rows for delta: 8 lanes cover one 128-byte row, 32 rows per pass (coalesced; a thread-per-row read of O and dO cost
   // a quarter of the kernel: every load instruction touched 64 different lines)
   bf16x8 orow[8];
+  auto load_o = [&] {
 #pragma unroll
-  for (int ps = 0; ps < 8; ++ps)
-    orow[ps] = *reinterpret_cast<const bf16x8*>(ctx + ((DIG_ATTN_B_ABL & 256) ? 0 : (tok0 + ps * 32 + (tid >> 3)) * D + h * DH + (tid & 7) * 8));
-  stage_tile<256>(T0, rs, base, ld, tid, wave);                                         // Q
-  stage_tile<256>(T1, rg, (unsigned)((tok0 * D + h * DH) * 2), D, tid, wave);           // dO
+    for (int ps = 0; ps < 8; ++ps)
+      orow[ps] = *reinterpret_cast<const bf16x8*>(ctx + ((DIG_ATTN_B_ABL & 256) ? 0 : (tok0 + ps * 32 + (tid >> 3)) * D + h * DH + (tid & 7) * 8));
+  };
+  if constexpr (!PROJ) load_o();                                          // (PROJ: behind the projection -- its dy fragments need the registers)
+  if constexpr (PROJ) {
+    const int nk = D >> 6;                                                // 64-wide pieces of the reduction (even, <= 8: the host checks)
+    const auto rp = __builtin_amdgcn_make_buffer_rsrc((void*)projt, 0, (unsigned)(D * D * 2), 0x00020000);
+    for (int kk = 0; kk < nk; ++kk)
+      stage_tile<256, 1, 512>(smem + kk * 8192, rp, (unsigned)(((size_t)h * DH * D + kk * 64) * 2), D, tid, wave);
+    bf16x8 yf[4][2][4];                                                   // dy fragments [ring slot][query block][k step]: lane = query row, 8 contiguous o
+    const bf16_t* yp = dctx + (tok0 + wave * 64 + (lane & 31)) * D + hi * 8;
+    auto load_y = [&](bf16x8 (&y)[2][4], int kk) {
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) y[blk][s] = *reinterpret_cast<const bf16x8*>(yp + (size_t)blk * 32 * D + kk * 64 + s * 16);
+    };
+    f32x16 od[2][2];                                                      // dO^T [query block][dt]: lane = query, registers = d
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) od[blk][dt][e] = 0.f;
+    auto mm = [&](const bf16x8 (&y)[2][4], int kk) {
+      const unsigned char* wt = smem + kk * 8192;
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const bf16x8 a = frag_direct_o(wt + dt * 4096, fo, s);         // Wproj^T rows 64 h + 32 dt + (lane & 31), o = 64 kk + 16 s + 8 hi ..
+#pragma unroll
+          for (int blk = 0; blk < 2; ++blk) od[blk][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, y[blk][s], od[blk][dt], 0, 0, 0);
+        }
+    };
+    // a ring of four 64-wide pieces of the dy rows in flight (128 registers): the row-per-lane loads are latency-bound, two pieces in flight
+    // left three round trips exposed (18 k cycles per wave for 3 k cycles of MFMAs)
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+      if (kk < nk) load_y(yf[kk], kk);
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      if (kk < nk) {
+        mm(yf[kk & 3], kk);
+        if (kk + 4 < nk) load_y(yf[kk & 3], kk + 4);
+      }
+    }
+    __syncthreads();                                                      // every wave is done with Wproj^T: T0 | T1 are free
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+      const int row = wave * 64 + blk * 32 + (lane & 31);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<uint2*>(T1 + row * 128 + (((4 * dt + g) ^ swz(row)) << 4) + hi * 8) =
+              make_uint2(pack_bf2(od[blk][dt][4 * g], od[blk][dt][4 * g + 1]), pack_bf2(od[blk][dt][4 * g + 2], od[blk][dt][4 * g + 3]));
+    }
+    stage_tile<256>(T0, rs, base, ld, tid, wave);                                       // Q
+    load_o();
+  } else {
+    stage_tile<256>(T0, rs, base, ld, tid, wave);                                       // Q
+    stage_tile<256>(T1, rg, (unsigned)((tok0 * D + h * DH) * 2), D, tid, wave);         // dO
+  }
   // K / V fragments of a key block, straight from global
   bf16x8 kf[4], vf[4];
   auto load_kv = [&](int kb) {
@@ -253,7 +324,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const bf16_t* __restri
     }
   };
   load_kv(wave * 2);
-  lse_s[tid] = -lse[(size_t)blockIdx.x * N_TOK + tid];              // negated: they seed the S / dP accumulators
+  lse_s[tid] = -lse[(size_t)bid * N_TOK + tid];              // negated: they seed the S / dP accumulators
   DIG_ATTN_TS(1)
   __syncthreads();
   DIG_ATTN_TS(2)
@@ -432,7 +503,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const bf16_t* __restri
           for (int e = 0; e < 4; ++e) {
             const float p = __expf(st[g * 4 + e]);
             const unsigned qi = qt * 32 + 8 * g + 4 * hi + e;
-            const float m = dig_drop_keep(drop.k0, drop.k1, (qi << 16) | (unsigned)key, blockIdx.x, drop.thr) ? drop.scale : 0.f;
+            const float m = dig_drop_keep(drop.k0, drop.k1, (qi << 16) | (unsigned)key, bid, drop.thr) ? drop.scale : 0.f;
             st[g * 4 + e] = p * m;                                          // dropped probabilities (for dV)
             dp[g * 4 + e] = p * (dp[g * 4 + e] * m + dl[e]);
           }
@@ -577,7 +648,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const bf16_t* __restri
         if (DROP) {                                                        // dP = mask * (dO V^T) / (1 - p)
           float g = dp[e];
           const unsigned key = kt * 32 + 8 * (e >> 2) + 4 * hi + (e & 3);
-          g = dig_drop_keep(drop.k0, drop.k1, ((unsigned)q << 16) | key, blockIdx.x, drop.thr) ? g * drop.scale : 0.f;
+          g = dig_drop_keep(drop.k0, drop.k1, ((unsigned)q << 16) | key, bid, drop.thr) ? g * drop.scale : 0.f;
           st[e] = __expf(st[e] + my_lse) * (g + my_del);                   // dS^T (my_lse = -lse, my_del = -delta)
         } else {
           st[e] = __expf(st[e]) * dp[e];
@@ -913,13 +984,35 @@ extern "C" int dig_attn_bwd_dropout(const void* qkv, const void* ctx, const void
   }
   if (drop && drop->thr)
     dig_launch(attn_bwd_kernel<true, DIG_ATTN_BWD_STORE>, dim3(n_img * heads), dim3(256), (unsigned)lds, stream, (const bf16_t*)qkv, (const bf16_t*)ctx,
-               (const bf16_t*)dctx, lse, (bf16_t*)dqkv, embed_dim, heads, scale, (unsigned)qb, (unsigned)(qb / 3), q_colsum, v_colsum, *drop, nqb);
+               (const bf16_t*)dctx, lse, (bf16_t*)dqkv, embed_dim, heads, scale, (unsigned)qb, (unsigned)(qb / 3), q_colsum, v_colsum, *drop, nqb, (const bf16_t*)nullptr);
   else {
     auto* k = store_mode == 3 ? attn_bwd_kernel<false, 3> : (store_mode == 1 ? attn_bwd_kernel<false, 1> : attn_bwd_kernel<false, 0>);
     dig_launch(k, dim3(n_img * heads), dim3(256), (unsigned)lds, stream, (const bf16_t*)qkv, (const bf16_t*)ctx,
                (const bf16_t*)dctx, lse, (bf16_t*)dqkv, embed_dim, heads, scale, (unsigned)qb, (unsigned)(qb / 3), q_colsum, v_colsum,
-               dig_dropout_t{}, nqb);
+               dig_dropout_t{}, nqb, (const bf16_t*)nullptr);
   }
+  return dig_check_launch();
+}
+
+// The projection's data gradient inside the attention backward (attn_bwd_kernel<.., PROJ>): dy [R, D] = gradient of the projection's output
+// rows, projt = Wproj^T [D in][D out] (bf16).  D a multiple of 128, at most 512 (the weight slice of a head fills the two operand tiles).
+extern "C" int dig_attn_bwd_proj(const void* qkv, const void* ctx, const void* dy, const void* projt, const float* lse, void* dqkv, int n_img,
+                                 int heads, int embed_dim, float scale, float* q_colsum, float* v_colsum, hipStream_t stream) {
+  if (!qkv || !ctx || !dy || !projt || !lse || !dqkv || n_img <= 0 || heads <= 0) return DIG_ERR_ARG;
+  if ((q_colsum == nullptr) != (v_colsum == nullptr)) return DIG_ERR_ARG;
+  if (embed_dim != heads * DH || (embed_dim & 127) || embed_dim > 512) return DIG_ERR_UNSUPPORTED;
+  if (!aligned16(qkv) || !aligned16(ctx) || !aligned16(dy) || !aligned16(projt) || !aligned16(dqkv)) return DIG_ERR_ALIGN;
+  const size_t qb = (size_t)n_img * N_TOK * 3 * embed_dim * 2;
+  if (qb >= (1ull << 32)) return DIG_ERR_ARG;
+  const int dev = dig_device();
+  static bool attr[DIG_MAX_DEVICES] = {};
+  if (!attr[dev]) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<false, DIG_ATTN_BWD_STORE, true>), hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS);
+    attr[dev] = true;
+  }
+  dig_launch(attn_bwd_kernel<false, DIG_ATTN_BWD_STORE, true>, dim3(n_img * heads), dim3(256), (unsigned)BWD_LDS, stream, (const bf16_t*)qkv,
+             (const bf16_t*)ctx, (const bf16_t*)dy, lse, (bf16_t*)dqkv, embed_dim, heads, scale, (unsigned)qb, (unsigned)(qb / 3), q_colsum, v_colsum,
+             dig_dropout_t{}, 8, (const bf16_t*)projt);
   return dig_check_launch();
 }
 

@@ -15,11 +15,12 @@ __device__ __forceinline__ int u_addr(int row, int col) { return row * 128 + (((
 // Stage a [256 x 64] bf16 tile (row stride ld elements, starting at element offset base) into LDS layout U.
 // 2048 16-B pieces; NT threads.
 // STEP = 2 (NT = 256: one iteration = one 32-row block): only the even 32-row blocks
-template <int NT, int STEP = 1>
+// PIECES = 512: a [64 x 64] tile (the first 64 rows of the same layout)
+template <int NT, int STEP = 1, int PIECES = 2048>
 __device__ __forceinline__ void stage_tile(unsigned char* lds, __amdgpu_buffer_rsrc_t rs, unsigned base_bytes, int ld,
                                            int tid, int wave) {
 #pragma unroll
-  for (int it = 0; it < 2048 / NT; it += STEP) {
+  for (int it = 0; it < PIECES / NT; it += STEP) {
     const int piece = it * NT + tid;
     const int row = piece >> 3, pc = piece & 7;
     const int c = pc ^ swz(row);

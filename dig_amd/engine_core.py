@@ -344,7 +344,9 @@ class _Step:
             st.w2t, st.w1t = w2t.data_ptr(), w1t.data_ptr()
             st.projt = projt.data_ptr() if (ops.MLP_CHAIN_LNB and ops.MLP_CHAIN_PROJ) else None
             st.tile_direct = tile_direct                              # (a switch: read on every call)
-            st.proj_wt, st.qkv_wt = (projt.data_ptr(), qkvt.data_ptr()) if tile_direct else (None, None)
+            st.attn_proj = int(ops.ATTN_BWD_PROJ and ops.attn_bwd_proj_supported(D) and not ops.attn_bwd_mode())   # (a switch, read on every call)
+            st.proj_wt = projt.data_ptr() if (tile_direct or st.attn_proj) else None
+            st.qkv_wt = qkvt.data_ptr() if tile_direct else None
             st.x, st.ln1, st.mu1, st.rs1 = sv.inp_ptr
             for k in ("qkv", "ctx", "lse", "x_mid", "ln2", "mu2", "rs2", "pre", "act"):
                 setattr(st, k, sv.ptr(k))
@@ -639,7 +641,10 @@ class _Step:
             else:
                 on_side(lambda dzp=dzp: wg(dzp, ctx, g["attn.proj.weight"]), dzp, ctx)
             _mark("blk: LayerNorm backward (norm2)", dev)
-            if not chain or dctx is None:
+            # (the projection's data gradient inside the attention backward launch where that form exists: no GEMM, no d(ctx) rows)
+            proj_attn = ((not chain or dctx is None) and ops.ATTN_BWD_PROJ and FUSED_QV_BIAS_SUMS and wT is not None and not ds
+                         and ops.attn_bwd_proj_supported(D) and not ops.attn_bwd_mode())
+            if (not chain or dctx is None) and not proj_attn:
                 # (direct form on proj.weight^T where it pays: both operands K-contiguous, bit-identical to the transpose-read form)
                 dctx = ops.dgrad_direct(dzp, wT[i][2]) if wT is not None else None
                 if dctx is None:
@@ -650,7 +655,11 @@ class _Step:
                 # q_bias / v_bias gradients: per-image column sums of dQ (already carrying the q scale) and dV leave the attention
                 # kernel as [2B, D] fp32 partials (DPP row reductions of the accumulators, no extra pass over the 150 MB dqkv);
                 # K has no bias
-                dqkv, qs, vs = ops.attn_bwd(qkv, ctx, dctx, lse, views * B, H, D, scale, bias_sums=True)
+                if proj_attn:
+                    dqkv, qs, vs = ops.attn_bwd_proj(qkv, ctx, dzp, wT[i][2], lse, views * B, H, D, scale, bias_sums=True)
+                    dctx = None                                             # (no d(ctx) rows: the qkv data gradient below gets a buffer of its own)
+                else:
+                    dqkv, qs, vs = ops.attn_bwd(qkv, ctx, dctx, lse, views * B, H, D, scale, bias_sums=True)
                 _mark("blk: attention backward", dev)
                 if grp:
                     wg(dqkv, ln1, g["attn.qkv.weight"])

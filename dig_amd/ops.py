@@ -284,6 +284,12 @@ def linear_dgrad(dy, w, out=None, gelu_pre=None, colsum=False, drop=None):
     return gemm(dy, w, rows, J, w.shape[0], tb=True, out=out, bk=dgrad_tile_code(rows, J, drop))
 
 
+# The projection's data gradient inside the attention backward launch (dig_attn_bwd_proj): every (image, head) workgroup computes its own d(ctx)
+# tile from dx_mid and proj.weight^T; no GEMM launch, d(ctx) never written.  Opt-in ("1"): measured in the step, three A/B pairs on one box,
+# 18.66 against 18.65 ms and 19.15 against 19.18 -- the launch grows by what the GEMM took (129 -> 169 us in the step, 127 -> 147 alone + 28.5 for
+# the GEMM): the six head-workgroups of an image each pull the image's 196 KB of dy rows and 48 KB of weight through L2 -> CU, 244 KB on top of
+# the 288 KB the backward proper moves per workgroup (profiles/r06_attn_bwd_lab.txt).
+ATTN_BWD_PROJ = os.environ.get("DIG_ATTN_BWD_PROJ", "0") == "1"
 DGRAD_DIRECT = os.environ.get("DIG_DGRAD_DIRECT", "1") != "0"     # the proj / qkv data gradients as direct-form GEMMs on the transposed weight copies
 HEAD_DGRAD_DIRECT = os.environ.get("DIG_HEAD_DGRAD_DIRECT", "0") == "1"   # ... and those of the BN-MLP heads: opt-in.  Measured in the step, two A/B pairs
 #                                                                           on one box: 19.18 / 19.20 against 19.17 / 19.19 ms -- the 4096 x 4096 layer's
@@ -594,7 +600,7 @@ class BlockBwd(ctypes.Structure):
                                     "x", "ln1", "mu1", "rs1", "qkv", "ctx", "lse", "x_mid", "ln2", "mu2", "rs2", "pre", "act", "dy",
                                     "dln2", "dpre", "dctx", "dqkv", "bparts", "ws1", "ws2", "qs", "vs")] +
                 [(k, _I) for k in ("wg_fn", "wg_wa", "wg_splits", "wg_n_wg", "wg_fold_n", "wg_fold_splits")] + [("wg_trans", _I * 4)] +
-                [("wg_defer", _I), ("fuse_ln2", _I)] +
+                [("wg_defer", _I), ("fuse_ln2", _I), ("attn_proj", _I)] +
                 [(k, _VP) for k in ("wg_map", "wg_slabs", "wg_fold_slabs", "wg_probs", "wg_fold_probs", "side")])
 
 
@@ -776,6 +782,21 @@ def attn_bwd(qkv, ctx, dctx, lse, n_img, heads, D, scale, bias_sums=False, drop=
     L.call("dig_attn_bwd_dropout", L.ptr(qkv), L.ptr(ctx), L.ptr(dctx), L.ptr(lse), L.ptr(dqkv), n_img, heads, D, cf(scale), L.ptr(qs), L.ptr(vs),
            ctypes.byref(drop) if drop is not None else None, q_rows, L.stream())
     return (dqkv, qs, vs) if bias_sums else dqkv
+
+
+def attn_bwd_proj(qkv, ctx, dy, projt, lse, n_img, heads, D, scale, bias_sums=False):
+    """attn_bwd with the projection's data gradient inside the launch: dy = gradient of the projection's output rows [R, D], projt = proj.weight^T
+    [in][out] (bf16); d(ctx) = dy @ proj.weight is computed per (image, head) workgroup and never written."""
+    dqkv = torch.empty_like(qkv)
+    qs = torch.empty((n_img, D), device=qkv.device, dtype=F32) if bias_sums else None
+    vs = torch.empty((n_img, D), device=qkv.device, dtype=F32) if bias_sums else None
+    L.call("dig_attn_bwd_proj", L.ptr(qkv), L.ptr(ctx), L.ptr(dy), L.ptr(projt), L.ptr(lse), L.ptr(dqkv), n_img, heads, D, cf(scale), L.ptr(qs), L.ptr(vs),
+           L.stream())
+    return (dqkv, qs, vs) if bias_sums else dqkv
+
+
+def attn_bwd_proj_supported(D):
+    return D % 128 == 0 and D <= 512
 
 
 def patch_embed_fwd(img, W, bias, mask_u8, mask_token, pos, D, gh, gw):

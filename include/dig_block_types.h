@@ -68,6 +68,9 @@ typedef struct dig_block_bwd {
                                           itself, behind the last data gradient (lab switch: the data-gradient chain then runs uninterrupted) */
   int fuse_ln2;                        /* 1: norm2's backward inside the fused MLP backward launch (dig_mlp_chain_bwd_ln) instead of its own launch; ws2 then
                                           holds [dig_mlp_chain_ln_parts(rows)][3][D] and is reduced by dig_layernorm_bwd_finalize_parts */
+  int attn_proj;                       /* 1 (with proj_wt and D a multiple of 128, at most 512): the projection's data gradient inside the attention backward
+                                          launch (dig_attn_bwd_proj: every (image, head) workgroup computes its own d(ctx) tile from dx_mid and
+                                          proj.weight^T) -- no GEMM launch, d(ctx) is never written */
   const unsigned* wg_map; float* wg_slabs; const float* wg_fold_slabs;
   dig_wgrad_prob_t* wg_probs; const dig_wgrad_prob_t* wg_fold_probs;
   hipStream_t side;                    /* stream of the parameter-gradient reductions (may equal the call's stream) */

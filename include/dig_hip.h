@@ -176,6 +176,12 @@ int dig_attn_bwd(const void* qkv, const void* ctx, const void* dctx, const float
  * per (image, head): q / k / v / dctx read once, five matrix products per tile pair, the dQ terms of the eight key blocks summed in LDS in a fixed
  * order), 0 = the two-phase kernel (two 4-wave workgroups per CU, seven products).  Same results up to fp32 summation order; both are
  * bit-reproducible run to run.  Returns the previous setting; any other argument only queries.  Process-wide. */
+/* dig_attn_bwd with the attention projection's data gradient inside the launch: dy [R, embed_dim] bf16 = gradient of the projection's OUTPUT rows
+ * (Attention.proj, modeling_finetune.py:117), projt = proj.weight^T [in][out] bf16.  Every (image, head) workgroup computes its own d(ctx) tile
+ * dy Wproj[:, 64 h ..] on the matrix cores (fp32 accumulation, rounded to bf16 like the GEMM's output) before the backward proper: d(ctx) is
+ * never written and the GEMM launch is gone.  embed_dim: a multiple of 128, at most 512.  Two-phase kernel, no dropout, 256 query rows. */
+int dig_attn_bwd_proj(const void* qkv, const void* ctx, const void* dy, const void* projt, const float* lse, void* dqkv, int n_img, int heads,
+                      int embed_dim, float scale, float* q_colsum, float* v_colsum, hipStream_t stream);
 int dig_attn_bwd_mode(int single_pass);
 /* How the two-phase kernel's results (dq | dk | dv rows of dqkv) leave: 0 = 16-byte row stores (a lane pair per row: 32 partial-line write
  * requests per instruction), 1 = the same stores, non-temporal, 3 = full 128-byte lines through 2 KiB of LDS per wave, non-temporal (default:

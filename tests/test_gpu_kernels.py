@@ -161,6 +161,41 @@ def _attention_fwd_bwd(dev, Bn, H, scale, spike):
     assert rel(bq - bq0, g[:, :D].sum(0)) < 2e-2 and rel(bv - bv0, g[:, 2 * D:].sum(0)) < 2e-2     # same tolerance as dq, dv
 
 
+@pytest.mark.parametrize("Bn,H", [(2, 2), (8, 6), (3, 8)])
+def test_attention_bwd_with_projection_gradient(dev, Bn, H):
+    """dig_attn_bwd_proj: d(ctx) = dy @ proj.weight computed inside the attention backward (per (image, head) workgroup, fp32 accumulation, rounded to
+    bf16) against the two-launch form (data-gradient GEMM -> dig_attn_bwd) and against fp32 autograd of the whole sub-block."""
+    from dig_amd import ops
+    D, scale = H * 64, 0.125
+    R = Bn * 256
+    qkv = torch.randn(R, 3 * D, device=dev).bfloat16()
+    ctx, lse = ops.attn_fwd(qkv, Bn, H, D)
+    Wp = (torch.randn(D, D, device=dev) * D ** -0.5).bfloat16()          # proj.weight [out, in]
+    dy = torch.randn(R, D, device=dev).bfloat16()
+    projt = Wp.t().contiguous()                                          # [in][out]
+    dctx = (dy.float() @ Wp.float()).bfloat16()                          # what the projection's data-gradient GEMM writes
+    ref, qs0, vs0 = ops.attn_bwd(qkv, ctx, dctx, lse, Bn, H, D, scale, bias_sums=True)
+    got, qs, vs = ops.attn_bwd_proj(qkv, ctx, dy, projt, lse, Bn, H, D, scale, bias_sums=True)
+    # the same arithmetic up to the summation order inside d(ctx) (a few bf16 roundings of d(ctx) differ by one ulp)
+    for lo in (0, D, 2 * D):
+        assert rel(got[:, lo:lo + D], ref[:, lo:lo + D]) < 4e-3
+    assert rel(qs, qs0) < 4e-3 and rel(vs, vs0) < 4e-3
+    assert torch.equal(ops.attn_bwd_proj(qkv, ctx, dy, projt, lse, Bn, H, D, scale), got)          # bit-reproducible run to run
+    # fp32 autograd of y = softmax(q k^T) v Wp^T
+    x = qkv.float().requires_grad_(True)
+    t = x.reshape(Bn, 256, 3, H, 64).permute(2, 0, 3, 1, 4)
+    o = ((t[0] @ t[1].transpose(-2, -1)).softmax(-1) @ t[2]).transpose(1, 2).reshape(R, D)
+    (o @ Wp.float().t()).backward(dy.float())
+    g = x.grad.clone(); g[:, :D] *= scale
+    for lo in (0, D, 2 * D):
+        assert rel(got[:, lo:lo + D], g[:, lo:lo + D]) < 2e-2
+    if dev.type != "cpu":
+        bad = torch.randn(256, 3 * 192, device=dev).bfloat16()           # D = 192: not a multiple of 128 -> refused, nothing launched
+        with pytest.raises(RuntimeError):
+            ops.attn_bwd_proj(bad, bad[:, :192].contiguous(), bad[:, :192].contiguous(), torch.zeros(192, 192, device=dev).bfloat16(),
+                              torch.zeros(3, 256, device=dev), 1, 3, 192, scale)
+
+
 @pytest.mark.parametrize("D,gelu", [(384, 0), (512, 0), (128, 0), (192, 1), (64, 1), (256, 0)])
 def test_layernorm(dev, D, gelu):
     from dig_amd import ops

@@ -66,5 +66,8 @@ int main() {
   timeline("product dig_attn_bwd", [] { dig_attn_bwd(qkv, ctx, dctx, lse, dqkv, Bn, H, D, 0.125f, nullptr, nullptr, 0); });
   float *qs, *vs; hipMalloc(&qs, (size_t)Bn * D * 4); hipMalloc(&vs, (size_t)Bn * D * 4);
   timeline("product dig_attn_bwd + q/v bias sums", [=] { dig_attn_bwd(qkv, ctx, dctx, lse, dqkv, Bn, H, D, 0.125f, qs, vs, 0); });
+  // the projection's data gradient inside the launch (dctx's buffer holds dy; the weight is random data)
+  unsigned short* projt; hipMalloc(&projt, (size_t)D * D * 2); hipMemcpy(projt, h.data(), (size_t)D * D * 2, hipMemcpyHostToDevice);
+  timeline("dig_attn_bwd_proj + q/v bias sums", [=] { dig_attn_bwd_proj(qkv, ctx, dctx, projt, lse, dqkv, Bn, H, D, 0.125f, qs, vs, 0); });
   return 0;
 }

@@ -22,6 +22,8 @@ def family(name):
         return "attn_block_online"
     if "attn_block_kernel" in name:
         return "attn_block_momentum"
+    if re.search(r"attn_bwd_kernel<(true|false), \d, true>", name):
+        return "attn_bwd_proj"
     if "attn_bwd" in name:
         return "attn_bwd"
     if "attn_fwd" in name:
