@@ -1018,7 +1018,8 @@ def test_optimizer_launch_leaves_shadow_and_transposes_for_the_next_forward():
 @pytest.mark.parametrize("switch", ["wgrad_off", "wgrad_pair", "wgrad_wa1", "wgrad_side_stream", "chain_mask3", "dgrad_128", "fwd_side", "fwd_serial",
                                     "chain_no_ln", "bwd_single", "chain_bwd_every2", "per_entry_point", "autograd_function", "attn_three_launches",
                                     "attn_bwd_single_pass", "wgrad_inline", "ln2_bwd_own_launch", "proj_dgrad_in_chain", "bn_three_launches",
-                                    "dgrad_transpose_read", "adamw_plain", "head_dgrad_transpose_read"])
+                                    "dgrad_transpose_read", "adamw_plain", "head_dgrad_transpose_read", "proj_dgrad_in_attn_bwd",
+                                    "attn_bwd_row_stores"])
 def test_engine_switches_agree_with_the_default_path(switch):
     """Every non-default execution plan of the step (environment switches of dig_amd/ops.py and engine_core.py: launch groupings, tile
     codes, stream plans, fusion masks) against the default plan on one ViT-S step from the same state and batch: the losses agree, and
@@ -1066,6 +1067,10 @@ def test_engine_switches_agree_with_the_default_path(switch):
         "dgrad_transpose_read": [(ops, "DGRAD_DIRECT", False)],
         "adamw_plain": [],
         "head_dgrad_transpose_read": [(ops, "HEAD_DGRAD_DIRECT", False)],  # the heads' data gradients on the [out, in] weights: another K split of the 4096-deep layers
+        # the projection's data gradient inside the attention backward launch (dig_attn_bwd_proj, opt-in plan): d(ctx) per (image, head) workgroup,
+        # another K order inside it -- a different BACKWARD kernel in front of the same attention backward
+        "proj_dgrad_in_attn_bwd": [(ops, "ATTN_BWD_PROJ", True)],
+        "attn_bwd_row_stores": [],                                        # (a library-wide mode, set below: the same results, bit for bit)
         "wgrad_inline": [(engine_core, "WGRAD_DEFER", "0")],              # the grouped launch of a block inside its data-gradient chain (the plan under a
                                                                           # process group) instead of all twelve behind the last data gradient: same sums
     }
@@ -1075,6 +1080,7 @@ def test_engine_switches_agree_with_the_default_path(switch):
         plans[switch] = [(optim_factory, "FOLD_SHADOW", False)]
     saved = [(m, k, getattr(m, k)) for m, k, _ in plans[switch]]
     prev_mode = ops.attn_bwd_mode(True) if switch == "attn_bwd_single_pass" else None
+    prev_store = ops.attn_bwd_store(0) if switch == "attn_bwd_row_stores" else None
     try:
         for m, k, v in plans[switch]:
             setattr(m, k, v)
@@ -1086,12 +1092,15 @@ def test_engine_switches_agree_with_the_default_path(switch):
             setattr(m, k, v)
         if prev_mode is not None:
             ops.attn_bwd_mode(prev_mode)
+        if prev_store is not None:
+            assert prev_store == 3, "full-line non-temporal stores are the default"
+            ops.attn_bwd_store(prev_store)
     if switch == "autograd_function":
         # the default dispatches the step as the registered operators dig::pretrain_step_fwd / _bwd; the autograd.Function form runs the same code
         assert engine_core.STEP_OPS and torch.ops.dig.pretrain_step_fwd is not None and not engine_core._LIVE_STEPS
         assert stats["grad_norm"] == ref_stats["grad_norm"] and torch.equal(g, ref_g)
         return
-    if switch in ("dgrad_transpose_read", "adamw_plain"):
+    if switch in ("dgrad_transpose_read", "adamw_plain", "attn_bwd_row_stores"):
         # same products, same K order per output element / the same step from a loaded state: bit for bit
         assert all(stats[k] == ref_stats[k] for k in ("loss", "loss_pixel", "loss_contrast", "grad_norm")), (stats, ref_stats)
         assert torch.equal(g, ref_g)
