@@ -329,12 +329,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const bf16_t* __restri
   __syncthreads();
   DIG_ATTN_TS(2)
   // delta[q] = sum_d dO[q,d] * O[q,d]
+  // ... and, without dropout, the v_bias gradient of this (image, head): the rows of P sum to one, so the column sums of dV = P^T dO over the keys
+  // ARE the column sums of dO over the queries -- summed here from the rows this pass reads anyway (8 adds per row) instead of 160 DPP adds per
+  // key block on the dV accumulators.  (The sums of the bf16 d(ctx) rows, in fp32: closer to the exact sum than the sums of the dV tiles were.)
+  constexpr bool VSUM_DO = !DROP;
+  float vs8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int ps = 0; ps < 8; ++ps) {
     const int row = ps * 32 + (tid >> 3), c = tid & 7;
     const bf16x8 gv = *reinterpret_cast<const bf16x8*>(T1 + row * 128 + ((c ^ swz(row)) << 4));
     float acc = 0.f;
     const uint4 ow = __builtin_bit_cast(uint4, orow[ps]), gw = __builtin_bit_cast(uint4, gv);
+    if (VSUM_DO && vsum) {
+      const unsigned w4[4] = {gw.x, gw.y, gw.z, gw.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { vs8[2 * i] += __uint_as_float(w4[i] << 16); vs8[2 * i + 1] += __uint_as_float(w4[i] & 0xffff0000u); }
+    }
     acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(dig_bf16x2, ow.x), __builtin_bit_cast(dig_bf16x2, gw.x), acc, false);   // v_dot2c_f32_bf16
     acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(dig_bf16x2, ow.y), __builtin_bit_cast(dig_bf16x2, gw.y), acc, false);
     acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(dig_bf16x2, ow.z), __builtin_bit_cast(dig_bf16x2, gw.z), acc, false);
@@ -345,6 +355,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const bf16_t* __restri
     acc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc), 0x4E, 0xF, 0xF, true));
     acc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc), 0x104, 0xF, 0xF, true));
     if (c == 0) del_s[row] = -acc;
+  }
+  if (VSUM_DO && vsum) {                                                 // this wave's 64 queries -> slot `wave` of the dV sums; slots 4..7 stay zero
+    lines_colsum_finish(vs8, csum_s + wave * 128 + 64, lane);
+    if ((lane >> 3) == 0) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) csum_s[(wave + 4) * 128 + 64 + 8 * (lane & 7) + j] = 0.f;
+    }
   }
   __syncthreads();
   DIG_ATTN_TS(3)
@@ -538,7 +555,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const bf16_t* __restri
         store_rows(okp + D, dv, hi);
       }
     } else if (dk[0][0] == 1.2345f && dv[1][3] == 5.4321f) okp[0] = 1;
-    if (vsum) wave_colsum(dv, csum_s + kb * 128 + 64, lane);
+    if (!VSUM_DO && vsum) wave_colsum(dv, csum_s + kb * 128 + 64, lane);
   }
   DIG_ATTN_TS(4)
 
@@ -597,6 +614,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const bf16_t* __restri
   DIG_ATTN_TS(5)
 
   // ---------------- phase A: dQ for query blocks 2*wave, 2*wave+1 ----------------
+  float qs8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int ps = 0; ps < 2; ++ps) {
     const int qb = wave * 2 + ps;
@@ -666,16 +684,25 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const bf16_t* __restri
 #pragma unroll
       for (int e = 0; e < 16; ++e) dq[dt][e] *= scale;
     if (!(DIG_ATTN_B_ABL & 128)) {
-      if (store_mode == 3) store_rows_lines<true>(dqkv + (tok0 + q0) * ld + h * DH, ld, dq, smem + BWD_STG_OFF + wave * 2048, lane);
+      // (full-line form: the q_bias gradient = column sums of the rows as they are STORED, added up from the staging copy: 32 adds per block
+      //  and one fold per wave instead of 160 DPP adds per block on the accumulators)
+      if (store_mode == 3) store_rows_lines<true, true>(dqkv + (tok0 + q0) * ld + h * DH, ld, dq, smem + BWD_STG_OFF + wave * 2048, lane, qs8);
       else if (store_mode == 1) store_rows<true>(dqkv + (tok0 + q) * ld + h * DH, dq, hi);
       else store_rows(dqkv + (tok0 + q) * ld + h * DH, dq, hi);
     }
     else if (dq[0][0] == 1.2345f && dq[1][3] == 5.4321f) dqkv[0] = 1;
-    if (qsum) wave_colsum(dq, csum_s + qb * 128, lane);
+    if (qsum && store_mode != 3) wave_colsum(dq, csum_s + qb * 128, lane);
   }
   DIG_ATTN_TS(6)
   // fused q_bias / v_bias gradients: this (image, head)'s column sums of dQ and dV, one partial row per image
   if (qsum) {
+    if (store_mode == 3) {                                                 // this wave's 64 query rows -> slot `wave`; slots 4..7 zero
+      lines_colsum_finish(qs8, csum_s + wave * 128, lane);
+      if ((lane >> 3) == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) csum_s[(wave + 4) * 128 + 8 * (lane & 7) + j] = 0.f;
+      }
+    }
     __syncthreads();
     int t = threadIdx.x;
     asm volatile("" : "+v"(t));                 // re-derived here: kept alive from the prologue the index cost the kernel a spilled register

@@ -130,8 +130,10 @@ __device__ __forceinline__ void store_rows(bf16_t* row, const f32x16 (&acc)[2], 
 // way (lab: 133 us with the row stores, 99 us with no stores at all, 45 us for all its loads).  The block goes through 2 KiB of wave-private LDS,
 // 16 rows at a time (64-bit pieces at 16-byte position (4 dt + g) ^ (row & 7): conflict-free both ways), and is read back 8 adjacent lanes per
 // row: one store instruction = 8 rows x 128 contiguous bytes.  `blk` = &T[the wave's first row][first column], ld in elements.
-template <bool NT = false>
-__device__ __forceinline__ void store_rows_lines(bf16_t* blk, int ld, const f32x16 (&acc)[2], unsigned char* stg, int lane) {
+// SUM: the rows' column sums ride along -- lane (r8 = lane >> 3, c = lane & 7) adds the bf16 values it stores (columns 8 c .. 8 c + 7 of rows r8 and
+// 8 + r8 of a pass) to cs[8]; after the caller's last block, lines_colsum_finish() folds the eight row groups of the wave.
+template <bool NT = false, bool SUM = false>
+__device__ __forceinline__ void store_rows_lines(bf16_t* blk, int ld, const f32x16 (&acc)[2], unsigned char* stg, int lane, float* cs = nullptr) {
   asm volatile("" : "+v"(lane));            // the addresses below are derived HERE from a copy the optimiser cannot see through: hoisted out of the
                                             // caller's loops they stay alive across its MFMA phases (a spilled register in the attention backward)
   const int rr = lane & 31, hi = lane >> 5;
@@ -157,6 +159,28 @@ __device__ __forceinline__ void store_rows_lines(bf16_t* blk, int ld, const f32x
     dig_u32x4* d1 = reinterpret_cast<dig_u32x4*>(blk + (size_t)(16 * pass + 8 + r8) * ld + c * 8);
     if (NT) { __builtin_nontemporal_store(v0, d0); __builtin_nontemporal_store(v1, d1); }
     else { *d0 = v0; *d1 = v1; }
+    if (SUM) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        cs[2 * i] += __uint_as_float(v0[i] << 16) + __uint_as_float(v1[i] << 16);
+        cs[2 * i + 1] += __uint_as_float(v0[i] & 0xffff0000u) + __uint_as_float(v1[i] & 0xffff0000u);
+      }
+    }
+  }
+}
+// cs[j] of lane (r8, c) -> the wave's sum over r8 = 0..7 in the lanes r8 = 0, which write out[8 c + j]  (out: 64 floats)
+__device__ __forceinline__ void lines_colsum_finish(float (&cs)[8], float* out, int lane) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float v = cs[j];
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));   // row_ror:8 (lane ^ 8 within a 16-lane row)
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    cs[j] = v;
+  }
+  if ((lane >> 3) == 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) out[8 * (lane & 7) + j] = cs[j];
   }
 }
 

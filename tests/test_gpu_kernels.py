@@ -152,7 +152,9 @@ def _attention_fwd_bwd(dev, Bn, H, scale, spike):
             for mode in (0, 1, 3):
                 ops.attn_bwd_store(mode)
                 d3, q3, v3 = ops.attn_bwd(qkv, ctx, dctx, lse, Bn, H, D, scale, bias_sums=True)
-                assert torch.equal(d3, dqkv) and torch.equal(q3, qs) and torch.equal(v3, vs), mode
+                # (the q sums of the full-line form add up the rows as stored -- bf16 -- the row-store forms the fp32 accumulators: one bias gradient,
+                #  two roundings; the v sums are the column sums of d(ctx) in every form)
+                assert torch.equal(d3, dqkv) and torch.equal(v3, vs) and (torch.equal(q3, qs) if mode == 3 else rel(q3, qs) < 2e-3), mode
         finally:
             ops.attn_bwd_store(prev)
     bq, bv = torch.randn(D, device=dev), torch.randn(D, device=dev)
