@@ -202,10 +202,14 @@ __device__ __forceinline__ void wave_colsum(const f32x16 (&acc)[2], float* out, 
 // Phase B (dK, dV) needs all of Q, dO in LDS and one key block's K / V rows in registers; phase A (dQ) needs all of K, V in
 // LDS and one query block's Q / dO rows in registers.  So: stage Q, dO -> delta from the LDS copy of dO and a coalesced read
 // of O -> phase B with K / V fragments fetched straight from global memory (each wave reads only its own 2 x 32 rows) ->
-// restage the same 64 KiB with K, V (the Q / dO fragments of the first query block are lifted out of LDS first) -> phase A.
-// Two such workgroups fit one CU (2 x 66 KiB), so the staging bursts, LDS fragment reads and row stores of one
+// restage the same 64 KiB with K, V (the Q / dO fragments of BOTH query blocks of the wave are lifted out of LDS first; the wave's
+// second key block goes into the tiles from its registers, the LDS-DMA brings the even blocks) -> phase A.
+// Two such workgroups fit one CU (2 x 78 KiB), so the staging bursts, LDS fragment reads and row stores of one
 // (image, head) overlap the MFMA phases of another -- the 8-wave / 128 KiB form ran one workgroup per CU with nothing to
 // overlap its serial phases (tools/experiments/attn_bwd_lab.hip: phase timeline and ablations).
+// Round 6: with both tile loops EMPTY the launch took 95 of its 133 us -- 400 MB read + 151 MB written at the fabric's byte rate
+// (profiles/r06_attn_bwd_lab.txt).  Hence the lifts above (192 instead of 256 KiB read per (image, head)), results that leave in full
+// 128-byte lines, non-temporal (STORE = 3), and bias-gradient sums taken from rows the kernel handles anyway.
 // ------------------------------------------------------------------------------------------------
 constexpr int BWD_STG_OFF = 2 * TILE + 2 * N_TOK * 4 + 8 * 128 * 4;
 constexpr int BWD_LDS = BWD_STG_OFF + 4 * 2048;                            // 78 KiB: two workgroups per CU

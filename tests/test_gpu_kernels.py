@@ -201,7 +201,7 @@ def test_attention_bwd_with_projection_gradient(dev, Bn, H):
 @pytest.mark.parametrize("D,gelu", [(384, 0), (512, 0), (128, 0), (192, 1), (64, 1), (256, 0)])
 def test_layernorm(dev, D, gelu):
     from dig_amd import ops
-    rows = 1000
+    rows = 1000 + (3 if D in (384, 192) else 0)                         # (1003: a last group of rows shorter than the 4 / 2 rows a wave keeps in flight)
     x = torch.randn(rows, D, device=dev).bfloat16()
     g = torch.randn(D, device=dev) * 0.2 + 1
     b = torch.randn(D, device=dev) * 0.1
