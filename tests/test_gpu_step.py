@@ -1100,7 +1100,19 @@ def test_engine_switches_agree_with_the_default_path(switch):
         assert engine_core.STEP_OPS and torch.ops.dig.pretrain_step_fwd is not None and not engine_core._LIVE_STEPS
         assert stats["grad_norm"] == ref_stats["grad_norm"] and torch.equal(g, ref_g)
         return
-    if switch in ("dgrad_transpose_read", "adamw_plain", "attn_bwd_row_stores"):
+    if switch == "attn_bwd_row_stores":
+        # the same kernel, another way out for its results: every gradient bit for bit -- except the q_bias gradients, whose sums the full-line form
+        # takes from the rows as stored (bf16) and the row-store form from the fp32 accumulators (2e-3: bf16 rounding of the summands)
+        assert all(stats[k] == ref_stats[k] for k in ("loss", "loss_pixel", "loss_contrast")), (stats, ref_stats)
+        assert abs(stats["grad_norm"] - ref_stats["grad_norm"]) <= 1e-5 * ref_stats["grad_norm"]
+        for name, sp in specs.items():
+            a, b = g[sp.offset:sp.offset + sp.numel], ref_g[sp.offset:sp.offset + sp.numel]
+            if name.endswith("attn.q_bias"):
+                assert float((a - b).norm() / b.norm()) <= 2e-3, name
+            else:
+                assert torch.equal(a, b), name
+        return
+    if switch in ("dgrad_transpose_read", "adamw_plain"):
         # same products, same K order per output element / the same step from a loaded state: bit for bit
         assert all(stats[k] == ref_stats[k] for k in ("loss", "loss_pixel", "loss_contrast", "grad_norm")), (stats, ref_stats)
         assert torch.equal(g, ref_g)
