@@ -151,7 +151,7 @@ __device__ __forceinline__ void dgelu2(float xa, float xb, float& ga, float& gb)
 // b = 0; attention probabilities a = (query << 16) | key, b = sample * heads + head; drop-path a = sample, b = 0.
 // multi-segment reduction descriptors (include/dig_hip.h: dig_reduce_seg_t, dig_colsum_seg_t)
 #define DIG_REDUCE_MAX_SEGS 8
-#define DIG_COLSUM_MAX_SEGS 12
+#define DIG_COLSUM_MAX_SEGS 112
 struct dig_reduce_seg_t { const float* partials; float* out; long long n; int splits; int reserved; };
 struct dig_colsum_seg_t { const float* partials; float* out; long long stride; int n_parts; int C; };
 

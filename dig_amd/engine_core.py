@@ -43,6 +43,10 @@ WGRAD_INLINE = os.environ.get("DIG_WGRAD_INLINE", "1") == "1"
 WGRAD_DEFER = os.environ.get("DIG_WGRAD_DEFER", "auto").strip().lower()
 if WGRAD_DEFER not in ("auto", "0", "1"):
     raise ValueError(f"DIG_WGRAD_DEFER={WGRAD_DEFER!r}: one of auto, 0, 1")
+# Block-call path, single process: the blocks' parameter-gradient reductions (five small launches per block on the second stream: 61 per step, each
+# taking CU slots from the chip-owning kernel of the data-gradient chain that runs beside it) held back and folded in ONE
+# dig_colsum_partials_multi launch behind the last data gradient (108 segments; the same sums).  "0": per block, on the second stream.
+RED_DEFER = os.environ.get("DIG_RED_DEFER", "1") != "0"
 BWD_SINGLE_STREAM = os.environ.get("DIG_BWD_SINGLE", "0") == "1"    # lab switch: the whole backward on the caller's stream (sum of solo kernel times)
 
 
@@ -320,6 +324,10 @@ class _Step:
         prev_block, n_launch, slabs_prev = None, 0, None
         deferred = []                                                    # deferred plan: (problem table, temporaries kept alive) per block
         defer = WGRAD_DEFER == "1" or (WGRAD_DEFER == "auto" and self.comm is LOCAL and self._defer_fits(dev, M.depth * n16))
+        red_defer = bool(RED_DEFER and defer and self.comm is LOCAL and ops.MLP_CHAIN_LNB and M.depth * 9 <= ops.COLSUM_MAX_SEGS)
+        red_segs, red_keep = [], []                                      # (partials address, destination, stride, partial rows, columns) of the held-back reductions
+        lib = ops.L.lib()
+        n_b, n_l2, n_l1 = lib.dig_mlp_chain_colsum_rows(R), lib.dig_mlp_chain_ln_parts(R), lib.dig_layernorm_bwd_parts(R)
         for i in reversed(range(M.depth)):
             blk, g, sv = ew.blocks[i], ew.blocks[i]["g"], saved[i]
             saved[i] = None
@@ -361,6 +369,18 @@ class _Step:
             st.wg_map, st.wg_slabs = wmap_ptr, slabs.data_ptr()
             st.wg_defer = int(defer)
             st.fuse_ln2 = int(ops.MLP_CHAIN_LNB)
+            st.defer_red = int(red_defer)
+            if red_defer:
+                # what dig_encoder_block_bwd would have launched on the second stream (csrc/encoder_block.inc), as segments of one launch
+                gb = g["qkv_bias"]
+                red_segs.append((st.bparts, g["mlp.fc1.bias"], Fh, n_b, Fh))
+                for k, dst in enumerate((g["norm2.weight"], g["norm2.bias"], g["mlp.fc2.bias"])):
+                    red_segs.append((st.ws2 + 4 * k * D, dst, 3 * D, n_l2, D))
+                red_segs.append((st.qs, gb[:D], D, n_img, D))
+                red_segs.append((st.vs, gb[2 * D:], D, n_img, D))
+                for k, dst in enumerate((g["norm1.weight"], g["norm1.bias"], g["attn.proj.bias"])):
+                    red_segs.append((st.ws1 + 4 * k * D, dst, 3 * D, n_l1, D))
+                red_keep.append(t32)
             if defer:
                 own = (ops._WgProb * 4)()
                 deferred.append((own, t16, sv, i))
@@ -369,7 +389,7 @@ class _Step:
                 st.wg_fold_probs = st.wg_fold_slabs = None
                 st.side = side_h
                 ops.L.call("dig_encoder_block_bwd", ctypes.byref(st), stream)
-                if side is not main:
+                if side is not main and not red_defer:
                     self._keep.append(t32)
                 dy_ptr, dy_owner = p16 + off["dctx"], t16
                 self._mark_kept(dev)
@@ -393,6 +413,11 @@ class _Step:
             if prev_block is not None:
                 self._grad_ready(dev, f"encoder.blocks.{prev_block}")
             prev_block = i
+        if red_segs:
+            # every block's bias / LayerNorm partial rows in one launch, on this stream, in front of the weight gradients (nothing runs beside it)
+            segs = (ops._ColsumSeg * len(red_segs))(*[ops._ColsumSeg(int(p_), d_.data_ptr(), st_, n_, c_) for p_, d_, st_, n_, c_ in red_segs])
+            ops.L.call("dig_colsum_partials_multi", segs, len(red_segs), stream)
+            del red_keep
         if defer:
             # the twelve launches now, in block order (each folds its predecessor's slabs), every bucket behind its fold
             prev_probs = None

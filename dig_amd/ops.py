@@ -381,6 +381,9 @@ def _batch_workspace(dev, numel):
     return w
 
 
+COLSUM_MAX_SEGS = 112                                               # include/dig_hip.h DIG_COLSUM_MAX_SEGS
+
+
 class _ReduceSeg(ctypes.Structure):
     """include/dig_hip.h `dig_reduce_seg_t`."""
     _fields_ = [("partials", ctypes.c_void_p), ("out", ctypes.c_void_p), ("n", ctypes.c_longlong), ("splits", ctypes.c_int), ("reserved", ctypes.c_int)]
@@ -431,7 +434,7 @@ class GradReduceBatch:
                 self._vec(ws[k * D:], out, 3 * D, n, D)
 
     def _vec(self, parts, out, stride, n_parts, C):
-        if len(self.vecs) == 12:
+        if len(self.vecs) == COLSUM_MAX_SEGS:
             self._flush_vecs()
         self.vecs.append((parts, out, stride, n_parts, C))
 
@@ -600,7 +603,7 @@ class BlockBwd(ctypes.Structure):
                                     "x", "ln1", "mu1", "rs1", "qkv", "ctx", "lse", "x_mid", "ln2", "mu2", "rs2", "pre", "act", "dy",
                                     "dln2", "dpre", "dctx", "dqkv", "bparts", "ws1", "ws2", "qs", "vs")] +
                 [(k, _I) for k in ("wg_fn", "wg_wa", "wg_splits", "wg_n_wg", "wg_fold_n", "wg_fold_splits")] + [("wg_trans", _I * 4)] +
-                [("wg_defer", _I), ("fuse_ln2", _I), ("attn_proj", _I)] +
+                [("wg_defer", _I), ("fuse_ln2", _I), ("attn_proj", _I), ("defer_red", _I)] +
                 [(k, _VP) for k in ("wg_map", "wg_slabs", "wg_fold_slabs", "wg_probs", "wg_fold_probs", "side")])
 
 

@@ -71,6 +71,9 @@ typedef struct dig_block_bwd {
   int attn_proj;                       /* 1 (with proj_wt and D a multiple of 128, at most 512): the projection's data gradient inside the attention backward
                                           launch (dig_attn_bwd_proj: every (image, head) workgroup computes its own d(ctx) tile from dx_mid and
                                           proj.weight^T) -- no GEMM launch, d(ctx) is never written */
+  int defer_red;                       /* 1: the block's parameter-gradient reductions (fc1 / q / v bias column sums, both LayerNorms' partials) are NOT launched:
+                                          bparts / ws1 / ws2 / qs / vs keep their partial rows and the caller folds the blocks' partials together, in one
+                                          dig_colsum_partials_multi launch behind the last data gradient (9 segments per block, same sums) */
   const unsigned* wg_map; float* wg_slabs; const float* wg_fold_slabs;
   dig_wgrad_prob_t* wg_probs; const dig_wgrad_prob_t* wg_fold_probs;
   hipStream_t side;                    /* stream of the parameter-gradient reductions (may equal the call's stream) */

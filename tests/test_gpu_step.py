@@ -1019,7 +1019,7 @@ def test_optimizer_launch_leaves_shadow_and_transposes_for_the_next_forward():
                                     "chain_no_ln", "bwd_single", "chain_bwd_every2", "per_entry_point", "autograd_function", "attn_three_launches",
                                     "attn_bwd_single_pass", "wgrad_inline", "ln2_bwd_own_launch", "proj_dgrad_in_chain", "bn_three_launches",
                                     "dgrad_transpose_read", "adamw_plain", "head_dgrad_transpose_read", "proj_dgrad_in_attn_bwd",
-                                    "attn_bwd_row_stores"])
+                                    "attn_bwd_row_stores", "reductions_per_block"])
 def test_engine_switches_agree_with_the_default_path(switch):
     """Every non-default execution plan of the step (environment switches of dig_amd/ops.py and engine_core.py: launch groupings, tile
     codes, stream plans, fusion masks) against the default plan on one ViT-S step from the same state and batch: the losses agree, and
@@ -1044,14 +1044,24 @@ def test_engine_switches_agree_with_the_default_path(switch):
         torch.cuda.synchronize()
         return stats[0], model.flat_grads.detach().float().clone(), {n: sp for n, sp in model.specs.items() if sp.arena == "online"}
 
-    ref_stats, ref_g, specs = one_step()
+    if switch == "per_entry_point":
+        engine_core.RED_DEFER, red_saved = False, engine_core.RED_DEFER   # (both sides of this comparison launch the reductions block by block)
+    try:
+        ref_stats, ref_g, specs = one_step()
+    finally:
+        if switch == "per_entry_point":
+            engine_core.RED_DEFER = red_saved
     plans = {
         "wgrad_off": [(engine_core, "WGRAD_GROUPING", "off")], "wgrad_pair": [(engine_core, "WGRAD_GROUPING", "pair")],
         "wgrad_wa1": [(ops, "WGRAD_GROUP_WA", 1), (ops, "WGRAD_GROUP_SLOTS", 512)], "wgrad_side_stream": [(engine_core, "WGRAD_INLINE", False)],
         "chain_mask3": [(ops, "MLP_CHAIN_MASK", 3)], "dgrad_128": [(ops, "DGRAD_BK", 0)], "fwd_side": [(engine_core, "FWD_MODE", "side")],
         "fwd_serial": [(engine_core, "FWD_MODE", "serial")], "chain_no_ln": [(ops, "MLP_CHAIN_LN", False)],
         "bwd_single": [(engine_core, "BWD_SINGLE_STREAM", True)], "chain_bwd_every2": [(engine_core, "CHAIN_BWD_EVERY", 2)],
-        "per_entry_point": [(ops, "BLOCK_CALLS", False)], "autograd_function": [(engine_core, "STEP_OPS", False)],
+        # (the per-entry-point plan launches every block's reductions by themselves: compared with the block-call path doing the same)
+        "per_entry_point": [(ops, "BLOCK_CALLS", False), (engine_core, "RED_DEFER", False)], "autograd_function": [(engine_core, "STEP_OPS", False)],
+        # the blocks' bias / LayerNorm-parameter reductions per block on the second stream instead of one launch behind the last data gradient:
+        # another grouping of the same partial rows (64 against 128 row groups for the LayerNorm vectors)
+        "reductions_per_block": [(engine_core, "RED_DEFER", False)],
         # the attention sub-block as three launches (qkv GEMM -> dig_attn_fwd -> proj GEMM) instead of dig_attn_block_fwd: a different FORWARD kernel
         "attn_three_launches": [(ops, "ATTN_BLOCK", False)],
         "attn_bwd_single_pass": [],                                       # (a library-wide mode, set below: a different BACKWARD kernel)
@@ -1074,7 +1084,8 @@ def test_engine_switches_agree_with_the_default_path(switch):
         "wgrad_inline": [(engine_core, "WGRAD_DEFER", "0")],              # the grouped launch of a block inside its data-gradient chain (the plan under a
                                                                           # process group) instead of all twelve behind the last data gradient: same sums
     }
-    tight = switch in ("wgrad_off", "wgrad_pair", "wgrad_wa1", "wgrad_side_stream", "fwd_side", "fwd_serial", "bwd_single", "wgrad_inline")
+    tight = switch in ("wgrad_off", "wgrad_pair", "wgrad_wa1", "wgrad_side_stream", "fwd_side", "fwd_serial", "bwd_single", "wgrad_inline",
+                       "reductions_per_block")
     if switch == "adamw_plain":
         from dig_amd import optim_factory
         plans[switch] = [(optim_factory, "FOLD_SHADOW", False)]
