@@ -209,6 +209,7 @@ int dig_reduce_partials(const float* partials, int splits, long long n, float* o
 
 struct dig_reduce_seg_t { const float* partials; float* out; long long n; int splits; int reserved; };
 struct dig_colsum_seg_t { const float* partials; float* out; long long stride; int n_parts; int C; };
+static const int DIG_COLSUM_MAX_SEGS = 112;      // include/dig_hip.h
 
 int dig_reduce_partials_multi(const dig_reduce_seg_t* segs, int n_segs, hipStream_t stream) {
   if (!segs || n_segs < 1 || n_segs > 8) return DIG_ERR_ARG;
@@ -220,7 +221,7 @@ int dig_reduce_partials_multi(const dig_reduce_seg_t* segs, int n_segs, hipStrea
 }
 
 int dig_colsum_partials_multi(const dig_colsum_seg_t* segs, int n_segs, hipStream_t) {
-  if (!segs || n_segs < 1 || n_segs > 12) return DIG_ERR_ARG;
+  if (!segs || n_segs < 1 || n_segs > DIG_COLSUM_MAX_SEGS) return DIG_ERR_ARG;
   for (int k = 0; k < n_segs; ++k) {
     const dig_colsum_seg_t& g = segs[k];
     if (!g.partials || !g.out || g.n_parts <= 0 || g.C <= 0 || (g.C & 7) || g.stride < g.C || (g.stride & 3)) return DIG_ERR_ARG;

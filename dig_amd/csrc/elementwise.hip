@@ -579,6 +579,41 @@ __global__ __launch_bounds__(256) void colsum_finalize_multi_kernel(ColsumSegs a
   }
 }
 
+// The same with 32 columns per block (every C a multiple of 32): a partial row is read in full 128-byte lines, 8 lanes per row, 32 row groups --
+// the 8-column form above reads 32 bytes per row and line, and a launch over all twelve encoder blocks' partial rows (216 MB, the deferred
+// reductions of the single-process backward) took 141 us on the caller's stream with it.
+__global__ __launch_bounds__(256) void colsum_finalize_multi32_kernel(ColsumSegs a) {
+  __shared__ float4 red[32][8];
+  int k = 0;
+  while (k + 1 < a.n_segs && (int)blockIdx.x >= a.first[k + 1]) ++k;
+  const float* __restrict__ partial = a.part[k];
+  const long long stride = a.stride[k];
+  const int nb = a.n_parts[k];
+  const int cx = threadIdx.x & 7, ry = threadIdx.x >> 3;
+  const int c = ((int)blockIdx.x - a.first[k]) * 32 + cx * 4;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int b = ry; b < nb; b += 32) {
+    const float4 v = *reinterpret_cast<const float4*>(partial + (size_t)b * stride + c);
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  red[ry][cx] = acc;
+  __syncthreads();
+  for (int st = 16; st > 0; st >>= 1) {
+    if (ry < st) {
+      const float4 o = red[ry + st][cx];
+      float4 m = red[ry][cx];
+      m.x += o.x; m.y += o.y; m.z += o.z; m.w += o.w;
+      red[ry][cx] = m;
+    }
+    __syncthreads();
+  }
+  if (ry == 0) {
+    float* out = a.out[k];
+    const float4 m = red[0][cx];
+    out[c] += m.x; out[c + 1] += m.y; out[c + 2] += m.z; out[c + 3] += m.w;
+  }
+}
+
 // P[t, k] (bf16, ld 64) = masked ? 0 : img patch element k (conv order c,p1,p2), k < 48; pad columns 48..63 = 0.
 // Lets the patch-embed weight gradient run as an MFMA wgrad GEMM (dW[D,48] = dy^T P) instead of a VALU loop.
 __global__ __launch_bounds__(256) void patchify_bf16_kernel(const float* __restrict__ img, const unsigned char* __restrict__ mask,
@@ -843,6 +878,10 @@ extern "C" int dig_colsum_partials_multi(const dig_colsum_seg_t* segs, int n_seg
   if (!segs || n_segs < 1 || n_segs > DIG_COLSUM_MAX_SEGS) return DIG_ERR_ARG;
   ColsumSegs a;
   a.n_segs = n_segs;
+  // more than one block's worth of segments with every width a multiple of 32: the full-line form (32 columns per workgroup)
+  bool wide = n_segs > 12;
+  for (int k = 0; k < n_segs && wide; ++k) wide = (segs[k].C & 31) == 0;
+  const int cols = wide ? 32 : 8;
   int blocks = 0;
   for (int k = 0; k < n_segs; ++k) {
     const dig_colsum_seg_t& g = segs[k];
@@ -850,10 +889,11 @@ extern "C" int dig_colsum_partials_multi(const dig_colsum_seg_t* segs, int n_seg
     if (!aligned16(g.partials)) return DIG_ERR_ALIGN;
     a.part[k] = g.partials; a.out[k] = g.out; a.stride[k] = g.stride; a.n_parts[k] = g.n_parts;
     a.first[k] = blocks;
-    blocks += g.C / 8;
+    blocks += g.C / cols;
   }
   a.first[n_segs] = blocks;
-  hipLaunchKernelGGL(colsum_finalize_multi_kernel, dim3(blocks), dim3(256), 0, stream, a);
+  if (wide) hipLaunchKernelGGL(colsum_finalize_multi32_kernel, dim3(blocks), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL(colsum_finalize_multi_kernel, dim3(blocks), dim3(256), 0, stream, a);
   return dig_check_launch();
 }
 

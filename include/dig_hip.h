@@ -411,7 +411,9 @@ int dig_colsum_partials(const float* partials, int n_parts, int C, float* out, h
 /* out[c] += sum_b partials[b * stride + c], c < C, for up to DIG_COLSUM_MAX_SEGS partial sets in one launch: the bias and LayerNorm
  * parameter gradients an encoder block's backward leaves as partials (fc1 bias from the fc2 dgrad, q / v bias from dig_attn_bwd, and the
  * three interleaved vectors of each dig_layernorm_bwd_partials workspace: stride 3*D, bases workspace + {0, D, 2D}) -- 5 finalize
- * launches -> 1, same summation order per column as dig_colsum_partials.  C % 8 == 0, stride % 4 == 0; `segs` is host memory. */
+ * launches -> 1, same summation order per column as dig_colsum_partials.  C % 8 == 0, stride % 4 == 0; `segs` is host memory.
+ * With more than 12 segments whose widths are all multiples of 32 (every encoder block's partial rows of a backward pass in one launch, round 6)
+ * a workgroup owns 32 columns -- full 128-byte lines of a partial row, 32 row groups: another summation order (1e-6 relative). */
 #define DIG_COLSUM_MAX_SEGS 112
 typedef struct dig_colsum_seg { const float* partials; float* out; long long stride; int n_parts; int C; } dig_colsum_seg_t;
 int dig_colsum_partials_multi(const dig_colsum_seg_t* segs, int n_segs, hipStream_t stream);

@@ -687,6 +687,36 @@ def test_grad_reduce_batch_equals_single_launches(dev):
             assert rel(u, v) < 1e-6, i
 
 
+def test_colsum_partials_multi_many_segments(dev):
+    """dig_colsum_partials_multi with more than one encoder block's worth of segments (the deferred reductions of the single-process backward: every
+    block's bias and LayerNorm partial rows in one launch; widths that are multiples of 32 take the full-line kernel, one width that is not sends the
+    whole launch to the 8-column kernel): out += column sums, against fp64 torch, += semantics, interleaved strides, fixed order."""
+    import ctypes
+    from dig_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(3)
+    for odd in (False, True):
+        segs, want, outs, keep = [], [], [], []
+        for k in range(40):
+            C = (384, 1536, 64, 512)[k % 4] if not (odd and k == 7) else 40
+            n_parts = (1, 5, 33, 512, 2048)[k % 5]
+            vecs = 3 if k % 3 == 0 else 1                                  # (a LayerNorm workspace interleaves three vectors: stride 3 C)
+            ws = torch.randn(n_parts, vecs, C, generator=g).to(dev)
+            keep.append(ws)
+            for v in range(vecs):
+                out = torch.randn(C, generator=g).to(dev)
+                want.append(out.double() + ws[:, v].double().sum(0))
+                outs.append(out)
+                segs.append(ops._ColsumSeg(ws.data_ptr() + 4 * v * C, out.data_ptr(), vecs * C, n_parts, C))
+        assert 12 < len(segs) <= ops.COLSUM_MAX_SEGS
+        arr = (ops._ColsumSeg * len(segs))(*segs)
+        ops.L.call("dig_colsum_partials_multi", arr, len(segs), ops.L.stream())
+        for o, w in zip(outs, want):
+            assert float((o.double() - w).abs().max() / w.abs().max()) < (2e-6 if dev.type != "cpu" else 2e-5)     # (the CPU build sums each column in one fp32 chain)
+    with pytest.raises(RuntimeError):                                      # more segments than one launch takes
+        big = (ops._ColsumSeg * (ops.COLSUM_MAX_SEGS + 1))(*([segs[0]] * (ops.COLSUM_MAX_SEGS + 1)))
+        ops.L.call("dig_colsum_partials_multi", big, ops.COLSUM_MAX_SEGS + 1, ops.L.stream())
+
+
 @pytest.mark.parametrize("R,D,Fh", [(64, 384, 512), (1024, 384, 1536), (65536, 384, 1536), (32768, 384, 1536), (256, 256, 1024), (8192, 512, 2048)])
 def test_wgrad_group(dev, R, D, Fh):
     """The grouped weight-gradient kernel (csrc/wgrad.hip) on the four Linear layers of a transformer block, in every launch grouping:
