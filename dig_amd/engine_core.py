@@ -565,6 +565,10 @@ class _Step:
                 grouped = None                                           # the blocks are done: only the patch embedding is left
         grp = ops.WgradGroup(dev) if grouped else None
         prev_block = None
+        # single process, per-entry-point path (the 512-wide model, single-view encoders): the blocks' bias / LayerNorm column-sum launches held
+        # back as in _encoder_backward_calls -- collected over ALL blocks and folded in one dig_colsum_partials_multi launch behind the loop
+        vred = ops.GradReduceBatch() if (RED_DEFER and grp and self.comm is LOCAL and path is None and not BATCH_REDUCE and PHASE_MARKS is None
+                                         and grouped is not None) else None
 
         def launch_group(*tensors):
             if WGRAD_INLINE:
@@ -639,7 +643,10 @@ class _Step:
                 dln2 = None                                                                              # the fc1 bias sums fused
             if grp:
                 wg(dact, ln2, g["mlp.fc1.weight"])
-                side_later(lambda: csum(bparts, g["mlp.fc1.bias"]), bparts)
+                if vred:
+                    vred.colsum_partials(bparts, g["mlp.fc1.bias"])
+                else:
+                    side_later(lambda: csum(bparts, g["mlp.fc1.bias"]), bparts)
                 if WGRAD_GROUPING == "pair":
                     launch_group(*held)
             else:
@@ -648,13 +655,15 @@ class _Step:
                 dln2 = ops.dgrad_direct(dact, wT[i][1]) if wT is not None else None        # (direct form on fc1.weight^T where it pays)
                 if dln2 is None:
                     dln2 = ops.linear_dgrad(dact, blk["mlp.fc1.weight"])
-            if chain and lnp is not None:
+            if chain and lnp is not None and vred:
+                vred.layernorm_finalize_parts(lnp, g["norm2.weight"], g["norm2.bias"], g["mlp.fc2.bias"])
+            elif chain and lnp is not None:
                 side_later(lambda lnp=lnp, g=g: ops.layernorm_finalize_parts(lnp, g["norm2.weight"], g["norm2.bias"], g["mlp.fc2.bias"]), lnp)
             else:
                 dx_mid, fin2, ws2 = ops.layernorm_bwd(dln2, x_mid, blk["norm2.weight"], blk["norm2.bias"], mu2, rs2, dx, g["norm2.weight"],
                                                       g["norm2.bias"], out=dln2, dres_colsum=None if ds else g["mlp.fc2.bias"], defer=True)
-                if red:                                                       # norm2 grads + colsum(dx) = fc2 bias grad: off the chain
-                    red.layernorm_finalize(ws2, x_mid.shape[0], D, g["norm2.weight"], g["norm2.bias"], None if ds else g["mlp.fc2.bias"])
+                if red or vred:                                               # norm2 grads + colsum(dx) = fc2 bias grad: off the chain
+                    (red or vred).layernorm_finalize(ws2, x_mid.shape[0], D, g["norm2.weight"], g["norm2.bias"], None if ds else g["mlp.fc2.bias"])
                 else:
                     side_later(fin2, ws2)
             # x_mid = x + proj(attn(ln1))
@@ -690,7 +699,10 @@ class _Step:
                     wg(dqkv, ln1, g["attn.qkv.weight"])
                     launch_group(*held)
                     _mark("blk: grouped weight gradients", dev)
-                    side_later(lambda: (csum(qs, gb[:D]), csum(vs, gb[2 * D:])), qs, vs)
+                    if vred:
+                        vred.colsum_partials(qs, gb[:D]); vred.colsum_partials(vs, gb[2 * D:])
+                    else:
+                        side_later(lambda: (csum(qs, gb[:D]), csum(vs, gb[2 * D:])), qs, vs)
                 else:
                     on_side(lambda: (wg(dqkv, ln1, g["attn.qkv.weight"]),
                                      csum(qs, gb[:D]), csum(vs, gb[2 * D:])), dqkv, ln1, qs, vs)
@@ -710,7 +722,9 @@ class _Step:
             dx, fin1, ws1 = ops.layernorm_bwd(dln1, x, blk["norm1.weight"], blk["norm1.bias"], mu1, rs1, dx_mid, g["norm1.weight"],
                                               g["norm1.bias"], out=dln1, dres_colsum=None if ds else g["attn.proj.bias"], defer=True)
             _mark("blk: LayerNorm backward (norm1)", dev)
-            if red:                                                           # norm1 grads + colsum(dx_mid) = proj bias grad
+            if vred:
+                vred.layernorm_finalize(ws1, x.shape[0], D, g["norm1.weight"], g["norm1.bias"], g["attn.proj.bias"])
+            elif red:                                                         # norm1 grads + colsum(dx_mid) = proj bias grad
                 red.layernorm_finalize(ws1, x.shape[0], D, g["norm1.weight"], g["norm1.bias"], None if ds else g["attn.proj.bias"])
                 side_later(red.flush, *red.tensors())
             else:
@@ -730,6 +744,8 @@ class _Step:
                 prev_block = i
             else:
                 self._grad_ready(dev, f"encoder.blocks.{i}")
+        if vred:
+            vred.flush()                                                     # (vectors only: one launch per 112 segments, on this stream)
         if grp:
             if WGRAD_INLINE:
                 grp.flush()

@@ -433,6 +433,14 @@ class GradReduceBatch:
             if out is not None:
                 self._vec(ws[k * D:], out, 3 * D, n, D)
 
+    def layernorm_finalize_parts(self, ln_parts, dgamma, dbeta, dcolsum):
+        """dig_layernorm_bwd_finalize_parts of a [parts, 3, D] partial tensor (the fused MLP backward's norm2 sums) at flush()."""
+        n, _, D = ln_parts.shape
+        flat = ln_parts.view(-1)
+        for k, out in enumerate((dgamma, dbeta, dcolsum)):
+            if out is not None:
+                self._vec(flat[k * D:], out, 3 * D, n, D)
+
     def _vec(self, parts, out, stride, n_parts, C):
         if len(self.vecs) == COLSUM_MAX_SEGS:
             self._flush_vecs()

@@ -1019,7 +1019,7 @@ def test_optimizer_launch_leaves_shadow_and_transposes_for_the_next_forward():
                                     "chain_no_ln", "bwd_single", "chain_bwd_every2", "per_entry_point", "autograd_function", "attn_three_launches",
                                     "attn_bwd_single_pass", "wgrad_inline", "ln2_bwd_own_launch", "proj_dgrad_in_chain", "bn_three_launches",
                                     "dgrad_transpose_read", "adamw_plain", "head_dgrad_transpose_read", "proj_dgrad_in_attn_bwd",
-                                    "attn_bwd_row_stores", "reductions_per_block"])
+                                    "attn_bwd_row_stores", "reductions_per_block", "per_entry_point_deferred"])
 def test_engine_switches_agree_with_the_default_path(switch):
     """Every non-default execution plan of the step (environment switches of dig_amd/ops.py and engine_core.py: launch groupings, tile
     codes, stream plans, fusion masks) against the default plan on one ViT-S step from the same state and batch: the losses agree, and
@@ -1062,6 +1062,9 @@ def test_engine_switches_agree_with_the_default_path(switch):
         # the blocks' bias / LayerNorm-parameter reductions per block on the second stream instead of one launch behind the last data gradient:
         # another grouping of the same partial rows (64 against 128 row groups for the LayerNorm vectors)
         "reductions_per_block": [(engine_core, "RED_DEFER", False)],
+        # the per-entry-point plan with ITS held-back reductions (one launch behind the block loop) against the block-call path with its own:
+        # the same partial rows through the same kernel
+        "per_entry_point_deferred": [(ops, "BLOCK_CALLS", False)],
         # the attention sub-block as three launches (qkv GEMM -> dig_attn_fwd -> proj GEMM) instead of dig_attn_block_fwd: a different FORWARD kernel
         "attn_three_launches": [(ops, "ATTN_BLOCK", False)],
         "attn_bwd_single_pass": [],                                       # (a library-wide mode, set below: a different BACKWARD kernel)
@@ -1123,7 +1126,7 @@ def test_engine_switches_agree_with_the_default_path(switch):
             else:
                 assert torch.equal(a, b), name
         return
-    if switch in ("dgrad_transpose_read", "adamw_plain"):
+    if switch in ("dgrad_transpose_read", "adamw_plain", "per_entry_point_deferred"):
         # same products, same K order per output element / the same step from a loaded state: bit for bit
         assert all(stats[k] == ref_stats[k] for k in ("loss", "loss_pixel", "loss_contrast", "grad_norm")), (stats, ref_stats)
         assert torch.equal(g, ref_g)
